@@ -1,0 +1,188 @@
+/*
+ * ssde.h -- C ABI of the MI355X-native smoothSDE negative-log-likelihood engine.
+ *
+ * This is the drop-in boundary for ONE path of the reference package
+ * (TheoMichelot/smoothSDE): the evaluation of the penalised negative
+ * log-likelihood and its parameter gradient, which the reference reaches as
+ *
+ *     R: tmb_obj$fn(x) / tmb_obj$gr(x)                 (R/sde.R:694-697)
+ *       -> .Call("EvalADFunObject", ptr, theta, ctrl)  (src/init.c:8)
+ *         -> objective_function<Type>::operator()      (src/smoothSDE.cpp:9-28)
+ *           -> nllk_ctcrw / nllk_ou_ssm / nllk_bm_ssm / nllk_sde
+ *                                                      (src/nllk/ headers)
+ *
+ * and which TMB::MakeADFun sets up from `tmb_dat` / `tmb_par` / `map`
+ * (R/sde.R:528-536, 542-598, 621-632, 656-669;
+ *  .Call("MakeADFunObject", data, parameters, reportenv, control), src/init.c:6).
+ *
+ * Entry points and what they replace:
+ *
+ *   ssde_create        <- MakeADFunObject       (src/init.c:6;  R/sde.R:656-658)
+ *   ssde_eval          <- EvalADFunObject       (src/init.c:8;  order 0 = fn, 1 = gr)
+ *   ssde_eval_device   <- (new) same evaluation, asynchronous, result left in HBM so the
+ *                         caller can all-reduce it over RCCL before reading it
+ *   ssde_report        <- REPORT(aest_all)      (src/nllk/nllk_ctcrw.hpp:249,
+ *                                                nllk_ou_ssm.hpp:215, nllk_bm_ssm.hpp:177)
+ *   ssde_penalty       <- smoothing penalty     (nllk_ctcrw.hpp:254-280, nllk_sde.hpp:89-124)
+ *   ssde_info          <- InfoADFunObject       (src/init.c:7)
+ *   ssde_destroy       <- external-pointer finalizer of the ADFun object
+ *   ssde_last_error    <- Rf_error text         (src/smoothSDE.cpp:25)
+ *
+ * Plain C types only: no R, torch or HIP types appear in any signature.  A HIP
+ * stream crosses the boundary as `void*` (NULL = the null stream).
+ *
+ * Layout conventions are those of the R objects the reference passes
+ * (column-major matrices; `obs` is n x d as.matrix(self$obs()), R/sde.R:531).
+ *
+ * PARAMETER VECTOR.  `par` is the FULL parameter vector in TMB template order,
+ * fixed ("mapped") entries included:
+ *   Kalman families (BM_SSM, OU_SSM, CTCRW; nllk_ctcrw.hpp:135-140):
+ *       [ log_sigma_obs | coeff_fe (sum ncol_fe) | log_lambda (n_smooth) | coeff_re (sum ncol_re) ]
+ *   direct families (BM, OU; nllk_sde.hpp:42-45, decay feature not supported):
+ *       [ coeff_fe | log_lambda | coeff_re ]
+ *   coeff_fe / coeff_re are ordered parameter-by-parameter exactly like the columns
+ *   of the reference's block-diagonal X_fe / X_re (R/sde.R:443-447).
+ * `par_fixed[k] != 0` marks an entry that TMB's `map` would hold fixed
+ * (R/sde.R:514-515, 565, 595, 627-631): no derivative is computed for it and
+ * its gradient slot is returned as 0.  The R shim scatters theta into the full
+ * vector and gathers the free gradient entries.
+ */
+#ifndef SSDE_H
+#define SSDE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDE_ABI_VERSION 1
+
+/* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
+enum {
+    SSDE_MODEL_BM     = 0, /* "BM"      -> nllk_sde + tr_dens BM branch  (tr_dens.hpp:32-37) */
+    SSDE_MODEL_OU     = 1, /* "OU"      -> nllk_sde + tr_dens OU branch  (tr_dens.hpp:45-52) */
+    SSDE_MODEL_BM_SSM = 2, /* "BM_SSM"  -> nllk_bm_ssm                                    */
+    SSDE_MODEL_OU_SSM = 3, /* "OU_SSM"  -> nllk_ou_ssm                                    */
+    SSDE_MODEL_CTCRW  = 4  /* "CTCRW"   -> nllk_ctcrw                                     */
+};
+
+/* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with
+ * the hipError_t text in ssde_last_error(). */
+enum {
+    SSDE_OK            = 0,
+    SSDE_ERR_ARG       = 1, /* malformed descriptor / argument                         */
+    SSDE_ERR_MODEL     = 2, /* "Unknown SDE type" (src/smoothSDE.cpp:25) / unsupported */
+    SSDE_ERR_HIP       = 3, /* HIP runtime error                                       */
+    SSDE_ERR_NODEVICE  = 4, /* no gfx950 device visible: there is NO CPU fallback      */
+    SSDE_ERR_ALLOC     = 5
+};
+
+/* how a missing observation is recognised (Q5 of SURVEY.md Appendix A) */
+enum {
+    SSDE_NA_R_ONLY = 0, /* R_IsNA(): NaN whose low word is 1954 (nllk_ctcrw.hpp:214, tr_dens.hpp:31) */
+    SSDE_NA_ANY_NAN = 1 /* any NaN counts as missing (non-R hosts)                                    */
+};
+
+/* ssde_desc.flags */
+#define SSDE_FLAG_DEVICE_DATA   0x1u /* id/times/obs/x_fe/x_re/h_array pointers are HBM pointers on `device` */
+#define SSDE_FLAG_FORCE_DENSE   0x2u /* disable the isotropic register path (testing the dense path)         */
+#define SSDE_FLAG_NO_UNIFORM_DT 0x4u /* disable hoisting of the transition matrices on a regular time grid    */
+
+typedef struct ssde_desc {
+    int32_t  abi_version;     /* SSDE_ABI_VERSION */
+    int32_t  model;           /* SSDE_MODEL_* */
+    int32_t  n_dim;           /* d = ncol(obs), 1..2 on the register paths */
+    int32_t  n_par;           /* q = SDE parameters per row: d+1 (BM, BM_SSM), d+2 (OU, OU_SSM, CTCRW) */
+    int64_t  n;               /* rows of the long-format data (all tracks concatenated) */
+    const double *id;         /* [n] track codes (TMB passes the factor as doubles); only
+                                 id[i] != id[i-1] is ever used (nllk_ctcrw.hpp:196)     */
+    const double *times;      /* [n]   DATA_VECTOR(times) */
+    const double *obs;        /* [n*d] DATA_MATRIX(obs), column-major */
+
+    /* design blocks, one per SDE parameter j = 0..q-1: the X_list_fe[[j]] /
+     * X_list_re[[j]] of R/sde.R:412-417 (the diagonal blocks of X_fe / X_re).
+     * x_fe[j] == NULL with ncol_fe[j] == 1 means an intercept-only column of ones. */
+    const int32_t *ncol_fe;       /* [q] */
+    const double *const *x_fe;    /* [q] each n x ncol_fe[j], column-major, or NULL */
+    const int32_t *ncol_re;       /* [q] number of random-effect columns of parameter j (may be 0) */
+    const double *const *x_re;    /* [q] each n x ncol_re[j], column-major, or NULL when 0 columns  */
+
+    /* smoothing penalty: DATA_IVECTOR(ncol_re) + DATA_SPARSE_MATRIX(S) of the reference */
+    int32_t  n_smooth;            /* number of penalty blocks; 0 = no random effects (R/sde.R:511-518) */
+    const int32_t *smooth_ncol;   /* [n_smooth] columns of each block (reference `ncol_re`)           */
+    const double *s_blocks;       /* the diagonal blocks of S, each smooth_ncol[s]^2 column-major,
+                                     concatenated */
+    int32_t  include_penalty;     /* DATA_INTEGER(include_penalty): read by nllk_sde only (Q7) */
+
+    /* Kalman families only */
+    int64_t  n_seg;               /* rows of a0 = number of ID segments (R/sde.R:547,574) */
+    const double *a0;             /* [n_seg x sdim] column-major, or NULL = built from obs as R/sde.R:549,576-580 */
+    const double *p0;             /* [sdim x sdim] column-major, or NULL = default of R/sde.R:554,584 */
+    const double *h_array;        /* [d x d x n] DATA_ARRAY(H_array), or NULL = sigma_obs^2 I (R/sde.R:563-568,593-598) */
+
+    const uint8_t *par_fixed;     /* [n_par_full] or NULL (= nothing fixed) */
+    int32_t  na_mode;             /* SSDE_NA_* */
+    int32_t  device;              /* HIP device ordinal, -1 = current device */
+    uint32_t flags;               /* SSDE_FLAG_* */
+    uint32_t reserved;
+} ssde_desc;
+
+typedef struct ssde_handle ssde_handle;
+
+/* facts about a created engine (InfoADFunObject counterpart) */
+typedef struct ssde_info_t {
+    int32_t n_par_full;     /* length of `par` / `grad` */
+    int32_t n_free;         /* entries with par_fixed == 0 */
+    int32_t sdim;           /* Kalman state dimension (0 for direct families) */
+    int32_t path;           /* 0 direct, 1 isotropic register Kalman, 2 dense Kalman */
+    int32_t const_coeff;    /* 1 if every SDE parameter is intercept-only */
+    int32_t uniform_dt;     /* 1 if one dt is shared by every scored interval (transition matrices hoisted) */
+    int64_t n_tracks;       /* ID segments */
+    int64_t n_rows;         /* n */
+    int64_t n_steps;        /* rows that are not the first row of a segment */
+    int64_t hbm_bytes;      /* resident bytes of the tiled streams */
+    double  algo_bytes_per_row; /* 8*(d + 1 + d*d*[H_array] + K_row) */
+    int32_t n_kernel_blocks;/* workgroups of the main kernel */
+    int32_t lanes_per_track;
+} ssde_info_t;
+
+/* Create an engine: validates the descriptor, finds the ID segments, uploads the
+ * data ONCE and re-tiles it in HBM (tracks -> wavefront lanes, time-major) so that
+ * every later evaluation streams it with coalesced loads.  The caller keeps
+ * ownership of every host array; nothing is aliased after return. */
+int ssde_create(const ssde_desc *desc, ssde_handle **out);
+
+/* fn(par) / gr(par).  order 0: *value only.  order 1: *value and grad[n_par_full].
+ * value = nllk including the smoothing penalty exactly as the reference adds it.
+ * A non-finite nllk is RETURNED (status SSDE_OK), not raised. */
+int ssde_eval(ssde_handle *h, const double *par, int32_t n_par_full, int32_t order,
+              double *value, double *grad);
+
+/* Same evaluation WITHOUT the penalty and without synchronising: enqueues on
+ * `stream` and leaves [nllk_data, grad...] (1 + n_par_full doubles) in the HBM
+ * buffer `out_dev`.  Used by multi-GPU hosts: shard tracks, all-reduce out_dev,
+ * then add ssde_penalty once. */
+int ssde_eval_device(ssde_handle *h, const double *par, int32_t n_par_full, int32_t order,
+                     double *out_dev, void *stream);
+
+/* Smoothing penalty and its gradient (host arithmetic, parameter-only). grad may be NULL;
+ * otherwise it is ADDED into grad[n_par_full]. */
+int ssde_penalty(ssde_handle *h, const double *par, int32_t n_par_full, double *value, double *grad);
+
+/* One-step-ahead predicted states for every row: aest_all [n x sdim] column-major. */
+int ssde_report(ssde_handle *h, const double *par, int32_t n_par_full, double *aest_all);
+
+int ssde_info(const ssde_handle *h, ssde_info_t *info);
+
+void ssde_destroy(ssde_handle *h);
+
+/* Message of the last failure on this handle (or of the last failed ssde_create when h == NULL). */
+const char *ssde_last_error(const ssde_handle *h);
+
+int ssde_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDE_H */

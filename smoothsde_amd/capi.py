@@ -1,0 +1,349 @@
+"""ctypes mirror of include/ssde.h and the loader of the HIP engine library.
+
+The product path is `libssde_hip.so` (hand-written HIP, gfx950).  There is NO CPU
+fallback: if the library is missing, or no GPU is visible when an engine is created,
+this module raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+
+`Problem` carries the arguments of the reference's `tmb_dat` list
+(/root/reference/R/sde.R:528-536, 542-598) as numpy arrays and exposes them as an
+`ssde_desc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+ABI_VERSION = 1
+
+MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4}
+KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
+# types the reference dispatches (src/smoothSDE.cpp:12-27) that this engine does not cover
+UNSUPPORTED_MODELS = ("BM_t", "CIR", "ESEAL_SSM")
+
+NA_R_ONLY, NA_ANY_NAN = 0, 1
+FLAG_DEVICE_DATA, FLAG_FORCE_DENSE, FLAG_NO_UNIFORM_DT = 0x1, 0x2, 0x4
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class SsdeDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("model", C.c_int32), ("n_dim", C.c_int32), ("n_par", C.c_int32),
+        ("n", C.c_int64),
+        ("id", C.c_void_p), ("times", C.c_void_p), ("obs", C.c_void_p),
+        ("ncol_fe", _ip), ("x_fe", C.POINTER(C.c_void_p)),
+        ("ncol_re", _ip), ("x_re", C.POINTER(C.c_void_p)),
+        ("n_smooth", C.c_int32), ("smooth_ncol", _ip), ("s_blocks", C.c_void_p),
+        ("include_penalty", C.c_int32),
+        ("n_seg", C.c_int64), ("a0", C.c_void_p), ("p0", C.c_void_p), ("h_array", C.c_void_p),
+        ("par_fixed", C.c_void_p), ("na_mode", C.c_int32), ("device", C.c_int32),
+        ("flags", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class SsdeInfo(C.Structure):
+    _fields_ = [
+        ("n_par_full", C.c_int32), ("n_free", C.c_int32), ("sdim", C.c_int32), ("path", C.c_int32),
+        ("const_coeff", C.c_int32), ("uniform_dt", C.c_int32),
+        ("n_tracks", C.c_int64), ("n_rows", C.c_int64), ("n_steps", C.c_int64), ("hbm_bytes", C.c_int64),
+        ("algo_bytes_per_row", C.c_double), ("n_kernel_blocks", C.c_int32), ("lanes_per_track", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def na_real() -> float:
+    """R's NA_real_: the NaN whose low word is 1954 (what R_IsNA tests)."""
+    return float(np.array([0x7FF00000000007A2], dtype=np.uint64).view(np.float64)[0])
+
+
+def _f64(a, order="F"):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["ALIGNED"] + (["F"] if order == "F" else ["C"]))
+
+
+def n_sde_par(model: str, n_dim: int) -> int:
+    return n_dim + 1 if model in ("BM", "BM_SSM") else n_dim + 2
+
+
+def state_dim(model: str, n_dim: int) -> int:
+    if model == "CTCRW":
+        return 2 * n_dim
+    return n_dim if model in KALMAN_MODELS else 0
+
+
+class Problem:
+    """Host-side container for one model's data, in the reference's argument shapes.
+
+    ID      : (n,) any dtype; only neighbour inequality matters (nllk_ctcrw.hpp:196)
+    times   : (n,)
+    obs     : (n, d)
+    X_fe    : list of q arrays (n, ncol_fe[j]) or None (= intercept-only)
+    X_re    : list of q arrays (n, ncol_re[j]) or None
+    S_list  : list of penalty blocks (one per smooth), smooth order = column order of X_re
+    """
+
+    def __init__(self, model: str, ID, times, obs, X_fe: Optional[Sequence] = None,
+                 X_re: Optional[Sequence] = None, S_list: Optional[Sequence] = None,
+                 a0=None, P0=None, H=None, par_fixed=None, include_penalty: int = 1,
+                 na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0):
+        if model in UNSUPPORTED_MODELS:
+            raise NotImplementedError(f"SDE type {model!r} is outside this engine's scope")
+        if model not in MODEL_CODES:
+            raise ValueError("Unknown SDE type")  # src/smoothSDE.cpp:25
+        self.model = model
+        obs = np.asarray(obs, dtype=np.float64)
+        if obs.ndim == 1:
+            obs = obs[:, None]
+        self.n, self.n_dim = obs.shape
+        self.q = n_sde_par(model, self.n_dim)
+        self.sdim = state_dim(model, self.n_dim)
+        self.obs = _f64(obs)
+        ID = np.asarray(ID)
+        if ID.dtype.kind not in "fiu":
+            _, ID = np.unique(ID, return_inverse=True)
+        self.id = _f64(ID)
+        self.times = _f64(times)
+        if self.id.shape != (self.n,) or self.times.shape != (self.n,):
+            raise ValueError("ID, times and obs must have the same number of rows")
+
+        self.X_fe, self.X_re = [], []
+        ncol_fe, ncol_re = [], []
+        for j in range(self.q):
+            xf = None if X_fe is None else X_fe[j]
+            if xf is None:
+                self.X_fe.append(None)
+                ncol_fe.append(1)
+            else:
+                xf = _f64(np.asarray(xf, dtype=np.float64).reshape(self.n, -1))
+                self.X_fe.append(xf)
+                ncol_fe.append(xf.shape[1])
+            xr = None if X_re is None else X_re[j]
+            if xr is None or np.asarray(xr).size == 0:
+                self.X_re.append(None)
+                ncol_re.append(0)
+            else:
+                xr = _f64(np.asarray(xr, dtype=np.float64).reshape(self.n, -1))
+                self.X_re.append(xr)
+                ncol_re.append(xr.shape[1])
+        self.ncol_fe = np.asarray(ncol_fe, dtype=np.int32)
+        self.ncol_re = np.asarray(ncol_re, dtype=np.int32)
+        self.n_fe, self.n_re = int(self.ncol_fe.sum()), int(self.ncol_re.sum())
+
+        S_list = [] if S_list is None else [np.asarray(s, dtype=np.float64) for s in S_list]
+        self.S_list = S_list
+        self.smooth_ncol = np.asarray([s.shape[0] for s in S_list], dtype=np.int32)
+        if int(self.smooth_ncol.sum()) != self.n_re:
+            raise ValueError("penalty blocks do not match the random-effect columns")
+        self.s_blocks = _f64(np.concatenate([s.flatten(order="F") for s in S_list])) if S_list else None
+        self.n_smooth = len(S_list)
+        self.include_penalty = int(include_penalty)
+
+        self.kalman = model in KALMAN_MODELS
+        first = np.ones(self.n, dtype=bool)
+        first[1:] = self.id[1:] != self.id[:-1]
+        self.seg_start = np.flatnonzero(first)
+        self.n_seg = len(self.seg_start)
+        self.a0 = None if a0 is None else _f64(np.asarray(a0, dtype=np.float64).reshape(self.n_seg, self.sdim))
+        self.P0 = None if P0 is None else _f64(np.asarray(P0, dtype=np.float64).reshape(self.sdim, self.sdim))
+        if H is not None:
+            H = np.asarray(H, dtype=np.float64)
+            if H.shape != (self.n_dim, self.n_dim, self.n):
+                raise ValueError("H must be an array of shape (d, d, n)")
+            H = _f64(H)
+        self.H = H
+
+        # full parameter vector layout (include/ssde.h)
+        o = 0
+        self.off_sigobs = None
+        if self.kalman:
+            self.off_sigobs = 0
+            o = 1
+        self.off_fe = o
+        o += self.n_fe
+        self.off_lambda = o
+        o += self.n_smooth
+        self.off_re = o
+        o += self.n_re
+        self.n_par_full = o
+        self.fe_off = np.concatenate([[0], np.cumsum(self.ncol_fe)[:-1]]).astype(int)
+        self.re_off = np.concatenate([[0], np.cumsum(self.ncol_re)[:-1]]).astype(int)
+
+        fixed = np.zeros(self.n_par_full, dtype=np.uint8)
+        if par_fixed is not None:
+            fixed[:] = np.asarray(par_fixed, dtype=np.uint8)
+        if self.kalman and self.H is not None:
+            fixed[0] = 1  # map log_sigma_obs = NA when H is supplied (R/sde.R:565, 595)
+        self.par_fixed = fixed
+        self.na_mode, self.device, self.flags = int(na_mode), int(device), int(flags)
+        self._keep = []
+
+    # -- parameter helpers ---------------------------------------------------------------
+    def par_names(self):
+        names = []
+        if self.kalman:
+            names.append("log_sigma_obs")
+        for j in range(self.q):
+            names += [f"coeff_fe[{j}][{c}]" for c in range(self.ncol_fe[j])]
+        names += [f"log_lambda[{s}]" for s in range(self.n_smooth)]
+        for j in range(self.q):
+            names += [f"coeff_re[{j}][{c}]" for c in range(self.ncol_re[j])]
+        return names
+
+    def free_index(self):
+        return np.flatnonzero(self.par_fixed == 0)
+
+    # -- ctypes view ------------------------------------------------------------------------
+    def desc(self) -> SsdeDesc:
+        d = SsdeDesc()
+        keep = self._keep = []
+
+        def ptr(a):
+            if a is None:
+                return None
+            keep.append(a)
+            return a.ctypes.data
+
+        d.abi_version = ABI_VERSION
+        d.model = MODEL_CODES[self.model]
+        d.n_dim, d.n_par, d.n = self.n_dim, self.q, self.n
+        d.id, d.times, d.obs = ptr(self.id), ptr(self.times), ptr(self.obs)
+        d.ncol_fe = self.ncol_fe.ctypes.data_as(_ip)
+        d.ncol_re = self.ncol_re.ctypes.data_as(_ip)
+        xfe = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_fe])
+        xre = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_re])
+        keep += [xfe, xre]
+        d.x_fe, d.x_re = xfe, xre
+        d.n_smooth = self.n_smooth
+        d.smooth_ncol = self.smooth_ncol.ctypes.data_as(_ip) if self.n_smooth else None
+        d.s_blocks = ptr(self.s_blocks)
+        d.include_penalty = self.include_penalty
+        d.n_seg = self.n_seg
+        d.a0, d.p0, d.h_array = ptr(self.a0), ptr(self.P0), ptr(self.H)
+        d.par_fixed = ptr(self.par_fixed)
+        d.na_mode, d.device, d.flags = self.na_mode, self.device, self.flags
+        return d
+
+
+# ---------------------------------------------------------------------------------------------
+_LIB = None
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssde_hip.so")
+
+
+def load_library():
+    """Load libssde_hip.so; raise loudly if the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"HIP engine library not found at {path}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.ssde_create.argtypes = [C.POINTER(SsdeDesc), C.POINTER(C.c_void_p)]
+    lib.ssde_create.restype = C.c_int
+    lib.ssde_eval.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp, _dp]
+    lib.ssde_eval.restype = C.c_int
+    lib.ssde_eval_device.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ssde_eval_device.restype = C.c_int
+    lib.ssde_penalty.argtypes = [C.c_void_p, _dp, C.c_int32, _dp, _dp]
+    lib.ssde_penalty.restype = C.c_int
+    lib.ssde_report.argtypes = [C.c_void_p, _dp, C.c_int32, _dp]
+    lib.ssde_report.restype = C.c_int
+    lib.ssde_info.argtypes = [C.c_void_p, C.POINTER(SsdeInfo)]
+    lib.ssde_info.restype = C.c_int
+    lib.ssde_destroy.argtypes = [C.c_void_p]
+    lib.ssde_destroy.restype = None
+    lib.ssde_last_error.argtypes = [C.c_void_p]
+    lib.ssde_last_error.restype = C.c_char_p
+    lib.ssde_abi_version.argtypes = []
+    lib.ssde_abi_version.restype = C.c_int
+    if lib.ssde_abi_version() != ABI_VERSION:
+        raise RuntimeError("libssde_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report",
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One created engine (= one `MakeADFun` object of the reference) on one GPU."""
+
+    def __init__(self, problem: Problem):
+        self.lib = load_library()
+        self.problem = problem
+        self._h = C.c_void_p()
+        d = problem.desc()
+        st = self.lib.ssde_create(C.byref(d), C.byref(self._h))
+        if st != 0:
+            msg = self.lib.ssde_last_error(None)
+            raise EngineError(f"ssde_create failed ({st}): {msg.decode() if msg else ''}")
+        self.n_par_full = problem.n_par_full
+
+    def _check(self, st):
+        if st != 0:
+            msg = self.lib.ssde_last_error(self._h)
+            raise EngineError(f"ssde call failed ({st}): {msg.decode() if msg else ''}")
+
+    def info(self) -> dict:
+        inf = SsdeInfo()
+        self._check(self.lib.ssde_info(self._h, C.byref(inf)))
+        return inf.as_dict()
+
+    def eval(self, par, order: int = 1):
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        if par.shape != (self.n_par_full,):
+            raise ValueError(f"par must have length {self.n_par_full}")
+        val = C.c_double()
+        grad = np.zeros(self.n_par_full)
+        self._check(self.lib.ssde_eval(self._h, par.ctypes.data_as(_dp), self.n_par_full, order,
+                                       C.byref(val), grad.ctypes.data_as(_dp)))
+        return (val.value, grad) if order >= 1 else val.value
+
+    def eval_device(self, par, out_ptr: int, order: int = 1, stream: int = 0):
+        """Asynchronous evaluation of the data term into an HBM buffer of 1+n_par_full doubles."""
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        self._check(self.lib.ssde_eval_device(self._h, par.ctypes.data_as(_dp), self.n_par_full, order,
+                                              C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def penalty(self, par, want_grad: bool = True):
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        val = C.c_double()
+        grad = np.zeros(self.n_par_full)
+        self._check(self.lib.ssde_penalty(self._h, par.ctypes.data_as(_dp), self.n_par_full, C.byref(val),
+                                          grad.ctypes.data_as(_dp) if want_grad else None))
+        return val.value, grad
+
+    def report(self, par):
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        out = np.zeros((self.problem.n, self.problem.sdim), order="F")
+        self._check(self.lib.ssde_report(self._h, par.ctypes.data_as(_dp), self.n_par_full,
+                                         out.ctypes.data_as(_dp)))
+        return out
+
+    def close(self):
+        if self._h:
+            self.lib.ssde_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

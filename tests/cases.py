@@ -1,0 +1,175 @@
+"""Small seeded parity cases (SURVEY.md 8(c) fixture matrix).
+
+A case is a plain dict of arrays (JSON-serialisable via tests/golden/gen_golden.py) plus
+one parameter vector.  `problem_from_spec` turns it into a smoothsde_amd.capi.Problem.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from smoothsde_amd.capi import Problem, n_sde_par, state_dim, na_real
+from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+
+# the six rows of the vignette's elephant track that survive offline
+# (/root/reference/vignettes/smoothSDE.pdf, output of smoothSDE.rmd:470)
+ELEPHANT_ROWS = np.array([
+    [572.3427, 1675.424, 33, 9703],
+    [572.5443, 1675.392, 32, 9704],
+    [572.6159, 1675.339, 31, 9705],
+    [572.7745, 1675.101, 31, 9706],
+    [572.8844, 1675.065, 31, 9707],
+    [573.6659, 1674.322, 30, 9708],
+])
+
+
+def _tracks(rng, model, d, lengths, irregular=True, scale=1.0):
+    """Random-walk-ish observations; the likelihood is evaluated, not fitted, so any
+    smooth-ish data will do."""
+    ID, times, obs = [], [], []
+    t0 = 0.0
+    for k, T in enumerate(lengths):
+        dts = rng.uniform(0.3, 2.0, size=T) if irregular else np.ones(T)
+        tt = t0 + np.cumsum(dts)
+        t0 = tt[-1] + 5.0
+        steps = rng.standard_normal((T, d)) * scale
+        if model in ("CTCRW",):
+            vel = np.cumsum(rng.standard_normal((T, d)) * 0.3, axis=0)
+            z = np.cumsum(vel * dts[:, None], axis=0) + 0.1 * steps
+        elif model in ("OU", "OU_SSM"):
+            z = 3.0 + steps
+        else:
+            z = np.cumsum(steps, axis=0)
+        ID += [float(k)] * T
+        times += list(tt)
+        obs.append(z + 10.0 * k)
+    return np.array(ID), np.array(times), np.vstack(obs)
+
+
+def _par_const(rng, model, d, kalman):
+    q = n_sde_par(model, d)
+    p = []
+    if kalman:
+        p.append(rng.uniform(-1.5, 0.0))  # log_sigma_obs
+    p += list(rng.uniform(-0.5, 0.5, size=d) + (3.0 if model in ("OU", "OU_SSM") else 0.0))  # mu
+    p += list(rng.uniform(-0.3, 0.7, size=q - d))  # log-scale parameters
+    return np.array(p)
+
+
+def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irregular=True,
+              fix_mu=False, with_H=False, with_P0=False, na_mode=1):
+    rng = np.random.default_rng(seed)
+    kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
+    ID, times, obs = _tracks(rng, model, d, lengths, irregular)
+    n = len(ID)
+    q = n_sde_par(model, d)
+    sdim = state_dim(model, d)
+    spec = dict(name=name, model=model, n_dim=d, ID=ID, times=times, obs=obs, X_fe=None, X_re=None,
+                S_list=None, a0=None, P0=None, H=None, par_fixed=None, na_mode=na_mode, include_penalty=1)
+    na = na_real() if na_mode == 0 else float("nan")
+    for r in na_rows:
+        if kalman:
+            obs[r, :] = na
+        else:
+            obs[r, rng.integers(0, d)] = na
+    if variant == "const":
+        par = _par_const(rng, model, d, kalman)
+    else:
+        # time-varying: covariate x in [0,1]; parameter d (tau / sigma) gets intercept + linear x;
+        # the last parameter (or mu_1 for BM) gets a 4-column spline block with a penalty;
+        # the rest stay intercept-only.
+        x = (np.sin(np.linspace(0, 7, n)) + 1) / 2 + 0.05 * rng.standard_normal(n)
+        x = np.clip(x, 0, 1)
+        X_fe = [None] * q
+        X_re = [None] * q
+        X_fe[d] = np.column_stack([np.ones(n), x])
+        jr = q - 1 if model not in ("BM", "BM_SSM") else 0
+        B = bspline_basis(x, n_basis=4)
+        X_re[jr] = B
+        S_list = [second_difference_penalty(4)]
+        if variant == "tv2":  # a second smooth, on mu_0 (two penalty blocks, two parameters with RE)
+            j2 = 0 if jr != 0 else d
+            X_re[j2] = bspline_basis(np.clip(x ** 2, 0, 1), n_basis=5)
+            S_list = ([second_difference_penalty(5)] + S_list) if j2 < jr else (S_list + [second_difference_penalty(5)])
+        spec.update(X_fe=X_fe, X_re=X_re, S_list=S_list)
+        ncol_fe = [1 if X_fe[j] is None else X_fe[j].shape[1] for j in range(q)]
+        p = []
+        if kalman:
+            p.append(rng.uniform(-1.5, 0.0))
+        for j in range(q):
+            base = rng.uniform(-0.3, 0.5) + (3.0 if (j < d and model in ("OU", "OU_SSM")) else 0.0)
+            p += [base] + list(rng.uniform(-0.4, 0.4, size=ncol_fe[j] - 1))
+        p += list(rng.uniform(-0.5, 1.0, size=len(S_list)))  # log_lambda
+        p += list(rng.uniform(-0.3, 0.3, size=sum(s.shape[0] for s in S_list)))  # coeff_re
+        par = np.array(p)
+    if with_H:
+        A = rng.standard_normal((n, d, d)) * 0.2
+        H = np.einsum("nij,nkj->ikn", A, A) + 0.05 * np.eye(d)[:, :, None]
+        spec["H"] = H
+    if with_P0:
+        A = rng.standard_normal((sdim, sdim))
+        spec["P0"] = A @ A.T + np.eye(sdim)
+    if fix_mu:
+        pb = problem_from_spec(dict(spec, par=par))
+        fixed = np.zeros(pb.n_par_full, dtype=np.uint8)
+        for a in range(d):
+            fixed[pb.off_fe + pb.fe_off[a]] = 1
+        spec["par_fixed"] = fixed
+    spec["par"] = par
+    return spec
+
+
+def elephant_spec():
+    """6-row CTCRW micro-fixture at the vignette's initial parameters
+    (par0 = c(0, 0, 1, 1), fixpar = c("mu1", "mu2"): smoothSDE.rmd:476-490)."""
+    rows = ELEPHANT_ROWS
+    spec = dict(name="elephant6_ctcrw", model="CTCRW", n_dim=2, ID=np.ones(6), times=rows[:, 3].copy(),
+                obs=rows[:, :2].copy(), X_fe=None, X_re=None, S_list=None, a0=None, P0=None, H=None,
+                na_mode=1, include_penalty=1)
+    fixed = np.zeros(5, dtype=np.uint8)
+    fixed[1:3] = 1
+    spec["par_fixed"] = fixed
+    spec["par"] = np.array([0.0, 0.0, 0.0, 0.0, 0.0])  # log_sigma_obs, mu1, mu2, log tau, log nu
+    return spec
+
+
+def problem_from_spec(spec, **over) -> Problem:
+    kw = dict(a0=spec.get("a0"), P0=spec.get("P0"), H=spec.get("H"), par_fixed=spec.get("par_fixed"),
+              include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1))
+    kw.update(over)
+    return Problem(spec["model"], spec["ID"], spec["times"], spec["obs"], spec.get("X_fe"), spec.get("X_re"),
+                   spec.get("S_list"), **kw)
+
+
+def all_specs():
+    specs = [elephant_spec()]
+    seed = 100
+    for model in ("CTCRW", "OU_SSM", "BM_SSM"):
+        for d in (1, 2):
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_const", model, d, seed=seed, lengths=[9, 2, 14, 6, 11],
+                                   na_rows=(3, 16, 17, 30)))
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_const_regular_fixmu", model, d, seed=seed,
+                                   lengths=[12, 12, 12], irregular=False, fix_mu=True))
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_tv", model, d, seed=seed, lengths=[13, 8, 10],
+                                   variant="tv", na_rows=(5,)))
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_H", model, d, seed=seed, lengths=[10, 7], with_H=True,
+                                   na_rows=(4,)))
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_P0", model, d, seed=seed, lengths=[8, 9], with_P0=True))
+    specs.append(make_spec("CTCRW_d2_tv2_RNA", "CTCRW", 2, seed=171, lengths=[15, 9], variant="tv2",
+                           na_rows=(6, 7), na_mode=0))
+    specs.append(make_spec("CTCRW_d2_tv_H_P0", "CTCRW", 2, seed=172, lengths=[11, 12], variant="tv",
+                           with_H=True, with_P0=True))
+    for model in ("OU", "BM"):
+        for d in (1, 2):
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_const", model, d, seed=seed, lengths=[9, 2, 14, 6],
+                                   na_rows=(3, 12)))
+            seed += 1
+            specs.append(make_spec(f"{model}_d{d}_tv", model, d, seed=seed, lengths=[16, 11],
+                                   variant="tv", na_rows=(5,)))
+    specs.append(make_spec("OU_d1_tv2", "OU", 1, seed=181, lengths=[20, 13], variant="tv2"))
+    return specs

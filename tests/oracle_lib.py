@@ -1,0 +1,70 @@
+"""Loader for the CPU oracle (oracle/liboracle.so) -- test infrastructure only.
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER of
+the HIP path.  Nothing in smoothsde_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from smoothsde_amd.capi import Problem, SsdeDesc
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB = None
+_dp = C.POINTER(C.c_double)
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
+
+
+def load_oracle():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        lib = C.CDLL(path)
+        lib.oracle_eval.argtypes = [C.POINTER(SsdeDesc), _dp, C.c_int, _dp, _dp, _dp, C.c_int]
+        lib.oracle_eval.restype = C.c_int
+        lib.oracle_eval_data.argtypes = [C.POINTER(SsdeDesc), _dp, C.c_int, _dp, _dp, C.c_int]
+        lib.oracle_eval_data.restype = C.c_int
+        lib.oracle_n_par_full.argtypes = [C.POINTER(SsdeDesc)]
+        lib.oracle_n_par_full.restype = C.c_int
+        _LIB = lib
+    return _LIB
+
+
+def oracle_eval(problem: Problem, par, order: int = 1, threads: int = 1, report: bool = False,
+                data_only: bool = False):
+    """nllk (+ penalty unless data_only), gradient over the full parameter vector, and
+    optionally aest_all (n x sdim)."""
+    lib = load_oracle()
+    d = problem.desc()
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    assert lib.oracle_n_par_full(C.byref(d)) == problem.n_par_full == par.size
+    val = C.c_double()
+    grad = np.zeros(problem.n_par_full)
+    aest = None
+    if data_only:
+        st = lib.oracle_eval_data(C.byref(d), par.ctypes.data_as(_dp), order, C.byref(val),
+                                  grad.ctypes.data_as(_dp), threads)
+    else:
+        ap = None
+        if report:
+            aest = np.zeros((problem.n, problem.sdim), order="F")
+            ap = aest.ctypes.data_as(_dp)
+        st = lib.oracle_eval(C.byref(d), par.ctypes.data_as(_dp), order, C.byref(val),
+                             grad.ctypes.data_as(_dp), ap, threads)
+    assert st == 0
+    out = [val.value]
+    if order >= 1:
+        out.append(grad)
+    if report:
+        out.append(aest)
+    return out[0] if len(out) == 1 else tuple(out)

@@ -1,0 +1,81 @@
+"""CPU suite: the oracle against the committed golden vectors and against the independent
+restatement (dense joint Gaussian / torch.distributions + autograd)."""
+import numpy as np
+import pytest
+
+from cases import all_specs, problem_from_spec
+from golden_io import load_golden
+from oracle_lib import oracle_eval
+
+GOLD = load_golden()
+VALUE_RTOL = 1e-12   # oracle is deterministic: re-evaluation must reproduce the fixture
+GRAD_TOL = lambda g: 1e-10 * np.max(np.abs(g)) + 1e-12  # noqa: E731
+
+
+@pytest.mark.parametrize("rec", GOLD, ids=[r["name"] for r in GOLD])
+def test_oracle_reproduces_golden(rec):
+    pb = problem_from_spec(rec)
+    val, grad = oracle_eval(pb, rec["par"], order=1)
+    exp = rec["expected"]
+    assert abs(val - exp["value"]) <= VALUE_RTOL * max(1.0, abs(exp["value"]))
+    assert np.max(np.abs(grad - exp["grad"])) <= GRAD_TOL(exp["grad"])
+    # independent restatement stored next to it (value 1e-10 rel, gradient 1e-8 rel + 1e-10)
+    assert abs(val - exp["indep_value"]) <= 1e-10 * max(1.0, abs(exp["indep_value"]))
+    assert np.max(np.abs(grad - exp["indep_grad"])) <= 1e-8 * np.max(np.abs(exp["indep_grad"])) + 1e-10
+
+
+def test_golden_inputs_match_generator():
+    """The fixture inputs are exactly what tests/cases.py generates (bitwise, NA payloads included)."""
+    specs = {s["name"]: s for s in all_specs()}
+    assert set(specs) == {r["name"] for r in GOLD}
+    for rec in GOLD:
+        s = specs[rec["name"]]
+        for key in ("ID", "times", "obs", "par"):
+            a, b = np.asarray(s[key], dtype=np.float64), np.asarray(rec[key], dtype=np.float64)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (rec["name"], key)
+
+
+@pytest.mark.parametrize("name", ["CTCRW_d2_const", "OU_SSM_d1_tv", "BM_SSM_d2_H", "OU_d2_tv", "CTCRW_d2_tv2_RNA"])
+def test_independent_restatement_live(name):
+    from refimpl import ref_eval
+    rec = next(r for r in GOLD if r["name"] == name)
+    pb = problem_from_spec(rec)
+    val, grad = oracle_eval(pb, rec["par"], order=1)
+    rval, rgrad = ref_eval(pb, rec["par"])
+    assert abs(val - rval) <= 1e-10 * max(1.0, abs(rval))
+    assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
+
+
+def test_oracle_threads_and_data_only():
+    rec = next(r for r in GOLD if r["name"] == "CTCRW_d2_tv")
+    pb = problem_from_spec(rec)
+    v1, g1 = oracle_eval(pb, rec["par"], order=1, threads=1)
+    v3, g3 = oracle_eval(pb, rec["par"], order=1, threads=3)
+    assert abs(v1 - v3) <= 1e-12 * abs(v1) and np.allclose(g1, g3, rtol=1e-11, atol=1e-12)
+    vd, gd = oracle_eval(pb, rec["par"], order=1, data_only=True)
+    assert vd != v1  # the penalty is non-zero in this case
+
+
+def test_oracle_finite_difference_gradient():
+    rec = next(r for r in GOLD if r["name"] == "CTCRW_d2_const")
+    pb = problem_from_spec(rec)
+    par = rec["par"]
+    _, g = oracle_eval(pb, par, order=1)
+    for k in range(pb.n_par_full):
+        h = 1e-6
+        e = np.zeros_like(par)
+        e[k] = h
+        fd = (oracle_eval(pb, par + e, order=0) - oracle_eval(pb, par - e, order=0)) / (2 * h)
+        assert abs(fd - g[k]) <= 1e-6 * max(1.0, abs(g[k]))
+
+
+def test_first_observation_never_scored():
+    """Quirk Q1: changing a track's first observation only moves a0."""
+    rec = next(r for r in GOLD if r["name"] == "BM_SSM_d1_const")
+    pb = problem_from_spec(rec)
+    a0 = np.zeros((pb.n_seg, pb.sdim))
+    a0[:, 0] = pb.obs[pb.seg_start, 0]
+    obs2 = rec["obs"].copy()
+    obs2[pb.seg_start, 0] += 123.0
+    pb2 = problem_from_spec(dict(rec, obs=obs2), a0=a0)
+    assert abs(oracle_eval(pb, rec["par"], 0) - oracle_eval(pb2, rec["par"], 0)) < 1e-12
