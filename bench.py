@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- track-timesteps/s of one nllk + gradient evaluation (BASELINE.json metric).
+
+A "step" is one evaluation of the hot path (value + full gradient, one ssde_eval_device, the
+RCCL all-reduce of the 1+p doubles when N > 1, and the D2H of the result) over one resident
+batch of synthetic tracks, each step at a different parameter vector.  Workload at every N:
+10^4 two-dimensional CTCRW tracks x 10^4 rows PER GPU (constant coefficients, sigma_obs free,
+mu fixed as in the vignette) -- weak scaling: tracks shard over ranks with no data-path
+collective other than the scalar all-reduce.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(seconds_target=15.0):
+    """The CPU oracle (port of the reference arithmetic, forward-mode gradient) on a bounded
+    sample of the same workload, on all host cores of this box.  Baseline, not the target."""
+    from oracle_lib import oracle_eval
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import simulate
+    cores = os.cpu_count() or 1
+    tracks, rows = 4 * cores, 2000
+    ID, times, obs = simulate("CTCRW", tracks, rows, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
+    fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
+    pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed)
+    par = np.array([0.0, 0.0, 0.0, 0.0, 0.0])
+    oracle_eval(pb, par, order=1, threads=cores)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle_eval(pb, par + 0.01 * reps, order=1, threads=cores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_target or reps >= 50:
+            break
+    rate = tracks * rows * reps / el
+    return {"value": rate, "unit": "track-timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{tracks} CTCRW tracks x {rows} rows, {reps} nllk+grad evaluations, "
+                      f"oracle/liboracle.so (g++ -O2, {cores} threads over track shards)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tracks", type=int, default=10_000, help="tracks per GPU")
+    ap.add_argument("--rows", type=int, default=10_000, help="rows per track")
+    ap.add_argument("--model", default="CTCRW")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if args.gpus > 1 and world == 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import simulate
+
+    M, T, d = args.tracks, args.rows, 2
+    # synthetic batch built directly in HBM (SURVEY.md 8(d) C2': tau=2, nu=1, mu=0, sigma_obs=0.1, dt=1)
+    ID, times, obs = simulate(args.model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1,
+                              seed=1 + rank, backend="torch", device=dev)
+    q = capi.n_sde_par(args.model, d)
+    fixed = np.zeros(1 + q, dtype=np.uint8)
+    fixed[1:1 + d] = 1  # fixpar = c("mu1","mu2") as in the vignette (smoothSDE.rmd:486-490)
+    pb = capi.Problem.from_torch(args.model, ID, times, obs, par_fixed=fixed)
+    eng = capi.Engine(pb)
+    del ID, times, obs
+    info = eng.info()
+    npar = pb.n_par_full
+    out = torch.zeros(1 + npar, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def theta(k):
+        base = np.zeros(npar)
+        base[0] = np.log(0.1)            # log sigma_obs
+        base[1 + d] = np.log(2.0)        # log tau
+        if q > d + 1:
+            base[2 + d] = 0.0            # log nu
+        return base + 0.01 * np.sin(np.arange(npar) + 0.7 * k)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k, events=None):
+        if events:
+            events[0].record(stream)
+        eng.eval_device(theta(k), out.data_ptr(), order=1, stream=stream.cuda_stream)
+        if events:
+            events[1].record(stream)
+        if world > 1:
+            dist.all_reduce(out)          # RCCL sum of [nllk, grad] over xGMI: 1+p doubles
+        return out.cpu().numpy()          # D2H of the result (synchronises)
+
+    for k in range(args.warmup):
+        res = step(-1 - k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        res = step(k, ev[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert np.all(np.isfinite(res)), res
+
+    rows_per_gpu = info["n_rows"]
+    total_rows = rows_per_gpu * world
+    value = total_rows * args.steps / elapsed
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    algo_bytes = info["algo_bytes_per_row"] * rows_per_gpu
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "track-timesteps/s nllk+grad",
+        "value": value, "unit": "track-timesteps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{M} {args.model} tracks x {T} rows per GPU, d=2, constant coefficients, "
+                               f"sigma_obs/tau/nu free, mu fixed, dt=1 (SURVEY 8(d) C2')",
+                   "tracks_per_gpu": M, "rows_per_track": T, "n_free_par": info["n_free"],
+                   "engine_path": {0: "direct", 1: "isotropic-register", 2: "dense"}[info["path"]],
+                   "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
+                   "direction_parts": info["lanes_per_track"], "parallelism": f"tracks x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kern_ms, "algo_bytes_per_launch": algo_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline must never take the bench line down
+            line["cpu_baseline"] = {"value": None, "unit": "track-timesteps/s", "cores": os.cpu_count(),
+                                    "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

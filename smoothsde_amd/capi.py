@@ -183,6 +183,56 @@ class Problem:
         self.na_mode, self.device, self.flags = int(na_mode), int(device), int(flags)
         self._keep = []
 
+    @classmethod
+    def from_torch(cls, model: str, ID, times, obs, par_fixed=None, na_mode: int = NA_ANY_NAN, flags: int = 0):
+        """Constant-coefficient problem whose data already live in HBM (torch CUDA tensors, fp64):
+        the engine re-tiles them in place of an upload (SSDE_FLAG_DEVICE_DATA)."""
+        import torch
+        assert ID.is_cuda and times.is_cuda and obs.is_cuda
+        self = cls.__new__(cls)
+        if model not in MODEL_CODES:
+            raise ValueError("Unknown SDE type")
+        self.model = model
+        if obs.dim() == 1:
+            obs = obs[:, None]
+        self.n, self.n_dim = int(obs.shape[0]), int(obs.shape[1])
+        self.q = n_sde_par(model, self.n_dim)
+        self.sdim = state_dim(model, self.n_dim)
+        self._t_id = ID.to(torch.float64).contiguous()
+        self._t_times = times.to(torch.float64).contiguous()
+        self._t_obs = obs.to(torch.float64).t().contiguous()     # (d, n) row-major == (n, d) column-major
+        self.id = self.times = self.obs = None
+        self.X_fe, self.X_re = [None] * self.q, [None] * self.q
+        self.ncol_fe = np.ones(self.q, dtype=np.int32)
+        self.ncol_re = np.zeros(self.q, dtype=np.int32)
+        self.n_fe, self.n_re = self.q, 0
+        self.S_list, self.smooth_ncol, self.s_blocks, self.n_smooth = [], np.zeros(0, dtype=np.int32), None, 0
+        self.include_penalty = 1
+        self.kalman = model in KALMAN_MODELS
+        first = torch.ones(self.n, dtype=torch.bool, device=ID.device)
+        first[1:] = self._t_id[1:] != self._t_id[:-1]
+        self.seg_start = first.nonzero().flatten().cpu().numpy()
+        self.n_seg = len(self.seg_start)
+        self.a0 = self.P0 = self.H = None
+        o = 0
+        self.off_sigobs = None
+        if self.kalman:
+            self.off_sigobs, o = 0, 1
+        self.off_fe = o
+        o += self.n_fe
+        self.off_lambda = self.off_re = o
+        self.n_par_full = o
+        self.fe_off = np.arange(self.q)
+        self.re_off = np.zeros(self.q, dtype=int)
+        fixed = np.zeros(self.n_par_full, dtype=np.uint8)
+        if par_fixed is not None:
+            fixed[:] = np.asarray(par_fixed, dtype=np.uint8)
+        self.par_fixed = fixed
+        self.na_mode, self.device = int(na_mode), int(ID.device.index or 0)
+        self.flags = int(flags) | FLAG_DEVICE_DATA
+        self._keep = []
+        return self
+
     # -- parameter helpers ---------------------------------------------------------------
     def par_names(self):
         names = []
@@ -212,7 +262,10 @@ class Problem:
         d.abi_version = ABI_VERSION
         d.model = MODEL_CODES[self.model]
         d.n_dim, d.n_par, d.n = self.n_dim, self.q, self.n
-        d.id, d.times, d.obs = ptr(self.id), ptr(self.times), ptr(self.obs)
+        if getattr(self, "_t_id", None) is not None:
+            d.id, d.times, d.obs = self._t_id.data_ptr(), self._t_times.data_ptr(), self._t_obs.data_ptr()
+        else:
+            d.id, d.times, d.obs = ptr(self.id), ptr(self.times), ptr(self.obs)
         d.ncol_fe = self.ncol_fe.ctypes.data_as(_ip)
         d.ncol_re = self.ncol_re.ctypes.data_as(_ip)
         xfe = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_fe])

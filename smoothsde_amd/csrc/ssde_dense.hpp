@@ -1,0 +1,224 @@
+// ssde_dense.hpp -- general (non-isotropic / time-varying) Kalman step for one lane.
+//
+// Covers everything the register-optimised isotropic kernels do not: per-row H_array
+// (nllk_ctcrw.hpp:203-205), a user P0 that is not block-identical (R/sde.R:552-557, 582-587),
+// and SDE parameters that vary from row to row through streamed design columns
+// (nllk_ctcrw.hpp:143-156).  The covariance is a full sdim x sdim matrix here.
+//
+// Derivatives: the reference differentiates its template with CppAD; this path carries N
+// tangent directions per lane with a small dual-number type written for the device
+// (__host__ __device__, so tests/hostsim can run the same code on the CPU).  The transition
+// matrices have known sparsity (makeT/Q/B_ctcrw, nllk_ctcrw.hpp:45-91), which the products
+// below exploit instead of multiplying dense 4x4 matrices.
+#ifndef SSDE_DENSE_HPP
+#define SSDE_DENSE_HPP
+
+#include "ssde_math.hpp"
+
+namespace ssde {
+
+template <int N>
+struct DualN {
+    double v;
+    double d[N > 0 ? N : 1];
+    SSDE_HD DualN() {}
+    SSDE_HD DualN(double x) : v(x) { for (int k = 0; k < N; k++) d[k] = 0.0; }
+};
+
+template <int N> SSDE_HD DualN<N> operator+(const DualN<N>& a, const DualN<N>& b) {
+    DualN<N> r; r.v = a.v + b.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] + b.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> operator-(const DualN<N>& a, const DualN<N>& b) {
+    DualN<N> r; r.v = a.v - b.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] - b.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> operator*(const DualN<N>& a, const DualN<N>& b) {
+    DualN<N> r; r.v = a.v * b.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * b.v + a.v * b.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> operator/(const DualN<N>& a, const DualN<N>& b) {
+    DualN<N> r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+    for (int k = 0; k < N; k++) r.d[k] = (a.d[k] - r.v * b.d[k]) * ib; return r; }
+template <int N> SSDE_HD DualN<N> operator-(const DualN<N>& a) {
+    DualN<N> r; r.v = -a.v; for (int k = 0; k < N; k++) r.d[k] = -a.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> operator+(const DualN<N>& a, double b) { DualN<N> r = a; r.v += b; return r; }
+template <int N> SSDE_HD DualN<N> operator+(double a, const DualN<N>& b) { DualN<N> r = b; r.v += a; return r; }
+template <int N> SSDE_HD DualN<N> operator-(const DualN<N>& a, double b) { DualN<N> r = a; r.v -= b; return r; }
+template <int N> SSDE_HD DualN<N> operator-(double a, const DualN<N>& b) {
+    DualN<N> r; r.v = a - b.v; for (int k = 0; k < N; k++) r.d[k] = -b.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> operator*(const DualN<N>& a, double b) {
+    DualN<N> r; r.v = a.v * b; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * b; return r; }
+template <int N> SSDE_HD DualN<N> operator*(double a, const DualN<N>& b) { return b * a; }
+template <int N> SSDE_HD DualN<N> operator/(double a, const DualN<N>& b) { return DualN<N>(a) / b; }
+template <int N> SSDE_HD DualN<N> dexp(const DualN<N>& a) {
+    DualN<N> r; r.v = exp(a.v); for (int k = 0; k < N; k++) r.d[k] = r.v * a.d[k]; return r; }
+template <int N> SSDE_HD DualN<N> dlog(const DualN<N>& a) {
+    DualN<N> r; r.v = log(a.v); const double ia = 1.0 / a.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * ia; return r; }
+template <int N> SSDE_HD DualN<N> dsqrt(const DualN<N>& a) {
+    DualN<N> r; r.v = sqrt(a.v); const double h = 0.5 / r.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * h; return r; }
+template <int N> SSDE_HD DualN<N> dfabs(const DualN<N>& a) { return a.v < 0.0 ? -a : a; }
+
+template <int MODEL, int D>
+struct DenseDims {
+    static constexpr int SD = (MODEL == M_CTCRW) ? 2 * D : D;
+    static constexpr int Q = (MODEL == M_BM_SSM) ? D + 1 : D + 2;
+    SSDE_HD static constexpr int z(int i) { return (MODEL == M_CTCRW) ? 2 * i : i; }  // Z picks positions
+};
+
+template <int MODEL, int D, int N>
+struct DenseLane {
+    static constexpr int SD = DenseDims<MODEL, D>::SD;
+    DualN<N> a[SD];
+    DualN<N> P[SD][SD];
+    DualN<N> nll;
+    SSDE_HD void init(const double* a0, const double* p0 /* SD x SD column-major */) {
+        for (int i = 0; i < SD; i++) {
+            a[i] = DualN<N>(a0[i]);
+            for (int j = 0; j < SD; j++) P[i][j] = DualN<N>(p0[i + j * SD]);
+        }
+        nll = DualN<N>(0.0);
+    }
+};
+
+// One row: par[] = the row's linear predictors (working scale) as duals, H = observation
+// covariance (d x d, row-major here), dt = interval after the row, y = observation, na = obs(i,0) NA.
+template <int MODEL, int D, int N>
+SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const DualN<N> (&H)[D][D], double dt,
+                        const double* y, bool na) {
+    typedef DualN<N> T_;
+    typedef DenseDims<MODEL, D> DM;
+    constexpr int SD = DM::SD;
+
+    // ---- transition pieces ---------------------------------------------------------------
+    T_ t12(0.0), e(1.0), q11(0.0), q12(0.0), q22(0.0);  // CTCRW: 2x2 block; OU/BM: e and q11 only
+    T_ drift[SD];
+    if (MODEL == M_CTCRW) {
+        const T_ tau = dexp(par[D]), nu = dexp(par[D + 1]);       // nllk_ctcrw.hpp:153-154
+        const T_ beta = 1.0 / tau;                                 // :155
+        const T_ sigma = 2.0 * nu / dsqrt(M_PI * tau);             // :156
+        e = dexp(-(beta * dt));
+        const T_ e2 = dexp(-2.0 * (beta * dt));
+        t12 = (1.0 - e) / beta;                                    // makeT :51
+        const T_ sb = sigma / beta;
+        q11 = sb * sb * (dt - 2.0 / beta * (1.0 - e) + 1.0 / (2.0 * beta) * (1.0 - e2));  // makeQ :68-69
+        q12 = sigma * sigma / (2.0 * beta * beta) * (1.0 - 2.0 * e + e2);                  // :70
+        q22 = sigma * sigma / (2.0 * beta) * (1.0 - e2);                                   // :72
+        for (int a = 0; a < D; a++) {
+            drift[2 * a] = (dt - t12) * par[a];                    // makeB :87
+            drift[2 * a + 1] = (1.0 - e) * par[a];                 // makeB :88
+        }
+    } else if (MODEL == M_OU_SSM) {
+        const T_ tau = dexp(par[D]), kappa = dexp(par[D + 1]);     // nllk_ou_ssm.hpp:123-124
+        e = dexp(-dt / tau);                                       // makeT :35   (-dt/tau)
+        q11 = kappa * (1.0 - dexp(-2.0 * dt / tau));               // makeQ :66
+        for (int a = 0; a < D; a++) drift[a] = (1.0 - e) * par[a]; // makeB :50
+    } else {
+        const T_ sigma = dexp(par[D]);                             // nllk_bm_ssm.hpp:90
+        q11 = sigma * sigma * dt;                                  // makeQ :33
+        for (int a = 0; a < D; a++) drift[a] = par[a] * dt;        // :139
+    }
+
+    // TP = T P using the sparsity of T
+    T_ TP[SD][SD];
+    for (int c = 0; c < SD; c++) {
+        if (MODEL == M_CTCRW) {
+            for (int a = 0; a < D; a++) {
+                TP[2 * a][c] = L.P[2 * a][c] + t12 * L.P[2 * a + 1][c];
+                TP[2 * a + 1][c] = e * L.P[2 * a + 1][c];
+            }
+        } else if (MODEL == M_OU_SSM) {
+            for (int r = 0; r < SD; r++) TP[r][c] = e * L.P[r][c];
+        } else {
+            for (int r = 0; r < SD; r++) TP[r][c] = L.P[r][c];
+        }
+    }
+    // Ta = T a
+    T_ Ta[SD];
+    if (MODEL == M_CTCRW) {
+        for (int a = 0; a < D; a++) { Ta[2 * a] = L.a[2 * a] + t12 * L.a[2 * a + 1]; Ta[2 * a + 1] = e * L.a[2 * a + 1]; }
+    } else if (MODEL == M_OU_SSM) {
+        for (int r = 0; r < SD; r++) Ta[r] = e * L.a[r];
+    } else {
+        for (int r = 0; r < SD; r++) Ta[r] = L.a[r];
+    }
+    // TPT = TP T' + Q
+    T_ TPT[SD][SD];
+    for (int r = 0; r < SD; r++) {
+        if (MODEL == M_CTCRW) {
+            for (int a = 0; a < D; a++) {
+                TPT[r][2 * a] = TP[r][2 * a] + t12 * TP[r][2 * a + 1];
+                TPT[r][2 * a + 1] = e * TP[r][2 * a + 1];
+            }
+        } else if (MODEL == M_OU_SSM) {
+            for (int c = 0; c < SD; c++) TPT[r][c] = e * TP[r][c];
+        } else {
+            for (int c = 0; c < SD; c++) TPT[r][c] = TP[r][c];
+        }
+    }
+    if (MODEL == M_CTCRW) {
+        for (int a = 0; a < D; a++) {
+            TPT[2 * a][2 * a] = TPT[2 * a][2 * a] + q11;
+            TPT[2 * a][2 * a + 1] = TPT[2 * a][2 * a + 1] + q12;
+            TPT[2 * a + 1][2 * a] = TPT[2 * a + 1][2 * a] + q12;
+            TPT[2 * a + 1][2 * a + 1] = TPT[2 * a + 1][2 * a + 1] + q22;
+        }
+    } else {
+        for (int r = 0; r < SD; r++) TPT[r][r] = TPT[r][r] + q11;
+    }
+
+    // ---- measurement --------------------------------------------------------------------
+    bool upd = !na;
+    T_ F[D][D], det(1.0);
+    if (upd) {
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) F[i][j] = L.P[DM::z(i)][DM::z(j)] + H[i][j];   // F = Z P Z' + H
+        if (D == 1) det = F[0][0];
+        else det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                                // det(): nllk_ctcrw.hpp:16-19
+        // CTCRW tests det <= 0; OU/BM take exp(logdet) = |det|, which fails the test only at 0
+        upd = (MODEL == M_CTCRW) ? (det.v > 0.0) : (fabs(det.v) > 0.0);
+    }
+    if (!upd) {
+        // missing observation, or detF <= 0; Q3: CTCRW drops the drift in the latter case only
+        const bool keep_drift = na || (MODEL != M_CTCRW);
+        for (int r = 0; r < SD; r++) L.a[r] = keep_drift ? Ta[r] + drift[r] : Ta[r];
+        for (int r = 0; r < SD; r++)
+            for (int c = 0; c < SD; c++) L.P[r][c] = TPT[r][c];
+        return;
+    }
+    T_ Fi[D][D];
+    if (D == 1) {
+        Fi[0][0] = 1.0 / F[0][0];
+    } else {
+        const T_ id = 1.0 / det;
+        Fi[0][0] = F[1][1] * id; Fi[0][1] = -(F[0][1] * id);
+        Fi[1][0] = -(F[1][0] * id); Fi[1][1] = F[0][0] * id;
+    }
+    T_ u[D];
+    for (int i = 0; i < D; i++) u[i] = y[i] - L.a[DM::z(i)];                             // line 221
+    T_ uFu(0.0);
+    for (int i = 0; i < D; i++) {
+        T_ s(0.0);
+        for (int j = 0; j < D; j++) s = s + Fi[j][i] * u[j];                             // F^-T u (lines 231-232)
+        uFu = uFu + u[i] * s;
+    }
+    L.nll = L.nll + (dlog(MODEL == M_CTCRW ? det : dfabs(det)) + uFu) * 0.5;             // line 234
+    // K = (T P Z') F^-1   (line 236)
+    T_ K[SD][D];
+    for (int r = 0; r < SD; r++)
+        for (int j = 0; j < D; j++) {
+            T_ s(0.0);
+            for (int i = 0; i < D; i++) s = s + TP[r][DM::z(i)] * Fi[i][j];
+            K[r][j] = s;
+        }
+    // a = T a + K u + drift   (line 238)
+    for (int r = 0; r < SD; r++) {
+        T_ s = Ta[r] + drift[r];
+        for (int j = 0; j < D; j++) s = s + K[r][j] * u[j];
+        L.a[r] = s;
+    }
+    // P = T P (T - K Z)' + Q = (T P T' + Q) - (T P Z') K'   (lines 240-241)
+    for (int r = 0; r < SD; r++)
+        for (int c = 0; c < SD; c++) {
+            T_ s = TPT[r][c];
+            for (int j = 0; j < D; j++) s = s - TP[r][DM::z(j)] * K[c][j];
+            L.P[r][c] = s;
+        }
+}
+
+}  // namespace ssde
+#endif

@@ -1,0 +1,170 @@
+// ssde_device.hpp -- kernel argument blocks and launch prototypes shared by the engine
+// (ssde_engine.hip) and the kernel translation units (k_*.hip).  gfx950 only.
+//
+// HBM layout ("tiles"): tracks are sorted by length, packed 64 to a wavefront ("group"),
+// and every group stores its rows time-major:
+//
+//     tiles[ group_off[g] + (s * C + c) * 64 + lane ]      s = step (row 1.. of the track),
+//                                                           c = channel, lane = track in group
+//
+// so that one wave-wide load of channel c at step s is 512 contiguous bytes, and a block of
+// U steps is U*C*512 contiguous bytes.  Channels: 0 = dt (interval AFTER the row,
+// nllk_ctcrw.hpp:126-129,206), 1..D = obs columns, then D*D H_array entries (if supplied),
+// then the streamed design columns.  A group's length is padded to a multiple of TILE_U
+// steps and the buffer ends with one spare block, so prefetching a block ahead never
+// leaves the allocation.
+#ifndef SSDE_DEVICE_HPP
+#define SSDE_DEVICE_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssde_math.hpp"
+
+namespace ssde {
+
+constexpr int WAVE = 64;
+constexpr int TILE_U = 4;        // steps per prefetch block of the register kernels
+constexpr int NACC_MAX = 8;      // 1 + 3 + D accumulators of the constant-coefficient kernels
+constexpr int MAX_PARTS = 4;     // direction split: at most one part per direction bit
+constexpr int MAX_PAR = 320;     // parameters passed by value in the kernel argument block
+constexpr int MAX_COLS = 96;     // streamed design columns (dense / direct kernels)
+constexpr int MAX_Q = 4;         // SDE parameters per row (d + 2, d <= 2)
+
+struct TileView {
+    const double* tiles;
+    const int64_t* group_off;    // [n_groups] offset of the group's first step, in doubles
+    const int32_t* group_len;    // [n_groups] steps, padded to a multiple of TILE_U
+    const int32_t* lane_nsteps;  // [n_groups*64] scored rows of the lane's track (T_m - 1), 0 = empty lane
+    const double* a0;            // [n_groups][sdim][64] initial state per lane
+    int n_groups;
+    int C;                       // channels per step
+};
+
+// ---- constant-coefficient isotropic Kalman kernels (k_iso.hip) -----------------------------
+struct IsoArgs {
+    TileView tv;
+    double* partials;            // [n_parts][NACC][n_groups]
+    int n_parts;
+    int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
+    int any_nan;
+    int uniform_dt;              // 1: transition hoisted (ctr / str valid), dt channel not read
+    double h;                    // sigma_obs^2
+    double mu[2];
+    double p0[3];                // CTCRW: p11,p12,p22; OU/BM: p
+    double tau, beta, sigma;     // CTCRW (nllk_ctcrw.hpp:152-156); OU: tau, kappa(in sigma); BM: sigma
+    CtcrwTrans ctr;
+    ScalTrans str;
+};
+hipError_t launch_iso(int model, int d, const IsoArgs& a, hipStream_t s);
+
+// ---- final deterministic reduction (k_reduce.hip) --------------------------------------------
+// out[0]    = sum_g partials[part 0][acc 0][g]                    (every part recomputes the nllk)
+// out[slot] = sum over the (part, k >= 1) pairs with map[part*(nacc-1) + k-1] == slot, and over g
+// One workgroup per output slot, fixed summation order: bitwise reproducible.
+struct ReduceArgs {
+    const double* partials;       // [n_parts][nacc][n_blocks]
+    int n_parts, nacc, n_blocks;
+    int n_out;                    // 1 + n_par_full
+    int16_t map[MAX_PAR + 16];    // -> output slot (1 + full-par index) or -1
+    double* out;
+};
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s);
+
+// ---- ingest (k_ingest.hip): long format -> tiles ------------------------------------------------
+struct IngestArgs {
+    const double* times;
+    const double* obs;           // n x d column-major
+    const double* h_array;       // d x d x n or NULL
+    const double* const* cols;   // device array of ncols column pointers (each length n) or NULL
+    int ncols;
+    int d;
+    int64_t n;
+    const int64_t* lane_row0;    // [n_groups*64], -1 = empty lane
+    const int32_t* lane_nsteps;
+    const int64_t* group_off;
+    const int32_t* group_len;
+    int n_groups, C;
+    double* tiles;
+    double* a0;                  // [n_groups][sdim][64] (written from obs when a0_src == NULL)
+    const double* a0_src;        // caller-supplied a0 [n_seg x sdim] column-major or NULL
+    const int64_t* lane_seg;     // [n_groups*64] segment index of the lane's track (for a0_src)
+    int64_t n_seg;
+    int sdim, model;
+    double* dt_minmax;           // [n_groups * ychunks * 2]: min / max of the intervals used INSIDE tracks
+    int ychunks;
+};
+int ingest_ychunks(int n_groups);
+hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
+
+// per-row flags of the direct families: bit i set = row i is scored (ID(i-1) == ID(i))
+hipError_t launch_scored_mask(const double* id, int64_t n, uint32_t* mask, hipStream_t s);
+// first-row flags for segment discovery on device data
+hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipStream_t s);
+
+// ---- general parameter description for the dense / direct kernels -------------------------------
+// Every coefficient of the linear predictor (nllk_ctcrw.hpp:143-149) is a "slot": SDE parameter
+// j it feeds, the streamed design column that multiplies it (or none = intercept column of
+// ones), and its index in the full parameter vector.  Slots are ordered parameter by parameter,
+// fixed-effect columns first.  The table lives in HBM (uploaded once) and is read with scalar
+// loads; the parameter vector is uploaded per evaluation.
+struct SlotTable {
+    int n_slots;
+    int q;
+    int16_t par_j[MAX_COLS];   // SDE parameter fed by the slot
+    int16_t col[MAX_COLS];     // streamed column index, or -1 for an intercept
+    int16_t pidx[MAX_COLS];    // index into the full parameter vector
+    int16_t is_free[MAX_COLS]; // 0 = held fixed (TMB map): no gradient wanted
+};
+
+// ---- direct families (k_direct.hip) ---------------------------------------------------------------
+struct DirectArgs {
+    const double* times;
+    const double* obs;           // n x d column-major (engine-owned copy)
+    const double* const* cols;   // device array of streamed column pointers (each length n)
+    const uint32_t* scored;      // bit i: row i is scored
+    int64_t n;
+    int d, model, any_nan;
+    const SlotTable* slots;      // device
+    const double* par;           // device, full parameter vector
+    int n_slots;                 // == slots->n_slots (host copy, selects the kernel variant)
+    int n_blocks;
+    double* partials;            // [1][1 + n_slots][n_blocks]
+};
+hipError_t launch_direct(const DirectArgs& a, hipStream_t s);
+
+// ---- dense / time-varying Kalman (k_dense.hip) ----------------------------------------------------
+constexpr int DENSE_NT = 2;      // tangent directions per lane
+struct DenseDir {                // one gradient direction
+    int16_t kind;                // 0 none, 1 log_sigma_obs, 2 coefficient slot
+    int16_t slot;                // slot index (kind 2)
+    int16_t pidx;                // index into the full parameter vector
+    int16_t pad;
+};
+struct DenseArgs {
+    TileView tv;
+    int model, d, any_nan, has_h;
+    const SlotTable* slots;      // device
+    const double* par;           // device
+    int n_slots;
+    double p0[16];               // sdim x sdim column-major
+    int n_dirblocks;
+    const DenseDir* dirs;        // device [n_dirblocks * DENSE_NT]
+    double* partials;            // [n_dirblocks][1 + DENSE_NT][n_groups]
+    double* report;              // optional aest_all
+    const int64_t* lane_row0;
+    int64_t n;
+};
+hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
+
+// ---- device helpers -------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+#endif
+
+}  // namespace ssde
+#endif

@@ -1,0 +1,650 @@
+// ssde_engine.hip -- C ABI (include/ssde.h) of the MI355X nllk engine: descriptor checks,
+// segment discovery, one-off upload + re-tiling, per-evaluation launch + reduction, penalty.
+//
+// Replaces, for the nllk/gradient path only, what TMB's MakeADFunObject / EvalADFunObject do
+// for the reference (/root/reference/src/init.c:6-8, R/sde.R:656-669, 694-697).
+// There is no CPU evaluation path in this library: without a gfx950 device ssde_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ssde.h"
+#include "ssde_device.hpp"
+#include "ssde_host.hpp"
+
+using namespace ssde;
+using namespace ssde_host;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum { PATH_DIRECT = 0, PATH_ISO = 1, PATH_DENSE = 2 };
+constexpr int PAR_RING = 8;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) { p = nullptr; return hipSuccess; }
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct ssde_handle {
+    std::string err;
+    int model = 0, d = 0, q = 0, sdim = 0, na_any = 0, device = 0, path = 0;
+    int64_t n = 0, n_seg = 0, n_steps = 0;
+    bool has_h = false, const_coeff = false, uniform_dt = false;
+    double dt_uniform = 0.0;
+    double p0_iso[3] = {0, 0, 0};
+    double p0_full[16] = {0};
+    ParLayout L;
+    Penalty pen;
+    std::vector<Slot> slots;
+    int n_stream_cols = 0;
+    std::vector<uint8_t> fixed;
+    int n_free = 0;
+
+    // Kalman tiles
+    DevBuf<double> tiles, a0;
+    DevBuf<int64_t> group_off, lane_row0;
+    DevBuf<int32_t> group_len, lane_nsteps;
+    int n_groups = 0, C = 0;
+    int64_t tile_doubles = 0;
+
+    // direct families (long format, engine-owned copies)
+    DevBuf<double> times, obs, colbuf;
+    DevBuf<uint32_t> scored;
+    DevBuf<const double*> colptr;
+    int direct_blocks = 0;
+
+    // dense / direct parameter plumbing
+    DevBuf<SlotTable> slot_table;
+    DevBuf<DenseDir> dirs;
+    std::vector<DenseDir> dirs_host;
+    int n_dirblocks = 0;
+    DevBuf<double> par_ring;
+    double* par_pinned = nullptr;
+    hipEvent_t par_ev[PAR_RING];
+    bool par_ev_ok = false;
+    int par_next = 0;
+
+    DevBuf<double> partials, out;
+    size_t partial_doubles = 0;
+
+    // iso direction split
+    int iso_parts = 1;
+    int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
+    int iso_free_mask = 0;
+
+    int64_t hbm_bytes = 0;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);               \
+            return SSDE_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+int fail(ssde_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_create_error = msg;
+    return code;
+}
+
+void destroy(ssde_handle* h) {
+    if (!h) return;
+    h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
+    h->group_len.release(); h->lane_nsteps.release();
+    h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
+    h->slot_table.release(); h->dirs.release(); h->par_ring.release();
+    h->partials.release(); h->out.release();
+    if (h->par_pinned) (void)hipHostFree(h->par_pinned);
+    if (h->par_ev_ok)
+        for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
+    delete h;
+}
+
+// copy a caller array (host or device) into a fresh device buffer
+template <class T>
+hipError_t stage(const T* src, size_t count, bool on_device, DevBuf<T>& dst) {
+    hipError_t e = dst.alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(dst.p, src, count * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+}
+
+int choose_iso_split(ssde_handle* h) {
+    // Which gradient directions are wanted at all
+    int m = 0;
+    const ParLayout& L = h->L;
+    if (!h->fixed[0]) m |= DIR_SIG;
+    for (int a = 0; a < h->d; a++)
+        if (!h->fixed[L.off_fe + a]) m |= DIR_MU;
+    if (!h->fixed[L.off_fe + h->d]) m |= DIR_P1;
+    if (h->q > h->d + 1 && !h->fixed[L.off_fe + h->d + 1]) m |= DIR_P2;
+    h->iso_free_mask = m;
+    // Direction split: a 10^4-track batch is only ~160 waves for 1024 SIMDs; give every
+    // covariance-affecting direction its own wave (each recomputes the cheap primal) until
+    // the grid holds a few waves per SIMD.  SSDE_ISO_SPLIT=fused|split overrides.
+    const char* env = getenv("SSDE_ISO_SPLIT");
+    bool split = h->n_groups < 2048;
+    if (env && !strcmp(env, "fused")) split = false;
+    if (env && !strcmp(env, "split")) split = true;
+    int np = 0;
+    if (split) {
+        // mu rides with the cheapest covariance direction (sigma_obs), else alone
+        int first = (m & DIR_SIG) | (m & DIR_MU);
+        if (first) h->iso_masks[np++] = first;
+        if (m & DIR_P1) h->iso_masks[np++] = DIR_P1;
+        if (m & DIR_P2) h->iso_masks[np++] = DIR_P2;
+    }
+    if (np == 0) { h->iso_masks[0] = m; np = 1; }
+    if (env && strchr(env, ',')) {  // explicit masks, e.g. "3,4,8"
+        np = 0;
+        int covered = 0;
+        for (const char* p = env; *p && np < MAX_PARTS;) {
+            int v = atoi(p) & m;
+            h->iso_masks[np++] = v;
+            covered |= v;
+            p = strchr(p, ',');
+            if (!p) break;
+            p++;
+        }
+        if (covered != m) { h->iso_masks[0] |= (m & ~covered); }
+    }
+    h->iso_parts = np;
+    return 0;
+}
+
+int build(const ssde_desc* d, ssde_handle* h) {
+    // ---- descriptor checks -------------------------------------------------------------------
+    if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
+    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_CTCRW) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (d->n_dim < 1 || d->n_dim > 2)
+        return fail(h, SSDE_ERR_MODEL, "n_dim must be 1 or 2 (wider responses are outside this engine's kernels)");
+    if (d->n_par != n_sde_par(d->model, d->n_dim)) return fail(h, SSDE_ERR_ARG, "n_par does not match model / n_dim");
+    if (d->n < 2) return fail(h, SSDE_ERR_ARG, "need at least two rows");
+    if (!d->id || !d->times || !d->obs || !d->ncol_fe) return fail(h, SSDE_ERR_ARG, "id/times/obs/ncol_fe must be non-NULL");
+    h->model = d->model; h->d = d->n_dim; h->q = d->n_par; h->n = d->n;
+    h->sdim = state_dim(d->model, d->n_dim);
+    h->na_any = d->na_mode == SSDE_NA_ANY_NAN;
+    h->has_h = is_kalman(d->model) && d->h_array != nullptr;
+    for (int j = 0; j < d->n_par; j++) {
+        if (d->ncol_fe[j] < 1) return fail(h, SSDE_ERR_ARG, "every SDE parameter needs at least one fixed-effect column");
+        if (!(d->x_fe && d->x_fe[j]) && d->ncol_fe[j] != 1)
+            return fail(h, SSDE_ERR_ARG, "x_fe[j] == NULL means intercept-only: ncol_fe[j] must be 1");
+        if (d->ncol_re && d->ncol_re[j] > 0 && !(d->x_re && d->x_re[j]))
+            return fail(h, SSDE_ERR_ARG, "x_re[j] missing for a parameter with random-effect columns");
+    }
+    h->L = make_layout(d);
+    if (h->L.n_full > MAX_PAR) return fail(h, SSDE_ERR_ARG, "too many parameters for the kernel argument block");
+    int nsm = 0;
+    for (int s = 0; s < d->n_smooth; s++) nsm += d->smooth_ncol[s];
+    if (nsm != h->L.n_re) return fail(h, SSDE_ERR_ARG, "smooth_ncol does not add up to the random-effect columns");
+    h->pen.setup(d);
+    h->slots = make_slots(d, h->L, &h->n_stream_cols);
+    if ((int)h->slots.size() > MAX_COLS || h->n_stream_cols > MAX_COLS)
+        return fail(h, SSDE_ERR_ARG, "too many design columns (limit 96)");
+    h->const_coeff = h->n_stream_cols == 0;
+    h->fixed.assign(h->L.n_full, 0);
+    if (d->par_fixed) h->fixed.assign(d->par_fixed, d->par_fixed + h->L.n_full);
+    if (h->has_h) h->fixed[0] = 1;  // log_sigma_obs is mapped when H is supplied (R/sde.R:565, 595)
+    // log_lambda never enters the data term
+    h->n_free = 0;
+    for (int k = 0; k < h->L.n_full; k++) h->n_free += h->fixed[k] ? 0 : 1;
+
+    // ---- device ------------------------------------------------------------------------------
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(h, SSDE_ERR_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (d->device >= 0) HIPCHK(h, hipSetDevice(d->device));
+    HIPCHK(h, hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, SSDE_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
+    const bool on_dev = (d->flags & SSDE_FLAG_DEVICE_DATA) != 0;
+    const int64_t n = d->n;
+
+    // ---- ID segments (nllk_ctcrw.hpp:196; R/sde.R:547,574) ---------------------------------------
+    std::vector<int64_t> starts;
+    {
+        std::vector<uint8_t> flags;
+        if (on_dev) {
+            DevBuf<uint8_t> f;
+            HIPCHK(h, f.alloc(n));
+            HIPCHK(h, launch_first_flags(d->id, n, f.p, 0));
+            flags.resize(n);
+            HIPCHK(h, hipMemcpy(flags.data(), f.p, n, hipMemcpyDeviceToHost));
+            f.release();
+            for (int64_t i = 0; i < n; i++)
+                if (flags[i]) starts.push_back(i);
+        } else {
+            for (int64_t i = 0; i < n; i++)
+                if (i == 0 || d->id[i] != d->id[i - 1]) starts.push_back(i);
+        }
+    }
+    h->n_seg = (int64_t)starts.size();
+    if (d->a0 && d->n_seg != h->n_seg) return fail(h, SSDE_ERR_ARG, "a0 rows do not match the number of ID segments");
+    h->n_steps = n - h->n_seg;
+    starts.push_back(n);
+
+    HIPCHK(h, h->out.alloc(1 + h->L.n_full));
+
+    // ---- direct families --------------------------------------------------------------------------
+    if (!is_kalman(d->model)) {
+        h->path = PATH_DIRECT;
+        HIPCHK(h, stage(d->times, (size_t)n, on_dev, h->times));
+        HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, on_dev, h->obs));
+        HIPCHK(h, h->colbuf.alloc((size_t)n * h->n_stream_cols));
+        std::vector<const double*> cp(h->n_stream_cols, nullptr);
+        for (auto& s : h->slots)
+            if (s.col >= 0) {
+                double* dst = h->colbuf.p + (size_t)s.col * n;
+                HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+                cp[s.col] = dst;
+            }
+        HIPCHK(h, h->colptr.upload(cp));
+        {
+            DevBuf<double> idb;
+            const double* idp = d->id;
+            if (!on_dev) { HIPCHK(h, stage(d->id, (size_t)n, false, idb)); idp = idb.p; }
+            HIPCHK(h, h->scored.alloc((size_t)((n + 31) / 32)));
+            HIPCHK(h, launch_scored_mask(idp, n, h->scored.p, 0));
+            HIPCHK(h, hipDeviceSynchronize());
+            idb.release();
+        }
+        h->direct_blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+        h->partial_doubles = (size_t)(1 + h->slots.size()) * h->direct_blocks;
+        h->hbm_bytes = (int64_t)(h->times.n + h->obs.n + h->colbuf.n) * 8 + (int64_t)h->scored.n * 4;
+    } else {
+        // ---- Kalman families: pick the path, then tile ------------------------------------------------
+        for (int i = 0; i < h->sdim; i++)
+            for (int j = 0; j < h->sdim; j++) h->p0_full[i + j * h->sdim] = p0_entry(d, i, j);
+        const bool iso_ok = !h->has_h && h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
+                            !(d->flags & SSDE_FLAG_FORCE_DENSE);
+        h->path = iso_ok ? PATH_ISO : PATH_DENSE;
+
+        // tracks -> lanes: longest first (stable), 64 per wavefront
+        const int64_t M = h->n_seg;
+        std::vector<int64_t> order(M);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            return (starts[a + 1] - starts[a]) > (starts[b + 1] - starts[b]);
+        });
+        h->n_groups = (int)((M + WAVE - 1) / WAVE);
+        const int G = h->n_groups;
+        h->C = 1 + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + h->n_stream_cols;
+        std::vector<int64_t> lane_row0((size_t)G * WAVE, -1), lane_seg((size_t)G * WAVE, 0), goff(G);
+        std::vector<int32_t> lane_ns((size_t)G * WAVE, 0), glen(G);
+        int64_t off = 0;
+        for (int g = 0; g < G; g++) {
+            int32_t mx = 0;
+            for (int l = 0; l < WAVE; l++) {
+                int64_t t = (int64_t)g * WAVE + l;
+                if (t >= M) break;
+                int64_t seg = order[t];
+                int64_t len = starts[seg + 1] - starts[seg];
+                if (len - 1 > INT32_MAX) return fail(h, SSDE_ERR_ARG, "track too long");
+                lane_row0[t] = starts[seg];
+                lane_seg[t] = seg;
+                lane_ns[t] = (int32_t)(len - 1);
+                mx = std::max(mx, lane_ns[t]);
+            }
+            glen[g] = (mx + TILE_U - 1) / TILE_U * TILE_U;
+            goff[g] = off;
+            off += (int64_t)glen[g] * h->C * WAVE;
+        }
+        h->tile_doubles = off + (int64_t)TILE_U * h->C * WAVE;  // spare prefetch block
+        HIPCHK(h, h->tiles.alloc((size_t)h->tile_doubles));
+        HIPCHK(h, hipMemset(h->tiles.p, 0, (size_t)h->tile_doubles * 8));
+        HIPCHK(h, h->a0.alloc((size_t)G * h->sdim * WAVE));
+        HIPCHK(h, h->group_off.upload(goff));
+        HIPCHK(h, h->group_len.upload(glen));
+        HIPCHK(h, h->lane_row0.upload(lane_row0));
+        HIPCHK(h, h->lane_nsteps.upload(lane_ns));
+
+        // stage the caller's arrays (host data) -- freed again after tiling
+        DevBuf<double> s_times, s_obs, s_h, s_a0, s_cols;
+        DevBuf<const double*> s_colptr;
+        DevBuf<int64_t> s_lane_seg;
+        const double *p_times = d->times, *p_obs = d->obs, *p_h = d->h_array;
+        if (!on_dev) {
+            HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p;
+            HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p;
+            if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
+        }
+        std::vector<const double*> cp(h->n_stream_cols, nullptr);
+        if (h->n_stream_cols > 0) {
+            if (!on_dev) HIPCHK(h, s_cols.alloc((size_t)n * h->n_stream_cols));
+            for (auto& s : h->slots)
+                if (s.col >= 0) {
+                    if (on_dev) cp[s.col] = s.src;
+                    else {
+                        double* dst = s_cols.p + (size_t)s.col * n;
+                        HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, hipMemcpyHostToDevice));
+                        cp[s.col] = dst;
+                    }
+                }
+            HIPCHK(h, s_colptr.upload(cp));
+        }
+        const double* p_a0 = nullptr;
+        if (d->a0) {
+            // a0 is tiny (n_seg x sdim): always treated as a host array
+            HIPCHK(h, stage(d->a0, (size_t)h->n_seg * h->sdim, false, s_a0));
+            p_a0 = s_a0.p;
+            HIPCHK(h, s_lane_seg.upload(lane_seg));
+        }
+        const int ych = ingest_ychunks(G);
+        DevBuf<double> mm;
+        HIPCHK(h, mm.alloc((size_t)G * ych * 2));
+        IngestArgs ia;
+        ia.times = p_times; ia.obs = p_obs; ia.h_array = h->has_h ? p_h : nullptr;
+        ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = n;
+        ia.lane_row0 = h->lane_row0.p; ia.lane_nsteps = h->lane_nsteps.p;
+        ia.group_off = h->group_off.p; ia.group_len = h->group_len.p;
+        ia.n_groups = G; ia.C = h->C; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
+        ia.a0_src = p_a0; ia.lane_seg = s_lane_seg.p; ia.n_seg = h->n_seg;
+        ia.sdim = h->sdim; ia.model = d->model; ia.dt_minmax = mm.p; ia.ychunks = ych;
+        HIPCHK(h, launch_ingest(ia, 0));
+        std::vector<double> mmh((size_t)G * ych * 2);
+        HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));  // also syncs
+        double dmin = INFINITY, dmax = -INFINITY;
+        for (size_t k = 0; k < mmh.size(); k += 2) { dmin = std::min(dmin, mmh[k]); dmax = std::max(dmax, mmh[k + 1]); }
+        h->uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
+        h->dt_uniform = h->uniform_dt ? dmin : 0.0;
+        mm.release(); s_times.release(); s_obs.release(); s_h.release(); s_a0.release(); s_cols.release();
+        s_colptr.release(); s_lane_seg.release();
+        h->hbm_bytes = h->tile_doubles * 8;
+
+        if (h->path == PATH_ISO) {
+            choose_iso_split(h);
+            h->partial_doubles = (size_t)MAX_PARTS * NACC_MAX * G;
+        } else {
+            // gradient directions of the dense kernel: free parameters that reach the data term
+            std::vector<DenseDir> dirs;
+            if (!h->fixed[0]) dirs.push_back({1, 0, 0, 0});
+            for (size_t k = 0; k < h->slots.size(); k++)
+                if (!h->fixed[h->slots[k].pidx]) dirs.push_back({2, (int16_t)k, (int16_t)h->slots[k].pidx, 0});
+            while (dirs.size() % DENSE_NT) dirs.push_back({0, 0, -1, 0});
+            if (dirs.empty()) dirs.resize(DENSE_NT, DenseDir{0, 0, -1, 0});
+            h->dirs_host = dirs;
+            h->n_dirblocks = (int)dirs.size() / DENSE_NT;
+            HIPCHK(h, h->dirs.upload(dirs));
+            h->partial_doubles = (size_t)h->n_dirblocks * (1 + DENSE_NT) * G;
+        }
+    }
+
+    if (h->path != PATH_ISO) {
+        SlotTable st;
+        memset(&st, 0, sizeof(st));
+        st.n_slots = (int)h->slots.size();
+        st.q = h->q;
+        for (size_t k = 0; k < h->slots.size(); k++) {
+            st.par_j[k] = (int16_t)h->slots[k].par_j;
+            st.col[k] = (int16_t)h->slots[k].col;
+            st.pidx[k] = (int16_t)h->slots[k].pidx;
+            st.is_free[k] = h->fixed[h->slots[k].pidx] ? 0 : 1;
+        }
+        HIPCHK(h, h->slot_table.upload(std::vector<SlotTable>(1, st)));
+        HIPCHK(h, h->par_ring.alloc((size_t)PAR_RING * MAX_PAR));
+        HIPCHK(h, hipHostMalloc((void**)&h->par_pinned, (size_t)PAR_RING * MAX_PAR * 8, hipHostMallocDefault));
+        for (int i = 0; i < PAR_RING; i++) HIPCHK(h, hipEventCreateWithFlags(&h->par_ev[i], hipEventDisableTiming));
+        h->par_ev_ok = true;
+    }
+    HIPCHK(h, h->partials.alloc(h->partial_doubles));
+    h->hbm_bytes += (int64_t)h->partial_doubles * 8;
+    return SSDE_OK;
+}
+
+// upload the parameter vector for the dense / direct kernels; returns the device pointer
+int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev) {
+    const int slot = h->par_next;
+    h->par_next = (h->par_next + 1) % PAR_RING;
+    HIPCHK(h, hipEventSynchronize(h->par_ev[slot]));  // the slot's previous copy has left the host buffer
+    double* host = h->par_pinned + (size_t)slot * MAX_PAR;
+    double* devp = h->par_ring.p + (size_t)slot * MAX_PAR;
+    memcpy(host, par, (size_t)h->L.n_full * 8);
+    HIPCHK(h, hipMemcpyAsync(devp, host, (size_t)h->L.n_full * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipEventRecord(h->par_ev[slot], s));
+    *dev = devp;
+    return SSDE_OK;
+}
+
+int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const ParLayout& L = h->L;
+    ReduceArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.partials = h->partials.p;
+    ra.n_out = 1 + L.n_full;
+    ra.out = out_dev;
+    for (int k = 0; k < MAX_PAR + 16; k++) ra.map[k] = -1;
+
+    if (h->path == PATH_ISO) {
+        IsoArgs a;
+        memset(&a, 0, sizeof(a));
+        a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
+        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+        a.partials = h->partials.p;
+        if (order >= 1) {
+            a.n_parts = h->iso_parts;
+            for (int p = 0; p < MAX_PARTS; p++) a.part_mask[p] = h->iso_masks[p];
+        } else {
+            a.n_parts = 1;
+        }
+        a.any_nan = h->na_any;
+        a.uniform_dt = h->uniform_dt ? 1 : 0;
+        const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
+        a.h = sig * sig;                                    // makeH: sigma_obs * sigma_obs
+        for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + i];
+        for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+        const double p1 = par[L.off_fe + h->d];
+        const double p2 = (h->q > h->d + 1) ? par[L.off_fe + h->d + 1] : 0.0;
+        if (h->model == SSDE_MODEL_CTCRW) {
+            a.tau = exp(p1);                                // :153
+            const double nu = exp(p2);                      // :154
+            a.beta = 1.0 / a.tau;                           // :155
+            a.sigma = 2.0 * nu / sqrt(M_PI * a.tau);        // :156
+            if (h->uniform_dt) ctcrw_trans(h->dt_uniform, a.tau, a.beta, a.sigma, a.ctr);
+        } else if (h->model == SSDE_MODEL_OU_SSM) {
+            a.tau = exp(p1);
+            a.sigma = exp(p2);                              // kappa
+            if (h->uniform_dt) ou_trans(h->dt_uniform, a.tau, a.sigma, a.str);
+        } else {
+            a.sigma = exp(p1);
+            if (h->uniform_dt) bm_trans(h->dt_uniform, a.sigma, a.str);
+        }
+        HIPCHK(h, launch_iso(h->model, h->d, a, s));
+        const int nacc = 4 + h->d;
+        ra.n_parts = a.n_parts; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+        if (order >= 1) {
+            for (int p = 0; p < a.n_parts; p++)
+                for (int k = 1; k < nacc; k++) {
+                    const int pidx = k - 1;  // accumulators are ordered like the parameter vector
+                    if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
+                }
+        }
+    } else if (h->path == PATH_DENSE) {
+        const double* pdev = nullptr;
+        int st = push_par(h, par, s, &pdev);
+        if (st) return st;
+        DenseArgs a;
+        memset(&a, 0, sizeof(a));
+        a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
+        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+        a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
+        a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
+        for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
+        a.n_dirblocks = h->n_dirblocks; a.dirs = h->dirs.p; a.partials = h->partials.p;
+        a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n;
+        HIPCHK(h, launch_dense(a, order >= 1, s));
+        if (order >= 1) {
+            ra.n_parts = h->n_dirblocks; ra.nacc = 1 + DENSE_NT;
+            for (size_t k = 0; k < h->dirs_host.size(); k++)
+                if (h->dirs_host[k].kind != 0) ra.map[k] = (int16_t)(1 + h->dirs_host[k].pidx);
+        } else {
+            ra.n_parts = 1; ra.nacc = 1;
+        }
+        ra.n_blocks = h->n_groups;
+    } else {
+        const double* pdev = nullptr;
+        int st = push_par(h, par, s, &pdev);
+        if (st) return st;
+        DirectArgs a;
+        memset(&a, 0, sizeof(a));
+        a.times = h->times.p; a.obs = h->obs.p; a.cols = h->colptr.p; a.scored = h->scored.p;
+        a.n = h->n; a.d = h->d; a.model = h->model; a.any_nan = h->na_any;
+        a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
+        a.n_blocks = h->direct_blocks; a.partials = h->partials.p;
+        if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
+        HIPCHK(h, launch_direct(a, s));
+        ra.n_parts = 1; ra.nacc = 1 + a.n_slots; ra.n_blocks = h->direct_blocks;
+        if (order >= 1)
+            for (int k = 0; k < a.n_slots; k++)
+                if (!h->fixed[h->slots[k].pidx]) ra.map[k] = (int16_t)(1 + h->slots[k].pidx);
+    }
+    HIPCHK(h, launch_reduce(ra, s));
+    return SSDE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssde_abi_version(void) { return SSDE_ABI_VERSION; }
+
+int ssde_create(const ssde_desc* desc, ssde_handle** out) {
+    if (!desc || !out) { g_create_error = "NULL argument"; return SSDE_ERR_ARG; }
+    *out = nullptr;
+    ssde_handle* h = new (std::nothrow) ssde_handle();
+    if (!h) { g_create_error = "out of host memory"; return SSDE_ERR_ALLOC; }
+    int st = build(desc, h);
+    if (st != SSDE_OK) {
+        g_create_error = h->err;
+        destroy(h);
+        return st;
+    }
+    *out = h;
+    return SSDE_OK;
+}
+
+void ssde_destroy(ssde_handle* h) { destroy(h); }
+
+const char* ssde_last_error(const ssde_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* out_dev,
+                     void* stream) {
+    if (!h || !par || !out_dev) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    return eval_device(h, par, order, out_dev, (hipStream_t)stream);
+}
+
+int ssde_penalty(ssde_handle* h, const double* par, int32_t n_par_full, double* value, double* grad) {
+    if (!h || !par || !value) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    std::vector<double> g(h->L.n_full, 0.0);
+    *value = h->pen.eval(h->L, par, grad ? g.data() : nullptr);
+    if (grad)
+        for (int k = 0; k < h->L.n_full; k++)
+            if (!h->fixed[k]) grad[k] += g[k];
+    return SSDE_OK;
+}
+
+int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* value, double* grad) {
+    if (!h || !par || !value) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    int st = eval_device(h, par, order, h->out.p, 0);
+    if (st) return st;
+    std::vector<double> o(1 + h->L.n_full);
+    HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
+    double pen = 0.0;
+    if (order >= 1 && grad) {
+        for (int k = 0; k < h->L.n_full; k++) grad[k] = o[1 + k];
+        st = ssde_penalty(h, par, n_par_full, &pen, grad);
+    } else {
+        st = ssde_penalty(h, par, n_par_full, &pen, nullptr);
+    }
+    *value = o[0] + pen;
+    return st;
+}
+
+int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* aest_all) {
+    if (!h || !par || !aest_all) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    if (!is_kalman(h->model)) { h->err = "aest_all is reported by the Kalman families only"; return SSDE_ERR_MODEL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    // ssde_report always runs the general kernel (value only) and un-tiles on the fly
+    DevBuf<double> rep, pbuf;
+    DevBuf<SlotTable> stb;
+    HIPCHK(h, rep.alloc((size_t)h->n * h->sdim));
+    HIPCHK(h, hipMemset(rep.p, 0, (size_t)h->n * h->sdim * 8));
+    HIPCHK(h, pbuf.upload(std::vector<double>(par, par + h->L.n_full)));
+    SlotTable st;
+    memset(&st, 0, sizeof(st));
+    st.n_slots = (int)h->slots.size(); st.q = h->q;
+    for (size_t k = 0; k < h->slots.size(); k++) {
+        st.par_j[k] = (int16_t)h->slots[k].par_j; st.col[k] = (int16_t)h->slots[k].col;
+        st.pidx[k] = (int16_t)h->slots[k].pidx; st.is_free[k] = 0;
+    }
+    HIPCHK(h, stb.upload(std::vector<SlotTable>(1, st)));
+    DenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
+    a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+    a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
+    a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
+    for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
+    a.n_dirblocks = 1; a.dirs = nullptr; a.partials = nullptr;
+    a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = h->n;
+    HIPCHK(h, launch_dense(a, false, 0));
+    HIPCHK(h, hipMemcpy(aest_all, rep.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
+    rep.release(); pbuf.release(); stb.release();
+    return SSDE_OK;
+}
+
+int ssde_info(const ssde_handle* h, ssde_info_t* info) {
+    if (!h || !info) return SSDE_ERR_ARG;
+    memset(info, 0, sizeof(*info));
+    info->n_par_full = h->L.n_full;
+    info->n_free = h->n_free;
+    info->sdim = h->sdim;
+    info->path = h->path;
+    info->const_coeff = h->const_coeff;
+    info->uniform_dt = h->uniform_dt;
+    info->n_tracks = h->n_seg;
+    info->n_rows = h->n;
+    info->n_steps = h->n_steps;
+    info->hbm_bytes = h->hbm_bytes;
+    info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols);
+    if (h->path == PATH_ISO) info->n_kernel_blocks = (h->n_groups + 7) / 8 * 8 * h->iso_parts;
+    else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;
+    else info->n_kernel_blocks = h->direct_blocks;
+    info->lanes_per_track = h->path == PATH_ISO ? h->iso_parts : (h->path == PATH_DENSE ? h->n_dirblocks : 1);
+    return SSDE_OK;
+}
+
+}  // extern "C"

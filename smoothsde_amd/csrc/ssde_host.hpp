@@ -1,0 +1,188 @@
+// ssde_host.hpp -- host-side bookkeeping shared by the engine and the test harness: parameter
+// vector layout (include/ssde.h), coefficient slot table, a0/P0 defaults, path selection,
+// smoothing penalty.  Plain C++17, no HIP.
+#ifndef SSDE_HOST_HPP
+#define SSDE_HOST_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ssde.h"
+
+namespace ssde_host {
+
+constexpr int kMaxCols = 96;   // == ssde::MAX_COLS
+constexpr int kMaxPar = 320;   // == ssde::MAX_PAR
+
+inline bool is_kalman(int model) {
+    return model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_OU_SSM || model == SSDE_MODEL_CTCRW;
+}
+inline int state_dim(int model, int d) {
+    return model == SSDE_MODEL_CTCRW ? 2 * d : (is_kalman(model) ? d : 0);
+}
+inline int n_sde_par(int model, int d) {
+    return (model == SSDE_MODEL_BM || model == SSDE_MODEL_BM_SSM) ? d + 1 : d + 2;
+}
+
+// full parameter vector layout (include/ssde.h, PARAMETER VECTOR)
+struct ParLayout {
+    int q = 0, n_fe = 0, n_re = 0, n_lambda = 0;
+    int off_sig = -1, off_fe = 0, off_lambda = 0, off_re = 0, n_full = 0;
+    std::vector<int> fe_off, re_off, ncol_fe, ncol_re;
+};
+
+inline ParLayout make_layout(const ssde_desc* d) {
+    ParLayout L;
+    L.q = d->n_par;
+    for (int j = 0; j < L.q; j++) {
+        L.fe_off.push_back(L.n_fe);
+        L.ncol_fe.push_back(d->ncol_fe[j]);
+        L.n_fe += d->ncol_fe[j];
+        int nr = d->ncol_re ? d->ncol_re[j] : 0;
+        L.re_off.push_back(L.n_re);
+        L.ncol_re.push_back(nr);
+        L.n_re += nr;
+    }
+    L.n_lambda = d->n_smooth;
+    int o = 0;
+    if (is_kalman(d->model)) { L.off_sig = 0; o = 1; }   // PARAMETER(log_sigma_obs) first (nllk_ctcrw.hpp:135)
+    L.off_fe = o; o += L.n_fe;
+    L.off_lambda = o; o += L.n_lambda;
+    L.off_re = o; o += L.n_re;
+    L.n_full = o;
+    return L;
+}
+
+// One coefficient of the linear predictor par_vec = X_fe coeff_fe + X_re coeff_re (nllk_ctcrw.hpp:143)
+struct Slot {
+    int par_j;            // SDE parameter
+    int col;              // index into the list of streamed columns, -1 = intercept (column of ones)
+    int pidx;             // index in the full parameter vector
+    const double* src;    // caller's column (length n) or NULL
+};
+
+inline std::vector<Slot> make_slots(const ssde_desc* d, const ParLayout& L, int* n_stream_cols) {
+    std::vector<Slot> s;
+    int ncol = 0;
+    for (int j = 0; j < L.q; j++) {
+        for (int c = 0; c < L.ncol_fe[j]; c++) {
+            Slot t;
+            t.par_j = j;
+            t.pidx = L.off_fe + L.fe_off[j] + c;
+            if (d->x_fe && d->x_fe[j]) { t.src = d->x_fe[j] + (int64_t)c * d->n; t.col = ncol++; }
+            else { t.src = nullptr; t.col = -1; }
+            s.push_back(t);
+        }
+        for (int c = 0; c < L.ncol_re[j]; c++) {
+            Slot t;
+            t.par_j = j;
+            t.pidx = L.off_re + L.re_off[j] + c;
+            t.src = d->x_re[j] + (int64_t)c * d->n;
+            t.col = ncol++;
+            s.push_back(t);
+        }
+    }
+    *n_stream_cols = ncol;
+    return s;
+}
+
+inline double p0_entry(const ssde_desc* d, int i, int j) {
+    const int sdim = state_dim(d->model, d->n_dim);
+    if (d->p0) return d->p0[i + j * sdim];
+    if (i != j) return 0.0;
+    if (d->model == SSDE_MODEL_CTCRW) return (i % 2 == 0) ? 1.0 : 10.0;   // R/sde.R:584
+    return 10.0;                                                           // R/sde.R:554
+}
+
+// Is P0 block-identical across dimensions and decoupled (so that the isotropic register path
+// applies)?  CTCRW: blockdiag of one symmetric 2x2 block; OU/BM: p * I.
+inline bool p0_is_isotropic(const ssde_desc* d, double iso[3]) {
+    const int dd = d->n_dim, sdim = state_dim(d->model, dd);
+    if (d->model == SSDE_MODEL_CTCRW) {
+        iso[0] = p0_entry(d, 0, 0); iso[1] = p0_entry(d, 0, 1); iso[2] = p0_entry(d, 1, 1);
+        if (p0_entry(d, 1, 0) != iso[1]) return false;
+        for (int i = 0; i < sdim; i++)
+            for (int j = 0; j < sdim; j++) {
+                double want = 0.0;
+                if (i / 2 == j / 2) want = (i % 2 == 0 && j % 2 == 0) ? iso[0] : (i % 2 == 1 && j % 2 == 1) ? iso[2] : iso[1];
+                if (p0_entry(d, i, j) != want) return false;
+            }
+        return true;
+    }
+    iso[0] = p0_entry(d, 0, 0); iso[1] = iso[2] = 0.0;
+    for (int i = 0; i < sdim; i++)
+        for (int j = 0; j < sdim; j++)
+            if (p0_entry(d, i, j) != (i == j ? iso[0] : 0.0)) return false;
+    return true;
+}
+
+// log|det| of a small dense matrix by partial-pivot LU (atomic::matinvpd's log-determinant,
+// nllk_sde.hpp:110)
+inline double logabsdet(std::vector<double> A, int n) {
+    double ld = 0.0;
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++)
+            if (std::fabs(A[i + k * n]) > std::fabs(A[piv + k * n])) piv = i;
+        if (piv != k)
+            for (int j = 0; j < n; j++) std::swap(A[k + j * n], A[piv + j * n]);
+        ld += std::log(std::fabs(A[k + k * n]));
+        for (int i = k + 1; i < n; i++) {
+            double f = A[i + k * n] / A[k + k * n];
+            for (int j = k + 1; j < n; j++) A[i + j * n] -= f * A[k + j * n];
+        }
+    }
+    return ld;
+}
+
+// Smoothing penalty and its gradient: nllk_ctcrw.hpp:254-280 (Kalman families: no constants,
+// include_penalty ignored) and nllk_sde.hpp:89-124 (direct families: + Sn/2 log(2 pi)
+// + log det(S^-1)/2, gated by include_penalty).  Parameter-only, O(sum Sn^2): host arithmetic.
+struct Penalty {
+    int model = 0, include_penalty = 1;
+    std::vector<int> ncol;
+    std::vector<std::vector<double>> S;   // column-major blocks
+    std::vector<double> logdet;           // log|det S_s|
+
+    void setup(const ssde_desc* d) {
+        model = d->model;
+        include_penalty = d->include_penalty;
+        const double* p = d->s_blocks;
+        for (int s = 0; s < d->n_smooth; s++) {
+            int n = d->smooth_ncol[s];
+            ncol.push_back(n);
+            S.emplace_back(p, p + (size_t)n * n);
+            logdet.push_back(is_kalman(model) ? 0.0 : logabsdet(S.back(), n));
+            p += (size_t)n * n;
+        }
+    }
+    double eval(const ParLayout& L, const double* par, double* grad /* may be NULL; added into */) const {
+        if (ncol.empty()) return 0.0;                                   // ncol_re(0) > 0
+        if (!is_kalman(model) && !include_penalty) return 0.0;          // nllk_sde.hpp:91
+        double pen = 0.0;
+        int start = 0;
+        for (size_t s = 0; s < ncol.size(); s++) {
+            const int n = ncol[s];
+            const double* b = par + L.off_re + start;
+            const double ll = par[L.off_lambda + s];
+            const double lam = std::exp(ll);
+            double quad = 0.0;
+            for (int a = 0; a < n; a++) {
+                double Sx = 0.0, Stx = 0.0;
+                for (int c = 0; c < n; c++) { Sx += S[s][a + c * n] * b[c]; Stx += S[s][c + a * n] * b[c]; }
+                quad += b[a] * Sx;
+                if (grad) grad[L.off_re + start + a] += 0.5 * lam * (Sx + Stx);
+            }
+            pen += -0.5 * n * ll + 0.5 * lam * quad;
+            if (!is_kalman(model)) pen += 0.5 * n * std::log(2.0 * M_PI) - 0.5 * logdet[s];
+            if (grad) grad[L.off_lambda + s] += -0.5 * n + 0.5 * lam * quad;
+            start += n;
+        }
+        return pen;
+    }
+};
+
+}  // namespace ssde_host
+#endif

@@ -1,0 +1,123 @@
+// tests/hostsim/hostsim.cpp -- TEST-ONLY host build of the kernel arithmetic.
+//
+// Compiles smoothsde_amd/csrc/ssde_math.hpp (the per-lane step functions the HIP kernels
+// inline) with g++ and walks tracks sequentially the way one wavefront lane does, so the
+// CPU suite (-m "not gpu") can check the hand-derived forward sensitivities against the
+// oracle without a GPU.  This is NOT a product path: it is built only by the tests, lives
+// outside the package, and libssde_hip.so contains no CPU evaluation code.
+#include <cstdint>
+#include <cstdio>
+#include <cmath>
+
+#include "../../smoothsde_amd/csrc/ssde_math.hpp"
+
+using namespace ssde;
+
+namespace {
+
+struct IsoArgs {
+    int model, d, mask, any_nan;
+    int64_t n, n_tracks;
+    const int64_t* row0;   // first row of each track
+    const int64_t* nrows;  // rows of each track
+    const double* times;
+    const double* obs;     // n x d column-major
+    double log_sigma_obs, mu[2], p1, p2;  // working-scale parameters
+    double p0[3];          // CTCRW: p11,p12,p22 ; OU/BM: p
+};
+
+template <int D, int MASK>
+void run_ctcrw(const IsoArgs& A, double* out) {
+    const double h = exp(A.log_sigma_obs) * exp(A.log_sigma_obs);
+    const double tau = exp(A.p1), nu = exp(A.p2), beta = 1.0 / tau;
+    const double sigma = 2.0 * nu / sqrt(M_PI * tau);
+    for (int k = 0; k < 4 + D; k++) out[k] = 0.0;
+    for (int64_t m = 0; m < A.n_tracks; m++) {
+        CtcrwLane<D, MASK> L;
+        double a0[2 * D];
+        for (int a = 0; a < D; a++) { a0[2 * a] = A.obs[A.row0[m] + a * A.n]; a0[2 * a + 1] = 0.0; }
+        L.init(a0, A.p0[0], A.p0[1], A.p0[2]);
+        for (int64_t s = 1; s < A.nrows[m]; s++) {
+            int64_t i = A.row0[m] + s;
+            double dt = (s < A.nrows[m] - 1) ? A.times[i + 1] - A.times[i] : 1.0;
+            CtcrwTrans tr;
+            ctcrw_trans(dt, tau, beta, sigma, tr);
+            double y[D];
+            for (int a = 0; a < D; a++) y[a] = A.obs[i + a * A.n];
+            ctcrw_step<D, MASK>(L, tr, h, A.mu, y, is_na(y[0], A.any_nan));
+        }
+        double o[4 + D];
+        ctcrw_finish<D, MASK>(L, o);
+        for (int k = 0; k < 4 + D; k++) out[k] += o[k];
+    }
+}
+
+template <int D, int MASK, int MODEL>
+void run_scal(const IsoArgs& A, double* out) {
+    const double h = exp(A.log_sigma_obs) * exp(A.log_sigma_obs);
+    for (int k = 0; k < 4 + D; k++) out[k] = 0.0;
+    for (int64_t m = 0; m < A.n_tracks; m++) {
+        ScalLane<D, MASK> L;
+        double a0x[D];
+        for (int a = 0; a < D; a++) a0x[a] = A.obs[A.row0[m] + a * A.n];
+        L.init(a0x, A.p0[0]);
+        for (int64_t s = 1; s < A.nrows[m]; s++) {
+            int64_t i = A.row0[m] + s;
+            double dt = (s < A.nrows[m] - 1) ? A.times[i + 1] - A.times[i] : 1.0;
+            ScalTrans tr;
+            if (MODEL == M_OU_SSM) ou_trans(dt, exp(A.p1), exp(A.p2), tr);
+            else bm_trans(dt, exp(A.p1), tr);
+            double y[D];
+            for (int a = 0; a < D; a++) y[a] = A.obs[i + a * A.n];
+            scal_step<D, MASK, MODEL == M_OU_SSM>(L, tr, h, A.mu, y, is_na(y[0], A.any_nan));
+        }
+        double o[4 + D];
+        scal_finish<D, MASK>(L, o);
+        for (int k = 0; k < 4 + D; k++) out[k] += o[k];
+    }
+}
+
+template <int D, int MASK>
+void run_model(const IsoArgs& A, double* out) {
+    if (A.model == M_CTCRW) run_ctcrw<D, MASK>(A, out);
+    else if (A.model == M_OU_SSM) run_scal<D, MASK, M_OU_SSM>(A, out);
+    else run_scal<D, MASK, M_BM_SSM>(A, out);
+}
+
+template <int D>
+void run_mask(const IsoArgs& A, double* out) {
+    switch (A.mask) {
+#define C(M) case M: run_model<D, M>(A, out); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15)
+#undef C
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// out = [nllk, g_sig, g_mu_0.., g_p1, g_p2]  (1 + 3 + d doubles)
+int hostsim_kalman_iso(int model, int d, int mask, int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0,
+                       const int64_t* nrows, const double* times, const double* obs, const double* theta /* ls, mu[d], p1, p2 */,
+                       const double* p0, double* out) {
+    IsoArgs A;
+    A.model = model; A.d = d; A.mask = mask; A.any_nan = any_nan; A.n = n; A.n_tracks = n_tracks;
+    A.row0 = row0; A.nrows = nrows; A.times = times; A.obs = obs;
+    A.log_sigma_obs = theta[0];
+    A.mu[0] = theta[1]; A.mu[1] = d > 1 ? theta[2] : 0.0;
+    A.p1 = theta[1 + d]; A.p2 = theta[2 + d];
+    A.p0[0] = p0[0]; A.p0[1] = p0[1]; A.p0[2] = p0[2];
+    if (d == 1) run_mask<1>(A, out);
+    else if (d == 2) run_mask<2>(A, out);
+    else return 1;
+    return 0;
+}
+
+// direct families, one transition: returns nll and adds gradient wrt (mu, p1, p2)
+double hostsim_direct(int model, double z0, double z1, double dt, double mu, double p1, double p2, double* g) {
+    if (model == M_BM) return bm_direct(z0, z1, dt, mu, p1, g[0], g[1]);
+    return ou_direct(z0, z1, dt, mu, p1, p2, g[0], g[1], g[2]);
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""GPU suite (-m gpu): the HIP engine, called through the C ABI, against the committed golden
+vectors, against the oracle on seeded inputs, and through size-independent properties.
+
+Tolerances (fp64): value |d| <= 1e-10 * max(1,|v|) against oracle/golden (north-star bar vs the
+reference: 1e-8); gradient |d| <= 1e-8 * max|g| + 1e-10."""
+import numpy as np
+import pytest
+
+from cases import problem_from_spec
+from golden_io import load_golden
+from smoothsde_amd import capi
+from smoothsde_amd.synth import simulate
+
+pytestmark = pytest.mark.gpu
+
+GOLD = load_golden()
+VT = 1e-10
+
+
+def _close(val, grad, eval_, egrad):
+    assert abs(val - eval_) <= VT * max(1.0, abs(eval_)), (val, eval_)
+    assert np.max(np.abs(grad - egrad)) <= 1e-8 * np.max(np.abs(egrad)) + 1e-10, (grad, egrad)
+
+
+@pytest.mark.parametrize("rec", GOLD, ids=[r["name"] for r in GOLD])
+def test_golden(rec):
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    v0 = eng.eval(rec["par"], order=0)
+    assert v0 == val
+    eng.close()
+
+
+KALMAN_CONST = [r for r in GOLD if r["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and r.get("X_fe") is None
+                and r.get("H") is None and r.get("P0") is None]
+
+
+@pytest.mark.parametrize("rec", KALMAN_CONST, ids=[r["name"] for r in KALMAN_CONST])
+@pytest.mark.parametrize("flags", [capi.FLAG_FORCE_DENSE, capi.FLAG_NO_UNIFORM_DT])
+def test_paths_agree(rec, flags):
+    """isotropic register path == dense path == non-hoisted path on the same inputs"""
+    pb = problem_from_spec(rec, flags=flags)
+    eng = capi.Engine(pb)
+    info = eng.info()
+    assert info["path"] == (2 if flags == capi.FLAG_FORCE_DENSE else 1)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    eng.close()
+
+
+@pytest.mark.parametrize("split", ["fused", "split", "1,2,4,8"])
+def test_direction_split_variants(split, monkeypatch):
+    monkeypatch.setenv("SSDE_ISO_SPLIT", split)
+    for name in ("CTCRW_d2_const", "OU_SSM_d2_const", "BM_SSM_d1_const", "CTCRW_d1_const_regular_fixmu"):
+        rec = next(r for r in GOLD if r["name"] == name)
+        eng = capi.Engine(problem_from_spec(rec))
+        val, grad = eng.eval(rec["par"], order=1)
+        _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+        eng.close()
+
+
+KALMAN = [r for r in GOLD if r["model"] in ("CTCRW", "OU_SSM", "BM_SSM")]
+
+
+@pytest.mark.parametrize("rec", KALMAN, ids=[r["name"] for r in KALMAN])
+def test_report_aest_all(rec):
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    aest = eng.report(rec["par"])
+    exp = rec["expected"]["aest_all"]
+    assert aest.shape == exp.shape
+    assert np.allclose(aest, exp, rtol=1e-10, atol=1e-10, equal_nan=True)
+    eng.close()
+
+
+def _oracle(pb, par, **kw):
+    from oracle_lib import oracle_eval
+    return oracle_eval(pb, par, order=1, threads=8, **kw)
+
+
+@pytest.mark.parametrize("model,par", [
+    ("CTCRW", [-1.0, 0.1, -0.1, 0.5, 0.2]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]), ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
+def test_medium_batch_vs_oracle(model, par):
+    """3000 ragged tracks (47 wavefronts, several TILE_U blocks), 5 % NA rows, irregular time grid"""
+    rng = np.random.default_rng(11)
+    ID, times, obs = simulate(model, 3000, 40, 2, seed=5)
+    keep = np.ones(len(ID), bool)
+    for m in range(3000):  # ragged: drop a random tail of every track
+        cut = rng.integers(0, 25)
+        if cut:
+            keep[m * 40 + 40 - cut: m * 40 + 40] = False
+    ID, obs = ID[keep], obs[keep]
+    times = np.cumsum(rng.uniform(0.5, 1.5, size=len(ID)))
+    na = rng.random(len(ID)) < 0.05
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    obs[na & ~first] = np.nan
+    pb = capi.Problem(model, ID, times, obs)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(np.array(par), order=1)
+    oval, ograd = _oracle(pb, np.array(par))
+    _close(val, grad, oval, ograd)
+    eng.close()
+
+
+def test_device_resident_inputs_and_determinism():
+    import torch
+    ID, times, obs = simulate("CTCRW", 700, 64, 2, seed=3, backend="torch", device="cuda:0")
+    pbd = capi.Problem.from_torch("CTCRW", ID, times, obs)
+    pbh = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy())
+    par = np.array([-0.5, 0.0, 0.1, 0.3, -0.2])
+    ed, eh = capi.Engine(pbd), capi.Engine(pbh)
+    vd, gd = ed.eval(par)
+    vh, gh = eh.eval(par)
+    assert vd == vh and np.array_equal(gd, gh)          # same tiles, same arithmetic: bitwise
+    for _ in range(3):                                   # deterministic reduction order
+        v2, g2 = ed.eval(par)
+        assert v2 == vd and np.array_equal(g2, gd)
+    oval, ograd = _oracle(pbh, par)
+    _close(vd, gd, oval, ograd)
+    assert ed.info()["uniform_dt"] == 1
+    ed.close(); eh.close()
+
+
+def test_additivity_over_track_shards_full_size_tracks():
+    """Size-independent property at the benchmark's track length (T = 1e4): the nllk and gradient
+    of a batch equal the sums over two disjoint track shards (what the multi-GPU path relies on)."""
+    import torch
+    ID, times, obs = simulate("CTCRW", 256, 10_000, 2, seed=9, backend="torch", device="cuda:0")
+    par = np.array([-2.0, 0.0, 0.0, 0.6, 0.1])
+    n = ID.numel()
+    cut = 100 * 10_000
+    full = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs))
+    a = capi.Engine(capi.Problem.from_torch("CTCRW", ID[:cut], times[:cut], obs[:cut]))
+    b = capi.Engine(capi.Problem.from_torch("CTCRW", ID[cut:], times[cut:], obs[cut:]))
+    vf, gf = full.eval(par)
+    va, ga = a.eval(par)
+    vb, gb = b.eval(par)
+    assert abs(vf - (va + vb)) <= 1e-12 * abs(vf)
+    assert np.max(np.abs(gf - (ga + gb))) <= 1e-11 * np.max(np.abs(gf))
+    # and a 16-track slice of it against the oracle at full track length
+    sl = 16 * 10_000
+    pbh = capi.Problem("CTCRW", ID[:sl].cpu().numpy(), times[:sl].cpu().numpy(), obs[:sl].cpu().numpy())
+    e = capi.Engine(pbh)
+    v, g = e.eval(par)
+    oval, ograd = _oracle(pbh, par)
+    _close(v, g, oval, ograd)
+    for x in (full, a, b, e):
+        x.close()
+
+
+def test_direct_large_vs_oracle():
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    ID, times, obs = simulate("OU", 500, 400, 1, mu=1.0, seed=21)
+    n = len(ID)
+    x = (np.sin(np.arange(n) * 0.01) + 1) / 2
+    B = bspline_basis(x, 9)
+    pb = capi.Problem("OU", ID, times, obs, X_re=[B, None, None], S_list=[second_difference_penalty(9)])
+    par = np.concatenate([[0.9, 0.5, 0.1], [0.2], 0.05 * np.sin(np.arange(9))])
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert eng.info()["algo_bytes_per_row"] == 88.0
+    eng.close()
+
+
+def test_error_paths():
+    rec = GOLD[1]
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    with pytest.raises(ValueError):
+        eng.eval(np.zeros(pb.n_par_full + 1))
+    # non-finite nllk is returned, not raised
+    bad = rec["par"].copy()
+    bad[0] = 800.0
+    v = eng.eval(bad, order=0)
+    assert not np.isfinite(v) or v > 0
+    eng.close()

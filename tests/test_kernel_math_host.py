@@ -1,0 +1,64 @@
+"""CPU suite: the per-lane arithmetic the HIP kernels inline (csrc/ssde_math.hpp), built for the
+host by tests/hostsim, against the oracle.  Tolerances: value 1e-11 rel, gradient
+1e-9 * max|g| + 1e-11 (the engine's stated bar against the reference is 1e-8)."""
+import numpy as np
+import pytest
+
+from cases import problem_from_spec
+from golden_io import load_golden
+from hostsim_lib import kalman_iso, load
+
+GOLD = {r["name"]: r for r in load_golden()}
+ISO = [n for n in GOLD if n.endswith("_const") or n.endswith("_const_regular_fixmu") or n == "elephant6_ctcrw"]
+ISO = [n for n in ISO if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM")]
+
+
+@pytest.mark.parametrize("name", ISO)
+def test_iso_lane_math_matches_golden(name):
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    val, grad = kalman_iso(pb, rec["par"], mask=15)
+    exp = rec["expected"]
+    assert abs(val - exp["value"]) <= 1e-11 * max(1.0, abs(exp["value"]))
+    g = grad.copy()
+    g[pb.par_fixed != 0] = 0.0
+    assert np.max(np.abs(g - exp["grad"])) <= 1e-9 * np.max(np.abs(exp["grad"])) + 1e-11
+
+
+@pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 5, 10])
+def test_direction_masks_are_consistent(mask):
+    rec = GOLD["CTCRW_d2_const"]
+    pb = problem_from_spec(rec)
+    vfull, gfull = kalman_iso(pb, rec["par"], mask=15)
+    v, g = kalman_iso(pb, rec["par"], mask=mask)
+    assert v == vfull
+    want = np.zeros_like(gfull)
+    if mask & 1: want[0] = gfull[0]
+    if mask & 2: want[1:3] = gfull[1:3]
+    if mask & 4: want[3] = gfull[3]
+    if mask & 8: want[4] = gfull[4]
+    assert np.array_equal(g, want)
+
+
+def test_direct_transition_gradients():
+    import ctypes as C
+    lib = load()
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(7)
+
+    def f(model, z0, z1, dt, m, a, b, g=None):
+        g = np.zeros(3) if g is None else g
+        return lib.hostsim_direct(model, z0, z1, dt, m, a, b, g.ctypes.data_as(dp))
+
+    for model in (0, 1):
+        for _ in range(20):
+            z0, z1, dt = rng.normal(), rng.normal(), rng.uniform(0.2, 3)
+            mu, p1, p2 = rng.normal(), rng.uniform(-1, 1), rng.uniform(-1, 1)
+            g = np.zeros(3)
+            f(model, z0, z1, dt, mu, p1, p2, g)
+            h = 1e-6
+            fd = [(f(model, z0, z1, dt, mu + h, p1, p2) - f(model, z0, z1, dt, mu - h, p1, p2)) / (2 * h),
+                  (f(model, z0, z1, dt, mu, p1 + h, p2) - f(model, z0, z1, dt, mu, p1 - h, p2)) / (2 * h),
+                  (f(model, z0, z1, dt, mu, p1, p2 + h) - f(model, z0, z1, dt, mu, p1, p2 - h)) / (2 * h)]
+            n = 2 if model == 0 else 3
+            assert np.allclose(g[:n], fd[:n], rtol=1e-6, atol=1e-7)
