@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../include/ssde.h"
@@ -131,6 +132,26 @@ struct LU {
         return s;
     }
 };
+
+// log|det| of an n x n column-major matrix of any size (penalty blocks can exceed MAXD):
+// atomic::matinvpd's log-determinant, nllk_sde.hpp:110
+inline double logabsdet_dyn(const double* S, int n) {
+    std::vector<double> A(S, S + (size_t)n * n);
+    double ld = 0.0;
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++)
+            if (std::fabs(A[i + (size_t)k * n]) > std::fabs(A[piv + (size_t)k * n])) piv = i;
+        if (piv != k)
+            for (int j = 0; j < n; j++) std::swap(A[k + (size_t)j * n], A[piv + (size_t)j * n]);
+        ld += std::log(std::fabs(A[k + (size_t)k * n]));
+        for (int i = k + 1; i < n; i++) {
+            double f = A[i + (size_t)k * n] / A[k + (size_t)k * n];
+            for (int j = k + 1; j < n; j++) A[i + (size_t)j * n] -= f * A[k + (size_t)j * n];
+        }
+    }
+    return ld;
+}
 
 // det(): nllk_ctcrw.hpp:12-24
 template <class Type>
@@ -249,9 +270,7 @@ Type penalty_sde(const Problem& p, const Type* par) {
     const double* Sb = d->s_blocks;
     for (int s = 0; s < d->n_smooth; s++) {
         int Sn = d->smooth_ncol[s];
-        Mat<double> Sd(Sn, Sn);
-        for (int a = 0; a < Sn * Sn; a++) Sd.a[a] = Sb[a];
-        double log_det = -LU<double>(Sd).logabsdet();  // line 110-111: det(S^-1) = 1/det(S)
+        double log_det = -logabsdet_dyn(Sb, Sn);  // line 110-111: det(S^-1) = 1/det(S)
         Type quad = Type(0.0);
         for (int a = 0; a < Sn; a++) {
             Type Sx = Type(0.0);

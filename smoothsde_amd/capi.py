@@ -302,6 +302,15 @@ def load_library():
             f"HIP engine library not found at {path}: build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64
+    # under an unversioned file name, so if this library pulled in /opt/rocm's copy first, torch
+    # would later load a SECOND runtime that finds no device.  Importing torch first makes the
+    # loader resolve our DT_NEEDED libamdhip64.so.7 to the runtime torch already mapped (same
+    # soname).  Hosts without torch (the R shim) simply use /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(path)
     lib.ssde_create.argtypes = [C.POINTER(SsdeDesc), C.POINTER(C.c_void_p)]
     lib.ssde_create.restype = C.c_int
