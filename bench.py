@@ -100,7 +100,7 @@ def main():
     del ID, times, obs
     info = eng.info()
     npar = pb.n_par_full
-    out = torch.zeros(1 + npar, dtype=torch.float64, device=dev)
+    out = torch.zeros(2 + npar, dtype=torch.float64, device=dev)  # [nllk, grad..., window_check]
     stream = torch.cuda.current_stream(dev)
 
     def theta(k):
@@ -125,6 +125,11 @@ def main():
 
     for k in range(args.warmup):
         res = step(-1 - k)
+        for _ in range(4):  # overlapping time windows must agree (k_iso.hip); widen the overlap if not
+            if res[-1] <= capi.WINDOW_TOL * world:
+                break
+            eng.widen_windows(4)
+            res = step(-1 - k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -140,6 +145,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert np.all(np.isfinite(res)), res
+    assert res[-1] <= capi.WINDOW_TOL * world, f"window hand-over check failed: {res[-1]}"
+    info = eng.info()
 
     rows_per_gpu = info["n_rows"]
     total_rows = rows_per_gpu * world
@@ -166,7 +173,8 @@ def main():
                    "tracks_per_gpu": M, "rows_per_track": T, "n_free_par": info["n_free"],
                    "engine_path": {0: "direct", 1: "isotropic-register", 2: "dense"}[info["path"]],
                    "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
-                   "direction_parts": info["lanes_per_track"], "parallelism": f"tracks x{world}"},
+                   "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
+                   "window_check": float(res[-1]), "parallelism": f"tracks x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "algo_bytes_per_launch": algo_bytes},

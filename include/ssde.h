@@ -143,8 +143,11 @@ typedef struct ssde_info_t {
     int64_t n_steps;        /* rows that are not the first row of a segment */
     int64_t hbm_bytes;      /* resident bytes of the tiled streams */
     double  algo_bytes_per_row; /* 8*(d + 1 + d*d*[H_array] + K_row) */
-    int32_t n_kernel_blocks;/* workgroups of the main kernel */
-    int32_t lanes_per_track;
+    int32_t n_kernel_blocks;/* workgroups of the main kernel (last evaluation) */
+    int32_t lanes_per_track;/* direction parts x time windows (register path), direction blocks (dense) */
+    int32_t window;         /* warm-up rows of a time window in the last evaluation (0 = sequential) */
+    int32_t window_retries; /* evaluations repeated because the window hand-over check failed */
+    double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the
@@ -160,9 +163,13 @@ int ssde_eval(ssde_handle *h, const double *par, int32_t n_par_full, int32_t ord
               double *value, double *grad);
 
 /* Same evaluation WITHOUT the penalty and without synchronising: enqueues on
- * `stream` and leaves [nllk_data, grad...] (1 + n_par_full doubles) in the HBM
- * buffer `out_dev`.  Used by multi-GPU hosts: shard tracks, all-reduce out_dev,
- * then add ssde_penalty once. */
+ * `stream` and leaves [nllk_data, grad..., window_check] (2 + n_par_full doubles) in
+ * the HBM buffer `out_dev`.  Used by multi-GPU hosts: shard tracks, all-reduce
+ * out_dev, then add ssde_penalty once.  window_check is the largest relative
+ * disagreement between overlapping time windows of the register path (0 when the
+ * evaluation ran as one sequential window): the caller must treat the result as
+ * invalid when it exceeds 1e-11 (ssde_eval re-evaluates with a longer overlap by
+ * itself; asynchronous callers do the same after ssde_widen_windows). */
 int ssde_eval_device(ssde_handle *h, const double *par, int32_t n_par_full, int32_t order,
                      double *out_dev, void *stream);
 
@@ -172,6 +179,10 @@ int ssde_penalty(ssde_handle *h, const double *par, int32_t n_par_full, double *
 
 /* One-step-ahead predicted states for every row: aest_all [n x sdim] column-major. */
 int ssde_report(ssde_handle *h, const double *par, int32_t n_par_full, double *aest_all);
+
+/* Multiply the warm-up overlap of the time windows by `factor` for all later evaluations
+ * (factor <= 0: force one sequential window). */
+int ssde_widen_windows(ssde_handle *h, int32_t factor);
 
 int ssde_info(const ssde_handle *h, ssde_info_t *info);
 

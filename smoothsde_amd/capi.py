@@ -52,6 +52,7 @@ class SsdeInfo(C.Structure):
         ("const_coeff", C.c_int32), ("uniform_dt", C.c_int32),
         ("n_tracks", C.c_int64), ("n_rows", C.c_int64), ("n_steps", C.c_int64), ("hbm_bytes", C.c_int64),
         ("algo_bytes_per_row", C.c_double), ("n_kernel_blocks", C.c_int32), ("lanes_per_track", C.c_int32),
+        ("window", C.c_int32), ("window_retries", C.c_int32), ("window_check", C.c_double),
     ]
 
     def as_dict(self):
@@ -322,6 +323,8 @@ def load_library():
     lib.ssde_penalty.restype = C.c_int
     lib.ssde_report.argtypes = [C.c_void_p, _dp, C.c_int32, _dp]
     lib.ssde_report.restype = C.c_int
+    lib.ssde_widen_windows.argtypes = [C.c_void_p, C.c_int32]
+    lib.ssde_widen_windows.restype = C.c_int
     lib.ssde_info.argtypes = [C.c_void_p, C.POINTER(SsdeInfo)]
     lib.ssde_info.restype = C.c_int
     lib.ssde_destroy.argtypes = [C.c_void_p]
@@ -336,7 +339,9 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report",
+WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
+
+EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows",
                     "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version")
 
 
@@ -378,8 +383,12 @@ class Engine:
                                        C.byref(val), grad.ctypes.data_as(_dp)))
         return (val.value, grad) if order >= 1 else val.value
 
+    def widen_windows(self, factor: int = 4):
+        self._check(self.lib.ssde_widen_windows(self._h, factor))
+
     def eval_device(self, par, out_ptr: int, order: int = 1, stream: int = 0):
-        """Asynchronous evaluation of the data term into an HBM buffer of 1+n_par_full doubles."""
+        """Asynchronous evaluation of the data term into an HBM buffer of 2+n_par_full doubles:
+        [nllk, grad..., window_check]; the caller rejects the result if window_check > WINDOW_TOL."""
         par = np.ascontiguousarray(par, dtype=np.float64)
         self._check(self.lib.ssde_eval_device(self._h, par.ctypes.data_as(_dp), self.n_par_full, order,
                                               C.c_void_p(out_ptr), C.c_void_p(stream)))

@@ -1,18 +1,30 @@
 // k_iso.hip -- constant-coefficient isotropic Kalman kernels for gfx950 (CTCRW, OU_SSM, BM_SSM).
 //
-// One wavefront lane = one track; a workgroup is ONE wave (64 lanes), so that the ~10^2..10^3
-// waves of a 10^4-track batch spread over all 256 CUs.  State, covariance and all forward
-// sensitivities stay in VGPRs for the whole track; observations stream from the tiled HBM
-// layout (ssde_device.hpp) with coalesced 512-B wave loads, prefetched one TILE_U-step block
-// ahead into registers (a stream consumed by a single wave gains nothing from an LDS round
-// trip; the LDS-shared variant for direction-split workgroups is k_iso_lds.hip).
-// fp64 throughout, no MFMA: the recursion is a serial chain of scalar fp64 FMAs per lane.
+// One wavefront lane = one track; a workgroup is ONE wave (64 lanes).  State, covariance and
+// all forward sensitivities stay in VGPRs; observations stream from the tiled HBM layout
+// (ssde_device.hpp) with coalesced 512-B wave loads, prefetched one TILE_U-step block ahead
+// into registers.  fp64 throughout, no MFMA: per lane the recursion is a serial chain of
+// scalar fp64 FMAs, so the kernel is bound by fp64 VALU issue, and a lone wave on a SIMD can
+// only issue every other fp64 slot.  A 10^4-track batch is just 157 waves for 1024 SIMDs, so
+// two more axes of parallelism are layered on the track axis:
+//
+//  * TIME WINDOWS.  A track is cut into n_chunks windows; window c > 0 starts `window` rows
+//    early from an arbitrary state (first observation, P0, zero sensitivities), runs the same
+//    filter WITHOUT scoring, and starts scoring at its own first row.  The Kalman filter and
+//    its sensitivity recursion forget their initial condition geometrically (the closed-loop
+//    matrix T - K Z is a contraction whenever observations arrive), so after the warm-up the
+//    window carries the sequential filter's state to rounding error.  This is VERIFIED, not
+//    assumed: every window dumps its state at its first scored row, the previous window dumps
+//    its state at the same row, window_check_kernel reduces the largest relative disagreement
+//    over every component (state, covariance, all sensitivities), and the evaluation reports
+//    it next to the result; the host re-evaluates with a longer warm-up (up to one single
+//    window = the plain sequential filter) when it exceeds its threshold.
+//  * DIRECTION PARTS.  The gradient directions may be split over "parts" that each recompute
+//    the primal filter; all parts of one (group, window) get workgroup ids that are equal
+//    mod 8, i.e. one XCD, so the tile is fetched from HBM once and re-served from that L2.
 //
 // Reference arithmetic: ssde_math.hpp (nllk_ctcrw.hpp:195-247, nllk_ou_ssm.hpp:163-213,
-// nllk_bm_ssm.hpp:127-175).  Gradient: forward sensitivities selected by a DIR_* mask; the
-// grid may be split into "parts" that each carry a subset of the directions (more waves for
-// the same batch) -- parts of one track group are placed on one XCD so the group's tile is
-// fetched from HBM once and re-served from that XCD's L2.
+// nllk_bm_ssm.hpp:127-175).
 #include "ssde_device.hpp"
 
 namespace ssde {
@@ -25,125 +37,163 @@ __device__ __forceinline__ void load_block(double (&dst)[TILE_U][C], const doubl
         for (int c = 0; c < C; c++) dst[u][c] = p[(u * C + c) * WAVE];
 }
 
+// ---- per-model lane policies --------------------------------------------------------------
+template <int MODEL, int D, int MASK>
+struct LaneOps;
+
 template <int D, int MASK>
-__device__ __forceinline__ void run_ctcrw(const IsoArgs& A, int g, int part) {
+struct LaneOps<M_CTCRW, D, MASK> {
+    typedef CtcrwLane<D, MASK> State;
+    typedef CtcrwTrans Trans;
+    static constexpr int SD = 2 * D;
+    __device__ static __forceinline__ Trans hoisted(const IsoArgs& A) { return A.ctr; }
+    __device__ static __forceinline__ void init(State& S, const double* a0, const IsoArgs& A) {
+        S.init(a0, A.p0[0], A.p0[1], A.p0[2]);
+    }
+    __device__ static __forceinline__ void warm_init(State& S, const double* y, const IsoArgs& A) {
+        double a0[SD];
+#pragma unroll
+        for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
+        S.init(a0, A.p0[0], A.p0[1], A.p0[2]);
+    }
+    __device__ static __forceinline__ void step(State& S, Trans& tr, const IsoArgs& A, bool uni, const double* mu,
+                                                const double* row) {
+        if (!uni) ctcrw_trans(row[0], A.tau, A.beta, A.sigma, tr);
+        ctcrw_step<D, MASK>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+    }
+    __device__ static __forceinline__ void finish(const State& S, double* out) { ctcrw_finish<D, MASK>(S, out); }
+};
+
+template <int MODEL, int D, int MASK>
+struct LaneOps {  // OU_SSM / BM_SSM
+    typedef ScalLane<D, MASK> State;
+    typedef ScalTrans Trans;
+    static constexpr int SD = D;
+    __device__ static __forceinline__ Trans hoisted(const IsoArgs& A) { return A.str; }
+    __device__ static __forceinline__ void init(State& S, const double* a0, const IsoArgs& A) { S.init(a0, A.p0[0]); }
+    __device__ static __forceinline__ void warm_init(State& S, const double* y, const IsoArgs& A) {
+        double a0[SD];
+#pragma unroll
+        for (int a = 0; a < D; a++) a0[a] = (y[a] == y[a]) ? y[a] : 0.0;
+        S.init(a0, A.p0[0]);
+    }
+    __device__ static __forceinline__ void step(State& S, Trans& tr, const IsoArgs& A, bool uni, const double* mu,
+                                                const double* row) {
+        if (!uni) {
+            if (MODEL == M_OU_SSM) ou_trans(row[0], A.tau, A.sigma, tr);
+            else bm_trans(row[0], A.sigma, tr);
+        }
+        scal_step<D, MASK, MODEL == M_OU_SSM>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+    }
+    __device__ static __forceinline__ void finish(const State& S, double* out) { scal_finish<D, MASK>(S, out); }
+};
+
+// window geometry shared by the kernel and the hand-over check
+__device__ __forceinline__ int chunk_len(int L, int n_chunks) {
+    return ((L + n_chunks - 1) / n_chunks + TILE_U - 1) / TILE_U * TILE_U;
+}
+
+template <int MODEL, int D, int MASK>
+__device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
+    typedef LaneOps<MODEL, D, MASK> Ops;
     constexpr int C = 1 + D;
     constexpr int NACC = 4 + D;
+    constexpr int SD = Ops::SD;
     const int lane = threadIdx.x;
     const TileView& tv = A.tv;
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
+    const int pc = part * A.n_chunks + chunk;
 
-    CtcrwLane<D, MASK> S;
-    double a0[2 * D];
-#pragma unroll
-    for (int c = 0; c < 2 * D; c++) a0[c] = tv.a0[((int64_t)g * 2 * D + c) * WAVE + lane];
-    S.init(a0, A.p0[0], A.p0[1], A.p0[2]);
+    // this workgroup's window: rows [s_acc, s_end) are scored, rows [s_begin, s_acc) warm up
+    int s_begin = 0, s_acc = 0, s_end = L;
+    if (A.n_chunks > 1) {
+        const int cl = chunk_len(L, A.n_chunks);
+        s_acc = min(L, chunk * cl);
+        s_end = min(L, s_acc + cl);
+        s_begin = max(0, s_acc - A.window);
+    }
+
+    typename Ops::State S;
+    typename Ops::Trans tr = Ops::hoisted(A);
+    const bool uni = A.uniform_dt != 0;
     double mu[D];
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
-    CtcrwTrans tr = A.ctr;
-    const bool uni = A.uniform_dt != 0;
 
     double cur[TILE_U][C], nxt[TILE_U][C];
-    load_block<C>(cur, base);
-    for (int s0 = 0; s0 < L; s0 += TILE_U) {
+    load_block<C>(cur, base + (int64_t)s_begin * C * WAVE);
+    if (s_begin == 0) {
+        double a0[SD];
+#pragma unroll
+        for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        Ops::init(S, a0, A);
+    } else {
+        Ops::warm_init(S, &cur[0][1], A);
+    }
+
+    for (int s0 = s_begin; s0 < s_end; s0 += TILE_U) {
         load_block<C>(nxt, base + (int64_t)(s0 + TILE_U) * C * WAVE);  // spare block keeps this in bounds
+        if (s0 == s_acc && s_acc > s_begin) {
+            // end of warm-up: publish the state for the hand-over check, start scoring from zero
+            double st[Ops::State::NSTATE];
+            S.dump(st);
+            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++) {
-            if (s0 + u < ns) {
-                if (!uni) ctcrw_trans(cur[u][0], A.tau, A.beta, A.sigma, tr);
-                ctcrw_step<D, MASK>(S, tr, A.h, mu, &cur[u][1], is_na(cur[u][1], A.any_nan));
-            }
+            for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+            S.reset_acc();
         }
+#pragma unroll
+        for (int u = 0; u < TILE_U; u++)
+            if (s0 + u < ns) Ops::step(S, tr, A, uni, mu, cur[u]);
 #pragma unroll
         for (int u = 0; u < TILE_U; u++)
 #pragma unroll
             for (int c = 0; c < C; c++) cur[u][c] = nxt[u][c];
     }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
+        // state on arrival at the next window's first scored row
+        double st[Ops::State::NSTATE];
+        S.dump(st);
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+    }
     double out[NACC];
-    ctcrw_finish<D, MASK>(S, out);
+    Ops::finish(S, out);
+    if (s_acc >= s_end) {
+#pragma unroll
+        for (int k = 0; k < NACC; k++) out[k] = 0.0;  // empty window
+    }
 #pragma unroll
     for (int k = 0; k < NACC; k++) {
         const double t = wave_sum(out[k]);
-        if (lane == 0) A.partials[((int64_t)part * NACC + k) * tv.n_groups + g] = t;
+        if (lane == 0) A.partials[((int64_t)pc * NACC + k) * tv.n_groups + g] = t;
     }
 }
 
-template <int MODEL, int D, int MASK>
-__device__ __forceinline__ void run_scal(const IsoArgs& A, int g, int part) {
-    constexpr int C = 1 + D;
-    constexpr int NACC = 4 + D;
-    const int lane = threadIdx.x;
-    const TileView& tv = A.tv;
-    const double* base = tv.tiles + tv.group_off[g] + lane;
-    const int L = tv.group_len[g];
-    const int ns = tv.lane_nsteps[g * WAVE + lane];
-
-    ScalLane<D, MASK> S;
-    double a0[D];
-#pragma unroll
-    for (int c = 0; c < D; c++) a0[c] = tv.a0[((int64_t)g * D + c) * WAVE + lane];
-    S.init(a0, A.p0[0]);
-    double mu[D];
-#pragma unroll
-    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
-    ScalTrans tr = A.str;
-    const bool uni = A.uniform_dt != 0;
-
-    double cur[TILE_U][C], nxt[TILE_U][C];
-    load_block<C>(cur, base);
-    for (int s0 = 0; s0 < L; s0 += TILE_U) {
-        load_block<C>(nxt, base + (int64_t)(s0 + TILE_U) * C * WAVE);
-#pragma unroll
-        for (int u = 0; u < TILE_U; u++) {
-            if (s0 + u < ns) {
-                if (!uni) {
-                    if (MODEL == M_OU_SSM) ou_trans(cur[u][0], A.tau, A.sigma, tr);
-                    else bm_trans(cur[u][0], A.sigma, tr);
-                }
-                scal_step<D, MASK, MODEL == M_OU_SSM>(S, tr, A.h, mu, &cur[u][1], is_na(cur[u][1], A.any_nan));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < TILE_U; u++)
-#pragma unroll
-            for (int c = 0; c < C; c++) cur[u][c] = nxt[u][c];
-    }
-    double out[NACC];
-    scal_finish<D, MASK>(S, out);
-#pragma unroll
-    for (int k = 0; k < NACC; k++) {
-        const double t = wave_sum(out[k]);
-        if (lane == 0) A.partials[((int64_t)part * NACC + k) * tv.n_groups + g] = t;
-    }
-}
-
-template <int MODEL, int D, int MASK>
-__device__ __forceinline__ void run_any(const IsoArgs& A, int g, int part) {
-    if (MODEL == M_CTCRW) run_ctcrw<D, MASK>(A, g, part);
-    else run_scal<MODEL, D, MASK>(A, g, part);
-}
-
-// Workgroup id -> (track group, part).  Workgroups are dealt round-robin over the 8 XCDs, so
-// ids that are equal mod 8 share an XCD (and its L2): all parts of one group get such ids.
-__device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part) {
+// Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
+// XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
+// get such ids because they stream the same rows.
+__device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part, int& chunk) {
     const int id = blockIdx.x;
-    const int np = A.n_parts;
-    g = (id / (8 * np)) * 8 + (id & 7);
-    part = (id >> 3) % np;
+    const int np = A.n_parts, nc = A.n_chunks;
+    const int hi = id >> 3;  // ((g/8) * nc + chunk) * np + part
+    part = hi % np;
+    chunk = (hi / np) % nc;
+    g = (hi / (np * nc)) * 8 + (id & 7);
     return g < A.tv.n_groups;
 }
 
 template <int MODEL, int D>
 __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
-    int g, part;
-    if (!decode_block(A, g, part)) return;
+    int g, part, chunk;
+    if (!decode_block(A, g, part, chunk)) return;
     // (no dynamic indexing into the by-value argument block: that would force a scratch copy)
     const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
     switch (mask) {
-#define SSDE_CASE(M) case M: run_any<MODEL, D, M>(A, g, part); break;
+#define SSDE_CASE(M) case M: run_lane<MODEL, D, M>(A, g, part, chunk); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE
@@ -151,20 +201,61 @@ __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
     }
 }
 
+// Hand-over check: for every (part, group, window boundary) compare the state the previous
+// window arrived with against the state the next window warmed up to, component by component.
+// Per component the error is max over the wave's lanes of |a - b| and the scale is the max over
+// the lanes of max(|a|, |b|); chk[] gets the largest error/scale ratio of the workgroup.
+__global__ __launch_bounds__(WAVE) void window_check_kernel(const IsoArgs A, int nstate, double* chk) {
+    const int g = blockIdx.x, c = blockIdx.y, part = blockIdx.z, lane = threadIdx.x;
+    const TileView& tv = A.tv;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    const int cl = chunk_len(L, A.n_chunks);
+    const int s_next = min(L, (c + 1) * cl);        // first scored row of window c+1
+    const bool valid = (ns > s_next) && (s_next < L) && (s_next - A.window > 0);
+    const int pc0 = part * A.n_chunks + c, pc1 = pc0 + 1;
+    const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
+    const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
+    double worst = 0.0;
+    for (int k = 0; k < nstate; k++) {
+        double a = valid ? out_c[k * WAVE] : 0.0, b = valid ? in_n[k * WAVE] : 0.0;
+        double err = fabs(a - b), sc = fmax(fabs(a), fabs(b));
+        if (valid && !(err == err)) err = INFINITY;  // NaN on either side must not pass
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            err = fmax(err, __shfl_xor(err, o, 64));
+            sc = fmax(sc, __shfl_xor(sc, o, 64));
+        }
+        if (err > 0.0) worst = fmax(worst, err / sc);
+    }
+    if (lane == 0) chk[((int64_t)part * (A.n_chunks - 1) + c) * tv.n_groups + g] = worst;
+}
+
+int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2 * d : 4 * (d + 1) + d; }
+
 hipError_t launch_iso(int model, int d, const IsoArgs& a, hipStream_t s) {
     const int g8 = (a.tv.n_groups + 7) / 8;
-    dim3 grid(g8 * 8 * a.n_parts), block(WAVE);
+    dim3 grid(g8 * 8 * a.n_parts * a.n_chunks), block(WAVE);
     if (grid.x == 0) return hipSuccess;
+    bool done = false;
 #define SSDE_LAUNCH(MODEL, D)                                                          \
     if (model == MODEL && d == D) {                                                    \
         hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a);              \
-        return hipGetLastError();                                                      \
+        done = true;                                                                   \
     }
     SSDE_LAUNCH(M_CTCRW, 1) SSDE_LAUNCH(M_CTCRW, 2)
     SSDE_LAUNCH(M_OU_SSM, 1) SSDE_LAUNCH(M_OU_SSM, 2)
     SSDE_LAUNCH(M_BM_SSM, 1) SSDE_LAUNCH(M_BM_SSM, 2)
 #undef SSDE_LAUNCH
-    return hipErrorInvalidValue;
+    if (!done) return hipErrorInvalidValue;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.n_chunks > 1) {
+        hipLaunchKernelGGL(window_check_kernel, dim3(a.tv.n_groups, a.n_chunks - 1, a.n_parts), block, 0, s, a,
+                           iso_nstate(model, d), a.chk);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 }  // namespace ssde

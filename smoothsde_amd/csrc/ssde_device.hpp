@@ -26,6 +26,7 @@ namespace ssde {
 constexpr int WAVE = 64;
 constexpr int TILE_U = 4;        // steps per prefetch block of the register kernels
 constexpr int NACC_MAX = 8;      // 1 + 3 + D accumulators of the constant-coefficient kernels
+constexpr int NSTATE_MAX = 32;   // state + sensitivity components dumped at a window hand-over
 constexpr int MAX_PARTS = 4;     // direction split: at most one part per direction bit
 constexpr int MAX_PAR = 320;     // parameters passed by value in the kernel argument block
 constexpr int MAX_COLS = 96;     // streamed design columns (dense / direct kernels)
@@ -44,7 +45,11 @@ struct TileView {
 // ---- constant-coefficient isotropic Kalman kernels (k_iso.hip) -----------------------------
 struct IsoArgs {
     TileView tv;
-    double* partials;            // [n_parts][NACC][n_groups]
+    double* partials;            // [n_parts * n_chunks][NACC][n_groups]
+    double* bnd;                 // [n_parts * n_chunks][n_groups][2][NSTATE_MAX][64] window hand-over states
+    double* chk;                 // [n_parts][n_chunks - 1][n_groups] largest relative hand-over disagreement
+    int n_chunks;                // time windows per track group (1 = plain sequential filter)
+    int window;                  // warm-up rows of a window, multiple of TILE_U
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;
@@ -57,17 +62,23 @@ struct IsoArgs {
     ScalTrans str;
 };
 hipError_t launch_iso(int model, int d, const IsoArgs& a, hipStream_t s);
+int iso_nstate(int model, int d);
 
 // ---- final deterministic reduction (k_reduce.hip) --------------------------------------------
-// out[0]    = sum_g partials[part 0][acc 0][g]                    (every part recomputes the nllk)
-// out[slot] = sum over the (part, k >= 1) pairs with map[part*(nacc-1) + k-1] == slot, and over g
+// out[0]      = sum over the first n_value_parts parts (the time windows of direction part 0) and g
+//               of partials[part][acc 0][g]        (every direction part recomputes the nllk)
+// out[slot]   = sum over the (part, k >= 1) pairs with map[(part / chunks_per_part)*(nacc-1) + k-1] == slot
+// out[n_out]  = max of chk[0..n_chk)  (window hand-over check; 0 when there is nothing to check)
 // One workgroup per output slot, fixed summation order: bitwise reproducible.
 struct ReduceArgs {
     const double* partials;       // [n_parts][nacc][n_blocks]
     int n_parts, nacc, n_blocks;
+    int n_value_parts, chunks_per_part;
     int n_out;                    // 1 + n_par_full
+    const double* chk;
+    int n_chk;
     int16_t map[MAX_PAR + 16];    // -> output slot (1 + full-par index) or -1
-    double* out;
+    double* out;                  // n_out + 1 doubles
 };
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s);
 

@@ -28,6 +28,7 @@ thread_local std::string g_create_error;
 
 enum { PATH_DIRECT = 0, PATH_ISO = 1, PATH_DENSE = 2 };
 constexpr int PAR_RING = 8;
+constexpr double SSDE_WINDOW_TOL = 1e-11;  // largest tolerated relative hand-over disagreement
 
 template <class T>
 struct DevBuf {
@@ -90,6 +91,16 @@ struct ssde_handle {
     DevBuf<double> partials, out;
     size_t partial_doubles = 0;
 
+    // iso time windows
+    DevBuf<double> bnd, chk;
+    int max_chunks = 1;            // allocation bound
+    int glen_max = 0;              // steps of the longest track group
+    double dt_min = 0.0;           // smallest interval used inside a track
+    int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
+    int last_chunks = 1, last_window = 0;
+    double last_check = 0.0;
+    int n_retries = 0;
+
     // iso direction split
     int iso_parts = 1;
     int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
@@ -117,6 +128,7 @@ int fail(ssde_handle* h, int code, const std::string& msg) {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
+    h->bnd.release(); h->chk.release();
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
     h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
@@ -150,7 +162,7 @@ int choose_iso_split(ssde_handle* h) {
     // covariance-affecting direction its own wave (each recomputes the cheap primal) until
     // the grid holds a few waves per SIMD.  SSDE_ISO_SPLIT=fused|split overrides.
     const char* env = getenv("SSDE_ISO_SPLIT");
-    bool split = h->n_groups < 2048;
+    bool split = false;  // time windows (below) fill the chip without recomputing the primal
     if (env && !strcmp(env, "fused")) split = false;
     if (env && !strcmp(env, "split")) split = true;
     int np = 0;
@@ -252,7 +264,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
     h->n_steps = n - h->n_seg;
     starts.push_back(n);
 
-    HIPCHK(h, h->out.alloc(1 + h->L.n_full));
+    HIPCHK(h, h->out.alloc(2 + h->L.n_full));
 
     // ---- direct families --------------------------------------------------------------------------
     if (!is_kalman(d->model)) {
@@ -376,13 +388,24 @@ int build(const ssde_desc* d, ssde_handle* h) {
         for (size_t k = 0; k < mmh.size(); k += 2) { dmin = std::min(dmin, mmh[k]); dmax = std::max(dmax, mmh[k + 1]); }
         h->uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
         h->dt_uniform = h->uniform_dt ? dmin : 0.0;
+        h->dt_min = std::isfinite(dmin) ? dmin : 0.0;
         mm.release(); s_times.release(); s_obs.release(); s_h.release(); s_a0.release(); s_cols.release();
         s_colptr.release(); s_lane_seg.release();
         h->hbm_bytes = h->tile_doubles * 8;
 
         if (h->path == PATH_ISO) {
             choose_iso_split(h);
-            h->partial_doubles = (size_t)MAX_PARTS * NACC_MAX * G;
+            // time windows: enough (group, window, part) workgroups for ~2 waves on each of the 1024 SIMDs
+            int glmax = 0;
+            for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
+            h->glen_max = glmax;
+            int want = (2048 + G * h->iso_parts - 1) / (G * h->iso_parts);
+            if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
+            h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * TILE_U))));
+            HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * h->max_chunks * G * 2 * NSTATE_MAX * WAVE));
+            HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * h->max_chunks * G));
+            h->partial_doubles = (size_t)MAX_PARTS * h->max_chunks * NACC_MAX * G;
+            h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
         } else {
             // gradient directions of the dense kernel: free parameters that reach the data term
             std::vector<DenseDir> dirs;
@@ -420,6 +443,73 @@ int build(const ssde_desc* d, ssde_handle* h) {
     return SSDE_OK;
 }
 
+// Warm-up length of a time window: iterate the (data-independent) covariance recursion on the
+// host at the smallest interval of the batch until it is stationary, take the spectral radius
+// rho of the closed-loop matrix T - K Z there, and ask for rho^W <= 1e-18 (plus slack for the
+// t * rho^t growth of the sensitivity recursions).  The device-side hand-over check decides
+// whether the estimate was good enough; it never has to be trusted.
+void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) {
+    *n_chunks = 1;
+    *window = 0;
+    if (h->max_chunks <= 1) return;
+    const double dt = h->uniform_dt ? h->dt_uniform : h->dt_min;
+    double rho = 1.0;
+    if (dt > 0.0 && std::isfinite(dt)) {
+        if (h->model == SSDE_MODEL_CTCRW) {
+            CtcrwTrans tr;
+            ctcrw_trans(dt, a.tau, a.beta, a.sigma, tr);
+            double p11 = a.p0[0], p12 = a.p0[1], p22 = a.p0[2], k1 = 0, k2 = 0;
+            for (int it = 0; it < 20000; it++) {
+                const double F = p11 + a.h, iF = 1.0 / F;
+                const double tp11 = p11 + tr.t12 * p12, tp12 = p12 + tr.t12 * p22, tp21 = tr.e * p12, tp22 = tr.e * p22;
+                k1 = tp11 * iF; k2 = tp21 * iF;
+                const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11, n12 = -tp11 * k2 + tp12 * tr.e + tr.q12,
+                             n22 = -tp21 * k2 + tp22 * tr.e + tr.q22;
+                const double ch = std::fabs(n11 - p11) + std::fabs(n12 - p12) + std::fabs(n22 - p22);
+                p11 = n11; p12 = n12; p22 = n22;
+                if (ch <= 1e-15 * (std::fabs(p11) + std::fabs(p22))) break;
+            }
+            // L = [[1 - k1, t12], [-k2, e]]
+            const double trc = (1.0 - k1) + tr.e, det = (1.0 - k1) * tr.e + k2 * tr.t12;
+            const double disc = trc * trc - 4.0 * det;
+            rho = disc >= 0.0 ? std::max(std::fabs(0.5 * (trc + std::sqrt(disc))), std::fabs(0.5 * (trc - std::sqrt(disc))))
+                              : std::sqrt(std::fabs(det));
+        } else {
+            ScalTrans tr;
+            if (h->model == SSDE_MODEL_OU_SSM) ou_trans(dt, a.tau, a.sigma, tr);
+            else bm_trans(dt, a.sigma, tr);
+            double p = a.p0[0], k = 0;
+            for (int it = 0; it < 20000; it++) {
+                const double F = p + a.h, tp = tr.t * p;
+                k = tp / F;
+                const double np_ = tp * (tr.t - k) + tr.q;
+                const double ch = std::fabs(np_ - p);
+                p = np_;
+                if (ch <= 1e-15 * std::fabs(p)) break;
+            }
+            rho = std::fabs(tr.t - k);
+        }
+    }
+    int W = 0;
+    if (!(rho < 0.9995) || !std::isfinite(rho)) return;  // no usable forgetting: sequential filter
+    W = (int)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
+    W = std::max(W, 16);
+    if (const char* e = getenv("SSDE_WINDOW")) W = std::max(1, atoi(e));  // testing: deliberately short overlaps
+    if ((int64_t)W * h->window_boost > (int64_t)h->glen_max) return;     // longer than a track: sequential filter
+    W *= h->window_boost;
+    W = (W + TILE_U - 1) / TILE_U * TILE_U;
+    // a window must be long enough to amortise its warm-up
+    int glmax = 0;
+    {
+        // group lengths are sorted descending: the first group is the longest
+        glmax = h->glen_max;
+    }
+    int nc = h->max_chunks;
+    while (nc > 1 && (glmax / nc) < 2 * W) nc--;
+    *n_chunks = nc;
+    *window = nc > 1 ? W : 0;
+}
+
 // upload the parameter vector for the dense / direct kernels; returns the device pointer
 int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev) {
     const int slot = h->par_next;
@@ -439,6 +529,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
     const ParLayout& L = h->L;
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
+    ra.n_value_parts = 1; ra.chunks_per_part = 1; ra.chk = nullptr; ra.n_chk = 0;
     ra.partials = h->partials.p;
     ra.n_out = 1 + L.n_full;
     ra.out = out_dev;
@@ -478,9 +569,14 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             a.sigma = exp(p1);
             if (h->uniform_dt) bm_trans(h->dt_uniform, a.sigma, a.str);
         }
+        plan_windows(h, a, &a.n_chunks, &a.window);
+        a.bnd = h->bnd.p; a.chk = h->chk.p;
+        h->last_chunks = a.n_chunks; h->last_window = a.window;
         HIPCHK(h, launch_iso(h->model, h->d, a, s));
         const int nacc = 4 + h->d;
-        ra.n_parts = a.n_parts; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+        ra.n_parts = a.n_parts * a.n_chunks; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+        ra.n_value_parts = a.n_chunks; ra.chunks_per_part = a.n_chunks;
+        ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
         if (order >= 1) {
             for (int p = 0; p < a.n_parts; p++)
                 for (int k = 1; k < nacc; k++) {
@@ -577,11 +673,21 @@ int ssde_penalty(ssde_handle* h, const double* par, int32_t n_par_full, double* 
 int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* value, double* grad) {
     if (!h || !par || !value) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
-    int st = eval_device(h, par, order, h->out.p, 0);
-    if (st) return st;
-    std::vector<double> o(1 + h->L.n_full);
-    HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> o(2 + h->L.n_full);
+    for (int attempt = 0;; attempt++) {
+        int st = eval_device(h, par, order, h->out.p, 0);
+        if (st) return st;
+        HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
+        h->last_check = o[1 + h->L.n_full];
+        // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
+        // until the windows agree with each other; 64x the estimate ends in one sequential window
+        if (h->last_check <= SSDE_WINDOW_TOL || h->last_chunks <= 1) break;
+        if (attempt >= 3) h->max_chunks = 1;   // give up on windows for this handle: sequential filter
+        else h->window_boost *= 4;
+        h->n_retries++;
+    }
     double pen = 0.0;
+    int st;
     if (order >= 1 && grad) {
         for (int k = 0; k < h->L.n_full; k++) grad[k] = o[1 + k];
         st = ssde_penalty(h, par, n_par_full, &pen, grad);
@@ -626,6 +732,13 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     return SSDE_OK;
 }
 
+int ssde_widen_windows(ssde_handle* h, int32_t factor) {
+    if (!h) return SSDE_ERR_ARG;
+    if (factor <= 0) h->max_chunks = 1;
+    else if (h->window_boost < (1 << 20)) h->window_boost *= factor;
+    return SSDE_OK;
+}
+
 int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     if (!h || !info) return SSDE_ERR_ARG;
     memset(info, 0, sizeof(*info));
@@ -640,10 +753,13 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_steps = h->n_steps;
     info->hbm_bytes = h->hbm_bytes;
     info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols);
-    if (h->path == PATH_ISO) info->n_kernel_blocks = (h->n_groups + 7) / 8 * 8 * h->iso_parts;
+    if (h->path == PATH_ISO) info->n_kernel_blocks = (h->n_groups + 7) / 8 * 8 * h->iso_parts * h->last_chunks;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;
     else info->n_kernel_blocks = h->direct_blocks;
-    info->lanes_per_track = h->path == PATH_ISO ? h->iso_parts : (h->path == PATH_DENSE ? h->n_dirblocks : 1);
+    info->lanes_per_track = h->path == PATH_ISO ? h->iso_parts * h->last_chunks : (h->path == PATH_DENSE ? h->n_dirblocks : 1);
+    info->window = h->last_window;
+    info->window_check = h->last_check;
+    info->window_retries = h->n_retries;
     return SSDE_OK;
 }
 

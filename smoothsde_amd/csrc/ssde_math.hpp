@@ -53,6 +53,19 @@ SSDE_HD bool is_na(double x, int any_nan) {
     return (uint32_t)(b & 0xffffffffu) == 1954u;
 }
 
+// 1/x for the innovation variance: hardware reciprocal seed + two Newton steps (full fp64
+// accuracy for finite normal x; the compiler's IEEE division sequence is ~2x longer).
+SSDE_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
 // Running sum of log|F| kept as mantissa * 2^exponent: one multiply and an exponent
 // extraction per row instead of a software fp64 log per row; a single log at the end.
 struct LogAcc {
@@ -126,6 +139,28 @@ struct CtcrwLane {
         accq = 0.0;
         ts.init(); tt.init(); tn.init();
     }
+    // accumulators only (used when a time window starts scoring after its warm-up rows)
+    SSDE_HD void reset_acc() {
+        ld.init();
+        accq = 0.0;
+        ts.g = tt.g = tn.g = 0.0;
+        for (int a = 0; a < D; a++) gmu[a] = 0.0;
+    }
+    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
+    SSDE_HD static void dump_tan(const CtcrwTan<D>& t, bool on, double* o, int& k) {
+        o[k++] = on ? t.p11 : 0.0; o[k++] = on ? t.p12 : 0.0; o[k++] = on ? t.p22 : 0.0;
+        for (int a = 0; a < D; a++) { o[k++] = on ? t.x[a] : 0.0; o[k++] = on ? t.v[a] : 0.0; }
+    }
+    // filter state + sensitivities, for the window hand-over check
+    SSDE_HD void dump(double* o) const {
+        int k = 0;
+        for (int a = 0; a < D; a++) { o[k++] = x[a]; o[k++] = v[a]; }
+        o[k++] = p11; o[k++] = p12; o[k++] = p22;
+        dump_tan(ts, (MASK & DIR_SIG) != 0, o, k);
+        dump_tan(tt, (MASK & DIR_P1) != 0, o, k);
+        dump_tan(tn, (MASK & DIR_P2) != 0, o, k);
+        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? mv[a] : 0.0; }
+    }
 };
 
 // tangent of one covariance-affecting direction; seeds are the derivatives of
@@ -167,7 +202,7 @@ SSDE_HD void ctcrw_step(CtcrwLane<D, MASK>& L, const CtcrwTrans& tr, double h, c
     const double F = L.p11 + h;                                // F = Z P Z' + H (line 223), scalar per dimension
     const double detF = (D == 1) ? F : F * F;                  // det(): lines 16-19
     const bool upd = !na && (detF > 0.0);                      // lines 214, 226
-    const double iF = upd ? 1.0 / F : 0.0;
+    const double iF = upd ? rcp(F) : 0.0;
     double u[D];
     double su2 = 0.0;
     for (int a = 0; a < D; a++) { u[a] = upd ? y[a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }  // line 221
@@ -267,6 +302,26 @@ struct ScalLane {
         accq = 0.0;
         ts.init(); t1.init(); t2.init();
     }
+    SSDE_HD void reset_acc() {
+        ld.init();
+        accq = 0.0;
+        ts.g = t1.g = t2.g = 0.0;
+        for (int a = 0; a < D; a++) gmu[a] = 0.0;
+    }
+    static constexpr int NSTATE = 4 * (D + 1) + D;
+    SSDE_HD static void dump_tan(const ScalTan<D>& t, bool on, double* o, int& k) {
+        o[k++] = on ? t.p : 0.0;
+        for (int a = 0; a < D; a++) o[k++] = on ? t.x[a] : 0.0;
+    }
+    SSDE_HD void dump(double* o) const {
+        int k = 0;
+        for (int a = 0; a < D; a++) o[k++] = x[a];
+        o[k++] = p;
+        dump_tan(ts, (MASK & DIR_SIG) != 0, o, k);
+        dump_tan(t1, (MASK & DIR_P1) != 0, o, k);
+        dump_tan(t2, (MASK & DIR_P2) != 0, o, k);
+        for (int a = 0; a < D; a++) o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0;
+    }
 };
 
 template <int D>
@@ -293,7 +348,7 @@ SSDE_HD void scal_step(ScalLane<D, MASK>& L, const ScalTrans& tr, double h, cons
                        bool na) {
     const double F = L.p + h;
     const bool upd = !na && (fabs(F) > 0.0);
-    const double iF = upd ? 1.0 / F : 0.0;
+    const double iF = upd ? rcp(F) : 0.0;
     double u[D];
     double su2 = 0.0;
     for (int a = 0; a < D; a++) { u[a] = upd ? y[a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }

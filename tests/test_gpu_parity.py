@@ -178,3 +178,78 @@ def test_error_paths():
     v = eng.eval(bad, order=0)
     assert not np.isfinite(v) or v > 0
     eng.close()
+
+
+# ---- time windows (k_iso.hip) ------------------------------------------------------------------------
+def _long_tracks(model="CTCRW", M=130, T=4000, seed=13):
+    ID, times, obs = simulate(model, M, T, 2, seed=seed)
+    return ID, times, obs
+
+
+@pytest.mark.parametrize("model,par", [("CTCRW", [-1.5, 0.0, 0.0, 0.5, 0.0]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]),
+                                       ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
+def test_time_windows_match_sequential_and_oracle(model, par, monkeypatch):
+    ID, times, obs = _long_tracks(model)
+    par = np.array(par)
+    pb = capi.Problem(model, ID, times, obs)
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    info = eng.info()
+    assert info["lanes_per_track"] > 1 and info["window"] > 0 and info["window_check"] <= capi.WINDOW_TOL
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    seq = capi.Engine(pb)
+    vs, gs = seq.eval(par)
+    assert seq.info()["lanes_per_track"] == 1
+    assert abs(v - vs) <= 1e-12 * abs(vs)
+    assert np.max(np.abs(g - gs)) <= 1e-10 * np.max(np.abs(gs))
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    eng.close(); seq.close()
+
+
+def test_short_overlap_is_detected_and_repaired(monkeypatch):
+    """A deliberately useless warm-up (4 rows) must fail the hand-over check and be repaired by
+    ssde_eval (longer overlap, finally one sequential window) -- never returned silently."""
+    ID, times, obs = _long_tracks()
+    par = np.array([0.5, 0.0, 0.0, 0.5, 0.0])      # sigma_obs = 1.6: slow forgetting
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    monkeypatch.setenv("SSDE_WINDOW", "4")
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    info = eng.info()
+    assert info["window_retries"] >= 1
+    assert info["window_check"] <= capi.WINDOW_TOL or info["lanes_per_track"] == 1
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    eng.close()
+
+
+def test_no_forgetting_falls_back_to_sequential():
+    ID, times, obs = _long_tracks(M=70, T=2000)
+    par = np.array([6.0, 0.0, 0.0, 0.5, 0.0])      # sigma_obs = 400: the filter barely updates
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    eng.close()
+
+
+def test_windows_with_missing_rows_and_irregular_times():
+    rng = np.random.default_rng(5)
+    ID, times, obs = _long_tracks(M=100, T=3000)
+    times = np.cumsum(rng.uniform(0.2, 1.8, size=len(ID)))
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    na = (rng.random(len(ID)) < 0.2) & ~first
+    obs[na] = np.nan
+    # a long gap of missing rows in every track: no forgetting across it
+    for m in range(100):
+        obs[m * 3000 + 1400: m * 3000 + 1460] = np.nan
+    par = np.array([-1.0, 0.02, -0.01, 0.4, 0.1])
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    assert eng.info()["window_check"] <= capi.WINDOW_TOL or eng.info()["lanes_per_track"] == 1
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    eng.close()
