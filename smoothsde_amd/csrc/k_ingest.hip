@@ -19,7 +19,7 @@ __global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
     const int ns = A.lane_nsteps[g * WAVE + lane];
     double* out = A.tiles + A.group_off[g] + lane;
     const int C = A.C, d = A.d;
-    double dmin = INFINITY, dmax = -INFINITY;
+    double dmin = INFINITY, dmax = -INFINITY, seen_nan = 0.0;
     for (int s = s_lo; s < s_hi; s++) {
         double* o = out + (int64_t)s * C * WAVE;
         if (s < ns) {
@@ -28,7 +28,11 @@ __global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
             // the engine never uses that prediction for the likelihood, only ssde_report shows it)
             o[0] = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
             if (s < ns - 1) { dmin = fmin(dmin, o[0]); dmax = fmax(dmax, o[0]); if (o[0] != o[0]) dmax = INFINITY; }
-            for (int a = 0; a < d; a++) o[(1 + a) * WAVE] = A.obs[i + (int64_t)a * A.n];
+            for (int a = 0; a < d; a++) {
+                const double yv = A.obs[i + (int64_t)a * A.n];
+                o[(1 + a) * WAVE] = yv;
+                if (yv != yv) seen_nan = 1.0;
+            }
             int c = 1 + d;
             if (A.h_array)
                 for (int k = 0; k < d * d; k++) o[(c++) * WAVE] = A.h_array[k + i * (int64_t)(d * d)];
@@ -41,10 +45,12 @@ __global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
     for (int o = 32; o > 0; o >>= 1) {
         dmin = fmin(dmin, __shfl_xor(dmin, o, 64));
         dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+        seen_nan = fmax(seen_nan, __shfl_xor(seen_nan, o, 64));
     }
     if (lane == 0) {
-        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 2 + 0] = dmin;
-        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 2 + 1] = dmax;
+        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 0] = dmin;
+        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 1] = dmax;
+        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 2] = seen_nan;
     }
     if (blockIdx.y == 0) {
         // initial state: a0 = first observation (velocities 0 for CTCRW), R/sde.R:549, 576-580

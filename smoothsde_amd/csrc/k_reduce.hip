@@ -42,7 +42,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs A) {
         if (tid < o) sh[tid] += sh[tid + o];
         __syncthreads();
     }
-    if (tid == 0) A.out[slot] = sh[0];
+    if (tid == 0) {
+        double r = sh[0];
+        for (int i = 0; i < 4; i++)
+            if (A.add_slot[i] == slot) r += A.add[i];
+        A.out[slot] = r;
+    }
 }
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s) {

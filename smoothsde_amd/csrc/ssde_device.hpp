@@ -26,6 +26,7 @@ namespace ssde {
 constexpr int WAVE = 64;
 constexpr int TILE_U = 4;        // steps per prefetch block of the register kernels
 constexpr int NACC_MAX = 8;      // 1 + 3 + D accumulators of the constant-coefficient kernels
+constexpr int GAIN_ROW = 16;     // doubles per row of the shared gain table (128-B rows for scalar loads)
 constexpr int NSTATE_MAX = 32;   // state + sensitivity components dumped at a window hand-over
 constexpr int MAX_PARTS = 4;     // direction split: at most one part per direction bit
 constexpr int MAX_PAR = 320;     // parameters passed by value in the kernel argument block
@@ -48,6 +49,14 @@ struct IsoArgs {
     double* partials;            // [n_parts * n_chunks][NACC][n_groups]
     double* bnd;                 // [n_parts * n_chunks][n_groups][2][NSTATE_MAX][64] window hand-over states
     double* chk;                 // [n_parts][n_chunks - 1][n_groups] largest relative hand-over disagreement
+    // shared-covariance path (regular time grid, no missing rows in the group): the covariance
+    // half of the filter is evaluated once per evaluation into `gain` (ssde_engine.hip) and the
+    // lanes run the mean half only
+    const double* gain;          // [gain_last + 1][GAIN_ROW] or NULL; rows beyond gain_last repeat the last one
+    int gain_last;
+    double gain_stat[GAIN_ROW];  // the stationary row (== row gain_last): windows past the transient keep it in SGPRs
+    const int32_t* group_flags;  // [n_groups] bit 0: every track of the group is NaN-free
+    int group_mode;              // 0: this launch handles every group; 1: only groups WITHOUT bit 0; 2: only groups WITH bit 0
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
     int window;                  // warm-up rows of a window, multiple of TILE_U
     int n_parts;
@@ -61,7 +70,7 @@ struct IsoArgs {
     CtcrwTrans ctr;
     ScalTrans str;
 };
-hipError_t launch_iso(int model, int d, const IsoArgs& a, hipStream_t s);
+hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
 int iso_nstate(int model, int d);
 
 // ---- final deterministic reduction (k_reduce.hip) --------------------------------------------
@@ -77,6 +86,8 @@ struct ReduceArgs {
     int n_out;                    // 1 + n_par_full
     const double* chk;
     int n_chk;
+    double add[4];                // data-independent terms of the shared-covariance path, added to
+    int16_t add_slot[4];          // out[add_slot[i]] (slot -1 = unused)
     int16_t map[MAX_PAR + 16];    // -> output slot (1 + full-par index) or -1
     double* out;                  // n_out + 1 doubles
 };
@@ -102,7 +113,7 @@ struct IngestArgs {
     const int64_t* lane_seg;     // [n_groups*64] segment index of the lane's track (for a0_src)
     int64_t n_seg;
     int sdim, model;
-    double* dt_minmax;           // [n_groups * ychunks * 2]: min / max of the intervals used INSIDE tracks
+    double* dt_minmax;           // [n_groups * ychunks * 3]: min / max of the intervals used INSIDE tracks, NaN seen
     int ychunks;
 };
 int ingest_ychunks(int n_groups);

@@ -101,6 +101,16 @@ struct ssde_handle {
     double last_check = 0.0;
     int n_retries = 0;
 
+    // shared-covariance path
+    DevBuf<int32_t> group_flags;
+    int n_clean_groups = 0;
+    bool use_shared = false;
+    std::vector<std::pair<int, int64_t>> clean_ns_hist;  // (scored rows, number of tracks) over NaN-free groups
+    DevBuf<double> gain_ring;
+    double* gain_pinned = nullptr;
+    size_t gain_rows_cap = 0;
+    int last_gain_rows = 0;
+
     // iso direction split
     int iso_parts = 1;
     int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
@@ -128,7 +138,8 @@ int fail(ssde_handle* h, int code, const std::string& msg) {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
-    h->bnd.release(); h->chk.release();
+    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release();
+    if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
     h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
@@ -372,7 +383,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
         }
         const int ych = ingest_ychunks(G);
         DevBuf<double> mm;
-        HIPCHK(h, mm.alloc((size_t)G * ych * 2));
+        HIPCHK(h, mm.alloc((size_t)G * ych * 3));
         IngestArgs ia;
         ia.times = p_times; ia.obs = p_obs; ia.h_array = h->has_h ? p_h : nullptr;
         ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = n;
@@ -382,10 +393,14 @@ int build(const ssde_desc* d, ssde_handle* h) {
         ia.a0_src = p_a0; ia.lane_seg = s_lane_seg.p; ia.n_seg = h->n_seg;
         ia.sdim = h->sdim; ia.model = d->model; ia.dt_minmax = mm.p; ia.ychunks = ych;
         HIPCHK(h, launch_ingest(ia, 0));
-        std::vector<double> mmh((size_t)G * ych * 2);
+        std::vector<double> mmh((size_t)G * ych * 3);
         HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));  // also syncs
         double dmin = INFINITY, dmax = -INFINITY;
-        for (size_t k = 0; k < mmh.size(); k += 2) { dmin = std::min(dmin, mmh[k]); dmax = std::max(dmax, mmh[k + 1]); }
+        std::vector<int32_t> gflags(G, 1);
+        for (size_t k = 0; k < mmh.size(); k += 3) {
+            dmin = std::min(dmin, mmh[k]); dmax = std::max(dmax, mmh[k + 1]);
+            if (mmh[k + 2] != 0.0) gflags[(k / 3) / ych] = 0;   // a NaN observation somewhere in the group
+        }
         h->uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
         h->dt_uniform = h->uniform_dt ? dmin : 0.0;
         h->dt_min = std::isfinite(dmin) ? dmin : 0.0;
@@ -395,6 +410,22 @@ int build(const ssde_desc* d, ssde_handle* h) {
 
         if (h->path == PATH_ISO) {
             choose_iso_split(h);
+            // shared-covariance path: regular grid + groups without missing rows
+            HIPCHK(h, h->group_flags.upload(gflags));
+            std::vector<int64_t> cnt;
+            for (int g = 0; g < G; g++) {
+                if (!gflags[g]) continue;
+                h->n_clean_groups++;
+                for (int l = 0; l < WAVE; l++) {
+                    const int ns = lane_ns[(size_t)g * WAVE + l];
+                    if (ns <= 0) continue;
+                    if ((size_t)ns >= cnt.size()) cnt.resize(ns + 1, 0);
+                    cnt[ns]++;
+                }
+            }
+            for (size_t ns = 1; ns < cnt.size(); ns++)
+                if (cnt[ns]) h->clean_ns_hist.push_back({(int)ns, cnt[ns]});
+            h->use_shared = h->uniform_dt && h->n_clean_groups > 0 && !getenv("SSDE_NO_SHARED");
             // time windows: enough (group, window, part) workgroups for ~2 waves on each of the 1024 SIMDs
             int glmax = 0;
             for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
@@ -402,6 +433,12 @@ int build(const ssde_desc* d, ssde_handle* h) {
             int want = (2048 + G * h->iso_parts - 1) / (G * h->iso_parts);
             if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
             h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * TILE_U))));
+            if (h->use_shared) {
+                h->gain_rows_cap = (size_t)glmax + 1;
+                HIPCHK(h, h->gain_ring.alloc((size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW));
+                HIPCHK(h, hipHostMalloc((void**)&h->gain_pinned, (size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW * 8,
+                                        hipHostMallocDefault));
+            }
             HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * h->max_chunks * G * 2 * NSTATE_MAX * WAVE));
             HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * h->max_chunks * G));
             h->partial_doubles = (size_t)MAX_PARTS * h->max_chunks * NACC_MAX * G;
@@ -421,6 +458,10 @@ int build(const ssde_desc* d, ssde_handle* h) {
         }
     }
 
+    if (h->path == PATH_ISO && h->use_shared) {
+        for (int i = 0; i < PAR_RING; i++) HIPCHK(h, hipEventCreateWithFlags(&h->par_ev[i], hipEventDisableTiming));
+        h->par_ev_ok = true;
+    }
     if (h->path != PATH_ISO) {
         SlotTable st;
         memset(&st, 0, sizeof(st));
@@ -510,6 +551,90 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     *window = nc > 1 ? W : 0;
 }
 
+// Shared-covariance path: run the covariance half of the filter (ssde_math.hpp) ONCE on the host
+// for the regular grid -- it does not depend on the observations -- until it is bitwise
+// stationary, upload the gains, and return the data-independent likelihood terms
+// (D/2 sum log F and its derivatives, weighted by how many tracks reach each row).
+template <int D>
+int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double add[4]) {
+    const int slot = h->par_next;
+    h->par_next = (h->par_next + 1) % PAR_RING;
+    HIPCHK(h, hipEventSynchronize(h->par_ev[slot]));
+    double* host = h->gain_pinned + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
+    double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
+    const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
+    std::vector<double> cum_ld, cum_g[NDIRP];
+    int last = 0;
+    (void)mask;
+    if (h->model == SSDE_MODEL_CTCRW) {
+        CtcrwCov<15> C;
+        C.init(a.p0[0], a.p0[1], a.p0[2]);
+        double ld = 0.0;
+        for (int t = 0; t < tmax; t++) {
+            const CtcrwCov<15> prev = C;
+            CtcrwGain G;
+            const double F = C.p11 + a.h;
+            ctcrw_cov_step<D, 15>(C, a.ctr, a.h, false, G);
+            double* r = host + (size_t)t * GAIN_ROW;
+            r[0] = G.iF; r[1] = G.k1; r[2] = G.k2; r[3] = G.bm;
+            for (int j = 0; j < NDIRP; j++) { r[4 + j] = G.diF[j]; r[7 + j] = G.dk1[j]; r[10 + j] = G.dk2[j]; }
+            r[13] = r[14] = r[15] = 0.0;
+            ld += (G.iF != 0.0) ? std::log(std::fabs(F)) : 0.0;
+            cum_ld.push_back(ld);
+            for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
+            last = t;
+            bool same = C.p11 == prev.p11 && C.p12 == prev.p12 && C.p22 == prev.p22;
+            for (int j = 0; j < NDIRP && same; j++)
+                same = C.d11[j] == prev.d11[j] && C.d12[j] == prev.d12[j] && C.d22[j] == prev.d22[j];
+            if (same) break;   // every later row repeats this one exactly
+        }
+    } else {
+        ScalCov<15> C;
+        C.init(a.p0[0]);
+        double ld = 0.0;
+        for (int t = 0; t < tmax; t++) {
+            const ScalCov<15> prev = C;
+            ScalGain G;
+            const double F = C.p + a.h;
+            if (h->model == SSDE_MODEL_OU_SSM) scal_cov_step<D, 15, true>(C, a.str, a.h, false, G);
+            else scal_cov_step<D, 15, false>(C, a.str, a.h, false, G);
+            double* r = host + (size_t)t * GAIN_ROW;
+            for (int k = 0; k < GAIN_ROW; k++) r[k] = 0.0;
+            r[0] = G.iF; r[1] = G.k;
+            for (int j = 0; j < NDIRP; j++) { r[4 + j] = G.diF[j]; r[7 + j] = G.dk[j]; }
+            ld += (G.iF != 0.0) ? std::log(std::fabs(F)) : 0.0;
+            cum_ld.push_back(ld);
+            for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
+            last = t;
+            bool same = C.p == prev.p;
+            for (int j = 0; j < NDIRP && same; j++) same = C.dp[j] == prev.dp[j];
+            if (same) break;
+        }
+    }
+    const int rows = last + 1;
+    h->last_gain_rows = rows;
+    HIPCHK(h, hipMemcpyAsync(dev, host, (size_t)rows * GAIN_ROW * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipEventRecord(h->par_ev[slot], s));
+    a.gain = dev;
+    a.gain_last = last;
+    for (int k = 0; k < GAIN_ROW; k++) a.gain_stat[k] = host[(size_t)last * GAIN_ROW + k];
+    // data-independent terms: a track with ns scored rows contributes cum(ns - 1); past the
+    // stationary row every further row adds the same increment
+    auto cum_at = [&](const std::vector<double>& c, int idx) {
+        if (idx <= last) return c[idx];
+        const double inc = last > 0 ? c[last] - c[last - 1] : c[last];
+        return c[last] + inc * (double)(idx - last);
+    };
+    double s_ld = 0.0, s_g[NDIRP] = {0, 0, 0};
+    for (auto& e : h->clean_ns_hist) {
+        s_ld += (double)e.second * cum_at(cum_ld, e.first - 1);
+        for (int j = 0; j < NDIRP; j++) s_g[j] += (double)e.second * cum_at(cum_g[j], e.first - 1);
+    }
+    add[0] = 0.5 * D * s_ld;
+    for (int j = 0; j < NDIRP; j++) add[1 + j] = 0.5 * D * s_g[j];
+    return SSDE_OK;
+}
+
 // upload the parameter vector for the dense / direct kernels; returns the device pointer
 int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev) {
     const int slot = h->par_next;
@@ -530,6 +655,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.n_value_parts = 1; ra.chunks_per_part = 1; ra.chk = nullptr; ra.n_chk = 0;
+    for (int i = 0; i < 4; i++) { ra.add[i] = 0.0; ra.add_slot[i] = -1; }
     ra.partials = h->partials.p;
     ra.n_out = 1 + L.n_full;
     ra.out = out_dev;
@@ -572,7 +698,25 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         plan_windows(h, a, &a.n_chunks, &a.window);
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
-        HIPCHK(h, launch_iso(h->model, h->d, a, s));
+        a.group_flags = h->group_flags.p;
+        a.group_mode = 0;
+        double add[4] = {0, 0, 0, 0};
+        if (h->use_shared) {
+            int st = (h->d == 1) ? build_gain_table<1>(h, a, h->iso_free_mask, s, add)
+                                 : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
+            if (st) return st;
+            a.group_mode = 3;
+        }
+        HIPCHK(h, launch_iso(h->model, h->d, a, h->n_clean_groups < h->n_groups, s));
+        for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
+        if (h->use_shared) {
+            ra.add_slot[0] = 0;
+            if (order >= 1) {
+                const int pj[NDIRP] = {0, L.off_fe + h->d, L.off_fe + h->d + 1};
+                for (int j = 0; j < NDIRP; j++)
+                    if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
+            }
+        }
         const int nacc = 4 + h->d;
         ra.n_parts = a.n_parts * a.n_chunks; ra.nacc = nacc; ra.n_blocks = h->n_groups;
         ra.n_value_parts = a.n_chunks; ra.chunks_per_part = a.n_chunks;

@@ -114,147 +114,192 @@ SSDE_HD void ctcrw_trans(double dt, double tau, double beta, double sigma, Ctcrw
     o.dq22 = -A * e2 * beta * dt;
 }
 
-template <int D>
-struct CtcrwTan {  // one covariance-affecting direction (sigma_obs, tau or nu)
-    double p11, p12, p22, x[D], v[D], g;
-    SSDE_HD void init() {
-        p11 = p12 = p22 = g = 0.0;
-        for (int a = 0; a < D; a++) x[a] = v[a] = 0.0;
+// The step is split in two halves:
+//   * the COVARIANCE half (P, F, K and their sensitivities) never looks at the observations --
+//     only at the interval, the parameters and whether the row is missing;
+//   * the MEAN half (state, residual, quadratic form and their sensitivities) consumes the
+//     gains the covariance half produced.
+// The general kernel runs both halves per lane.  On a regular time grid without missing rows
+// the covariance half is identical for every track, so the engine evaluates it ONCE per
+// evaluation (ssde_engine.hip: gain table) and the lanes run the mean half only.
+constexpr int NDIRP = 3;  // covariance-affecting directions: 0 = log sigma_obs, 1 = par[n_dim], 2 = par[n_dim+1]
+
+struct CtcrwGain {  // what one row's covariance half hands to the mean half
+    double iF, k1, k2, bm;                       // bm = 0 only in CTCRW's detF <= 0 branch (Q3)
+    double diF[NDIRP], dk1[NDIRP], dk2[NDIRP];
+};
+
+template <int MASK>
+struct CtcrwCov {
+    double p11, p12, p22;
+    double d11[NDIRP], d12[NDIRP], d22[NDIRP];
+    LogAcc ld;          // sum log|F|
+    double gld[NDIRP];  // sum dF/F per direction
+    SSDE_HD void init(double p0_11, double p0_12, double p0_22) {
+        p11 = p0_11; p12 = p0_12; p22 = p0_22;
+        for (int j = 0; j < NDIRP; j++) d11[j] = d12[j] = d22[j] = gld[j] = 0.0;
+        ld.init();
+    }
+    SSDE_HD void reset_acc() { ld.init(); for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
+};
+
+SSDE_HD constexpr int dir_bit(int j) { return j == 0 ? DIR_SIG : (j == 1 ? DIR_P1 : DIR_P2); }
+
+// covariance half of one row (nllk_ctcrw.hpp:223-229, 236, 240-241 and their derivatives)
+template <int D, int MASK>
+SSDE_HD void ctcrw_cov_step(CtcrwCov<MASK>& C, const CtcrwTrans& tr, double h, bool na, CtcrwGain& G) {
+    const double F = C.p11 + h;                                // F = Z P Z' + H (line 223), scalar per dimension
+    const double detF = (D == 1) ? F : F * F;                  // det(): lines 16-19
+    const bool upd = !na && (detF > 0.0);                      // lines 214, 226
+    const double iF = upd ? rcp(F) : 0.0;
+    C.ld.mul(upd ? F : 1.0);                                   // log(detF) = D log|F| (line 234)
+    const double tp11 = C.p11 + tr.t12 * C.p12, tp12 = C.p12 + tr.t12 * C.p22;  // T P
+    const double tp21 = tr.e * C.p12, tp22 = tr.e * C.p22;
+    const double k1 = tp11 * iF, k2 = tp21 * iF;               // K = T P Z' F^-1 (line 236)
+    G.iF = iF; G.k1 = k1; G.k2 = k2;
+    G.bm = (na || upd) ? 1.0 : 0.0;                            // Q3: detF <= 0 predicts WITHOUT B mu (lines 226-228)
+    for (int j = 0; j < NDIRP; j++) {
+        if (!(MASK & dir_bit(j))) { G.diF[j] = G.dk1[j] = G.dk2[j] = 0.0; continue; }
+        // seeds: derivatives of (h, e, t12, q11, q12, q22) in direction j
+        const double dh = (j == 0) ? 2.0 * h : 0.0;
+        const double de = (j == 1) ? tr.de : 0.0, dt12 = (j == 1) ? tr.dt12 : 0.0;
+        const double dq11 = (j == 1) ? tr.dq11 : (j == 2 ? 2.0 * tr.q11 : 0.0);
+        const double dq12 = (j == 1) ? tr.dq12 : (j == 2 ? 2.0 * tr.q12 : 0.0);
+        const double dq22 = (j == 1) ? tr.dq22 : (j == 2 ? 2.0 * tr.q22 : 0.0);
+        const double dF = C.d11[j] + dh;
+        const double diF = -iF * iF * dF;
+        C.gld[j] += dF * iF;
+        const double dtp11 = C.d11[j] + dt12 * C.p12 + tr.t12 * C.d12[j];
+        const double dtp12 = C.d12[j] + dt12 * C.p22 + tr.t12 * C.d22[j];
+        const double dtp21 = de * C.p12 + tr.e * C.d12[j];
+        const double dtp22 = de * C.p22 + tr.e * C.d22[j];
+        const double dk1 = dtp11 * iF + tp11 * diF;
+        const double dk2 = dtp21 * iF + tp21 * diF;
+        G.diF[j] = diF; G.dk1[j] = dk1; G.dk2[j] = dk2;
+        C.d11[j] = dtp11 * (1.0 - k1) - tp11 * dk1 + dtp12 * tr.t12 + tp12 * dt12 + dq11;
+        C.d12[j] = -dtp11 * k2 - tp11 * dk2 + dtp12 * tr.e + tp12 * de + dq12;
+        C.d22[j] = -dtp21 * k2 - tp21 * dk2 + dtp22 * tr.e + tp22 * de + dq22;
+    }
+    const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11;  // P = T P (T - K Z)' + Q (lines 240-241)
+    const double n12 = -tp11 * k2 + tp12 * tr.e + tr.q12;
+    const double n22 = -tp21 * k2 + tp22 * tr.e + tr.q22;
+    C.p11 = n11; C.p12 = n12; C.p22 = n22;
+}
+
+template <int D, int MASK>
+struct CtcrwMean {
+    double x[D], v[D];
+    double tx[NDIRP][D], tv[NDIRP][D];   // sensitivities of (x, v) in the covariance-affecting directions
+    double mx[D], mv[D];                 // d/d mu_a touches dimension a only
+    double accq, gq[NDIRP], gmu[D];
+    // a0 = (x_1, v_1, x_2, v_2, ...): one row of the reference's a0 matrix (R/sde.R:576-580)
+    SSDE_HD void init(const double* a0) {
+        for (int a = 0; a < D; a++) {
+            x[a] = a0[2 * a]; v[a] = a0[2 * a + 1]; mx[a] = mv[a] = gmu[a] = 0.0;
+            for (int j = 0; j < NDIRP; j++) tx[j][a] = tv[j][a] = 0.0;
+        }
+        accq = 0.0;
+        for (int j = 0; j < NDIRP; j++) gq[j] = 0.0;
+    }
+    SSDE_HD void reset_acc() {
+        accq = 0.0;
+        for (int j = 0; j < NDIRP; j++) gq[j] = 0.0;
+        for (int a = 0; a < D; a++) gmu[a] = 0.0;
     }
 };
+
+// mean half of one row (nllk_ctcrw.hpp:221, 231-234, 238 and their derivatives);
+// scored = the row's observation enters the likelihood (not NA and detF > 0)
+template <int D, int MASK>
+SSDE_HD void ctcrw_mean_step(CtcrwMean<D, MASK>& M, const CtcrwTrans& tr, const CtcrwGain& G, const double* mu,
+                             const double* y, bool scored) {
+    double u[D];
+    double su2 = 0.0;
+    for (int a = 0; a < D; a++) { u[a] = scored ? y[a] - M.x[a] : 0.0; su2 += u[a] * u[a]; }  // line 221
+    M.accq += G.iF * su2;                                                                    // u' F^-1 u
+    for (int j = 0; j < NDIRP; j++) {
+        if (!(MASK & dir_bit(j))) continue;
+        const double de = (j == 1) ? tr.de : 0.0, dt12 = (j == 1) ? tr.dt12 : 0.0;
+        double sud = 0.0;
+        double du[D];
+        for (int a = 0; a < D; a++) { du[a] = scored ? -M.tx[j][a] : 0.0; sud += u[a] * du[a]; }
+        M.gq[j] += 0.5 * G.diF[j] * su2 + G.iF * sud;
+        for (int a = 0; a < D; a++) {
+            const double bmu = G.bm * mu[a];   // d(B mu): db1 = -dt12, db2 = -de
+            const double nx = M.tx[j][a] + dt12 * M.v[a] + tr.t12 * M.tv[j][a] + G.dk1[j] * u[a] + G.k1 * du[a] - dt12 * bmu;
+            const double nv = de * M.v[a] + tr.e * M.tv[j][a] + G.dk2[j] * u[a] + G.k2 * du[a] - de * bmu;
+            M.tx[j][a] = nx; M.tv[j][a] = nv;
+        }
+    }
+    if (MASK & DIR_MU) {
+        for (int a = 0; a < D; a++) {
+            const double du = scored ? -M.mx[a] : 0.0;
+            M.gmu[a] += G.iF * u[a] * du;
+            const double nx = M.mx[a] + tr.t12 * M.mv[a] + G.k1 * du + G.bm * tr.b1;
+            const double nv = tr.e * M.mv[a] + G.k2 * du + G.bm * tr.b2;
+            M.mx[a] = nx; M.mv[a] = nv;
+        }
+    }
+    for (int a = 0; a < D; a++) {                              // a = T a + K u + B mu (line 238)
+        const double nx = M.x[a] + tr.t12 * M.v[a] + G.k1 * u[a] + G.bm * tr.b1 * mu[a];
+        const double nv = tr.e * M.v[a] + G.k2 * u[a] + G.bm * tr.b2 * mu[a];
+        M.x[a] = nx; M.v[a] = nv;
+    }
+}
 
 template <int D, int MASK>
 struct CtcrwLane {
-    double x[D], v[D], p11, p12, p22;
-    LogAcc ld;
-    double accq;
-    CtcrwTan<D> ts, tt, tn;      // DIR_SIG, DIR_P1 (log tau), DIR_P2 (log nu)
-    double mx[D], mv[D], gmu[D]; // DIR_MU: d/d mu_a touches dimension a only
-
-    // a0 = (x_1, v_1, x_2, v_2, ...): one row of the reference's a0 matrix (R/sde.R:576-580)
+    CtcrwCov<MASK> C;
+    CtcrwMean<D, MASK> M;
     SSDE_HD void init(const double* a0, double p0_11, double p0_12, double p0_22) {
-        for (int a = 0; a < D; a++) { x[a] = a0[2 * a]; v[a] = a0[2 * a + 1]; mx[a] = mv[a] = gmu[a] = 0.0; }
-        p11 = p0_11; p12 = p0_12; p22 = p0_22;
-        ld.init();
-        accq = 0.0;
-        ts.init(); tt.init(); tn.init();
+        C.init(p0_11, p0_12, p0_22);
+        M.init(a0);
     }
     // accumulators only (used when a time window starts scoring after its warm-up rows)
-    SSDE_HD void reset_acc() {
-        ld.init();
-        accq = 0.0;
-        ts.g = tt.g = tn.g = 0.0;
-        for (int a = 0; a < D; a++) gmu[a] = 0.0;
-    }
+    SSDE_HD void reset_acc() { C.reset_acc(); M.reset_acc(); }
     static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
-    SSDE_HD static void dump_tan(const CtcrwTan<D>& t, bool on, double* o, int& k) {
-        o[k++] = on ? t.p11 : 0.0; o[k++] = on ? t.p12 : 0.0; o[k++] = on ? t.p22 : 0.0;
-        for (int a = 0; a < D; a++) { o[k++] = on ? t.x[a] : 0.0; o[k++] = on ? t.v[a] : 0.0; }
-    }
     // filter state + sensitivities, for the window hand-over check
     SSDE_HD void dump(double* o) const {
         int k = 0;
-        for (int a = 0; a < D; a++) { o[k++] = x[a]; o[k++] = v[a]; }
-        o[k++] = p11; o[k++] = p12; o[k++] = p22;
-        dump_tan(ts, (MASK & DIR_SIG) != 0, o, k);
-        dump_tan(tt, (MASK & DIR_P1) != 0, o, k);
-        dump_tan(tn, (MASK & DIR_P2) != 0, o, k);
-        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? mv[a] : 0.0; }
+        for (int a = 0; a < D; a++) { o[k++] = M.x[a]; o[k++] = M.v[a]; }
+        o[k++] = C.p11; o[k++] = C.p12; o[k++] = C.p22;
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0;
+            o[k++] = on ? C.d11[j] : 0.0; o[k++] = on ? C.d12[j] : 0.0; o[k++] = on ? C.d22[j] : 0.0;
+            for (int a = 0; a < D; a++) { o[k++] = on ? M.tx[j][a] : 0.0; o[k++] = on ? M.tv[j][a] : 0.0; }
+        }
+        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? M.mv[a] : 0.0; }
     }
 };
-
-// tangent of one covariance-affecting direction; seeds are the derivatives of
-// (h, e, t12, b1, b2, q11, q12, q22) in that direction.
-template <int D>
-SSDE_HD void ctcrw_tan_step(CtcrwTan<D>& t, const double* v, double p12, double p22,
-                            const CtcrwTrans& tr, double iF, double su2, const double* u, double k1, double k2,
-                            double tp11, double tp12, double tp21, double bm, const double* mu, double dh,
-                            double de, double dt12, double dq11, double dq12, double dq22, bool upd) {
-    const double dF = t.p11 + dh;
-    const double diF = -iF * iF * dF;
-    double sud = 0.0;
-    double du[D];
-    for (int a = 0; a < D; a++) { du[a] = upd ? -t.x[a] : 0.0; sud += u[a] * du[a]; }
-    t.g += 0.5 * ((double)D * dF * iF + diF * su2) + iF * sud;
-    const double dtp11 = t.p11 + dt12 * p12 + tr.t12 * t.p12;
-    const double dtp12 = t.p12 + dt12 * p22 + tr.t12 * t.p22;
-    const double dtp21 = de * p12 + tr.e * t.p12;
-    const double dtp22 = de * p22 + tr.e * t.p22;
-    const double dk1 = dtp11 * iF + tp11 * diF;
-    const double dk2 = dtp21 * iF + tp21 * diF;
-    for (int a = 0; a < D; a++) {
-        const double bmu = bm * mu[a];
-        const double nx = t.x[a] + dt12 * v[a] + tr.t12 * t.v[a] + dk1 * u[a] + k1 * du[a] - dt12 * bmu;
-        const double nv = de * v[a] + tr.e * t.v[a] + dk2 * u[a] + k2 * du[a] - de * bmu;
-        t.x[a] = nx; t.v[a] = nv;
-    }
-    const double tp22 = tr.e * p22;
-    t.p11 = dtp11 * (1.0 - k1) - tp11 * dk1 + dtp12 * tr.t12 + tp12 * dt12 + dq11;
-    t.p12 = -dtp11 * k2 - tp11 * dk2 + dtp12 * tr.e + tp12 * de + dq12;
-    t.p22 = -dtp21 * k2 - tp21 * dk2 + dtp22 * tr.e + tp22 * de + dq22;
-}
 
 // One row of a track: score y (unless NA), then propagate over the interval described by tr.
 //   h = sigma_obs^2; mu[a] = mean velocity; na = obs(i,0) is NA (nllk_ctcrw.hpp:214)
 template <int D, int MASK>
 SSDE_HD void ctcrw_step(CtcrwLane<D, MASK>& L, const CtcrwTrans& tr, double h, const double* mu, const double* y,
                         bool na) {
-    const double F = L.p11 + h;                                // F = Z P Z' + H (line 223), scalar per dimension
-    const double detF = (D == 1) ? F : F * F;                  // det(): lines 16-19
-    const bool upd = !na && (detF > 0.0);                      // lines 214, 226
-    const double iF = upd ? rcp(F) : 0.0;
-    double u[D];
-    double su2 = 0.0;
-    for (int a = 0; a < D; a++) { u[a] = upd ? y[a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }  // line 221
-    L.ld.mul(upd ? F : 1.0);                                   // log(detF) = D log|F| (line 234)
-    L.accq += iF * su2;                                        // u' F^-1 u   (lines 231-233)
-    const double tp11 = L.p11 + tr.t12 * L.p12, tp12 = L.p12 + tr.t12 * L.p22;  // T P
-    const double tp21 = tr.e * L.p12, tp22 = tr.e * L.p22;
-    const double k1 = tp11 * iF, k2 = tp21 * iF;               // K = T P Z' F^-1 (line 236)
-    // Q3: the detF <= 0 branch of CTCRW predicts WITHOUT B mu (lines 226-228)
-    const double bm = (na || upd) ? 1.0 : 0.0;
-
-    if (MASK & DIR_SIG)
-        ctcrw_tan_step<D>(L.ts, L.v, L.p12, L.p22, tr, iF, su2, u, k1, k2, tp11, tp12, tp21, bm, mu,
-                          2.0 * h, 0.0, 0.0, 0.0, 0.0, 0.0, upd);
-    if (MASK & DIR_P1)
-        ctcrw_tan_step<D>(L.tt, L.v, L.p12, L.p22, tr, iF, su2, u, k1, k2, tp11, tp12, tp21, bm, mu,
-                          0.0, tr.de, tr.dt12, tr.dq11, tr.dq12, tr.dq22, upd);
-    if (MASK & DIR_P2)
-        ctcrw_tan_step<D>(L.tn, L.v, L.p12, L.p22, tr, iF, su2, u, k1, k2, tp11, tp12, tp21, bm, mu,
-                          0.0, 0.0, 0.0, 2.0 * tr.q11, 2.0 * tr.q12, 2.0 * tr.q22, upd);
-    if (MASK & DIR_MU) {
-        for (int a = 0; a < D; a++) {
-            const double du = upd ? -L.mx[a] : 0.0;
-            L.gmu[a] += iF * u[a] * du;
-            const double nx = L.mx[a] + tr.t12 * L.mv[a] + k1 * du + bm * tr.b1;
-            const double nv = tr.e * L.mv[a] + k2 * du + bm * tr.b2;
-            L.mx[a] = nx; L.mv[a] = nv;
-        }
-    }
-    for (int a = 0; a < D; a++) {                              // a = T a + K u + B mu (line 238)
-        const double nx = L.x[a] + tr.t12 * L.v[a] + k1 * u[a] + bm * tr.b1 * mu[a];
-        const double nv = tr.e * L.v[a] + k2 * u[a] + bm * tr.b2 * mu[a];
-        L.x[a] = nx; L.v[a] = nv;
-    }
-    const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11;  // P = T P (T - K Z)' + Q (lines 240-241)
-    const double n12 = -tp11 * k2 + tp12 * tr.e + tr.q12;
-    const double n22 = -tp21 * k2 + tp22 * tr.e + tr.q22;
-    L.p11 = n11; L.p12 = n12; L.p22 = n22;
+    CtcrwGain G;
+    ctcrw_cov_step<D, MASK>(L.C, tr, h, na, G);
+    ctcrw_mean_step<D, MASK>(L.M, tr, G, mu, y, G.iF != 0.0);
 }
 
-// lane totals: nllk contribution and gradient slots [sig, mu_0..mu_{D-1}, p1, p2]
+// totals: nllk contribution and gradient slots [sig, mu_0..mu_{D-1}, p1, p2]; the covariance
+// half contributes (D/2) log-determinant terms, the mean half the quadratic-form terms
 template <int D, int MASK>
-SSDE_HD void ctcrw_finish(const CtcrwLane<D, MASK>& L, double* out /* 1 + 3 + D */) {
-    out[0] = 0.5 * ((double)D * L.ld.value() + L.accq);
-    out[1] = (MASK & DIR_SIG) ? L.ts.g : 0.0;
-    for (int a = 0; a < D; a++) out[2 + a] = (MASK & DIR_MU) ? L.gmu[a] : 0.0;
-    out[2 + D] = (MASK & DIR_P1) ? L.tt.g : 0.0;
-    out[3 + D] = (MASK & DIR_P2) ? L.tn.g : 0.0;
+SSDE_HD void ctcrw_finish_parts(double ld, const double* gld, const CtcrwMean<D, MASK>& M, double* out /* 1 + 3 + D */) {
+    out[0] = 0.5 * ((double)D * ld + M.accq);
+    out[1] = (MASK & DIR_SIG) ? 0.5 * D * gld[0] + M.gq[0] : 0.0;
+    for (int a = 0; a < D; a++) out[2 + a] = (MASK & DIR_MU) ? M.gmu[a] : 0.0;
+    out[2 + D] = (MASK & DIR_P1) ? 0.5 * D * gld[1] + M.gq[1] : 0.0;
+    out[3 + D] = (MASK & DIR_P2) ? 0.5 * D * gld[2] + M.gq[2] : 0.0;
+}
+template <int D, int MASK>
+SSDE_HD void ctcrw_finish(const CtcrwLane<D, MASK>& L, double* out) {
+    ctcrw_finish_parts<D, MASK>(L.C.ld.value(), L.C.gld, L.M, out);
 }
 
 // ---------------------------------------------------------------------------------------
-// OU_SSM / BM_SSM, isotropic: state x[a], covariance p (scalar), transition a' = t a + c_a.
+// OU_SSM / BM_SSM, isotropic: state x[a], covariance p (scalar), transition a' = t a + b mu_a.
+// Same split into a covariance half and a mean half.
 // ---------------------------------------------------------------------------------------
 struct ScalTrans {
     double t, b, q;     // OU: t = e^{-dt/tau}, b = 1 - t, q = kappa (1 - e^{-2dt/tau});  BM: t = 1, b = dt, q = sigma^2 dt
@@ -282,101 +327,132 @@ SSDE_HD void bm_trans(double dt, double sigma, ScalTrans& o) {
     o.dq = 2.0 * o.q;
 }
 
-template <int D>
-struct ScalTan {
-    double p, x[D], g;
-    SSDE_HD void init() { p = g = 0.0; for (int a = 0; a < D; a++) x[a] = 0.0; }
+struct ScalGain {
+    double iF, k;
+    double diF[NDIRP], dk[NDIRP];
 };
+
+template <int MASK>
+struct ScalCov {
+    double p, dp[NDIRP];
+    LogAcc ld;
+    double gld[NDIRP];
+    SSDE_HD void init(double p0) { p = p0; for (int j = 0; j < NDIRP; j++) dp[j] = gld[j] = 0.0; ld.init(); }
+    SSDE_HD void reset_acc() { ld.init(); for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
+};
+
+// Both families take detF = exp(logdet F) > 0 unless F == 0 (nllk_ou_ssm.hpp:190-195,
+// nllk_bm_ssm.hpp:152-157) and keep the drift in every branch (Q3).
+template <int D, int MASK, bool HAS_P2>
+SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool na, ScalGain& G) {
+    const double F = C.p + h;
+    const bool upd = !na && (fabs(F) > 0.0);
+    const double iF = upd ? rcp(F) : 0.0;
+    C.ld.mul(upd ? F : 1.0);
+    const double tp = tr.t * C.p;
+    const double k = tp * iF;
+    G.iF = iF; G.k = k;
+    for (int j = 0; j < NDIRP; j++) {
+        if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) { G.diF[j] = G.dk[j] = 0.0; continue; }
+        const double dh = (j == 0) ? 2.0 * h : 0.0;
+        const double dt_ = (j == 1) ? tr.dt_ : 0.0;
+        const double dq = (j == 1) ? tr.dq : (j == 2 ? tr.q : 0.0);
+        const double dF = C.dp[j] + dh;
+        const double diF = -iF * iF * dF;
+        C.gld[j] += dF * iF;
+        const double dtp = dt_ * C.p + tr.t * C.dp[j];
+        const double dk = dtp * iF + tp * diF;
+        G.diF[j] = diF; G.dk[j] = dk;
+        C.dp[j] = dtp * (tr.t - k) + tp * (dt_ - dk) + dq;
+    }
+    C.p = tp * (tr.t - k) + tr.q;
+}
+
+template <int D, int MASK>
+struct ScalMean {
+    double x[D], tx[NDIRP][D], mx[D];
+    double accq, gq[NDIRP], gmu[D];
+    SSDE_HD void init(const double* a0) {
+        for (int a = 0; a < D; a++) {
+            x[a] = a0[a]; mx[a] = gmu[a] = 0.0;
+            for (int j = 0; j < NDIRP; j++) tx[j][a] = 0.0;
+        }
+        accq = 0.0;
+        for (int j = 0; j < NDIRP; j++) gq[j] = 0.0;
+    }
+    SSDE_HD void reset_acc() {
+        accq = 0.0;
+        for (int j = 0; j < NDIRP; j++) gq[j] = 0.0;
+        for (int a = 0; a < D; a++) gmu[a] = 0.0;
+    }
+};
+
+template <int D, int MASK, bool HAS_P2>
+SSDE_HD void scal_mean_step(ScalMean<D, MASK>& M, const ScalTrans& tr, const ScalGain& G, const double* mu,
+                            const double* y, bool scored) {
+    double u[D];
+    double su2 = 0.0;
+    for (int a = 0; a < D; a++) { u[a] = scored ? y[a] - M.x[a] : 0.0; su2 += u[a] * u[a]; }
+    M.accq += G.iF * su2;
+    for (int j = 0; j < NDIRP; j++) {
+        if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+        const double dt_ = (j == 1) ? tr.dt_ : 0.0, db = (j == 1) ? tr.db : 0.0;
+        double sud = 0.0;
+        double du[D];
+        for (int a = 0; a < D; a++) { du[a] = scored ? -M.tx[j][a] : 0.0; sud += u[a] * du[a]; }
+        M.gq[j] += 0.5 * G.diF[j] * su2 + G.iF * sud;
+        for (int a = 0; a < D; a++)
+            M.tx[j][a] = dt_ * M.x[a] + tr.t * M.tx[j][a] + G.dk[j] * u[a] + G.k * du[a] + db * mu[a];
+    }
+    if (MASK & DIR_MU) {
+        for (int a = 0; a < D; a++) {
+            const double du = scored ? -M.mx[a] : 0.0;
+            M.gmu[a] += G.iF * u[a] * du;
+            M.mx[a] = tr.t * M.mx[a] + G.k * du + tr.b;
+        }
+    }
+    for (int a = 0; a < D; a++) M.x[a] = tr.t * M.x[a] + G.k * u[a] + tr.b * mu[a];
+}
 
 template <int D, int MASK>
 struct ScalLane {
-    double x[D], p;
-    LogAcc ld;
-    double accq;
-    ScalTan<D> ts, t1, t2;
-    double mx[D], gmu[D];
-    SSDE_HD void init(const double* a0x, double p0) {
-        for (int a = 0; a < D; a++) { x[a] = a0x[a]; mx[a] = gmu[a] = 0.0; }
-        p = p0;
-        ld.init();
-        accq = 0.0;
-        ts.init(); t1.init(); t2.init();
-    }
-    SSDE_HD void reset_acc() {
-        ld.init();
-        accq = 0.0;
-        ts.g = t1.g = t2.g = 0.0;
-        for (int a = 0; a < D; a++) gmu[a] = 0.0;
-    }
+    ScalCov<MASK> C;
+    ScalMean<D, MASK> M;
+    SSDE_HD void init(const double* a0, double p0) { C.init(p0); M.init(a0); }
+    SSDE_HD void reset_acc() { C.reset_acc(); M.reset_acc(); }
     static constexpr int NSTATE = 4 * (D + 1) + D;
-    SSDE_HD static void dump_tan(const ScalTan<D>& t, bool on, double* o, int& k) {
-        o[k++] = on ? t.p : 0.0;
-        for (int a = 0; a < D; a++) o[k++] = on ? t.x[a] : 0.0;
-    }
     SSDE_HD void dump(double* o) const {
         int k = 0;
-        for (int a = 0; a < D; a++) o[k++] = x[a];
-        o[k++] = p;
-        dump_tan(ts, (MASK & DIR_SIG) != 0, o, k);
-        dump_tan(t1, (MASK & DIR_P1) != 0, o, k);
-        dump_tan(t2, (MASK & DIR_P2) != 0, o, k);
-        for (int a = 0; a < D; a++) o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0;
+        for (int a = 0; a < D; a++) o[k++] = M.x[a];
+        o[k++] = C.p;
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0;
+            o[k++] = on ? C.dp[j] : 0.0;
+            for (int a = 0; a < D; a++) o[k++] = on ? M.tx[j][a] : 0.0;
+        }
+        for (int a = 0; a < D; a++) o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0;
     }
 };
 
-template <int D>
-SSDE_HD void scal_tan_step(ScalTan<D>& t, const double* x, double p, const ScalTrans& tr, double iF, double su2,
-                           const double* u, double k, double tp, const double* mu, double dh, double dt_, double db,
-                           double dq, bool upd) {
-    const double dF = t.p + dh;
-    const double diF = -iF * iF * dF;
-    double sud = 0.0;
-    double du[D];
-    for (int a = 0; a < D; a++) { du[a] = upd ? -t.x[a] : 0.0; sud += u[a] * du[a]; }
-    t.g += 0.5 * ((double)D * dF * iF + diF * su2) + iF * sud;
-    const double dtp = dt_ * p + tr.t * t.p;
-    const double dk = dtp * iF + tp * diF;
-    for (int a = 0; a < D; a++)
-        t.x[a] = dt_ * x[a] + tr.t * t.x[a] + dk * u[a] + k * du[a] + db * mu[a];
-    t.p = dtp * (tr.t - k) + tp * (dt_ - dk) + dq;
-}
-
-// MODEL is M_OU_SSM or M_BM_SSM: both take detF = exp(logdet F) > 0 unless F == 0
-// (nllk_ou_ssm.hpp:190-195, nllk_bm_ssm.hpp:152-157) and keep the drift in every branch (Q3).
 template <int D, int MASK, bool HAS_P2>
 SSDE_HD void scal_step(ScalLane<D, MASK>& L, const ScalTrans& tr, double h, const double* mu, const double* y,
                        bool na) {
-    const double F = L.p + h;
-    const bool upd = !na && (fabs(F) > 0.0);
-    const double iF = upd ? rcp(F) : 0.0;
-    double u[D];
-    double su2 = 0.0;
-    for (int a = 0; a < D; a++) { u[a] = upd ? y[a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }
-    L.ld.mul(upd ? F : 1.0);
-    L.accq += iF * su2;
-    const double tp = tr.t * L.p;
-    const double k = tp * iF;
-    if (MASK & DIR_SIG) scal_tan_step<D>(L.ts, L.x, L.p, tr, iF, su2, u, k, tp, mu, 2.0 * h, 0.0, 0.0, 0.0, upd);
-    if (MASK & DIR_P1) scal_tan_step<D>(L.t1, L.x, L.p, tr, iF, su2, u, k, tp, mu, 0.0, tr.dt_, tr.db, tr.dq, upd);
-    if (HAS_P2 && (MASK & DIR_P2)) scal_tan_step<D>(L.t2, L.x, L.p, tr, iF, su2, u, k, tp, mu, 0.0, 0.0, 0.0, tr.q, upd);
-    if (MASK & DIR_MU) {
-        for (int a = 0; a < D; a++) {
-            const double du = upd ? -L.mx[a] : 0.0;
-            L.gmu[a] += iF * u[a] * du;
-            L.mx[a] = tr.t * L.mx[a] + k * du + tr.b;
-        }
-    }
-    for (int a = 0; a < D; a++) L.x[a] = tr.t * L.x[a] + k * u[a] + tr.b * mu[a];
-    L.p = tp * (tr.t - k) + tr.q;
+    ScalGain G;
+    scal_cov_step<D, MASK, HAS_P2>(L.C, tr, h, na, G);
+    scal_mean_step<D, MASK, HAS_P2>(L.M, tr, G, mu, y, G.iF != 0.0);
 }
 
 template <int D, int MASK>
-SSDE_HD void scal_finish(const ScalLane<D, MASK>& L, double* out /* 1 + 3 + D */) {
-    out[0] = 0.5 * ((double)D * L.ld.value() + L.accq);
-    out[1] = (MASK & DIR_SIG) ? L.ts.g : 0.0;
-    for (int a = 0; a < D; a++) out[2 + a] = (MASK & DIR_MU) ? L.gmu[a] : 0.0;
-    out[2 + D] = (MASK & DIR_P1) ? L.t1.g : 0.0;
-    out[3 + D] = (MASK & DIR_P2) ? L.t2.g : 0.0;
+SSDE_HD void scal_finish_parts(double ld, const double* gld, const ScalMean<D, MASK>& M, double* out /* 1 + 3 + D */) {
+    out[0] = 0.5 * ((double)D * ld + M.accq);
+    out[1] = (MASK & DIR_SIG) ? 0.5 * D * gld[0] + M.gq[0] : 0.0;
+    for (int a = 0; a < D; a++) out[2 + a] = (MASK & DIR_MU) ? M.gmu[a] : 0.0;
+    out[2 + D] = (MASK & DIR_P1) ? 0.5 * D * gld[1] + M.gq[1] : 0.0;
+    out[3 + D] = (MASK & DIR_P2) ? 0.5 * D * gld[2] + M.gq[2] : 0.0;
+}
+template <int D, int MASK>
+SSDE_HD void scal_finish(const ScalLane<D, MASK>& L, double* out) {
+    scal_finish_parts<D, MASK>(L.C.ld.value(), L.C.gld, L.M, out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -253,3 +253,39 @@ def test_windows_with_missing_rows_and_irregular_times():
     oval, ograd = _oracle(pb, par)
     _close(v, g, oval, ograd)
     eng.close()
+
+
+# ---- shared-covariance path (regular grid: covariance half evaluated once per evaluation) ---------------
+@pytest.mark.parametrize("model,par", [("CTCRW", [-1.2, 0.03, -0.02, 0.5, 0.1]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]),
+                                       ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
+@pytest.mark.parametrize("d", [1, 2])
+def test_shared_covariance_path_mixed_groups(model, par, d, monkeypatch):
+    """Regular grid; 300 ragged tracks of which the first 100 contain missing rows: their wavefront
+    groups take the general kernel, the NaN-free groups the shared-gain kernel."""
+    rng = np.random.default_rng(3)
+    ID, times, obs = simulate(model, 300, 900, d, seed=31)
+    keep = np.ones(len(ID), bool)
+    for m in range(300):
+        cut = rng.integers(0, 400)
+        if cut:
+            keep[m * 900 + 900 - cut: m * 900 + 900] = False
+    ID, obs = ID[keep], obs[keep]
+    times = np.arange(1, len(ID) + 1, dtype=float) * 0.5
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    na = (rng.random(len(ID)) < 0.03) & ~first & (ID < 100)
+    obs[na] = np.nan
+    par = np.array(par)
+    if d == 1:
+        par = np.delete(par, 2)
+    pb = capi.Problem(model, ID, times, obs)
+    eng = capi.Engine(pb)
+    assert eng.info()["uniform_dt"] == 1
+    v, g = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    monkeypatch.setenv("SSDE_NO_SHARED", "1")
+    gen = capi.Engine(pb)
+    v2, g2 = gen.eval(par)
+    assert abs(v - v2) <= 1e-12 * abs(v2)
+    assert np.max(np.abs(g - g2)) <= 1e-10 * np.max(np.abs(g2))
+    eng.close(); gen.close()
