@@ -90,7 +90,7 @@ struct LaneOps {  // OU_SSM / BM_SSM
 
 // window geometry shared by the kernel and the hand-over check
 __device__ __forceinline__ int chunk_len(int L, int n_chunks) {
-    return ((L + n_chunks - 1) / n_chunks + TILE_U - 1) / TILE_U * TILE_U;
+    return ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
 }
 
 template <int MODEL, int D, int MASK>
@@ -261,10 +261,10 @@ struct MeanOps {  // OU_SSM / BM_SSM
 };
 
 template <int D>
-__device__ __forceinline__ void load_obs_block(double (&dst)[TILE_U][D], const double* p) {
+__device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const double* p) {
     constexpr int C = 1 + D;
 #pragma unroll
-    for (int u = 0; u < TILE_U; u++)
+    for (int u = 0; u < SHARED_U; u++)
 #pragma unroll
         for (int a = 0; a < D; a++) dst[u][a] = p[(u * C + 1 + a) * WAVE];  // the dt channel is not read
 }
@@ -298,7 +298,7 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
 
-    double cur[TILE_U][D], nxt[TILE_U][D];
+    double cur[SHARED_U][D], nxt[SHARED_U][D];
     load_obs_block<D>(cur, base + (int64_t)s_begin * C * WAVE);
     {
         double a0[SD];
@@ -313,8 +313,8 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
         }
         M.init(a0);
     }
-    for (int s0 = s_begin; s0 < s_end; s0 += TILE_U) {
-        load_obs_block<D>(nxt, base + (int64_t)(s0 + TILE_U) * C * WAVE);
+    for (int s0 = s_begin; s0 < s_end; s0 += SHARED_U) {
+        load_obs_block<D>(nxt, base + (int64_t)(s0 + SHARED_U) * C * WAVE);  // TILE_SPARE keeps this in bounds
         if (s0 == s_acc && s_acc > s_begin) {
             double st[Ops::NSTATE];
             Ops::dump(M, st);
@@ -324,12 +324,12 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
             M.reset_acc();
         }
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++) {
+        for (int u = 0; u < SHARED_U; u++) {
             const double* row = STATIONARY ? A.gain_stat : gain + (int64_t)min(s0 + u, glast) * GAIN_ROW;
             if (s0 + u < ns) Ops::step(M, tr, row, mu, cur[u]);
         }
 #pragma unroll
-        for (int u = 0; u < TILE_U; u++)
+        for (int u = 0; u < SHARED_U; u++)
 #pragma unroll
             for (int a = 0; a < D; a++) cur[u][a] = nxt[u][a];
     }

@@ -341,7 +341,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             goff[g] = off;
             off += (int64_t)glen[g] * h->C * WAVE;
         }
-        h->tile_doubles = off + (int64_t)TILE_U * h->C * WAVE;  // spare prefetch block
+        h->tile_doubles = off + (int64_t)TILE_SPARE * h->C * WAVE;  // spare rows for prefetching ahead
         HIPCHK(h, h->tiles.alloc((size_t)h->tile_doubles));
         HIPCHK(h, hipMemset(h->tiles.p, 0, (size_t)h->tile_doubles * 8));
         HIPCHK(h, h->a0.alloc((size_t)G * h->sdim * WAVE));
@@ -432,7 +432,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             h->glen_max = glmax;
             int want = (2048 + G * h->iso_parts - 1) / (G * h->iso_parts);
             if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
-            h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * TILE_U))));
+            h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * WIN_ALIGN))));
             if (h->use_shared) {
                 h->gain_rows_cap = (size_t)glmax + 1;
                 HIPCHK(h, h->gain_ring.alloc((size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW));
@@ -538,7 +538,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     if (const char* e = getenv("SSDE_WINDOW")) W = std::max(1, atoi(e));  // testing: deliberately short overlaps
     if ((int64_t)W * h->window_boost > (int64_t)h->glen_max) return;     // longer than a track: sequential filter
     W *= h->window_boost;
-    W = (W + TILE_U - 1) / TILE_U * TILE_U;
+    W = (W + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
     // a window must be long enough to amortise its warm-up
     int glmax = 0;
     {
