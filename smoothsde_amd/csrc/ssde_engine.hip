@@ -564,8 +564,13 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
     std::vector<double> cum_ld, cum_g[NDIRP];
-    int last = 0;
+    int last = 0, stable = 0;
     (void)mask;
+    // Stationarity test.  In floating point the recursion ends in a last-bit limit cycle rather than a
+    // bitwise fixed point, so "stationary" = every component moved by less than 2e-15 relative for 4 rows
+    // in a row; the row reached then is used for all later rows (a 1e-15 relative perturbation of gains
+    // that themselves carry rounding errors of that size).
+    auto close = [](double a, double b) { return std::fabs(a - b) <= 2e-15 * (std::fabs(a) + std::fabs(b)) + 1e-300; };
     if (h->model == SSDE_MODEL_CTCRW) {
         CtcrwCov<15> C;
         C.init(a.p0[0], a.p0[1], a.p0[2]);
@@ -583,10 +588,11 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
             cum_ld.push_back(ld);
             for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
             last = t;
-            bool same = C.p11 == prev.p11 && C.p12 == prev.p12 && C.p22 == prev.p22;
+            bool same = close(C.p11, prev.p11) && close(C.p12, prev.p12) && close(C.p22, prev.p22);
             for (int j = 0; j < NDIRP && same; j++)
-                same = C.d11[j] == prev.d11[j] && C.d12[j] == prev.d12[j] && C.d22[j] == prev.d22[j];
-            if (same) break;   // every later row repeats this one exactly
+                same = close(C.d11[j], prev.d11[j]) && close(C.d12[j], prev.d12[j]) && close(C.d22[j], prev.d22[j]);
+            stable = same ? stable + 1 : 0;
+            if (stable >= 4) break;
         }
     } else {
         ScalCov<15> C;
@@ -606,9 +612,10 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
             cum_ld.push_back(ld);
             for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
             last = t;
-            bool same = C.p == prev.p;
-            for (int j = 0; j < NDIRP && same; j++) same = C.dp[j] == prev.dp[j];
-            if (same) break;
+            bool same = close(C.p, prev.p);
+            for (int j = 0; j < NDIRP && same; j++) same = close(C.dp[j], prev.dp[j]);
+            stable = same ? stable + 1 : 0;
+            if (stable >= 4) break;
         }
     }
     const int rows = last + 1;
