@@ -88,10 +88,6 @@ struct LaneOps {  // OU_SSM / BM_SSM
     __device__ static __forceinline__ void finish(const State& S, double* out) { scal_finish<D, MASK>(S, out); }
 };
 
-// window geometry shared by the kernel and the hand-over check
-__device__ __forceinline__ int chunk_len(int L, int n_chunks) {
-    return ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-}
 
 template <int MODEL, int D, int MASK>
 __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
@@ -173,219 +169,6 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     }
 }
 
-// Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
-// XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
-// get such ids because they stream the same rows.
-__device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part, int& chunk) {
-    const int id = blockIdx.x;
-    const int np = A.n_parts, nc = A.n_chunks;
-    const int hi = id >> 3;  // ((g/8) * nc + chunk) * np + part
-    part = hi % np;
-    chunk = (hi / np) % nc;
-    g = (hi / (np * nc)) * 8 + (id & 7);
-    return g < A.tv.n_groups;
-}
-
-// ---- shared-covariance variant: mean half only, gains from the per-evaluation table ------------
-template <int MODEL, int D, int MASK>
-struct MeanOps;
-template <int D, int MASK>
-struct MeanOps<M_CTCRW, D, MASK> {
-    typedef CtcrwMean<D, MASK> State;
-    typedef CtcrwTrans Trans;
-    static constexpr int SD = 2 * D;
-    __device__ static __forceinline__ Trans hoisted(const IsoArgs& A) { return A.ctr; }
-    __device__ static __forceinline__ void step(State& M, const Trans& tr, const double* __restrict__ row,
-                                                const double* mu, const double* y) {
-        CtcrwGain G;
-        G.iF = row[0]; G.k1 = row[1]; G.k2 = row[2]; G.bm = row[3];
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) { G.diF[j] = row[4 + j]; G.dk1[j] = row[7 + j]; G.dk2[j] = row[10 + j]; }
-        ctcrw_mean_step<D, MASK>(M, tr, G, mu, y, G.iF != 0.0);
-    }
-    __device__ static __forceinline__ void finish(const State& M, double* out) {
-        const double z[NDIRP] = {0.0, 0.0, 0.0};
-        ctcrw_finish_parts<D, MASK>(0.0, z, M, out);
-    }
-    __device__ static __forceinline__ void dump(const State& M, double* o) {
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = M.x[a]; o[k++] = M.v[a]; }
-        o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0;
-            o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) { o[k++] = on ? M.tx[j][a] : 0.0; o[k++] = on ? M.tv[j][a] : 0.0; }
-        }
-#pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? M.mv[a] : 0.0; }
-    }
-    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
-};
-template <int MODEL, int D, int MASK>
-struct MeanOps {  // OU_SSM / BM_SSM
-    typedef ScalMean<D, MASK> State;
-    typedef ScalTrans Trans;
-    static constexpr int SD = D;
-    __device__ static __forceinline__ Trans hoisted(const IsoArgs& A) { return A.str; }
-    __device__ static __forceinline__ void step(State& M, const Trans& tr, const double* __restrict__ row,
-                                                const double* mu, const double* y) {
-        ScalGain G;
-        G.iF = row[0]; G.k = row[1];
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) { G.diF[j] = row[4 + j]; G.dk[j] = row[7 + j]; }
-        scal_mean_step<D, MASK, MODEL == M_OU_SSM>(M, tr, G, mu, y, G.iF != 0.0);
-    }
-    __device__ static __forceinline__ void finish(const State& M, double* out) {
-        const double z[NDIRP] = {0.0, 0.0, 0.0};
-        scal_finish_parts<D, MASK>(0.0, z, M, out);
-    }
-    __device__ static __forceinline__ void dump(const State& M, double* o) {
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < D; a++) o[k++] = M.x[a];
-        o[k++] = 0.0;
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0;
-            o[k++] = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) o[k++] = on ? M.tx[j][a] : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < D; a++) o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0;
-    }
-    static constexpr int NSTATE = 4 * (D + 1) + D;
-};
-
-template <int D>
-__device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const double* p) {
-    constexpr int C = 1 + D;
-#pragma unroll
-    for (int u = 0; u < SHARED_U; u++)
-#pragma unroll
-        for (int a = 0; a < D; a++) dst[u][a] = p[(u * C + 1 + a) * WAVE];  // the dt channel is not read
-}
-
-// STATIONARY: the whole window lies past the covariance transient, every row uses A.gain_stat
-template <int MODEL, int D, int MASK, bool STATIONARY>
-__device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int part, int chunk) {
-    typedef MeanOps<MODEL, D, MASK> Ops;
-    constexpr int C = 1 + D;
-    constexpr int NACC = 4 + D;
-    constexpr int SD = Ops::SD;
-    const int lane = threadIdx.x;
-    const TileView& tv = A.tv;
-    const double* base = tv.tiles + tv.group_off[g] + lane;
-    const int L = tv.group_len[g];
-    const int ns = tv.lane_nsteps[g * WAVE + lane];
-    const int pc = part * A.n_chunks + chunk;
-    const double* __restrict__ gain = A.gain;
-    const int glast = A.gain_last;
-
-    int s_begin = 0, s_acc = 0, s_end = L;
-    if (A.n_chunks > 1) {
-        const int cl = chunk_len(L, A.n_chunks);
-        s_acc = min(L, chunk * cl);
-        s_end = min(L, s_acc + cl);
-        s_begin = max(0, s_acc - A.window);
-    }
-    typename Ops::State M;
-    const typename Ops::Trans tr = Ops::hoisted(A);
-    double mu[D];
-#pragma unroll
-    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
-
-    double cur[SHARED_U][D], nxt[SHARED_U][D];
-    load_obs_block<D>(cur, base + (int64_t)s_begin * C * WAVE);
-    {
-        double a0[SD];
-        if (s_begin == 0) {
-#pragma unroll
-            for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
-        } else {
-#pragma unroll
-            for (int c = 0; c < SD; c++) a0[c] = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) a0[(MODEL == M_CTCRW) ? 2 * a : a] = (cur[0][a] == cur[0][a]) ? cur[0][a] : 0.0;
-        }
-        M.init(a0);
-    }
-    for (int s0 = s_begin; s0 < s_end; s0 += SHARED_U) {
-        load_obs_block<D>(nxt, base + (int64_t)(s0 + SHARED_U) * C * WAVE);  // TILE_SPARE keeps this in bounds
-        if (s0 == s_acc && s_acc > s_begin) {
-            double st[Ops::NSTATE];
-            Ops::dump(M, st);
-            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
-#pragma unroll
-            for (int k = 0; k < Ops::NSTATE; k++) o[k * WAVE] = st[k];
-            M.reset_acc();
-        }
-#pragma unroll
-        for (int u = 0; u < SHARED_U; u++) {
-            const double* row = STATIONARY ? A.gain_stat : gain + (int64_t)min(s0 + u, glast) * GAIN_ROW;
-            if (s0 + u < ns) Ops::step(M, tr, row, mu, cur[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < SHARED_U; u++)
-#pragma unroll
-            for (int a = 0; a < D; a++) cur[u][a] = nxt[u][a];
-    }
-    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
-        double st[Ops::NSTATE];
-        Ops::dump(M, st);
-        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
-#pragma unroll
-        for (int k = 0; k < Ops::NSTATE; k++) o[k * WAVE] = st[k];
-    }
-    double out[NACC];
-    Ops::finish(M, out);
-    if (s_acc >= s_end) {
-#pragma unroll
-        for (int k = 0; k < NACC; k++) out[k] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < NACC; k++) {
-        const double t = wave_sum(out[k]);
-        if (lane == 0) A.partials[((int64_t)pc * NACC + k) * tv.n_groups + g] = t;
-    }
-}
-
-__device__ __forceinline__ bool group_selected(const IsoArgs& A, int g) {
-    if (A.group_mode == 0) return true;
-    const bool clean = (A.group_flags[g] & 1) != 0;
-    return A.group_mode == 2 ? clean : !clean;
-}
-
-template <int MODEL, int D>
-__global__ __launch_bounds__(WAVE) void iso_shared_kernel(const IsoArgs A) {
-    int g, part, chunk;
-    if (!decode_block(A, g, part, chunk)) return;
-    if (!group_selected(A, g)) return;
-    const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
-    // windows that start past the covariance transient never touch the table
-    bool stationary = false;
-    {
-        const int L = A.tv.group_len[g];
-        int s_begin = 0;
-        if (A.n_chunks > 1) s_begin = max(0, min(L, chunk * chunk_len(L, A.n_chunks)) - A.window);
-        stationary = s_begin >= A.gain_last;
-    }
-    switch (mask) {
-#define SSDE_CASE(M)                                                         \
-    case M:                                                                  \
-        if (stationary) run_lane_shared<MODEL, D, M, true>(A, g, part, chunk); \
-        else run_lane_shared<MODEL, D, M, false>(A, g, part, chunk);         \
-        break;
-        SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
-        SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
-#undef SSDE_CASE
-        default: break;
-    }
-}
-
 template <int MODEL, int D>
 __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
     int g, part, chunk;
@@ -447,7 +230,8 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
     if (model == MODEL && d == D) {                                                    \
         if (shared) {                                                                  \
             a.group_mode = 2;                                                          \
-            hipLaunchKernelGGL((iso_shared_kernel<MODEL, D>), grid, block, 0, s, a);   \
+            hipError_t es = launch_iso_shared(model, d, a, s);                         \
+            if (es != hipSuccess) return es;                                           \
             a.group_mode = 1;                                                          \
             if (any_dirty) hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a); \
         } else {                                                                       \

@@ -1,0 +1,388 @@
+// k_iso_shared.hip -- shared-covariance kernels for gfx950: constant coefficients, regular time
+// grid, track groups without missing rows (CTCRW, OU_SSM, BM_SSM).
+//
+// In that regime the covariance half of the Kalman filter (P, F, K and all their sensitivities;
+// ssde_math.hpp ctcrw_cov_step / scal_cov_step) does not depend on the observations and is the
+// same for every track, so ssde_engine.hip evaluates it ONCE per evaluation into a small gain
+// table that becomes stationary after the filter's transient (tens of rows).  The lanes run the
+// mean half only:
+//   * rows inside the transient read their gains from the table (wave-uniform addresses),
+//   * rows past it use the stationary gains held in scalar registers, with the update written as
+//     the minimal FMA chain (~62 fp64 instructions per row for 2-D CTCRW with three
+//     covariance directions, against ~245 for the general per-lane filter) and the quadratic
+//     forms accumulated as plain sums that are scaled once at the end.
+// Observations stream from the tiled HBM layout with coalesced 512-B wave loads, prefetched
+// SHARED_U rows ahead into registers; the dt channel is never read (16 B/row actual traffic
+// for 24 B/row of algorithmic input).  Time windows and their hand-over check work exactly as
+// in k_iso.hip, except that only the mean state needs a warm-up (the gains are exact).
+#include "ssde_device.hpp"
+
+namespace ssde {
+
+template <int D>
+__device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const double* p) {
+    constexpr int C = 1 + D;
+#pragma unroll
+    for (int u = 0; u < SHARED_U; u++)
+#pragma unroll
+        for (int a = 0; a < D; a++) dst[u][a] = p[(u * C + 1 + a) * WAVE];  // the dt channel is not read
+}
+
+// ---- CTCRW -------------------------------------------------------------------------------------
+template <int D, int MASK>
+struct SharedCtcrw {
+    static constexpr int SD = 2 * D;
+    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
+    CtcrwMean<D, MASK> M;          // state + table-phase accumulators
+    double acc2, sacc[NDIRP], macc[D];  // stationary-phase sums: u'u, u' tx_j, u_a mx_a
+    // stationary constants (wave-uniform)
+    double k1, k2, c1, t12, e, iF, hd[NDIRP], dk1[NDIRP], dk2[NDIRP], dt12, de, cb1, cb2;
+    double cx[D], cv[D], bmu[D];
+    CtcrwTrans tr;
+
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        tr = A.ctr;
+        const double* r = A.gain_stat;
+        iF = r[0]; k1 = r[1]; k2 = r[2];
+        const double bm = r[3];
+        c1 = 1.0 - k1; t12 = tr.t12; e = tr.e; dt12 = tr.dt12; de = tr.de;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = 0.5 * r[4 + j]; dk1[j] = r[7 + j]; dk2[j] = r[10 + j]; }
+        cb1 = bm * tr.b1; cb2 = bm * tr.b2;
+#pragma unroll
+        for (int a = 0; a < D; a++) { bmu[a] = bm * A.mu[a]; cx[a] = cb1 * A.mu[a]; cv[a] = cb2 * A.mu[a]; }
+    }
+    __device__ __forceinline__ void init(const double* a0) { M.init(a0); reset_acc(); }
+    __device__ __forceinline__ void reset_acc() {
+        M.reset_acc();
+        acc2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) sacc[j] = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) macc[a] = 0.0;
+    }
+    // table phase: generic mean half with the row's gains
+    __device__ __forceinline__ void step_table(const double* __restrict__ row, const double* mu, const double* y) {
+        CtcrwGain G;
+        G.iF = row[0]; G.k1 = row[1]; G.k2 = row[2]; G.bm = row[3];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { G.diF[j] = row[4 + j]; G.dk1[j] = row[7 + j]; G.dk2[j] = row[10 + j]; }
+        ctcrw_mean_step<D, MASK>(M, tr, G, mu, y, G.iF != 0.0);
+    }
+    // stationary phase: same recursion (nllk_ctcrw.hpp:221, 238 and its derivatives) with
+    // du = -tx folded in: tx' = (1-k1) tx + t12 tv + dk1 u [+ dt12 (v - B mu)], etc.
+    __device__ __forceinline__ void step_stat(const double* y) {
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double u = y[a] - M.x[a];
+            acc2 = fma(u, u, acc2);
+#pragma unroll
+            for (int j = 0; j < NDIRP; j++) {
+                if (!(MASK & dir_bit(j))) continue;
+                const double tx = M.tx[j][a], tv = M.tv[j][a];
+                sacc[j] = fma(u, tx, sacc[j]);
+                double nx = dk1[j] * u, nv = dk2[j] * u;
+                if (j == 1) {
+                    const double w = M.v[a] - bmu[a];
+                    nx = fma(dt12, w, nx);
+                    nv = fma(de, w, nv);
+                }
+                M.tx[j][a] = fma(c1, tx, fma(t12, tv, nx));
+                M.tv[j][a] = fma(e, tv, fma(-k2, tx, nv));
+            }
+            if (MASK & DIR_MU) {
+                const double mx = M.mx[a], mv = M.mv[a];
+                macc[a] = fma(u, mx, macc[a]);
+                M.mx[a] = fma(c1, mx, fma(t12, mv, cb1));
+                M.mv[a] = fma(e, mv, fma(-k2, mx, cb2));
+            }
+            const double x = M.x[a], v = M.v[a];
+            M.x[a] = fma(k1, u, fma(t12, v, x)) + cx[a];
+            M.v[a] = fma(k2, u, fma(e, v, cv[a]));
+        }
+    }
+    __device__ __forceinline__ void finish(double* out) const {
+        const double z[NDIRP] = {0.0, 0.0, 0.0};
+        ctcrw_finish_parts<D, MASK>(0.0, z, M, out);
+        out[0] += 0.5 * iF * acc2;
+        if (MASK & DIR_SIG) out[1] += hd[0] * acc2 - iF * sacc[0];
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) out[2 + a] -= iF * macc[a];
+        }
+        if (MASK & DIR_P1) out[2 + D] += hd[1] * acc2 - iF * sacc[1];
+        if (MASK & DIR_P2) out[3 + D] += hd[2] * acc2 - iF * sacc[2];
+    }
+    __device__ __forceinline__ void dump(double* o) const {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[k++] = M.x[a]; o[k++] = M.v[a]; }
+        o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0;
+            o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) { o[k++] = on ? M.tx[j][a] : 0.0; o[k++] = on ? M.tv[j][a] : 0.0; }
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? M.mv[a] : 0.0; }
+    }
+    __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
+    }
+};
+
+// ---- OU_SSM / BM_SSM ---------------------------------------------------------------------------
+template <int MODEL, int D, int MASK>
+struct SharedScal {
+    static constexpr int SD = D;
+    static constexpr int NSTATE = 4 * (D + 1) + D;
+    static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    ScalMean<D, MASK> M;
+    double acc2, sacc[NDIRP], macc[D];
+    double k, c, t, b, iF, hd[NDIRP], dk[NDIRP], dt_, cmu[D], dbmu[D];
+    ScalTrans tr;
+
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        tr = A.str;
+        const double* r = A.gain_stat;
+        iF = r[0]; k = r[1];
+        t = tr.t; b = tr.b; c = tr.t - k; dt_ = tr.dt_;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = 0.5 * r[4 + j]; dk[j] = r[7 + j]; }
+#pragma unroll
+        for (int a = 0; a < D; a++) { cmu[a] = tr.b * A.mu[a]; dbmu[a] = tr.db * A.mu[a]; }
+    }
+    __device__ __forceinline__ void init(const double* a0) { M.init(a0); reset_acc(); }
+    __device__ __forceinline__ void reset_acc() {
+        M.reset_acc();
+        acc2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) sacc[j] = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) macc[a] = 0.0;
+    }
+    __device__ __forceinline__ void step_table(const double* __restrict__ row, const double* mu, const double* y) {
+        ScalGain G;
+        G.iF = row[0]; G.k = row[1];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { G.diF[j] = row[4 + j]; G.dk[j] = row[7 + j]; }
+        scal_mean_step<D, MASK, HAS_P2>(M, tr, G, mu, y, G.iF != 0.0);
+    }
+    // x' = t x + k u + b mu;  tx' = (t - k) tx + dk u [+ dt_ x + db mu]   (nllk_ou_ssm.hpp:204, nllk_bm_ssm.hpp:166)
+    __device__ __forceinline__ void step_stat(const double* y) {
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double x = M.x[a];
+            const double u = y[a] - x;
+            acc2 = fma(u, u, acc2);
+#pragma unroll
+            for (int j = 0; j < NDIRP; j++) {
+                if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+                const double tx = M.tx[j][a];
+                sacc[j] = fma(u, tx, sacc[j]);
+                double nx = dk[j] * u;
+                if (j == 1) nx = fma(dt_, x, nx) + dbmu[a];
+                M.tx[j][a] = fma(c, tx, nx);
+            }
+            if (MASK & DIR_MU) {
+                const double mx = M.mx[a];
+                macc[a] = fma(u, mx, macc[a]);
+                M.mx[a] = fma(c, mx, b);
+            }
+            M.x[a] = fma(k, u, fma(t, x, cmu[a]));
+        }
+    }
+    __device__ __forceinline__ void finish(double* out) const {
+        const double z[NDIRP] = {0.0, 0.0, 0.0};
+        scal_finish_parts<D, MASK>(0.0, z, M, out);
+        out[0] += 0.5 * iF * acc2;
+        if (MASK & DIR_SIG) out[1] += hd[0] * acc2 - iF * sacc[0];
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) out[2 + a] -= iF * macc[a];
+        }
+        if (MASK & DIR_P1) out[2 + D] += hd[1] * acc2 - iF * sacc[1];
+        if (HAS_P2 && (MASK & DIR_P2)) out[3 + D] += hd[2] * acc2 - iF * sacc[2];
+    }
+    __device__ __forceinline__ void dump(double* o) const {
+        int kk = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) o[kk++] = M.x[a];
+        o[kk++] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0;
+            o[kk++] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) o[kk++] = on ? M.tx[j][a] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) o[kk++] = (MASK & DIR_MU) ? M.mx[a] : 0.0;
+    }
+    __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) a0[a] = (y[a] == y[a]) ? y[a] : 0.0;
+    }
+};
+
+template <int MODEL, int D, int MASK>
+struct SharedSel { typedef SharedScal<MODEL, D, MASK> type; };
+template <int D, int MASK>
+struct SharedSel<M_CTCRW, D, MASK> { typedef SharedCtcrw<D, MASK> type; };
+
+// rows [sa, sb) of the lane's window; STAT = stationary gains.  sa is a multiple of SHARED_U.
+template <bool STAT, int D, class Lane>
+__device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const double* base, int sa, int sb, int ns,
+                                            int ns_min, const double* mu) {
+    constexpr int C = 1 + D;
+    if (sa >= sb) return;
+    const double* __restrict__ gain = A.gain;
+    const int glast = A.gain_last;
+    double cur[SHARED_U][D], nxt[SHARED_U][D];
+    load_obs_block<D>(cur, base + (int64_t)sa * C * WAVE);
+    for (int s0 = sa; s0 < sb; s0 += SHARED_U) {
+        load_obs_block<D>(nxt, base + (int64_t)(s0 + SHARED_U) * C * WAVE);  // TILE_SPARE keeps this in bounds
+        if (s0 + SHARED_U <= ns_min) {
+            // every lane's track covers the whole block: no per-row predication
+#pragma unroll
+            for (int u = 0; u < SHARED_U; u++) {
+                if (STAT) S.step_stat(cur[u]);
+                else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, cur[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < SHARED_U; u++) {
+                if (s0 + u < ns) {
+                    if (STAT) S.step_stat(cur[u]);
+                    else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, cur[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SHARED_U; u++)
+#pragma unroll
+            for (int a = 0; a < D; a++) cur[u][a] = nxt[u][a];
+    }
+}
+
+template <int MODEL, int D, int MASK>
+__device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int part, int chunk) {
+    typedef typename SharedSel<MODEL, D, MASK>::type Lane;
+    constexpr int C = 1 + D;
+    constexpr int NACC = 4 + D;
+    constexpr int SD = Lane::SD;
+    const int lane = threadIdx.x;
+    const TileView& tv = A.tv;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int ns_min = ns;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ns_min = min(ns_min, __shfl_xor(ns_min, o, 64));
+    ns_min = __builtin_amdgcn_readfirstlane(ns_min);
+    const int pc = part * A.n_chunks + chunk;
+
+    int s_begin = 0, s_acc = 0, s_end = L;
+    if (A.n_chunks > 1) {
+        const int cl = chunk_len(L, A.n_chunks);
+        s_acc = min(L, chunk * cl);
+        s_end = min(L, s_acc + cl);
+        s_begin = max(0, s_acc - A.window);
+    }
+    // first row from which the stationary gains apply (gain_stat[0] == 0 would mean "never scored":
+    // that degenerate case stays on the table path)
+    int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+    if (A.gain_stat[0] == 0.0) s_stat = INT32_MAX;
+
+    Lane S;
+    S.setup(A);
+    double mu[D];
+#pragma unroll
+    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
+    {
+        double a0[SD];
+        if (s_begin == 0) {
+#pragma unroll
+            for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        } else {
+            double y0[D];
+#pragma unroll
+            for (int a = 0; a < D; a++) y0[a] = base[((int64_t)s_begin * C + 1 + a) * WAVE];
+            Lane::warm_a0(y0, a0);
+        }
+        S.init(a0);
+    }
+    // warm-up rows [s_begin, s_acc), then scored rows [s_acc, s_end); each split at s_stat
+    {
+        const int m = min(max(s_stat, s_begin), s_acc);
+        run_segment<false, D>(S, A, base, s_begin, m, ns, ns_min, mu);
+        run_segment<true, D>(S, A, base, m, s_acc, ns, ns_min, mu);
+    }
+    if (s_acc > s_begin) {
+        double st[Lane::NSTATE];
+        S.dump(st);
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < Lane::NSTATE; k++) o[k * WAVE] = st[k];
+        S.reset_acc();
+    }
+    {
+        const int m = min(max(s_stat, s_acc), s_end);
+        run_segment<false, D>(S, A, base, s_acc, m, ns, ns_min, mu);
+        run_segment<true, D>(S, A, base, m, s_end, ns, ns_min, mu);
+    }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
+        double st[Lane::NSTATE];
+        S.dump(st);
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < Lane::NSTATE; k++) o[k * WAVE] = st[k];
+    }
+    double out[NACC];
+    S.finish(out);
+    if (s_acc >= s_end) {
+#pragma unroll
+        for (int k = 0; k < NACC; k++) out[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; k++) {
+        const double t = wave_sum(out[k]);
+        if (lane == 0) A.partials[((int64_t)pc * NACC + k) * tv.n_groups + g] = t;
+    }
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(WAVE) void iso_shared_kernel(const IsoArgs A) {
+    int g, part, chunk;
+    if (!decode_block(A, g, part, chunk)) return;
+    if (!group_selected(A, g)) return;
+    const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
+    switch (mask) {
+#define SSDE_CASE(M) case M: run_lane_shared<MODEL, D, M>(A, g, part, chunk); break;
+        SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
+        SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
+#undef SSDE_CASE
+        default: break;
+    }
+}
+
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid(g8 * 8 * a.n_parts * a.n_chunks), block(WAVE);
+    if (grid.x == 0) return hipSuccess;
+#define SSDE_LAUNCH(MODEL, D)                                                          \
+    if (model == MODEL && d == D) {                                                    \
+        hipLaunchKernelGGL((iso_shared_kernel<MODEL, D>), grid, block, 0, s, a);       \
+        return hipGetLastError();                                                      \
+    }
+    SSDE_LAUNCH(M_CTCRW, 1) SSDE_LAUNCH(M_CTCRW, 2)
+    SSDE_LAUNCH(M_OU_SSM, 1) SSDE_LAUNCH(M_OU_SSM, 2)
+    SSDE_LAUNCH(M_BM_SSM, 1) SSDE_LAUNCH(M_BM_SSM, 2)
+#undef SSDE_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ssde

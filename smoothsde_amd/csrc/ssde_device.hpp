@@ -26,7 +26,7 @@ namespace ssde {
 constexpr int WAVE = 64;
 constexpr int TILE_U = 4;        // steps per prefetch block of the general register kernel
 constexpr int WIN_ALIGN = 16;    // time-window starts / lengths / warm-ups are multiples of this many rows
-constexpr int SHARED_U = 16;     // steps per prefetch block of the shared-covariance kernel (divides WIN_ALIGN)
+constexpr int SHARED_U = 8;      // steps per prefetch block of the shared-covariance kernel (divides WIN_ALIGN)
 constexpr int TILE_SPARE = 64;   // spare rows after the last group, so prefetching ahead stays in bounds
 constexpr int NACC_MAX = 8;      // 1 + 3 + D accumulators of the constant-coefficient kernels
 constexpr int GAIN_ROW = 16;     // doubles per row of the shared gain table (128-B rows for scalar loads)
@@ -74,6 +74,7 @@ struct IsoArgs {
     ScalTrans str;
 };
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s);
 int iso_nstate(int model, int d);
 
 // ---- final deterministic reduction (k_reduce.hip) --------------------------------------------
@@ -184,6 +185,30 @@ hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------------
 #if defined(__HIPCC__)
+// window geometry shared by the kernels and the hand-over check
+__device__ __forceinline__ int chunk_len(int L, int n_chunks) {
+    return ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+}
+// Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
+// XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
+// get such ids because they stream the same rows.
+__device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part, int& chunk) {
+    const int id = blockIdx.x;
+    const int np = A.n_parts, nc = A.n_chunks;
+    const int hi = id >> 3;  // ((g/8) * nc + chunk) * np + part
+    part = hi % np;
+    chunk = (hi / np) % nc;
+    g = (hi / (np * nc)) * 8 + (id & 7);
+    return g < A.tv.n_groups;
+}
+
+__device__ __forceinline__ bool group_selected(const IsoArgs& A, int g) {
+    if (A.group_mode == 0) return true;
+    const bool clean = (A.group_flags[g] & 1) != 0;
+    return A.group_mode == 2 ? clean : !clean;
+}
+
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
