@@ -289,6 +289,9 @@ _LIB = None
 
 
 def lib_path() -> str:
+    override = os.environ.get("SSDE_LIB")  # kernel-tuning builds (same ABI); the default is the in-tree library
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libssde_hip.so")
 
 

@@ -217,8 +217,9 @@ __global__ __launch_bounds__(WAVE) void window_check_kernel(const IsoArgs A, int
 
 int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2 * d : 4 * (d + 1) + d; }
 
-// a.group_mode: 0 = general kernel on every group; 3 = shared-covariance kernel on the NaN-free
-// groups and (when `any_dirty`) the general kernel on the others
+// a.group_mode: 0 = general kernel on every group; 3 = the shared-covariance kernels
+// (launch_iso_shared, issued by the engine on its side streams) own the NaN-free groups and this
+// launch runs the general kernel on the others (only when `any_dirty`)
 hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipStream_t s) {
     const int g8 = (a0.tv.n_groups + 7) / 8;
     dim3 grid(g8 * 8 * a0.n_parts * a0.n_chunks), block(WAVE);
@@ -229,9 +230,6 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
 #define SSDE_LAUNCH(MODEL, D)                                                          \
     if (model == MODEL && d == D) {                                                    \
         if (shared) {                                                                  \
-            a.group_mode = 2;                                                          \
-            hipError_t es = launch_iso_shared(model, d, a, s);                         \
-            if (es != hipSuccess) return es;                                           \
             a.group_mode = 1;                                                          \
             if (any_dirty) hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a); \
         } else {                                                                       \
@@ -246,12 +244,14 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
     if (!done) return hipErrorInvalidValue;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.n_chunks > 1) {
-        hipLaunchKernelGGL(window_check_kernel, dim3(a.tv.n_groups, a.n_chunks - 1, a.n_parts), block, 0, s, a,
-                           iso_nstate(model, d), a.chk);
-        e = hipGetLastError();
-    }
     return e;
+}
+
+hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s) {
+    if (a.n_chunks <= 1 || a.tv.n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_check_kernel, dim3(a.tv.n_groups, a.n_chunks - 1, a.n_parts), dim3(WAVE), 0, s, a,
+                       iso_nstate(model, d), a.chk);
+    return hipGetLastError();
 }
 
 }  // namespace ssde

@@ -42,15 +42,12 @@ struct SharedCtcrw {
 
     __device__ __forceinline__ void setup(const IsoArgs& A) {
         tr = A.ctr;
-        const double* r = A.gain_stat;
-        iF = r[0]; k1 = r[1]; k2 = r[2];
-        const double bm = r[3];
-        c1 = 1.0 - k1; t12 = tr.t12; e = tr.e; dt12 = tr.dt12; de = tr.de;
+        const double* c = A.statc;   // static indices into the kernel argument block: scalar loads
+        iF = c[0]; k1 = c[1]; k2 = c[2]; c1 = c[3]; t12 = c[4]; e = c[5]; dt12 = c[6]; de = c[7]; cb1 = c[8]; cb2 = c[9];
 #pragma unroll
-        for (int j = 0; j < NDIRP; j++) { hd[j] = 0.5 * r[4 + j]; dk1[j] = r[7 + j]; dk2[j] = r[10 + j]; }
-        cb1 = bm * tr.b1; cb2 = bm * tr.b2;
+        for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
 #pragma unroll
-        for (int a = 0; a < D; a++) { bmu[a] = bm * A.mu[a]; cx[a] = cb1 * A.mu[a]; cv[a] = cb2 * A.mu[a]; }
+        for (int a = 0; a < D; a++) { cx[a] = c[19 + a]; cv[a] = c[21 + a]; bmu[a] = c[23 + a]; }
     }
     __device__ __forceinline__ void init(const double* a0) { M.init(a0); reset_acc(); }
     __device__ __forceinline__ void reset_acc() {
@@ -147,13 +144,12 @@ struct SharedScal {
 
     __device__ __forceinline__ void setup(const IsoArgs& A) {
         tr = A.str;
-        const double* r = A.gain_stat;
-        iF = r[0]; k = r[1];
-        t = tr.t; b = tr.b; c = tr.t - k; dt_ = tr.dt_;
+        const double* cc = A.statc;
+        iF = cc[0]; k = cc[1]; c = cc[2]; t = cc[3]; b = cc[4]; dt_ = cc[5];
 #pragma unroll
-        for (int j = 0; j < NDIRP; j++) { hd[j] = 0.5 * r[4 + j]; dk[j] = r[7 + j]; }
+        for (int j = 0; j < NDIRP; j++) { hd[j] = cc[10 + j]; dk[j] = cc[13 + j]; }
 #pragma unroll
-        for (int a = 0; a < D; a++) { cmu[a] = tr.b * A.mu[a]; dbmu[a] = tr.db * A.mu[a]; }
+        for (int a = 0; a < D; a++) { cmu[a] = cc[19 + a]; dbmu[a] = cc[21 + a]; }
     }
     __device__ __forceinline__ void init(const double* a0) { M.init(a0); reset_acc(); }
     __device__ __forceinline__ void reset_acc() {
@@ -268,7 +264,9 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
     }
 }
 
-template <int MODEL, int D, int MASK>
+// STATONLY: the whole window (warm-up included) lies past the covariance transient -- the lean
+// kernel; otherwise the window touches the transient and also carries the table-phase code.
+template <int MODEL, int D, int MASK, bool STATONLY>
 __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int part, int chunk) {
     typedef typename SharedSel<MODEL, D, MASK>::type Lane;
     constexpr int C = 1 + D;
@@ -296,6 +294,7 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     // that degenerate case stays on the table path)
     int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
     if (A.gain_stat[0] == 0.0) s_stat = INT32_MAX;
+    if (STATONLY != (s_begin >= s_stat)) return;   // the other launch owns this window
 
     Lane S;
     S.setup(A);
@@ -317,8 +316,8 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     }
     // warm-up rows [s_begin, s_acc), then scored rows [s_acc, s_end); each split at s_stat
     {
-        const int m = min(max(s_stat, s_begin), s_acc);
-        run_segment<false, D>(S, A, base, s_begin, m, ns, ns_min, mu);
+        const int m = STATONLY ? s_begin : min(max(s_stat, s_begin), s_acc);
+        if (!STATONLY) run_segment<false, D>(S, A, base, s_begin, m, ns, ns_min, mu);
         run_segment<true, D>(S, A, base, m, s_acc, ns, ns_min, mu);
     }
     if (s_acc > s_begin) {
@@ -330,8 +329,8 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
         S.reset_acc();
     }
     {
-        const int m = min(max(s_stat, s_acc), s_end);
-        run_segment<false, D>(S, A, base, s_acc, m, ns, ns_min, mu);
+        const int m = STATONLY ? s_acc : min(max(s_stat, s_acc), s_end);
+        if (!STATONLY) run_segment<false, D>(S, A, base, s_acc, m, ns, ns_min, mu);
         run_segment<true, D>(S, A, base, m, s_end, ns, ns_min, mu);
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
@@ -354,34 +353,70 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     }
 }
 
-template <int MODEL, int D>
-__global__ __launch_bounds__(WAVE) void iso_shared_kernel(const IsoArgs A) {
+// One kernel per (model, dimension, direction mask, stat-only): the register allocation of a
+// kernel is the worst case over everything it contains, so the masks are NOT folded into one
+// kernel with a switch here (k_iso.hip does that for the general path).
+#ifndef SSDE_SHARED_MINWAVES
+#define SSDE_SHARED_MINWAVES 1
+#endif
+template <int MODEL, int D, int MASK, bool STATONLY>
+__global__ __launch_bounds__(WAVE, SSDE_SHARED_MINWAVES) void iso_shared_kernel(const IsoArgs A) {
     int g, part, chunk;
     if (!decode_block(A, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
-    const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
-    switch (mask) {
-#define SSDE_CASE(M) case M: run_lane_shared<MODEL, D, M>(A, g, part, chunk); break;
-        SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
-        SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
-#undef SSDE_CASE
-        default: break;
+    run_lane_shared<MODEL, D, MASK, STATONLY>(A, g, part, chunk);
+}
+
+// host side: the stationary constants (layout in ssde_device.hpp)
+void fill_stat_consts(int model, int d, IsoArgs& a) {
+    double* c = a.statc;
+    for (int i = 0; i < 32; i++) c[i] = 0.0;
+    const double* r = a.gain_stat;
+    if (model == M_CTCRW) {
+        const CtcrwTrans& tr = a.ctr;
+        const double bm = r[3];
+        c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = 1.0 - r[1]; c[4] = tr.t12; c[5] = tr.e; c[6] = tr.dt12; c[7] = tr.de;
+        c[8] = bm * tr.b1; c[9] = bm * tr.b2;
+        for (int j = 0; j < NDIRP; j++) { c[10 + j] = 0.5 * r[4 + j]; c[13 + j] = r[7 + j]; c[16 + j] = r[10 + j]; }
+        for (int k = 0; k < d; k++) { c[19 + k] = c[8] * a.mu[k]; c[21 + k] = c[9] * a.mu[k]; c[23 + k] = bm * a.mu[k]; }
+    } else {
+        const ScalTrans& tr = a.str;
+        c[0] = r[0]; c[1] = r[1]; c[2] = tr.t - r[1]; c[3] = tr.t; c[4] = tr.b; c[5] = tr.dt_;
+        for (int j = 0; j < NDIRP; j++) { c[10 + j] = 0.5 * r[4 + j]; c[13 + j] = r[7 + j]; }
+        for (int k = 0; k < d; k++) { c[19 + k] = tr.b * a.mu[k]; c[21 + k] = tr.db * a.mu[k]; }
     }
 }
 
-hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
-    const int g8 = (a.tv.n_groups + 7) / 8;
-    dim3 grid(g8 * 8 * a.n_parts * a.n_chunks), block(WAVE);
-    if (grid.x == 0) return hipSuccess;
-#define SSDE_LAUNCH(MODEL, D)                                                          \
-    if (model == MODEL && d == D) {                                                    \
-        hipLaunchKernelGGL((iso_shared_kernel<MODEL, D>), grid, block, 0, s, a);       \
-        return hipGetLastError();                                                      \
+template <int MODEL, int D>
+static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
+    dim3 block(WAVE);
+    switch (a.part_mask[0]) {
+#define SSDE_CASE(M)                                                                                     \
+    case M:                                                                                              \
+        if (a.stat_only) hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M, false>), grid, block, 0, s, a);          \
+        break;
+        SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
+        SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
+#undef SSDE_CASE
+        default: return hipErrorInvalidValue;
     }
-    SSDE_LAUNCH(M_CTCRW, 1) SSDE_LAUNCH(M_CTCRW, 2)
-    SSDE_LAUNCH(M_OU_SSM, 1) SSDE_LAUNCH(M_OU_SSM, 2)
-    SSDE_LAUNCH(M_BM_SSM, 1) SSDE_LAUNCH(M_BM_SSM, 2)
-#undef SSDE_LAUNCH
+    return hipGetLastError();
+}
+
+// the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0]);
+// a.stat_only selects the lean kernel (windows past the transient) or the transient kernel
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
+    if (a.n_parts != 1) return hipErrorInvalidValue;
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid(g8 * 8 * a.n_chunks);
+    if (grid.x == 0) return hipSuccess;
+    if (model == M_CTCRW && d == 1) return launch_masks<M_CTCRW, 1>(a, grid, s);
+    if (model == M_CTCRW && d == 2) return launch_masks<M_CTCRW, 2>(a, grid, s);
+    if (model == M_OU_SSM && d == 1) return launch_masks<M_OU_SSM, 1>(a, grid, s);
+    if (model == M_OU_SSM && d == 2) return launch_masks<M_OU_SSM, 2>(a, grid, s);
+    if (model == M_BM_SSM && d == 1) return launch_masks<M_BM_SSM, 1>(a, grid, s);
+    if (model == M_BM_SSM && d == 2) return launch_masks<M_BM_SSM, 2>(a, grid, s);
     return hipErrorInvalidValue;
 }
 

@@ -57,7 +57,14 @@ struct IsoArgs {
     // lanes run the mean half only
     const double* gain;          // [gain_last + 1][GAIN_ROW] or NULL; rows beyond gain_last repeat the last one
     int gain_last;
-    double gain_stat[GAIN_ROW];  // the stationary row (== row gain_last): windows past the transient keep it in SGPRs
+    double gain_stat[GAIN_ROW];  // the stationary row (== row gain_last)
+    // every wave-uniform constant of the stationary update, precomputed on the host so that the
+    // kernel receives them as scalar (SGPR) operands instead of recomputing them into VGPRs
+    //   CTCRW : 0 iF 1 k1 2 k2 3 c1=1-k1 4 t12 5 e 6 dt12 7 de 8 cb1 9 cb2 | 10+j hd_j | 13+j dk1_j | 16+j dk2_j
+    //           | 19+a cx_a | 21+a cv_a | 23+a bmu_a
+    //   OU/BM : 0 iF 1 k 2 c=t-k 3 t 4 b 5 dt_ | 10+j hd_j | 13+j dk_j | 19+a cmu_a | 21+a dbmu_a
+    double statc[32];
+    int stat_only;               // 1: this launch handles only windows that lie entirely past the transient
     const int32_t* group_flags;  // [n_groups] bit 0: every track of the group is NaN-free
     int group_mode;              // 0: this launch handles every group; 1: only groups WITHOUT bit 0; 2: only groups WITH bit 0
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
@@ -75,6 +82,8 @@ struct IsoArgs {
 };
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s);
+hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
+void fill_stat_consts(int model, int d, IsoArgs& a);
 int iso_nstate(int model, int d);
 
 // ---- final deterministic reduction (k_reduce.hip) --------------------------------------------

@@ -111,6 +111,10 @@ struct ssde_handle {
     size_t gain_rows_cap = 0;
     int last_gain_rows = 0;
 
+    // side streams: the kernels of one evaluation that do not depend on each other run concurrently
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+
     // iso direction split
     int iso_parts = 1;
     int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
@@ -140,6 +144,8 @@ void destroy(ssde_handle* h) {
     if (!h) return;
     h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
+    for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
     h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
@@ -425,7 +431,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             }
             for (size_t ns = 1; ns < cnt.size(); ns++)
                 if (cnt[ns]) h->clean_ns_hist.push_back({(int)ns, cnt[ns]});
-            h->use_shared = h->uniform_dt && h->n_clean_groups > 0 && !getenv("SSDE_NO_SHARED");
+            h->use_shared = h->uniform_dt && h->n_clean_groups > 0 && h->iso_parts == 1 && !getenv("SSDE_NO_SHARED");
             // time windows: enough (group, window, part) workgroups for ~2 waves on each of the 1024 SIMDs
             int glmax = 0;
             for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
@@ -459,6 +465,11 @@ int build(const ssde_desc* d, ssde_handle* h) {
     }
 
     if (h->path == PATH_ISO && h->use_shared) {
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < PAR_RING; i++) HIPCHK(h, hipEventCreateWithFlags(&h->par_ev[i], hipEventDisableTiming));
         h->par_ev_ok = true;
     }
@@ -625,6 +636,7 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     a.gain = dev;
     a.gain_last = last;
     for (int k = 0; k < GAIN_ROW; k++) a.gain_stat[k] = host[(size_t)last * GAIN_ROW + k];
+    fill_stat_consts(h->model, h->d, a);
     // data-independent terms: a track with ns scored rows contributes cum(ns - 1); past the
     // stationary row every further row adds the same increment
     auto cum_at = [&](const std::vector<double>& c, int idx) {
@@ -714,7 +726,30 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             if (st) return st;
             a.group_mode = 3;
         }
-        HIPCHK(h, launch_iso(h->model, h->d, a, h->n_clean_groups < h->n_groups, s));
+        if (h->use_shared) {
+            // three independent launches (stationary windows, transient windows, NaN-carrying groups):
+            // fork onto side streams so they share the chip, join before the hand-over check / reduction
+            HIPCHK(h, hipEventRecord(h->ev_fork, s));
+            IsoArgs b = a;
+            b.group_mode = 2;
+            b.stat_only = 0;
+            HIPCHK(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+            HIPCHK(h, launch_iso_shared(h->model, h->d, b, h->aux[0]));   // few, slower blocks first
+            HIPCHK(h, hipEventRecord(h->ev_join[0], h->aux[0]));
+            const bool any_dirty = h->n_clean_groups < h->n_groups;
+            if (any_dirty) {
+                HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
+                HIPCHK(h, launch_iso(h->model, h->d, a, true, h->aux[1]));
+                HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
+            }
+            b.stat_only = 1;
+            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s));
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
+            if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
+        } else {
+            HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+        }
+        HIPCHK(h, launch_window_check(h->model, h->d, a, s));
         for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
         if (h->use_shared) {
             ra.add_slot[0] = 0;
