@@ -1,0 +1,61 @@
+"""Multi-GPU evaluation: independent tracks shard over ranks, one all-reduce of the 1+p doubles.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU
+tests).  Tracks (ID segments) are independent -- the filter state is re-initialised at every ID
+change and the log-likelihood is a plain sum (/root/reference/src/nllk/nllk_ctcrw.hpp:196-200,
+234) -- so every rank owns a contiguous block of whole tracks for good, evaluates its partial
+[nllk, gradient] on its own GPU, and a single sum all-reduce of that tiny vector (latency-bound,
+a few hundred bytes) yields the batch value on every rank.  The parameter-only smoothing penalty
+is added once, after the reduction.  There is no other data-path collective.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_rows(ID, world_size: int, rank: int) -> Tuple[int, int]:
+    """Row range [lo, hi) of this rank: contiguous whole tracks, balanced by row count."""
+    ID = np.asarray(ID)
+    n = len(ID)
+    first = np.ones(n, dtype=bool)
+    first[1:] = ID[1:] != ID[:-1]
+    starts = np.append(np.flatnonzero(first), n)
+    # boundary k is the first segment start at or beyond k * n / world_size
+    cuts = [int(starts[np.searchsorted(starts, (k * n) // world_size, side="left")]) for k in range(world_size)] + [n]
+    return cuts[rank], cuts[rank + 1]
+
+
+class ShardedObjective:
+    """fn/gr over all ranks' tracks.
+
+    local_eval(par) -> torch tensor [nllk_data, grad (n_par_full), window_check] on the rank's device
+                       (Engine.eval_device on a GPU; the tests inject an oracle-backed callable)
+    penalty(par)    -> (value, grad) of the smoothing penalty (parameter-only, identical on every rank)
+    """
+
+    def __init__(self, local_eval: Callable, n_par_full: int, penalty: Optional[Callable] = None, group=None,
+                 on_window_failure: Optional[Callable] = None, window_tol: float = 1e-11):
+        self.local_eval, self.n_par_full, self.penalty = local_eval, n_par_full, penalty
+        self.group, self.on_window_failure, self.window_tol = group, on_window_failure, window_tol
+
+    def eval(self, par):
+        import torch.distributed as dist
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        for attempt in range(6):
+            out = self.local_eval(par)
+            if world > 1:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+            res = out.detach().cpu().numpy()
+            # every rank sees the same reduced check value, so every rank takes the same branch
+            if res[-1] <= self.window_tol * world or self.on_window_failure is None:
+                break
+            self.on_window_failure()
+        value, grad = float(res[0]), res[1:1 + self.n_par_full].copy()
+        if self.penalty is not None:
+            pv, pg = self.penalty(par)
+            value += pv
+            grad += pg
+        return value, grad

@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's `SDE` R6 class for the nllk/gradient path.
+
+The reference host is R (`SDE$new`, `$setup()`, `$fit()`, `logLik.SDE`:
+/root/reference/R/sde.R:45-182, 491-720, R/utility.R:115-123).  R is not in this image, so
+this module restates that surface in Python with the same names, argument meaning and error
+behaviour; the R glue that a maintainer would drop into the package is R_glue/ (see
+INTEGRATION.md).  What changes underneath: `$setup()` builds an `Engine` (HIP, via the C ABI)
+instead of calling `TMB::MakeADFun`, and returns an object with the same `par`, `fn`, `gr`
+members that `$fit()` hands to a BFGS optimiser (the reference uses `optim(method = "BFGS")`,
+R/sde.R:694-697).
+
+Out of scope here, as in SURVEY.md: mgcv smooth construction (stays in R; a B-spline stand-in
+is provided for `s(x, k=)` and an identity-penalised indicator block for `s(ID, bs="re")`),
+the Laplace approximation over `coeff_re` (`fit()` optimises the joint
+penalised likelihood with the smoothing parameters held at their current values and says so),
+sdreport, plotting, posterior simulation.
+"""
+from __future__ import annotations
+
+import re
+import time
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .synth import bspline_basis, second_difference_penalty
+
+PAR_NAMES = {
+    "BM": lambda d: _mu_names(d) + ["sigma"],
+    "BM_SSM": lambda d: _mu_names(d) + ["sigma"],
+    "OU": lambda d: _mu_names(d) + ["tau", "kappa"],
+    "OU_SSM": lambda d: _mu_names(d) + ["tau", "kappa"],
+    "CTCRW": lambda d: _mu_names(d) + ["tau", "nu"],
+}
+
+
+def _mu_names(d):  # c(mu = lapply(1:n_dim, ...)) names: "mu" for one dimension, "mu1", "mu2", ... otherwise
+    return ["mu"] if d == 1 else [f"mu{i + 1}" for i in range(d)]
+
+
+class Design:
+    """Pre-built design blocks of one SDE parameter (what mgcv::gam(fit=FALSE) gives the reference,
+    R/sde.R:396-424): X_fe (n x nsdf, first column the intercept), X_re (n x k) and the penalty
+    blocks S (one per smooth, sizes adding up to k)."""
+
+    def __init__(self, X_fe=None, X_re=None, S: Optional[Sequence] = None, names_fe=None, names_re=None):
+        self.X_fe = None if X_fe is None else np.asarray(X_fe, dtype=np.float64)
+        self.X_re = None if X_re is None else np.asarray(X_re, dtype=np.float64)
+        self.S = [] if S is None else [np.asarray(s, dtype=np.float64) for s in S]
+        self.names_fe, self.names_re = names_fe, names_re
+
+
+def _parse_formula(form: str, data: Dict[str, np.ndarray], n: int) -> Design:
+    """Tiny stand-in for mgcv's formula interface: `~ 1`, `~ x1 + x2`, `s(x, k = K)`, `s(ID, bs = "re")`."""
+    rhs = form.strip()
+    if rhs.startswith("~"):
+        rhs = rhs[1:]
+    terms = [t.strip() for t in re.split(r"\+(?![^()]*\))", rhs) if t.strip()]
+    X_fe, names_fe = [np.ones(n)], ["(Intercept)"]
+    X_re, S, names_re = [], [], []
+    for t in terms:
+        if t == "1":
+            continue
+        m = re.fullmatch(r"s\(\s*([A-Za-z_][\w.]*)\s*(?:,(.*))?\)", t)
+        if m:
+            var, opts = m.group(1), (m.group(2) or "")
+            if var not in data:
+                raise KeyError(f"variable '{var}' not found in 'data'")
+            if re.search(r"bs\s*=\s*[\"']re[\"']", opts):
+                codes, inv = np.unique(np.asarray(data[var]), return_inverse=True)
+                Z = np.zeros((n, len(codes)))
+                Z[np.arange(n), inv] = 1.0
+                X_re.append(Z)
+                S.append(np.eye(len(codes)))
+                names_re += [f"s({var}).{i + 1}" for i in range(len(codes))]
+            else:
+                km = re.search(r"k\s*=\s*(\d+)", opts)
+                k = int(km.group(1)) if km else 10
+                x = np.asarray(data[var], dtype=np.float64)
+                lo, hi = np.nanmin(x), np.nanmax(x)
+                xs = (x - lo) / (hi - lo) if hi > lo else np.zeros_like(x)
+                B = bspline_basis(xs, n_basis=k - 1)
+                X_re.append(B)
+                S.append(second_difference_penalty(k - 1))
+                names_re += [f"s({var}).{i + 1}" for i in range(k - 1)]
+        else:
+            if t not in data:
+                raise KeyError(f"variable '{t}' not found in 'data'")
+            X_fe.append(np.asarray(data[t], dtype=np.float64))
+            names_fe.append(t)
+    return Design(np.column_stack(X_fe), np.column_stack(X_re) if X_re else None, S, names_fe, names_re)
+
+
+class TmbObj:
+    """The members of a `MakeADFun` object that the reference uses: `par`, `fn`, `gr` over the FREE
+    parameters (fixed ones are held at their values, TMB's `map`).  `fn`/`gr` arrive as separate
+    calls with the same x (R/sde.R:694-697): one GPU evaluation serves both."""
+
+    def __init__(self, engine, par_full: np.ndarray, free: np.ndarray):
+        self.engine = engine
+        self.par_full = np.array(par_full, dtype=np.float64)
+        self.free = free
+        self.par = self.par_full[free].copy()
+        self._last_x = None
+        self._last = None
+        self.n_eval = 0
+
+    def _eval(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self._last_x is None or not np.array_equal(x, self._last_x):
+            full = self.par_full.copy()
+            full[self.free] = x
+            val, grad = self.engine.eval(full, order=1)
+            self._last_x, self._last = x.copy(), (val, grad[self.free])
+            self.n_eval += 1
+        return self._last
+
+    def fn(self, x=None):
+        return self._eval(self.par if x is None else x)[0]
+
+    def gr(self, x=None):
+        return self._eval(self.par if x is None else x)[1]
+
+
+class SDE:
+    def __init__(self, formulas=None, data=None, type=None, response=None, par0=None, fixpar=None, other_data=None):
+        if data is None or type is None or response is None:
+            raise TypeError("SDE(formulas, data, type, response, ...) needs data, type and response")
+        self.type_ = type
+        self.response_ = [response] if isinstance(response, str) else list(response)
+        self.fixpar_ = None if fixpar is None else list(fixpar)
+        self.other_data_ = other_data or {}
+        if hasattr(data, "to_dict") and hasattr(data, "columns"):
+            data = {c: data[c].to_numpy() for c in data.columns}
+        data = dict(data)
+        if any(r not in data for r in self.response_):
+            raise ValueError("'response' not found in 'data'")          # R/sde.R:51-52
+        if type in capi.UNSUPPORTED_MODELS:
+            raise NotImplementedError(f"SDE type {type!r} is outside this engine's scope")
+        if type not in PAR_NAMES:
+            raise ValueError("Unknown SDE type")
+        n_dim = len(self.response_)
+        names = PAR_NAMES[type](n_dim)
+        if formulas is None:
+            formulas = {k: "~1" for k in names}                         # R/sde.R:93-94
+        elif len(formulas) != len(names):
+            raise ValueError(f"'formulas' should be a list of length {len(names)} for the model {type}, "
+                             f"with components {', '.join(names)}")    # R/sde.R:95-100
+        elif list(formulas.keys()) != names:
+            raise ValueError(f"'formulas' should be a list with components {', '.join(names)}")
+        if self.fixpar_:
+            for f in self.fixpar_:
+                if not (isinstance(formulas[f], str) and formulas[f].replace(" ", "") == "~1"):
+                    raise ValueError("formulas should be ~1 for fixed parameters")   # R/sde.R:106-108
+        self.formulas_ = dict(formulas)
+        n = len(np.asarray(data[self.response_[0]]))
+        if "ID" not in data:
+            warnings.warn("No ID column found in 'data', assuming same ID for all observations")  # R/sde.R:112-115
+            data["ID"] = np.ones(n)
+        if "time" not in data:
+            raise ValueError("'data' should have a time column")        # R/sde.R:121-123
+        self.data_ = data
+        self.n_ = n
+        self.names_ = names
+        self.make_mat()
+        self.coeff_fe_ = np.zeros(int(np.sum(self.terms_["ncol_fe"])))   # R/sde.R:138-140
+        self.coeff_re_ = np.zeros(int(np.sum(self.terms_["ncol_re_par"])))
+        self.lambda_vals_ = np.ones(len(self.terms_["ncol_re"]))
+        if par0 is not None:
+            if len(par0) != len(names):
+                raise ValueError(f"'par0' should be of length {len(names)} with one entry for each SDE parameter "
+                                 f"({', '.join(names)})")               # R/sde.R:147-151
+            i0 = np.concatenate([[0], np.cumsum(self.terms_["ncol_fe"])[:-1]]).astype(int)
+            for i, nm in enumerate(names):                               # link: identity for mu*, log otherwise
+                self.coeff_fe_[i0[i]] = par0[i] if nm.startswith("mu") else np.log(par0[i])
+        self.tmb_obj_ = None
+        self.tmb_obj_joint_ = None
+        self.out_ = None
+        self.engine_ = None
+
+    # -- accessors (R/sde.R:188-360) --------------------------------------------------------------
+    def formulas(self): return self.formulas_
+    def data(self): return self.data_
+    def type(self): return self.type_
+    def response(self): return self.response_
+    def fixpar(self): return self.fixpar_
+    def coeff_fe(self): return self.coeff_fe_
+    def coeff_re(self): return self.coeff_re_
+    def lambda_(self): return self.lambda_vals_    # `lambda` is a Python keyword
+    def terms(self): return self.terms_
+    def mats(self): return self.mats_
+    def out(self): return self.out_
+    def tmb_obj(self): return self.tmb_obj_
+    def tmb_obj_joint(self): return self.tmb_obj_joint_
+
+    def obs(self):
+        return np.column_stack([np.asarray(self.data_[r], dtype=np.float64) for r in self.response_])
+
+    def ind_fixcoeff(self):
+        """Indices (in coeff_fe) of the coefficients of fixed SDE parameters (R/sde.R ind_fixcoeff)."""
+        if not self.fixpar_:
+            return np.zeros(0, dtype=int)
+        i0 = np.concatenate([[0], np.cumsum(self.terms_["ncol_fe"])[:-1]]).astype(int)
+        return np.array([i0[self.names_.index(f)] for f in self.fixpar_], dtype=int)
+
+    # -- design matrices (R/sde.R:378-455) -------------------------------------------------------------
+    def make_mat(self):
+        designs: List[Design] = []
+        for nm in self.names_:
+            f = self.formulas_[nm]
+            designs.append(f if isinstance(f, Design) else _parse_formula(f, self.data_, self.n_))
+        ncol_fe = [1 if d.X_fe is None else d.X_fe.shape[1] for d in designs]
+        ncol_re_par = [0 if d.X_re is None else d.X_re.shape[1] for d in designs]
+        ncol_re = [s.shape[0] for d in designs for s in d.S]
+        self.designs_ = designs
+        self.terms_ = dict(ncol_fe=np.array(ncol_fe), ncol_re=np.array(ncol_re, dtype=int),
+                           ncol_re_par=np.array(ncol_re_par))
+        self.mats_ = dict(X_list_fe=[d.X_fe for d in designs], X_list_re=[d.X_re for d in designs],
+                          S_list=[s for d in designs for s in d.S])
+        return self.mats_
+
+    # -- TMB setup counterpart (R/sde.R:491-670) -----------------------------------------------------------
+    def _problem(self, include_penalty=1, **over):
+        X_fe = []
+        for d in self.designs_:
+            # an intercept-only block is passed as "no column" (broadcast), SURVEY 7.3-5
+            X_fe.append(None if (d.X_fe is None or (d.X_fe.shape[1] == 1 and np.all(d.X_fe == 1.0))) else d.X_fe)
+        X_re = [d.X_re for d in self.designs_]
+        kw = dict(a0=None, P0=self.other_data_.get("P0"), H=self.other_data_.get("H"), include_penalty=include_penalty)
+        kw.update(over)
+        pb = capi.Problem(self.type_, self.data_["ID"], self.data_["time"], self.obs(), X_fe, X_re,
+                          self.mats_["S_list"], **kw)
+        fixed = pb.par_fixed.copy()
+        for k in self.ind_fixcoeff():                      # map$coeff_fe with NA for fixed coefficients
+            fixed[pb.off_fe + k] = 1
+        fixed[pb.off_lambda:pb.off_lambda + pb.n_smooth] = 1   # smoothing parameters are not optimised here (no Laplace)
+        pb.par_fixed = fixed
+        return pb
+
+    def _par_full(self, pb):
+        p = np.zeros(pb.n_par_full)
+        if pb.kalman:
+            p[0] = 0.0                                      # log_sigma_obs = 0 (R/sde.R:560, 590)
+        p[pb.off_fe:pb.off_fe + pb.n_fe] = self.coeff_fe_
+        p[pb.off_lambda:pb.off_lambda + pb.n_smooth] = np.log(self.lambda_vals_)
+        p[pb.off_re:pb.off_re + pb.n_re] = self.coeff_re_
+        return p
+
+    def setup(self, silent=True, map=None):
+        pb = self._problem(include_penalty=1)
+        self.problem_ = pb
+        self.engine_ = capi.Engine(pb)
+        self.tmb_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())
+        # joint object "excluding penalty" (R/sde.R:663-669): include_penalty = 0 is honoured by the
+        # direct families only (Q7); the Kalman families share the same engine
+        if pb.kalman or pb.n_smooth == 0:
+            self.tmb_obj_joint_ = self.tmb_obj_
+        else:
+            pbj = self._problem(include_penalty=0)
+            self.engine_joint_ = capi.Engine(pbj)
+            self.tmb_obj_joint_ = TmbObj(self.engine_joint_, self._par_full(pbj), pbj.free_index())
+        return self.tmb_obj_
+
+    def fit(self, silent=True, map=None, maxiter=200):
+        from scipy.optimize import minimize
+        if self.tmb_obj_ is None:
+            self.setup(silent=silent, map=map)
+        if self.problem_.n_smooth > 0:
+            warnings.warn("random effects present: optimising the joint penalised likelihood with the smoothing "
+                          "parameters fixed (the Laplace layer of TMB is outside this engine, SURVEY 8(f)-1)")
+        obj = self.tmb_obj_
+        t0 = time.perf_counter()
+        res = minimize(obj.fn, obj.par, jac=obj.gr, method="BFGS", options=dict(maxiter=maxiter))  # optim(..., "BFGS")
+        self.out_ = dict(par=res.x, value=res.fun, counts=(res.nfev, res.njev), convergence=int(not res.success),
+                         message=res.message, systime=time.perf_counter() - t0)
+        full = obj.par_full.copy()
+        full[obj.free] = res.x
+        pb = self.problem_
+        self.par_full_ = full
+        self.log_sigma_obs_ = full[0] if pb.kalman else None
+        self.coeff_fe_ = full[pb.off_fe:pb.off_fe + pb.n_fe].copy()        # R/sde.R:707-713
+        self.coeff_re_ = full[pb.off_re:pb.off_re + pb.n_re].copy()
+        return self.out_
+
+    def logLik(self):
+        """- tmb_obj_joint$fn(par_all) with attributes nobs (R/utility.R:115-123); df is the number of
+        free fixed-effect parameters (the random-effect EDF term needs sdreport's joint precision,
+        SURVEY 8(f)-2)."""
+        obj = self.tmb_obj_joint_
+        x = self.par_full_[obj.free] if getattr(self, "par_full_", None) is not None else obj.par
+        return dict(value=-obj.fn(x), df=len(self.tmb_obj_.par), nobs=self.n_)
+
+    def par(self, t=None):
+        """SDE parameters on the natural scale for every row (R/sde.R:749-856, new_data = NULL)."""
+        out = {}
+        fe_off = np.concatenate([[0], np.cumsum(self.terms_["ncol_fe"])]).astype(int)
+        re_off = np.concatenate([[0], np.cumsum(self.terms_["ncol_re_par"])]).astype(int)
+        for j, (nm, d) in enumerate(zip(self.names_, self.designs_)):
+            cf = self.coeff_fe_[fe_off[j]:fe_off[j + 1]]
+            lp = (np.full(self.n_, cf[0]) if d.X_fe is None else d.X_fe @ cf)
+            if d.X_re is not None:
+                lp = lp + d.X_re @ self.coeff_re_[re_off[j]:re_off[j + 1]]
+            out[nm] = lp if nm.startswith("mu") else np.exp(lp)
+        return out

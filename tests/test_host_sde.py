@@ -1,0 +1,87 @@
+"""CPU suite: the host-side mirror of the reference's SDE class -- the same three checks the reference's
+own test file makes (/root/reference/tests/testthat/test_sde.R:4-72: constructor works, missing columns
+are reported, coefficient vector lengths), plus parameter-vector bookkeeping."""
+import warnings
+
+import numpy as np
+import pytest
+
+from smoothsde_amd.sde import SDE, Design
+
+
+def _data(n_id=10, n_each=10, seed=1):
+    rng = np.random.default_rng(seed)
+    n = n_id * n_each
+    return dict(ID=np.repeat(np.arange(n_id), n_each), Z=np.cumsum(rng.normal(size=n)), x1=rng.normal(size=n),
+                x2=np.cumsum(rng.normal(0, 0.1, size=n)), time=np.arange(1, n + 1, dtype=float))
+
+
+def test_constructor_works():                                   # test_sde.R:4-15
+    d = _data()
+    sde = SDE(formulas={"mu": "~ x1", "sigma": "~ x2"}, data=d, type="BM", response="Z")
+    assert sde.type() == "BM" and sde.response() == ["Z"]
+
+
+def test_missing_columns_are_reported():                        # test_sde.R:17-51
+    d = _data()
+    d_noid = {k: v for k, v in d.items() if k != "ID"}
+    with pytest.warns(UserWarning, match="No ID column found"):
+        SDE(formulas={"mu": "~1", "sigma": "~1"}, data=d_noid, type="BM", response="Z")
+    with pytest.raises(ValueError, match="'response' not found in 'data'"):
+        SDE(formulas={"mu": "~1", "sigma": "~1"}, data=d, type="BM", response="nope")
+    with pytest.raises(KeyError, match="not found in 'data'"):
+        SDE(formulas={"mu": "~ x7", "sigma": "~1"}, data=d, type="BM", response="Z")
+    d_notime = {k: v for k, v in d.items() if k != "time"}
+    with pytest.raises(ValueError, match="should have a time column"):
+        SDE(formulas={"mu": "~1", "sigma": "~1"}, data=d_notime, type="BM", response="Z")
+
+
+def test_coefficient_vector_lengths():                          # test_sde.R:53-72
+    d = _data()
+    f = {"mu": '~ s(x1, k = 5, bs = "ts") + x2', "sigma": '~ s(ID, bs = "re") + s(x2, k = 5, bs = "ts")'}
+    sde = SDE(formulas=f, data=d, type="BM", response="Z")
+    assert len(sde.coeff_fe()) == 3
+    assert len(sde.coeff_re()) == 18
+    assert len(sde.lambda_()) == 3
+
+
+def test_formula_list_checks_and_par0():
+    d = _data()
+    with pytest.raises(ValueError, match="should be a list of length 4"):
+        SDE(formulas={"mu1": "~1"}, data=dict(d, Y=d["Z"]), type="CTCRW", response=["Z", "Y"])
+    with pytest.raises(ValueError, match="with components mu1, mu2, tau, nu"):
+        SDE(formulas={"a": "~1", "b": "~1", "c": "~1", "d": "~1"}, data=dict(d, Y=d["Z"]), type="CTCRW",
+            response=["Z", "Y"])
+    with pytest.raises(ValueError, match="formulas should be ~1 for fixed parameters"):
+        SDE(formulas={"mu": "~ x1", "sigma": "~1"}, data=d, type="BM", response="Z", fixpar=["mu"])
+    sde = SDE(data=dict(d, Y=d["Z"]), type="CTCRW", response=["Z", "Y"], par0=[0, 0, 2.0, 1.0], fixpar=["mu1", "mu2"])
+    assert np.allclose(sde.coeff_fe(), [0, 0, np.log(2.0), 0.0])
+    assert list(sde.ind_fixcoeff()) == [0, 1]
+    with pytest.raises(ValueError, match="'par0' should be of length 4"):
+        SDE(data=dict(d, Y=d["Z"]), type="CTCRW", response=["Z", "Y"], par0=[0, 1])
+    with pytest.raises(ValueError, match="Unknown SDE type"):
+        SDE(data=d, type="XYZ", response="Z")
+    with pytest.raises(NotImplementedError):
+        SDE(data=d, type="CIR", response="Z")
+
+
+def test_problem_layout_matches_tmb_parameter_order():
+    d = _data()
+    f = {"mu": "~ x1", "tau": '~ s(x2, k = 5)', "kappa": "~1"}
+    sde = SDE(formulas=f, data=d, type="OU_SSM", response="Z", fixpar=["kappa"])
+    pb = sde._problem()
+    # [log_sigma_obs | coeff_fe (2 + 1 + 1) | log_lambda (1) | coeff_re (4)]   (nllk_ou_ssm.hpp:105-110)
+    assert pb.n_par_full == 1 + 4 + 1 + 4
+    assert (pb.off_fe, pb.off_lambda, pb.off_re) == (1, 5, 6)
+    assert list(np.flatnonzero(pb.par_fixed)) == [4, 5]        # kappa's intercept, log_lambda
+    assert pb.X_fe[2] is None and pb.X_fe[0].shape == (100, 2) and pb.X_re[1].shape == (100, 4)
+
+
+def test_design_objects_are_accepted():
+    d = _data()
+    n = len(d["Z"])
+    des = Design(X_fe=np.column_stack([np.ones(n), d["x1"]]), X_re=np.random.default_rng(0).normal(size=(n, 3)),
+                 S=[np.eye(3)])
+    sde = SDE(formulas={"mu": des, "sigma": "~1"}, data=d, type="BM", response="Z")
+    assert len(sde.coeff_fe()) == 3 and len(sde.coeff_re()) == 3 and len(sde.lambda_()) == 1
+    assert np.allclose(sde.par()["sigma"], 1.0)

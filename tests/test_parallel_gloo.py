@@ -1,0 +1,86 @@
+"""CPU suite: the N > 1 path (track sharding + one all-reduce + penalty once) with world_size 2 over gloo.
+The per-rank evaluator is the ORACLE here (there is no GPU and no CPU fallback in the product); on a GPU the
+same ShardedObjective wraps Engine.eval_device (bench.py, tests/test_gpu_parallel.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smoothsde_amd.parallel import shard_rows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_rows_cover_whole_tracks():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 40, size=37)
+    ID = np.repeat(np.arange(37), lens)
+    for world in (1, 2, 3, 8):
+        cuts = [shard_rows(ID, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(ID)
+        for (a, b), (c, d) in zip(cuts[:-1], cuts[1:]):
+            assert b == c
+        for lo, hi in cuts:
+            if lo < hi and lo > 0:
+                assert ID[lo] != ID[lo - 1]
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cases import problem_from_spec
+    from golden_io import load_golden
+    from oracle_lib import oracle_eval
+    from smoothsde_amd import capi
+    from smoothsde_amd.parallel import ShardedObjective
+    rec = next(r for r in load_golden() if r["name"] == "CTCRW_d2_tv")
+    lo, hi = shard_rows(rec["ID"], world, rank)
+    sl = slice(lo, hi)
+    spec = dict(rec, ID=rec["ID"][sl], times=rec["times"][sl], obs=rec["obs"][sl],
+                X_fe=[None if x is None else x[sl] for x in rec["X_fe"]],
+                X_re=[None if x is None else x[sl] for x in rec["X_re"]])
+    pb = problem_from_spec(spec)
+    full = problem_from_spec(rec)
+
+    def local_eval(par):
+        v, g = oracle_eval(pb, par, order=1, data_only=True)
+        return torch.tensor(np.concatenate([[v], g, [0.0]]))
+
+    def penalty(par):
+        v_all, g_all = oracle_eval(full, par, order=1)
+        v_dat, g_dat = oracle_eval(full, par, order=1, data_only=True)
+        return v_all - v_dat, g_all - g_dat
+
+    obj = ShardedObjective(local_eval, pb.n_par_full, penalty)
+    val, grad = obj.eval(rec["par"])
+    q.put((rank, val, grad))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    from golden_io import load_golden
+    rec = next(r for r in load_golden() if r["name"] == "CTCRW_d2_tv")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, val, grad in res:
+        assert abs(val - rec["expected"]["value"]) <= 1e-11 * abs(rec["expected"]["value"])
+        assert np.max(np.abs(grad - rec["expected"]["grad"])) <= 1e-10 * np.max(np.abs(rec["expected"]["grad"]))
