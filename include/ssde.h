@@ -148,6 +148,8 @@ typedef struct ssde_info_t {
     int32_t window;         /* warm-up rows of a time window in the last evaluation (0 = sequential) */
     int32_t window_retries; /* evaluations repeated because the window hand-over check failed */
     double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval */
+    double  main_kernel_ms; /* HIP-event duration of the dominant kernel launch of the last evaluation */
+    int64_t main_kernel_rows;/* rows scored by that launch (the rest belong to the small concurrent launches) */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the

@@ -53,6 +53,7 @@ class SsdeInfo(C.Structure):
         ("n_tracks", C.c_int64), ("n_rows", C.c_int64), ("n_steps", C.c_int64), ("hbm_bytes", C.c_int64),
         ("algo_bytes_per_row", C.c_double), ("n_kernel_blocks", C.c_int32), ("lanes_per_track", C.c_int32),
         ("window", C.c_int32), ("window_retries", C.c_int32), ("window_check", C.c_double),
+        ("main_kernel_ms", C.c_double), ("main_kernel_rows", C.c_int64),
     ]
 
     def as_dict(self):

@@ -115,6 +115,12 @@ struct ssde_handle {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 
+    // timing of the dominant kernel (recorded on the stream it is launched on)
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    bool ev_k_valid = false;
+    std::vector<int32_t> glen_host, lane_ns_host;
+    int last_s_stat = 0;
+
     // iso direction split
     int iso_parts = 1;
     int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
@@ -146,6 +152,8 @@ void destroy(ssde_handle* h) {
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
+    if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
     h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
@@ -282,6 +290,8 @@ int build(const ssde_desc* d, ssde_handle* h) {
     starts.push_back(n);
 
     HIPCHK(h, h->out.alloc(2 + h->L.n_full));
+    HIPCHK(h, hipEventCreate(&h->ev_k0));
+    HIPCHK(h, hipEventCreate(&h->ev_k1));
 
     // ---- direct families --------------------------------------------------------------------------
     if (!is_kalman(d->model)) {
@@ -355,6 +365,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
         HIPCHK(h, h->group_len.upload(glen));
         HIPCHK(h, h->lane_row0.upload(lane_row0));
         HIPCHK(h, h->lane_nsteps.upload(lane_ns));
+        h->glen_host = glen; h->lane_ns_host = lane_ns;
 
         // stage the caller's arrays (host data) -- freed again after tiling
         DevBuf<double> s_times, s_obs, s_h, s_a0, s_cols;
@@ -744,11 +755,19 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
             b.stat_only = 1;
+            HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_iso_shared(h->model, h->d, b, s));
+            HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            h->ev_k_valid = true;
+            h->last_s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
         } else {
+            HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+            HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            h->ev_k_valid = true;
+            h->last_s_stat = -1;
         }
         HIPCHK(h, launch_window_check(h->model, h->d, a, s));
         for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
@@ -784,7 +803,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
         a.n_dirblocks = h->n_dirblocks; a.dirs = h->dirs.p; a.partials = h->partials.p;
         a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n;
+        HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_dense(a, order >= 1, s));
+        HIPCHK(h, hipEventRecord(h->ev_k1, s));
+        h->ev_k_valid = true; h->last_s_stat = -1;
         if (order >= 1) {
             ra.n_parts = h->n_dirblocks; ra.nacc = 1 + DENSE_NT;
             for (size_t k = 0; k < h->dirs_host.size(); k++)
@@ -804,7 +826,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
         a.n_blocks = h->direct_blocks; a.partials = h->partials.p;
         if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
+        HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_direct(a, s));
+        HIPCHK(h, hipEventRecord(h->ev_k1, s));
+        h->ev_k_valid = true; h->last_s_stat = -1;
         ra.n_parts = 1; ra.nacc = 1 + a.n_slots; ra.n_blocks = h->direct_blocks;
         if (order >= 1)
             for (int k = 0; k < a.n_slots; k++)
@@ -947,6 +972,32 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->window = h->last_window;
     info->window_check = h->last_check;
     info->window_retries = h->n_retries;
+    info->main_kernel_ms = 0.0;
+    if (h->ev_k_valid && hipEventQuery(h->ev_k1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) info->main_kernel_ms = ms;
+    }
+    // rows scored by the dominant launch: everything, except on the shared-covariance path where the
+    // windows that touch the covariance transient run in the small concurrent launch
+    info->main_kernel_rows = h->n_steps;
+    if (h->path == PATH_ISO && h->last_s_stat >= 0) {
+        int64_t rows = 0;
+        const int nc = h->last_chunks;
+        for (int g = 0; g < h->n_groups; g++) {
+            const int L = h->glen_host[g];
+            const int cl = nc > 1 ? ((L + nc - 1) / nc + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN : L;
+            for (int c = 0; c < nc; c++) {
+                const int s_acc = std::min(L, c * cl), s_end = std::min(L, s_acc + cl);
+                const int s_begin = nc > 1 ? std::max(0, s_acc - h->last_window) : 0;
+                if (s_begin < h->last_s_stat) continue;   // transient launch
+                for (int l = 0; l < WAVE; l++) {
+                    const int ns = h->lane_ns_host[(size_t)g * WAVE + l];
+                    rows += std::max(0, std::min(ns, s_end) - s_acc);
+                }
+            }
+        }
+        info->main_kernel_rows = rows;
+    }
     return SSDE_OK;
 }
 
