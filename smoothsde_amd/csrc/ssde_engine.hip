@@ -120,6 +120,8 @@ struct ssde_handle {
     bool ev_k_valid = false;
     std::vector<int32_t> glen_host, lane_ns_host;
     int last_s_stat = 0;
+    mutable int rows_key[3] = {-1, -1, -1};
+    mutable int64_t rows_cached = 0;
 
     // iso direction split
     int iso_parts = 1;
@@ -980,7 +982,10 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     // rows scored by the dominant launch: everything, except on the shared-covariance path where the
     // windows that touch the covariance transient run in the small concurrent launch
     info->main_kernel_rows = h->n_steps;
-    if (h->path == PATH_ISO && h->last_s_stat >= 0) {
+    if (h->path == PATH_ISO && h->last_s_stat >= 0 && h->rows_key[0] == h->last_chunks &&
+        h->rows_key[1] == h->last_window && h->rows_key[2] == h->last_s_stat) {
+        info->main_kernel_rows = h->rows_cached;
+    } else if (h->path == PATH_ISO && h->last_s_stat >= 0) {
         int64_t rows = 0;
         const int nc = h->last_chunks;
         for (int g = 0; g < h->n_groups; g++) {
@@ -997,6 +1002,8 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
             }
         }
         info->main_kernel_rows = rows;
+        h->rows_cached = rows;
+        h->rows_key[0] = h->last_chunks; h->rows_key[1] = h->last_window; h->rows_key[2] = h->last_s_stat;
     }
     return SSDE_OK;
 }
