@@ -1,0 +1,77 @@
+# backend_hip.R -- R glue for the MI355X engine (drop-in for TMB::MakeADFun inside SDE$setup).
+#
+# NOT run in the build image (no R there).  A maintainer of smoothSDE adds this file to R/, the shim
+# R_glue/src/ssde_rcall.c to src/, links libssde_hip.so, and changes ONE call in R/sde.R (see
+# INTEGRATION.md): where $setup() calls MakeADFun(...) at R/sde.R:656-658 and :666-668 it calls
+# make_hip_obj(...) instead when other_data$backend == "hip".  $fit() (optim BFGS on obj$fn / obj$gr,
+# R/sde.R:694-697) and logLik.SDE (obj_joint$fn, R/utility.R:118) stay as they are.
+
+#' Build a MakeADFun-like object backed by the HIP engine
+#'
+#' @param sde SDE object (after initialize)
+#' @param tmb_dat,tmb_par,map the lists SDE$setup has just assembled (R/sde.R:504-536, 621-632)
+#' @return list(par, fn, gr, he, report, env) shaped like TMB::MakeADFun's value
+make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
+    mats <- sde$make_mat()                      # X_list_fe / X_list_re / S_list (R/sde.R:452-454)
+    kalman <- sde$type() %in% c("BM_SSM", "OU_SSM", "CTCRW")
+    # full parameter vector in template order (nllk_ctcrw.hpp:135-140, nllk_sde.hpp:42-45);
+    # without random effects TMB carries dummy log_lambda / coeff_re entries: the engine has none
+    has_re <- !is.null(mats$S)
+    par_full <- c(if(kalman) tmb_par$log_sigma_obs, tmb_par$coeff_fe,
+                  if(has_re) tmb_par$log_lambda, if(has_re) tmb_par$coeff_re)
+    fixed <- rep(FALSE, length(par_full))
+    off_fe <- if(kalman) 1 else 0
+    if(!is.null(map$coeff_fe)) fixed[off_fe + which(is.na(map$coeff_fe))] <- TRUE
+    if(kalman && !is.null(map$log_sigma_obs)) fixed[1] <- TRUE
+    if(has_re) {
+        # no Laplace layer in the engine (SURVEY 8(f)-1): smoothing parameters are held fixed
+        off_l <- off_fe + length(tmb_par$coeff_fe)
+        fixed[off_l + seq_along(tmb_par$log_lambda)] <- TRUE
+    }
+    spec <- list(type = sde$type(), ID = as.numeric(sde$data()$ID), times = as.numeric(sde$data()$time),
+                 obs = as.matrix(sde$obs()),
+                 X_list_fe = lapply(seq_along(sde$formulas()), function(j) {
+                     i1 <- sum(sde$terms()$ncol_fe[seq_len(j - 1)]); nj <- sde$terms()$ncol_fe[j]
+                     as.matrix(sde$mats()$X_fe[(j - 1) * nrow(sde$data()) + seq_len(nrow(sde$data())),
+                                               i1 + seq_len(nj), drop = FALSE])
+                 }),
+                 X_list_re = lapply(mats$X_list_re, function(x) if(ncol(x) > 0) as.matrix(x) else NULL),
+                 a0 = tmb_dat$a0, P0 = tmb_dat$P0,
+                 H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
+                 par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device)
+    # one penalty matrix per smooth: the diagonal blocks of S, sizes terms()$ncol_re (R/sde.R:424-447)
+    if(has_re) {
+        ncol_re <- sde$terms()$ncol_re; off <- cumsum(c(0, ncol_re)); S <- as.matrix(sde$mats()$S)
+        spec$S_list <- lapply(seq_along(ncol_re), function(s) S[off[s] + seq_len(ncol_re[s]), off[s] + seq_len(ncol_re[s]), drop = FALSE])
+    }
+    ptr <- .Call("ssdeR_create", spec, PACKAGE = "smoothSDE")
+    free <- which(!fixed)
+    last <- new.env()
+    eval_at <- function(x) {                    # fn(x) and gr(x) arrive separately with the same x
+        if(is.null(last$x) || !identical(x, last$x)) {
+            full <- par_full; full[free] <- x
+            last$res <- .Call("ssdeR_eval", ptr, full, 1L, PACKAGE = "smoothSDE")
+            last$x <- x
+        }
+        last$res
+    }
+    env <- new.env()
+    env$last.par.best <- par_full[free]
+    list(par = par_full[free],
+         fn = function(x = par_full[free]) eval_at(x)$value,
+         gr = function(x = par_full[free]) matrix(eval_at(x)$gradient[free], nrow = 1),
+         he = function(x = par_full[free]) {     # finite differences of the GPU gradient
+             h <- 1e-5; p <- length(x)
+             H <- matrix(0, p, p)
+             for(k in seq_len(p)) {
+                 e <- rep(0, p); e[k] <- h
+                 H[, k] <- (eval_at(x + e)$gradient[free] - eval_at(x - e)$gradient[free]) / (2 * h)
+             }
+             (H + t(H)) / 2
+         },
+         report = function(x = par_full[free]) {
+             full <- par_full; full[free] <- x
+             list(aest_all = .Call("ssdeR_report", ptr, full, PACKAGE = "smoothSDE"))
+         },
+         env = env, ptr = ptr)
+}
