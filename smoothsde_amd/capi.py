@@ -186,9 +186,12 @@ class Problem:
         self._keep = []
 
     @classmethod
-    def from_torch(cls, model: str, ID, times, obs, par_fixed=None, na_mode: int = NA_ANY_NAN, flags: int = 0):
-        """Constant-coefficient problem whose data already live in HBM (torch CUDA tensors, fp64):
-        the engine re-tiles them in place of an upload (SSDE_FLAG_DEVICE_DATA)."""
+    def from_torch(cls, model: str, ID, times, obs, par_fixed=None, na_mode: int = NA_ANY_NAN, flags: int = 0,
+                   X_re=None, S_list=None):
+        """Problem whose data already live in HBM (torch CUDA tensors, fp64): the engine re-tiles /
+        copies them on the device instead of uploading (SSDE_FLAG_DEVICE_DATA).  Fixed effects are
+        intercept-only; `X_re[j]` may be an (n, k) CUDA tensor of streamed design columns for SDE
+        parameter j, with the penalty blocks in `S_list` (numpy)."""
         import torch
         assert ID.is_cuda and times.is_cuda and obs.is_cuda
         self = cls.__new__(cls)
@@ -209,6 +212,20 @@ class Problem:
         self.ncol_re = np.zeros(self.q, dtype=np.int32)
         self.n_fe, self.n_re = self.q, 0
         self.S_list, self.smooth_ncol, self.s_blocks, self.n_smooth = [], np.zeros(0, dtype=np.int32), None, 0
+        self._t_xre = [None] * self.q
+        if X_re is not None:
+            for j in range(self.q):
+                if X_re[j] is not None:
+                    xt = X_re[j].to(torch.float64)
+                    self._t_xre[j] = xt.t().contiguous()          # (k, n) row-major == (n, k) column-major
+                    self.ncol_re[j] = xt.shape[1]
+            self.n_re = int(self.ncol_re.sum())
+            self.S_list = [np.asarray(s_, dtype=np.float64) for s_ in (S_list or [])]
+            self.smooth_ncol = np.asarray([s_.shape[0] for s_ in self.S_list], dtype=np.int32)
+            self.s_blocks = _f64(np.concatenate([s_.flatten(order="F") for s_ in self.S_list])) if self.S_list else None
+            self.n_smooth = len(self.S_list)
+            if int(self.smooth_ncol.sum()) != self.n_re:
+                raise ValueError("penalty blocks do not match the random-effect columns")
         self.include_penalty = 1
         self.kalman = model in KALMAN_MODELS
         first = torch.ones(self.n, dtype=torch.bool, device=ID.device)
@@ -222,10 +239,13 @@ class Problem:
             self.off_sigobs, o = 0, 1
         self.off_fe = o
         o += self.n_fe
-        self.off_lambda = self.off_re = o
+        self.off_lambda = o
+        o += self.n_smooth
+        self.off_re = o
+        o += self.n_re
         self.n_par_full = o
         self.fe_off = np.arange(self.q)
-        self.re_off = np.zeros(self.q, dtype=int)
+        self.re_off = np.concatenate([[0], np.cumsum(self.ncol_re)[:-1]]).astype(int)
         fixed = np.zeros(self.n_par_full, dtype=np.uint8)
         if par_fixed is not None:
             fixed[:] = np.asarray(par_fixed, dtype=np.uint8)
@@ -271,7 +291,10 @@ class Problem:
         d.ncol_fe = self.ncol_fe.ctypes.data_as(_ip)
         d.ncol_re = self.ncol_re.ctypes.data_as(_ip)
         xfe = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_fe])
-        xre = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_re])
+        if getattr(self, "_t_xre", None) is not None:
+            xre = (C.c_void_p * self.q)(*[None if x is None else x.data_ptr() for x in self._t_xre])
+        else:
+            xre = (C.c_void_p * self.q)(*[ptr(x) for x in self.X_re])
         keep += [xfe, xre]
         d.x_fe, d.x_re = xfe, xre
         d.n_smooth = self.n_smooth
