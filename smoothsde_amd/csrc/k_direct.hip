@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     for (int k = 0; k < KMAX; k++) acc[k] = 0.0;
     double nll = 0.0;
 
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
+    // every workgroup streams ONE contiguous range of rows (consecutive 2-KB pieces of each column)
+    const int64_t per_block = ((A.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t row_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t row_hi = row_lo + per_block < A.n ? row_lo + per_block : A.n;
+    for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
         if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
         const double dt = A.times[i] - A.times[i - 1];  // dtimes(i-1), nllk_sde.hpp:37,80
         double w[KMAX];
