@@ -57,6 +57,19 @@ def main():
     report("C2: 1e4 CTCRW x 1e3, regular grid", eng, np.array([np.log(0.1), 0, 0, np.log(2.0), 0.0]), M * 1000)
     eng.close()
 
+    # one-off cost of handing HOST arrays over the boundary (PCIe upload + re-tiling), same C2 batch
+    IDh, th, oh = ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy()
+    t0 = time.perf_counter()
+    eng = capi.Engine(capi.Problem("CTCRW", IDh, th, oh, par_fixed=[0, 1, 1, 0, 0]))
+    torch.cuda.synchronize()
+    t_create = time.perf_counter() - t0
+    eng.eval(np.array([np.log(0.1), 0, 0, np.log(2.0), 0.0]))
+    print(json.dumps(dict(config="C2 create from host arrays (PCIe upload + segment scan + re-tiling)", rows=M * 1000,
+                          seconds=t_create, host_bytes=IDh.nbytes + th.nbytes + oh.nbytes,
+                          effective_GBps=(th.nbytes + oh.nbytes + IDh.nbytes) / t_create / 1e9)), flush=True)
+    eng.close()
+    del IDh, th, oh
+
     # irregular time grid: general per-lane kernel (covariance half per lane, exp per row)
     ID, times, obs = simulate("CTCRW", M, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=2, backend="torch", device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(5)
