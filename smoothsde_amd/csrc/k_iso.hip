@@ -169,6 +169,17 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     }
 }
 
+// One kernel per direction mask when the whole launch uses a single mask (n_parts == 1, the default):
+// a kernel's register allocation is the worst case over everything it contains.
+template <int MODEL, int D, int MASK>
+__global__ __launch_bounds__(WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
+    int g, part, chunk;
+    if (!decode_block(A, g, part, chunk)) return;
+    if (!group_selected(A, g)) return;
+    run_lane<MODEL, D, MASK>(A, g, part, chunk);
+}
+
+// Direction-split launches (several parts with different masks) keep the masks in one kernel.
 template <int MODEL, int D>
 __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
     int g, part, chunk;
@@ -178,6 +189,18 @@ __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
     const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
     switch (mask) {
 #define SSDE_CASE(M) case M: run_lane<MODEL, D, M>(A, g, part, chunk); break;
+        SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
+        SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
+#undef SSDE_CASE
+        default: break;
+    }
+}
+
+template <int MODEL, int D>
+static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
+    dim3 block(WAVE);
+    switch (a.part_mask[0]) {
+#define SSDE_CASE(M) case M: hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE
@@ -234,11 +257,10 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
     const bool shared = a0.group_mode == 3;
 #define SSDE_LAUNCH(MODEL, D)                                                          \
     if (model == MODEL && d == D) {                                                    \
-        if (shared) {                                                                  \
-            a.group_mode = 1;                                                          \
-            if (any_dirty) hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a); \
-        } else {                                                                       \
-            hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a);          \
+        if (shared) a.group_mode = 1;                                                  \
+        if (!shared || any_dirty) {                                                    \
+            if (a.n_parts == 1) launch_one_mask<MODEL, D>(a, grid, s);                 \
+            else hipLaunchKernelGGL((iso_kernel<MODEL, D>), grid, block, 0, s, a);     \
         }                                                                              \
         done = true;                                                                   \
     }

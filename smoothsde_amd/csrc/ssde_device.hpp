@@ -26,7 +26,10 @@ namespace ssde {
 constexpr int WAVE = 64;
 constexpr int TILE_U = 4;        // steps per prefetch block of the general register kernel
 constexpr int WIN_ALIGN = 16;    // time-window starts / lengths / warm-ups are multiples of this many rows
-constexpr int SHARED_U = 8;      // steps per prefetch block of the shared-covariance kernel (divides WIN_ALIGN)
+#ifndef SSDE_SHARED_U
+#define SSDE_SHARED_U 8
+#endif
+constexpr int SHARED_U = SSDE_SHARED_U;     // steps per prefetch block of the shared-covariance kernel (divides WIN_ALIGN)
 constexpr int TILE_SPARE = 64;   // spare rows after the last group, so prefetching ahead stays in bounds
 constexpr int NACC_MAX = 8;      // 1 + 3 + D accumulators of the constant-coefficient kernels
 constexpr int GAIN_ROW = 16;     // doubles per row of the shared gain table (128-B rows for scalar loads)
