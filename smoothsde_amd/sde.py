@@ -11,9 +11,9 @@ R/sde.R:694-697).
 
 Out of scope here, as in SURVEY.md: mgcv smooth construction (stays in R; a B-spline stand-in
 is provided for `s(x, k=)` and an identity-penalised indicator block for `s(ID, bs="re")`),
-the Laplace approximation over `coeff_re` (`fit()` optimises the joint
-penalised likelihood with the smoothing parameters held at their current values and says so),
-sdreport, plotting, posterior simulation.
+sdreport, plotting, posterior simulation.  The Laplace approximation over `coeff_re`
+(`random = "coeff_re"`, R/sde.R:522) is provided by `smoothsde_amd.laplace` on top of the GPU
+gradient (finite-difference Hessian / outer gradient instead of TMB's AD).
 """
 from __future__ import annotations
 
@@ -222,7 +222,7 @@ class SDE:
         return self.mats_
 
     # -- TMB setup counterpart (R/sde.R:491-670) -----------------------------------------------------------
-    def _problem(self, include_penalty=1, **over):
+    def _problem(self, include_penalty=1, fix_lambda=True, **over):
         X_fe = []
         for d in self.designs_:
             # an intercept-only block is passed as "no column" (broadcast), SURVEY 7.3-5
@@ -235,7 +235,8 @@ class SDE:
         fixed = pb.par_fixed.copy()
         for k in self.ind_fixcoeff():                      # map$coeff_fe with NA for fixed coefficients
             fixed[pb.off_fe + k] = 1
-        fixed[pb.off_lambda:pb.off_lambda + pb.n_smooth] = 1   # smoothing parameters are not optimised here (no Laplace)
+        if fix_lambda:                                     # joint fit: smoothing parameters held at their values
+            fixed[pb.off_lambda:pb.off_lambda + pb.n_smooth] = 1
         pb.par_fixed = fixed
         return pb
 
@@ -248,11 +249,23 @@ class SDE:
         p[pb.off_re:pb.off_re + pb.n_re] = self.coeff_re_
         return p
 
-    def setup(self, silent=True, map=None):
-        pb = self._problem(include_penalty=1)
+    def setup(self, silent=True, map=None, laplace=None):
+        """laplace=None: integrate coeff_re out (Laplace approximation, like `random = "coeff_re"` in the
+        reference, R/sde.R:522) whenever there are random effects; laplace=False: joint penalised
+        likelihood with the smoothing parameters held fixed."""
+        has_re = len(self.mats_["S_list"]) > 0
+        self.laplace_ = has_re if laplace is None else (bool(laplace) and has_re)
+        pb = self._problem(include_penalty=1, fix_lambda=not self.laplace_)
         self.problem_ = pb
         self.engine_ = capi.Engine(pb)
         self.tmb_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())
+        if self.laplace_:
+            from .laplace import LaplaceObjective
+            free = set(pb.free_index().tolist())
+            idx_r = [k for k in range(pb.off_re, pb.off_re + pb.n_re) if k in free]
+            idx_o = [k for k in sorted(free) if k not in set(idx_r)]
+            self.joint_obj_ = self.tmb_obj_
+            self.tmb_obj_ = LaplaceObjective(lambda p: self.engine_.eval(p, order=1), self._par_full(pb), idx_o, idx_r)
         # joint object "excluding penalty" (R/sde.R:663-669): include_penalty = 0 is honoured by the
         # direct families only (Q7); the Kalman families share the same engine
         if pb.kalman or pb.n_smooth == 0:
@@ -267,28 +280,35 @@ class SDE:
         from scipy.optimize import minimize
         if self.tmb_obj_ is None:
             self.setup(silent=silent, map=map)
-        if self.problem_.n_smooth > 0:
+        if self.problem_.n_smooth > 0 and not self.laplace_:
             warnings.warn("random effects present: optimising the joint penalised likelihood with the smoothing "
-                          "parameters fixed (the Laplace layer of TMB is outside this engine, SURVEY 8(f)-1)")
+                          "parameters fixed (setup(laplace=False)); the default integrates them out (Laplace)")
         obj = self.tmb_obj_
         t0 = time.perf_counter()
         res = minimize(obj.fn, obj.par, jac=obj.gr, method="BFGS", options=dict(maxiter=maxiter))  # optim(..., "BFGS")
         self.out_ = dict(par=res.x, value=res.fun, counts=(res.nfev, res.njev), convergence=int(not res.success),
                          message=res.message, systime=time.perf_counter() - t0)
         full = obj.par_full.copy()
-        full[obj.free] = res.x
+        if self.laplace_:
+            full[obj.io] = res.x
+            obj.fn(res.x)
+            full[obj.ir] = obj.u_hat
+        else:
+            full[obj.free] = res.x
         pb = self.problem_
         self.par_full_ = full
         self.log_sigma_obs_ = full[0] if pb.kalman else None
         self.coeff_fe_ = full[pb.off_fe:pb.off_fe + pb.n_fe].copy()        # R/sde.R:707-713
         self.coeff_re_ = full[pb.off_re:pb.off_re + pb.n_re].copy()
+        if pb.n_smooth:
+            self.lambda_vals_ = np.exp(full[pb.off_lambda:pb.off_lambda + pb.n_smooth])   # R/sde.R:712
         return self.out_
 
     def logLik(self):
         """- tmb_obj_joint$fn(par_all) with attributes nobs (R/utility.R:115-123); df is the number of
         free fixed-effect parameters (the random-effect EDF term needs sdreport's joint precision,
         SURVEY 8(f)-2)."""
-        obj = self.tmb_obj_joint_
+        obj = self.tmb_obj_joint_ if not getattr(self, "laplace_", False) else self.joint_obj_
         x = self.par_full_[obj.free] if getattr(self, "par_full_", None) is not None else obj.par
         return dict(value=-obj.fn(x), df=len(self.tmb_obj_.par), nobs=self.n_)
 

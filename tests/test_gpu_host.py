@@ -32,19 +32,40 @@ def test_fit_recovers_ctcrw_parameters():
     assert abs(-ll["value"] - oval) <= 1e-10 * abs(oval) and ll["nobs"] == len(ID)
 
 
-def test_fit_ou_with_smooth_mean():
+def _ou_smooth_sde():
     ID, times, obs = simulate("OU", 30, 300, 1, mu=1.0, tau=2.0, kappa=1.0, seed=5)
     cov = (np.sin(np.arange(len(ID)) * 0.02) + 1) / 2
+    obs[:, 0] += 1.5 * np.sin(3 * cov)                      # the mean really depends on the covariate
     data = dict(ID=ID, time=times, z=obs[:, 0], cov=cov)
-    sde = SDE(formulas={"mu": "~ s(cov, k = 6)", "tau": "~1", "kappa": "~1"}, data=data, type="OU", response="z",
-              par0=[0.5, 1.0, 1.0])
-    with pytest.warns(UserWarning, match="Laplace"):
+    return SDE(formulas={"mu": "~ s(cov, k = 6)", "tau": "~1", "kappa": "~1"}, data=data, type="OU", response="z",
+               par0=[0.5, 1.0, 1.0])
+
+
+def test_fit_ou_with_smooth_mean_joint():
+    sde = _ou_smooth_sde()
+    sde.setup(laplace=False)
+    with pytest.warns(UserWarning, match="smoothing"):
         out = sde.fit(maxiter=60)
     assert np.isfinite(out["value"])
     from oracle_lib import oracle_eval
     oval, ograd = oracle_eval(sde.problem_, sde.par_full_, order=1, threads=8)
     assert abs(out["value"] - oval) <= 1e-10 * abs(oval)
-    assert abs(np.exp(sde.coeff_fe()[1]) - 2.0) < 0.6
+    assert abs(np.exp(sde.coeff_fe()[1]) - 2.0) < 0.8
+
+
+def test_fit_ou_with_smooth_mean_laplace():
+    """`random = "coeff_re"` counterpart: coeff_re integrated out, log_lambda estimated (R/sde.R:522, 707-713)."""
+    sde = _ou_smooth_sde()
+    out = sde.fit(maxiter=40)
+    assert sde.laplace_ and np.isfinite(out["value"])
+    assert sde.lambda_()[0] != 1.0 and np.all(np.isfinite(sde.coeff_re()))
+    # at the optimum the inner gradient vanishes: u_hat minimises the joint nllk
+    from oracle_lib import oracle_eval
+    _, g = oracle_eval(sde.problem_, sde.par_full_, order=1, threads=8)
+    pb = sde.problem_
+    assert np.max(np.abs(g[pb.off_re:pb.off_re + pb.n_re])) < 1e-3 * max(1.0, np.max(np.abs(g)))
+    mu_hat = sde.par()["mu"]
+    assert np.corrcoef(mu_hat, 1.0 + 1.5 * np.sin(3 * sde.data()["cov"]))[0, 1] > 0.9
 
 
 def test_sharded_objective_single_rank_on_device():

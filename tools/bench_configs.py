@@ -51,6 +51,20 @@ def main():
     M = 10_000
     T = 1_000 if a.quick else 10_000
 
+    # C1: elephant-like single 2-D CTCRW track, 3672 hourly fixes, tau and nu smooth in a temperature covariate
+    # (vignette model, smoothSDE.rmd:476-490): time-varying coefficients -> dense kernel, 19 free parameters
+    from smoothsde_amd.synth import bspline_basis
+    ID1, t1, o1 = simulate("CTCRW", 1, 3672, 2, tau=1.0, nu=1.0, sigma_obs=0.05, z0=[572.34, 1675.42], seed=342)
+    temp = 30 + 10 * np.sin(np.arange(3672) * 2 * np.pi / 24) + np.random.default_rng(342).normal(0, 2, 3672)
+    B = bspline_basis((temp - temp.min()) / (temp.max() - temp.min()), 9)
+    S9 = second_difference_penalty(9)
+    pb1 = capi.Problem("CTCRW", ID1, t1, o1, X_re=[None, None, B, B], S_list=[S9, S9],
+                       par_fixed=np.r_[0, 1, 1, 0, 0, 1, 1, np.zeros(18)].astype(np.uint8))
+    eng = capi.Engine(pb1)
+    par1 = np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(18))]
+    report("C1: single elephant-like CTCRW track x 3672, tau/nu splines (dense kernel)", eng, par1, 3672, 5)
+    eng.close()
+
     # C2: 1e4 CTCRW tracks x 1e3 rows, constant coefficients, regular grid
     ID, times, obs = simulate("CTCRW", M, 1000, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1, backend="torch", device=dev)
     eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=[0, 1, 1, 0, 0]))
