@@ -1,0 +1,116 @@
+"""GPU suite: edge cases of the reference's loop structure against the oracle."""
+import numpy as np
+import pytest
+
+from smoothsde_amd import capi
+from smoothsde_amd.synth import simulate
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(pb, par):
+    from oracle_lib import oracle_eval
+    return oracle_eval(pb, par, order=1, threads=4)
+
+
+def _agree(pb, par, nan_ok=False):
+    eng = capi.Engine(pb)
+    v, g = eng.eval(np.asarray(par, dtype=float))
+    ov, og = _oracle(pb, np.asarray(par, dtype=float))
+    eng.close()
+    if nan_ok and not np.isfinite(ov):
+        assert not np.isfinite(v)
+        return v, g
+    assert abs(v - ov) <= 1e-10 * max(1.0, abs(ov)), (v, ov)
+    assert np.max(np.abs(g - og)) <= 1e-8 * np.max(np.abs(og)) + 1e-10, (g, og)
+    return v, g
+
+
+@pytest.mark.parametrize("model,par", [("CTCRW", [-1.0, 0.1, -0.1, 0.3, 0.1]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]),
+                                       ("BM_SSM", [-1.0, 0.05, 0.0, 0.2]), ("OU", [0.3, -0.2, 0.6, 0.1]), ("BM", [0.05, 0.0, 0.2])])
+def test_tiny_and_degenerate_tracks(model, par):
+    """one-row tracks (never scored, Q1), two-row tracks, a single long track, 65 tracks (two wavefronts)"""
+    rng = np.random.default_rng(2)
+    lens = [1, 2, 1, 7, 1, 3] + [2] * 60 + [40]
+    ID = np.repeat(np.arange(len(lens)), lens).astype(float)
+    n = len(ID)
+    times = np.cumsum(rng.uniform(0.5, 1.5, n))
+    obs = rng.normal(size=(n, 2)).cumsum(axis=0) * 0.3
+    _agree(capi.Problem(model, ID, times, obs), par)
+    # n = 2: the smallest problem the engine accepts
+    _agree(capi.Problem(model, np.zeros(2), np.array([0.0, 1.0]), obs[:2]), par)
+
+
+def test_reappearing_id_is_a_new_segment():
+    """Q9: a0 has one row per ID *segment* in data order; an ID that comes back is a new segment."""
+    rng = np.random.default_rng(3)
+    ID = np.array([0] * 6 + [1] * 5 + [0] * 7, dtype=float)
+    n = len(ID)
+    obs = rng.normal(size=(n, 2)).cumsum(axis=0)
+    pb = capi.Problem("CTCRW", ID, np.arange(1.0, n + 1), obs)
+    assert pb.n_seg == 3
+    _agree(pb, [-0.5, 0.0, 0.0, 0.2, 0.0])
+
+
+def test_all_rows_missing_after_the_first():
+    ID, times, obs = simulate("OU_SSM", 3, 20, 2, seed=1)
+    obs[1:20] = np.nan          # track 0: nothing is ever scored, the filter only predicts
+    pb = capi.Problem("OU_SSM", ID, times, obs)
+    _agree(pb, [-1.0, 0.3, -0.2, 0.6, 0.1])
+
+
+def test_r_na_versus_plain_nan():
+    """Q5: with R semantics only NA_real_ (payload 1954) is 'missing'; a plain NaN is data and poisons the
+    likelihood exactly as it does in the reference.  Only column 0 is tested by the Kalman families."""
+    ID, times, obs = simulate("CTCRW", 4, 30, 2, seed=2)
+    na = capi.na_real()
+    o1 = obs.copy(); o1[5] = na; o1[40, 0] = na          # second case: column 1 holds a number, row still skipped
+    _agree(capi.Problem("CTCRW", ID, times, o1, na_mode=capi.NA_R_ONLY), [-1.0, 0.0, 0.0, 0.3, 0.0])
+    o2 = obs.copy(); o2[5] = np.nan                      # plain NaN under R semantics
+    v, _ = _agree(capi.Problem("CTCRW", ID, times, o2, na_mode=capi.NA_R_ONLY), [-1.0, 0.0, 0.0, 0.3, 0.0], nan_ok=True)
+    assert not np.isfinite(v)
+    # direct families test every dimension of both endpoints (tr_dens.hpp:31)
+    o3 = obs.copy(); o3[7, 1] = na; o3[33, 0] = na
+    _agree(capi.Problem("OU", ID, times, o3, na_mode=capi.NA_R_ONLY), [0.3, -0.2, 0.6, 0.1])
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM", "BM_SSM"])
+@pytest.mark.parametrize("dense", [False, True])
+def test_nonpositive_innovation_variance_branch(model, dense):
+    """Q3: detF <= 0 skips the update; CTCRW then predicts WITHOUT B mu, OU/BM keep the drift
+    (nllk_ctcrw.hpp:226-228 vs nllk_ou_ssm.hpp:192-194).  Forced with a negative P0."""
+    ID, times, obs = simulate(model, 5, 12, 1, seed=4)
+    sdim = 2 if model == "CTCRW" else 1
+    P0 = -np.eye(sdim) * 5.0 if sdim == 1 else np.diag([-5.0, 1.0])
+    par = [-2.0, 0.7, 0.3, 0.1] if model != "BM_SSM" else [-2.0, 0.7, 0.1]
+    pb = capi.Problem(model, ID, times, obs, P0=P0, flags=capi.FLAG_FORCE_DENSE if dense else 0)
+    _agree(pb, par, nan_ok=True)
+
+
+def test_user_a0_and_block_identical_p0_stay_on_register_path():
+    ID, times, obs = simulate("CTCRW", 70, 50, 2, seed=6)
+    a0 = np.zeros((70, 4)); a0[:, 0] = obs[::50, 0] + 0.3; a0[:, 1] = 0.2; a0[:, 2] = obs[::50, 1]; a0[:, 3] = -0.1
+    blk = np.array([[2.0, 0.3], [0.3, 4.0]])
+    P0 = np.kron(np.eye(2), blk)
+    pb = capi.Problem("CTCRW", ID, times, obs, a0=a0, P0=P0)
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == 1
+    eng.close()
+    _agree(pb, [-0.8, 0.05, -0.05, 0.4, 0.1])
+
+
+def test_penalty_only_and_fixed_everything():
+    """all data-term parameters fixed: the gradient is that of the penalty alone"""
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    ID, times, obs = simulate("BM", 5, 30, 1, seed=8)
+    x = np.linspace(0, 1, len(ID))
+    B = bspline_basis(x, 4)
+    pb = capi.Problem("BM", ID, times, obs, X_re=[B, None], S_list=[second_difference_penalty(4)])
+    par = np.r_[0.1, 0.2, 0.5, 0.1 * np.arange(4)]
+    _agree(pb, par)
+    pb0 = capi.Problem("BM", ID, times, obs, X_re=[B, None], S_list=[second_difference_penalty(4)], include_penalty=0)
+    eng = capi.Engine(pb0)
+    v0, _ = eng.eval(par)
+    eng.close()
+    ov = _oracle(pb0, par)[0]
+    assert abs(v0 - ov) <= 1e-10 * abs(ov)
