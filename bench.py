@@ -113,10 +113,15 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    host_enqueue_s = []
+
     def step(k, events=None):
+        th = theta(k)
         if events:
             events[0].record(stream)
-        eng.eval_device(theta(k), out.data_ptr(), order=1, stream=stream.cuda_stream)
+        t_h = time.perf_counter()
+        eng.eval_device(th, out.data_ptr(), order=1, stream=stream.cuda_stream)
+        host_enqueue_s.append(time.perf_counter() - t_h)
         if events:
             events[1].record(stream)
         if world > 1:
@@ -189,6 +194,7 @@ def main():
                      "rows_in_launch": info["main_kernel_rows"],
                      "whole_evaluation": {"gpu_ms": eval_ms, "achieved": eval_achieved,
                                           "frac": eval_achieved / HBM_PEAK_GBS, "traffic": traffic_eval,
+                                          "host_enqueue_ms": 1e3 * float(np.mean(host_enqueue_s[-args.steps:])),
                                           "note": "all kernels of one evaluation incl. the concurrent transient-window "
                                                   "launch, the hand-over check and the reduction"}},
     }

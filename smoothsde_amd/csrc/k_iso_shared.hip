@@ -230,10 +230,223 @@ struct SharedScal {
     }
 };
 
+
+// ---- stationary-only lanes in BASIS form ----------------------------------------------------------
+// Past the covariance transient the gain sensitivities dk1_j, dk2_j are constants, so the state
+// sensitivities of ALL covariance directions are linear combinations of the responses of one linear
+// filter to three forcings (zero initial state, which is how every stationary window starts):
+//     (A1,B1) <- forcing (u, 0),  (A2,B2) <- forcing (0, u),  (A3,B3) <- forcing (dt12 w, de w), w = v - B mu
+//     tx_j = dk1_j A1 + dk2_j A2 + [j = tau] A3        (same for tv_j with B)
+// and  sum_t u tx_j = dk1_j S1 + dk2_j S2 + [j = tau] S3.  The per-row work no longer grows with the
+// number of covariance directions: 50 fp64 instructions per row for 2-D CTCRW instead of 62.
+template <int D, int MASK>
+struct BasisCtcrw {
+    static constexpr int SD = 2 * D;
+    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
+    static constexpr bool ANYP = (MASK & (DIR_SIG | DIR_P1 | DIR_P2)) != 0;
+    static constexpr bool P1 = (MASK & DIR_P1) != 0;
+    double x[D], v[D], A1[D], B1[D], A2[D], B2[D], A3[D], B3[D], mx[D], mv[D];
+    double acc2, S1, S2, S3, macc[D];
+    double k1, k2, c1, t12, e, iF, hd[NDIRP], dk1[NDIRP], dk2[NDIRP], dt12, de, cb1, cb2;
+    double cx[D], cv[D], bmu[D];
+
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        const double* c = A.statc;
+        iF = c[0]; k1 = c[1]; k2 = c[2]; c1 = c[3]; t12 = c[4]; e = c[5]; dt12 = c[6]; de = c[7]; cb1 = c[8]; cb2 = c[9];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            cx[a] = c[19 + a]; bmu[a] = c[23 + a];
+            double t = c[21 + a];
+            asm volatile("v_mov_b64 %0, %1" : "=v"(cv[a]) : "s"(t));   // fma(e, v, cv): one scalar source per VALU op
+        }
+    }
+    __device__ __forceinline__ void init(const double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            x[a] = a0[2 * a]; v[a] = a0[2 * a + 1];
+            A1[a] = B1[a] = A2[a] = B2[a] = A3[a] = B3[a] = mx[a] = mv[a] = 0.0;
+        }
+        reset_acc();
+    }
+    __device__ __forceinline__ void reset_acc() {
+        acc2 = S1 = S2 = S3 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) macc[a] = 0.0;
+    }
+    __device__ __forceinline__ void step_table(const double*, const double*, const double*) {}  // never used
+    __device__ __forceinline__ void step_stat(const double* y) {
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double u = y[a] - x[a];
+            acc2 = fma(u, u, acc2);
+            if (ANYP) {
+                const double a1 = A1[a], b1 = B1[a], a2 = A2[a], b2 = B2[a];
+                S1 = fma(u, a1, S1);
+                S2 = fma(u, a2, S2);
+                A1[a] = fma(c1, a1, fma(t12, b1, u));
+                B1[a] = fma(e, b1, -k2 * a1);
+                A2[a] = fma(c1, a2, t12 * b2);
+                B2[a] = fma(e, b2, fma(-k2, a2, u));
+                if (P1) {
+                    const double a3 = A3[a], b3 = B3[a];
+                    const double w = v[a] - bmu[a];
+                    S3 = fma(u, a3, S3);
+                    A3[a] = fma(c1, a3, fma(t12, b3, dt12 * w));
+                    B3[a] = fma(e, b3, fma(-k2, a3, de * w));
+                }
+            }
+            if (MASK & DIR_MU) {
+                const double m1 = mx[a], m2 = mv[a];
+                macc[a] = fma(u, m1, macc[a]);
+                mx[a] = fma(c1, m1, fma(t12, m2, cb1));
+                mv[a] = fma(e, m2, fma(-k2, m1, cb2));
+            }
+            const double xx = x[a], vv = v[a];
+            x[a] = fma(k1, u, fma(t12, vv, xx)) + cx[a];
+            v[a] = fma(k2, u, fma(e, vv, cv[a]));
+        }
+    }
+    __device__ __forceinline__ void finish(double* out) const {
+        out[0] = 0.5 * iF * acc2;
+        const double s3[NDIRP] = {0.0, S3, 0.0};
+        const int slot[NDIRP] = {1, 2 + D, 3 + D};
+#pragma unroll
+        for (int k = 1; k < 4 + D; k++) out[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++)
+            if (MASK & dir_bit(j)) out[slot[j]] = hd[j] * acc2 - iF * (dk1[j] * S1 + dk2[j] * S2 + s3[j]);
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) out[2 + a] = -iF * macc[a];
+        }
+    }
+    // hand-over states in DIRECTION form (what the transient kernel and k_iso.hip dump)
+    __device__ __forceinline__ void dump(double* o) const {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[k++] = x[a]; o[k++] = v[a]; }
+        o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0;
+            o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double tx = dk1[j] * A1[a] + dk2[j] * A2[a] + (j == 1 ? A3[a] : 0.0);
+                const double tv = dk1[j] * B1[a] + dk2[j] * B2[a] + (j == 1 ? B3[a] : 0.0);
+                o[k++] = on ? tx : 0.0; o[k++] = on ? tv : 0.0;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? mv[a] : 0.0; }
+    }
+    __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
+    }
+};
+
+// OU_SSM / BM_SSM: tx_j = dk_j A1 + [j = par n_dim] A3 with A1 <- forcing u, A3 <- forcing dt_ x + db mu
 template <int MODEL, int D, int MASK>
+struct BasisScal {
+    static constexpr int SD = D;
+    static constexpr int NSTATE = 4 * (D + 1) + D;
+    static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    static constexpr bool ANYP = (MASK & (DIR_SIG | DIR_P1 | (HAS_P2 ? DIR_P2 : 0))) != 0;
+    static constexpr bool P1 = (MASK & DIR_P1) != 0;
+    double x[D], A1[D], A3[D], mx[D];
+    double acc2, S1, S3, macc[D];
+    double k, c, t, b, iF, hd[NDIRP], dk[NDIRP], dt_, cmu[D], dbmu[D];
+
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        const double* cc = A.statc;
+        iF = cc[0]; k = cc[1]; c = cc[2]; t = cc[3]; b = cc[4]; dt_ = cc[5];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = cc[10 + j]; dk[j] = cc[13 + j]; }
+#pragma unroll
+        for (int a = 0; a < D; a++) { cmu[a] = cc[19 + a]; dbmu[a] = cc[21 + a]; }
+    }
+    __device__ __forceinline__ void init(const double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) { x[a] = a0[a]; A1[a] = A3[a] = mx[a] = 0.0; }
+        reset_acc();
+    }
+    __device__ __forceinline__ void reset_acc() {
+        acc2 = S1 = S3 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) macc[a] = 0.0;
+    }
+    __device__ __forceinline__ void step_table(const double*, const double*, const double*) {}
+    __device__ __forceinline__ void step_stat(const double* y) {
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double xx = x[a];
+            const double u = y[a] - xx;
+            acc2 = fma(u, u, acc2);
+            if (ANYP) {
+                const double a1 = A1[a];
+                S1 = fma(u, a1, S1);
+                A1[a] = fma(c, a1, u);
+                if (P1) {
+                    const double a3 = A3[a];
+                    S3 = fma(u, a3, S3);
+                    A3[a] = fma(c, a3, fma(dt_, xx, dbmu[a]));
+                }
+            }
+            if (MASK & DIR_MU) {
+                const double m1 = mx[a];
+                macc[a] = fma(u, m1, macc[a]);
+                mx[a] = fma(c, m1, b);
+            }
+            x[a] = fma(k, u, fma(t, xx, cmu[a]));
+        }
+    }
+    __device__ __forceinline__ void finish(double* out) const {
+        out[0] = 0.5 * iF * acc2;
+        const double s3[NDIRP] = {0.0, S3, 0.0};
+        const int slot[NDIRP] = {1, 2 + D, 3 + D};
+#pragma unroll
+        for (int kk = 1; kk < 4 + D; kk++) out[kk] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++)
+            if ((MASK & dir_bit(j)) && (j < 2 || HAS_P2)) out[slot[j]] = hd[j] * acc2 - iF * (dk[j] * S1 + s3[j]);
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) out[2 + a] = -iF * macc[a];
+        }
+    }
+    __device__ __forceinline__ void dump(double* o) const {
+        int kk = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) o[kk++] = x[a];
+        o[kk++] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            const bool on = (MASK & dir_bit(j)) != 0 && (j < 2 || HAS_P2);
+            o[kk++] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) o[kk++] = on ? dk[j] * A1[a] + (j == 1 ? A3[a] : 0.0) : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) o[kk++] = (MASK & DIR_MU) ? mx[a] : 0.0;
+    }
+    __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
+#pragma unroll
+        for (int a = 0; a < D; a++) a0[a] = (y[a] == y[a]) ? y[a] : 0.0;
+    }
+};
+
+// direction form for windows that touch the transient, basis form for the stationary-only kernel
+template <int MODEL, int D, int MASK, bool STATONLY>
 struct SharedSel { typedef SharedScal<MODEL, D, MASK> type; };
 template <int D, int MASK>
-struct SharedSel<M_CTCRW, D, MASK> { typedef SharedCtcrw<D, MASK> type; };
+struct SharedSel<M_CTCRW, D, MASK, false> { typedef SharedCtcrw<D, MASK> type; };
+template <int MODEL, int D, int MASK>
+struct SharedSel<MODEL, D, MASK, true> { typedef BasisScal<MODEL, D, MASK> type; };
+template <int D, int MASK>
+struct SharedSel<M_CTCRW, D, MASK, true> { typedef BasisCtcrw<D, MASK> type; };
 
 // rows [s0, s0 + SHARED_U) from a register block
 template <bool STAT, int D, class Lane>
@@ -281,7 +494,7 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 // kernel; otherwise the window touches the transient and also carries the table-phase code.
 template <int MODEL, int D, int MASK, bool STATONLY>
 __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int part, int chunk) {
-    typedef typename SharedSel<MODEL, D, MASK>::type Lane;
+    typedef typename SharedSel<MODEL, D, MASK, STATONLY>::type Lane;
     constexpr int C = 1 + D;
     constexpr int NACC = 4 + D;
     constexpr int SD = Lane::SD;
