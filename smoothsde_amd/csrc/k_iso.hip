@@ -95,7 +95,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     constexpr int C = 1 + D;
     constexpr int NACC = 4 + D;
     constexpr int SD = Ops::SD;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const TileView& tv = A.tv;
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -172,7 +172,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 // One kernel per direction mask when the whole launch uses a single mask (n_parts == 1, the default):
 // a kernel's register allocation is the worst case over everything it contains.
 template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
+__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
     int g, part, chunk;
     if (!decode_block(A, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
 
 // Direction-split launches (several parts with different masks) keep the masks in one kernel.
 template <int MODEL, int D>
-__global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
+__global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
     int g, part, chunk;
     if (!decode_block(A, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WAVE) void iso_kernel(const IsoArgs A) {
 
 template <int MODEL, int D>
 static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
-    dim3 block(WAVE);
+    dim3 block(WG_WAVES * WAVE);
     switch (a.part_mask[0]) {
 #define SSDE_CASE(M) case M: hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
@@ -250,7 +250,7 @@ int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2
 // launch runs the general kernel on the others (only when `any_dirty`)
 hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipStream_t s) {
     const int g8 = (a0.tv.n_groups + 7) / 8;
-    dim3 grid(g8 * 8 * a0.n_parts * a0.n_chunks), block(WAVE);
+    dim3 grid((g8 * 8 * a0.n_parts * a0.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
     bool done = false;
     IsoArgs a = a0;

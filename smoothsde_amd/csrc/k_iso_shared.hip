@@ -25,7 +25,11 @@ __device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const
 #pragma unroll
     for (int u = 0; u < SHARED_U; u++)
 #pragma unroll
+#ifdef SSDE_DIAG_NOSTREAM   // timing-only diagnostic build (results are wrong): every block re-reads one 8-KB window
+        for (int a = 0; a < D; a++) dst[u][a] = p[((u * C + 1 + a) * WAVE) & 1023];
+#else
         for (int a = 0; a < D; a++) dst[u][a] = p[(u * C + 1 + a) * WAVE];  // the dt channel is not read
+#endif
 }
 
 // ---- CTCRW -------------------------------------------------------------------------------------
@@ -480,12 +484,17 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
     constexpr int C = 1 + D;
     if (sa >= sb) return;
     double bufA[SHARED_U][D], bufB[SHARED_U][D];
-    load_obs_block<D>(bufA, base + (int64_t)sa * C * WAVE);
+#ifdef SSDE_DIAG_NOSTREAM
+#define SSDE_ROWPTR(s) (base)
+#else
+#define SSDE_ROWPTR(s) (base + (int64_t)(s) * C * WAVE)
+#endif
+    load_obs_block<D>(bufA, SSDE_ROWPTR(sa));
     for (int s0 = sa; s0 < sb; s0 += 2 * SHARED_U) {
         // TILE_SPARE (>= 3 blocks) keeps the look-ahead loads inside the allocation
-        load_obs_block<D>(bufB, base + (int64_t)(s0 + SHARED_U) * C * WAVE);
+        load_obs_block<D>(bufB, SSDE_ROWPTR(s0 + SHARED_U));
         run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu);
-        load_obs_block<D>(bufA, base + (int64_t)(s0 + 2 * SHARED_U) * C * WAVE);
+        load_obs_block<D>(bufA, SSDE_ROWPTR(s0 + 2 * SHARED_U));
         if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu);
     }
 }
@@ -498,7 +507,7 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     constexpr int C = 1 + D;
     constexpr int NACC = 4 + D;
     constexpr int SD = Lane::SD;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const TileView& tv = A.tv;
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -586,11 +595,20 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
 #define SSDE_SHARED_MINWAVES 1
 #endif
 template <int MODEL, int D, int MASK, bool STATONLY>
-__global__ __launch_bounds__(WAVE, SSDE_SHARED_MINWAVES) void iso_shared_kernel(const IsoArgs A) {
+__global__ __launch_bounds__(WG_WAVES * WAVE, SSDE_SHARED_MINWAVES) void iso_shared_kernel(const IsoArgs A) {
     int g, part, chunk;
     if (!decode_block(A, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
+#ifdef SSDE_DIAG_CLOCK   // diagnostic build only: the clock the chip holds inside this kernel (MI355X_MICROARCH.md, DVFS item 6)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     run_lane_shared<MODEL, D, MASK, STATONLY>(A, g, part, chunk);
+#ifdef SSDE_DIAG_CLOCK
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (STATONLY && threadIdx.x == 0 && (blockIdx.x == 100 || blockIdx.x == 200))
+        printf("block %d: %llu shader cycles, %llu x 10 ns -> %.3f GHz, %.1f us\n", (int)blockIdx.x, t1 - t0, r1 - r0,
+               (double)(t1 - t0) / (double)(r1 - r0) * 0.1, (double)(r1 - r0) * 0.01);
+#endif
 }
 
 // host side: the stationary constants (layout in ssde_device.hpp)
@@ -615,7 +633,7 @@ void fill_stat_consts(int model, int d, IsoArgs& a) {
 
 template <int MODEL, int D>
 static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
-    dim3 block(WAVE);
+    dim3 block(WG_WAVES * WAVE);
     switch (a.part_mask[0]) {
 #define SSDE_CASE(M)                                                                                     \
     case M:                                                                                              \
@@ -635,7 +653,7 @@ static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
     if (a.n_parts != 1) return hipErrorInvalidValue;
     const int g8 = (a.tv.n_groups + 7) / 8;
-    dim3 grid(g8 * 8 * a.n_chunks);
+    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES);
     if (grid.x == 0) return hipSuccess;
     if (model == M_CTCRW && d == 1) return launch_masks<M_CTCRW, 1>(a, grid, s);
     if (model == M_CTCRW && d == 2) return launch_masks<M_CTCRW, 2>(a, grid, s);

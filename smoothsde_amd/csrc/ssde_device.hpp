@@ -24,6 +24,10 @@
 namespace ssde {
 
 constexpr int WAVE = 64;
+constexpr int WG_WAVES = 4;       // waves per workgroup of the register Kalman kernels: the four waves of a
+                                 // workgroup land on the four SIMDs of one CU, which is what balances the SIMDs
+                                 // (single-wave workgroups were observed to be packed unevenly); the waves are
+                                 // independent work items and never synchronise
 constexpr int TILE_U = 4;        // steps per prefetch block of the general register kernel
 constexpr int WIN_ALIGN = 16;    // time-window starts / lengths / warm-ups are multiples of this many rows
 #ifndef SSDE_SHARED_U
@@ -205,7 +209,7 @@ __device__ __forceinline__ int chunk_len(int L, int n_chunks) {
 // XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
 // get such ids because they stream the same rows.
 __device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part, int& chunk) {
-    const int id = blockIdx.x;
+    const int id = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);   // one work item per WAVE
     const int np = A.n_parts, nc = A.n_chunks;
     const int hi = id >> 3;  // ((g/8) * nc + chunk) * np + part
     part = hi % np;

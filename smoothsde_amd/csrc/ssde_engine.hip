@@ -449,8 +449,9 @@ int build(const ssde_desc* d, ssde_handle* h) {
             int glmax = 0;
             for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
             h->glen_max = glmax;
-            // at most 2048 workgroups (two per SIMD) INCLUDING the padding of the group count to a multiple of 8
-            int want = std::max(1, 2048 / (((G + 7) / 8 * 8) * h->iso_parts));
+            // one wave per SIMD (1024 work items INCLUDING the padding of the group count to a multiple of 8):
+            // a lone wave already issues fp64 at the SIMD's rate, and fewer windows mean fewer warm-up rows
+            int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
             if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
             h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * WIN_ALIGN))));
             if (h->use_shared) {
