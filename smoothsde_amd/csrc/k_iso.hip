@@ -103,13 +103,8 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     const int pc = part * A.n_chunks + chunk;
 
     // this workgroup's window: rows [s_acc, s_end) are scored, rows [s_begin, s_acc) warm up
-    int s_begin = 0, s_acc = 0, s_end = L;
-    if (A.n_chunks > 1) {
-        const int cl = chunk_len(L, A.n_chunks);
-        s_acc = min(L, chunk * cl);
-        s_end = min(L, s_acc + cl);
-        s_begin = max(0, s_acc - A.window);
-    }
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end);
 
     typename Ops::State S;
     typename Ops::Trans tr = Ops::hoisted(A);
@@ -219,8 +214,8 @@ __global__ __launch_bounds__(4 * WAVE) void window_check_kernel(const IsoArgs A,
     const TileView& tv = A.tv;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
-    const int cl = chunk_len(L, A.n_chunks);
-    const int s_next = min(L, (c + 1) * cl);        // first scored row of window c+1
+    int sb_, s_next, se_;
+    window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_);   // s_next = first scored row of window c+1
     const bool valid = (ns > s_next) && (s_next < L);
     const int pc0 = part * A.n_chunks + c, pc1 = pc0 + 1;
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;

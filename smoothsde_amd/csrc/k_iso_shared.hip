@@ -518,13 +518,8 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     ns_min = __builtin_amdgcn_readfirstlane(ns_min);
     const int pc = part * A.n_chunks + chunk;
 
-    int s_begin = 0, s_acc = 0, s_end = L;
-    if (A.n_chunks > 1) {
-        const int cl = chunk_len(L, A.n_chunks);
-        s_acc = min(L, chunk * cl);
-        s_end = min(L, s_acc + cl);
-        s_begin = max(0, s_acc - A.window);
-    }
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end);
     // first row from which the stationary gains apply (gain_stat[0] == 0 would mean "never scored":
     // that degenerate case stays on the table path)
     int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;

@@ -75,7 +75,8 @@ struct IsoArgs {
     const int32_t* group_flags;  // [n_groups] bit 0: every track of the group is NaN-free
     int group_mode;              // 0: this launch handles every group; 1: only groups WITHOUT bit 0; 2: only groups WITH bit 0
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
-    int window;                  // warm-up rows of a window, multiple of TILE_U
+    int window;                  // warm-up rows of a window, multiple of WIN_ALIGN
+    int t0;                      // > 0: window 0 is the covariance transient [0, t0) (shared-covariance path)
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;
@@ -200,11 +201,30 @@ struct DenseArgs {
 hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------------
-#if defined(__HIPCC__)
-// window geometry shared by the kernels and the hand-over check
-__device__ __forceinline__ int chunk_len(int L, int n_chunks) {
-    return ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+// Window geometry shared by the kernels, the hand-over check and the engine.
+//   t0 == 0 : n_chunks equal windows over [0, L)
+//   t0 >  0 : window 0 is the covariance transient [0, t0) (no warm-up: it starts from the true initial
+//             state) and windows 1..n_chunks-1 split [t0, L) equally
+// Rows [s_acc, s_end) are scored, rows [s_begin, s_acc) warm up.  All bounds are multiples of WIN_ALIGN
+// (except L itself).
+__host__ __device__ inline void window_bounds(int L, int n_chunks, int window, int t0, int c, int& s_begin, int& s_acc,
+                                              int& s_end) {
+    if (n_chunks <= 1) { s_begin = 0; s_acc = 0; s_end = L; return; }
+    if (t0 > 0) {
+        if (c == 0) { s_begin = 0; s_acc = 0; s_end = L < t0 ? L : t0; return; }
+        const int rest = L > t0 ? L - t0 : 0;
+        const int cl = ((rest + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        s_acc = t0 + (c - 1) * cl; if (s_acc > L) s_acc = L;
+        s_end = s_acc + cl; if (s_end > L) s_end = L;
+    } else {
+        const int cl = ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        s_acc = c * cl; if (s_acc > L) s_acc = L;
+        s_end = s_acc + cl; if (s_end > L) s_end = L;
+    }
+    s_begin = s_acc - window; if (s_begin < 0) s_begin = 0;
 }
+
+#if defined(__HIPCC__)
 // Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
 // XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
 // get such ids because they stream the same rows.

@@ -94,6 +94,7 @@ struct ssde_handle {
     // iso time windows
     DevBuf<double> bnd, chk;
     int max_chunks = 1;            // allocation bound
+    int want_chunks = 1;           // planned number of equal windows (the transient window comes on top)
     int glen_max = 0;              // steps of the longest track group
     double dt_min = 0.0;           // smallest interval used inside a track
     int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
@@ -119,7 +120,7 @@ struct ssde_handle {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     bool ev_k_valid = false;
     std::vector<int32_t> glen_host, lane_ns_host;
-    int last_s_stat = 0;
+    int last_s_stat = 0, last_t0 = 0;
     mutable int rows_key[3] = {-1, -1, -1};
     mutable int64_t rows_cached = 0;
 
@@ -453,7 +454,8 @@ int build(const ssde_desc* d, ssde_handle* h) {
             // a lone wave already issues fp64 at the SIMD's rate, and fewer windows mean fewer warm-up rows
             int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
             if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
-            h->max_chunks = std::max(1, std::min(want, std::max(1, glmax / (4 * WIN_ALIGN))));
+            h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
+            h->want_chunks = std::max(1, std::min(want, h->max_chunks));
             if (h->use_shared) {
                 h->gain_rows_cap = (size_t)glmax + 1;
                 HIPCHK(h, h->gain_ring.alloc((size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW));
@@ -571,7 +573,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
         // group lengths are sorted descending: the first group is the longest
         glmax = h->glen_max;
     }
-    int nc = h->max_chunks;
+    int nc = h->want_chunks;
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
     *n_chunks = nc;
     *window = nc > 1 ? W : 0;
@@ -740,7 +742,17 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                                  : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
             if (st) return st;
             a.group_mode = 3;
+            // the covariance transient gets its own short window [0, t0): every other window (warm-up
+            // included) then lies in the stationary regime and runs the lean kernel
+            if (a.n_chunks > 1) {
+                const int s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+                a.t0 = (s_stat + a.window + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+                if (a.t0 + 2 * a.window >= h->glen_max) { a.t0 = 0; }            // tracks too short to bother
+                else if (a.n_chunks < h->max_chunks) a.n_chunks += 1;           // window 0 + the planned ones
+            }
+            h->last_chunks = a.n_chunks;
         }
+        h->last_t0 = a.t0;
         if (h->use_shared) {
             // three independent launches (stationary windows, transient windows, NaN-carrying groups):
             // fork onto side streams so they share the chip, join before the hand-over check / reduction
@@ -897,7 +909,7 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
         // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
         // until the windows agree with each other; 64x the estimate ends in one sequential window
         if (h->last_check <= SSDE_WINDOW_TOL || h->last_chunks <= 1) break;
-        if (attempt >= 3) h->max_chunks = 1;   // give up on windows for this handle: sequential filter
+        if (attempt >= 3) { h->max_chunks = 1; h->want_chunks = 1; }   // give up on windows: sequential filter
         else h->window_boost *= 4;
         h->n_retries++;
     }
@@ -949,7 +961,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
 
 int ssde_widen_windows(ssde_handle* h, int32_t factor) {
     if (!h) return SSDE_ERR_ARG;
-    if (factor <= 0) h->max_chunks = 1;
+    if (factor <= 0) { h->max_chunks = 1; h->want_chunks = 1; }
     else if (h->window_boost < (1 << 20)) h->window_boost *= factor;
     return SSDE_OK;
 }
@@ -984,17 +996,16 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     // windows that touch the covariance transient run in the small concurrent launch
     info->main_kernel_rows = h->n_steps;
     if (h->path == PATH_ISO && h->last_s_stat >= 0 && h->rows_key[0] == h->last_chunks &&
-        h->rows_key[1] == h->last_window && h->rows_key[2] == h->last_s_stat) {
+        h->rows_key[1] == h->last_window && h->rows_key[2] == h->last_s_stat + 100000 * h->last_t0) {
         info->main_kernel_rows = h->rows_cached;
     } else if (h->path == PATH_ISO && h->last_s_stat >= 0) {
         int64_t rows = 0;
         const int nc = h->last_chunks;
         for (int g = 0; g < h->n_groups; g++) {
             const int L = h->glen_host[g];
-            const int cl = nc > 1 ? ((L + nc - 1) / nc + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN : L;
             for (int c = 0; c < nc; c++) {
-                const int s_acc = std::min(L, c * cl), s_end = std::min(L, s_acc + cl);
-                const int s_begin = nc > 1 ? std::max(0, s_acc - h->last_window) : 0;
+                int s_begin, s_acc, s_end;
+                window_bounds(L, nc, h->last_window, h->last_t0, c, s_begin, s_acc, s_end);
                 if (s_begin < h->last_s_stat) continue;   // transient launch
                 for (int l = 0; l < WAVE; l++) {
                     const int ns = h->lane_ns_host[(size_t)g * WAVE + l];
@@ -1004,7 +1015,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         }
         info->main_kernel_rows = rows;
         h->rows_cached = rows;
-        h->rows_key[0] = h->last_chunks; h->rows_key[1] = h->last_window; h->rows_key[2] = h->last_s_stat;
+        h->rows_key[0] = h->last_chunks; h->rows_key[1] = h->last_window; h->rows_key[2] = h->last_s_stat + 100000 * h->last_t0;
     }
     return SSDE_OK;
 }
