@@ -169,7 +169,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 template <int MODEL, int D, int MASK>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
     int g, part, chunk;
-    if (!decode_block(A, g, part, chunk)) return;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
     run_lane<MODEL, D, MASK>(A, g, part, chunk);
 }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_kernel(const IsoA
 template <int MODEL, int D>
 __global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
     int g, part, chunk;
-    if (!decode_block(A, g, part, chunk)) return;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
     // (no dynamic indexing into the by-value argument block: that would force a scratch copy)
     const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];

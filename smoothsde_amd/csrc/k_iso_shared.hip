@@ -524,7 +524,6 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     // that degenerate case stays on the table path)
     int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
     if (A.gain_stat[0] == 0.0) s_stat = INT32_MAX;
-    if (STATONLY != (s_begin >= s_stat)) return;   // the other launch owns this window
 
     Lane S;
     S.setup(A);
@@ -583,27 +582,25 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     }
 }
 
-// One kernel per (model, dimension, direction mask, stat-only): the register allocation of a
-// kernel is the worst case over everything it contains, so the masks are NOT folded into one
-// kernel with a switch here (k_iso.hip does that for the general path).
-#ifndef SSDE_SHARED_MINWAVES
-#define SSDE_SHARED_MINWAVES 1
-#endif
-template <int MODEL, int D, int MASK, bool STATONLY>
-__global__ __launch_bounds__(WG_WAVES * WAVE, SSDE_SHARED_MINWAVES) void iso_shared_kernel(const IsoArgs A) {
+// One kernel per (model, dimension, direction mask): the register allocation of a kernel is the worst
+// case over everything it contains, so the masks are NOT folded into one kernel with a switch here.
+// With a dedicated transient window (t0 > 0) the grid enumerates windows 1..n_chunks-1; the wave that
+// owns window 1 first runs window 0 (direction form, gain table), every window >= 1 runs the lean
+// basis-form code.  Without it (short tracks, a single window) every wave runs the general shared code.
+template <int MODEL, int D, int MASK>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_shared_kernel(const IsoArgs A) {
     int g, part, chunk;
-    if (!decode_block(A, g, part, chunk)) return;
-    if (!group_selected(A, g)) return;
-#ifdef SSDE_DIAG_CLOCK   // diagnostic build only: the clock the chip holds inside this kernel (MI355X_MICROARCH.md, DVFS item 6)
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    run_lane_shared<MODEL, D, MASK, STATONLY>(A, g, part, chunk);
-#ifdef SSDE_DIAG_CLOCK
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (STATONLY && threadIdx.x == 0 && (blockIdx.x == 100 || blockIdx.x == 200))
-        printf("block %d: %llu shader cycles, %llu x 10 ns -> %.3f GHz, %.1f us\n", (int)blockIdx.x, t1 - t0, r1 - r0,
-               (double)(t1 - t0) / (double)(r1 - r0) * 0.1, (double)(r1 - r0) * 0.01);
-#endif
+    if (A.t0 > 0) {
+        if (!decode_block(A, A.n_chunks - 1, g, part, chunk)) return;
+        if (!group_selected(A, g)) return;
+        chunk += 1;
+        if (chunk == 1) run_lane_shared<MODEL, D, MASK, false>(A, g, part, 0);
+        run_lane_shared<MODEL, D, MASK, true>(A, g, part, chunk);
+    } else {
+        if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+        if (!group_selected(A, g)) return;
+        run_lane_shared<MODEL, D, MASK, false>(A, g, part, chunk);
+    }
 }
 
 // host side: the stationary constants (layout in ssde_device.hpp)
@@ -630,11 +627,7 @@ template <int MODEL, int D>
 static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
     dim3 block(WG_WAVES * WAVE);
     switch (a.part_mask[0]) {
-#define SSDE_CASE(M)                                                                                     \
-    case M:                                                                                              \
-        if (a.stat_only) hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M, false>), grid, block, 0, s, a);          \
-        break;
+#define SSDE_CASE(M) case M: hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE
@@ -643,12 +636,12 @@ static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0]);
-// a.stat_only selects the lean kernel (windows past the transient) or the transient kernel
+// the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0])
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
     if (a.n_parts != 1) return hipErrorInvalidValue;
     const int g8 = (a.tv.n_groups + 7) / 8;
-    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES);
+    const int n_grid_chunks = a.t0 > 0 ? a.n_chunks - 1 : a.n_chunks;
+    dim3 grid((g8 * 8 * n_grid_chunks + WG_WAVES - 1) / WG_WAVES);
     if (grid.x == 0) return hipSuccess;
     if (model == M_CTCRW && d == 1) return launch_masks<M_CTCRW, 1>(a, grid, s);
     if (model == M_CTCRW && d == 2) return launch_masks<M_CTCRW, 2>(a, grid, s);

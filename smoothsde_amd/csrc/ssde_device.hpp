@@ -71,7 +71,6 @@ struct IsoArgs {
     //           | 19+a cx_a | 21+a cv_a | 23+a bmu_a
     //   OU/BM : 0 iF 1 k 2 c=t-k 3 t 4 b 5 dt_ | 10+j hd_j | 13+j dk_j | 19+a cmu_a | 21+a dbmu_a
     double statc[32];
-    int stat_only;               // 1: this launch handles only windows that lie entirely past the transient
     const int32_t* group_flags;  // [n_groups] bit 0: every track of the group is NaN-free
     int group_mode;              // 0: this launch handles every group; 1: only groups WITHOUT bit 0; 2: only groups WITH bit 0
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
@@ -212,10 +211,14 @@ __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, i
     if (n_chunks <= 1) { s_begin = 0; s_acc = 0; s_end = L; return; }
     if (t0 > 0) {
         if (c == 0) { s_begin = 0; s_acc = 0; s_end = L < t0 ? L : t0; return; }
+        // the wave that owns window 1 also runs window 0 first (and window 0's rows cost ~1.5x): window 1
+        // is shortened by delta so that all waves finish together
+        const int delta = (3 * t0 / 2 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         const int rest = L > t0 ? L - t0 : 0;
-        const int cl = ((rest + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-        s_acc = t0 + (c - 1) * cl; if (s_acc > L) s_acc = L;
-        s_end = s_acc + cl; if (s_end > L) s_end = L;
+        int cl = ((rest + delta + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        if (cl <= delta + WIN_ALIGN) cl = delta + 2 * WIN_ALIGN;
+        s_acc = (c == 1) ? t0 : t0 + (c - 1) * cl - delta; if (s_acc > L) s_acc = L;
+        s_end = t0 + c * cl - delta; if (s_end > L) s_end = L; if (s_end < s_acc) s_end = s_acc;
     } else {
         const int cl = ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         s_acc = c * cl; if (s_acc > L) s_acc = L;
@@ -228,9 +231,10 @@ __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, i
 // Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
 // XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
 // get such ids because they stream the same rows.
-__device__ __forceinline__ bool decode_block(const IsoArgs& A, int& g, int& part, int& chunk) {
+// nc = number of windows the GRID enumerates (the shared-covariance kernel enumerates windows 1.. only)
+__device__ __forceinline__ bool decode_block(const IsoArgs& A, int nc, int& g, int& part, int& chunk) {
     const int id = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);   // one work item per WAVE
-    const int np = A.n_parts, nc = A.n_chunks;
+    const int np = A.n_parts;
     const int hi = id >> 3;  // ((g/8) * nc + chunk) * np + part
     part = hi % np;
     chunk = (hi / np) % nc;

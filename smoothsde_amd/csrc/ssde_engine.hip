@@ -754,28 +754,22 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         }
         h->last_t0 = a.t0;
         if (h->use_shared) {
-            // three independent launches (stationary windows, transient windows, NaN-carrying groups):
-            // fork onto side streams so they share the chip, join before the hand-over check / reduction
-            HIPCHK(h, hipEventRecord(h->ev_fork, s));
+            // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
+            // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check
             IsoArgs b = a;
             b.group_mode = 2;
-            b.stat_only = 0;
-            HIPCHK(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
-            HIPCHK(h, launch_iso_shared(h->model, h->d, b, h->aux[0]));   // few, slower blocks first
-            HIPCHK(h, hipEventRecord(h->ev_join[0], h->aux[0]));
             const bool any_dirty = h->n_clean_groups < h->n_groups;
             if (any_dirty) {
+                HIPCHK(h, hipEventRecord(h->ev_fork, s));
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
                 HIPCHK(h, launch_iso(h->model, h->d, a, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
-            b.stat_only = 1;
             HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_iso_shared(h->model, h->d, b, s));
             HIPCHK(h, hipEventRecord(h->ev_k1, s));
             h->ev_k_valid = true;
             h->last_s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
-            HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[0], 0));
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
         } else {
             HIPCHK(h, hipEventRecord(h->ev_k0, s));
@@ -1006,7 +1000,6 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
             for (int c = 0; c < nc; c++) {
                 int s_begin, s_acc, s_end;
                 window_bounds(L, nc, h->last_window, h->last_t0, c, s_begin, s_acc, s_end);
-                if (s_begin < h->last_s_stat) continue;   // transient launch
                 for (int l = 0; l < WAVE; l++) {
                     const int ns = h->lane_ns_host[(size_t)g * WAVE + l];
                     rows += std::max(0, std::min(ns, s_end) - s_acc);
