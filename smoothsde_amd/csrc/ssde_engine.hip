@@ -974,7 +974,8 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_steps = h->n_steps;
     info->hbm_bytes = h->hbm_bytes;
     info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols);
-    if (h->path == PATH_ISO) info->n_kernel_blocks = (h->n_groups + 7) / 8 * 8 * h->iso_parts * h->last_chunks;
+    if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
+        info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * (h->last_t0 > 0 ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;
     else info->n_kernel_blocks = h->direct_blocks;
     info->lanes_per_track = h->path == PATH_ISO ? h->iso_parts * h->last_chunks : (h->path == PATH_DENSE ? h->n_dirblocks : 1);
