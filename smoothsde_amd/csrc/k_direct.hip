@@ -142,6 +142,169 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     }
 }
 
+// ---- fast kernel -------------------------------------------------------------------------------------
+// KA / KB: register capacity for the streamed columns of the (at most two) parameters that have any.
+template <int MODEL, int D, int KA, int KB>
+__global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A) {
+    constexpr int Q = (MODEL == M_BM) ? D + 1 : D + 2;
+    const int ncA = A.ncA, ncB = A.ncB, ja = A.ja, jb = A.jb;
+    const int64_t n = A.n;
+    double accI[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
+    double accA[KA > 0 ? KA : 1], accB[KB > 0 ? KB : 1];
+#pragma unroll
+    for (int c = 0; c < KA; c++) accA[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < KB; c++) accB[c] = 0.0;
+    double nll = 0.0;
+    const bool varies1 = (ja == D) || (jb == D), varies2 = (ja == D + 1) || (jb == D + 1);
+    // natural-scale values / derived constants of parameters that have no streamed column
+    const double nat_p1 = exp(A.base[D]);
+    const double nat_p2 = (Q > D + 1) ? exp(A.base[D + 1]) : 0.0;
+    const double inv_p1 = 1.0 / nat_p1;
+    // with a regular grid and constant scale parameters the whole transition kernel is row-independent
+    const bool all_const = A.uniform_dt && !varies1 && !varies2;
+    double c_e = 0.0, c_isd = 0.0, c_lsd = 0.0, c_dls = 0.0, c_z = 0.0;
+    if (all_const) {
+        const double dt = A.dt_uniform;
+        if (MODEL == M_BM) {
+            const double sd = nat_p1 * sqrt(dt);
+            c_isd = 1.0 / sd; c_lsd = log(sd);
+        } else {
+            c_z = dt * inv_p1; c_e = exp(-c_z);
+            const double ome2 = 1.0 - c_e * c_e, var = nat_p2 * ome2;
+            c_isd = 1.0 / sqrt(var); c_lsd = 0.5 * log(var); c_dls = -c_e * c_e * c_z / ome2;
+        }
+    }
+
+    const int64_t per_block = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t row_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t row_hi = row_lo + per_block < n ? row_lo + per_block : n;
+    for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
+        if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
+        const double dt = all_const ? A.dt_uniform : A.times[i] - A.times[i - 1];   // dtimes(i-1), nllk_sde.hpp:37,80
+        // streamed columns of row i-1 (Q6) and the two linear predictors they feed
+        double wA[KA > 0 ? KA : 1], wB[KB > 0 ? KB : 1];
+        double sumA = 0.0, sumB = 0.0;
+#pragma unroll
+        for (int c = 0; c < KA; c++)
+            if (c < ncA) { wA[c] = A.colA[(int64_t)c * n + (i - 1)]; sumA = fma(wA[c], A.coefA[c], sumA); }
+#pragma unroll
+        for (int c = 0; c < KB; c++)
+            if (c < ncB) { wB[c] = A.colB[(int64_t)c * n + (i - 1)]; sumB = fma(wB[c], A.coefB[c], sumB); }
+        double par[MAX_Q];
+#pragma unroll
+        for (int j = 0; j < MAX_Q; j++) par[j] = A.base[j] + ((j == ja) ? sumA : 0.0) + ((j == jb) ? sumB : 0.0);
+
+        double g[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
+        if (MODEL == M_BM) {
+            double isd = c_isd, lsd = c_lsd;
+            if (!all_const) {
+                const double sd = (varies1 ? exp(par[D]) : nat_p1) * sqrt(dt);   // tr_dens.hpp:36
+                isd = rcp(sd); lsd = log(sd);
+            }
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double z0 = A.obs[(i - 1) + (int64_t)a * n], z1 = A.obs[i + (int64_t)a * n];
+                if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;          // tr_dens.hpp:31
+                const double r = (z1 - (z0 + par[a] * dt)) * isd;                    // :35, :37
+                g[a] += -r * dt * isd;
+                g[D] += 1.0 - r * r;
+                nll += SSDE_LOG_SQRT_2PI + lsd + 0.5 * r * r;
+            }
+        } else {
+            double e = c_e, isd = c_isd, lsd = c_lsd, dls_lt = c_dls, z = c_z;
+            if (!all_const) {
+                z = dt * (varies1 ? rcp(exp(par[D])) : inv_p1);                       // dt / tau
+                e = exp(-z);
+                const double ome2 = 1.0 - e * e;
+                const double var = (varies2 ? exp(par[D + 1]) : nat_p2) * ome2;      // tr_dens.hpp:50-51
+                isd = rcp(sqrt(var)); lsd = 0.5 * log(var);
+                dls_lt = -e * e * z * rcp(ome2);
+            }
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double z0 = A.obs[(i - 1) + (int64_t)a * n], z1 = A.obs[i + (int64_t)a * n];
+                if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;
+                const double mu = par[a];
+                const double r = (z1 - (mu + e * (z0 - mu))) * isd;                  // :49, :52
+                g[a] += -r * (1.0 - e) * isd;
+                g[D] += -r * (e * z * (z0 - mu)) * isd + (1.0 - r * r) * dls_lt;
+                g[D + 1] += 0.5 * (1.0 - r * r);
+                nll += SSDE_LOG_SQRT_2PI + lsd + 0.5 * r * r;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAX_Q; j++) accI[j] += g[j];
+        const double gA = (ja == 0) ? g[0] : (ja == 1) ? g[1] : (ja == 2) ? g[2] : g[3];
+        const double gB = (jb == 0) ? g[0] : (jb == 1) ? g[1] : (jb == 2) ? g[2] : g[3];
+#pragma unroll
+        for (int c = 0; c < KA; c++)
+            if (c < ncA) accA[c] = fma(wA[c], gA, accA[c]);
+#pragma unroll
+        for (int c = 0; c < KB; c++)
+            if (c < ncB) accB[c] = fma(wB[c], gB, accB[c]);
+    }
+
+    // workgroup reduction: accumulator order = [nll | Q intercept slots | ncA | ncB]
+    constexpr int NMAX = 1 + MAX_Q + KA + KB;
+    __shared__ double sh[4][NMAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double t = wave_sum(nll);
+    if (lane == 0) sh[wv][0] = t;
+#pragma unroll
+    for (int j = 0; j < MAX_Q; j++) { t = wave_sum(accI[j]); if (lane == 0) sh[wv][1 + j] = t; }
+#pragma unroll
+    for (int c = 0; c < KA; c++) { t = wave_sum(accA[c]); if (lane == 0) sh[wv][1 + MAX_Q + c] = t; }
+#pragma unroll
+    for (int c = 0; c < KB; c++) { t = wave_sum(accB[c]); if (lane == 0) sh[wv][1 + MAX_Q + KA + c] = t; }
+    __syncthreads();
+    const int nacc = 1 + MAX_Q + ncA + ncB;
+    if ((int)threadIdx.x < nacc) {
+        int k = threadIdx.x;   // output slot
+        int src = k < 1 + MAX_Q + ncA ? k : 1 + MAX_Q + KA + (k - (1 + MAX_Q + ncA));
+        A.partials[(int64_t)k * A.n_blocks + blockIdx.x] = (sh[0][src] + sh[1][src]) + (sh[2][src] + sh[3][src]);
+    }
+}
+
+hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
+    dim3 grid(a.n_blocks), block(256);
+#define SSDE_F(MODEL, D, KA, KB)                                                            \
+    if (a.model == MODEL && a.d == D && a.ncA <= KA && a.ncB <= KB) {                       \
+        hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB>), grid, block, 0, s, a);   \
+        return hipGetLastError();                                                           \
+    }
+#define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
+    SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2)
+#undef SSDE_FK
+#undef SSDE_F
+    return hipErrorInvalidValue;
+}
+
+// min / max of the scored intervals (regular-grid detection for the direct families)
+__global__ __launch_bounds__(256) void dt_minmax_kernel(const double* times, const uint32_t* scored, int64_t n, double* out) {
+    __shared__ double sh[2][4];
+    double mn = INFINITY, mx = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (i >= 1 && ((scored[i >> 5] >> (i & 31)) & 1u)) {
+            const double dt = times[i] - times[i - 1];
+            mn = fmin(mn, dt); mx = fmax(mx, dt);
+            if (dt != dt) mx = INFINITY;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mn; sh[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = fmin(fmin(sh[0][0], sh[0][1]), fmin(sh[0][2], sh[0][3]));
+        out[2 * blockIdx.x + 1] = fmax(fmax(sh[1][0], sh[1][1]), fmax(sh[1][2], sh[1][3]));
+    }
+}
+hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t n, double* out, int n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(dt_minmax_kernel, dim3(n_blocks), dim3(256), 0, s, times, scored, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_direct(const DirectArgs& a, hipStream_t s) {
     dim3 grid(a.n_blocks), block(256);
 #define SSDE_L(MODEL, D, K)                                                            \

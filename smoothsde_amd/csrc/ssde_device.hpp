@@ -175,6 +175,32 @@ struct DirectArgs {
 };
 hipError_t launch_direct(const DirectArgs& a, hipStream_t s);
 
+// Fast direct kernel: at most two SDE parameters have streamed design columns (the common case: one or
+// two smooth terms); their column blocks are contiguous in the engine-owned column buffer, so a column
+// is base + c * n, and the slot -> parameter routing is static inside the kernel.
+constexpr int DIRECT_KCAP = 24;   // streamed columns per parameter the fast kernel can hold
+struct DirectFastArgs {
+    const double* times;
+    const double* obs;
+    const uint32_t* scored;
+    int64_t n;
+    int d, model, any_nan;
+    int n_blocks;
+    double* partials;             // [1 + n_acc][n_blocks], accumulators: q intercept slots, then ncA, then ncB
+    double base[MAX_Q];           // intercept part of every parameter (working scale)
+    int has_icpt[MAX_Q];          // parameter has an intercept coefficient (its gradient is wanted)
+    int ja, jb;                   // parameters with streamed columns (-1 = none)
+    int ncA, ncB;
+    const double* colA;           // first streamed column of parameter ja (columns are n apart)
+    const double* colB;
+    double coefA[DIRECT_KCAP], coefB[DIRECT_KCAP];
+    int uniform_dt;               // every scored interval equals dt_uniform
+    double dt_uniform;
+};
+hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s);
+hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t n, double* out2_per_block, int n_blocks,
+                            hipStream_t s);
+
 // ---- dense / time-varying Kalman (k_dense.hip) ----------------------------------------------------
 constexpr int DENSE_NT = 2;      // tangent directions per lane
 struct DenseDir {                // one gradient direction

@@ -77,6 +77,15 @@ struct ssde_handle {
     DevBuf<const double*> colptr;
     int direct_blocks = 0;
 
+    // fast direct kernel (<= 2 parameters with streamed columns)
+    bool direct_fast = false;
+    int df_ja = -1, df_jb = -1;
+    std::vector<int> df_pidxA, df_pidxB;          // full-par indices of the streamed coefficients
+    int df_icpt[MAX_Q] = {-1, -1, -1, -1};         // full-par index of each parameter's intercept, or -1
+    const double *df_colA = nullptr, *df_colB = nullptr;
+    bool direct_uniform_dt = false;
+    double direct_dt = 0.0;
+
     // dense / direct parameter plumbing
     DevBuf<SlotTable> slot_table;
     DevBuf<DenseDir> dirs;
@@ -320,7 +329,46 @@ int build(const ssde_desc* d, ssde_handle* h) {
             idb.release();
         }
         h->direct_blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-        h->partial_doubles = (size_t)(1 + h->slots.size()) * h->direct_blocks;
+        h->partial_doubles = (size_t)(1 + MAX_Q + h->slots.size()) * h->direct_blocks;
+        {
+            // regular grid?  (min / max over the scored intervals)
+            const int nb = 1024;
+            DevBuf<double> mm;
+            HIPCHK(h, mm.alloc((size_t)nb * 2));
+            HIPCHK(h, launch_dt_minmax(h->times.p, h->scored.p, n, mm.p, nb, 0));
+            std::vector<double> mmh((size_t)nb * 2);
+            HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
+            double dmin = INFINITY, dmax = -INFINITY;
+            for (int b = 0; b < nb; b++) { dmin = std::min(dmin, mmh[2 * b]); dmax = std::max(dmax, mmh[2 * b + 1]); }
+            h->direct_uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
+            h->direct_dt = h->direct_uniform_dt ? dmin : 0.0;
+            h->uniform_dt = h->direct_uniform_dt;
+            mm.release();
+            // which parameters have streamed columns (slots are ordered parameter by parameter)
+            std::vector<int> streamed_par;
+            for (auto& sl : h->slots) {
+                if (sl.col < 0) { h->df_icpt[sl.par_j] = sl.pidx; continue; }
+                if (streamed_par.empty() || streamed_par.back() != sl.par_j) streamed_par.push_back(sl.par_j);
+            }
+            bool ok = streamed_par.size() <= 2 && !getenv("SSDE_NO_DIRECT_FAST");
+            if (ok) {
+                for (auto& sl : h->slots) {
+                    if (sl.col < 0) continue;
+                    const bool isA = sl.par_j == streamed_par[0];
+                    auto& pid = isA ? h->df_pidxA : h->df_pidxB;
+                    const double*& base = isA ? h->df_colA : h->df_colB;
+                    if (pid.empty()) base = h->colbuf.p + (size_t)sl.col * n;
+                    else if (h->colbuf.p + (size_t)sl.col * n != base + pid.size() * (size_t)n) ok = false;  // must be contiguous
+                    pid.push_back(sl.pidx);
+                }
+                if ((int)h->df_pidxA.size() > DIRECT_KCAP || (int)h->df_pidxB.size() > DIRECT_KCAP) ok = false;
+            }
+            h->direct_fast = ok;
+            if (ok) {
+                h->df_ja = streamed_par.size() > 0 ? streamed_par[0] : -1;
+                h->df_jb = streamed_par.size() > 1 ? streamed_par[1] : -1;
+            }
+        }
         h->hbm_bytes = (int64_t)(h->times.n + h->obs.n + h->colbuf.n) * 8 + (int64_t)h->scored.n * 4;
     } else {
         // ---- Kalman families: pick the path, then tile ------------------------------------------------
@@ -825,6 +873,39 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         }
         ra.n_blocks = h->n_groups;
     } else {
+        if (h->direct_fast) {
+            DirectFastArgs f;
+            memset(&f, 0, sizeof(f));
+            f.times = h->times.p; f.obs = h->obs.p; f.scored = h->scored.p; f.n = h->n;
+            f.d = h->d; f.model = h->model; f.any_nan = h->na_any; f.n_blocks = h->direct_blocks;
+            f.partials = h->partials.p;
+            for (int j = 0; j < MAX_Q; j++) {
+                f.has_icpt[j] = h->df_icpt[j] >= 0;
+                f.base[j] = h->df_icpt[j] >= 0 ? par[h->df_icpt[j]] : 0.0;
+            }
+            f.ja = h->df_ja; f.jb = h->df_jb;
+            f.ncA = (int)h->df_pidxA.size(); f.ncB = (int)h->df_pidxB.size();
+            f.colA = h->df_colA; f.colB = h->df_colB;
+            for (int c = 0; c < f.ncA; c++) f.coefA[c] = par[h->df_pidxA[c]];
+            for (int c = 0; c < f.ncB; c++) f.coefB[c] = par[h->df_pidxB[c]];
+            f.uniform_dt = h->direct_uniform_dt ? 1 : 0;
+            f.dt_uniform = h->direct_dt;
+            HIPCHK(h, hipEventRecord(h->ev_k0, s));
+            HIPCHK(h, launch_direct_fast(f, s));
+            HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            h->ev_k_valid = true; h->last_s_stat = -1;
+            ra.n_parts = 1; ra.nacc = 1 + MAX_Q + f.ncA + f.ncB; ra.n_blocks = h->direct_blocks;
+            if (order >= 1) {
+                for (int j = 0; j < MAX_Q; j++)
+                    if (h->df_icpt[j] >= 0 && !h->fixed[h->df_icpt[j]]) ra.map[j] = (int16_t)(1 + h->df_icpt[j]);
+                for (int c = 0; c < f.ncA; c++)
+                    if (!h->fixed[h->df_pidxA[c]]) ra.map[MAX_Q + c] = (int16_t)(1 + h->df_pidxA[c]);
+                for (int c = 0; c < f.ncB; c++)
+                    if (!h->fixed[h->df_pidxB[c]]) ra.map[MAX_Q + f.ncA + c] = (int16_t)(1 + h->df_pidxB[c]);
+            }
+            HIPCHK(h, launch_reduce(ra, s));
+            return SSDE_OK;
+        }
         const double* pdev = nullptr;
         int st = push_par(h, par, s, &pdev);
         if (st) return st;
