@@ -179,18 +179,28 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     const int64_t per_block = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
     const int64_t row_lo = (int64_t)blockIdx.x * per_block;
     const int64_t row_hi = row_lo + per_block < n ? row_lo + per_block : n;
-    for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
-        if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
-        const double dt = all_const ? A.dt_uniform : A.times[i] - A.times[i - 1];   // dtimes(i-1), nllk_sde.hpp:37,80
+    // The loop runs over the EARLIER row r of each transition (r -> r+1): the design columns, which are
+    // read at the earlier row (Q6), are then fetched at 512-B-aligned wave addresses.  Streams are read
+    // once: non-temporal loads.
+    for (int64_t r = row_lo + threadIdx.x; r < row_hi; r += 256) {
+        const int64_t i = r + 1;
+        if (i >= n || !((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
+        const double dt = all_const ? A.dt_uniform
+                                    : __builtin_nontemporal_load(&A.times[i]) - __builtin_nontemporal_load(&A.times[r]);  // dtimes(i-1)
         // streamed columns of row i-1 (Q6) and the two linear predictors they feed
         double wA[KA > 0 ? KA : 1], wB[KB > 0 ? KB : 1];
         double sumA = 0.0, sumB = 0.0;
+        // ALL KA / KB register slots are loaded unconditionally (slots past the column count re-read the last
+        // real column and carry a zero coefficient): a guard per slot would make hipcc branch around every load
+        // and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
 #pragma unroll
-        for (int c = 0; c < KA; c++)
-            if (c < ncA) { wA[c] = A.colA[(int64_t)c * n + (i - 1)]; sumA = fma(wA[c], A.coefA[c], sumA); }
+        for (int c = 0; c < KA; c++) wA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r]);
 #pragma unroll
-        for (int c = 0; c < KB; c++)
-            if (c < ncB) { wB[c] = A.colB[(int64_t)c * n + (i - 1)]; sumB = fma(wB[c], A.coefB[c], sumB); }
+        for (int c = 0; c < KB; c++) wB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r]);
+#pragma unroll
+        for (int c = 0; c < KA; c++) sumA = fma(wA[c], A.coefA[c], sumA);
+#pragma unroll
+        for (int c = 0; c < KB; c++) sumB = fma(wB[c], A.coefB[c], sumB);
         double par[MAX_Q];
 #pragma unroll
         for (int j = 0; j < MAX_Q; j++) par[j] = A.base[j] + ((j == ja) ? sumA : 0.0) + ((j == jb) ? sumB : 0.0);
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             }
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double z0 = A.obs[(i - 1) + (int64_t)a * n], z1 = A.obs[i + (int64_t)a * n];
+                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
                 if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;          // tr_dens.hpp:31
                 const double r = (z1 - (z0 + par[a] * dt)) * isd;                    // :35, :37
                 g[a] += -r * dt * isd;
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             }
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double z0 = A.obs[(i - 1) + (int64_t)a * n], z1 = A.obs[i + (int64_t)a * n];
+                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
                 if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;
                 const double mu = par[a];
                 const double r = (z1 - (mu + e * (z0 - mu))) * isd;                  // :49, :52
@@ -238,11 +248,9 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
         const double gA = (ja == 0) ? g[0] : (ja == 1) ? g[1] : (ja == 2) ? g[2] : g[3];
         const double gB = (jb == 0) ? g[0] : (jb == 1) ? g[1] : (jb == 2) ? g[2] : g[3];
 #pragma unroll
-        for (int c = 0; c < KA; c++)
-            if (c < ncA) accA[c] = fma(wA[c], gA, accA[c]);
+        for (int c = 0; c < KA; c++) accA[c] = fma(wA[c], gA, accA[c]);   // slots >= ncA are never read back
 #pragma unroll
-        for (int c = 0; c < KB; c++)
-            if (c < ncB) accB[c] = fma(wB[c], gB, accB[c]);
+        for (int c = 0; c < KB; c++) accB[c] = fma(wB[c], gB, accB[c]);
     }
 
     // workgroup reduction: accumulator order = [nll | Q intercept slots | ncA | ncB]
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
 hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
     dim3 grid(a.n_blocks), block(256);
 #define SSDE_F(MODEL, D, KA, KB)                                                            \
-    if (a.model == MODEL && a.d == D && a.ncA <= KA && a.ncB <= KB) {                       \
+    if (a.model == MODEL && a.d == D && a.ncA <= KA && a.ncB <= KB && (KA == 0 || a.ncA > 0) && (KB == 0 || a.ncB > 0)) { \
         hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB>), grid, block, 0, s, a);   \
         return hipGetLastError();                                                           \
     }

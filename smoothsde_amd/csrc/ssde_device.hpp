@@ -191,7 +191,8 @@ struct DirectFastArgs {
     int has_icpt[MAX_Q];          // parameter has an intercept coefficient (its gradient is wanted)
     int ja, jb;                   // parameters with streamed columns (-1 = none)
     int ncA, ncB;
-    const double* colA;           // first streamed column of parameter ja (columns are n apart)
+    int64_t col_stride;           // doubles between consecutive streamed columns
+    const double* colA;           // first streamed column of parameter ja
     const double* colB;
     double coefA[DIRECT_KCAP], coefB[DIRECT_KCAP];
     int uniform_dt;               // every scored interval equals dt_uniform

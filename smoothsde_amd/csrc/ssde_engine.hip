@@ -79,6 +79,7 @@ struct ssde_handle {
 
     // fast direct kernel (<= 2 parameters with streamed columns)
     bool direct_fast = false;
+    int64_t col_stride = 0;                        // doubles between consecutive streamed columns
     int df_ja = -1, df_jb = -1;
     std::vector<int> df_pidxA, df_pidxB;          // full-par indices of the streamed coefficients
     int df_icpt[MAX_Q] = {-1, -1, -1, -1};         // full-par index of each parameter's intercept, or -1
@@ -310,11 +311,15 @@ int build(const ssde_desc* d, ssde_handle* h) {
         h->path = PATH_DIRECT;
         HIPCHK(h, stage(d->times, (size_t)n, on_dev, h->times));
         HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, on_dev, h->obs));
-        HIPCHK(h, h->colbuf.alloc((size_t)n * h->n_stream_cols));
+        // column stride: padded so that the same row of different columns does not fall on addresses that are
+        // equal modulo a large power of two (all columns of a row are fetched together)
+        h->col_stride = ((n + 63) / 64) * 64 + 160;
+        if (const char* e = getenv("SSDE_COL_PAD")) h->col_stride = ((n + 63) / 64) * 64 + atoi(e);
+        HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * h->n_stream_cols));
         std::vector<const double*> cp(h->n_stream_cols, nullptr);
         for (auto& s : h->slots)
             if (s.col >= 0) {
-                double* dst = h->colbuf.p + (size_t)s.col * n;
+                double* dst = h->colbuf.p + (size_t)s.col * h->col_stride;
                 HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
                 cp[s.col] = dst;
             }
@@ -329,6 +334,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             idb.release();
         }
         h->direct_blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+        if (const char* e = getenv("SSDE_DIRECT_BLOCKS")) h->direct_blocks = std::max(1, std::min(atoi(e), 65536));
         h->partial_doubles = (size_t)(1 + MAX_Q + h->slots.size()) * h->direct_blocks;
         {
             // regular grid?  (min / max over the scored intervals)
@@ -357,8 +363,8 @@ int build(const ssde_desc* d, ssde_handle* h) {
                     const bool isA = sl.par_j == streamed_par[0];
                     auto& pid = isA ? h->df_pidxA : h->df_pidxB;
                     const double*& base = isA ? h->df_colA : h->df_colB;
-                    if (pid.empty()) base = h->colbuf.p + (size_t)sl.col * n;
-                    else if (h->colbuf.p + (size_t)sl.col * n != base + pid.size() * (size_t)n) ok = false;  // must be contiguous
+                    if (pid.empty()) base = h->colbuf.p + (size_t)sl.col * h->col_stride;
+                    else if (h->colbuf.p + (size_t)sl.col * h->col_stride != base + pid.size() * (size_t)h->col_stride) ok = false;  // contiguous
                     pid.push_back(sl.pidx);
                 }
                 if ((int)h->df_pidxA.size() > DIRECT_KCAP || (int)h->df_pidxB.size() > DIRECT_KCAP) ok = false;
@@ -885,7 +891,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
             f.ja = h->df_ja; f.jb = h->df_jb;
             f.ncA = (int)h->df_pidxA.size(); f.ncB = (int)h->df_pidxB.size();
-            f.colA = h->df_colA; f.colB = h->df_colB;
+            f.colA = h->df_colA; f.colB = h->df_colB; f.col_stride = h->col_stride;
             for (int c = 0; c < f.ncA; c++) f.coefA[c] = par[h->df_pidxA[c]];
             for (int c = 0; c < f.ncB; c++) f.coefB[c] = par[h->df_pidxB[c]];
             f.uniform_dt = h->direct_uniform_dt ? 1 : 0;
