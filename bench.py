@@ -35,8 +35,8 @@ def cpu_baseline(seconds_target=15.0):
     from oracle_lib import oracle_eval
     from smoothsde_amd import capi
     from smoothsde_amd.synth import simulate
-    cores = os.cpu_count() or 1
-    tracks, rows = 4 * cores, 2000
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    tracks, rows = 8 * cores, 2000
     ID, times, obs = simulate("CTCRW", tracks, rows, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
     fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
     pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed)
