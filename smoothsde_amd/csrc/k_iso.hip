@@ -113,19 +113,34 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
 
-    double cur[TILE_U][C], nxt[TILE_U][C];
-    load_block<C>(cur, base + (int64_t)s_begin * C * WAVE);
+    int ns_min = ns;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ns_min = min(ns_min, __shfl_xor(ns_min, o, 64));
+    ns_min = __builtin_amdgcn_readfirstlane(ns_min);
+
+    // two register blocks in ping-pong: while one is consumed the other is in flight (no copies)
+    double bufA[TILE_U][C], bufB[TILE_U][C];
+    load_block<C>(bufA, base + (int64_t)s_begin * C * WAVE);
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
         for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
         Ops::init(S, a0, A);
     } else {
-        Ops::warm_init(S, &cur[0][1], A);
+        Ops::warm_init(S, &bufA[0][1], A);
     }
 
-    for (int s0 = s_begin; s0 < s_end; s0 += TILE_U) {
-        load_block<C>(nxt, base + (int64_t)(s0 + TILE_U) * C * WAVE);  // spare block keeps this in bounds
+    auto run_block = [&](const double (&blk)[TILE_U][C], int s0) {
+        if (s0 + TILE_U <= ns_min) {          // every lane's track covers the block: no per-row predication
+#pragma unroll
+            for (int u = 0; u < TILE_U; u++) Ops::step(S, tr, A, uni, mu, blk[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < TILE_U; u++)
+                if (s0 + u < ns) Ops::step(S, tr, A, uni, mu, blk[u]);
+        }
+    };
+    auto handover = [&](int s0) {
         if (s0 == s_acc && s_acc > s_begin) {
             // end of warm-up: publish the state for the hand-over check, start scoring from zero
             double st[Ops::State::NSTATE];
@@ -135,13 +150,17 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
             for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
             S.reset_acc();
         }
-#pragma unroll
-        for (int u = 0; u < TILE_U; u++)
-            if (s0 + u < ns) Ops::step(S, tr, A, uni, mu, cur[u]);
-#pragma unroll
-        for (int u = 0; u < TILE_U; u++)
-#pragma unroll
-            for (int c = 0; c < C; c++) cur[u][c] = nxt[u][c];
+    };
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * TILE_U) {
+        // TILE_SPARE keeps the look-ahead loads inside the allocation
+        load_block<C>(bufB, base + (int64_t)(s0 + TILE_U) * C * WAVE);
+        handover(s0);
+        run_block(bufA, s0);
+        load_block<C>(bufA, base + (int64_t)(s0 + 2 * TILE_U) * C * WAVE);
+        if (s0 + TILE_U < s_end) {
+            handover(s0 + TILE_U);
+            run_block(bufB, s0 + TILE_U);
+        }
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
         // state on arrival at the next window's first scored row
