@@ -186,7 +186,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 // One kernel per direction mask when the whole launch uses a single mask (n_parts == 1, the default):
 // a kernel's register allocation is the worst case over everything it contains.
 template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_kernel(const IsoArgs A) {
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoArgs A) {
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
