@@ -166,19 +166,28 @@ SSDE_HD void ctcrw_cov_step(CtcrwCov<MASK>& C, const CtcrwTrans& tr, double h, b
         const double dq11 = (j == 1) ? tr.dq11 : (j == 2 ? 2.0 * tr.q11 : 0.0);
         const double dq12 = (j == 1) ? tr.dq12 : (j == 2 ? 2.0 * tr.q12 : 0.0);
         const double dq22 = (j == 1) ? tr.dq22 : (j == 2 ? 2.0 * tr.q22 : 0.0);
-        const double dF = C.d11[j] + dh;
+        // (terms whose seed is structurally zero in this direction are left out at compile time: IEEE
+        //  arithmetic does not let the compiler drop a multiplication by a literal 0.0 by itself)
+        const double dF = (j == 0) ? C.d11[j] + dh : C.d11[j];
         const double diF = -iF * iF * dF;
         C.gld[j] += dF * iF;
-        const double dtp11 = C.d11[j] + dt12 * C.p12 + tr.t12 * C.d12[j];
-        const double dtp12 = C.d12[j] + dt12 * C.p22 + tr.t12 * C.d22[j];
-        const double dtp21 = de * C.p12 + tr.e * C.d12[j];
-        const double dtp22 = de * C.p22 + tr.e * C.d22[j];
+        double dtp11 = C.d11[j] + tr.t12 * C.d12[j];
+        double dtp12 = C.d12[j] + tr.t12 * C.d22[j];
+        double dtp21 = tr.e * C.d12[j];
+        double dtp22 = tr.e * C.d22[j];
+        if (j == 1) {
+            dtp11 += dt12 * C.p12; dtp12 += dt12 * C.p22;
+            dtp21 += de * C.p12;   dtp22 += de * C.p22;
+        }
         const double dk1 = dtp11 * iF + tp11 * diF;
         const double dk2 = dtp21 * iF + tp21 * diF;
         G.diF[j] = diF; G.dk1[j] = dk1; G.dk2[j] = dk2;
-        C.d11[j] = dtp11 * (1.0 - k1) - tp11 * dk1 + dtp12 * tr.t12 + tp12 * dt12 + dq11;
-        C.d12[j] = -dtp11 * k2 - tp11 * dk2 + dtp12 * tr.e + tp12 * de + dq12;
-        C.d22[j] = -dtp21 * k2 - tp21 * dk2 + dtp22 * tr.e + tp22 * de + dq22;
+        double n11j = dtp11 * (1.0 - k1) - tp11 * dk1 + dtp12 * tr.t12;
+        double n12j = -dtp11 * k2 - tp11 * dk2 + dtp12 * tr.e;
+        double n22j = -dtp21 * k2 - tp21 * dk2 + dtp22 * tr.e;
+        if (j == 1) { n11j += tp12 * dt12; n12j += tp12 * de; n22j += tp22 * de; }
+        if (j != 0) { n11j += dq11; n12j += dq12; n22j += dq22; }
+        C.d11[j] = n11j; C.d12[j] = n12j; C.d22[j] = n22j;
     }
     const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11;  // P = T P (T - K Z)' + Q (lines 240-241)
     const double n12 = -tp11 * k2 + tp12 * tr.e + tr.q12;
@@ -225,9 +234,12 @@ SSDE_HD void ctcrw_mean_step(CtcrwMean<D, MASK>& M, const CtcrwTrans& tr, const 
         for (int a = 0; a < D; a++) { du[a] = scored ? -M.tx[j][a] : 0.0; sud += u[a] * du[a]; }
         M.gq[j] += 0.5 * G.diF[j] * su2 + G.iF * sud;
         for (int a = 0; a < D; a++) {
-            const double bmu = G.bm * mu[a];   // d(B mu): db1 = -dt12, db2 = -de
-            const double nx = M.tx[j][a] + dt12 * M.v[a] + tr.t12 * M.tv[j][a] + G.dk1[j] * u[a] + G.k1 * du[a] - dt12 * bmu;
-            const double nv = de * M.v[a] + tr.e * M.tv[j][a] + G.dk2[j] * u[a] + G.k2 * du[a] - de * bmu;
+            double nx = M.tx[j][a] + tr.t12 * M.tv[j][a] + G.dk1[j] * u[a] + G.k1 * du[a];
+            double nv = tr.e * M.tv[j][a] + G.dk2[j] * u[a] + G.k2 * du[a];
+            if (j == 1) {                      // only log tau moves T and B: d(B mu) = -(dt12, de) mu
+                const double w = M.v[a] - G.bm * mu[a];
+                nx += dt12 * w; nv += de * w;
+            }
             M.tx[j][a] = nx; M.tv[j][a] = nv;
         }
     }
@@ -357,13 +369,17 @@ SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool
         const double dh = (j == 0) ? 2.0 * h : 0.0;
         const double dt_ = (j == 1) ? tr.dt_ : 0.0;
         const double dq = (j == 1) ? tr.dq : (j == 2 ? tr.q : 0.0);
-        const double dF = C.dp[j] + dh;
+        const double dF = (j == 0) ? C.dp[j] + dh : C.dp[j];
         const double diF = -iF * iF * dF;
         C.gld[j] += dF * iF;
-        const double dtp = dt_ * C.p + tr.t * C.dp[j];
+        double dtp = tr.t * C.dp[j];
+        if (j == 1) dtp += dt_ * C.p;
         const double dk = dtp * iF + tp * diF;
         G.diF[j] = diF; G.dk[j] = dk;
-        C.dp[j] = dtp * (tr.t - k) + tp * (dt_ - dk) + dq;
+        double np_ = dtp * (tr.t - k) - tp * dk;
+        if (j == 1) np_ += tp * dt_;
+        if (j != 0) np_ += dq;
+        C.dp[j] = np_;
     }
     C.p = tp * (tr.t - k) + tr.q;
 }
@@ -401,8 +417,11 @@ SSDE_HD void scal_mean_step(ScalMean<D, MASK>& M, const ScalTrans& tr, const Sca
         double du[D];
         for (int a = 0; a < D; a++) { du[a] = scored ? -M.tx[j][a] : 0.0; sud += u[a] * du[a]; }
         M.gq[j] += 0.5 * G.diF[j] * su2 + G.iF * sud;
-        for (int a = 0; a < D; a++)
-            M.tx[j][a] = dt_ * M.x[a] + tr.t * M.tx[j][a] + G.dk[j] * u[a] + G.k * du[a] + db * mu[a];
+        for (int a = 0; a < D; a++) {
+            double nx = tr.t * M.tx[j][a] + G.dk[j] * u[a] + G.k * du[a];
+            if (j == 1) nx += dt_ * M.x[a] + db * mu[a];
+            M.tx[j][a] = nx;
+        }
     }
     if (MASK & DIR_MU) {
         for (int a = 0; a < D; a++) {
