@@ -29,19 +29,45 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def _usable_cores():
+    """Cores this process may use: the affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds_target=15.0):
     """The CPU oracle (port of the reference arithmetic, forward-mode gradient) on a bounded
     sample of the same workload, on all host cores of this box.  Baseline, not the target."""
     from oracle_lib import oracle_eval
     from smoothsde_amd import capi
     from smoothsde_amd.synth import simulate
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _usable_cores()
     tracks, rows = 8 * cores, 2000
     ID, times, obs = simulate("CTCRW", tracks, rows, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
     fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
     pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed)
     par = np.array([0.0, 0.0, 0.0, 0.0, 0.0])
-    oracle_eval(pb, par, order=1, threads=cores)  # warm
+    # the affinity mask can promise more cores than the box's CPU share grants: measure how many
+    # cores the threads really got (process CPU time / wall time) and size the pool to that
+    oracle_eval(pb, par, order=1, threads=cores)  # warm (library load, first-touch)
+    w0, c0 = time.perf_counter(), time.process_time()
+    oracle_eval(pb, par, order=1, threads=cores)
+    busy = (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)
+    if busy < 0.6 * cores:
+        cores = max(1, int(round(busy)))
     t0 = time.perf_counter()
     reps = 0
     while True:
