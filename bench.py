@@ -209,7 +209,7 @@ def main():
         "config": {"workload": f"{M} {args.model} tracks x {T} rows per GPU, d=2, constant coefficients, "
                                f"sigma_obs/tau/nu free, mu fixed, dt=1 (SURVEY 8(d) C2')",
                    "tracks_per_gpu": M, "rows_per_track": T, "n_free_par": info["n_free"],
-                   "engine_path": {0: "direct", 1: "isotropic-register", 2: "dense"}[info["path"]],
+                   "engine_path": capi.PATH_NAMES[info["path"]],
                    "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
                    "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
                    "window_check": float(res[-1]), "parallelism": f"tracks x{world}"},

@@ -135,7 +135,8 @@ typedef struct ssde_info_t {
     int32_t n_par_full;     /* length of `par` / `grad` */
     int32_t n_free;         /* entries with par_fixed == 0 */
     int32_t sdim;           /* Kalman state dimension (0 for direct families) */
-    int32_t path;           /* 0 direct, 1 isotropic register Kalman, 2 dense Kalman */
+    int32_t path;           /* 0 direct, 1 isotropic register Kalman (constant coefficients), 2 dense Kalman,
+                               3 isotropic Kalman with row-varying coefficients */
     int32_t const_coeff;    /* 1 if every SDE parameter is intercept-only */
     int32_t uniform_dt;     /* 1 if one dt is shared by every scored interval (transition matrices hoisted) */
     int64_t n_tracks;       /* ID segments */
@@ -144,7 +145,8 @@ typedef struct ssde_info_t {
     int64_t hbm_bytes;      /* resident bytes of the tiled streams */
     double  algo_bytes_per_row; /* 8*(d + 1 + d*d*[H_array] + K_row) */
     int32_t n_kernel_blocks;/* workgroups of the main kernel (last evaluation) */
-    int32_t lanes_per_track;/* direction parts x time windows (register path), direction blocks (dense) */
+    int32_t lanes_per_track;/* direction parts x time windows (register path), direction blocks (dense),
+                               direction lanes x time windows (row-varying path) */
     int32_t window;         /* warm-up rows of a time window in the last evaluation (0 = sequential) */
     int32_t window_retries; /* evaluations repeated because the window hand-over check failed */
     double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval */

@@ -25,6 +25,7 @@ KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
 UNSUPPORTED_MODELS = ("BM_t", "CIR", "ESEAL_SSM")
 
 NA_R_ONLY, NA_ANY_NAN = 0, 1
+PATH_NAMES = {0: "direct", 1: "isotropic-register", 2: "dense", 3: "isotropic-row-varying"}
 FLAG_DEVICE_DATA, FLAG_FORCE_DENSE, FLAG_NO_UNIFORM_DT = 0x1, 0x2, 0x4
 
 _dp = C.POINTER(C.c_double)

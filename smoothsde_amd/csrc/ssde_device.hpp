@@ -226,6 +226,59 @@ struct DenseArgs {
 };
 hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 
+// ---- row-varying-coefficient isotropic Kalman (k_tv.hip, ssde_tv.hpp) -----------------------------
+// Long-format data (no tiles): a row-parallel pre-pass writes one 128-byte record per row, the
+// serial recursion runs one WAVE per (pack of tracks, time window, direction block) with
+// lane = (track of the pack, gradient direction).
+constexpr int TV_U = 4;           // rows per prefetch block (divides WIN_ALIGN)
+constexpr int TV_NSTATE = 14;     // doubles per lane dumped at a window hand-over (CTCRW, d = 2)
+constexpr int TV_STATS = 6;       // per block: min/max of dt, par[d], par[d+1] over the rows the filter propagates
+struct TvItem { int32_t pack, c, nc, b; };        // work item of one wave: track pack, window c of nc, direction block
+struct TvDir { int16_t kind, dim, pidx, slot; };  // TVK_* kind, dimension (TVK_MU), full-par index, coefficient slot
+struct TvArgs {
+    const double* times;         // [n]
+    const double* obs;           // [n x d] column-major
+    const double* colbuf;        // streamed design columns, column c at colbuf + c * col_stride
+    int64_t col_stride;
+    const uint32_t* scored;      // bit i: ID(i-1) == ID(i)
+    int64_t n;
+    int d, model, any_nan;
+    const SlotTable* slots;      // device
+    int n_slots;
+    const double* par;           // device, full parameter vector
+    double* rec;                 // [n][TV_RS] per-evaluation row records
+    const double* wdir;          // [n][ndp] d par_row / d coefficient of every direction (built once)
+    int ndp;                     // directions padded to a multiple of the lanes per track
+    int lpt_shift;               // lanes per track = 1 << lpt_shift; tracks per wave = 64 >> lpt_shift
+    const TvDir* dirs;           // [ndp]
+    const int64_t* trk_row0;     // [n_tracks] first row of the track (tracks sorted by length, longest first)
+    const int32_t* trk_ns;       // [n_tracks] rows - 1
+    const double* a0;            // [n_tracks][sdim]
+    int64_t n_tracks;
+    const TvItem* items;
+    int n_items;
+    int window;                  // warm-up rows of a time window
+    double h;                    // sigma_obs^2
+    double p0[3];
+    double* bnd;                 // [n_items][2][TV_NSTATE][64]
+    double* chk;                 // [n_items]
+    double* gval;                // [n_items][64] per-lane nllk
+    double* gdir;                // [n_items][64] per-lane d nllk / d direction
+    double* stats;               // [stats_blocks][TV_STATS]
+    int stats_blocks;
+    double* report;              // optional aest_all [n x sdim]
+    int n_out;                   // 1 + n_par_full
+    int16_t dir_of_par[MAX_PAR]; // full-par index -> direction, -1 = no gradient (fixed, or not in the data term)
+    double* out;                 // n_out + 1 doubles
+};
+hipError_t launch_tv_weights(const TvArgs& a, hipStream_t s);
+hipError_t launch_tv_a0(const TvArgs& a, const double* a0_src, const int64_t* trk_seg, int64_t n_seg, int sdim,
+                        double* a0_dst, hipStream_t s);
+hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s);
+hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s);
+hipError_t launch_tv_check(const TvArgs& a, hipStream_t s);
+hipError_t launch_tv_reduce(const TvArgs& a, hipStream_t s);
+
 // ---- device helpers -------------------------------------------------------------------------------
 // Window geometry shared by the kernels, the hand-over check and the engine.
 //   t0 == 0 : n_chunks equal windows over [0, L)

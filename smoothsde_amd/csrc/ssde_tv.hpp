@@ -1,0 +1,243 @@
+// ssde_tv.hpp -- isotropic Kalman step with ROW-VARYING SDE parameters (spline / covariate
+// dependent tau, nu, mu, ... : the models smoothSDE exists for), one tangent direction per lane.
+//
+// Reference: the same recursions as ssde_math.hpp (nllk_ctcrw.hpp:195-247, nllk_ou_ssm.hpp:163-213,
+// nllk_bm_ssm.hpp:127-175), with par_mat.row(i) differing from row to row (the linear predictor
+// par_vec = X_fe coeff_fe + X_re coeff_re, nllk_ctcrw.hpp:143-156).  H = sigma_obs^2 I and a
+// block-identical P0 are still required (else the dense kernel runs), so the covariance keeps its
+// 3-scalar (CTCRW) / 1-scalar (OU, BM) form.
+//
+// Work split (k_tv.hip):
+//   * a row-parallel pre-pass evaluates everything that does not depend on the filter state --
+//     linear predictor (A2), link transforms (A3), transition entries and their derivatives (A4) --
+//     into one 128-byte RECORD per row (tv_make_record below).  All exp() calls live there;
+//   * the serial recursion then runs one wavefront per (track, time window), lane = gradient
+//     direction: every lane repeats the cheap primal step and carries ONE tangent, for any kind of
+//     direction (log sigma_obs, a coefficient of mu_a, of par[D], of par[D+1]) -- the kinds differ
+//     only in their seeds, which are lane-wise selects, so the wave never diverges.
+// The functions are __host__ __device__: tests/hostsim runs them on the CPU against the oracle.
+#ifndef SSDE_TV_HPP
+#define SSDE_TV_HPP
+
+#include "ssde_math.hpp"
+
+namespace ssde {
+
+constexpr int TV_RS = 16;   // doubles per row record (128 B: four 16-byte loads per lane)
+enum { TVK_NONE = 0, TVK_SIG = 1, TVK_MU = 2, TVK_P1 = 3, TVK_P2 = 4 };
+
+// Record layout
+//   CTCRW : 0 e  1 t12  2 b1  3 q11  4 q12  5 q22 | d/d par[D]: 6 de  7 dt12  8 dq11  9 dq12  10 dq22
+//   OU/BM : 0 t  1 b    2 q                        | d/d par[D]: 3 dt_ 4 db    5 dq ; d/d par[D+1]: 6 dq2
+//   both  : 11 + a = mu_a (row's linear predictor), 13 + a = y_a (the row's observation)
+// (CTCRW d/d par[D+1] = log nu: dq = 2 q, nothing else moves.)
+constexpr int TVR_MU = 11, TVR_Y = 13;
+
+// par[] = the row's linear predictors on the working scale (length D + 1 or D + 2)
+template <int MODEL, int D>
+SSDE_HD void tv_make_record(double dt, const double* par, const double* y, double* r) {
+    for (int k = 0; k < TV_RS; k++) r[k] = 0.0;
+    if (MODEL == M_CTCRW) {
+        const double tau = exp(par[D]), nu = exp(par[D + 1]);      // nllk_ctcrw.hpp:153-154
+        const double beta = 1.0 / tau;                             // :155
+        const double sigma = 2.0 * nu / sqrt(M_PI * tau);          // :156
+        CtcrwTrans tr;
+        ctcrw_trans(dt, tau, beta, sigma, tr);
+        r[0] = tr.e; r[1] = tr.t12; r[2] = tr.b1; r[3] = tr.q11; r[4] = tr.q12; r[5] = tr.q22;
+        r[6] = tr.de; r[7] = tr.dt12; r[8] = tr.dq11; r[9] = tr.dq12; r[10] = tr.dq22;
+    } else if (MODEL == M_OU_SSM) {
+        ScalTrans tr;
+        ou_trans(dt, exp(par[D]), exp(par[D + 1]), tr);            // nllk_ou_ssm.hpp:123-124
+        r[0] = tr.t; r[1] = tr.b; r[2] = tr.q; r[3] = tr.dt_; r[4] = tr.db; r[5] = tr.dq; r[6] = tr.q;
+    } else {
+        ScalTrans tr;
+        bm_trans(dt, exp(par[D]), tr);                             // nllk_bm_ssm.hpp:90
+        r[0] = tr.t; r[1] = tr.b; r[2] = tr.q; r[3] = tr.dt_; r[4] = tr.db; r[5] = tr.dq; r[6] = 0.0;
+    }
+    for (int a = 0; a < D; a++) { r[TVR_MU + a] = par[a]; r[TVR_Y + a] = y[a]; }
+}
+
+// ---------------------------------------------------------------------------------------
+// CTCRW lane: primal (x, v per dimension; p11, p12, p22) + one tangent
+// ---------------------------------------------------------------------------------------
+template <int D>
+struct TvCtcrwLane {
+    static constexpr int SD = 2 * D;
+    static constexpr int NSTATE = 2 * D + 3 + 3 + 2 * D;
+    double x[D], v[D], p11, p12, p22;
+    double tx[D], tv[D], d11, d12, d22;
+    LogAcc ld;
+    double accq, gld, gq;
+    SSDE_HD void init(const double* a0 /* x1, v1, x2, v2 */, const double* p0 /* p11, p12, p22 */) {
+        for (int a = 0; a < D; a++) { x[a] = a0[2 * a]; v[a] = a0[2 * a + 1]; tx[a] = tv[a] = 0.0; }
+        p11 = p0[0]; p12 = p0[1]; p22 = p0[2];
+        d11 = d12 = d22 = 0.0;
+        reset_acc();
+    }
+    // a time window warms up from the row's observation, velocities 0 (any state would do)
+    SSDE_HD void warm_init(const double* y, const double* p0) {
+        double a0[SD];
+        for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
+        init(a0, p0);
+    }
+    SSDE_HD void reset_acc() { ld.init(); accq = gld = gq = 0.0; }
+    SSDE_HD void dump(double* o) const {
+        int k = 0;
+        for (int a = 0; a < D; a++) { o[k++] = x[a]; o[k++] = v[a]; }
+        o[k++] = p11; o[k++] = p12; o[k++] = p22;
+        o[k++] = d11; o[k++] = d12; o[k++] = d22;
+        for (int a = 0; a < D; a++) { o[k++] = tx[a]; o[k++] = tv[a]; }
+    }
+    SSDE_HD void state(double* o) const { for (int a = 0; a < D; a++) { o[2 * a] = x[a]; o[2 * a + 1] = v[a]; } }
+    SSDE_HD double value() const { return 0.5 * ((double)D * ld.value() + accq); }
+    SSDE_HD double grad() const { return 0.5 * (double)D * gld + gq; }
+};
+
+// One row: score y (record slots 13..), then propagate over the interval after the row.
+//   kind / dim / w : the lane's direction (TVK_*), its dimension for TVK_MU, and the row's weight
+//                    d par_row / d coefficient (design-matrix entry; 1 for an intercept or sigma_obs)
+template <int D, bool GRAD>
+SSDE_HD void tv_ctcrw_step(TvCtcrwLane<D>& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
+    const double e = r[0], t12 = r[1], b1 = r[2], q11 = r[3], q12 = r[4], q22 = r[5];
+    const bool na = is_na(r[TVR_Y], any_nan);                   // obs(i,0) only: nllk_ctcrw.hpp:214
+    const double F = L.p11 + h;                                 // line 223
+    const double detF = (D == 1) ? F : F * F;
+    const bool upd = !na && (detF > 0.0);                       // lines 214, 226
+    const double iF = upd ? rcp(F) : 0.0;
+    const double bm = (na || upd) ? 1.0 : 0.0;                  // Q3
+    L.ld.mul(upd ? F : 1.0);
+    const double tp11 = L.p11 + t12 * L.p12, tp12 = L.p12 + t12 * L.p22;
+    const double tp21 = e * L.p12, tp22 = e * L.p22;
+    const double k1 = tp11 * iF, k2 = tp21 * iF;                // line 236
+    double u[D], su2 = 0.0;
+    for (int a = 0; a < D; a++) { u[a] = upd ? r[TVR_Y + a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }   // line 221
+    L.accq += iF * su2;
+    if (GRAD) {
+        const double s1 = (kind == TVK_P1) ? w : 0.0, s2 = (kind == TVK_P2) ? 2.0 * w : 0.0;
+        const double dh = (kind == TVK_SIG) ? 2.0 * h : 0.0;
+        const double de = s1 * r[6], dt12 = s1 * r[7];
+        const double dq11 = s1 * r[8] + s2 * q11, dq12 = s1 * r[9] + s2 * q12, dq22 = s1 * r[10] + s2 * q22;
+        const double dF = L.d11 + dh;
+        const double diF = -iF * iF * dF;
+        L.gld += dF * iF;
+        const double dtp11 = L.d11 + t12 * L.d12 + dt12 * L.p12;
+        const double dtp12 = L.d12 + t12 * L.d22 + dt12 * L.p22;
+        const double dtp21 = e * L.d12 + de * L.p12;
+        const double dtp22 = e * L.d22 + de * L.p22;
+        const double dk1 = dtp11 * iF + tp11 * diF;
+        const double dk2 = dtp21 * iF + tp21 * diF;
+        L.d11 = dtp11 * (1.0 - k1) - tp11 * dk1 + dtp12 * t12 + tp12 * dt12 + dq11;
+        L.d12 = -dtp11 * k2 - tp11 * dk2 + dtp12 * e + tp12 * de + dq12;
+        L.d22 = -dtp21 * k2 - tp21 * dk2 + dtp22 * e + tp22 * de + dq22;
+        double sud = 0.0;
+        for (int a = 0; a < D; a++) {
+            const double du = upd ? -L.tx[a] : 0.0;
+            sud += u[a] * du;
+            const double dmu = (kind == TVK_MU && dim == a) ? w : 0.0;
+            const double vm = L.v[a] - bm * r[TVR_MU + a];      // d(B mu) = -(dt12, de) mu + B dmu
+            const double nx = L.tx[a] + t12 * L.tv[a] + dk1 * u[a] + k1 * du + dt12 * vm + bm * b1 * dmu;
+            const double nv = e * L.tv[a] + dk2 * u[a] + k2 * du + de * vm + bm * (1.0 - e) * dmu;
+            L.tx[a] = nx; L.tv[a] = nv;
+        }
+        L.gq += 0.5 * diF * su2 + iF * sud;
+    }
+    for (int a = 0; a < D; a++) {                               // a = T a + K u + B mu (line 238)
+        const double mu = r[TVR_MU + a];
+        const double nx = L.x[a] + t12 * L.v[a] + k1 * u[a] + bm * b1 * mu;
+        const double nv = e * L.v[a] + k2 * u[a] + bm * (1.0 - e) * mu;
+        L.x[a] = nx; L.v[a] = nv;
+    }
+    const double n11 = tp11 * (1.0 - k1) + tp12 * t12 + q11;    // lines 240-241
+    const double n12 = -tp11 * k2 + tp12 * e + q12;
+    const double n22 = -tp21 * k2 + tp22 * e + q22;
+    L.p11 = n11; L.p12 = n12; L.p22 = n22;
+}
+
+// ---------------------------------------------------------------------------------------
+// OU_SSM / BM_SSM lane: x per dimension, scalar p, one tangent
+// ---------------------------------------------------------------------------------------
+template <int D>
+struct TvScalLane {
+    static constexpr int SD = D;
+    static constexpr int NSTATE = D + 1 + 1 + D;
+    double x[D], p, tx[D], dp;
+    LogAcc ld;
+    double accq, gld, gq;
+    SSDE_HD void init(const double* a0, const double* p0) {
+        for (int a = 0; a < D; a++) { x[a] = a0[a]; tx[a] = 0.0; }
+        p = p0[0]; dp = 0.0;
+        reset_acc();
+    }
+    SSDE_HD void warm_init(const double* y, const double* p0) {
+        double a0[SD];
+        for (int a = 0; a < D; a++) a0[a] = (y[a] == y[a]) ? y[a] : 0.0;
+        init(a0, p0);
+    }
+    SSDE_HD void reset_acc() { ld.init(); accq = gld = gq = 0.0; }
+    SSDE_HD void dump(double* o) const {
+        int k = 0;
+        for (int a = 0; a < D; a++) o[k++] = x[a];
+        o[k++] = p; o[k++] = dp;
+        for (int a = 0; a < D; a++) o[k++] = tx[a];
+    }
+    SSDE_HD void state(double* o) const { for (int a = 0; a < D; a++) o[a] = x[a]; }
+    SSDE_HD double value() const { return 0.5 * ((double)D * ld.value() + accq); }
+    SSDE_HD double grad() const { return 0.5 * (double)D * gld + gq; }
+};
+
+template <int D, bool GRAD>
+SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
+    const double t = r[0], b = r[1], q = r[2];
+    const bool na = is_na(r[TVR_Y], any_nan);
+    const double F = L.p + h;
+    const bool upd = !na && (fabs(F) > 0.0);                    // detF = exp(logdet F): nllk_ou_ssm.hpp:190-195
+    const double iF = upd ? rcp(F) : 0.0;
+    L.ld.mul(upd ? F : 1.0);
+    const double tp = t * L.p;
+    const double k = tp * iF;
+    double u[D], su2 = 0.0;
+    for (int a = 0; a < D; a++) { u[a] = upd ? r[TVR_Y + a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }
+    L.accq += iF * su2;
+    if (GRAD) {
+        const double s1 = (kind == TVK_P1) ? w : 0.0, s2 = (kind == TVK_P2) ? w : 0.0;
+        const double dh = (kind == TVK_SIG) ? 2.0 * h : 0.0;
+        const double dt_ = s1 * r[3], db = s1 * r[4], dq = s1 * r[5] + s2 * r[6];
+        const double dF = L.dp + dh;
+        const double diF = -iF * iF * dF;
+        L.gld += dF * iF;
+        const double dtp = t * L.dp + dt_ * L.p;
+        const double dk = dtp * iF + tp * diF;
+        L.dp = dtp * (t - k) - tp * dk + tp * dt_ + dq;
+        double sud = 0.0;
+        for (int a = 0; a < D; a++) {
+            const double du = upd ? -L.tx[a] : 0.0;
+            sud += u[a] * du;
+            const double dmu = (kind == TVK_MU && dim == a) ? w : 0.0;
+            L.tx[a] = t * L.tx[a] + dk * u[a] + k * du + dt_ * L.x[a] + db * r[TVR_MU + a] + b * dmu;
+        }
+        L.gq += 0.5 * diF * su2 + iF * sud;
+    }
+    for (int a = 0; a < D; a++) L.x[a] = t * L.x[a] + k * u[a] + b * r[TVR_MU + a];
+    L.p = tp * (t - k) + q;
+}
+
+// model -> lane type / step
+template <int MODEL, int D>
+struct TvOps {
+    typedef TvScalLane<D> Lane;
+    template <bool GRAD>
+    SSDE_HD static void step(Lane& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
+        tv_scal_step<D, GRAD>(L, r, h, kind, dim, w, any_nan);
+    }
+};
+template <int D>
+struct TvOps<M_CTCRW, D> {
+    typedef TvCtcrwLane<D> Lane;
+    template <bool GRAD>
+    SSDE_HD static void step(Lane& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
+        tv_ctcrw_step<D, GRAD>(L, r, h, kind, dim, w, any_nan);
+    }
+};
+
+}  // namespace ssde
+#endif

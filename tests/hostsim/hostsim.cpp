@@ -10,6 +10,7 @@
 #include <cmath>
 
 #include "../../smoothsde_amd/csrc/ssde_math.hpp"
+#include "../../smoothsde_amd/csrc/ssde_tv.hpp"
 
 using namespace ssde;
 
@@ -93,9 +94,53 @@ void run_mask(const IsoArgs& A, double* out) {
     }
 }
 
+// row-varying coefficients (ssde_tv.hpp): records by the pre-pass arithmetic, then one lane per direction
+template <int MODEL, int D>
+void run_tv(int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows, const double* times,
+            const double* obs, const double* parmat, int q, int nd, const int* kinds, const int* dims, const double* wmat,
+            double log_sigma_obs, const double* p0, const double* a0, double* out) {
+    typedef TvOps<MODEL, D> Ops;
+    constexpr int SD = Ops::Lane::SD;
+    const double h = exp(log_sigma_obs) * exp(log_sigma_obs);
+    for (int k = 0; k < 1 + nd; k++) out[k] = 0.0;
+    for (int kk = -1; kk < nd; kk++) {              // kk = -1: value-only lane
+        for (int64_t m = 0; m < n_tracks; m++) {
+            typename Ops::Lane L;
+            double a[SD];
+            for (int c = 0; c < SD; c++) a[c] = 0.0;
+            if (a0) for (int c = 0; c < SD; c++) a[c] = a0[m * SD + c];
+            else for (int c = 0; c < D; c++) a[MODEL == M_CTCRW ? 2 * c : c] = obs[row0[m] + c * n];
+            L.init(a, p0);
+            for (int64_t s = 1; s < nrows[m]; s++) {
+                const int64_t i = row0[m] + s;
+                const double dt = (s < nrows[m] - 1) ? times[i + 1] - times[i] : 1.0;
+                double par[4], y[D], rec[TV_RS];
+                for (int j = 0; j < q; j++) par[j] = parmat[i + (int64_t)j * n];
+                for (int c = 0; c < D; c++) y[c] = obs[i + c * n];
+                tv_make_record<MODEL, D>(dt, par, y, rec);
+                if (kk < 0) Ops::template step<false>(L, rec, h, 0, 0, 0.0, any_nan);
+                else Ops::template step<true>(L, rec, h, kinds[kk], dims[kk], wmat[i * nd + kk], any_nan);
+            }
+            if (kk < 0) out[0] += L.value();
+            else out[1 + kk] += L.grad();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// out = [nllk (data term), d/d direction_0 .. d/d direction_{nd-1}]
+int hostsim_kalman_tv(int model, int d, int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows,
+                      const double* times, const double* obs, const double* parmat, int q, int nd, const int* kinds,
+                      const int* dims, const double* wmat, double log_sigma_obs, const double* p0, const double* a0,
+                      double* out) {
+#define TV(MODEL, D) if (model == MODEL && d == D) { run_tv<MODEL, D>(any_nan, n, n_tracks, row0, nrows, times, obs, parmat, q, nd, kinds, dims, wmat, log_sigma_obs, p0, a0, out); return 0; }
+    TV(M_CTCRW, 1) TV(M_CTCRW, 2) TV(M_OU_SSM, 1) TV(M_OU_SSM, 2) TV(M_BM_SSM, 1) TV(M_BM_SSM, 2)
+#undef TV
+    return 1;
+}
 
 // out = [nllk, g_sig, g_mu_0.., g_p1, g_p2]  (1 + 3 + d doubles)
 int hostsim_kalman_iso(int model, int d, int mask, int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0,

@@ -21,8 +21,52 @@ def load():
         lib.hostsim_kalman_iso.restype = C.c_int
         lib.hostsim_direct.argtypes = [C.c_int] + [C.c_double] * 6 + [_dp]
         lib.hostsim_direct.restype = C.c_double
+        _ipt = C.POINTER(C.c_int)
+        lib.hostsim_kalman_tv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp,
+                                          C.c_int, C.c_int, _ipt, _ipt, _dp, C.c_double, _dp, _dp, _dp]
+        lib.hostsim_kalman_tv.restype = C.c_int
         _LIB = lib
     return _LIB
+
+
+def kalman_tv(pb, par):
+    """Row-varying-coefficient isotropic Kalman nllk (data term) + gradient over the full parameter
+    vector by the arithmetic of csrc/ssde_tv.hpp: linear predictors formed here, one lane per direction."""
+    from smoothsde_amd.capi import MODEL_CODES
+    lib = load()
+    d, q, n = pb.n_dim, pb.q, pb.n
+    par = np.asarray(par, dtype=np.float64)
+    parmat = np.zeros((n, q), order="F")
+    kinds, dims, pidx, wcols = [1], [0], [0], [np.ones(n)]          # log_sigma_obs
+    for j in range(q):
+        kind, dim = (2, j) if j < d else (3 + (j - d), 0)
+        for src, off, nc in ((pb.X_fe[j], pb.off_fe + pb.fe_off[j], pb.ncol_fe[j]),
+                             (pb.X_re[j], pb.off_re + pb.re_off[j], pb.ncol_re[j])):
+            for c in range(nc):
+                col = np.ones(n) if src is None else src[:, c]
+                parmat[:, j] += col * par[off + c]
+                kinds.append(kind); dims.append(dim); pidx.append(off + c); wcols.append(col)
+    nd = len(kinds)
+    wmat = np.ascontiguousarray(np.column_stack(wcols))
+    row0 = np.ascontiguousarray(pb.seg_start, dtype=np.int64)
+    nrows = np.diff(np.append(pb.seg_start, n)).astype(np.int64)
+    if pb.model == "CTCRW":
+        p0 = np.array([1.0, 0.0, 10.0]) if pb.P0 is None else np.array([pb.P0[0, 0], pb.P0[0, 1], pb.P0[1, 1]])
+    else:
+        p0 = np.array([10.0, 0, 0]) if pb.P0 is None else np.array([pb.P0[0, 0], 0, 0])
+    a0 = None if pb.a0 is None else np.ascontiguousarray(pb.a0)
+    ki, di = np.asarray(kinds, dtype=np.int32), np.asarray(dims, dtype=np.int32)
+    out = np.zeros(1 + nd)
+    _ipt = C.POINTER(C.c_int)
+    st = lib.hostsim_kalman_tv(MODEL_CODES[pb.model], d, int(pb.na_mode == 1), n, pb.n_seg, row0.ctypes.data_as(_lp),
+                               nrows.ctypes.data_as(_lp), pb.times.ctypes.data_as(_dp), pb.obs.ctypes.data_as(_dp),
+                               parmat.ctypes.data_as(_dp), q, nd, ki.ctypes.data_as(_ipt), di.ctypes.data_as(_ipt),
+                               wmat.ctypes.data_as(_dp), float(par[0]), p0.ctypes.data_as(_dp),
+                               None if a0 is None else a0.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    assert st == 0
+    grad = np.zeros(pb.n_par_full)
+    grad[np.asarray(pidx)] = out[1:]
+    return out[0], grad
 
 
 def kalman_iso(pb, par, mask):

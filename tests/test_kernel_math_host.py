@@ -6,7 +6,8 @@ import pytest
 
 from cases import problem_from_spec
 from golden_io import load_golden
-from hostsim_lib import kalman_iso, load
+from hostsim_lib import kalman_iso, kalman_tv, load
+from oracle_lib import oracle_eval
 
 GOLD = {r["name"]: r for r in load_golden()}
 ISO = [n for n in GOLD if n.endswith("_const") or n.endswith("_const_regular_fixmu") or n == "elephant6_ctcrw"]
@@ -23,6 +24,25 @@ def test_iso_lane_math_matches_golden(name):
     g = grad.copy()
     g[pb.par_fixed != 0] = 0.0
     assert np.max(np.abs(g - exp["grad"])) <= 1e-9 * np.max(np.abs(exp["grad"])) + 1e-11
+
+
+TV = [n for n in GOLD if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and GOLD[n].get("H") is None
+      and GOLD[n].get("P0") is None]
+
+
+@pytest.mark.parametrize("name", TV)
+def test_tv_lane_math_matches_oracle(name):
+    """csrc/ssde_tv.hpp (records + one generic tangent per lane) against the oracle's data term, on every
+    golden Kalman case without H_array / custom P0 (constant-coefficient cases are the special case of
+    intercept-only directions)."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = np.asarray(rec["par"], dtype=np.float64)
+    val, grad = kalman_tv(pb, par)
+    oval, ograd = oracle_eval(pb, par, order=1, data_only=True)
+    grad[pb.par_fixed != 0] = 0.0
+    assert abs(val - oval) <= 1e-11 * max(1.0, abs(oval))
+    assert np.max(np.abs(grad - ograd)) <= 1e-9 * np.max(np.abs(ograd)) + 1e-11
 
 
 @pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 5, 10])

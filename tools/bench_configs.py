@@ -37,7 +37,7 @@ def report(name, eng, par, rows, reps=10):
     out = dict(config=name, rows=rows, ms_per_eval=1e3 * wall, track_timesteps_per_s=rows / wall,
                main_kernel_ms=inf["main_kernel_ms"], algo_bytes_per_row=bpr,
                algo_GBps=rows * bpr / wall / 1e9, frac_of_8TBps=rows * bpr / wall / 8e12,
-               path={0: "direct", 1: "isotropic-register", 2: "dense"}[inf["path"]], uniform_dt=inf["uniform_dt"],
+               path=capi.PATH_NAMES[inf["path"]], uniform_dt=inf["uniform_dt"],
                lanes_per_track=inf["lanes_per_track"], window=inf["window"], window_check=inf["window_check"],
                window_retries=inf["window_retries"], hbm_resident_GB=inf["hbm_bytes"] / 1e9)
     print(json.dumps(out), flush=True)
