@@ -235,102 +235,96 @@ struct SharedScal {
 };
 
 
-// ---- stationary-only lanes in BASIS form ----------------------------------------------------------
-// Past the covariance transient the gain sensitivities dk1_j, dk2_j are constants, so the state
-// sensitivities of ALL covariance directions are linear combinations of the responses of one linear
-// filter to three forcings (zero initial state, which is how every stationary window starts):
-//     (A1,B1) <- forcing (u, 0),  (A2,B2) <- forcing (0, u),  (A3,B3) <- forcing (dt12 w, de w), w = v - B mu
-//     tx_j = dk1_j A1 + dk2_j A2 + [j = tau] A3        (same for tv_j with B)
-// and  sum_t u tx_j = dk1_j S1 + dk2_j S2 + [j = tau] S3.  The per-row work no longer grows with the
-// number of covariance directions: 50 fp64 instructions per row for 2-D CTCRW instead of 62.
+// ---- stationary-only CTCRW lanes in TRANSFER-FUNCTION form -------------------------------------------
+// Past the covariance transient the filter is linear and time-invariant: with the closed-loop matrix
+// L = T - K Z = [[c1, t12], [-k2, e]] (c1 = 1 - k1) the innovation is u = [A(q)/D(q)] y, where
+//     A(q) = (1 - q^-1)(1 - e q^-1)           (open-loop poles: the integrator and e)
+//     D(q) = 1 + d1 q^-1 + d2 q^-2,  d1 = -(c1 + e),  d2 = c1 e + k2 t12    (closed-loop poles),
+// and d u / d theta_j = q^-1 (1 - q^-1) (pi0_j + pi1_j q^-1 + pi2_j q^-2) / D(q)^2 y for EVERY covariance
+// direction j (the gains' sensitivities are constants there).  So per row and dimension
+//     dy = y_t - y_{t-1} - mu dt      (the factor 1 - q^-1 taken on the data: increments are O(1), so are w, r;
+//                                      a constant drift mu only shifts the increments)
+//     w  = dy - d1 w_{t-1} - d2 w_{t-2}        u = w - e w_{t-1}        r = w - d1 r_{t-1} - d2 r_{t-2}
+//     S += u^2,   C_k += u r_{t-k}  (k = 1, 2, 3)
+// and at the end  d nll / d theta_j = hd_j S + iF (pi0_j C_1 + pi1_j C_2 + pi2_j C_3):
+// 11 fp64 instructions per row and dimension whatever the number of directions (25 in the basis form
+// this replaces, ~120 in the general filter), which moves the headline kernel from fp64 issue to HBM.
+// The hand-over dump converts back to the direction form the other kernels use (x, v and their
+// sensitivities are short linear combinations of y_{t-1}, w and r), so the window check is unchanged.
 template <int D, int MASK>
-struct BasisCtcrw {
+struct TfCtcrw {
     static constexpr int SD = 2 * D;
     static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
     static constexpr bool ANYP = (MASK & (DIR_SIG | DIR_P1 | DIR_P2)) != 0;
-    static constexpr bool P1 = (MASK & DIR_P1) != 0;
-    double x[D], v[D], A1[D], B1[D], A2[D], B2[D], A3[D], B3[D], mx[D], mv[D];
-    double acc2, S1, S2, S3, macc[D];
-    double k1, k2, c1, t12, e, iF, hd[NDIRP], dk1[NDIRP], dk2[NDIRP], dt12, de, cb1, cb2;
-    double cx[D], cv[D], bmu[D];
+    double yp[D], w1[D], w2[D], r1[D], r2[D], r3[D], su[D];
+    double acc2, C1, C2, C3;
+    double e, nd1, nd2, cm[D];
+    const double* c;   // the argument block's constants (scalar loads, used outside the row loop only)
 
     __device__ __forceinline__ void setup(const IsoArgs& A) {
-        const double* c = A.statc;
-        iF = c[0]; k1 = c[1]; k2 = c[2]; c1 = c[3]; t12 = c[4]; e = c[5]; dt12 = c[6]; de = c[7]; cb1 = c[8]; cb2 = c[9];
+        c = A.statc;
+        e = c[5]; nd1 = c[26]; nd2 = c[27];
 #pragma unroll
-        for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
-#pragma unroll
-        for (int a = 0; a < D; a++) {
-            cx[a] = c[19 + a]; bmu[a] = c[23 + a];
-            double t = c[21 + a];
-            asm volatile("v_mov_b64 %0, %1" : "=v"(cv[a]) : "s"(t));   // fma(e, v, cv): one scalar source per VALU op
-        }
+        for (int a = 0; a < D; a++) cm[a] = c[29 + a];
     }
-    __device__ __forceinline__ void init(const double* a0) {
+    // yprev = the observation of the row BEFORE the window's first row
+    __device__ __forceinline__ void init(const double* yprev) {
 #pragma unroll
-        for (int a = 0; a < D; a++) {
-            x[a] = a0[2 * a]; v[a] = a0[2 * a + 1];
-            A1[a] = B1[a] = A2[a] = B2[a] = A3[a] = B3[a] = mx[a] = mv[a] = 0.0;
-        }
+        for (int a = 0; a < D; a++) { yp[a] = yprev[a]; w1[a] = w2[a] = r1[a] = r2[a] = r3[a] = 0.0; }
         reset_acc();
     }
     __device__ __forceinline__ void reset_acc() {
-        acc2 = S1 = S2 = S3 = 0.0;
+        acc2 = C1 = C2 = C3 = 0.0;
 #pragma unroll
-        for (int a = 0; a < D; a++) macc[a] = 0.0;
+        for (int a = 0; a < D; a++) su[a] = 0.0;
     }
     __device__ __forceinline__ void step_table(const double*, const double*, const double*) {}  // never used
     __device__ __forceinline__ void step_stat(const double* y) {
 #pragma unroll
         for (int a = 0; a < D; a++) {
-            const double u = y[a] - x[a];
+            const double dy = (y[a] - yp[a]) - cm[a];
+            yp[a] = y[a];
+            const double w0 = fma(nd1, w1[a], fma(nd2, w2[a], dy));
+            const double u = fma(-e, w1[a], w0);
             acc2 = fma(u, u, acc2);
             if (ANYP) {
-                const double a1 = A1[a], b1 = B1[a], a2 = A2[a], b2 = B2[a];
-                S1 = fma(u, a1, S1);
-                S2 = fma(u, a2, S2);
-                A1[a] = fma(c1, a1, fma(t12, b1, u));
-                B1[a] = fma(e, b1, -k2 * a1);
-                A2[a] = fma(c1, a2, t12 * b2);
-                B2[a] = fma(e, b2, fma(-k2, a2, u));
-                if (P1) {
-                    const double a3 = A3[a], b3 = B3[a];
-                    const double w = v[a] - bmu[a];
-                    S3 = fma(u, a3, S3);
-                    A3[a] = fma(c1, a3, fma(t12, b3, dt12 * w));
-                    B3[a] = fma(e, b3, fma(-k2, a3, de * w));
-                }
+                C1 = fma(u, r1[a], C1);
+                C2 = fma(u, r2[a], C2);
+                C3 = fma(u, r3[a], C3);
+                const double r0 = fma(nd1, r1[a], fma(nd2, r2[a], w0));
+                r3[a] = r2[a]; r2[a] = r1[a]; r1[a] = r0;
             }
-            if (MASK & DIR_MU) {
-                const double m1 = mx[a], m2 = mv[a];
-                macc[a] = fma(u, m1, macc[a]);
-                mx[a] = fma(c1, m1, fma(t12, m2, cb1));
-                mv[a] = fma(e, m2, fma(-k2, m1, cb2));
-            }
-            const double xx = x[a], vv = v[a];
-            x[a] = fma(k1, u, fma(t12, vv, xx)) + cx[a];
-            v[a] = fma(k2, u, fma(e, vv, cv[a]));
+            if (MASK & DIR_MU) su[a] += u;
+            w2[a] = w1[a]; w1[a] = w0;
         }
     }
     __device__ __forceinline__ void finish(double* out) const {
+        const double iF = c[0];
         out[0] = 0.5 * iF * acc2;
-        const double s3[NDIRP] = {0.0, S3, 0.0};
         const int slot[NDIRP] = {1, 2 + D, 3 + D};
 #pragma unroll
         for (int k = 1; k < 4 + D; k++) out[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++)
-            if (MASK & dir_bit(j)) out[slot[j]] = hd[j] * acc2 - iF * (dk1[j] * S1 + dk2[j] * S2 + s3[j]);
+            if (MASK & dir_bit(j)) out[slot[j]] = c[10 + j] * acc2 + iF * (c[31 + j] * C1 + c[34 + j] * C2 + c[37 + j] * C3);
         if (MASK & DIR_MU) {
 #pragma unroll
-            for (int a = 0; a < D; a++) out[2 + a] = -iF * macc[a];
+            for (int a = 0; a < D; a++) out[2 + a] = -iF * c[46] * su[a];
         }
     }
-    // hand-over states in DIRECTION form (what the transient kernel and k_iso.hip dump)
+    // hand-over states in DIRECTION form (what the transient kernel and k_iso.hip dump): the state on
+    // arrival at the next row t, from y_{t-1}, w_{t-1}, w_{t-2}, r_{t-1..t-3}
+    //   x = y_{t-1} + mu dt - c1 w_{t-1} + d2 w_{t-2}          v = k2 w_{t-1} + mu
+    //   dx/dtheta_j = -(pi0_j r_{t-1} + pi1_j r_{t-2} + pi2_j r_{t-3})
+    //   dv/dtheta_j = dk2_j w_{t-1} - k2 (alpha_j r_{t-2} + beta_j r_{t-3}),  alpha = d d1, beta = d d2
     __device__ __forceinline__ void dump(double* o) const {
+        const double k2 = c[2], c1 = c[3], d2 = c[28];
         int k = 0;
 #pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = x[a]; o[k++] = v[a]; }
+        for (int a = 0; a < D; a++) {
+            o[k++] = yp[a] + cm[a] - c1 * w1[a] + d2 * w2[a];
+            o[k++] = k2 * w1[a] + c[23 + a];
+        }
         o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
@@ -338,18 +332,15 @@ struct BasisCtcrw {
             o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double tx = dk1[j] * A1[a] + dk2[j] * A2[a] + (j == 1 ? A3[a] : 0.0);
-                const double tv = dk1[j] * B1[a] + dk2[j] * B2[a] + (j == 1 ? B3[a] : 0.0);
+                const double tx = -(c[31 + j] * r1[a] + c[34 + j] * r2[a] + c[37 + j] * r3[a]);
+                const double tv = c[16 + j] * w1[a] - k2 * (c[40 + j] * r2[a] + c[43 + j] * r3[a]);
                 o[k++] = on ? tx : 0.0; o[k++] = on ? tv : 0.0;
             }
         }
 #pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? mv[a] : 0.0; }
+        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? c[46] : 0.0; o[k++] = (MASK & DIR_MU) ? c[47] : 0.0; }
     }
-    __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
-#pragma unroll
-        for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
-    }
+    __device__ static __forceinline__ void warm_a0(const double*, double*) {}
 };
 
 // OU_SSM / BM_SSM: tx_j = dk_j A1 + [j = par n_dim] A3 with A1 <- forcing u, A3 <- forcing dt_ x + db mu
@@ -450,7 +441,7 @@ struct SharedSel<M_CTCRW, D, MASK, false> { typedef SharedCtcrw<D, MASK> type; }
 template <int MODEL, int D, int MASK>
 struct SharedSel<MODEL, D, MASK, true> { typedef BasisScal<MODEL, D, MASK> type; };
 template <int D, int MASK>
-struct SharedSel<M_CTCRW, D, MASK, true> { typedef BasisCtcrw<D, MASK> type; };
+struct SharedSel<M_CTCRW, D, MASK, true> { typedef TfCtcrw<D, MASK> type; };
 
 // rows [s0, s0 + SHARED_U) from a register block
 template <bool STAT, int D, class Lane>
@@ -532,7 +523,12 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
     {
         double a0[SD];
-        if (s_begin == 0) {
+        if (STATONLY && MODEL == M_CTCRW) {
+            // transfer-function lanes start from the observation of the row before the window (s_begin > 0:
+            // stationary-only windows lie past the covariance transient)
+#pragma unroll
+            for (int a = 0; a < D; a++) a0[a] = base[((int64_t)(s_begin - 1) * C + 1 + a) * WAVE];
+        } else if (s_begin == 0) {
 #pragma unroll
             for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
         } else {
@@ -606,7 +602,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_shared_kernel(const Is
 // host side: the stationary constants (layout in ssde_device.hpp)
 void fill_stat_consts(int model, int d, IsoArgs& a) {
     double* c = a.statc;
-    for (int i = 0; i < 32; i++) c[i] = 0.0;
+    for (int i = 0; i < 48; i++) c[i] = 0.0;
     const double* r = a.gain_stat;
     if (model == M_CTCRW) {
         const CtcrwTrans& tr = a.ctr;
@@ -615,6 +611,25 @@ void fill_stat_consts(int model, int d, IsoArgs& a) {
         c[8] = bm * tr.b1; c[9] = bm * tr.b2;
         for (int j = 0; j < NDIRP; j++) { c[10 + j] = 0.5 * r[4 + j]; c[13 + j] = r[7 + j]; c[16 + j] = r[10 + j]; }
         for (int k = 0; k < d; k++) { c[19 + k] = c[8] * a.mu[k]; c[21 + k] = c[9] * a.mu[k]; c[23 + k] = bm * a.mu[k]; }
+        // transfer-function form (TfCtcrw)
+        const double k1 = r[1], k2 = r[2], c1 = 1.0 - k1, e = tr.e, t12 = tr.t12;
+        const double d1 = -(c1 + e), d2 = c1 * e + k2 * t12;
+        c[26] = -d1; c[27] = -d2; c[28] = d2;
+        const double dt = tr.b1 + tr.t12;                     // b1 = dt - t12
+        for (int k = 0; k < d; k++) c[29 + k] = bm * a.mu[k] * dt;
+        for (int j = 0; j < NDIRP; j++) {
+            const double de = (j == 1) ? tr.de : 0.0, dt12 = (j == 1) ? tr.dt12 : 0.0;
+            const double dk1 = r[7 + j], dk2 = r[10 + j];
+            const double alpha = dk1 - de;                                        // d d1 / d theta_j
+            const double beta = -dk1 * e + c1 * de + dk2 * t12 + k2 * dt12;       // d d2 / d theta_j
+            c[31 + j] = -dk1;
+            c[34 + j] = -de * d1 - beta + e * alpha;
+            c[37 + j] = -de * d2 + e * beta;
+            c[40 + j] = alpha; c[43 + j] = beta;
+        }
+        const double D1 = 1.0 + d1 + d2;                      // D(1): steady-state response to a constant input
+        c[46] = dt * (1.0 - e) / D1;                          // d x / d mu_a
+        c[47] = 1.0 - k2 * dt / D1;                           // d v / d mu_a
     } else {
         const ScalTrans& tr = a.str;
         c[0] = r[0]; c[1] = r[1]; c[2] = tr.t - r[1]; c[3] = tr.t; c[4] = tr.b; c[5] = tr.dt_;

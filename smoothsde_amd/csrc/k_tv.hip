@@ -75,10 +75,11 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
 #pragma unroll
             for (int jj = 0; jj < Q; jj++) par[jj] += (j == jj) ? t : 0.0;
         }
-        // the interval after the row (nllk_ctcrw.hpp:126-129); the last row of a track never propagates
-        // (Q4): give it dt = 1 like the reference's dtimes(n-1) so that its record stays finite
+        // the interval after the row, dtimes(n-1) = 1 (nllk_ctcrw.hpp:126-129).  At a track's last row it spans
+        // to the next track (Q4): the filter state it produces is discarded, but REPORT(aest_all) shows it, so
+        // the record follows the reference there too; only the planner's statistics skip those rows
         const bool used = (i + 1 < A.n) && ((A.scored[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
-        const double dt = used ? A.times[i + 1] - A.times[i] : 1.0;
+        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : 1.0;
         double y[D];
 #pragma unroll
         for (int a = 0; a < D; a++) y[a] = A.obs[i + (int64_t)a * A.n];

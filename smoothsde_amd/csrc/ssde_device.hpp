@@ -70,7 +70,9 @@ struct IsoArgs {
     //   CTCRW : 0 iF 1 k1 2 k2 3 c1=1-k1 4 t12 5 e 6 dt12 7 de 8 cb1 9 cb2 | 10+j hd_j | 13+j dk1_j | 16+j dk2_j
     //           | 19+a cx_a | 21+a cv_a | 23+a bmu_a
     //   OU/BM : 0 iF 1 k 2 c=t-k 3 t 4 b 5 dt_ | 10+j hd_j | 13+j dk_j | 19+a cmu_a | 21+a dbmu_a
-    double statc[32];
+    //   CTCRW transfer-function lanes (TfCtcrw): 26 -d1 27 -d2 28 d2 | 29+a mu_a dt | 31+j pi0_j | 34+j pi1_j | 37+j pi2_j
+    //           | 40+j d d1_j | 43+j d d2_j | 46 dx/dmu 47 dv/dmu
+    double statc[48];
     const int32_t* group_flags;  // [n_groups] bit 0: every track of the group is NaN-free
     int group_mode;              // 0: this launch handles every group; 1: only groups WITHOUT bit 0; 2: only groups WITH bit 0
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
