@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""tools/summarise_profiles.py TAG -- turn gpurun_out/prof_TAG/ (written by tools/collect_profiles.sh on the GPU box)
+into the small files kept under profiles/: kernel statistics of this engine's kernels, per-dispatch PMC bytes,
+pmc_latest.json (read by bench.py for `roofline.traffic`), the bench line and the other configurations' timings."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+rnd, letter = tag[:3], tag[3:] or "x"
+pre = os.path.join(dst, f"{rnd}_{letter}_")
+
+# --- kernel statistics: this engine's kernels only (the synthetic-data generator launches 10^5 torch kernels) ----
+rows = list(csv.DictReader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))))
+with open(pre + "kernel_stats.csv", "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in rows:
+        if "ssde::" in r["Name"]:
+            w.writerow(r)
+
+# --- PMC passes ---------------------------------------------------------------------------------------------------
+def pmc(sub, stem):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(src, sub, f"{stem}_counter_collection.csv"))):
+        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return agg
+
+fetch, write = pmc("pmc_fetch", "fetch"), pmc("pmc_write", "write")
+with open(pre + "pmc_bytes.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_avg", "fetch_bytes_corrected_x2", "WRITE_SIZE_KiB_avg", "write_bytes"])
+    for k in fetch:
+        fa = sum(fetch[k]) / len(fetch[k])
+        wa = sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))
+        w.writerow([k, len(fetch[k]), f"{fa:.1f}", f"{2 * 1024 * fa:.0f}", f"{wa:.1f}", f"{1024 * wa:.0f}"])
+
+main = next(k for k in fetch if "iso_shared_kernel" in k or "iso_mask_kernel" in k)
+per = {}
+for k in fetch:
+    if any(t in k for t in ("iso_shared", "iso_mask", "window_check", "reduce_kernel")):
+        per[k] = {"fetch_corrected": 2 * 1024 * sum(fetch[k]) / len(fetch[k]),
+                  "write": 1024 * sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))}
+main_bytes = per[main]["fetch_corrected"] + per[main]["write"]
+line = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
+pj = {
+    "source": f"tools/collect_profiles.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
+              "--kernel-include-regex ssde) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline; MI355X",
+    "calibration": "tools/microbench_fetch.hip: 1 GiB read once with coalesced 8-B/lane loads -> FETCH_SIZE = 0.5 of the "
+                   "bytes, so FETCH_SIZE (KiB) is doubled (as MI355X_MICROARCH.md prescribes); WRITE_SIZE (KiB) taken as is",
+    "per_evaluation_bytes": per,
+    "main_kernel": main,
+    "main_kernel_bytes": main_bytes,
+    "hbm_bytes_per_launch": sum(v["fetch_corrected"] + v["write"] for v in per.values()),
+    "algorithmic_bytes_per_launch": line["roofline"]["algo_bytes_per_launch"],
+    "note": "traffic < algorithmic because on a regular grid the dt channel (8 of the 24 B/row) is never read",
+}
+json.dump(pj, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+line["roofline"]["traffic"] = main_bytes
+line["roofline"]["whole_evaluation"]["traffic"] = pj["hbm_bytes_per_launch"]
+json.dump(line, open(pre + "bench_line.json", "w"))
+shutil.copy(os.path.join(src, "other_configs.txt"), pre + "other_configs.txt")
+shutil.copy(os.path.join(src, "tv_configs.txt"), pre + "tv_configs.txt")
+print("wrote", pre + "*", "and profiles/pmc_latest.json; main kernel", main, f"{main_bytes / 1e9:.3f} GB per launch")
