@@ -123,6 +123,12 @@ class TmbObj:
     def gr(self, x=None):
         return self._eval(self.par if x is None else x)[1]
 
+    def he(self, x=None):
+        """Hessian over the free parameters by central differences of the GPU gradient (`tmb_obj$he`,
+        used by edf_conditional, R/sde.R:1363)."""
+        from .report import fd_hessian
+        return fd_hessian(self.gr, self.par if x is None else np.asarray(x, dtype=np.float64))
+
 
 class SDE:
     def __init__(self, formulas=None, data=None, type=None, response=None, par0=None, fixpar=None, other_data=None):
@@ -177,6 +183,7 @@ class SDE:
                 self.coeff_fe_[i0[i]] = par0[i] if nm.startswith("mu") else np.log(par0[i])
         self.tmb_obj_ = None
         self.tmb_obj_joint_ = None
+        self.tmb_rep_ = None
         self.out_ = None
         self.engine_ = None
 
@@ -194,6 +201,7 @@ class SDE:
     def out(self): return self.out_
     def tmb_obj(self): return self.tmb_obj_
     def tmb_obj_joint(self): return self.tmb_obj_joint_
+    def tmb_rep(self): return self.tmb_rep_
 
     def obs(self):
         return np.column_stack([np.asarray(self.data_[r], dtype=np.float64) for r in self.response_])
@@ -258,20 +266,20 @@ class SDE:
         pb = self._problem(include_penalty=1, fix_lambda=not self.laplace_)
         self.problem_ = pb
         self.engine_ = capi.Engine(pb)
-        self.tmb_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())
+        self.joint_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())   # all free parameters, fixed + random
+        self.tmb_obj_ = self.joint_obj_
         if self.laplace_:
             from .laplace import LaplaceObjective
             free = set(pb.free_index().tolist())
             idx_r = [k for k in range(pb.off_re, pb.off_re + pb.n_re) if k in free]
             idx_o = [k for k in sorted(free) if k not in set(idx_r)]
-            self.joint_obj_ = self.tmb_obj_
             self.tmb_obj_ = LaplaceObjective(lambda p: self.engine_.eval(p, order=1), self._par_full(pb), idx_o, idx_r)
         # joint object "excluding penalty" (R/sde.R:663-669): include_penalty = 0 is honoured by the
         # direct families only (Q7); the Kalman families share the same engine
         if pb.kalman or pb.n_smooth == 0:
-            self.tmb_obj_joint_ = self.tmb_obj_
+            self.tmb_obj_joint_ = self.joint_obj_
         else:
-            pbj = self._problem(include_penalty=0)
+            pbj = self._problem(include_penalty=0, fix_lambda=not self.laplace_)
             self.engine_joint_ = capi.Engine(pbj)
             self.tmb_obj_joint_ = TmbObj(self.engine_joint_, self._par_full(pbj), pbj.free_index())
         return self.tmb_obj_
@@ -297,6 +305,7 @@ class SDE:
             full[obj.free] = res.x
         pb = self.problem_
         self.par_full_ = full
+        self.tmb_rep_ = None
         self.log_sigma_obs_ = full[0] if pb.kalman else None
         self.coeff_fe_ = full[pb.off_fe:pb.off_fe + pb.n_fe].copy()        # R/sde.R:707-713
         self.coeff_re_ = full[pb.off_re:pb.off_re + pb.n_re].copy()
@@ -304,13 +313,75 @@ class SDE:
             self.lambda_vals_ = np.exp(full[pb.off_lambda:pb.off_lambda + pb.n_smooth])   # R/sde.R:712
         return self.out_
 
-    def logLik(self):
-        """- tmb_obj_joint$fn(par_all) with attributes nobs (R/utility.R:115-123); df is the number of
-        free fixed-effect parameters (the random-effect EDF term needs sdreport's joint precision,
-        SURVEY 8(f)-2)."""
-        obj = self.tmb_obj_joint_ if not getattr(self, "laplace_", False) else self.joint_obj_
+    def report(self):
+        """sdreport counterpart (R/sde.R:702-704): estimates, cov.fixed and the joint precision of
+        (fixed, random) built from finite differences of the GPU gradient (smoothsde_amd/report.py)."""
+        from .report import sdreport
+        pb = self.problem_
+        full = self.par_full_ if getattr(self, "par_full_", None) is not None else self.tmb_obj_.par_full
+        if self.laplace_:
+            lap = self.tmb_obj_
+            u_keep = lap.u_hat.copy()
+
+            def marg(theta):
+                lap.u_hat = u_keep.copy()
+                return lap.fn(theta, update_warm_start=False)
+            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, lap.io, lap.ir, marginal_fn=marg)
+            lap.u_hat = u_keep
+        else:
+            free = pb.free_index()
+            ir = np.array([k for k in free if pb.off_re <= k < pb.off_re + pb.n_re], dtype=int)
+            io = np.array([k for k in free if k not in set(ir.tolist())], dtype=int)
+            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, io, ir, marginal_fn=None)
+        self.tmb_rep_ = rep
+        return rep
+
+    def post_coeff(self, n_post, seed=None):
+        """Posterior draws of all coefficients from MVN(par_all, jointCov) (R/sde.R:871-915): a dict with one
+        (n_post x k) matrix per parameter block."""
+        rep = self.tmb_rep_ if self.tmb_rep_ is not None else self.report()
+        cov = np.linalg.inv(rep.jointPrecision) if rep.jointPrecision is not None else rep.cov_fixed   # prec_to_cov
+        cov = 0.5 * (cov + cov.T)
+        draws = np.random.default_rng(seed).multivariate_normal(rep.par_all(), cov, size=int(n_post), method="eigh")
+        names = rep.names_all()
+        out = {nm: draws[:, [i for i, k in enumerate(names) if k == nm]] for nm in dict.fromkeys(names)}
+        out.setdefault("coeff_re", np.zeros((int(n_post), 0)))          # R/sde.R:907-910
+        return out
+
+    def _joint_free_x(self):
+        obj = self.tmb_obj_joint_
         x = self.par_full_[obj.free] if getattr(self, "par_full_", None) is not None else obj.par
-        return dict(value=-obj.fn(x), df=len(self.tmb_obj_.par), nobs=self.n_)
+        return obj, x
+
+    def edf_conditional(self):
+        """Effective degrees of freedom (R/sde.R:1360-1375): fixed-effect count + tr(H_re V_re), H the Hessian of
+        the joint objective `tmb_obj_joint` (excluding the penalty for the direct families; the Kalman families
+        ignore that flag, Q7), V the joint covariance."""
+        n_lambda = self.problem_.n_smooth if getattr(self, "laplace_", False) else 0
+        edf = float(len(self.tmb_obj_.par) - n_lambda)
+        rep = self.tmb_rep_ if self.tmb_rep_ is not None else self.report()
+        if rep.jointPrecision is not None:
+            pb = self.problem_
+            jobj, x = self._joint_free_x()
+            H = jobj.he(x)
+            ind_h = [i for i, k in enumerate(jobj.free) if pb.off_re <= k < pb.off_re + pb.n_re]
+            V = np.linalg.inv(rep.jointPrecision)
+            ind_v = [i for i, nm in enumerate(rep.names_all()) if nm == "coeff_re"]
+            edf += float(np.trace(H[np.ix_(ind_h, ind_h)] @ V[np.ix_(ind_v, ind_v)]))
+        return edf
+
+    def logLik(self):
+        """- tmb_obj_joint$fn(par_all) with attributes df = edf_conditional() and nobs (R/utility.R:115-123)."""
+        obj, x = self._joint_free_x()
+        return dict(value=-obj.fn(x), df=self.edf_conditional(), nobs=self.n_)
+
+    def AIC_conditional(self):
+        ll = self.logLik()
+        return -2.0 * ll["value"] + 2.0 * ll["df"]                       # R/sde.R:1318-1328
+
+    def AIC_marginal(self):
+        n_lambda = 0 if not getattr(self, "laplace_", False) else self.problem_.n_smooth
+        return 2.0 * self.out_["value"] + 2.0 * (len(self.out_["par"]) - n_lambda)   # R/sde.R:1340-1349
 
     def par(self, t=None):
         """SDE parameters on the natural scale for every row (R/sde.R:749-856, new_data = NULL)."""

@@ -30,6 +30,12 @@ def test_fit_recovers_ctcrw_parameters():
     ll = sde.logLik()
     oval = oracle_eval(sde.problem_, sde.par_full_, order=0, threads=8)
     assert abs(-ll["value"] - oval) <= 1e-10 * abs(oval) and ll["nobs"] == len(ID)
+    assert ll["df"] == 3                                     # no random effects: the free fixed effects
+    # without random effects sdreport gives cov.fixed only; standard errors are small and positive
+    rep = sde.report()
+    assert rep.jointPrecision is None and rep.cov_fixed.shape == (3, 3)
+    se = rep.as_list("Std. Error")
+    assert 0 < se["log_sigma_obs"][0] < 0.1 and np.all(se["coeff_fe"] > 0) and np.all(se["coeff_fe"] < 0.2)
 
 
 def _ou_smooth_sde():
@@ -66,6 +72,22 @@ def test_fit_ou_with_smooth_mean_laplace():
     assert np.max(np.abs(g[pb.off_re:pb.off_re + pb.n_re])) < 1e-3 * max(1.0, np.max(np.abs(g)))
     mu_hat = sde.par()["mu"]
     assert np.corrcoef(mu_hat, 1.0 + 1.5 * np.sin(3 * sde.data()["cov"]))[0, 1] > 0.9
+    # sdreport counterpart on top of the GPU gradient (R/sde.R:702-719, 871-915, 1318-1375)
+    rep = sde.report()
+    n_re = pb.n_re
+    assert rep.names_random == ["coeff_re"] * n_re and rep.names_fixed == ["coeff_fe"] * 3 + ["log_lambda"]
+    Q = rep.jointPrecision
+    assert Q.shape == (4 + n_re, 4 + n_re) and np.allclose(Q, Q.T)
+    assert np.all(np.linalg.eigvalsh(Q[4:, 4:]) > 0)
+    assert np.allclose(rep.as_list("Estimate")["coeff_re"], sde.coeff_re())
+    post = sde.post_coeff(200, seed=1)
+    assert post["coeff_fe"].shape == (200, 3) and post["coeff_re"].shape == (200, n_re) and post["log_lambda"].shape == (200, 1)
+    assert np.max(np.abs(post["coeff_re"].mean(axis=0) - sde.coeff_re())) < 1.0
+    edf = sde.edf_conditional()
+    assert 3.0 < edf <= 3.0 + n_re + 1e-6, edf
+    ll = sde.logLik()
+    assert np.isfinite(ll["value"]) and ll["df"] == pytest.approx(edf)
+    assert np.isfinite(sde.AIC_conditional()) and np.isfinite(sde.AIC_marginal())
 
 
 def test_sharded_objective_single_rank_on_device():
