@@ -38,7 +38,8 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
                  X_list_re = lapply(mats$X_list_re, function(x) if(ncol(x) > 0) as.matrix(x) else NULL),
                  a0 = tmb_dat$a0, P0 = tmb_dat$P0,
                  H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
-                 par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device)
+                 par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device,
+                 other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL)
     # one penalty matrix per smooth: the diagonal blocks of S, sizes terms()$ncol_re (R/sde.R:424-447)
     if(has_re) {
         ncol_re <- sde$terms()$ncol_re; off <- cumsum(c(0, ncol_re)); S <- as.matrix(sde$mats()$S)

@@ -40,6 +40,7 @@ static int model_code(const char *type) {
     if (!strcmp(type, "BM_SSM")) return SSDE_MODEL_BM_SSM;
     if (!strcmp(type, "OU_SSM")) return SSDE_MODEL_OU_SSM;
     if (!strcmp(type, "CTCRW")) return SSDE_MODEL_CTCRW;
+    if (!strcmp(type, "BM_t")) return SSDE_MODEL_BM_T;
     return -1;
 }
 
@@ -55,7 +56,7 @@ SEXP ssdeR_create(SEXP spec) {
     SEXP obs = get_elt(spec, "obs");
     d.n = Rf_nrows(obs);
     d.n_dim = Rf_ncols(obs);
-    d.n_par = (d.model == SSDE_MODEL_BM || d.model == SSDE_MODEL_BM_SSM) ? d.n_dim + 1 : d.n_dim + 2;
+    d.n_par = (d.model == SSDE_MODEL_BM || d.model == SSDE_MODEL_BM_SSM || d.model == SSDE_MODEL_BM_T) ? d.n_dim + 1 : d.n_dim + 2;
     d.id = REAL(get_elt(spec, "ID"));
     d.times = REAL(get_elt(spec, "times"));
     d.obs = REAL(obs);
@@ -97,6 +98,8 @@ SEXP ssdeR_create(SEXP spec) {
         for (R_xlen_t k = 0; k < Rf_xlength(fx); k++) fixed[k] = LOGICAL(fx)[k] != 0;
     }
     d.par_fixed = fixed;
+    SEXP od = get_elt(spec, "other_data");                          /* tmb_dat$other_data: df of BM_t (R/sde.R:539-541) */
+    if (od != R_NilValue && Rf_xlength(od) > 0) { d.other_data = REAL(od); d.n_other_data = (int32_t)Rf_xlength(od); }
     d.na_mode = SSDE_NA_R_ONLY;                                     /* R_IsNA semantics (nllk_ctcrw.hpp:214) */
     SEXP dev = get_elt(spec, "device");
     d.device = (dev == R_NilValue) ? -1 : Rf_asInteger(dev);

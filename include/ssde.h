@@ -38,7 +38,7 @@
  * fixed ("mapped") entries included:
  *   Kalman families (BM_SSM, OU_SSM, CTCRW; nllk_ctcrw.hpp:135-140):
  *       [ log_sigma_obs | coeff_fe (sum ncol_fe) | log_lambda (n_smooth) | coeff_re (sum ncol_re) ]
- *   direct families (BM, OU; nllk_sde.hpp:42-45, decay feature not supported):
+ *   direct families (BM, BM_t, OU; nllk_sde.hpp:42-45, decay feature not supported):
  *       [ coeff_fe | log_lambda | coeff_re ]
  *   coeff_fe / coeff_re are ordered parameter-by-parameter exactly like the columns
  *   of the reference's block-diagonal X_fe / X_re (R/sde.R:443-447).
@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 1
+#define SSDE_ABI_VERSION 2
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -64,7 +64,9 @@ enum {
     SSDE_MODEL_OU     = 1, /* "OU"      -> nllk_sde + tr_dens OU branch  (tr_dens.hpp:45-52) */
     SSDE_MODEL_BM_SSM = 2, /* "BM_SSM"  -> nllk_bm_ssm                                    */
     SSDE_MODEL_OU_SSM = 3, /* "OU_SSM"  -> nllk_ou_ssm                                    */
-    SSDE_MODEL_CTCRW  = 4  /* "CTCRW"   -> nllk_ctcrw                                     */
+    SSDE_MODEL_CTCRW  = 4, /* "CTCRW"   -> nllk_ctcrw                                     */
+    SSDE_MODEL_BM_T   = 5  /* "BM_t"    -> nllk_sde + tr_dens BM_t branch (tr_dens.hpp:38-44): one response,
+                              par = (mu, log sigma), degrees of freedom in other_data[0] (R/sde.R:539-541) */
 };
 
 /* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with
@@ -93,7 +95,7 @@ typedef struct ssde_desc {
     int32_t  abi_version;     /* SSDE_ABI_VERSION */
     int32_t  model;           /* SSDE_MODEL_* */
     int32_t  n_dim;           /* d = ncol(obs), 1..2 on the register paths */
-    int32_t  n_par;           /* q = SDE parameters per row: d+1 (BM, BM_SSM), d+2 (OU, OU_SSM, CTCRW) */
+    int32_t  n_par;           /* q = SDE parameters per row: d+1 (BM, BM_t, BM_SSM), d+2 (OU, OU_SSM, CTCRW) */
     int64_t  n;               /* rows of the long-format data (all tracks concatenated) */
     const double *id;         /* [n] track codes (TMB passes the factor as doubles); only
                                  id[i] != id[i-1] is ever used (nllk_ctcrw.hpp:196)     */
@@ -126,6 +128,9 @@ typedef struct ssde_desc {
     int32_t  device;              /* HIP device ordinal, -1 = current device */
     uint32_t flags;               /* SSDE_FLAG_* */
     uint32_t reserved;
+    const double *other_data;     /* DATA_VECTOR(other_data) (nllk_sde.hpp:29): [0] = degrees of freedom for BM_t; NULL otherwise */
+    int32_t  n_other_data;
+    int32_t  reserved2;
 } ssde_desc;
 
 typedef struct ssde_handle ssde_handle;

@@ -514,7 +514,17 @@ Type nllk_direct(const Problem& p, const Type* par) {
         for (int a = 0; a < n_dim; a++) {
             double z0 = d->obs[(i - 1) + (int64_t)a * n], z1 = d->obs[i + (int64_t)a * n];
             if (is_na(z0, d->na_mode) || is_na(z1, d->na_mode)) continue;  // tr_dens.hpp:31
-            if (d->model == SSDE_MODEL_BM) {
+            if (d->model == SSDE_MODEL_BM_T) {
+                const double df = d->other_data[0];                                    // tr_dens.hpp:40
+                Type mean = linpred(p, par, i - 1, 0) * dt;                            // :41 (par(0), par(1) whatever i)
+                Type sd = exp(linpred(p, par, i - 1, 1)) * std::sqrt(dt);              // :42
+                Type scale = sd / std::sqrt(df / (df - 2.0));                          // :43
+                Type x = (Type(z1) - Type(z0) - mean) / scale;
+                // R's dt(x, df, log = TRUE) = lgamma((df+1)/2) - lgamma(df/2) - log(df pi)/2 - (df+1)/2 log(1 + x^2/df)
+                Type logdt = Type(std::lgamma(0.5 * (df + 1.0)) - std::lgamma(0.5 * df) - 0.5 * std::log(df * M_PI)) -
+                             Type(0.5 * (df + 1.0)) * log(Type(1.0) + x * x / df);
+                res = res + logdt - log(scale);                                        // :44
+            } else if (d->model == SSDE_MODEL_BM) {
                 Type mean = Type(z0) + linpred(p, par, i - 1, a) * dt;                 // tr_dens.hpp:35
                 Type sd = exp(linpred(p, par, i - 1, n_dim)) * std::sqrt(dt);          // :36
                 res = res + dnorm_log(Type(z1), mean, sd);                             // :37

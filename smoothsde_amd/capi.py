@@ -17,12 +17,12 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4}
+MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
 # types the reference dispatches (src/smoothSDE.cpp:12-27) that this engine does not cover
-UNSUPPORTED_MODELS = ("BM_t", "CIR", "ESEAL_SSM")
+UNSUPPORTED_MODELS = ("CIR", "ESEAL_SSM")
 
 NA_R_ONLY, NA_ANY_NAN = 0, 1
 PATH_NAMES = {0: "direct", 1: "isotropic-register", 2: "dense", 3: "isotropic-row-varying"}
@@ -44,6 +44,7 @@ class SsdeDesc(C.Structure):
         ("n_seg", C.c_int64), ("a0", C.c_void_p), ("p0", C.c_void_p), ("h_array", C.c_void_p),
         ("par_fixed", C.c_void_p), ("na_mode", C.c_int32), ("device", C.c_int32),
         ("flags", C.c_uint32), ("reserved", C.c_uint32),
+        ("other_data", C.c_void_p), ("n_other_data", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -71,7 +72,7 @@ def _f64(a, order="F"):
 
 
 def n_sde_par(model: str, n_dim: int) -> int:
-    return n_dim + 1 if model in ("BM", "BM_SSM") else n_dim + 2
+    return n_dim + 1 if model in ("BM", "BM_SSM", "BM_t") else n_dim + 2
 
 
 def state_dim(model: str, n_dim: int) -> int:
@@ -94,7 +95,7 @@ class Problem:
     def __init__(self, model: str, ID, times, obs, X_fe: Optional[Sequence] = None,
                  X_re: Optional[Sequence] = None, S_list: Optional[Sequence] = None,
                  a0=None, P0=None, H=None, par_fixed=None, include_penalty: int = 1,
-                 na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0):
+                 na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0, other_data=None):
         if model in UNSUPPORTED_MODELS:
             raise NotImplementedError(f"SDE type {model!r} is outside this engine's scope")
         if model not in MODEL_CODES:
@@ -184,6 +185,13 @@ class Problem:
             fixed[0] = 1  # map log_sigma_obs = NA when H is supplied (R/sde.R:565, 595)
         self.par_fixed = fixed
         self.na_mode, self.device, self.flags = int(na_mode), int(device), int(flags)
+        # DATA_VECTOR(other_data): the degrees of freedom of BM_t (R/sde.R:539-541)
+        self.other_data = None if other_data is None else _f64(np.atleast_1d(np.asarray(other_data, dtype=np.float64)))
+        if model == "BM_t":
+            if self.n_dim != 1:
+                raise ValueError("BM_t takes one response variable")
+            if self.other_data is None or not (self.other_data[0] > 2):
+                raise ValueError("BM_t needs other_data = df (degrees of freedom > 2)")
         self._keep = []
 
     @classmethod
@@ -253,6 +261,7 @@ class Problem:
         self.par_fixed = fixed
         self.na_mode, self.device = int(na_mode), int(ID.device.index or 0)
         self.flags = int(flags) | FLAG_DEVICE_DATA
+        self.other_data = None
         self._keep = []
         return self
 
@@ -306,6 +315,8 @@ class Problem:
         d.a0, d.p0, d.h_array = ptr(self.a0), ptr(self.P0), ptr(self.H)
         d.par_fixed = ptr(self.par_fixed)
         d.na_mode, d.device, d.flags = self.na_mode, self.device, self.flags
+        d.other_data = ptr(getattr(self, "other_data", None))
+        d.n_other_data = 0 if getattr(self, "other_data", None) is None else len(self.other_data)
         return d
 
 

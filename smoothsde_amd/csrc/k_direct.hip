@@ -1,5 +1,5 @@
-// k_direct.hip -- direct transition-density families "BM" and "OU" (nllk_sde.hpp:77-84 with
-// tr_dens.hpp:32-37, 45-52) for gfx950.
+// k_direct.hip -- direct transition-density families "BM", "BM_t" and "OU" (nllk_sde.hpp:77-84 with
+// tr_dens.hpp:32-52) for gfx950.
 //
 // No recursion: row i depends only on rows i-1, i and on the parameters of row i-1 (Q6), so
 // the long format is streamed as it is -- lane = row, every column read is coalesced
@@ -21,7 +21,7 @@ template <int MODEL, int D, int KMAX>
 __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     const SlotTable* __restrict__ T = A.slots;
     const int ns = A.n_slots;
-    constexpr int Q = (MODEL == M_BM) ? D + 1 : D + 2;
+    constexpr int Q = (MODEL == M_BM || MODEL == M_BM_T) ? D + 1 : D + 2;
 
     // ---- loop invariants (wave-uniform) ---------------------------------------------------------
     const double* cptr[KMAX];
@@ -77,7 +77,12 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
             }
         }
         double g[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
-        if (MODEL == M_BM) {
+        if (MODEL == M_BM_T) {
+            // tr_dens.hpp:38-44: Student-t increment, scale = sd / sqrt(df / (df - 2))
+            const double z0 = A.obs[i - 1], z1 = A.obs[i];
+            if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan)))
+                nll += bmt_direct(z0, z1, dt, par[0], varies[1] ? par[1] : base[1], A.tdf, A.tconst, g[0], g[1]);
+        } else if (MODEL == M_BM) {
             // tr_dens.hpp:35-37: mean = z0 + mu dt, sd = exp(par[D]) sqrt(dt)
             const double sig = varies[D] ? exp(par[D]) : nat_p1;
             const double sd = sig * sqrt(dt);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
 // KA / KB: register capacity for the streamed columns of the (at most two) parameters that have any.
 template <int MODEL, int D, int KA, int KB>
 __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A) {
-    constexpr int Q = (MODEL == M_BM) ? D + 1 : D + 2;
+    constexpr int Q = (MODEL == M_BM || MODEL == M_BM_T) ? D + 1 : D + 2;
     const int ncA = A.ncA, ncB = A.ncB, ja = A.ja, jb = A.jb;
     const int64_t n = A.n;
     double accI[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
@@ -166,7 +171,9 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     double c_e = 0.0, c_isd = 0.0, c_lsd = 0.0, c_dls = 0.0, c_z = 0.0;
     if (all_const) {
         const double dt = A.dt_uniform;
-        if (MODEL == M_BM) {
+        if (MODEL == M_BM_T) {
+            // (nothing hoisted: one log1p per row dominates anyway)
+        } else if (MODEL == M_BM) {
             const double sd = nat_p1 * sqrt(dt);
             c_isd = 1.0 / sd; c_lsd = log(sd);
         } else {
@@ -206,7 +213,11 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
         for (int j = 0; j < MAX_Q; j++) par[j] = A.base[j] + ((j == ja) ? sumA : 0.0) + ((j == jb) ? sumB : 0.0);
 
         double g[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
-        if (MODEL == M_BM) {
+        if (MODEL == M_BM_T) {
+            const double z0 = __builtin_nontemporal_load(&A.obs[r]), z1 = A.obs[i];
+            if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan)))                       // tr_dens.hpp:31
+                nll += bmt_direct(z0, z1, dt, par[0], par[1], A.tdf, A.tconst, g[0], g[1]);   // :38-44
+        } else if (MODEL == M_BM) {
             double isd = c_isd, lsd = c_lsd;
             if (!all_const) {
                 const double sd = (varies1 ? exp(par[D]) : nat_p1) * sqrt(dt);   // tr_dens.hpp:36
@@ -282,7 +293,7 @@ hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
         return hipGetLastError();                                                           \
     }
 #define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
-    SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2)
+    SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2) SSDE_FK(M_BM_T, 1)
 #undef SSDE_FK
 #undef SSDE_F
     return hipErrorInvalidValue;
@@ -321,7 +332,7 @@ hipError_t launch_direct(const DirectArgs& a, hipStream_t s) {
         return hipGetLastError();                                                      \
     }
 #define SSDE_LK(MODEL, D) SSDE_L(MODEL, D, 4) SSDE_L(MODEL, D, 16) SSDE_L(MODEL, D, 32) SSDE_L(MODEL, D, 64)
-    SSDE_LK(M_BM, 1) SSDE_LK(M_BM, 2) SSDE_LK(M_OU, 1) SSDE_LK(M_OU, 2)
+    SSDE_LK(M_BM, 1) SSDE_LK(M_BM, 2) SSDE_LK(M_OU, 1) SSDE_LK(M_OU, 2) SSDE_LK(M_BM_T, 1)
 #undef SSDE_LK
 #undef SSDE_L
     return hipErrorInvalidValue;

@@ -174,6 +174,7 @@ struct DirectArgs {
     int n_slots;                 // == slots->n_slots (host copy, selects the kernel variant)
     int n_blocks;
     double* partials;            // [1][1 + n_slots][n_blocks]
+    double tdf, tconst;          // BM_t: degrees of freedom and the normalising constant of dt(., df)
 };
 hipError_t launch_direct(const DirectArgs& a, hipStream_t s);
 
@@ -199,6 +200,7 @@ struct DirectFastArgs {
     double coefA[DIRECT_KCAP], coefB[DIRECT_KCAP];
     int uniform_dt;               // every scored interval equals dt_uniform
     double dt_uniform;
+    double tdf, tconst;           // BM_t
 };
 hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s);
 hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t n, double* out2_per_block, int n_blocks,

@@ -56,6 +56,7 @@ struct ssde_handle {
     int64_t n = 0, n_seg = 0, n_steps = 0;
     bool has_h = false, const_coeff = false, uniform_dt = false;
     double dt_uniform = 0.0;
+    double tdf = 0.0, tconst = 0.0;     // BM_t: degrees of freedom, normalising constant of dt(., df)
     double p0_iso[3] = {0, 0, 0};
     double p0_full[16] = {0};
     ParLayout L;
@@ -527,7 +528,15 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
 int build(const ssde_desc* d, ssde_handle* h) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
-    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_CTCRW) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_BM_T) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (d->model == SSDE_MODEL_BM_T) {
+        // tr_dens.hpp:38-44 reads par(0), par(1) whatever the dimension: one response variable
+        if (d->n_dim != 1) return fail(h, SSDE_ERR_MODEL, "BM_t takes one response variable");
+        if (!d->other_data || d->n_other_data < 1 || !(d->other_data[0] > 2.0))
+            return fail(h, SSDE_ERR_ARG, "BM_t needs other_data[0] = degrees of freedom > 2");
+        h->tdf = d->other_data[0];
+        h->tconst = std::lgamma(0.5 * (h->tdf + 1.0)) - std::lgamma(0.5 * h->tdf) - 0.5 * std::log(h->tdf * M_PI);
+    }
     if (d->n_dim < 1 || d->n_dim > 2)
         return fail(h, SSDE_ERR_MODEL, "n_dim must be 1 or 2 (wider responses are outside this engine's kernels)");
     if (d->n_par != n_sde_par(d->model, d->n_dim)) return fail(h, SSDE_ERR_ARG, "n_par does not match model / n_dim");
@@ -1202,6 +1211,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             for (int c = 0; c < f.ncB; c++) f.coefB[c] = par[h->df_pidxB[c]];
             f.uniform_dt = h->direct_uniform_dt ? 1 : 0;
             f.dt_uniform = h->direct_dt;
+            f.tdf = h->tdf; f.tconst = h->tconst;
             HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_direct_fast(f, s));
             HIPCHK(h, hipEventRecord(h->ev_k1, s));
@@ -1227,6 +1237,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.n = h->n; a.d = h->d; a.model = h->model; a.any_nan = h->na_any;
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
         a.n_blocks = h->direct_blocks; a.partials = h->partials.p;
+        a.tdf = h->tdf; a.tconst = h->tconst;
         if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
         HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_direct(a, s));

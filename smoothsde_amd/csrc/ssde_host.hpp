@@ -23,7 +23,7 @@ inline int state_dim(int model, int d) {
     return model == SSDE_MODEL_CTCRW ? 2 * d : (is_kalman(model) ? d : 0);
 }
 inline int n_sde_par(int model, int d) {
-    return (model == SSDE_MODEL_BM || model == SSDE_MODEL_BM_SSM) ? d + 1 : d + 2;
+    return (model == SSDE_MODEL_BM || model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_BM_T) ? d + 1 : d + 2;
 }
 
 // full parameter vector layout (include/ssde.h, PARAMETER VECTOR)

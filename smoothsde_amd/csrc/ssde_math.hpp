@@ -38,7 +38,7 @@ namespace ssde {
 enum { DIR_SIG = 1, DIR_MU = 2, DIR_P1 = 4, DIR_P2 = 8 };
 
 // model codes (== SSDE_MODEL_* of include/ssde.h)
-enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4 };
+enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4, M_BM_T = 5 };
 
 // R_IsNA / any-NaN test on the bit pattern (Q5)
 SSDE_HD bool is_na(double x, int any_nan) {
@@ -487,6 +487,20 @@ SSDE_HD double bm_direct(double z0, double z1, double dt, double mu, double lsig
     g_mu += -r * dt / sd;
     g_ls += 1.0 - r * r;
     return SSDE_LOG_SQRT_2PI + log(sd) + 0.5 * r * r;
+}
+// BM_t: Brownian motion with Student-t increments, par = (mu, log sigma), df degrees of freedom (tr_dens.hpp:38-44):
+//   scale = sd / sqrt(df / (df - 2)),  log dens = dt(x, df, log) - log(scale),  x = (z1 - z0 - mu dt) / scale
+// tconst = lgamma((df+1)/2) - lgamma(df/2) - log(df pi)/2 (R's dt() normalising constant; host side)
+SSDE_HD double bmt_direct(double z0, double z1, double dt, double mu, double lsig, double df, double tconst,
+                          double& g_mu, double& g_ls) {
+    const double sd = exp(lsig) * sqrt(dt);
+    const double scale = sd / sqrt(df / (df - 2.0));
+    const double x = (z1 - z0 - mu * dt) / scale;
+    const double q = x * x / df;
+    const double w = (df + 1.0) * x / (df + x * x);        // d/dx of (df+1)/2 log(1 + x^2/df)
+    g_mu += -w * dt / scale;
+    g_ls += 1.0 - w * x;
+    return -(tconst - 0.5 * (df + 1.0) * log1p(q) - log(scale));
 }
 // OU: par = (mu_a, log tau, log kappa): tr_dens.hpp:49-52
 SSDE_HD double ou_direct(double z0, double z1, double dt, double mu, double ltau, double lkap, double& g_mu,

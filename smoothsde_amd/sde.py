@@ -29,6 +29,7 @@ from .synth import bspline_basis, second_difference_penalty
 
 PAR_NAMES = {
     "BM": lambda d: _mu_names(d) + ["sigma"],
+    "BM_t": lambda d: ["mu", "sigma"],                   # R/sde.R:61
     "BM_SSM": lambda d: _mu_names(d) + ["sigma"],
     "OU": lambda d: _mu_names(d) + ["tau", "kappa"],
     "OU_SSM": lambda d: _mu_names(d) + ["tau", "kappa"],
@@ -236,7 +237,8 @@ class SDE:
             # an intercept-only block is passed as "no column" (broadcast), SURVEY 7.3-5
             X_fe.append(None if (d.X_fe is None or (d.X_fe.shape[1] == 1 and np.all(d.X_fe == 1.0))) else d.X_fe)
         X_re = [d.X_re for d in self.designs_]
-        kw = dict(a0=None, P0=self.other_data_.get("P0"), H=self.other_data_.get("H"), include_penalty=include_penalty)
+        kw = dict(a0=None, P0=self.other_data_.get("P0"), H=self.other_data_.get("H"), include_penalty=include_penalty,
+                  other_data=self.other_data_.get("df") if self.type_ == "BM_t" else None)   # R/sde.R:539-541
         kw.update(over)
         pb = capi.Problem(self.type_, self.data_["ID"], self.data_["time"], self.obs(), X_fe, X_re,
                           self.mats_["S_list"], **kw)

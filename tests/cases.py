@@ -56,7 +56,7 @@ def _par_const(rng, model, d, kalman):
 
 
 def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irregular=True,
-              fix_mu=False, with_H=False, with_P0=False, na_mode=1):
+              fix_mu=False, with_H=False, with_P0=False, na_mode=1, other_data=None):
     rng = np.random.default_rng(seed)
     kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
     ID, times, obs = _tracks(rng, model, d, lengths, irregular)
@@ -65,6 +65,8 @@ def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irr
     sdim = state_dim(model, d)
     spec = dict(name=name, model=model, n_dim=d, ID=ID, times=times, obs=obs, X_fe=None, X_re=None,
                 S_list=None, a0=None, P0=None, H=None, par_fixed=None, na_mode=na_mode, include_penalty=1)
+    if other_data is not None:
+        spec["other_data"] = np.atleast_1d(np.asarray(other_data, dtype=np.float64))
     na = na_real() if na_mode == 0 else float("nan")
     for r in na_rows:
         if kalman:
@@ -82,7 +84,7 @@ def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irr
         X_fe = [None] * q
         X_re = [None] * q
         X_fe[d] = np.column_stack([np.ones(n), x])
-        jr = q - 1 if model not in ("BM", "BM_SSM") else 0
+        jr = q - 1 if model not in ("BM", "BM_SSM", "BM_t") else 0
         B = bspline_basis(x, n_basis=4)
         X_re[jr] = B
         S_list = [second_difference_penalty(4)]
@@ -134,7 +136,8 @@ def elephant_spec():
 
 def problem_from_spec(spec, **over) -> Problem:
     kw = dict(a0=spec.get("a0"), P0=spec.get("P0"), H=spec.get("H"), par_fixed=spec.get("par_fixed"),
-              include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1))
+              include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1),
+              other_data=spec.get("other_data"))
     kw.update(over)
     return Problem(spec["model"], spec["ID"], spec["times"], spec["obs"], spec.get("X_fe"), spec.get("X_re"),
                    spec.get("S_list"), **kw)
@@ -172,4 +175,7 @@ def all_specs():
             specs.append(make_spec(f"{model}_d{d}_tv", model, d, seed=seed, lengths=[16, 11],
                                    variant="tv", na_rows=(5,)))
     specs.append(make_spec("OU_d1_tv2", "OU", 1, seed=181, lengths=[20, 13], variant="tv2"))
+    # BM with Student-t increments (tr_dens.hpp:38-44), degrees of freedom in other_data
+    specs.append(make_spec("BM_t_d1_const", "BM_t", 1, seed=191, lengths=[9, 2, 14, 6], na_rows=(3, 12), other_data=5.0))
+    specs.append(make_spec("BM_t_d1_tv", "BM_t", 1, seed=192, lengths=[16, 11], variant="tv", na_rows=(5,), other_data=3.5))
     return specs

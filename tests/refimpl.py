@@ -183,6 +183,13 @@ def direct_nllk(pb: Problem, par: torch.Tensor) -> torch.Tensor:
             z0, z1 = pb.obs[i - 1, a], pb.obs[i, a]
             if _is_na(z0, pb.na_mode) or _is_na(z1, pb.na_mode):
                 continue
+            if pb.model == "BM_t":
+                # scaled Student-t increment (tr_dens.hpp:38-44): torch.distributions.StudentT(df, loc, scale)
+                df = float(pb.other_data[0])
+                sd = torch.exp(p[1]) * math.sqrt(dt)
+                scale = sd / math.sqrt(df / (df - 2))
+                total = total - torch.distributions.StudentT(df, z0 + p[0] * dt, scale).log_prob(torch.tensor(z1))
+                continue
             if pb.model == "BM":
                 mean = z0 + p[a] * dt
                 sd = torch.exp(p[d]) * math.sqrt(dt)

@@ -289,3 +289,37 @@ def test_shared_covariance_path_mixed_groups(model, par, d, monkeypatch):
     assert abs(v - v2) <= 1e-12 * abs(v2)
     assert np.max(np.abs(g - g2)) <= 1e-10 * np.max(np.abs(g2))
     eng.close(); gen.close()
+
+
+DIRECT = [r for r in GOLD if r["model"] in ("BM", "OU", "BM_t")]
+
+
+@pytest.mark.parametrize("rec", DIRECT, ids=[r["name"] for r in DIRECT])
+def test_generic_direct_kernel(rec, monkeypatch):
+    """the runtime-routed direct kernel (the fallback for three or more streamed parameters) on every
+    direct-family golden case, incl. BM_t (Student-t increments, tr_dens.hpp:38-44)"""
+    monkeypatch.setenv("SSDE_NO_DIRECT_FAST", "1")
+    eng = capi.Engine(problem_from_spec(rec))
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    eng.close()
+
+
+def test_bm_t_medium_batch_vs_oracle():
+    """2000 ragged BM_t tracks with NA rows and a smooth on log sigma, df = 4"""
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    rng = np.random.default_rng(5)
+    ID, times, obs = simulate("BM", 2000, 30, 1, mu=0.2, sigma=0.7, seed=9)
+    obs[rng.random(len(ID)) < 0.03] = np.nan
+    n = len(ID)
+    x = (np.sin(np.arange(n) * 0.01) + 1) / 2
+    pb = capi.Problem("BM_t", ID, times, obs, X_re=[None, bspline_basis(x, 6)], S_list=[second_difference_penalty(6)],
+                      other_data=4.0)
+    par = np.r_[0.15, -0.3, 0.2, 0.1 * np.sin(np.arange(6))]
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    eng.close()
+    with pytest.raises(ValueError):
+        capi.Problem("BM_t", ID, times, obs)                 # no degrees of freedom
