@@ -58,12 +58,15 @@ __global__ __launch_bounds__(256) void tv_a0_kernel(const TvArgs A, const double
 }
 
 // ---- per evaluation: row records ----------------------------------------------------------------
-template <int MODEL, int D>
+template <int MODEL, int D, bool DENSE>
 __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     constexpr int Q = (MODEL == M_BM_SSM) ? D + 1 : D + 2;
+    constexpr int NS = TV_STATS / 2;
     __shared__ double sh[TV_STATS][4];
     const SlotTable* __restrict__ T = A.slots;
-    double smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double smin[NS], smax[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
         double par[Q];
 #pragma unroll
@@ -84,19 +87,32 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
 #pragma unroll
         for (int a = 0; a < D; a++) y[a] = A.obs[i + (int64_t)a * A.n];
         double r[TV_RS];
-        tv_make_record<MODEL, D>(dt, par, y, r);
+        double hmax = A.h;
+        if (DENSE) {
+            double hrow[D * D];
+            if (A.has_h) {
+                hmax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < D * D; k++) hrow[k] = A.h_array[i * (D * D) + k];   // H_array[,,i]
+#pragma unroll
+                for (int a = 0; a < D; a++) hmax = fmax(hmax, hrow[a + a * D]);
+            }
+            tv_make_record_dense<MODEL, D>(dt, par, y, A.has_h ? hrow : nullptr, r);
+        } else {
+            tv_make_record<MODEL, D>(dt, par, y, r);
+        }
         double2* o = (double2*)(A.rec + i * TV_RS);
 #pragma unroll
         for (int k = 0; k < TV_RS / 2; k++) o[k] = make_double2(r[2 * k], r[2 * k + 1]);
         if (used) {
-            const double v[3] = {dt, par[D], Q > D + 1 ? par[Q - 1] : 0.0};
+            const double v[NS] = {dt, par[D], Q > D + 1 ? par[Q - 1] : 0.0, hmax};
 #pragma unroll
-            for (int k = 0; k < 3; k++) { smin[k] = fmin(smin[k], v[k]); smax[k] = fmax(smax[k], v[k]); }
+            for (int k = 0; k < NS; k++) { smin[k] = fmin(smin[k], v[k]); smax[k] = fmax(smax[k], v[k]); }
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < NS; k++) {
         double a = smin[k], b = smax[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_xor(a, o, 64)); b = fmax(b, __shfl_xor(b, o, 64)); }
@@ -115,10 +131,11 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
 // ---- the recursion --------------------------------------------------------------------------------
 struct TvRow { double r[TV_RS]; double w; };
 
-__device__ __forceinline__ void tv_load_block(TvRow (&dst)[TV_U], const double* rec, const double* wp, int ndp,
+template <int U>
+__device__ __forceinline__ void tv_load_block(TvRow (&dst)[U], const double* rec, const double* wp, int ndp,
                                               int64_t i0, int64_t imax) {
 #pragma unroll
-    for (int u = 0; u < TV_U; u++) {
+    for (int u = 0; u < U; u++) {
         const int64_t i = (i0 + u < imax) ? i0 + u : imax;          // look-ahead rows stay inside the buffers
         const double2* p = (const double2*)(rec + i * TV_RS);
 #pragma unroll
@@ -127,11 +144,11 @@ __device__ __forceinline__ void tv_load_block(TvRow (&dst)[TV_U], const double* 
     }
 }
 
-template <int MODEL, int D, bool GRAD, bool REPORT>
+template <class Ops, bool GRAD, bool REPORT>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvArgs A) {
-    typedef TvOps<MODEL, D> Ops;
     typedef typename Ops::Lane Lane;
     constexpr int SD = Lane::SD;
+    constexpr int TV_U = Ops::U;
     const int item = blockIdx.x * WG_WAVES + (threadIdx.x >> 6);      // one work item per WAVE, no barriers
     if (item >= A.n_items) return;
     const int lane = threadIdx.x & 63;
@@ -152,7 +169,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
     const double* wp = A.wdir + k;
     const int64_t imax = A.n - 1;
     const double h = A.h;
-    const double p0[3] = {A.p0[0], A.p0[1], A.p0[2]};
+    double p0[Ops::DENSE ? 16 : 3];
+#pragma unroll
+    for (int q = 0; q < (Ops::DENSE ? SD * SD : 3); q++) p0[q] = Ops::DENSE ? A.p0f[q] : A.p0[q];
 
     int ns_min = ns;
 #pragma unroll
@@ -160,8 +179,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
     ns_min = __builtin_amdgcn_readfirstlane(ns_min);
 
     TvRow bufA[TV_U], bufB[TV_U];
-    tv_load_block(bufA, A.rec, wp, A.ndp, row0 + 1 + s_begin, imax);
+    tv_load_block<TV_U>(bufA, A.rec, wp, A.ndp, row0 + 1 + s_begin, imax);
     Lane S;
+    if constexpr (Ops::DENSE) S.has_h = A.has_h != 0;
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
             for (int c = 0; c < SD; c++) A.report[row0 + (int64_t)c * A.n] = a0[c];
         }
     } else {
-        S.warm_init(&bufA[0].r[TVR_Y], p0);
+        S.warm_init(&bufA[0].r[Ops::Y_OFF], p0);
     }
 
     auto one = [&](const TvRow& row, int s) {
@@ -205,10 +225,10 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
         }
     };
     for (int s0 = s_begin; s0 < s_end; s0 += 2 * TV_U) {
-        tv_load_block(bufB, A.rec, wp, A.ndp, row0 + 1 + s0 + TV_U, imax);
+        tv_load_block<TV_U>(bufB, A.rec, wp, A.ndp, row0 + 1 + s0 + TV_U, imax);
         handover(s0);
         run_block(bufA, s0);
-        tv_load_block(bufA, A.rec, wp, A.ndp, row0 + 1 + s0 + 2 * TV_U, imax);
+        tv_load_block<TV_U>(bufA, A.rec, wp, A.ndp, row0 + 1 + s0 + 2 * TV_U, imax);
         if (s0 + TV_U < s_end) {
             handover(s0 + TV_U);
             run_block(bufB, s0 + TV_U);
@@ -320,7 +340,8 @@ hipError_t launch_tv_a0(const TvArgs& a, const double* a0_src, const int64_t* tr
 hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s) {
 #define X(MODEL, D)                                                                                         \
     if (a.model == MODEL && a.d == D) {                                                                     \
-        hipLaunchKernelGGL((tv_prepare_kernel<MODEL, D>), dim3(a.stats_blocks), dim3(256), 0, s, a);        \
+        if (a.dense) hipLaunchKernelGGL((tv_prepare_kernel<MODEL, D, true>), dim3(a.stats_blocks), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((tv_prepare_kernel<MODEL, D, false>), dim3(a.stats_blocks), dim3(256), 0, s, a);        \
         return hipGetLastError();                                                                           \
     }
     SSDE_TV_MODELS(X)
@@ -331,21 +352,27 @@ hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s) {
 hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s) {
     if (a.n_items == 0) return hipSuccess;
     dim3 grid((a.n_items + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
+#define XO(OPS)                                                                                             \
+        if (a.report) hipLaunchKernelGGL((tv_filter_kernel<OPS, false, true>), grid, block, 0, s, a);       \
+        else if (want_grad) hipLaunchKernelGGL((tv_filter_kernel<OPS, true, false>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((tv_filter_kernel<OPS, false, false>), grid, block, 0, s, a);
 #define X(MODEL, D)                                                                                         \
     if (a.model == MODEL && a.d == D) {                                                                     \
-        if (a.report) hipLaunchKernelGGL((tv_filter_kernel<MODEL, D, false, true>), grid, block, 0, s, a);  \
-        else if (want_grad) hipLaunchKernelGGL((tv_filter_kernel<MODEL, D, true, false>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((tv_filter_kernel<MODEL, D, false, false>), grid, block, 0, s, a);          \
+        typedef TvOps<MODEL, D> OpsI;                                                                       \
+        typedef TvDenseOps<MODEL, D> OpsD;                                                                  \
+        if (a.dense) { XO(OpsD) } else { XO(OpsI) }                                                         \
         return hipGetLastError();                                                                           \
     }
     SSDE_TV_MODELS(X)
 #undef X
+#undef XO
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_tv_check(const TvArgs& a, hipStream_t s) {
     if (a.n_items == 0) return hipSuccess;
-    const int nstate = a.model == M_CTCRW ? 4 * a.d + 6 : 2 * a.d + 2;
+    const int sd = a.model == M_CTCRW ? 2 * a.d : a.d;
+    const int nstate = a.dense ? 2 * (sd + sd * sd) : (a.model == M_CTCRW ? 4 * a.d + 6 : 2 * a.d + 2);
     hipLaunchKernelGGL(tv_check_kernel, dim3(a.n_items), dim3(WAVE), 0, s, a, nstate);
     return hipGetLastError();
 }

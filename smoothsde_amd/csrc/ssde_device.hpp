@@ -235,8 +235,8 @@ hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 // serial recursion runs one WAVE per (pack of tracks, time window, direction block) with
 // lane = (track of the pack, gradient direction).
 constexpr int TV_U = 4;           // rows per prefetch block (divides WIN_ALIGN)
-constexpr int TV_NSTATE = 14;     // doubles per lane dumped at a window hand-over (CTCRW, d = 2)
-constexpr int TV_STATS = 6;       // per block: min/max of dt, par[d], par[d+1] over the rows the filter propagates
+constexpr int TV_NSTATE = 40;     // doubles per lane dumped at a window hand-over (dense CTCRW, d = 2: 2 (4 + 16))
+constexpr int TV_STATS = 8;       // per block: min/max of dt, par[d], par[d+1], largest diag(H) over the rows the filter propagates
 struct TvItem { int32_t pack, c, nc, b; };        // work item of one wave: track pack, window c of nc, direction block
 struct TvDir { int16_t kind, dim, pidx, slot; };  // TVK_* kind, dimension (TVK_MU), full-par index, coefficient slot
 struct TvArgs {
@@ -264,6 +264,10 @@ struct TvArgs {
     int window;                  // warm-up rows of a time window
     double h;                    // sigma_obs^2
     double p0[3];
+    int dense;                   // 1: full-covariance lanes (per-row H_array and / or a P0 that is not block-identical)
+    int has_h;
+    const double* h_array;       // [d x d x n] or NULL
+    double p0f[16];              // sdim x sdim column-major (dense lanes)
     double* bnd;                 // [n_items][2][TV_NSTATE][64]
     double* chk;                 // [n_items]
     double* gval;                // [n_items][64] per-lane nllk

@@ -142,7 +142,8 @@ struct ssde_handle {
     int iso_free_mask = 0;
 
     // row-varying isotropic path (k_tv.hip)
-    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats;
+    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats, tv_harr;
+    bool tv_dense = false;         // full-covariance lanes: per-row H_array and / or a P0 that is not block-identical
     DevBuf<TvDir> tv_dirs;
     DevBuf<int64_t> tv_row0;
     DevBuf<int32_t> tv_ns;
@@ -185,7 +186,7 @@ void destroy(ssde_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
     if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
-    h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
+    h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
     h->tv_gval.release(); h->tv_gdir.release(); h->tv_stats.release(); h->tv_dirs.release(); h->tv_row0.release();
     h->tv_ns.release(); h->tv_items_g.release(); h->tv_items_v.release();
     if (h->tv_stats_pinned) (void)hipHostFree(h->tv_stats_pinned);
@@ -264,6 +265,8 @@ void tv_base_args(const ssde_handle* h, TvArgs& a) {
     a.dirs = h->tv_dirs.p; a.trk_row0 = h->tv_row0.p; a.trk_ns = h->tv_ns.p; a.a0 = h->tv_a0.p;
     a.n_tracks = h->n_seg;
     for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+    a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
+    for (int i = 0; i < 16; i++) a.p0f[i] = h->p0_full[i];
     a.bnd = h->tv_bnd.p; a.chk = h->tv_chk.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
     a.stats = h->tv_stats.p; a.stats_blocks = h->tv_stats_blocks;
     a.n_out = 1 + h->L.n_full;
@@ -278,6 +281,7 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     h->max_chunks = 1 << 20;        // "1" means: forced to one sequential window (ssde_widen_windows / retries)
     HIPCHK(h, stage(d->times, (size_t)n, on_dev, h->times));
     HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, on_dev, h->obs));
+    if (h->has_h) HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, on_dev, h->tv_harr));
     h->col_stride = ((n + 63) / 64) * 64 + 160;
     HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * h->n_stream_cols));
     for (auto& sl : h->slots)
@@ -365,7 +369,7 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
         HIPCHK(h, hipDeviceSynchronize());
         s_a0.release(); s_seg.release();
     }
-    h->hbm_bytes = (int64_t)(h->times.n + h->obs.n + h->colbuf.n + h->tv_wdir.n + h->tv_rec.n + h->tv_a0.n) * 8 +
+    h->hbm_bytes = (int64_t)(h->times.n + h->obs.n + h->colbuf.n + h->tv_wdir.n + h->tv_rec.n + h->tv_a0.n + h->tv_harr.n) * 8 +
                    (int64_t)h->scored.n * 4;
     return SSDE_OK;
 }
@@ -411,22 +415,26 @@ double closed_loop_rho(int model, double dt, double p1, double p2, double hobs, 
 // Time windows of the tv path.  The warm-up length comes from the slowest-forgetting corner of the
 // parameter ranges the LAST evaluation's pre-pass saw (dt, par[d], par[d+1]); the device-side
 // hand-over check decides whether it was enough.  Rebuilds the work-item tables when the plan changes.
-int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {
+int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2 (replaced by the largest diag(H) with H_array)
     int W = 0;
     if (h->max_chunks > 1 && h->tv_stats_valid) {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int b = 0; b < h->tv_stats_blocks; b++)
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 4; k++) {
                 lo[k] = std::min(lo[k], h->tv_stats_pinned[b * TV_STATS + 2 * k]);
                 hi[k] = std::max(hi[k], h->tv_stats_pinned[b * TV_STATS + 2 * k + 1]);
             }
         double rho = 0.0;
         bool ok = std::isfinite(lo[0]) && std::isfinite(hi[0]) && std::isfinite(lo[1]) && std::isfinite(hi[1]) &&
                   std::isfinite(lo[2]) && std::isfinite(hi[2]);
+        // per-row H_array: the largest observation variance forgets slowest
+        if (h->has_h) { ok = ok && std::isfinite(hi[3]) && hi[3] > 0.0; hobs = hi[3]; }
+        const double p0d[3] = {h->p0_full[0], h->model == SSDE_MODEL_CTCRW ? h->p0_full[1] : 0.0,
+                               h->model == SSDE_MODEL_CTCRW ? h->p0_full[1 + h->sdim] : 0.0};
         if (ok)
             for (int c = 0; c < 8; c++) {
                 const double r = closed_loop_rho(h->model, (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1],
-                                                 (c & 4) ? hi[2] : lo[2], hobs, h->p0_iso);
+                                                 (c & 4) ? hi[2] : lo[2], hobs, p0d);
                 rho = std::max(rho, std::isfinite(r) ? r : 1.0);
             }
         if (ok && rho < 0.9995) {
@@ -487,7 +495,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     TvArgs a;
     tv_base_args(h, a);
     a.par = pdev;
-    const double sig = exp(par[0]);                      // nllk_ctcrw.hpp:136
+    const double sig = exp(par[0]);                      // nllk_ctcrw.hpp:136 (unused when H_array is supplied)
     a.h = sig * sig;
     const size_t stats_bytes = (size_t)h->tv_stats_blocks * TV_STATS * 8;
     bool prepared = false;
@@ -688,10 +696,12 @@ int build(const ssde_desc* d, ssde_handle* h) {
                             !(d->flags & SSDE_FLAG_FORCE_DENSE);
         h->path = iso_ok ? PATH_ISO : PATH_DENSE;
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
-        const bool tv_ok = !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
-                           !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
+        // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic
+        // lanes), per-row H_array or a P0 that is not block-identical (full-covariance lanes)
+        const bool tv_ok = !iso_ok && !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
                            (double)n * (TV_RS + 64) * 8.0 < 150e9;
         if (tv_ok) {
+            h->tv_dense = h->has_h || !p0_is_isotropic(d, h->p0_iso);
             int st = build_tv(d, h, starts, on_dev);
             if (st) return st;
         }

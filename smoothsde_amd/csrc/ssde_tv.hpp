@@ -19,6 +19,7 @@
 #ifndef SSDE_TV_HPP
 #define SSDE_TV_HPP
 
+#include "ssde_dense.hpp"
 #include "ssde_math.hpp"
 
 namespace ssde {
@@ -225,6 +226,9 @@ SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind,
 template <int MODEL, int D>
 struct TvOps {
     typedef TvScalLane<D> Lane;
+    static constexpr int U = 4;            // rows per prefetch block
+    static constexpr int Y_OFF = TVR_Y;    // where the record keeps the observation
+    static constexpr bool DENSE = false;
     template <bool GRAD>
     SSDE_HD static void step(Lane& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
         tv_scal_step<D, GRAD>(L, r, h, kind, dim, w, any_nan);
@@ -233,9 +237,82 @@ struct TvOps {
 template <int D>
 struct TvOps<M_CTCRW, D> {
     typedef TvCtcrwLane<D> Lane;
+    static constexpr int U = 4;
+    static constexpr int Y_OFF = TVR_Y;
+    static constexpr bool DENSE = false;
     template <bool GRAD>
     SSDE_HD static void step(Lane& L, const double* r, double h, int kind, int dim, double w, int any_nan) {
         tv_ctcrw_step<D, GRAD>(L, r, h, kind, dim, w, any_nan);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// General ("dense") variant for the same lane = direction kernels: per-row H_array
+// (nllk_ctcrw.hpp:203-205) and / or a P0 that is not block-identical (R/sde.R:552-557, 582-587).
+// Full sdim x sdim covariance, the step of ssde_dense.hpp with ONE dual direction per lane.
+// Record: 0..Q-1 the row's linear predictors | 4 dt | 5.. y | 7.. H_array[,,i] (column-major d x d)
+// ---------------------------------------------------------------------------------------
+constexpr int TVD_DT = 4, TVD_Y = 5, TVD_H = 7;
+
+template <int MODEL, int D>
+SSDE_HD void tv_make_record_dense(double dt, const double* par, const double* y, const double* hrow /* or NULL */, double* r) {
+    constexpr int Q = (MODEL == M_BM_SSM) ? D + 1 : D + 2;
+    for (int k = 0; k < TV_RS; k++) r[k] = 0.0;
+    for (int j = 0; j < Q; j++) r[j] = par[j];
+    r[TVD_DT] = dt;
+    for (int a = 0; a < D; a++) r[TVD_Y + a] = y[a];
+    if (hrow) for (int k = 0; k < D * D; k++) r[TVD_H + k] = hrow[k];
+}
+
+template <int MODEL, int D>
+struct TvDenseLane {
+    static constexpr int SD = DenseDims<MODEL, D>::SD;
+    static constexpr int NSTATE = 2 * (SD + SD * SD);
+    DenseLane<MODEL, D, 1> L;
+    bool has_h;
+    SSDE_HD void init(const double* a0, const double* p0 /* SD x SD column-major */) { L.init(a0, p0); }
+    SSDE_HD void warm_init(const double* y, const double* p0) {
+        double a0[SD];
+        for (int c = 0; c < SD; c++) a0[c] = 0.0;
+        for (int a = 0; a < D; a++) a0[DenseDims<MODEL, D>::z(a)] = (y[a] == y[a]) ? y[a] : 0.0;
+        L.init(a0, p0);
+    }
+    SSDE_HD void reset_acc() { L.nll = DualN<1>(0.0); }
+    SSDE_HD void dump(double* o) const {
+        int k = 0;
+        for (int i = 0; i < SD; i++) { o[k++] = L.a[i].v; o[k++] = L.a[i].d[0]; }
+        for (int i = 0; i < SD; i++)
+            for (int j = 0; j < SD; j++) { o[k++] = L.P[i][j].v; o[k++] = L.P[i][j].d[0]; }
+    }
+    SSDE_HD void state(double* o) const { for (int i = 0; i < SD; i++) o[i] = L.a[i].v; }
+    SSDE_HD double value() const { return L.nll.v; }
+    SSDE_HD double grad() const { return L.nll.d[0]; }
+};
+
+template <int MODEL, int D>
+struct TvDenseOps {
+    typedef TvDenseLane<MODEL, D> Lane;
+    static constexpr int U = 2;            // the 4 x 4 dual covariance needs the registers
+    static constexpr int Y_OFF = TVD_Y;
+    static constexpr bool DENSE = true;
+    template <bool GRAD>
+    SSDE_HD static void step(Lane& S, const double* r, double h, int kind, int dim, double w, int any_nan) {
+        constexpr int Q = DenseDims<MODEL, D>::Q;
+        DualN<1> par[Q];
+        for (int j = 0; j < Q; j++) {
+            par[j].v = r[j];
+            const bool mine = (j < D) ? (kind == TVK_MU && dim == j) : (j == D ? kind == TVK_P1 : kind == TVK_P2);
+            par[j].d[0] = (GRAD && mine) ? w : 0.0;
+        }
+        DualN<1> H[D][D];
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) {
+                if (S.has_h) H[i][j] = DualN<1>(r[TVD_H + i + j * D]);           // H_array[,,i], no parameter in it
+                else { H[i][j].v = (i == j) ? h : 0.0; H[i][j].d[0] = (GRAD && i == j && kind == TVK_SIG) ? 2.0 * h : 0.0; }
+            }
+        double y[D];
+        for (int a = 0; a < D; a++) y[a] = r[TVD_Y + a];
+        dense_step<MODEL, D, 1>(S.L, par, H, r[TVD_DT], y, is_na(y[0], any_nan));
     }
 };
 

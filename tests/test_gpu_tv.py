@@ -192,3 +192,67 @@ def test_device_resident_inputs():
     oval, ograd = _oracle(pbh, par)
     _close(vd, gd, oval, ograd)
     ed.close(); eh.close()
+
+
+# ---- full-covariance lanes: per-row H_array and / or a P0 that is not block-identical ---------------------------
+HP_GOLD = [r for r in GOLD if r["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and (r.get("H") is not None or r.get("P0") is not None)]
+
+
+@pytest.mark.parametrize("rec", HP_GOLD, ids=[r["name"] for r in HP_GOLD])
+def test_golden_H_and_P0_cases_take_the_tv_path(rec):
+    eng = capi.Engine(problem_from_spec(rec))
+    # (a one-dimensional model's P0 is trivially block-identical: the constant-coefficient register path takes it)
+    iso_ok = rec.get("H") is None and rec["n_dim"] == 1 and rec.get("X_fe") is None
+    assert eng.info()["path"] == (1 if iso_ok else PATH_TV)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    assert abs(eng.eval(rec["par"], order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    aest = eng.report(rec["par"])
+    assert np.allclose(aest, rec["expected"]["aest_all"], rtol=1e-10, atol=1e-10, equal_nan=True)
+    eng.close()
+
+
+def _random_H(n, d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, d, d)) * 0.15
+    return np.einsum("nij,nkj->ikn", A, A) + 0.02 * np.eye(d)[:, :, None]
+
+
+@pytest.mark.parametrize("model,d", [("CTCRW", 2), ("CTCRW", 1), ("OU_SSM", 2), ("BM_SSM", 1)])
+def test_H_array_long_tracks_use_verified_windows(model, d):
+    """3 tracks x 1500 rows, per-row error ellipses (H_array), tau (or sigma) smooth in a covariate, NA rows"""
+    ID, times, obs = simulate(model, 3, 1500, d, mu=0.0 if model != "OU_SSM" else 3.0, sigma_obs=0.15, seed=21)
+    n = len(ID)
+    rng = np.random.default_rng(4)
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    obs[(rng.random(n) < 0.03) & ~first] = np.nan
+    q = capi.n_sde_par(model, d)
+    X_re = [None] * q
+    X_re[d] = bspline_basis(_covariate(n, 6), 7)
+    pb = capi.Problem(model, ID, times, obs, X_re=X_re, S_list=[second_difference_penalty(7)], H=_random_H(n, d, 2))
+    par = 0.1 * np.cos(np.arange(pb.n_par_full))
+    if model == "OU_SSM":
+        par[pb.off_fe:pb.off_fe + d] = 3.0
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    info = eng.info()
+    assert info["path"] == PATH_TV and info["window"] > 0, info
+    assert info["window_check"] <= capi.WINDOW_TOL
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert grad[0] == 0.0                      # log_sigma_obs is mapped when H is supplied (R/sde.R:565, 595)
+    eng.close()
+
+
+def test_constant_coefficients_with_custom_P0():
+    """constant coefficients but a full P0: no streamed column at all, still the lane = direction kernel"""
+    ID, times, obs = simulate("CTCRW", 5, 400, 2, seed=12)
+    A = np.random.default_rng(1).standard_normal((4, 4))
+    pb = capi.Problem("CTCRW", ID, times, obs, P0=A @ A.T + np.eye(4))
+    par = np.array([-1.2, 0.1, -0.1, 0.4, 0.1])
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == PATH_TV
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    eng.close()
