@@ -187,6 +187,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 // a kernel's register allocation is the worst case over everything it contains.
 template <int MODEL, int D, int MASK>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoArgs A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoA
 // Direction-split launches (several parts with different masks) keep the masks in one kernel.
 template <int MODEL, int D>
 __global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
@@ -226,13 +228,14 @@ static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
 // window arrived with against the state the next window warmed up to, component by component.
 // Per component the error is max over the wave's lanes of |a - b| and the scale is the max over
 // the lanes of max(|a|, |b|); chk[] gets the largest error/scale ratio of the workgroup.
-__global__ __launch_bounds__(4 * WAVE) void window_check_kernel(const IsoArgs A, int nstate, double* chk) {
-    __shared__ double sh[4];
-    const int g = blockIdx.x, c = blockIdx.y, part = blockIdx.z;
+// (g, c, part): the boundary between windows c and c + 1.  Returns the workgroup's largest error / scale
+// ratio in thread 0.  Groups handled by the shared-covariance kernels dump the compact layout.
+__device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstate_full, int g, int c, int part, double* sh) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const TileView& tv = A.tv;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
+    const int nstate = (A.nstate_clean > 0 && (A.group_flags[g] & 1)) ? A.nstate_clean : nstate_full;
     int sb_, s_next, se_;
     window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_);   // s_next = first scored row of window c+1
     const bool valid = (ns > s_next) && (s_next < L);
@@ -253,8 +256,14 @@ __global__ __launch_bounds__(4 * WAVE) void window_check_kernel(const IsoArgs A,
     }
     if (lane == 0) sh[wv] = worst;
     __syncthreads();
-    if (threadIdx.x == 0)
-        chk[((int64_t)part * (A.n_chunks - 1) + c) * tv.n_groups + g] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(4 * WAVE) void window_check_kernel(const IsoArgs A, int nstate, double* chk) {
+    __shared__ double sh[4];
+    const int g = blockIdx.x, c = blockIdx.y, part = blockIdx.z;
+    const double w = window_check_block(A, nstate, g, c, part, sh);
+    if (threadIdx.x == 0) chk[((int64_t)part * (A.n_chunks - 1) + c) * A.tv.n_groups + g] = w;
 }
 
 int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2 * d : 4 * (d + 1) + d; }
@@ -286,6 +295,28 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return e;
+}
+
+// One launch for everything after the main kernel(s): workgroups [0, n_check) run one hand-over check each and
+// raise out[n_out] (a non-negative double orders like its bit pattern; the main kernel zeroed it), the others
+// produce one output slot each (reduce_slot, k_reduce.hip).
+__global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, const ReduceArgs R, int nstate, int n_check) {
+    __shared__ double sh[256];
+    if ((int)blockIdx.x < n_check) {
+        const int G = A.tv.n_groups, nb = A.n_chunks - 1;
+        const int g = blockIdx.x % G, c = (blockIdx.x / G) % nb, part = blockIdx.x / (G * nb);
+        const double w = window_check_block(A, nstate, g, c, part, sh);
+        if (threadIdx.x == 0 && w > 0.0)
+            atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
+        return;
+    }
+    reduce_slot(R, blockIdx.x - n_check, sh);
+}
+
+hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {
+    const int n_check = a.n_chunks > 1 ? a.tv.n_groups * (a.n_chunks - 1) * a.n_parts : 0;
+    hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, r, iso_nstate(model, d), n_check);
+    return hipGetLastError();
 }
 
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s) {

@@ -36,7 +36,7 @@ __device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const
 template <int D, int MASK>
 struct SharedCtcrw {
     static constexpr int SD = 2 * D;
-    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
+    static constexpr int NSTATE = shared_nstate(2 * D, MASK, true);
     CtcrwMean<D, MASK> M;          // state + table-phase accumulators
     double acc2, sacc[NDIRP], macc[D];  // stationary-phase sums: u'u, u' tx_j, u_a mx_a
     // stationary constants (wave-uniform)
@@ -120,20 +120,21 @@ struct SharedCtcrw {
         if (MASK & DIR_P1) out[2 + D] += hd[1] * acc2 - iF * sacc[1];
         if (MASK & DIR_P2) out[3 + D] += hd[2] * acc2 - iF * sacc[2];
     }
+    // compact hand-over layout of the shared-covariance kernels: state, wanted directions, mu
     __device__ __forceinline__ void dump(double* o) const {
         int k = 0;
 #pragma unroll
         for (int a = 0; a < D; a++) { o[k++] = M.x[a]; o[k++] = M.v[a]; }
-        o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0;
-            o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+            if (!(MASK & dir_bit(j))) continue;
 #pragma unroll
-            for (int a = 0; a < D; a++) { o[k++] = on ? M.tx[j][a] : 0.0; o[k++] = on ? M.tv[j][a] : 0.0; }
+            for (int a = 0; a < D; a++) { o[k++] = M.tx[j][a]; o[k++] = M.tv[j][a]; }
         }
+        if (MASK & DIR_MU) {
 #pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? M.mx[a] : 0.0; o[k++] = (MASK & DIR_MU) ? M.mv[a] : 0.0; }
+            for (int a = 0; a < D; a++) { o[k++] = M.mx[a]; o[k++] = M.mv[a]; }
+        }
     }
     __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
 #pragma unroll
@@ -145,8 +146,8 @@ struct SharedCtcrw {
 template <int MODEL, int D, int MASK>
 struct SharedScal {
     static constexpr int SD = D;
-    static constexpr int NSTATE = 4 * (D + 1) + D;
     static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    static constexpr int NSTATE = shared_nstate(D, MASK, HAS_P2);
     ScalMean<D, MASK> M;
     double acc2, sacc[NDIRP], macc[D];
     double k, c, t, b, iF, hd[NDIRP], dk[NDIRP], dt_, cmu[D], dbmu[D];
@@ -217,16 +218,16 @@ struct SharedScal {
         int kk = 0;
 #pragma unroll
         for (int a = 0; a < D; a++) o[kk++] = M.x[a];
-        o[kk++] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0;
-            o[kk++] = 0.0;
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
 #pragma unroll
-            for (int a = 0; a < D; a++) o[kk++] = on ? M.tx[j][a] : 0.0;
+            for (int a = 0; a < D; a++) o[kk++] = M.tx[j][a];
         }
+        if (MASK & DIR_MU) {
 #pragma unroll
-        for (int a = 0; a < D; a++) o[kk++] = (MASK & DIR_MU) ? M.mx[a] : 0.0;
+            for (int a = 0; a < D; a++) o[kk++] = M.mx[a];
+        }
     }
     __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
 #pragma unroll
@@ -254,7 +255,7 @@ struct SharedScal {
 template <int D, int MASK>
 struct TfCtcrw {
     static constexpr int SD = 2 * D;
-    static constexpr int NSTATE = 4 * (2 * D + 3) + 2 * D;
+    static constexpr int NSTATE = shared_nstate(2 * D, MASK, true);
     static constexpr bool ANYP = (MASK & (DIR_SIG | DIR_P1 | DIR_P2)) != 0;
     double yp[D], w1[D], w2[D], r1[D], r2[D], r3[D], su[D];
     double acc2, C1, C2, C3;
@@ -325,20 +326,19 @@ struct TfCtcrw {
             o[k++] = yp[a] + cm[a] - c1 * w1[a] + d2 * w2[a];
             o[k++] = k2 * w1[a] + c[23 + a];
         }
-        o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0;
-            o[k++] = 0.0; o[k++] = 0.0; o[k++] = 0.0;
+            if (!(MASK & dir_bit(j))) continue;
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double tx = -(c[31 + j] * r1[a] + c[34 + j] * r2[a] + c[37 + j] * r3[a]);
-                const double tv = c[16 + j] * w1[a] - k2 * (c[40 + j] * r2[a] + c[43 + j] * r3[a]);
-                o[k++] = on ? tx : 0.0; o[k++] = on ? tv : 0.0;
+                o[k++] = -(c[31 + j] * r1[a] + c[34 + j] * r2[a] + c[37 + j] * r3[a]);
+                o[k++] = c[16 + j] * w1[a] - k2 * (c[40 + j] * r2[a] + c[43 + j] * r3[a]);
             }
         }
+        if (MASK & DIR_MU) {
 #pragma unroll
-        for (int a = 0; a < D; a++) { o[k++] = (MASK & DIR_MU) ? c[46] : 0.0; o[k++] = (MASK & DIR_MU) ? c[47] : 0.0; }
+            for (int a = 0; a < D; a++) { o[k++] = c[46]; o[k++] = c[47]; }
+        }
     }
     __device__ static __forceinline__ void warm_a0(const double*, double*) {}
 };
@@ -347,8 +347,8 @@ struct TfCtcrw {
 template <int MODEL, int D, int MASK>
 struct BasisScal {
     static constexpr int SD = D;
-    static constexpr int NSTATE = 4 * (D + 1) + D;
     static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    static constexpr int NSTATE = shared_nstate(D, MASK, HAS_P2);
     static constexpr bool ANYP = (MASK & (DIR_SIG | DIR_P1 | (HAS_P2 ? DIR_P2 : 0))) != 0;
     static constexpr bool P1 = (MASK & DIR_P1) != 0;
     double x[D], A1[D], A3[D], mx[D];
@@ -416,16 +416,16 @@ struct BasisScal {
         int kk = 0;
 #pragma unroll
         for (int a = 0; a < D; a++) o[kk++] = x[a];
-        o[kk++] = 0.0;
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
-            const bool on = (MASK & dir_bit(j)) != 0 && (j < 2 || HAS_P2);
-            o[kk++] = 0.0;
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
 #pragma unroll
-            for (int a = 0; a < D; a++) o[kk++] = on ? dk[j] * A1[a] + (j == 1 ? A3[a] : 0.0) : 0.0;
+            for (int a = 0; a < D; a++) o[kk++] = dk[j] * A1[a] + (j == 1 ? A3[a] : 0.0);
         }
+        if (MASK & DIR_MU) {
 #pragma unroll
-        for (int a = 0; a < D; a++) o[kk++] = (MASK & DIR_MU) ? mx[a] : 0.0;
+            for (int a = 0; a < D; a++) o[kk++] = mx[a];
+        }
     }
     __device__ static __forceinline__ void warm_a0(const double* y, double* a0) {
 #pragma unroll
@@ -585,6 +585,7 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
 // basis-form code.  Without it (short tracks, a single window) every wave runs the general shared code.
 template <int MODEL, int D, int MASK>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_shared_kernel(const IsoArgs A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
     if (A.t0 > 0) {
         if (!decode_block(A, A.n_chunks - 1, g, part, chunk)) return;

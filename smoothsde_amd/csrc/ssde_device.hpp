@@ -88,10 +88,23 @@ struct IsoArgs {
     double tau, beta, sigma;     // CTCRW (nllk_ctcrw.hpp:152-156); OU: tau, kappa(in sigma); BM: sigma
     CtcrwTrans ctr;
     ScalTrans str;
+    // hand-over dumps of the shared-covariance kernels are compact (state + the sensitivities of the wanted
+    // directions only, no covariance part): components per lane, 0 = no group uses that layout
+    int nstate_clean;
+    double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
 };
+// components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance
+// direction, one block for mu
+__host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool has_p2) {
+    return (1 + ((mask & DIR_SIG) ? 1 : 0) + ((mask & DIR_P1) ? 1 : 0) + (((mask & DIR_P2) && has_p2) ? 1 : 0) +
+            ((mask & DIR_MU) ? 1 : 0)) * sd;
+}
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s);
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
+struct ReduceArgs;
+// the hand-over checks and the final sums of an isotropic evaluation in ONE launch (the checks raise out[n_out])
+hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s);
 void fill_stat_consts(int model, int d, IsoArgs& a);
 int iso_nstate(int model, int d);
 
@@ -341,6 +354,50 @@ __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
+}
+
+// one output slot by one 256-thread workgroup: 0 = nllk, 1.. = gradient entries, n_out = hand-over check
+__device__ __forceinline__ void reduce_slot(const ReduceArgs& A, int slot, double* sh) {
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    if (slot == A.n_out) {
+        for (int b = tid; b < A.n_chk; b += 256) acc = fmax(acc, A.chk[b] == A.chk[b] ? A.chk[b] : INFINITY);
+        sh[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) sh[tid] = fmax(sh[tid], sh[tid + o]);
+            __syncthreads();
+        }
+        if (tid == 0) A.out[slot] = sh[0];
+        return;
+    }
+    if (slot == 0) {
+        for (int part = 0; part < A.n_value_parts; part++) {
+            const double* p = A.partials + ((int64_t)part * A.nacc) * A.n_blocks;  // accumulator 0
+            for (int b = tid; b < A.n_blocks; b += 256) acc += p[b];
+        }
+    } else {
+        const int nk = A.nacc - 1;
+        for (int part = 0; part < A.n_parts; part++) {
+            for (int k = 1; k < A.nacc; k++) {
+                if (A.map[(part / A.chunks_per_part) * nk + (k - 1)] != slot) continue;
+                const double* p = A.partials + ((int64_t)part * A.nacc + k) * A.n_blocks;
+                for (int b = tid; b < A.n_blocks; b += 256) acc += p[b];
+            }
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double r = sh[0];
+        for (int i = 0; i < 4; i++)
+            if (A.add_slot[i] == slot) r += A.add[i];
+        A.out[slot] = r;
+    }
 }
 #endif
 

@@ -1112,6 +1112,8 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         }
         plan_windows(h, a, &a.n_chunks, &a.window);
         a.bnd = h->bnd.p; a.chk = h->chk.p;
+        a.chk_out = out_dev + (1 + L.n_full);
+        a.nstate_clean = h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
         a.group_flags = h->group_flags.p;
         a.group_mode = 0;
@@ -1157,7 +1159,6 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             h->ev_k_valid = true;
             h->last_s_stat = -1;
         }
-        HIPCHK(h, launch_window_check(h->model, h->d, a, s));
         for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
         if (h->use_shared) {
             ra.add_slot[0] = 0;
@@ -1178,6 +1179,9 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                     if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
                 }
         }
+        // the hand-over checks and the final sums in one launch
+        HIPCHK(h, launch_iso_finalize(h->model, h->d, a, ra, s));
+        return SSDE_OK;
     } else if (h->path == PATH_DENSE) {
         const double* pdev = nullptr;
         int st = push_par(h, par, s, &pdev);
