@@ -16,8 +16,8 @@
 //                      weights are prefetched a 4-row block ahead in ping-pong registers.
 //                      Time windows with a verified hand-over (as in k_iso.hip) cut the serial
 //                      chain of a long track into concurrent pieces.
-//   tv_check_kernel    largest relative disagreement at every window hand-over.
-//   tv_reduce_kernel   fixed-order sums -> [nllk, gradient..., hand-over check].
+//   tv_finalize_kernel largest relative disagreement at every window hand-over + fixed-order sums
+//                      -> [nllk, gradient..., hand-over check], one launch.
 #include <algorithm>
 
 #include "ssde_device.hpp"
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     constexpr int NS = TV_STATS / 2;
     __shared__ double sh[TV_STATS][4];
     const SlotTable* __restrict__ T = A.slots;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.out) A.out[A.n_out] = 0.0;   // raised by the finalize launch's checks
     double smin[NS], smax[NS];
 #pragma unroll
     for (int k = 0; k < NS; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
@@ -247,9 +248,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
     A.gdir[(int64_t)item * WAVE + lane] = (empty || !has || !GRAD) ? 0.0 : S.grad();
 }
 
-// ---- hand-over check: item (pack, c, b) arrived vs item + 1 = (pack, c + 1, b) warmed up ----------
-__global__ __launch_bounds__(WAVE) void tv_check_kernel(const TvArgs A, int nstate) {
-    const int item = blockIdx.x, lane = threadIdx.x;
+// ---- finalize: hand-over checks + fixed-order sums in one launch -------------------------------------------------
+// check: item (pack, c, b) arrived vs item + 1 = (pack, c + 1, b) warmed up; one wave per item
+__device__ __forceinline__ double tv_check_item(const TvArgs& A, int item, int lane, int nstate) {
     const TvItem it = A.items[item];
     double worst = 0.0;
     if (it.c + 1 < it.nc) {
@@ -274,26 +275,25 @@ __global__ __launch_bounds__(WAVE) void tv_check_kernel(const TvArgs A, int nsta
             if (err > 0.0) worst = fmax(worst, err / sc);
         }
     }
-    if (lane == 0) A.chk[item] = worst;
+    return worst;
 }
 
-// ---- final sums: slot 0 = nllk, 1.. = gradient entries, n_out = hand-over check --------------------
-__global__ __launch_bounds__(256) void tv_reduce_kernel(const TvArgs A) {
+// workgroups [0, n_check): four items' checks each (one per wave), raising out[n_out] (zeroed by the pre-pass; a
+// non-negative double orders like its bit pattern); the others: one output slot each (0 = nllk, 1.. = gradient)
+__global__ __launch_bounds__(256) void tv_finalize_kernel(const TvArgs A, int nstate, int n_check) {
     __shared__ double sh[256];
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    const int lpt = 1 << A.lpt_shift, tpw = WAVE >> A.lpt_shift;
-    double acc = 0.0;
-    if (slot == A.n_out) {
-        for (int i = tid; i < A.n_items; i += 256) acc = fmax(acc, A.chk[i] == A.chk[i] ? A.chk[i] : INFINITY);
-        sh[tid] = acc;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) sh[tid] = fmax(sh[tid], sh[tid + o]);
-            __syncthreads();
-        }
-        if (tid == 0) A.out[slot] = sh[0];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < n_check) {
+        const int item = blockIdx.x * 4 + (tid >> 6);
+        if (item >= A.n_items) return;
+        const double w = tv_check_item(A, item, tid & 63, nstate);
+        if ((tid & 63) == 0 && w > 0.0)
+            atomicMax((unsigned long long*)(A.out + A.n_out), (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
         return;
     }
+    const int slot = blockIdx.x - n_check;
+    const int lpt = 1 << A.lpt_shift, tpw = WAVE >> A.lpt_shift;
+    double acc = 0.0;
     int b = 0, ds = 0;
     const double* src = A.gval;
     bool any = true;
@@ -369,16 +369,11 @@ hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_tv_check(const TvArgs& a, hipStream_t s) {
-    if (a.n_items == 0) return hipSuccess;
+hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s) {
     const int sd = a.model == M_CTCRW ? 2 * a.d : a.d;
     const int nstate = a.dense ? 2 * (sd + sd * sd) : (a.model == M_CTCRW ? 4 * a.d + 6 : 2 * a.d + 2);
-    hipLaunchKernelGGL(tv_check_kernel, dim3(a.n_items), dim3(WAVE), 0, s, a, nstate);
-    return hipGetLastError();
-}
-
-hipError_t launch_tv_reduce(const TvArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(tv_reduce_kernel, dim3(a.n_out + 1), dim3(256), 0, s, a);
+    const int n_check = (a.n_items + 3) / 4;
+    hipLaunchKernelGGL(tv_finalize_kernel, dim3(n_check + a.n_out), dim3(256), 0, s, a, nstate, n_check);
     return hipGetLastError();
 }
 

@@ -282,7 +282,6 @@ struct TvArgs {
     const double* h_array;       // [d x d x n] or NULL
     double p0f[16];              // sdim x sdim column-major (dense lanes)
     double* bnd;                 // [n_items][2][TV_NSTATE][64]
-    double* chk;                 // [n_items]
     double* gval;                // [n_items][64] per-lane nllk
     double* gdir;                // [n_items][64] per-lane d nllk / d direction
     double* stats;               // [stats_blocks][TV_STATS]
@@ -297,8 +296,7 @@ hipError_t launch_tv_a0(const TvArgs& a, const double* a0_src, const int64_t* tr
                         double* a0_dst, hipStream_t s);
 hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s);
 hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s);
-hipError_t launch_tv_check(const TvArgs& a, hipStream_t s);
-hipError_t launch_tv_reduce(const TvArgs& a, hipStream_t s);
+hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------------
 // Window geometry shared by the kernels, the hand-over check and the engine.

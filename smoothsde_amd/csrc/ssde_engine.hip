@@ -267,7 +267,7 @@ void tv_base_args(const ssde_handle* h, TvArgs& a) {
     for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
     a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
     for (int i = 0; i < 16; i++) a.p0f[i] = h->p0_full[i];
-    a.bnd = h->tv_bnd.p; a.chk = h->tv_chk.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
+    a.bnd = h->tv_bnd.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
     a.stats = h->tv_stats.p; a.stats_blocks = h->tv_stats_blocks;
     a.n_out = 1 + h->L.n_full;
     for (int k = 0; k < MAX_PAR; k++) a.dir_of_par[k] = h->tv_dir_of_par[k];
@@ -495,6 +495,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     TvArgs a;
     tv_base_args(h, a);
     a.par = pdev;
+    a.out = out_dev;                                     // the pre-pass zeroes the hand-over check slot
     const double sig = exp(par[0]);                      // nllk_ctcrw.hpp:136 (unused when H_array is supplied)
     a.h = sig * sig;
     const size_t stats_bytes = (size_t)h->tv_stats_blocks * TV_STATS * 8;
@@ -512,7 +513,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     st = tv_plan(h, a.h, s);
     if (st) return st;
     tv_base_args(h, a);                                  // the plan may have re-allocated the item buffers
-    a.par = pdev; a.h = sig * sig;
+    a.par = pdev; a.h = sig * sig; a.out = out_dev;
     a.window = h->tv_window;
     if (!prepared) {
         HIPCHK(h, launch_tv_prepare(a, s));
@@ -527,8 +528,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     HIPCHK(h, launch_tv_filter(a, grad, s));
     HIPCHK(h, hipEventRecord(h->ev_k1, s));
     h->ev_k_valid = true; h->last_s_stat = -1;
-    HIPCHK(h, launch_tv_check(a, s));
-    HIPCHK(h, launch_tv_reduce(a, s));
+    HIPCHK(h, launch_tv_finalize(a, s));
     h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
     return SSDE_OK;
 }
