@@ -460,7 +460,12 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
     for (int64_t p = 0; p < n_packs; p++) {
         const int L = h->tv_ns_host[(size_t)p * tpw];
         int nc = 1;
-        if (W > 0) nc = std::max(1, std::min(nc_cap, L / std::max(2 * W, 32)));
+        // As many windows as the chip has room for (nc_cap): with idle SIMDs around, a window may be much
+        // shorter than its warm-up -- the redundant warm-up rows run in parallel, the serial chain of a wave
+        // is what the evaluation waits for.  SSDE_TV_MINLEN: shortest scored stretch of a window (rows).
+        int minlen = 2 * WIN_ALIGN;
+        if (const char* e = getenv("SSDE_TV_MINLEN")) minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
+        if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + minlen - 1) / minlen));
         max_nc = std::max(max_nc, nc);
         for (int b = 0; b < h->tv_nb; b++)
             for (int c = 0; c < nc; c++) {
