@@ -276,6 +276,7 @@ struct TvArgs {
     int n_items;
     int window;                  // warm-up rows of a time window
     double h;                    // sigma_obs^2
+    int h_from_par;              // 1: the kernels take sigma_obs^2 = exp(2 par[0]) themselves (hipGraph replay)
     double p0[3];
     int dense;                   // 1: full-covariance lanes (per-row H_array and / or a P0 that is not block-identical)
     int has_h;

@@ -157,6 +157,15 @@ struct ssde_handle {
     bool tv_stats_valid = false;
     int tv_stats_blocks = 0;
     int16_t tv_dir_of_par[MAX_PAR];
+    // hipGraph replay of a synchronous tv evaluation (ssde_eval): upload, pre-pass, statistics read-back, filter,
+    // finalize and result read-back are captured once per plan and replayed with ONE launch call
+    hipStream_t tv_stream = nullptr;
+    hipGraphExec_t tv_gexec[2] = {nullptr, nullptr};    // [order]
+    int tv_graph_plan[2] = {-1, -1};                    // plan generation the executable was captured for
+    int tv_plan_gen = 0;
+    DevBuf<double> tv_par_dev;
+    double* tv_par_pinned = nullptr;
+    double* tv_out_pinned = nullptr;
 
     int64_t hbm_bytes = 0;
 };
@@ -189,6 +198,11 @@ void destroy(ssde_handle* h) {
     h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
     h->tv_gval.release(); h->tv_gdir.release(); h->tv_stats.release(); h->tv_dirs.release(); h->tv_row0.release();
     h->tv_ns.release(); h->tv_items_g.release(); h->tv_items_v.release();
+    for (int i = 0; i < 2; i++) if (h->tv_gexec[i]) (void)hipGraphExecDestroy(h->tv_gexec[i]);
+    if (h->tv_stream) (void)hipStreamDestroy(h->tv_stream);
+    h->tv_par_dev.release();
+    if (h->tv_par_pinned) (void)hipHostFree(h->tv_par_pinned);
+    if (h->tv_out_pinned) (void)hipHostFree(h->tv_out_pinned);
     if (h->tv_stats_pinned) (void)hipHostFree(h->tv_stats_pinned);
     if (h->tv_stats_ev) (void)hipEventDestroy(h->tv_stats_ev);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
@@ -355,6 +369,10 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     HIPCHK(h, h->tv_stats.alloc((size_t)h->tv_stats_blocks * TV_STATS));
     HIPCHK(h, hipHostMalloc((void**)&h->tv_stats_pinned, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipHostMallocDefault));
     HIPCHK(h, hipEventCreateWithFlags(&h->tv_stats_ev, hipEventDisableTiming));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->tv_stream, hipStreamNonBlocking));
+    HIPCHK(h, h->tv_par_dev.alloc(MAX_PAR));
+    HIPCHK(h, hipHostMalloc((void**)&h->tv_par_pinned, MAX_PAR * 8, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&h->tv_out_pinned, (MAX_PAR + 2) * 8, hipHostMallocDefault));
     TvArgs a;
     tv_base_args(h, a);
     HIPCHK(h, launch_tv_weights(a, 0));
@@ -490,6 +508,7 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
     HIPCHK(h, hipMemcpy(h->tv_items_v.p, iv.data(), iv.size() * sizeof(TvItem), hipMemcpyHostToDevice));
     h->tv_n_items_g = (int)ig.size(); h->tv_n_items_v = (int)iv.size();
     h->tv_window = W; h->tv_max_nc = max_nc;
+    h->tv_plan_gen++;                                    // captured graphs of the old plan are stale
     return SSDE_OK;
 }
 
@@ -519,6 +538,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     if (st) return st;
     tv_base_args(h, a);                                  // the plan may have re-allocated the item buffers
     a.par = pdev; a.h = sig * sig; a.out = out_dev;
+    a.h_from_par = 1;                                    // same arithmetic as the graph replay: bitwise-equal results
     a.window = h->tv_window;
     if (!prepared) {
         HIPCHK(h, launch_tv_prepare(a, s));
@@ -534,6 +554,51 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     HIPCHK(h, hipEventRecord(h->ev_k1, s));
     h->ev_k_valid = true; h->last_s_stat = -1;
     HIPCHK(h, launch_tv_finalize(a, s));
+    h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
+    return SSDE_OK;
+}
+
+// Synchronous tv evaluation replayed from a hipGraph: the evaluation is launch-bound (C1: 40 us of kernels,
+// seven stream operations), so the whole sequence is captured once per plan and direction order.  Needs the
+// parameter ranges of an earlier evaluation (the planner's input), so the first evaluation takes eval_tv.
+int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) {
+    const int n_full = h->L.n_full;
+    const int ord = order >= 1 ? 1 : 0;
+    const double sig = exp(par[0]);
+    int st = tv_plan(h, sig * sig, h->tv_stream);        // from the statistics of the previous evaluation
+    if (st) return st;
+    if (!h->tv_gexec[ord] || h->tv_graph_plan[ord] != h->tv_plan_gen) {
+        if (h->tv_gexec[ord]) { (void)hipGraphExecDestroy(h->tv_gexec[ord]); h->tv_gexec[ord] = nullptr; }
+        TvArgs a;
+        tv_base_args(h, a);
+        a.par = h->tv_par_dev.p; a.h_from_par = 1; a.h = 0.0; a.out = h->out.p; a.window = h->tv_window;
+        a.items = ord ? h->tv_items_g.p : h->tv_items_v.p;
+        a.n_items = ord ? h->tv_n_items_g : h->tv_n_items_v;
+        hipStream_t s = h->tv_stream;
+        hipGraph_t g = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(h->tv_par_dev.p, h->tv_par_pinned, (size_t)n_full * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = launch_tv_prepare(a, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = launch_tv_filter(a, ord == 1, s);
+        if (e == hipSuccess) e = launch_tv_finalize(a, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_out_pinned, h->out.p, (size_t)(2 + n_full) * 8, hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipStreamEndCapture(s, &g);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            h->err = std::string("hipGraph capture of the tv evaluation failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+            return SSDE_ERR_HIP;
+        }
+        e = hipGraphInstantiate(&h->tv_gexec[ord], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { h->tv_gexec[ord] = nullptr; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return SSDE_ERR_HIP; }
+        h->tv_graph_plan[ord] = h->tv_plan_gen;
+    }
+    memcpy(h->tv_par_pinned, par, (size_t)n_full * 8);
+    HIPCHK(h, hipGraphLaunch(h->tv_gexec[ord], h->tv_stream));
+    HIPCHK(h, hipStreamSynchronize(h->tv_stream));
+    memcpy(o_host, h->tv_out_pinned, (size_t)(2 + n_full) * 8);
+    h->ev_k_valid = false;                               // no per-kernel timing inside a replayed graph
     h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
     return SSDE_OK;
 }
@@ -1318,10 +1383,17 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
     if (!h || !par || !value) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     std::vector<double> o(2 + h->L.n_full);
+    const bool use_graph = h->path == PATH_TV && !getenv("SSDE_NO_GRAPH");
     for (int attempt = 0;; attempt++) {
-        int st = eval_device(h, par, order, h->out.p, 0);
-        if (st) return st;
-        HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
+        if (use_graph && h->tv_stats_valid) {
+            HIPCHK(h, hipSetDevice(h->device));
+            int st = eval_tv_graph(h, par, order, o.data());
+            if (st) return st;
+        } else {
+            int st = eval_device(h, par, order, h->out.p, 0);
+            if (st) return st;
+            HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
+        }
         h->last_check = o[1 + h->L.n_full];
         // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
         // until the windows agree with each other; 64x the estimate ends in one sequential window
