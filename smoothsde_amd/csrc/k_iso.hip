@@ -89,7 +89,36 @@ struct LaneOps {  // OU_SSM / BM_SSM
 };
 
 
-template <int MODEL, int D, int MASK>
+// DER >= 0: the covariance direction DER (1 = par[d] for BM_SSM, 2 = par[d+1] for CTCRW / OU_SSM) is NOT carried
+// through the recursion but derived from the log sigma_obs direction.  The filter is homogeneous in the variances:
+// scaling (sigma_obs^2, process variance, P0) by c scales P and F by c and leaves the mean and the gains alone, so
+//   CTCRW / BM_SSM (variance ~ nu^2, sigma^2):  dP_der = 2 P - dP_sig,  dx_der = -dx_sig,  g_der = D N - Q - g_sig
+//   OU_SSM (variance ~ kappa):                  dP_der = P - dP_sig/2,  dx_der = -dx_sig/2, g_der = (D N - Q - g_sig)/2
+// (N = scored rows, Q = sum u'F^-1 u) up to the sensitivity to P0, which the filter forgets like everything else
+// about its start: windows c >= 1 use the identity (a third less sensitivity arithmetic), window 0 carries every
+// direction, and the hand-over check compares the derived components with window c - 1's at every boundary.
+template <int MODEL, int DER>
+struct DeriveOps {
+    static constexpr double CP = (MODEL == M_OU_SSM) ? 1.0 : 2.0, CB = (MODEL == M_OU_SSM) ? 0.5 : 1.0;
+    // fill block DER of a direction-form dump (layout of CtcrwLane / ScalLane ::dump) from block 0 (sigma_obs)
+    template <int D>
+    __device__ static __forceinline__ void fill(double* st) {
+        if (MODEL == M_CTCRW) {
+            constexpr int B0 = 2 * D + 3, BS = 3 + 2 * D;
+#pragma unroll
+            for (int q = 0; q < 3; q++) st[B0 + DER * BS + q] = CP * st[2 * D + q] - CB * st[B0 + q];
+#pragma unroll
+            for (int q = 3; q < BS; q++) st[B0 + DER * BS + q] = -CB * st[B0 + q];
+        } else {
+            constexpr int B0 = D + 1, BS = 1 + D;
+            st[B0 + DER * BS] = CP * st[D] - CB * st[B0];
+#pragma unroll
+            for (int q = 1; q < BS; q++) st[B0 + DER * BS + q] = -CB * st[B0 + q];
+        }
+    }
+};
+
+template <int MODEL, int D, int MASK, int DER = -1>
 __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
     typedef LaneOps<MODEL, D, MASK> Ops;
     constexpr int C = 1 + D;
@@ -145,6 +174,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
             // end of warm-up: publish the state for the hand-over check, start scoring from zero
             double st[Ops::State::NSTATE];
             S.dump(st);
+            if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
             double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
 #pragma unroll
             for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
@@ -166,12 +196,17 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         // state on arrival at the next window's first scored row
         double st[Ops::State::NSTATE];
         S.dump(st);
+        if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
         double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
 #pragma unroll
         for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
     }
     double out[NACC];
     Ops::finish(S, out);
+    if (DER >= 0) {   // gradient of the derived direction: slots [value, sig, mu.., par[d], par[d+1]]
+        constexpr double CB = DeriveOps<MODEL, DER>::CB;
+        out[1 + D + DER] = CB * ((double)D * S.C.nupd - S.M.accq - out[1]);
+    }
     if (s_acc >= s_end) {
 #pragma unroll
         for (int k = 0; k < NACC; k++) out[k] = 0.0;  // empty window
@@ -191,7 +226,10 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoA
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     if (!group_selected(A, g)) return;
-    run_lane<MODEL, D, MASK>(A, g, part, chunk);
+    constexpr int DERJ = (MODEL == M_BM_SSM) ? 1 : 2;
+    constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
+    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), DERJ>(A, g, part, chunk);
+    else run_lane<MODEL, D, MASK>(A, g, part, chunk);
 }
 
 // Direction-split launches (several parts with different masks) keep the masks in one kernel.

@@ -91,6 +91,7 @@ struct IsoArgs {
     // hand-over dumps of the shared-covariance kernels are compact (state + the sensitivities of the wanted
     // directions only, no covariance part): components per lane, 0 = no group uses that layout
     int nstate_clean;
+    int derive;                  // windows >= 1 of the general kernel derive one variance direction from log sigma_obs (k_iso.hip)
     double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
 };
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance

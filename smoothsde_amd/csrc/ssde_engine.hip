@@ -1183,6 +1183,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         plan_windows(h, a, &a.n_chunks, &a.window);
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         a.chk_out = out_dev + (1 + L.n_full);
+        a.derive = getenv("SSDE_NO_DERIVE") ? 0 : 1;
         a.nstate_clean = h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
         a.group_flags = h->group_flags.p;

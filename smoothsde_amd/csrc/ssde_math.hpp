@@ -135,12 +135,13 @@ struct CtcrwCov {
     double d11[NDIRP], d12[NDIRP], d22[NDIRP];
     LogAcc ld;          // sum log|F|
     double gld[NDIRP];  // sum dF/F per direction
+    double nupd;        // rows that entered the likelihood
     SSDE_HD void init(double p0_11, double p0_12, double p0_22) {
         p11 = p0_11; p12 = p0_12; p22 = p0_22;
         for (int j = 0; j < NDIRP; j++) d11[j] = d12[j] = d22[j] = gld[j] = 0.0;
-        ld.init();
+        ld.init(); nupd = 0.0;
     }
-    SSDE_HD void reset_acc() { ld.init(); for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
+    SSDE_HD void reset_acc() { ld.init(); nupd = 0.0; for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
 };
 
 SSDE_HD constexpr int dir_bit(int j) { return j == 0 ? DIR_SIG : (j == 1 ? DIR_P1 : DIR_P2); }
@@ -153,6 +154,7 @@ SSDE_HD void ctcrw_cov_step(CtcrwCov<MASK>& C, const CtcrwTrans& tr, double h, b
     const bool upd = !na && (detF > 0.0);                      // lines 214, 226
     const double iF = upd ? rcp(F) : 0.0;
     C.ld.mul(upd ? F : 1.0);                                   // log(detF) = D log|F| (line 234)
+    C.nupd += upd ? 1.0 : 0.0;
     const double tp11 = C.p11 + tr.t12 * C.p12, tp12 = C.p12 + tr.t12 * C.p22;  // T P
     const double tp21 = tr.e * C.p12, tp22 = tr.e * C.p22;
     const double k1 = tp11 * iF, k2 = tp21 * iF;               // K = T P Z' F^-1 (line 236)
@@ -349,8 +351,9 @@ struct ScalCov {
     double p, dp[NDIRP];
     LogAcc ld;
     double gld[NDIRP];
-    SSDE_HD void init(double p0) { p = p0; for (int j = 0; j < NDIRP; j++) dp[j] = gld[j] = 0.0; ld.init(); }
-    SSDE_HD void reset_acc() { ld.init(); for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
+    double nupd;        // rows that entered the likelihood
+    SSDE_HD void init(double p0) { p = p0; for (int j = 0; j < NDIRP; j++) dp[j] = gld[j] = 0.0; ld.init(); nupd = 0.0; }
+    SSDE_HD void reset_acc() { ld.init(); nupd = 0.0; for (int j = 0; j < NDIRP; j++) gld[j] = 0.0; }
 };
 
 // Both families take detF = exp(logdet F) > 0 unless F == 0 (nllk_ou_ssm.hpp:190-195,
@@ -361,6 +364,7 @@ SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool
     const bool upd = !na && (fabs(F) > 0.0);
     const double iF = upd ? rcp(F) : 0.0;
     C.ld.mul(upd ? F : 1.0);
+    C.nupd += upd ? 1.0 : 0.0;
     const double tp = tr.t * C.p;
     const double k = tp * iF;
     G.iF = iF; G.k = k;
