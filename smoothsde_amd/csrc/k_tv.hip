@@ -68,14 +68,42 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     double smin[NS], smax[NS];
 #pragma unroll
     for (int k = 0; k < NS; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
+    // slot table and coefficients once per workgroup into LDS (the row loop then reads them as broadcasts instead
+    // of chasing two dependent scalar loads per slot and row); intercept slots are folded into per-parameter constants
+    __shared__ double s_coef[MAX_COLS];
+    __shared__ int s_col[MAX_COLS], s_pj[MAX_COLS];
+    __shared__ double s_base[MAX_Q];
+    __shared__ int s_ns;
+    __shared__ double t_coef[MAX_COLS];
+    __shared__ int t_col[MAX_COLS], t_pj[MAX_COLS];
+    if ((int)threadIdx.x < A.n_slots) {                               // all slots' loads in flight together
+        const int k = threadIdx.x;
+        t_col[k] = T->col[k]; t_pj[k] = T->par_j[k]; t_coef[k] = A.par[T->pidx[k]];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = 0;
+        double base[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < A.n_slots; k++) {
+            if (t_col[k] < 0) {
+#pragma unroll
+                for (int j = 0; j < MAX_Q; j++) base[j] += (t_pj[k] == j) ? t_coef[k] : 0.0;
+                continue;
+            }
+            s_col[m] = t_col[k]; s_pj[m] = t_pj[k]; s_coef[m] = t_coef[k]; m++;
+        }
+        s_ns = m;
+        for (int j = 0; j < MAX_Q; j++) s_base[j] = base[j];
+    }
+    __syncthreads();
+    const int nsl = s_ns;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
         double par[Q];
 #pragma unroll
-        for (int j = 0; j < Q; j++) par[j] = 0.0;
-        for (int k = 0; k < A.n_slots; k++) {                         // par_vec = X_fe coeff_fe + X_re coeff_re
-            const int col = T->col[k], j = T->par_j[k];
-            const double w = (col >= 0) ? A.colbuf[(int64_t)col * A.col_stride + i] : 1.0;
-            const double t = w * A.par[T->pidx[k]];
+        for (int j = 0; j < Q; j++) par[j] = s_base[j];
+        for (int k = 0; k < nsl; k++) {                               // par_vec = X_fe coeff_fe + X_re coeff_re
+            const int j = s_pj[k];
+            const double t = A.colbuf[(int64_t)s_col[k] * A.col_stride + i] * s_coef[k];
 #pragma unroll
             for (int jj = 0; jj < Q; jj++) par[jj] += (j == jj) ? t : 0.0;
         }
