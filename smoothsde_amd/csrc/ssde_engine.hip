@@ -109,6 +109,8 @@ struct ssde_handle {
     int want_chunks = 1;           // planned number of equal windows (the transient window comes on top)
     int glen_max = 0;              // steps of the longest track group
     double dt_min = 0.0;           // smallest interval used inside a track
+    bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
+    int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
     int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
     int last_chunks = 1, last_window = 0;
     double last_check = 0.0;
@@ -900,7 +902,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             // one wave per SIMD (1024 work items INCLUDING the padding of the group count to a multiple of 8):
             // a lone wave already issues fp64 at the SIMD's rate, and fewer windows mean fewer warm-up rows
             int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
-            if (const char* e = getenv("SSDE_CHUNKS")) want = atoi(e);
+            if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
             h->want_chunks = std::max(1, std::min(want, h->max_chunks));
             if (h->use_shared) {
@@ -968,6 +970,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
 void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) {
     *n_chunks = 1;
     *window = 0;
+    h->plan_warmup = 0;
     if (h->max_chunks <= 1) return;
     const double dt = h->uniform_dt ? h->dt_uniform : h->dt_min;
     double rho = 1.0;
@@ -1025,6 +1028,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
     *n_chunks = nc;
     *window = nc > 1 ? W : 0;
+    h->plan_warmup = W;                                  // usable warm-up length even when one window is planned
 }
 
 // Shared-covariance path: run the covariance half of the filter (ssde_math.hpp) ONCE on the host
@@ -1196,6 +1200,16 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             a.group_mode = 3;
             // the covariance transient gets its own short window [0, t0): every other window (warm-up
             // included) then lies in the stationary regime and runs the lean kernel
+            // A batch with more track groups than SIMDs needs no time windows to fill the chip, but the lean
+            // stationary kernel only exists for windows past the covariance transient: split every track into
+            // the transient window and ONE stationary window (same wave, so no extra work items)
+            if (a.n_chunks == 1 && h->plan_warmup > 0 && h->max_chunks >= 2 && !h->chunks_forced) {
+                a.n_chunks = 1; a.window = h->plan_warmup;
+                const int s_stat0 = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+                const int t0c = (s_stat0 + a.window + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+                if (t0c + 2 * a.window < h->glen_max) { a.t0 = t0c; a.n_chunks = 2; h->last_window = a.window; }
+                else a.window = 0;
+            } else
             if (a.n_chunks > 1) {
                 const int s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
                 a.t0 = (s_stat + a.window + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;

@@ -323,3 +323,26 @@ def test_bm_t_medium_batch_vs_oracle():
     eng.close()
     with pytest.raises(ValueError):
         capi.Problem("BM_t", ID, times, obs)                 # no degrees of freedom
+
+
+def test_more_groups_than_simds_split_transient_and_stationary(monkeypatch):
+    """33 000 tracks = 516 wavefront groups: no time windows are needed to fill the chip, but every track is still
+    split into the covariance transient and ONE stationary window so that the bulk runs the lean stationary
+    kernel; against the plain sequential filter (SSDE_CHUNKS=1), which the other tests pin to the oracle"""
+    import torch
+    ID, times, obs = simulate("CTCRW", 33000, 400, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=6, backend="torch", device="cuda:0")
+    pb = capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=[0, 1, 1, 0, 0])
+    par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.05])
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    info = eng.info()
+    assert info["lanes_per_track"] == 2 and info["window"] > 0 and info["window_check"] <= capi.WINDOW_TOL, info
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    seq = capi.Engine(pb)
+    vs, gs = seq.eval(par)
+    assert seq.info()["lanes_per_track"] == 1
+    assert abs(v - vs) <= 1e-12 * abs(vs)
+    assert np.max(np.abs(g - gs)) <= 1e-10 * np.max(np.abs(gs))
+    eng.close(); seq.close()
+    del ID, times, obs
+    torch.cuda.empty_cache()
