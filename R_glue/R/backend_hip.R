@@ -17,8 +17,9 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
     # full parameter vector in template order (nllk_ctcrw.hpp:135-140, nllk_sde.hpp:42-45);
     # without random effects TMB carries dummy log_lambda / coeff_re entries: the engine has none
     has_re <- !is.null(mats$S)
+    has_decay <- length(tmb_dat$t_decay) > 1    # decaying response model: log_decay sits between log_lambda and coeff_re
     par_full <- c(if(kalman) tmb_par$log_sigma_obs, tmb_par$coeff_fe,
-                  if(has_re) tmb_par$log_lambda, if(has_re) tmb_par$coeff_re)
+                  if(has_re) tmb_par$log_lambda, if(has_decay) tmb_par$log_decay, if(has_re) tmb_par$coeff_re)
     fixed <- rep(FALSE, length(par_full))
     off_fe <- if(kalman) 1 else 0
     if(!is.null(map$coeff_fe)) fixed[off_fe + which(is.na(map$coeff_fe))] <- TRUE
@@ -39,7 +40,9 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
                  a0 = tmb_dat$a0, P0 = tmb_dat$P0,
                  H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
                  par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device,
-                 other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL)
+                 other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL,
+                 t_decay = if(length(tmb_dat$t_decay) > 1) as.numeric(tmb_dat$t_decay) else NULL,
+                 col_decay = as.integer(tmb_dat$col_decay), ind_decay = as.integer(tmb_dat$ind_decay))
     # one penalty matrix per smooth: the diagonal blocks of S, sizes terms()$ncol_re (R/sde.R:424-447)
     if(has_re) {
         ncol_re <- sde$terms()$ncol_re; off <- cumsum(c(0, ncol_re)); S <- as.matrix(sde$mats()$S)

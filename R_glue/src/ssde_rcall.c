@@ -100,6 +100,18 @@ SEXP ssdeR_create(SEXP spec) {
     d.par_fixed = fixed;
     SEXP od = get_elt(spec, "other_data");                          /* tmb_dat$other_data: df of BM_t (R/sde.R:539-541) */
     if (od != R_NilValue && Rf_xlength(od) > 0) { d.other_data = REAL(od); d.n_other_data = (int32_t)Rf_xlength(od); }
+    /* decaying response model (R/sde.R:635-644): t_decay (q*n), col_decay / ind_decay (1-based in R) */
+    SEXP td = get_elt(spec, "t_decay"), cd = get_elt(spec, "col_decay"), idd = get_elt(spec, "ind_decay");
+    if (td != R_NilValue && Rf_xlength(td) > 1) {
+        int nc = (int)Rf_xlength(cd);
+        int32_t *c0 = (int32_t *)R_alloc(nc, sizeof(int32_t)), *i0 = (int32_t *)R_alloc(nc, sizeof(int32_t));
+        int nrate = 0;
+        for (int k = 0; k < nc; k++) {
+            c0[k] = INTEGER(cd)[k] - 1; i0[k] = INTEGER(idd)[k] - 1;
+            if (i0[k] + 1 > nrate) nrate = i0[k] + 1;
+        }
+        d.t_decay = REAL(td); d.n_decay_cols = nc; d.col_decay = c0; d.ind_decay = i0; d.n_decay = nrate;
+    }
     d.na_mode = SSDE_NA_R_ONLY;                                     /* R_IsNA semantics (nllk_ctcrw.hpp:214) */
     SEXP dev = get_elt(spec, "device");
     d.device = (dev == R_NilValue) ? -1 : Rf_asInteger(dev);

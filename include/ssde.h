@@ -38,8 +38,8 @@
  * fixed ("mapped") entries included:
  *   Kalman families (BM_SSM, OU_SSM, CTCRW; nllk_ctcrw.hpp:135-140):
  *       [ log_sigma_obs | coeff_fe (sum ncol_fe) | log_lambda (n_smooth) | coeff_re (sum ncol_re) ]
- *   direct families (BM, BM_t, OU; nllk_sde.hpp:42-45, decay feature not supported):
- *       [ coeff_fe | log_lambda | coeff_re ]
+ *   direct families (BM, BM_t, OU; nllk_sde.hpp:42-45):
+ *       [ coeff_fe | log_lambda | log_decay (only with decaying columns, see n_decay) | coeff_re ]
  *   coeff_fe / coeff_re are ordered parameter-by-parameter exactly like the columns
  *   of the reference's block-diagonal X_fe / X_re (R/sde.R:443-447).
  * `par_fixed[k] != 0` marks an entry that TMB's `map` would hold fixed
@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 2
+#define SSDE_ABI_VERSION 3
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -130,7 +130,16 @@ typedef struct ssde_desc {
     uint32_t reserved;
     const double *other_data;     /* DATA_VECTOR(other_data) (nllk_sde.hpp:29): [0] = degrees of freedom for BM_t; NULL otherwise */
     int32_t  n_other_data;
-    int32_t  reserved2;
+    /* decaying random-effect columns, direct families only (nllk_sde.hpp:30-32, 47-58; R/sde.R:163-177, 635-648):
+     * column col_decay[c] of X_re (0-based, counted over the concatenated blocks of all SDE parameters, i.e. the
+     * index inside coeff_re) is multiplied row by row by exp(-exp(log_decay[ind_decay[c]]) * t_decay).
+     * The parameter vector then carries log_decay: [ coeff_fe | log_lambda | log_decay (n_decay) | coeff_re ]. */
+    int32_t  n_decay;             /* number of decay rates, 0 = feature unused (the reference's dummy log_decay is dropped) */
+    const double *t_decay;        /* [q * n], entry j*n + i belongs to row i of SDE parameter j (the rows of X_re) */
+    int32_t  n_decay_cols;
+    int32_t  reserved3;
+    const int32_t *col_decay;     /* [n_decay_cols] */
+    const int32_t *ind_decay;     /* [n_decay_cols] 0-based index into log_decay */
 } ssde_desc;
 
 typedef struct ssde_handle ssde_handle;

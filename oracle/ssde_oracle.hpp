@@ -169,8 +169,9 @@ struct Problem {
     const ssde_desc* d;
     int64_t row_lo, row_hi;  // evaluate rows [row_lo, row_hi) (a whole number of segments)
     int64_t seg_lo;          // index of the a0 row of the segment starting at row_lo
-    int n_fe, n_re, n_lambda;  // totals
-    int off_sigobs, off_fe, off_lambda, off_re, n_par_full;
+    int n_fe, n_re, n_lambda, n_decay;  // totals
+    int off_sigobs, off_fe, off_lambda, off_decay, off_re, n_par_full;
+    std::vector<int> decay_of_col;     // per coeff_re column: index into log_decay, or -1
     std::vector<int> fe_off, re_off;  // per SDE parameter offsets inside coeff_fe / coeff_re
 };
 
@@ -204,8 +205,13 @@ inline Problem make_problem(const ssde_desc* d) {
     if (is_kalman(d->model)) { p.off_sigobs = 0; o = 1; }  // PARAMETER(log_sigma_obs) first: nllk_ctcrw.hpp:135
     p.off_fe = o; o += p.n_fe;
     p.off_lambda = o; o += p.n_lambda;
+    p.n_decay = (!is_kalman(d->model) && d->n_decay > 0) ? d->n_decay : 0;     // PARAMETER_VECTOR(log_decay), nllk_sde.hpp:44
+    p.off_decay = o; o += p.n_decay;
     p.off_re = o; o += p.n_re;
     p.n_par_full = o;
+    p.decay_of_col.assign(p.n_re, -1);
+    if (p.n_decay > 0)
+        for (int c = 0; c < d->n_decay_cols; c++) p.decay_of_col[d->col_decay[c]] = d->ind_decay[c];   // :50-51
     return p;
 }
 
@@ -223,8 +229,17 @@ Type linpred(const Problem& p, const Type* par, int64_t i, int j) {
     }
     Type re = Type(0.0);
     int nre = d->ncol_re ? d->ncol_re[j] : 0;
-    for (int c = 0; c < nre; c++)
-        re = re + par[p.off_re + p.re_off[j] + c] * d->x_re[j][i + (int64_t)c * d->n];
+    for (int c = 0; c < nre; c++) {
+        const int k = p.n_decay > 0 ? p.decay_of_col[p.re_off[j] + c] : -1;
+        if (k >= 0) {
+            // X_re_copy.col = X_re.col * exp(-decay_rate * t_decay), decay_rate = exp(log_decay) (nllk_sde.hpp:47-57);
+            // t_decay runs over the rows of the block-diagonal X_re: entry j*n + i
+            Type decay = exp(-(exp(par[p.off_decay + k]) * d->t_decay[(int64_t)j * d->n + i]));
+            re = re + par[p.off_re + p.re_off[j] + c] * (decay * d->x_re[j][i + (int64_t)c * d->n]);
+        } else {
+            re = re + par[p.off_re + p.re_off[j] + c] * d->x_re[j][i + (int64_t)c * d->n];
+        }
+    }
     return fe + re;
 }
 

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -44,7 +44,9 @@ class SsdeDesc(C.Structure):
         ("n_seg", C.c_int64), ("a0", C.c_void_p), ("p0", C.c_void_p), ("h_array", C.c_void_p),
         ("par_fixed", C.c_void_p), ("na_mode", C.c_int32), ("device", C.c_int32),
         ("flags", C.c_uint32), ("reserved", C.c_uint32),
-        ("other_data", C.c_void_p), ("n_other_data", C.c_int32), ("reserved2", C.c_int32),
+        ("other_data", C.c_void_p), ("n_other_data", C.c_int32),
+        ("n_decay", C.c_int32), ("t_decay", C.c_void_p), ("n_decay_cols", C.c_int32), ("reserved3", C.c_int32),
+        ("col_decay", C.c_void_p), ("ind_decay", C.c_void_p),
     ]
 
 
@@ -95,7 +97,8 @@ class Problem:
     def __init__(self, model: str, ID, times, obs, X_fe: Optional[Sequence] = None,
                  X_re: Optional[Sequence] = None, S_list: Optional[Sequence] = None,
                  a0=None, P0=None, H=None, par_fixed=None, include_penalty: int = 1,
-                 na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0, other_data=None):
+                 na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0, other_data=None,
+                 t_decay=None, col_decay=None, ind_decay=None):
         if model in UNSUPPORTED_MODELS:
             raise NotImplementedError(f"SDE type {model!r} is outside this engine's scope")
         if model not in MODEL_CODES:
@@ -162,6 +165,25 @@ class Problem:
             H = _f64(H)
         self.H = H
 
+        # decaying random-effect columns (direct families; nllk_sde.hpp:30-32, 47-58; R/sde.R:163-177):
+        # col_decay / ind_decay are 0-based here (the R objects are 1-based)
+        self.n_decay, self.t_decay, self.col_decay, self.ind_decay = 0, None, None, None
+        self.decay_of_col = np.full(self.n_re, -1, dtype=int)
+        if t_decay is not None:
+            if self.kalman:
+                raise ValueError("decaying terms are a feature of the direct families (BM, BM_t, OU)")
+            self.t_decay = _f64(np.asarray(t_decay, dtype=np.float64).ravel())
+            if self.t_decay.shape != (self.q * self.n,):
+                raise ValueError("'t_decay' should be of length (number of parameters) x (number of data)")  # R/sde.R:170-173
+            self.col_decay = np.ascontiguousarray(col_decay, dtype=np.int32)
+            self.ind_decay = np.ascontiguousarray(ind_decay, dtype=np.int32)
+            if self.col_decay.shape != self.ind_decay.shape:
+                raise ValueError("Check length of 'ind_decay' and 'col_decay'")                               # R/sde.R:174-176
+            if len(self.col_decay) and (self.col_decay.min() < 0 or self.col_decay.max() >= self.n_re):
+                raise ValueError(f"'col_decay' should be between 0 and {self.n_re - 1}")                      # R/sde.R:637-640
+            self.n_decay = int(self.ind_decay.max()) + 1 if len(self.ind_decay) else 0
+            self.decay_of_col[self.col_decay] = self.ind_decay
+
         # full parameter vector layout (include/ssde.h)
         o = 0
         self.off_sigobs = None
@@ -172,6 +194,8 @@ class Problem:
         o += self.n_fe
         self.off_lambda = o
         o += self.n_smooth
+        self.off_decay = o
+        o += self.n_decay
         self.off_re = o
         o += self.n_re
         self.n_par_full = o
@@ -250,9 +274,11 @@ class Problem:
         o += self.n_fe
         self.off_lambda = o
         o += self.n_smooth
+        self.off_decay, self.n_decay, self.t_decay, self.col_decay, self.ind_decay = o, 0, None, None, None
         self.off_re = o
         o += self.n_re
         self.n_par_full = o
+        self.decay_of_col = np.full(self.n_re, -1, dtype=int)
         self.fe_off = np.arange(self.q)
         self.re_off = np.concatenate([[0], np.cumsum(self.ncol_re)[:-1]]).astype(int)
         fixed = np.zeros(self.n_par_full, dtype=np.uint8)
@@ -273,6 +299,7 @@ class Problem:
         for j in range(self.q):
             names += [f"coeff_fe[{j}][{c}]" for c in range(self.ncol_fe[j])]
         names += [f"log_lambda[{s}]" for s in range(self.n_smooth)]
+        names += [f"log_decay[{k}]" for k in range(self.n_decay)]
         for j in range(self.q):
             names += [f"coeff_re[{j}][{c}]" for c in range(self.ncol_re[j])]
         return names
@@ -317,6 +344,10 @@ class Problem:
         d.na_mode, d.device, d.flags = self.na_mode, self.device, self.flags
         d.other_data = ptr(getattr(self, "other_data", None))
         d.n_other_data = 0 if getattr(self, "other_data", None) is None else len(self.other_data)
+        d.n_decay = self.n_decay
+        if self.n_decay > 0:
+            d.t_decay, d.n_decay_cols = ptr(self.t_decay), len(self.col_decay)
+            d.col_decay, d.ind_decay = ptr(self.col_decay), ptr(self.ind_decay)
         return d
 
 

@@ -27,14 +27,22 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     const double* cptr[KMAX];
     double coef[KMAX];
     int pj[KMAX];
+    int dk[KMAX];                                // decay-rate index of a decaying column, else -1
+    double rho[MAX_DECAY] = {0.0, 0.0, 0.0, 0.0};
+    const bool any_decay = A.n_decay > 0;
+    if (any_decay) {
+#pragma unroll
+        for (int k = 0; k < MAX_DECAY; k++) rho[k] = (k < A.n_decay) ? exp(A.par[A.off_decay + k]) : 0.0;   // nllk_sde.hpp:47
+    }
     double base[MAX_Q] = {0.0, 0.0, 0.0, 0.0};   // intercept part of every parameter
     bool varies[MAX_Q] = {false, false, false, false};
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
-        cptr[k] = nullptr; coef[k] = 0.0; pj[k] = -1;
+        cptr[k] = nullptr; coef[k] = 0.0; pj[k] = -1; dk[k] = -1;
         if (k < ns) {
             const int c = T->col[k];
             pj[k] = T->par_j[k];
+            dk[k] = any_decay ? T->decay[k] : -1;
             coef[k] = A.par[T->pidx[k]];
             if (c >= 0) {
                 cptr[k] = A.cols[c];
@@ -53,6 +61,7 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     double acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) acc[k] = 0.0;
+    double accd[MAX_DECAY] = {0.0, 0.0, 0.0, 0.0};   // d nll / d log_decay
     double nll = 0.0;
 
     // every workgroup streams ONE contiguous range of rows (consecutive 2-KB pieces of each column)
@@ -62,13 +71,19 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
         if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
         const double dt = A.times[i] - A.times[i - 1];  // dtimes(i-1), nllk_sde.hpp:37,80
-        double w[KMAX];
+        double w[KMAX], dfac[KMAX];
         double par[MAX_Q] = {base[0], base[1], base[2], base[3]};
 #pragma unroll
         for (int k = 0; k < KMAX; k++) {
-            w[k] = 1.0;
+            w[k] = 1.0; dfac[k] = 0.0;
             if (cptr[k] != nullptr) {                    // uniform: a scalar branch, not a per-lane select
                 w[k] = cptr[k][i - 1];
+                if (any_decay && dk[k] >= 0) {           // X_re_copy.col = X_re.col * exp(-rate * t_decay), row i-1 (Q6)
+                    const double r = (dk[k] == 0) ? rho[0] : (dk[k] == 1) ? rho[1] : (dk[k] == 2) ? rho[2] : rho[3];
+                    const double rt = r * A.t_decay[(int64_t)pj[k] * A.n + (i - 1)];
+                    w[k] *= exp(-rt);
+                    dfac[k] = -rt;                       // d w / d log_decay = w * (-rate * t)
+                }
                 const double t = w[k] * coef[k];
                 if (pj[k] == 0) par[0] += t;
                 else if (pj[k] == 1) par[1] += t;
@@ -124,12 +139,18 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
             if (pj[k] >= 0) {                            // uniform
                 const double gj = (pj[k] == 0) ? g[0] : (pj[k] == 1) ? g[1] : (pj[k] == 2) ? g[2] : g[3];
                 acc[k] += w[k] * gj;
+                if (any_decay && dk[k] >= 0) {
+                    const double t = gj * coef[k] * w[k] * dfac[k];
+#pragma unroll
+                    for (int q = 0; q < MAX_DECAY; q++) accd[q] += (dk[k] == q) ? t : 0.0;
+                }
             }
         }
     }
 
     // workgroup reduction: wave shuffles, then 4 wave totals through LDS
-    __shared__ double sh[4][KMAX + 1];
+    // accumulator order: [nll | n_slots coefficients | n_decay decay rates]
+    __shared__ double sh[4][KMAX + 1 + MAX_DECAY];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double t = wave_sum(nll);
     if (lane == 0) sh[wv][0] = t;
@@ -140,8 +161,15 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
             if (lane == 0) sh[wv][1 + k] = t;
         }
     }
+    if (any_decay) {
+#pragma unroll
+        for (int q = 0; q < MAX_DECAY; q++) {
+            t = wave_sum(accd[q]);
+            if (lane == 0 && q < A.n_decay) sh[wv][1 + ns + q] = t;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x <= ns) {
+    if ((int)threadIdx.x <= ns + A.n_decay) {
         const int k = threadIdx.x;
         A.partials[(int64_t)k * A.n_blocks + blockIdx.x] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
     }

@@ -173,7 +173,9 @@ struct SlotTable {
     int16_t col[MAX_COLS];     // streamed column index, or -1 for an intercept
     int16_t pidx[MAX_COLS];    // index into the full parameter vector
     int16_t is_free[MAX_COLS]; // 0 = held fixed (TMB map): no gradient wanted
+    int16_t decay[MAX_COLS];   // decaying column: index into log_decay, else -1 (direct families)
 };
+constexpr int MAX_DECAY = 4;   // decay rates (direct families)
 
 // ---- direct families (k_direct.hip) ---------------------------------------------------------------
 struct DirectArgs {
@@ -189,6 +191,8 @@ struct DirectArgs {
     int n_blocks;
     double* partials;            // [1][1 + n_slots][n_blocks]
     double tdf, tconst;          // BM_t: degrees of freedom and the normalising constant of dt(., df)
+    const double* t_decay;       // [q * n] or NULL: decaying columns are scaled by exp(-exp(log_decay) * t_decay) (nllk_sde.hpp:47-57)
+    int n_decay, off_decay;      // decay rates and where log_decay sits in the parameter vector
 };
 hipError_t launch_direct(const DirectArgs& a, hipStream_t s);
 

@@ -74,7 +74,7 @@ struct ssde_handle {
     int64_t tile_doubles = 0;
 
     // direct families (long format, engine-owned copies)
-    DevBuf<double> times, obs, colbuf;
+    DevBuf<double> times, obs, colbuf, tdecay;
     DevBuf<uint32_t> scored;
     DevBuf<const double*> colptr;
     int direct_blocks = 0;
@@ -209,7 +209,7 @@ void destroy(ssde_handle* h) {
     if (h->tv_stats_ev) (void)hipEventDestroy(h->tv_stats_ev);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
-    h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
+    h->tdecay.release(); h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
     h->slot_table.release(); h->dirs.release(); h->par_ring.release();
     h->partials.release(); h->out.release();
     if (h->par_pinned) (void)hipHostFree(h->par_pinned);
@@ -633,6 +633,13 @@ int build(const ssde_desc* d, ssde_handle* h) {
         if (d->ncol_re && d->ncol_re[j] > 0 && !(d->x_re && d->x_re[j]))
             return fail(h, SSDE_ERR_ARG, "x_re[j] missing for a parameter with random-effect columns");
     }
+    if (d->n_decay > 0) {
+        if (is_kalman(d->model)) return fail(h, SSDE_ERR_ARG, "decaying terms are a feature of the direct families (nllk_sde.hpp:47-58)");
+        if (d->n_decay > MAX_DECAY) return fail(h, SSDE_ERR_ARG, "more than 4 decay rates");
+        if (!d->t_decay || !d->col_decay || !d->ind_decay || d->n_decay_cols < 1) return fail(h, SSDE_ERR_ARG, "t_decay / col_decay / ind_decay missing");
+        for (int c = 0; c < d->n_decay_cols; c++)
+            if (d->ind_decay[c] < 0 || d->ind_decay[c] >= d->n_decay) return fail(h, SSDE_ERR_ARG, "ind_decay out of range");
+    }
     h->L = make_layout(d);
     if (h->L.n_full > MAX_PAR) return fail(h, SSDE_ERR_ARG, "too many parameters for the kernel argument block");
     int nsm = 0;
@@ -708,6 +715,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
                 cp[s.col] = dst;
             }
         HIPCHK(h, h->colptr.upload(cp));
+        if (h->L.n_decay > 0) HIPCHK(h, stage(d->t_decay, (size_t)n * d->n_par, on_dev, h->tdecay));
         {
             DevBuf<double> idb;
             const double* idp = d->id;
@@ -719,7 +727,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
         }
         h->direct_blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
         if (const char* e = getenv("SSDE_DIRECT_BLOCKS")) h->direct_blocks = std::max(1, std::min(atoi(e), 65536));
-        h->partial_doubles = (size_t)(1 + MAX_Q + h->slots.size()) * h->direct_blocks;
+        h->partial_doubles = (size_t)(1 + MAX_Q + h->slots.size() + MAX_DECAY) * h->direct_blocks;
         {
             // regular grid?  (min / max over the scored intervals)
             const int nb = 1024;
@@ -740,7 +748,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
                 if (sl.col < 0) { h->df_icpt[sl.par_j] = sl.pidx; continue; }
                 if (streamed_par.empty() || streamed_par.back() != sl.par_j) streamed_par.push_back(sl.par_j);
             }
-            bool ok = streamed_par.size() <= 2 && !getenv("SSDE_NO_DIRECT_FAST");
+            bool ok = streamed_par.size() <= 2 && !getenv("SSDE_NO_DIRECT_FAST") && h->L.n_decay == 0;   // decaying columns: generic kernel
             if (ok) {
                 for (auto& sl : h->slots) {
                     if (sl.col < 0) continue;
@@ -950,6 +958,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
             st.col[k] = (int16_t)h->slots[k].col;
             st.pidx[k] = (int16_t)h->slots[k].pidx;
             st.is_free[k] = h->fixed[h->slots[k].pidx] ? 0 : 1;
+            st.decay[k] = (int16_t)h->slots[k].decay;
         }
         if (!h->slot_table.p) HIPCHK(h, h->slot_table.upload(std::vector<SlotTable>(1, st)));
         HIPCHK(h, h->par_ring.alloc((size_t)PAR_RING * MAX_PAR));
@@ -1337,15 +1346,19 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
         a.n_blocks = h->direct_blocks; a.partials = h->partials.p;
         a.tdf = h->tdf; a.tconst = h->tconst;
+        a.t_decay = h->tdecay.p; a.n_decay = L.n_decay; a.off_decay = L.off_decay;
         if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
         HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_direct(a, s));
         HIPCHK(h, hipEventRecord(h->ev_k1, s));
         h->ev_k_valid = true; h->last_s_stat = -1;
-        ra.n_parts = 1; ra.nacc = 1 + a.n_slots; ra.n_blocks = h->direct_blocks;
-        if (order >= 1)
+        ra.n_parts = 1; ra.nacc = 1 + a.n_slots + L.n_decay; ra.n_blocks = h->direct_blocks;
+        if (order >= 1) {
             for (int k = 0; k < a.n_slots; k++)
                 if (!h->fixed[h->slots[k].pidx]) ra.map[k] = (int16_t)(1 + h->slots[k].pidx);
+            for (int q = 0; q < L.n_decay; q++)
+                if (!h->fixed[L.off_decay + q]) ra.map[a.n_slots + q] = (int16_t)(1 + L.off_decay + q);
+        }
     }
     HIPCHK(h, launch_reduce(ra, s));
     return SSDE_OK;

@@ -28,8 +28,8 @@ inline int n_sde_par(int model, int d) {
 
 // full parameter vector layout (include/ssde.h, PARAMETER VECTOR)
 struct ParLayout {
-    int q = 0, n_fe = 0, n_re = 0, n_lambda = 0;
-    int off_sig = -1, off_fe = 0, off_lambda = 0, off_re = 0, n_full = 0;
+    int q = 0, n_fe = 0, n_re = 0, n_lambda = 0, n_decay = 0;
+    int off_sig = -1, off_fe = 0, off_lambda = 0, off_decay = 0, off_re = 0, n_full = 0;
     std::vector<int> fe_off, re_off, ncol_fe, ncol_re;
 };
 
@@ -50,6 +50,8 @@ inline ParLayout make_layout(const ssde_desc* d) {
     if (is_kalman(d->model)) { L.off_sig = 0; o = 1; }   // PARAMETER(log_sigma_obs) first (nllk_ctcrw.hpp:135)
     L.off_fe = o; o += L.n_fe;
     L.off_lambda = o; o += L.n_lambda;
+    L.n_decay = (!is_kalman(d->model) && d->n_decay > 0) ? d->n_decay : 0;     // PARAMETER_VECTOR(log_decay), nllk_sde.hpp:44
+    L.off_decay = o; o += L.n_decay;
     L.off_re = o; o += L.n_re;
     L.n_full = o;
     return L;
@@ -61,6 +63,7 @@ struct Slot {
     int col;              // index into the list of streamed columns, -1 = intercept (column of ones)
     int pidx;             // index in the full parameter vector
     const double* src;    // caller's column (length n) or NULL
+    int decay = -1;       // index into log_decay of a decaying random-effect column (nllk_sde.hpp:47-57), -1 = none
 };
 
 inline std::vector<Slot> make_slots(const ssde_desc* d, const ParLayout& L, int* n_stream_cols) {
@@ -81,6 +84,9 @@ inline std::vector<Slot> make_slots(const ssde_desc* d, const ParLayout& L, int*
             t.pidx = L.off_re + L.re_off[j] + c;
             t.src = d->x_re[j] + (int64_t)c * d->n;
             t.col = ncol++;
+            if (L.n_decay > 0)
+                for (int k = 0; k < d->n_decay_cols; k++)
+                    if (d->col_decay[k] == L.re_off[j] + c) t.decay = d->ind_decay[k];
             s.push_back(t);
         }
     }

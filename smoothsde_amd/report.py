@@ -105,6 +105,8 @@ def _block_name(pb, k: int) -> str:
         return "coeff_fe"
     if pb.off_lambda <= k < pb.off_lambda + pb.n_smooth:
         return "log_lambda"
+    if getattr(pb, "n_decay", 0) and pb.off_decay <= k < pb.off_decay + pb.n_decay:
+        return "log_decay"
     return "coeff_re"
 
 

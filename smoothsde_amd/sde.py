@@ -239,6 +239,10 @@ class SDE:
         X_re = [d.X_re for d in self.designs_]
         kw = dict(a0=None, P0=self.other_data_.get("P0"), H=self.other_data_.get("H"), include_penalty=include_penalty,
                   other_data=self.other_data_.get("df") if self.type_ == "BM_t" else None)   # R/sde.R:539-541
+        if self.other_data_.get("t_decay") is not None:        # decaying response model, R/sde.R:635-644 (1-based in R)
+            kw.update(t_decay=self.other_data_["t_decay"],
+                      col_decay=np.asarray(self.other_data_["col_decay"], dtype=int) - 1,
+                      ind_decay=np.asarray(self.other_data_["ind_decay"], dtype=int) - 1)
         kw.update(over)
         pb = capi.Problem(self.type_, self.data_["ID"], self.data_["time"], self.obs(), X_fe, X_re,
                           self.mats_["S_list"], **kw)
@@ -256,6 +260,8 @@ class SDE:
             p[0] = 0.0                                      # log_sigma_obs = 0 (R/sde.R:560, 590)
         p[pb.off_fe:pb.off_fe + pb.n_fe] = self.coeff_fe_
         p[pb.off_lambda:pb.off_lambda + pb.n_smooth] = np.log(self.lambda_vals_)
+        if pb.n_decay:
+            p[pb.off_decay:pb.off_decay + pb.n_decay] = np.log(getattr(self, "rho_", np.ones(pb.n_decay)))   # R/sde.R:177
         p[pb.off_re:pb.off_re + pb.n_re] = self.coeff_re_
         return p
 
@@ -313,6 +319,8 @@ class SDE:
         self.coeff_re_ = full[pb.off_re:pb.off_re + pb.n_re].copy()
         if pb.n_smooth:
             self.lambda_vals_ = np.exp(full[pb.off_lambda:pb.off_lambda + pb.n_smooth])   # R/sde.R:712
+        if pb.n_decay:
+            self.rho_ = np.exp(full[pb.off_decay:pb.off_decay + pb.n_decay])             # R/sde.R:715-718
         return self.out_
 
     def report(self):

@@ -56,7 +56,7 @@ def _par_const(rng, model, d, kalman):
 
 
 def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irregular=True,
-              fix_mu=False, with_H=False, with_P0=False, na_mode=1, other_data=None):
+              fix_mu=False, with_H=False, with_P0=False, na_mode=1, other_data=None, decay=False):
     rng = np.random.default_rng(seed)
     kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
     ID, times, obs = _tracks(rng, model, d, lengths, irregular)
@@ -101,6 +101,19 @@ def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irr
             base = rng.uniform(-0.3, 0.5) + (3.0 if (j < d and model in ("OU", "OU_SSM")) else 0.0)
             p += [base] + list(rng.uniform(-0.4, 0.4, size=ncol_fe[j] - 1))
         p += list(rng.uniform(-0.5, 1.0, size=len(S_list)))  # log_lambda
+        if decay:
+            # decaying response (nllk_sde.hpp:47-58): every smooth decays with its own rate, except that the
+            # last column of the first smooth is left alone (mixed blocks must work too)
+            n_re_tot = sum(s.shape[0] for s in S_list)
+            cols, inds, start = [], [], 0
+            for k, s_ in enumerate(S_list):
+                for c in range(s_.shape[0]):
+                    if not (k == 0 and c == s_.shape[0] - 1):
+                        cols.append(start + c); inds.append(k)
+                start += s_.shape[0]
+            spec.update(t_decay=rng.uniform(0.0, 2.5, size=q * n), col_decay=np.array(cols, dtype=np.int32),
+                        ind_decay=np.array(inds, dtype=np.int32))
+            p += list(rng.uniform(-1.0, 0.3, size=len(S_list)))  # log_decay
         p += list(rng.uniform(-0.3, 0.3, size=sum(s.shape[0] for s in S_list)))  # coeff_re
         par = np.array(p)
     if with_H:
@@ -137,7 +150,8 @@ def elephant_spec():
 def problem_from_spec(spec, **over) -> Problem:
     kw = dict(a0=spec.get("a0"), P0=spec.get("P0"), H=spec.get("H"), par_fixed=spec.get("par_fixed"),
               include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1),
-              other_data=spec.get("other_data"))
+              other_data=spec.get("other_data"), t_decay=spec.get("t_decay"), col_decay=spec.get("col_decay"),
+              ind_decay=spec.get("ind_decay"))
     kw.update(over)
     return Problem(spec["model"], spec["ID"], spec["times"], spec["obs"], spec.get("X_fe"), spec.get("X_re"),
                    spec.get("S_list"), **kw)
@@ -178,4 +192,7 @@ def all_specs():
     # BM with Student-t increments (tr_dens.hpp:38-44), degrees of freedom in other_data
     specs.append(make_spec("BM_t_d1_const", "BM_t", 1, seed=191, lengths=[9, 2, 14, 6], na_rows=(3, 12), other_data=5.0))
     specs.append(make_spec("BM_t_d1_tv", "BM_t", 1, seed=192, lengths=[16, 11], variant="tv", na_rows=(5,), other_data=3.5))
+    # decaying random-effect columns (nllk_sde.hpp:47-58): one rate, two rates
+    specs.append(make_spec("OU_d1_decay", "OU", 1, seed=201, lengths=[18, 12], variant="tv", na_rows=(7,), decay=True))
+    specs.append(make_spec("BM_d2_decay2", "BM", 2, seed=202, lengths=[15, 14], variant="tv2", decay=True))
     return specs

@@ -44,7 +44,19 @@ def linear_predictor(pb: Problem, par: torch.Tensor) -> torch.Tensor:
             col = torch.as_tensor(pb.X_fe[j]) @ cf
         if pb.ncol_re[j] > 0:
             cr = par[pb.off_re + pb.re_off[j]: pb.off_re + pb.re_off[j] + pb.ncol_re[j]]
-            col = col + torch.as_tensor(pb.X_re[j]) @ cr
+            Xr = torch.as_tensor(pb.X_re[j])
+            if getattr(pb, "n_decay", 0) > 0:
+                # X_re_decay of the R class (R/sde.R:303-321): whole columns scaled by exp(-rho * t_decay)
+                scaled = []
+                for c in range(pb.ncol_re[j]):
+                    k = pb.decay_of_col[pb.re_off[j] + c]
+                    xc = Xr[:, c]
+                    if k >= 0:
+                        rho = torch.exp(par[pb.off_decay + k])
+                        xc = xc * torch.exp(-rho * torch.as_tensor(pb.t_decay[j * pb.n:(j + 1) * pb.n]))
+                    scaled.append(xc)
+                Xr = torch.stack(scaled, dim=1)
+            col = col + Xr @ cr
         cols.append(col)
     return torch.stack(cols, dim=1)
 

@@ -346,3 +346,28 @@ def test_more_groups_than_simds_split_transient_and_stationary(monkeypatch):
     eng.close(); seq.close()
     del ID, times, obs
     torch.cuda.empty_cache()
+
+
+def test_decaying_columns_medium_batch_vs_oracle():
+    """decaying response model (nllk_sde.hpp:47-58): 500 ragged OU tracks, a 6-column smooth on mu whose columns decay
+    with t_decay at two different rates, plus a non-decaying slope on log tau"""
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    rng = np.random.default_rng(15)
+    ID, times, obs = simulate("OU", 500, 40, 1, mu=1.0, tau=2.0, kappa=1.0, seed=19)
+    n = len(ID)
+    x = (np.sin(np.arange(n) * 0.02) + 1) / 2
+    X_fe = [None, np.column_stack([np.ones(n), x]), None]
+    pb = capi.Problem("OU", ID, times, obs, X_fe=X_fe, X_re=[bspline_basis(x, 6), None, None],
+                      S_list=[second_difference_penalty(6)], t_decay=rng.uniform(0, 3, size=3 * n),
+                      col_decay=[0, 1, 2, 3, 5], ind_decay=[0, 0, 0, 1, 1])
+    assert pb.n_decay == 2 and pb.n_par_full == 4 + 1 + 2 + 6
+    par = np.r_[1.0, 0.6, -0.2, 0.1, 0.3, -0.4, 0.2, 0.4 * np.sin(np.arange(6))]
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert grad[pb.off_decay] != 0.0 and grad[pb.off_decay + 1] != 0.0
+    eng.close()
+    with pytest.raises(ValueError):
+        capi.Problem("OU_SSM", ID, times, obs, X_re=[bspline_basis(x, 6), None, None], S_list=[second_difference_penalty(6)],
+                     t_decay=np.zeros(3 * n), col_decay=[0], ind_decay=[0])
