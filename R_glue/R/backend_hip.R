@@ -14,14 +14,15 @@
 make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
     mats <- sde$make_mat()                      # X_list_fe / X_list_re / S_list (R/sde.R:452-454)
     kalman <- sde$type() %in% c("BM_SSM", "OU_SSM", "CTCRW")
+    eseal <- sde$type() == "ESEAL_SSM"          # leading parameters log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
     # full parameter vector in template order (nllk_ctcrw.hpp:135-140, nllk_sde.hpp:42-45);
     # without random effects TMB carries dummy log_lambda / coeff_re entries: the engine has none
     has_re <- !is.null(mats$S)
     has_decay <- length(tmb_dat$t_decay) > 1    # decaying response model: log_decay sits between log_lambda and coeff_re
-    par_full <- c(if(kalman) tmb_par$log_sigma_obs, tmb_par$coeff_fe,
+    par_full <- c(if(kalman) tmb_par$log_sigma_obs, if(eseal) c(tmb_par$log_tau, tmb_par$a1, tmb_par$log_a2), tmb_par$coeff_fe,
                   if(has_re) tmb_par$log_lambda, if(has_decay) tmb_par$log_decay, if(has_re) tmb_par$coeff_re)
     fixed <- rep(FALSE, length(par_full))
-    off_fe <- if(kalman) 1 else 0
+    off_fe <- if(kalman) 1 else if(eseal) 3 else 0
     if(!is.null(map$coeff_fe)) fixed[off_fe + which(is.na(map$coeff_fe))] <- TRUE
     if(kalman && !is.null(map$log_sigma_obs)) fixed[1] <- TRUE
     if(has_re) {
@@ -41,6 +42,7 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
                  H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
                  par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device,
                  other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL,
+                 eseal_h = if(eseal) as.numeric(tmb_dat$h) else NULL, eseal_R = if(eseal) as.numeric(tmb_dat$R) else NULL,
                  t_decay = if(length(tmb_dat$t_decay) > 1) as.numeric(tmb_dat$t_decay) else NULL,
                  col_decay = as.integer(tmb_dat$col_decay), ind_decay = as.integer(tmb_dat$ind_decay))
     # one penalty matrix per smooth: the diagonal blocks of S, sizes terms()$ncol_re (R/sde.R:424-447)

@@ -41,6 +41,7 @@ static int model_code(const char *type) {
     if (!strcmp(type, "OU_SSM")) return SSDE_MODEL_OU_SSM;
     if (!strcmp(type, "CTCRW")) return SSDE_MODEL_CTCRW;
     if (!strcmp(type, "BM_t")) return SSDE_MODEL_BM_T;
+    if (!strcmp(type, "ESEAL_SSM")) return SSDE_MODEL_ESEAL_SSM;
     return -1;
 }
 
@@ -56,7 +57,8 @@ SEXP ssdeR_create(SEXP spec) {
     SEXP obs = get_elt(spec, "obs");
     d.n = Rf_nrows(obs);
     d.n_dim = Rf_ncols(obs);
-    d.n_par = (d.model == SSDE_MODEL_BM || d.model == SSDE_MODEL_BM_SSM || d.model == SSDE_MODEL_BM_T) ? d.n_dim + 1 : d.n_dim + 2;
+    d.n_par = (d.model == SSDE_MODEL_BM || d.model == SSDE_MODEL_BM_SSM || d.model == SSDE_MODEL_BM_T ||
+               d.model == SSDE_MODEL_ESEAL_SSM) ? d.n_dim + 1 : d.n_dim + 2;
     d.id = REAL(get_elt(spec, "ID"));
     d.times = REAL(get_elt(spec, "times"));
     d.obs = REAL(obs);
@@ -100,6 +102,9 @@ SEXP ssdeR_create(SEXP spec) {
     d.par_fixed = fixed;
     SEXP od = get_elt(spec, "other_data");                          /* tmb_dat$other_data: df of BM_t (R/sde.R:539-541) */
     if (od != R_NilValue && Rf_xlength(od) > 0) { d.other_data = REAL(od); d.n_other_data = (int32_t)Rf_xlength(od); }
+    SEXP eh = get_elt(spec, "eseal_h"), eR = get_elt(spec, "eseal_R");     /* tmb_dat$h, tmb_dat$R (R/sde.R:611-614) */
+    if (eh != R_NilValue) d.eseal_h = REAL(eh);
+    if (eR != R_NilValue) d.eseal_R = REAL(eR);
     /* decaying response model (R/sde.R:635-644): t_decay (q*n), col_decay / ind_decay (1-based in R) */
     SEXP td = get_elt(spec, "t_decay"), cd = get_elt(spec, "col_decay"), idd = get_elt(spec, "ind_decay");
     if (td != R_NilValue && Rf_xlength(td) > 1) {

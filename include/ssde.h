@@ -38,6 +38,8 @@
  * fixed ("mapped") entries included:
  *   Kalman families (BM_SSM, OU_SSM, CTCRW; nllk_ctcrw.hpp:135-140):
  *       [ log_sigma_obs | coeff_fe (sum ncol_fe) | log_lambda (n_smooth) | coeff_re (sum ncol_re) ]
+ *   ESEAL_SSM (nllk_e_seal_ssm.hpp:114-124):
+ *       [ log_tau | a1 | log_a2 | coeff_fe | log_lambda | coeff_re ]
  *   direct families (BM, BM_t, OU; nllk_sde.hpp:42-45):
  *       [ coeff_fe | log_lambda | log_decay (only with decaying columns, see n_decay) | coeff_re ]
  *   coeff_fe / coeff_re are ordered parameter-by-parameter exactly like the columns
@@ -56,7 +58,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 3
+#define SSDE_ABI_VERSION 4
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -65,8 +67,10 @@ enum {
     SSDE_MODEL_BM_SSM = 2, /* "BM_SSM"  -> nllk_bm_ssm                                    */
     SSDE_MODEL_OU_SSM = 3, /* "OU_SSM"  -> nllk_ou_ssm                                    */
     SSDE_MODEL_CTCRW  = 4, /* "CTCRW"   -> nllk_ctcrw                                     */
-    SSDE_MODEL_BM_T   = 5  /* "BM_t"    -> nllk_sde + tr_dens BM_t branch (tr_dens.hpp:38-44): one response,
+    SSDE_MODEL_BM_T   = 5, /* "BM_t"    -> nllk_sde + tr_dens BM_t branch (tr_dens.hpp:38-44): one response,
                               par = (mu, log sigma), degrees of freedom in other_data[0] (R/sde.R:539-541) */
+    SSDE_MODEL_ESEAL_SSM = 6 /* "ESEAL_SSM" -> nllk_eseal_ssm (nllk_e_seal_ssm.hpp:83-250): one response, par = (mu, log sigma),
+                              state (1, lipid mass), Z_i = (a1, a2 / R_i), H_i = tau^2 / h_i; needs a0, eseal_h, eseal_R */
 };
 
 /* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with
@@ -140,6 +144,10 @@ typedef struct ssde_desc {
     int32_t  reserved3;
     const int32_t *col_decay;     /* [n_decay_cols] */
     const int32_t *ind_decay;     /* [n_decay_cols] 0-based index into log_decay */
+    /* ESEAL_SSM only: DATA_VECTOR(h) (daily drift dives) and DATA_VECTOR(R) (non-lipid tissue mass),
+     * nllk_e_seal_ssm.hpp:100-101, R/sde.R:611-614 */
+    const double *eseal_h;        /* [n] */
+    const double *eseal_R;        /* [n] */
 } ssde_desc;
 
 typedef struct ssde_handle ssde_handle;

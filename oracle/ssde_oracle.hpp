@@ -179,6 +179,7 @@ inline bool is_kalman(int model) {
     return model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_OU_SSM || model == SSDE_MODEL_CTCRW;
 }
 inline int state_dim(const ssde_desc* d) {
+    if (d->model == SSDE_MODEL_ESEAL_SSM) return 2;
     if (d->model == SSDE_MODEL_CTCRW) return 2 * d->n_dim;
     if (is_kalman(d->model)) return d->n_dim;
     return 0;
@@ -203,6 +204,7 @@ inline Problem make_problem(const ssde_desc* d) {
     int o = 0;
     p.off_sigobs = -1;
     if (is_kalman(d->model)) { p.off_sigobs = 0; o = 1; }  // PARAMETER(log_sigma_obs) first: nllk_ctcrw.hpp:135
+    if (d->model == SSDE_MODEL_ESEAL_SSM) o = 3;           // PARAMETER(log_tau), (a1), (log_a2): nllk_e_seal_ssm.hpp:114-116
     p.off_fe = o; o += p.n_fe;
     p.off_lambda = o; o += p.n_lambda;
     p.n_decay = (!is_kalman(d->model) && d->n_decay > 0) ? d->n_decay : 0;     // PARAMETER_VECTOR(log_decay), nllk_sde.hpp:44
@@ -557,13 +559,88 @@ Type nllk_direct(const Problem& p, const Type* par) {
     return -llk;
 }
 
+// nllk_eseal_ssm (nllk_e_seal_ssm.hpp:83-250), Kalman loop only (lines 139-207): state (1, L), time-varying
+// Z_i = (a1, a2 / R_i) (makeZ :43-48), H_i = tau^2 / h_i (:55-59), T_i = [[1, 0], [mu_i dt_i, 1]] (:16-23),
+// Q_i = diag(0, sigma_i^2 dt_i) (:30-35).  Returns -llk without priors / penalty.
+template <class Type>
+Type nllk_eseal(const Problem& p, const Type* par) {
+    const ssde_desc* d = p.d;
+    Type tau = exp(par[0]), a1 = par[1], a2 = exp(par[2]);                       // :114-118
+    Mat<Type> P0(2, 2);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) P0(i, j) = Type(d->p0 ? d->p0[i + j * 2] : ((i == 1 && j == 1) ? 10.0 : 0.0));   // R/sde.R:603
+    Mat<Type> aest(2, 1), Pest(2, 2);
+    int64_t k = p.seg_lo;
+    Type llk = Type(0.0);
+    for (int64_t i = p.row_lo; i < p.row_hi; i++) {
+        bool first = (i == p.row_lo) || (d->id[i] != d->id[i - 1]);             // :154-158, 163
+        if (first) {
+            for (int c = 0; c < 2; c++) aest(c, 0) = Type(d->a0[k + (int64_t)c * d->n_seg]);
+            k = k + 1;
+            Pest = P0;
+            continue;
+        }
+        Mat<Type> Z(1, 2), H(1, 1), T(2, 2), Q(2, 2);
+        Z(0, 0) = a1; Z(0, 1) = a2 / Type(d->eseal_R[i]);                         // :170
+        H(0, 0) = tau * tau / Type(d->eseal_h[i]);                                // :171
+        double dt = dtimes_kalman(d, i);                                          // :104-107
+        Type mu = linpred(p, par, i, 0), sigma = exp(linpred(p, par, i, 1));     // :136-137
+        T(0, 0) = Type(1.0); T(1, 0) = mu * dt; T(1, 1) = Type(1.0);              // :172
+        Q(1, 1) = sigma * sigma * dt;                                             // :173
+        Mat<Type> Tt = transpose(T), Zt = transpose(Z);
+        if (is_na(d->obs[i], d->na_mode)) {                                       // :175-178
+            aest = mul(T, aest);
+            Pest = add(mul(mul(T, Pest), Tt), Q);
+            continue;
+        }
+        Mat<Type> Za = mul(Z, aest);
+        Type u = Type(d->obs[i]) - Za(0, 0);                                      // :181-182
+        Mat<Type> F = add(mul(mul(Z, Pest), Zt), H);                              // :184
+        Type detF = F(0, 0);                                                      // :185
+        if (detF <= 0.0) {                                                        // :187-189
+            aest = mul(T, aest);
+            Pest = add(mul(mul(T, Pest), Tt), Q);
+        } else {
+            Type Finv = Type(1.0) / F(0, 0);
+            llk = llk - (log(detF) + u * Finv * u) / Type(2.0);                   // :192-195
+            Mat<Type> K = mul(mul(T, Pest), Zt);                                  // :197 (2 x 1)
+            K(0, 0) = K(0, 0) * Finv; K(1, 0) = K(1, 0) * Finv;
+            Mat<Type> Ku(2, 1);
+            Ku(0, 0) = K(0, 0) * u; Ku(1, 0) = K(1, 0) * u;
+            aest = add(mul(T, aest), Ku);                                         // :199
+            Mat<Type> L = sub(T, mul(K, Z));                                      // :201
+            Pest = add(mul(mul(T, Pest), transpose(L)), Q);                       // :202
+        }
+    }
+    return -llk;
+}
+
+// dinvgamma(x, shape, scale, log) of nllk_e_seal_ssm.hpp:68-78
+template <class Type>
+Type dinvgamma_log(Type x, double shape, double scale) {
+    return Type(shape * std::log(scale) - std::lgamma(shape)) - Type(shape + 1.0) * log(x) - Type(scale) / x;
+}
+// -(priors) of lines 212-216: on sigma(0)^2 (first ROW's sigma) and tau^2; integer division n/2 as in the reference
+template <class Type>
+Type eseal_priors(const Problem& p, const Type* par) {
+    const ssde_desc* d = p.d;
+    const long n = (long)d->n;
+    Type sigma0 = exp(linpred(p, par, 0, 1)), tau = exp(par[0]);
+    Type lp = dinvgamma_log(sigma0 * sigma0, (double)(10 * n), (double)(4 * (10 * n - 1))) +
+              dinvgamma_log(tau * tau, (double)(n / 2), (double)(n / 2 - 1));
+    return -lp;
+}
+
 template <class Type>
 Type nllk_data(const Problem& p, const Type* par, double* aest_all) {
+    if (p.d->model == SSDE_MODEL_ESEAL_SSM) return nllk_eseal<Type>(p, par);
     if (is_kalman(p.d->model)) return nllk_kalman<Type>(p, par, aest_all);
     return nllk_direct<Type>(p, par);
 }
+// parameter-only terms, added once: smoothing penalty (+ the ESEAL priors)
 template <class Type>
 Type penalty(const Problem& p, const Type* par) {
+    if (p.d->model == SSDE_MODEL_ESEAL_SSM) return penalty_kalman<Type>(p, par) + eseal_priors<Type>(p, par);   // :218-246
     if (is_kalman(p.d->model)) return penalty_kalman<Type>(p, par);
     return penalty_sde<Type>(p, par);
 }

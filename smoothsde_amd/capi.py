@@ -17,12 +17,12 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5}
+MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
 # types the reference dispatches (src/smoothSDE.cpp:12-27) that this engine does not cover
-UNSUPPORTED_MODELS = ("CIR", "ESEAL_SSM")
+UNSUPPORTED_MODELS = ("CIR",)
 
 NA_R_ONLY, NA_ANY_NAN = 0, 1
 PATH_NAMES = {0: "direct", 1: "isotropic-register", 2: "dense", 3: "isotropic-row-varying"}
@@ -47,6 +47,7 @@ class SsdeDesc(C.Structure):
         ("other_data", C.c_void_p), ("n_other_data", C.c_int32),
         ("n_decay", C.c_int32), ("t_decay", C.c_void_p), ("n_decay_cols", C.c_int32), ("reserved3", C.c_int32),
         ("col_decay", C.c_void_p), ("ind_decay", C.c_void_p),
+        ("eseal_h", C.c_void_p), ("eseal_R", C.c_void_p),
     ]
 
 
@@ -74,12 +75,14 @@ def _f64(a, order="F"):
 
 
 def n_sde_par(model: str, n_dim: int) -> int:
-    return n_dim + 1 if model in ("BM", "BM_SSM", "BM_t") else n_dim + 2
+    return n_dim + 1 if model in ("BM", "BM_SSM", "BM_t", "ESEAL_SSM") else n_dim + 2
 
 
 def state_dim(model: str, n_dim: int) -> int:
     if model == "CTCRW":
         return 2 * n_dim
+    if model == "ESEAL_SSM":
+        return 2
     return n_dim if model in KALMAN_MODELS else 0
 
 
@@ -98,7 +101,7 @@ class Problem:
                  X_re: Optional[Sequence] = None, S_list: Optional[Sequence] = None,
                  a0=None, P0=None, H=None, par_fixed=None, include_penalty: int = 1,
                  na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0, other_data=None,
-                 t_decay=None, col_decay=None, ind_decay=None):
+                 t_decay=None, col_decay=None, ind_decay=None, eseal_h=None, eseal_R=None):
         if model in UNSUPPORTED_MODELS:
             raise NotImplementedError(f"SDE type {model!r} is outside this engine's scope")
         if model not in MODEL_CODES:
@@ -151,7 +154,19 @@ class Problem:
         self.n_smooth = len(S_list)
         self.include_penalty = int(include_penalty)
 
-        self.kalman = model in KALMAN_MODELS
+        self.kalman = model in KALMAN_MODELS or model == "ESEAL_SSM"     # Kalman-style penalty (no constants)
+        # leading scalar parameters of the template: log_sigma_obs (nllk_ctcrw.hpp:135) or log_tau, a1, log_a2
+        # (nllk_e_seal_ssm.hpp:114-116)
+        self.lead_names = ["log_tau", "a1", "log_a2"] if model == "ESEAL_SSM" else (["log_sigma_obs"] if self.kalman else [])
+        self.eseal_h = self.eseal_R = None
+        if model == "ESEAL_SSM":
+            if self.n_dim != 1:
+                raise ValueError("ESEAL_SSM takes one response variable")
+            if eseal_h is None or eseal_R is None or a0 is None:
+                raise ValueError("ESEAL_SSM needs h (daily drift dives), R (non-lipid tissue mass) and a0 (R/sde.R:599-614)")
+            self.eseal_h, self.eseal_R = _f64(eseal_h), _f64(eseal_R)
+            if self.eseal_h.shape != (self.n,) or self.eseal_R.shape != (self.n,):
+                raise ValueError("h and R must have one entry per row")
         first = np.ones(self.n, dtype=bool)
         first[1:] = self.id[1:] != self.id[:-1]
         self.seg_start = np.flatnonzero(first)
@@ -185,11 +200,8 @@ class Problem:
             self.decay_of_col[self.col_decay] = self.ind_decay
 
         # full parameter vector layout (include/ssde.h)
-        o = 0
-        self.off_sigobs = None
-        if self.kalman:
-            self.off_sigobs = 0
-            o = 1
+        o = len(self.lead_names)
+        self.off_sigobs = 0 if self.lead_names == ["log_sigma_obs"] else None
         self.off_fe = o
         o += self.n_fe
         self.off_lambda = o
@@ -205,7 +217,7 @@ class Problem:
         fixed = np.zeros(self.n_par_full, dtype=np.uint8)
         if par_fixed is not None:
             fixed[:] = np.asarray(par_fixed, dtype=np.uint8)
-        if self.kalman and self.H is not None:
+        if self.off_sigobs is not None and self.H is not None:
             fixed[0] = 1  # map log_sigma_obs = NA when H is supplied (R/sde.R:565, 595)
         self.par_fixed = fixed
         self.na_mode, self.device, self.flags = int(na_mode), int(device), int(flags)
@@ -230,6 +242,8 @@ class Problem:
         self = cls.__new__(cls)
         if model not in MODEL_CODES:
             raise ValueError("Unknown SDE type")
+        if model in ("ESEAL_SSM", "BM_t"):
+            raise NotImplementedError("device-resident construction covers BM, OU, BM_SSM, OU_SSM, CTCRW")
         self.model = model
         if obs.dim() == 1:
             obs = obs[:, None]
@@ -261,6 +275,8 @@ class Problem:
                 raise ValueError("penalty blocks do not match the random-effect columns")
         self.include_penalty = 1
         self.kalman = model in KALMAN_MODELS
+        self.lead_names = ["log_sigma_obs"] if self.kalman else []
+        self.eseal_h = self.eseal_R = None
         first = torch.ones(self.n, dtype=torch.bool, device=ID.device)
         first[1:] = self._t_id[1:] != self._t_id[:-1]
         self.seg_start = first.nonzero().flatten().cpu().numpy()
@@ -293,9 +309,7 @@ class Problem:
 
     # -- parameter helpers ---------------------------------------------------------------
     def par_names(self):
-        names = []
-        if self.kalman:
-            names.append("log_sigma_obs")
+        names = list(self.lead_names)
         for j in range(self.q):
             names += [f"coeff_fe[{j}][{c}]" for c in range(self.ncol_fe[j])]
         names += [f"log_lambda[{s}]" for s in range(self.n_smooth)]
@@ -348,6 +362,7 @@ class Problem:
         if self.n_decay > 0:
             d.t_decay, d.n_decay_cols = ptr(self.t_decay), len(self.col_decay)
             d.col_decay, d.ind_decay = ptr(self.col_decay), ptr(self.ind_decay)
+        d.eseal_h, d.eseal_R = ptr(getattr(self, "eseal_h", None)), ptr(getattr(self, "eseal_R", None))
         return d
 
 

@@ -156,6 +156,36 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     }
 }
 
+// ---- ESEAL_SSM pre-pass (nllk_e_seal_ssm.hpp:136-137, 170-173): z_i, H_i, drift, q per row ---------------------------
+__global__ __launch_bounds__(256) void tv_prepare_eseal_kernel(const TvArgs A) {
+    const SlotTable* __restrict__ T = A.slots;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.out) A.out[A.n_out] = 0.0;
+    const double tau = exp(A.par[0]), a1 = A.par[1], a2 = exp(A.par[2]);          // :114-118
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
+        double par[2] = {0.0, 0.0};
+        for (int k = 0; k < A.n_slots; k++) {
+            const int col = T->col[k], j = T->par_j[k];
+            const double t = ((col >= 0) ? A.colbuf[(int64_t)col * A.col_stride + i] : 1.0) * A.par[T->pidx[k]];
+            par[0] += (j == 0) ? t : 0.0; par[1] += (j == 1) ? t : 0.0;
+        }
+        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : 1.0;       // :104-107
+        const double sigma = exp(par[1]);
+        double r[TV_RS];
+#pragma unroll
+        for (int k = 0; k < TV_RS; k++) r[k] = 0.0;
+        r[TVE_Z] = a2 / A.eseal_R[i];                                              // makeZ :43-48
+        r[TVE_H] = tau * tau / A.eseal_h[i];                                       // makeH :55-59
+        r[TVE_DRIFT] = par[0] * dt;                                                // makeT :16-23
+        r[TVE_Q] = sigma * sigma * dt;                                             // makeQ :30-35
+        r[TVE_DT] = dt; r[TVE_Y] = A.obs[i]; r[TVE_A1] = a1;
+        double2* o = (double2*)(A.rec + i * TV_RS);
+#pragma unroll
+        for (int k = 0; k < TV_RS / 2; k++) o[k] = make_double2(r[2 * k], r[2 * k + 1]);
+    }
+    // no planner statistics: ESEAL tracks run as one sequential window
+    if (threadIdx.x < TV_STATS) A.stats[blockIdx.x * TV_STATS + threadIdx.x] = (threadIdx.x & 1) ? -INFINITY : INFINITY;
+}
+
 // ---- finalize: hand-over checks + fixed-order sums in one launch -------------------------------------------------
 // check: item (pack, c, b) arrived vs item + 1 = (pack, c + 1, b) warmed up; one wave per item
 __device__ __forceinline__ double tv_check_item(const TvArgs& A, int item, int lane, int nstate) {
@@ -244,6 +274,10 @@ hipError_t launch_tv_a0(const TvArgs& a, const double* a0_src, const int64_t* tr
 }
 
 hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s) {
+    if (a.model == M_ESEAL) {
+        hipLaunchKernelGGL(tv_prepare_eseal_kernel, dim3(a.stats_blocks), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
 #define X(MODEL, D)                                                                                         \
     if (a.model == MODEL && a.d == D) {                                                                     \
         if (a.dense) hipLaunchKernelGGL((tv_prepare_kernel<MODEL, D, true>), dim3(a.stats_blocks), dim3(256), 0, s, a);  \
@@ -264,7 +298,8 @@ hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s) {
 
 hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s) {
     const int sd = a.model == M_CTCRW ? 2 * a.d : a.d;
-    const int nstate = a.dense ? 2 * (sd + sd * sd) : (a.model == M_CTCRW ? 4 * a.d + 6 : 2 * a.d + 2);
+    const int nstate = a.model == M_ESEAL ? TvEsealLane::NSTATE
+                     : a.dense ? 2 * (sd + sd * sd) : (a.model == M_CTCRW ? 4 * a.d + 6 : 2 * a.d + 2);
     const int n_check = (a.n_items + 3) / 4;
     hipLaunchKernelGGL(tv_finalize_kernel, dim3(n_check + a.n_out), dim3(256), 0, s, a, nstate, n_check);
     return hipGetLastError();

@@ -5,6 +5,13 @@
 namespace ssde {
 
 hipError_t launch_tv_filter_dense(const TvArgs& a, bool want_grad, hipStream_t s) {
+    if (a.model == M_ESEAL) {                       // scalar lipid-mass filter (TvEsealOps), no report variant
+        if (a.n_items == 0) return hipSuccess;
+        dim3 grid((a.n_items + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
+        if (want_grad) hipLaunchKernelGGL((tv_filter_kernel<TvEsealOps, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((tv_filter_kernel<TvEsealOps, false, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     SSDE_TV_LAUNCH_FILTER(TvDenseOps)
 }
 

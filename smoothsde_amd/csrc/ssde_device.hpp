@@ -287,6 +287,8 @@ struct TvArgs {
     int has_h;
     const double* h_array;       // [d x d x n] or NULL
     double p0f[16];              // sdim x sdim column-major (dense lanes)
+    const double* eseal_h;       // ESEAL_SSM: daily drift dives h_i and non-lipid tissue mass R_i (nllk_e_seal_ssm.hpp:100-101)
+    const double* eseal_R;
     double* bnd;                 // [n_items][2][TV_NSTATE][64]
     double* gval;                // [n_items][64] per-lane nllk
     double* gdir;                // [n_items][64] per-lane d nllk / d direction

@@ -144,7 +144,7 @@ struct ssde_handle {
     int iso_free_mask = 0;
 
     // row-varying isotropic path (k_tv.hip)
-    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats, tv_harr;
+    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats, tv_harr, tv_eh, tv_eR;
     bool tv_dense = false;         // full-covariance lanes: per-row H_array and / or a P0 that is not block-identical
     DevBuf<TvDir> tv_dirs;
     DevBuf<int64_t> tv_row0;
@@ -197,7 +197,7 @@ void destroy(ssde_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
     if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
-    h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
+    h->tv_eh.release(); h->tv_eR.release(); h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
     h->tv_gval.release(); h->tv_gdir.release(); h->tv_stats.release(); h->tv_dirs.release(); h->tv_row0.release();
     h->tv_ns.release(); h->tv_items_g.release(); h->tv_items_v.release();
     for (int i = 0; i < 2; i++) if (h->tv_gexec[i]) (void)hipGraphExecDestroy(h->tv_gexec[i]);
@@ -283,6 +283,7 @@ void tv_base_args(const ssde_handle* h, TvArgs& a) {
     for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
     a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
     for (int i = 0; i < 16; i++) a.p0f[i] = h->p0_full[i];
+    a.eseal_h = h->tv_eh.p; a.eseal_R = h->tv_eR.p;
     a.bnd = h->tv_bnd.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
     a.stats = h->tv_stats.p; a.stats_blocks = h->tv_stats_blocks;
     a.n_out = 1 + h->L.n_full;
@@ -298,6 +299,14 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     HIPCHK(h, stage(d->times, (size_t)n, on_dev, h->times));
     HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, on_dev, h->obs));
     if (h->has_h) HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, on_dev, h->tv_harr));
+    if (is_eseal(d->model)) {
+        HIPCHK(h, stage(d->eseal_h, (size_t)n, on_dev, h->tv_eh));
+        HIPCHK(h, stage(d->eseal_R, (size_t)n, on_dev, h->tv_eR));
+        // priors (nllk_e_seal_ssm.hpp:212-216): n and the design weights of log sigma at the first row
+        h->pen.eseal_n = n;
+        for (auto& sl : h->slots)
+            if (sl.par_j == 1) h->pen.eseal_sig0.push_back({sl.pidx, sl.col >= 0 ? sl.src[0] : 1.0});
+    }
     h->col_stride = ((n + 63) / 64) * 64 + 160;
     HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * h->n_stream_cols));
     for (auto& sl : h->slots)
@@ -333,7 +342,11 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     // gradient directions: log_sigma_obs, then every free coefficient slot
     std::vector<TvDir> dirs;
     for (int k = 0; k < MAX_PAR; k++) h->tv_dir_of_par[k] = -1;
-    if (!h->fixed[0]) { h->tv_dir_of_par[0] = (int16_t)dirs.size(); dirs.push_back({TVK_SIG, 0, 0, -1}); }
+    if (!h->fixed[0]) { h->tv_dir_of_par[0] = (int16_t)dirs.size(); dirs.push_back({TVK_SIG, 0, 0, -1}); }   // log_sigma_obs / log_tau
+    if (is_eseal(d->model)) {                                            // a1, log_a2 (nllk_e_seal_ssm.hpp:115-116)
+        if (!h->fixed[1]) { h->tv_dir_of_par[1] = (int16_t)dirs.size(); dirs.push_back({TVK_A1, 0, 1, -1}); }
+        if (!h->fixed[2]) { h->tv_dir_of_par[2] = (int16_t)dirs.size(); dirs.push_back({TVK_A2, 0, 2, -1}); }
+    }
     for (size_t k = 0; k < h->slots.size(); k++) {
         const Slot& sl = h->slots[k];
         if (h->fixed[sl.pidx]) continue;
@@ -437,7 +450,7 @@ double closed_loop_rho(int model, double dt, double p1, double p2, double hobs, 
 // hand-over check decides whether it was enough.  Rebuilds the work-item tables when the plan changes.
 int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2 (replaced by the largest diag(H) with H_array)
     int W = 0;
-    if (h->max_chunks > 1 && h->tv_stats_valid) {
+    if (h->max_chunks > 1 && h->tv_stats_valid && !is_eseal(h->model)) {   // ESEAL tracks: one sequential window
         double lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int b = 0; b < h->tv_stats_blocks; b++)
             for (int k = 0; k < 4; k++) {
@@ -608,7 +621,18 @@ int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) 
 int build(const ssde_desc* d, ssde_handle* h) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
-    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_BM_T) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_ESEAL_SSM) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (is_eseal(d->model)) {
+        // nllk_e_seal_ssm.hpp: one response, state (1, lipid mass) with a0 = (1, L0) and P0 = diag(0, p0) (R/sde.R:602-603):
+        // the constant first component is what turns the 2 x 2 filter into the scalar filter of ssde_tv.hpp
+        if (d->n_dim != 1) return fail(h, SSDE_ERR_MODEL, "ESEAL_SSM takes one response variable");
+        if (!d->a0 || !d->eseal_h || !d->eseal_R) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM needs a0, eseal_h and eseal_R");
+        if (d->p0 && (d->p0[0] != 0.0 || d->p0[1] != 0.0 || d->p0[2] != 0.0))
+            return fail(h, SSDE_ERR_ARG, "ESEAL_SSM: P0 must be diag(0, p0) (R/sde.R:603)");
+        for (int64_t sgi = 0; sgi < d->n_seg; sgi++)
+            if (d->a0[sgi] != 1.0) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM: the first column of a0 must be 1 (R/sde.R:602)");
+        if (d->flags & SSDE_FLAG_DEVICE_DATA) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM takes host arrays");
+    }
     if (d->model == SSDE_MODEL_BM_T) {
         // tr_dens.hpp:38-44 reads par(0), par(1) whatever the dimension: one response variable
         if (d->n_dim != 1) return fail(h, SSDE_ERR_MODEL, "BM_t takes one response variable");
@@ -697,6 +721,14 @@ int build(const ssde_desc* d, ssde_handle* h) {
     HIPCHK(h, hipEventCreate(&h->ev_k0));
     HIPCHK(h, hipEventCreate(&h->ev_k1));
 
+    // ---- ESEAL_SSM: the lane = direction kernels with the scalar lipid-mass lanes ----------------------------
+    if (is_eseal(d->model)) {
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) h->p0_full[i + j * 2] = p0_entry(d, i, j);
+        h->tv_dense = true;
+        int st = build_tv(d, h, starts, on_dev);
+        if (st) return st;
+    } else
     // ---- direct families --------------------------------------------------------------------------
     if (!is_kalman(d->model)) {
         h->path = PATH_DIRECT;
@@ -1445,7 +1477,7 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
 int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* aest_all) {
     if (!h || !par || !aest_all) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
-    if (!is_kalman(h->model)) { h->err = "aest_all is reported by the Kalman families only"; return SSDE_ERR_MODEL; }
+    if (!is_kalman(h->model)) { h->err = "aest_all is reported by the Kalman families only (the ESEAL template has no REPORT)"; return SSDE_ERR_MODEL; }
     HIPCHK(h, hipSetDevice(h->device));
     if (h->path == PATH_TV) {
         // one sequential window per track, direction block 0, states written straight to the long format

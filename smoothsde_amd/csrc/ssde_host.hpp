@@ -19,11 +19,13 @@ constexpr int kMaxPar = 320;   // == ssde::MAX_PAR
 inline bool is_kalman(int model) {
     return model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_OU_SSM || model == SSDE_MODEL_CTCRW;
 }
+inline bool is_eseal(int model) { return model == SSDE_MODEL_ESEAL_SSM; }
 inline int state_dim(int model, int d) {
+    if (is_eseal(model)) return 2;                        // (1, lipid mass): nllk_e_seal_ssm.hpp:150-158
     return model == SSDE_MODEL_CTCRW ? 2 * d : (is_kalman(model) ? d : 0);
 }
 inline int n_sde_par(int model, int d) {
-    return (model == SSDE_MODEL_BM || model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_BM_T) ? d + 1 : d + 2;
+    return (model == SSDE_MODEL_BM || model == SSDE_MODEL_BM_SSM || model == SSDE_MODEL_BM_T || is_eseal(model)) ? d + 1 : d + 2;
 }
 
 // full parameter vector layout (include/ssde.h, PARAMETER VECTOR)
@@ -48,6 +50,7 @@ inline ParLayout make_layout(const ssde_desc* d) {
     L.n_lambda = d->n_smooth;
     int o = 0;
     if (is_kalman(d->model)) { L.off_sig = 0; o = 1; }   // PARAMETER(log_sigma_obs) first (nllk_ctcrw.hpp:135)
+    if (is_eseal(d->model)) o = 3;                       // log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
     L.off_fe = o; o += L.n_fe;
     L.off_lambda = o; o += L.n_lambda;
     L.n_decay = (!is_kalman(d->model) && d->n_decay > 0) ? d->n_decay : 0;     // PARAMETER_VECTOR(log_decay), nllk_sde.hpp:44
@@ -98,6 +101,7 @@ inline double p0_entry(const ssde_desc* d, int i, int j) {
     const int sdim = state_dim(d->model, d->n_dim);
     if (d->p0) return d->p0[i + j * sdim];
     if (i != j) return 0.0;
+    if (is_eseal(d->model)) return i == 1 ? 10.0 : 0.0;                    // diag(c(0, 10)), R/sde.R:603
     if (d->model == SSDE_MODEL_CTCRW) return (i % 2 == 0) ? 1.0 : 10.0;   // R/sde.R:584
     return 10.0;                                                           // R/sde.R:554
 }
@@ -151,6 +155,10 @@ struct Penalty {
     std::vector<int> ncol;
     std::vector<std::vector<double>> S;   // column-major blocks
     std::vector<double> logdet;           // log|det S_s|
+    // ESEAL_SSM priors (nllk_e_seal_ssm.hpp:212-216): inverse gamma on sigma(0)^2 -- the FIRST row's sigma -- and
+    // on tau^2; (full-par index, design weight at row 0) of every coefficient of log sigma
+    int64_t eseal_n = 0;
+    std::vector<std::pair<int, double>> eseal_sig0;
 
     void setup(const ssde_desc* d) {
         model = d->model;
@@ -160,13 +168,33 @@ struct Penalty {
             int n = d->smooth_ncol[s];
             ncol.push_back(n);
             S.emplace_back(p, p + (size_t)n * n);
-            logdet.push_back(is_kalman(model) ? 0.0 : logabsdet(S.back(), n));
+            logdet.push_back((is_kalman(model) || is_eseal(model)) ? 0.0 : logabsdet(S.back(), n));
             p += (size_t)n * n;
         }
     }
+    // -(log priors) and their gradient; dinvgamma(x, shape, scale) = shape log(scale) - lgamma(shape) - (shape+1) log x - scale/x
+    double eseal_priors(const double* par, double* grad) const {
+        const double n = (double)eseal_n, nh = (double)(eseal_n / 2);   // integer division, as in the reference
+        double ls0 = 0.0;
+        for (auto& e : eseal_sig0) ls0 += e.second * par[e.first];
+        const double x1 = std::exp(2.0 * ls0), sh1 = 10.0 * n, sc1 = 4.0 * (10.0 * n - 1.0);
+        const double x2 = std::exp(2.0 * par[0]), sh2 = nh, sc2 = nh - 1.0;
+        const double lp = (sh1 * std::log(sc1) - std::lgamma(sh1) - (sh1 + 1.0) * std::log(x1) - sc1 / x1) +
+                          (sh2 * std::log(sc2) - std::lgamma(sh2) - (sh2 + 1.0) * std::log(x2) - sc2 / x2);
+        if (grad) {
+            const double d1 = 2.0 * (sh1 + 1.0) - 2.0 * sc1 / x1;       // d(-lp)/d log sigma0
+            for (auto& e : eseal_sig0) grad[e.first] += d1 * e.second;
+            grad[0] += 2.0 * (sh2 + 1.0) - 2.0 * sc2 / x2;              // d(-lp)/d log tau
+        }
+        return -lp;
+    }
     double eval(const ParLayout& L, const double* par, double* grad /* may be NULL; added into */) const {
+        if (is_eseal(model)) return eval_smooth(L, par, grad) + eseal_priors(par, grad);
+        return eval_smooth(L, par, grad);
+    }
+    double eval_smooth(const ParLayout& L, const double* par, double* grad) const {
         if (ncol.empty()) return 0.0;                                   // ncol_re(0) > 0
-        if (!is_kalman(model) && !include_penalty) return 0.0;          // nllk_sde.hpp:91
+        if (!is_kalman(model) && !is_eseal(model) && !include_penalty) return 0.0;   // nllk_sde.hpp:91
         double pen = 0.0;
         int start = 0;
         for (size_t s = 0; s < ncol.size(); s++) {
@@ -182,7 +210,7 @@ struct Penalty {
                 if (grad) grad[L.off_re + start + a] += 0.5 * lam * (Sx + Stx);
             }
             pen += -0.5 * n * ll + 0.5 * lam * quad;
-            if (!is_kalman(model)) pen += 0.5 * n * std::log(2.0 * M_PI) - 0.5 * logdet[s];
+            if (!is_kalman(model) && !is_eseal(model)) pen += 0.5 * n * std::log(2.0 * M_PI) - 0.5 * logdet[s];
             if (grad) grad[L.off_lambda + s] += -0.5 * n + 0.5 * lam * quad;
             start += n;
         }

@@ -38,7 +38,7 @@ namespace ssde {
 enum { DIR_SIG = 1, DIR_MU = 2, DIR_P1 = 4, DIR_P2 = 8 };
 
 // model codes (== SSDE_MODEL_* of include/ssde.h)
-enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4, M_BM_T = 5 };
+enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4, M_BM_T = 5, M_ESEAL = 6 };
 
 // R_IsNA / any-NaN test on the bit pattern (Q5)
 SSDE_HD bool is_na(double x, int any_nan) {

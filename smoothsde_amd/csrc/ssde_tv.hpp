@@ -25,7 +25,7 @@
 namespace ssde {
 
 constexpr int TV_RS = 16;   // doubles per row record (128 B: four 16-byte loads per lane)
-enum { TVK_NONE = 0, TVK_SIG = 1, TVK_MU = 2, TVK_P1 = 3, TVK_P2 = 4 };
+enum { TVK_NONE = 0, TVK_SIG = 1, TVK_MU = 2, TVK_P1 = 3, TVK_P2 = 4, TVK_A1 = 5, TVK_A2 = 6 };
 
 // Record layout
 //   CTCRW : 0 e  1 t12  2 b1  3 q11  4 q12  5 q22 | d/d par[D]: 6 de  7 dt12  8 dq11  9 dq12  10 dq22
@@ -313,6 +313,69 @@ struct TvDenseOps {
         double y[D];
         for (int a = 0; a < D; a++) y[a] = r[TVD_Y + a];
         dense_step<MODEL, D, 1>(S.L, par, H, r[TVD_DT], y, is_na(y[0], any_nan));
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// ESEAL_SSM (nllk_e_seal_ssm.hpp:139-207).  The first state component is the constant 1 (a0 = (1, L0),
+// P0 = diag(0, p0), R/sde.R:602-603; T and Q never touch it), so the 2 x 2 filter is a SCALAR filter on the lipid
+// mass L with a row-varying observation loading:
+//     y_i = a1 + z_i L + N(0, H_i),  z_i = a2 / R_i,  H_i = tau^2 / h_i;    L' = L + mu_i dt_i + N(0, sigma_i^2 dt_i)
+// Record: 0 z  1 H  2 mu dt  3 sigma^2 dt  4 dt  5 y  6 a1.   Directions: TVK_SIG = log tau (dH = 2 H),
+// TVK_A1 = a1, TVK_A2 = log a2 (dz = z), TVK_MU = a coefficient of mu (d drift = w dt), TVK_P1 = of log sigma (dq = 2 q w).
+// ---------------------------------------------------------------------------------------
+constexpr int TVE_Z = 0, TVE_H = 1, TVE_DRIFT = 2, TVE_Q = 3, TVE_DT = 4, TVE_Y = 5, TVE_A1 = 6;
+
+struct TvEsealLane {
+    static constexpr int SD = 2;
+    static constexpr int NSTATE = 4;
+    double x, p, tx, dp;
+    LogAcc ld;
+    double accq, gld, gq;
+    bool has_h;                                    // (unused; the kernel sets it on full-covariance lanes)
+    SSDE_HD void init(const double* a0 /* (1, L0) */, const double* p0 /* 2 x 2 column-major */) {
+        x = a0[1]; p = p0[3]; tx = dp = 0.0;
+        reset_acc();
+    }
+    SSDE_HD void warm_init(const double*, const double* p0) { x = 0.0; p = p0[3]; tx = dp = 0.0; reset_acc(); }
+    SSDE_HD void reset_acc() { ld.init(); accq = gld = gq = 0.0; }
+    SSDE_HD void dump(double* o) const { o[0] = x; o[1] = p; o[2] = tx; o[3] = dp; }
+    SSDE_HD void state(double* o) const { o[0] = 1.0; o[1] = x; }
+    SSDE_HD double value() const { return 0.5 * (ld.value() + accq); }
+    SSDE_HD double grad() const { return 0.5 * gld + gq; }
+};
+
+struct TvEsealOps {
+    typedef TvEsealLane Lane;
+    static constexpr int U = 4;
+    static constexpr int Y_OFF = TVE_Y;
+    static constexpr bool DENSE = true;            // initial covariance from the full P0
+    template <bool GRAD>
+    SSDE_HD static void step(Lane& L, const double* r, double, int kind, int, double w, int any_nan) {
+        const double z = r[TVE_Z], H = r[TVE_H], drift = r[TVE_DRIFT], q = r[TVE_Q];
+        const bool na = is_na(r[TVE_Y], any_nan);                      // line 175
+        const double F = z * z * L.p + H;                              // line 184
+        const bool upd = !na && (F > 0.0);                             // line 187
+        const double iF = upd ? rcp(F) : 0.0;
+        L.ld.mul(upd ? F : 1.0);
+        const double u = upd ? r[TVE_Y] - r[TVE_A1] - z * L.x : 0.0;   // line 182
+        const double k = L.p * z * iF;                                 // K = T P Z' F^-1, second row (line 197)
+        L.accq += iF * u * u;
+        if (GRAD) {
+            const double dz = (kind == TVK_A2) ? z : 0.0, dH = (kind == TVK_SIG) ? 2.0 * H : 0.0;
+            const double da1 = (kind == TVK_A1) ? 1.0 : 0.0;
+            const double ddrift = (kind == TVK_MU) ? w * r[TVE_DT] : 0.0, dq = (kind == TVK_P1) ? 2.0 * q * w : 0.0;
+            const double dF = 2.0 * z * dz * L.p + z * z * L.dp + dH;
+            const double du = upd ? -da1 - dz * L.x - z * L.tx : 0.0;
+            const double diF = -iF * iF * dF;
+            L.gld += dF * iF;
+            L.gq += 0.5 * diF * u * u + iF * u * du;
+            const double dk = (L.dp * z + L.p * dz) * iF + L.p * z * diF;
+            L.tx = L.tx + ddrift + dk * u + k * du;
+            L.dp = L.dp * (1.0 - k * z) - L.p * (dk * z + k * dz) + dq;
+        }
+        L.x = L.x + drift + k * u;                                     // lines 176, 188, 199
+        L.p = L.p * (1.0 - k * z) + q;                                 // lines 177, 189, 201-202
     }
 };
 

@@ -99,7 +99,9 @@ class SdReport:
 
 
 def _block_name(pb, k: int) -> str:
-    if pb.kalman and k == 0:
+    if k < len(getattr(pb, "lead_names", [])):
+        return pb.lead_names[k]
+    if not hasattr(pb, "lead_names") and pb.kalman and k == 0:
         return "log_sigma_obs"
     if pb.off_fe <= k < pb.off_fe + pb.n_fe:
         return "coeff_fe"

@@ -31,6 +31,7 @@ PAR_NAMES = {
     "BM": lambda d: _mu_names(d) + ["sigma"],
     "BM_t": lambda d: ["mu", "sigma"],                   # R/sde.R:61
     "BM_SSM": lambda d: _mu_names(d) + ["sigma"],
+    "ESEAL_SSM": lambda d: ["mu", "sigma"],              # R/sde.R:70
     "OU": lambda d: _mu_names(d) + ["tau", "kappa"],
     "OU_SSM": lambda d: _mu_names(d) + ["tau", "kappa"],
     "CTCRW": lambda d: _mu_names(d) + ["tau", "nu"],
@@ -239,6 +240,11 @@ class SDE:
         X_re = [d.X_re for d in self.designs_]
         kw = dict(a0=None, P0=self.other_data_.get("P0"), H=self.other_data_.get("H"), include_penalty=include_penalty,
                   other_data=self.other_data_.get("df") if self.type_ == "BM_t" else None)   # R/sde.R:539-541
+        if self.type_ == "ESEAL_SSM":                          # R/sde.R:599-614: a0 = (1, first dep_fat of every track)
+            ids = np.asarray(self.data_["ID"])
+            first = np.r_[True, ids[1:] != ids[:-1]]
+            kw.update(a0=np.column_stack([np.ones(first.sum()), np.asarray(self.data_["dep_fat"], dtype=float)[first]]),
+                      P0=np.diag([0.0, 10.0]), eseal_h=self.data_["h"], eseal_R=self.data_["R"])
         if self.other_data_.get("t_decay") is not None:        # decaying response model, R/sde.R:635-644 (1-based in R)
             kw.update(t_decay=self.other_data_["t_decay"],
                       col_decay=np.asarray(self.other_data_["col_decay"], dtype=int) - 1,
@@ -256,8 +262,10 @@ class SDE:
 
     def _par_full(self, pb):
         p = np.zeros(pb.n_par_full)
-        if pb.kalman:
+        if pb.lead_names == ["log_sigma_obs"]:
             p[0] = 0.0                                      # log_sigma_obs = 0 (R/sde.R:560, 590)
+        elif self.type_ == "ESEAL_SSM":
+            p[0:3] = [np.log(1.0), -0.578, np.log(1.214)]   # ssm_par, R/sde.R:606-608
         p[pb.off_fe:pb.off_fe + pb.n_fe] = self.coeff_fe_
         p[pb.off_lambda:pb.off_lambda + pb.n_smooth] = np.log(self.lambda_vals_)
         if pb.n_decay:
@@ -314,7 +322,7 @@ class SDE:
         pb = self.problem_
         self.par_full_ = full
         self.tmb_rep_ = None
-        self.log_sigma_obs_ = full[0] if pb.kalman else None
+        self.log_sigma_obs_ = full[0] if pb.lead_names == ["log_sigma_obs"] else None
         self.coeff_fe_ = full[pb.off_fe:pb.off_fe + pb.n_fe].copy()        # R/sde.R:707-713
         self.coeff_re_ = full[pb.off_re:pb.off_re + pb.n_re].copy()
         if pb.n_smooth:

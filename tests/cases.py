@@ -147,11 +147,46 @@ def elephant_spec():
     return spec
 
 
+def eseal_spec(name, seed, lengths, variant="const", na_rows=()):
+    """Elephant-seal body-condition model (nllk_e_seal_ssm.hpp): drift rate observations, lipid mass state."""
+    rng = np.random.default_rng(seed)
+    ID, times, L0s, obs, hh, RR = [], [], [], [], [], []
+    t0 = 0.0
+    for k, T in enumerate(lengths):
+        dts = rng.uniform(0.7, 1.5, size=T)
+        tt = t0 + np.cumsum(dts)
+        t0 = tt[-1] + 5.0
+        L = 30.0 + 5.0 * k + np.cumsum(0.3 * dts + 0.4 * np.sqrt(dts) * rng.standard_normal(T))
+        R = rng.uniform(150.0, 250.0, size=T)
+        h = rng.integers(3, 25, size=T).astype(float)
+        y = -0.578 + 1.214 * L / R + rng.standard_normal(T) / np.sqrt(h)
+        ID += [float(k)] * T; times += list(tt); L0s.append(L[0]); obs += list(y); hh += list(h); RR += list(R)
+    n = len(ID)
+    obs = np.array(obs)[:, None]
+    for r in na_rows:
+        obs[r, 0] = float("nan")
+    spec = dict(name=name, model="ESEAL_SSM", n_dim=1, ID=np.array(ID), times=np.array(times), obs=obs, X_fe=None,
+                X_re=None, S_list=None, a0=np.column_stack([np.ones(len(lengths)), L0s]), P0=None, H=None,
+                par_fixed=None, na_mode=1, include_penalty=1, eseal_h=np.array(hh), eseal_R=np.array(RR))
+    p = [rng.uniform(-0.3, 0.3), -0.578 + rng.uniform(-0.1, 0.1), np.log(1.214) + rng.uniform(-0.1, 0.1)]
+    if variant == "const":
+        p += [rng.uniform(0.1, 0.5), rng.uniform(-1.2, -0.5)]
+    else:
+        x = np.clip((np.sin(np.linspace(0, 5, n)) + 1) / 2 + 0.05 * rng.standard_normal(n), 0, 1)
+        spec.update(X_fe=[np.column_stack([np.ones(n), x]), None], X_re=[None, bspline_basis(x, n_basis=4)],
+                    S_list=[second_difference_penalty(4)])
+        p += [rng.uniform(0.1, 0.5), rng.uniform(-0.3, 0.3), rng.uniform(-1.2, -0.5)]   # mu: intercept + slope, log sigma
+        p += [rng.uniform(-0.5, 1.0)]                                                      # log_lambda
+        p += list(rng.uniform(-0.3, 0.3, size=4))                                          # coeff_re
+    spec["par"] = np.array(p)
+    return spec
+
+
 def problem_from_spec(spec, **over) -> Problem:
     kw = dict(a0=spec.get("a0"), P0=spec.get("P0"), H=spec.get("H"), par_fixed=spec.get("par_fixed"),
               include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1),
               other_data=spec.get("other_data"), t_decay=spec.get("t_decay"), col_decay=spec.get("col_decay"),
-              ind_decay=spec.get("ind_decay"))
+              ind_decay=spec.get("ind_decay"), eseal_h=spec.get("eseal_h"), eseal_R=spec.get("eseal_R"))
     kw.update(over)
     return Problem(spec["model"], spec["ID"], spec["times"], spec["obs"], spec.get("X_fe"), spec.get("X_re"),
                    spec.get("S_list"), **kw)
@@ -195,4 +230,7 @@ def all_specs():
     # decaying random-effect columns (nllk_sde.hpp:47-58): one rate, two rates
     specs.append(make_spec("OU_d1_decay", "OU", 1, seed=201, lengths=[18, 12], variant="tv", na_rows=(7,), decay=True))
     specs.append(make_spec("BM_d2_decay2", "BM", 2, seed=202, lengths=[15, 14], variant="tv2", decay=True))
+    # elephant-seal state-space model (nllk_e_seal_ssm.hpp)
+    specs.append(eseal_spec("ESEAL_const", 211, [14, 9, 11], na_rows=(4, 20)))
+    specs.append(eseal_spec("ESEAL_tv", 212, [16, 12], variant="tv", na_rows=(6,)))
     return specs

@@ -50,7 +50,7 @@ def main():
     for spec in all_specs():
         pb = problem_from_spec(spec)
         par = spec["par"]
-        if pb.kalman:
+        if pb.kalman and pb.model != "ESEAL_SSM":     # (the ESEAL template has no REPORT)
             val, grad, aest = oracle_eval(pb, par, order=1, report=True)
         else:
             val, grad = oracle_eval(pb, par, order=1)

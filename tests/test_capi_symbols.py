@@ -34,11 +34,11 @@ def test_desc_struct_matches_header_layout():
     src = open(os.path.join(ROOT, "include", "ssde.h")).read()
     body = src[src.index("typedef struct ssde_desc {"):src.index("} ssde_desc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b([a-z_0-9]+)\s*;", body)
+    fields = re.findall(r"\b([A-Za-z_0-9]+)\s*;", body)
     assert fields == [f for f, _ in capi.SsdeDesc._fields_]
     body = src[src.index("typedef struct ssde_info_t {"):src.index("} ssde_info_t;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b([a-z_0-9]+)\s*;", body)
+    fields = re.findall(r"\b([A-Za-z_0-9]+)\s*;", body)
     assert fields == [f for f, _ in capi.SsdeInfo._fields_]
 
 

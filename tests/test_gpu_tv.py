@@ -256,3 +256,49 @@ def test_constant_coefficients_with_custom_P0():
     oval, ograd = _oracle(pb, par)
     _close(val, grad, oval, ograd)
     eng.close()
+
+
+# ---- ESEAL_SSM (nllk_e_seal_ssm.hpp): scalar lipid-mass lanes --------------------------------------------------------
+def _eseal_problem(lengths=(300, 180, 240), seed=3, smooth=True, par_fixed=None):
+    from cases import eseal_spec
+    spec = eseal_spec("x", seed, list(lengths), variant="tv" if smooth else "const", na_rows=(7, 50, 51))
+    pb = problem_from_spec(spec, par_fixed=par_fixed)
+    return pb, spec["par"]
+
+
+def test_eseal_long_tracks_vs_oracle():
+    pb, par = _eseal_problem()
+    assert pb.par_names()[:3] == ["log_tau", "a1", "log_a2"] and pb.off_fe == 3
+    eng = capi.Engine(pb)
+    info = eng.info()
+    assert info["path"] == PATH_TV and info["sdim"] == 2
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert eng.eval(par, order=0) == val
+    # the priors (inverse gamma on sigma(0)^2 and tau^2, nllk_e_seal_ssm.hpp:212-216) live in ssde_penalty
+    pen, gpen = eng.penalty(par)
+    dval, dgrad = _oracle(pb, par, data_only=True)
+    assert abs((val - pen) - dval) <= 1e-10 * abs(dval)
+    assert np.max(np.abs((grad - gpen) - dgrad)) <= 1e-8 * np.max(np.abs(dgrad)) + 1e-10
+    eng.close()
+
+
+def test_eseal_fixed_ssm_parameters_and_errors():
+    fixed = np.zeros(11, dtype=np.uint8)
+    fixed[[1, 2]] = 1                        # a1, log_a2 held at their values (map), as Schick et al. fix them
+    pb, par = _eseal_problem(par_fixed=fixed)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert grad[1] == 0.0 and grad[2] == 0.0
+    with pytest.raises(capi.EngineError):
+        eng.report(par)                      # the ESEAL template has no REPORT(aest_all)
+    eng.close()
+    with pytest.raises(ValueError):
+        capi.Problem("ESEAL_SSM", pb.id, pb.times, pb.obs, a0=pb.a0)          # h and R missing
+    bad = pb.a0.copy(); bad[0, 0] = 2.0
+    pb_bad = capi.Problem("ESEAL_SSM", pb.id, pb.times, pb.obs, a0=bad, eseal_h=pb.eseal_h, eseal_R=pb.eseal_R)
+    with pytest.raises(capi.EngineError):
+        capi.Engine(pb_bad)
