@@ -1,0 +1,125 @@
+"""GPU suite: seeded random problems across every model and kernel path against the oracle.
+
+Each case draws a model, the number / lengths of tracks (ragged, including one- and two-row tracks), a regular or
+irregular time grid, missing rows, which SDE parameters get covariate columns or smooths, which parameters are held
+fixed (TMB's `map`), and optionally H_array / P0 / a0 / BM_t's df / decaying columns.  Small sizes (the oracle
+finishes in milliseconds), many shapes: this is the net for rare indexing / masking bugs, not a throughput test.
+
+Tolerances (fp64): value 1e-10 * max(1,|v|); gradient 1e-8 * max|g| + 1e-10."""
+import numpy as np
+import pytest
+
+from smoothsde_amd import capi
+from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["CTCRW", "OU_SSM", "BM_SSM", "OU", "BM", "BM_t", "ESEAL_SSM"]
+
+
+def _oracle(pb, par):
+    from oracle_lib import oracle_eval
+    return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4)
+
+
+def random_problem(seed):
+    rng = np.random.default_rng(seed)
+    model = MODELS[seed % len(MODELS)]
+    d = 1 if model in ("BM_t", "ESEAL_SSM") else int(rng.integers(1, 3))
+    kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
+    n_tracks = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(60, 140))
+    long_tracks = rng.random() < 0.35
+    lens = rng.integers(1, 12, size=n_tracks) if not long_tracks else rng.integers(150, 700, size=n_tracks)
+    if n_tracks > 20:
+        lens = rng.integers(1, 40, size=n_tracks)
+    if lens.sum() < 2:
+        lens[0] = 3
+    if model == "ESEAL_SSM":
+        lens = np.maximum(lens, 2)
+    ID = np.repeat(np.arange(n_tracks), lens).astype(float)
+    n = len(ID)
+    regular = rng.random() < 0.5
+    times = np.arange(1.0, n + 1) if regular else np.cumsum(rng.uniform(0.4, 1.8, size=n))
+    scale = 0.3 if model != "CTCRW" else 1.0
+    obs = np.cumsum(rng.standard_normal((n, d)) * scale, axis=0) + (3.0 if model in ("OU", "OU_SSM") else 0.0)
+    if model in ("OU", "OU_SSM"):
+        obs = 3.0 + rng.standard_normal((n, d))
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    kw = {}
+    if model == "ESEAL_SSM":
+        R = rng.uniform(150, 250, size=n)
+        h = rng.integers(3, 25, size=n).astype(float)
+        L = 30 + np.cumsum(0.2 + 0.3 * rng.standard_normal(n))
+        obs = (-0.58 + 1.2 * L / R + rng.standard_normal(n) / np.sqrt(h))[:, None]
+        kw.update(eseal_h=h, eseal_R=R, a0=np.column_stack([np.ones(n_tracks), L[first]]))
+    na_frac = rng.choice([0.0, 0.0, 0.05, 0.2])
+    na = (rng.random(n) < na_frac) & (~first if (kalman or model == "ESEAL_SSM") else np.ones(n, bool))
+    if kalman or model == "ESEAL_SSM":
+        obs[na, :] = np.nan
+    else:
+        obs[na, rng.integers(0, d, size=int(na.sum()))] = np.nan
+    q = capi.n_sde_par(model, d)
+    x = np.clip((np.sin(np.arange(n) * 0.07 + seed) + 1) / 2 + 0.05 * rng.standard_normal(n), 0, 1)
+    X_fe, X_re, S_list = [None] * q, [None] * q, []
+    style = rng.choice(["const", "const", "slope", "smooth", "both"])
+    if style in ("slope", "both"):
+        j = int(rng.integers(0, q))
+        X_fe[j] = np.column_stack([np.ones(n), x])
+    if style in ("smooth", "both"):
+        for j in sorted(set(int(v) for v in rng.integers(0, q, size=int(rng.integers(1, 3))))):
+            k = int(rng.integers(3, 7))
+            X_re[j] = bspline_basis(np.clip(x ** (1 + 0.5 * j), 0, 1), n_basis=k)
+            S_list.append(second_difference_penalty(k))
+    if kalman and rng.random() < 0.25:
+        A = rng.standard_normal((n, d, d)) * 0.2
+        kw["H"] = np.einsum("nij,nkj->ikn", A, A) + 0.05 * np.eye(d)[:, :, None]
+    sdim = capi.state_dim(model, d)
+    if kalman and rng.random() < 0.25:
+        A = rng.standard_normal((sdim, sdim))
+        kw["P0"] = A @ A.T + np.eye(sdim)
+    if kalman and rng.random() < 0.2:
+        kw["a0"] = rng.standard_normal((n_tracks, sdim)) + (3.0 if model == "OU_SSM" else 0.0)
+    if model == "BM_t":
+        kw["other_data"] = float(rng.uniform(2.5, 9.0))
+    n_re = sum(0 if b is None else b.shape[1] for b in X_re)
+    if not kalman and model != "ESEAL_SSM" and n_re > 0 and rng.random() < 0.4:
+        cols = sorted(set(int(c) for c in rng.integers(0, n_re, size=int(rng.integers(1, n_re + 1)))))
+        kw.update(t_decay=rng.uniform(0, 2, size=q * n), col_decay=cols, ind_decay=[int(c % 2) for c in cols])
+        if max(kw["ind_decay"]) == 1 and 0 not in kw["ind_decay"]:
+            kw["ind_decay"] = [0] * len(cols)
+    pb = capi.Problem(model, ID, times, obs, X_fe=X_fe, X_re=X_re, S_list=S_list or None,
+                      na_mode=int(rng.integers(0, 2)) if na_frac == 0 else 1, **kw)
+    par = 0.25 * rng.standard_normal(pb.n_par_full)
+    if model in ("OU", "OU_SSM"):
+        for a in range(d):
+            par[pb.off_fe + pb.fe_off[a]] += 3.0
+    if model == "ESEAL_SSM":
+        par[0:3] = [0.1, -0.58, np.log(1.2)]
+        par[pb.off_fe + pb.fe_off[1]] -= 1.0
+    if pb.lead_names == ["log_sigma_obs"]:
+        par[0] = rng.uniform(-1.5, 0.3)
+    fixed = pb.par_fixed.copy()
+    fixed[rng.random(pb.n_par_full) < 0.2] = 1
+    if fixed.all():
+        fixed[-1] = 0
+    pb.par_fixed = fixed
+    return pb, par
+
+
+@pytest.mark.parametrize("seed", range(210))
+def test_random_problem_matches_oracle(seed):
+    pb, par = random_problem(seed)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    oval, ograd = _oracle(pb, par)
+    info = eng.info()
+    ctx = (pb.model, pb.n_dim, pb.n, pb.n_seg, info["path"], info["window"])
+    if not np.isfinite(oval):
+        assert not np.isfinite(val), ctx
+    else:
+        assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (val, oval, ctx)
+        assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd, ctx)
+        assert np.all(grad[pb.par_fixed != 0] == 0.0)
+        v0 = eng.eval(par, order=0)
+        assert abs(v0 - val) <= 1e-12 * max(1.0, abs(val)), ctx
+    eng.close()
