@@ -105,11 +105,19 @@ def main():
                   file=sys.stderr)
         if args.gpus > 1 and world == 1:
             sys.exit(2)
+    # rehearsal on a one-GPU box (never used by the driver): SSDE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # SSDE_BENCH_BACKEND=gloo carries the all-reduce (RCCL refuses two ranks on one device)
+    if os.environ.get("SSDE_BENCH_SHARE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("SSDE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from smoothsde_amd import capi
     from smoothsde_amd.synth import simulate
