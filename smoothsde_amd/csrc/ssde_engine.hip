@@ -1053,6 +1053,10 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     }
     int W = 0;
     if (!(rho < 0.9995) || !std::isfinite(rho)) return;  // no usable forgetting: sequential filter
+    // The stationary CTCRW lanes run the filter as 1/D(q)^2 recursions (k_iso_shared.hip): with closed-loop poles
+    // close to 1 their intermediate signals grow like 1/(1-rho)^2 and cancel in the innovation -- below rho = 0.97
+    // that costs < 1e-12 relative; above, the evaluation stays on the sequential direction-form filter
+    if (h->use_shared && h->model == SSDE_MODEL_CTCRW && rho > 0.97) return;
     W = (int)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
     W = std::max(W, 16);
     if (const char* e = getenv("SSDE_WINDOW")) W = std::max(1, atoi(e));  // testing: deliberately short overlaps
