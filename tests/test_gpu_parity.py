@@ -371,3 +371,20 @@ def test_decaying_columns_medium_batch_vs_oracle():
     with pytest.raises(ValueError):
         capi.Problem("OU_SSM", ID, times, obs, X_re=[bspline_basis(x, 6), None, None], S_list=[second_difference_penalty(6)],
                      t_decay=np.zeros(3 * n), col_decay=[0], ind_decay=[0])
+
+
+@pytest.mark.parametrize("ls,ln,expect_windows", [(1.0, -2.0, True), (1.5, -2.0, True), (2.0, -2.0, False)])
+def test_stationary_lanes_with_slow_forgetting(ls, ln, expect_windows):
+    """closed-loop spectral radius 0.92 / 0.95 (long warm-ups, transfer-function lanes close to their conditioning
+    limit) and 0.97 (beyond it: the engine must stay on the sequential filter) -- all against the oracle"""
+    ID, times, obs = simulate("CTCRW", 64, 12000, 2, tau=2.0, nu=np.exp(ln), sigma_obs=np.exp(ls), seed=31)
+    pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=[0, 1, 1, 0, 0])
+    par = np.array([ls, 0.0, 0.0, np.log(2.0), ln])
+    eng = capi.Engine(pb)
+    v, g = eng.eval(par)
+    info = eng.info()
+    assert (info["window"] > 0) == expect_windows, info
+    assert info["window_check"] <= capi.WINDOW_TOL
+    oval, ograd = _oracle(pb, par)
+    _close(v, g, oval, ograd)
+    eng.close()
