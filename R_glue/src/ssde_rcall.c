@@ -42,6 +42,7 @@ static int model_code(const char *type) {
     if (!strcmp(type, "CTCRW")) return SSDE_MODEL_CTCRW;
     if (!strcmp(type, "BM_t")) return SSDE_MODEL_BM_T;
     if (!strcmp(type, "ESEAL_SSM")) return SSDE_MODEL_ESEAL_SSM;
+    if (!strcmp(type, "CIR")) return SSDE_MODEL_CIR;
     return -1;
 }
 

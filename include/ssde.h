@@ -69,8 +69,10 @@ enum {
     SSDE_MODEL_CTCRW  = 4, /* "CTCRW"   -> nllk_ctcrw                                     */
     SSDE_MODEL_BM_T   = 5, /* "BM_t"    -> nllk_sde + tr_dens BM_t branch (tr_dens.hpp:38-44): one response,
                               par = (mu, log sigma), degrees of freedom in other_data[0] (R/sde.R:539-541) */
-    SSDE_MODEL_ESEAL_SSM = 6 /* "ESEAL_SSM" -> nllk_eseal_ssm (nllk_e_seal_ssm.hpp:83-250): one response, par = (mu, log sigma),
+    SSDE_MODEL_ESEAL_SSM = 6, /* "ESEAL_SSM" -> nllk_eseal_ssm (nllk_e_seal_ssm.hpp:83-250): one response, par = (mu, log sigma),
                               state (1, lipid mass), Z_i = (a1, a2 / R_i), H_i = tau^2 / h_i; needs a0, eseal_h, eseal_R */
+    SSDE_MODEL_CIR    = 7  /* "CIR"     -> nllk_sde + tr_dens CIR branch (tr_dens.hpp:53-67): par = (log mu_a, log beta, log sigma),
+                              positive observations; log I_q(x) is formed directly (no overflow at large x) */
 };
 
 /* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with

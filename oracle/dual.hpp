@@ -63,6 +63,17 @@ template <int N> inline Dual<N> sqrt(const Dual<N>& a) {
     Dual<N> r; r.v = std::sqrt(a.v); for (int k = 0; k < N; k++) r.d[k] = a.d[k] / (2.0 * r.v); return r; }
 template <int N> inline Dual<N> fabs(const Dual<N>& a) { return a.v < 0 ? -a : a; }
 
+// digamma for the derivative of lgamma (x > 0): recurrence to x >= 10, then the asymptotic series
+inline double digamma_d(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    double i2 = 1.0 / (x * x);
+    return r + std::log(x) - 0.5 / x - i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0)))));
+}
+inline double lgamma(double x) { return std::lgamma(x); }
+template <int N> inline Dual<N> lgamma(const Dual<N>& a) {
+    Dual<N> r; r.v = std::lgamma(a.v); double psi = digamma_d(a.v); for (int k = 0; k < N; k++) r.d[k] = psi * a.d[k]; return r; }
+
 inline double asDouble(double x) { return x; }
 template <int N> inline double asDouble(const Dual<N>& x) { return x.v; }
 

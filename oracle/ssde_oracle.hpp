@@ -514,7 +514,26 @@ Type dnorm_log(Type x, Type mean, Type sd) {
     return Type(-std::log(std::sqrt(2.0 * M_PI))) - log(sd) - Type(0.5) * resid * resid;
 }
 
-// nllk_sde (nllk_sde.hpp:16-127) with tr_dens' BM (tr_dens.hpp:32-37) and OU (:45-52)
+// log(besselI(x, nu)) of tr_dens.hpp:64-66 for a real order nu > -1.  TMB's besselI is not in the container; the
+// published ascending series I_nu(x) = (x/2)^nu sum_k (x^2/4)^k / (k! Gamma(nu+k+1)) is summed here (all terms
+// positive) with the logarithm taken term-wise so that large x does not overflow (the reference's unscaled besselI
+// returns Inf beyond x ~ 700; where it is finite the two agree to rounding).  Templated: duals differentiate it
+// with respect to x AND nu, as TMB's AD does.
+template <class Type>
+Type log_besselI(Type x, Type nu) {
+    Type y = x * x * Type(0.25);
+    Type t = Type(1.0), S = Type(1.0);
+    double off = 0.0;
+    for (int k = 1; k < 20000; k++) {
+        t = t * y / (Type((double)k) * (Type((double)k) + nu));
+        S = S + t;
+        if ((double)k > 0.5 * asDouble(x) && asDouble(t) < 1e-18 * asDouble(S)) break;
+        if (asDouble(S) > 1e200) { t = t * 1e-200; S = S * 1e-200; off += 200.0 * std::log(10.0); }
+    }
+    return nu * log(x * Type(0.5)) - lgamma(nu + Type(1.0)) + log(S) + Type(off);
+}
+
+// nllk_sde (nllk_sde.hpp:16-127) with tr_dens' BM (tr_dens.hpp:32-37), BM_t (:38-44), OU (:45-52) and CIR (:53-67)
 // branches; returns -llk without the penalty.
 template <class Type>
 Type nllk_direct(const Problem& p, const Type* par) {
@@ -541,6 +560,16 @@ Type nllk_direct(const Problem& p, const Type* par) {
                 Type logdt = Type(std::lgamma(0.5 * (df + 1.0)) - std::lgamma(0.5 * df) - 0.5 * std::log(df * M_PI)) -
                              Type(0.5 * (df + 1.0)) * log(Type(1.0) + x * x / df);
                 res = res + logdt - log(scale);                                        // :44
+            } else if (d->model == SSDE_MODEL_CIR) {
+                Type mu = exp(linpred(p, par, i - 1, a));                              // tr_dens.hpp:56
+                Type beta = exp(linpred(p, par, i - 1, n_dim));                        // :57
+                Type sigma = exp(linpred(p, par, i - 1, n_dim + 1));                   // :58
+                Type c = Type(2.0) * beta / ((Type(1.0) - exp(-(beta * dt))) * sigma * sigma);   // :60
+                Type q = Type(2.0) * beta * mu / (sigma * sigma) - Type(1.0);          // :61
+                Type u = c * z0 * exp(-(beta * dt));                                   // :62
+                Type v = c * z1;                                                       // :63
+                Type logb = log_besselI(Type(2.0) * sqrt(u * v), q);                   // :64, log(b) of :66
+                res = res + log(c) - u - v + q / Type(2.0) * (log(v) - log(u)) + logb; // :66
             } else if (d->model == SSDE_MODEL_BM) {
                 Type mean = Type(z0) + linpred(p, par, i - 1, a) * dt;                 // tr_dens.hpp:35
                 Type sd = exp(linpred(p, par, i - 1, n_dim)) * std::sqrt(dt);          // :36

@@ -19,10 +19,10 @@ import numpy as np
 
 ABI_VERSION = 4
 
-MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6}
+MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
 # types the reference dispatches (src/smoothSDE.cpp:12-27) that this engine does not cover
-UNSUPPORTED_MODELS = ("CIR",)
+UNSUPPORTED_MODELS = ()
 
 NA_R_ONLY, NA_ANY_NAN = 0, 1
 PATH_NAMES = {0: "direct", 1: "isotropic-register", 2: "dense", 3: "isotropic-row-varying"}
@@ -242,7 +242,7 @@ class Problem:
         self = cls.__new__(cls)
         if model not in MODEL_CODES:
             raise ValueError("Unknown SDE type")
-        if model in ("ESEAL_SSM", "BM_t"):
+        if model in ("ESEAL_SSM", "BM_t", "CIR"):
             raise NotImplementedError("device-resident construction covers BM, OU, BM_SSM, OU_SSM, CTCRW")
         self.model = model
         if obs.dim() == 1:

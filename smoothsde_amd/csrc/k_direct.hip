@@ -1,4 +1,4 @@
-// k_direct.hip -- direct transition-density families "BM", "BM_t" and "OU" (nllk_sde.hpp:77-84 with
+// k_direct.hip -- direct transition-density families "BM", "BM_t", "OU" and "CIR" (nllk_sde.hpp:77-84 with
 // tr_dens.hpp:32-52) for gfx950.
 //
 // No recursion: row i depends only on rows i-1, i and on the parameters of row i-1 (Q6), so
@@ -97,6 +97,14 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
             const double z0 = A.obs[i - 1], z1 = A.obs[i];
             if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan)))
                 nll += bmt_direct(z0, z1, dt, par[0], varies[1] ? par[1] : base[1], A.tdf, A.tconst, g[0], g[1]);
+        } else if (MODEL == M_CIR) {
+            // tr_dens.hpp:53-67: par = (log mu_a, log beta, log sigma), non-central chi-square transition
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double z0 = A.obs[(i - 1) + (int64_t)a * A.n], z1 = A.obs[i + (int64_t)a * A.n];
+                if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;
+                nll += cir_direct(z0, z1, dt, par[a], par[D], par[D + 1], g[a], g[D], g[D + 1]);
+            }
         } else if (MODEL == M_BM) {
             // tr_dens.hpp:35-37: mean = z0 + mu dt, sd = exp(par[D]) sqrt(dt)
             const double sig = varies[D] ? exp(par[D]) : nat_p1;
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     double c_e = 0.0, c_isd = 0.0, c_lsd = 0.0, c_dls = 0.0, c_z = 0.0;
     if (all_const) {
         const double dt = A.dt_uniform;
-        if (MODEL == M_BM_T) {
-            // (nothing hoisted: one log1p per row dominates anyway)
+        if (MODEL == M_BM_T || MODEL == M_CIR) {
+            // (nothing hoisted: the per-row log1p / Bessel series dominates anyway)
         } else if (MODEL == M_BM) {
             const double sd = nat_p1 * sqrt(dt);
             c_isd = 1.0 / sd; c_lsd = log(sd);
@@ -245,6 +253,13 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             const double z0 = __builtin_nontemporal_load(&A.obs[r]), z1 = A.obs[i];
             if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan)))                       // tr_dens.hpp:31
                 nll += bmt_direct(z0, z1, dt, par[0], par[1], A.tdf, A.tconst, g[0], g[1]);   // :38-44
+        } else if (MODEL == M_CIR) {
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
+                if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;              // tr_dens.hpp:31
+                nll += cir_direct(z0, z1, dt, par[a], par[D], par[D + 1], g[a], g[D], g[D + 1]);   // :53-67
+            }
         } else if (MODEL == M_BM) {
             double isd = c_isd, lsd = c_lsd;
             if (!all_const) {
@@ -321,7 +336,7 @@ hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
         return hipGetLastError();                                                           \
     }
 #define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
-    SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2) SSDE_FK(M_BM_T, 1)
+    SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2) SSDE_FK(M_BM_T, 1) SSDE_FK(M_CIR, 1) SSDE_FK(M_CIR, 2)
 #undef SSDE_FK
 #undef SSDE_F
     return hipErrorInvalidValue;
@@ -360,7 +375,7 @@ hipError_t launch_direct(const DirectArgs& a, hipStream_t s) {
         return hipGetLastError();                                                      \
     }
 #define SSDE_LK(MODEL, D) SSDE_L(MODEL, D, 4) SSDE_L(MODEL, D, 16) SSDE_L(MODEL, D, 32) SSDE_L(MODEL, D, 64)
-    SSDE_LK(M_BM, 1) SSDE_LK(M_BM, 2) SSDE_LK(M_OU, 1) SSDE_LK(M_OU, 2) SSDE_LK(M_BM_T, 1)
+    SSDE_LK(M_BM, 1) SSDE_LK(M_BM, 2) SSDE_LK(M_OU, 1) SSDE_LK(M_OU, 2) SSDE_LK(M_BM_T, 1) SSDE_LK(M_CIR, 1) SSDE_LK(M_CIR, 2)
 #undef SSDE_LK
 #undef SSDE_L
     return hipErrorInvalidValue;

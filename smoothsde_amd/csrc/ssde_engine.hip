@@ -621,7 +621,7 @@ int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) 
 int build(const ssde_desc* d, ssde_handle* h) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
-    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_ESEAL_SSM) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
+    if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_CIR) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
     if (is_eseal(d->model)) {
         // nllk_e_seal_ssm.hpp: one response, state (1, lipid mass) with a0 = (1, L0) and P0 = diag(0, p0) (R/sde.R:602-603):
         // the constant first component is what turns the 2 x 2 filter into the scalar filter of ssde_tv.hpp

@@ -38,7 +38,7 @@ namespace ssde {
 enum { DIR_SIG = 1, DIR_MU = 2, DIR_P1 = 4, DIR_P2 = 8 };
 
 // model codes (== SSDE_MODEL_* of include/ssde.h)
-enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4, M_BM_T = 5, M_ESEAL = 6 };
+enum { M_BM = 0, M_OU = 1, M_BM_SSM = 2, M_OU_SSM = 3, M_CTCRW = 4, M_BM_T = 5, M_ESEAL = 6, M_CIR = 7 };
 
 // R_IsNA / any-NaN test on the bit pattern (Q5)
 SSDE_HD bool is_na(double x, int any_nan) {
@@ -523,6 +523,70 @@ SSDE_HD double ou_direct(double z0, double z1, double dt, double mu, double ltau
     g_lt += -r * (e * z * (z0 - mu)) / sd + (1.0 - r * r) * dls_lt;
     g_lk += 0.5 * (1.0 - r * r);
     return SSDE_LOG_SQRT_2PI + log(sd) + 0.5 * r * r;
+}
+
+// ---------------------------------------------------------------------------------------
+// CIR (tr_dens.hpp:53-67): the transition density needs log I_q(x) for a real order q > -1 and its derivatives
+// with respect to x AND q (q = 2 beta mu / sigma^2 - 1 moves with every parameter).  The reference takes
+// log(besselI(x, q)) (TMB's bessel_i, AD through R's algorithm), which overflows to Inf for x > ~700; here the
+// logarithm is formed directly from the ascending series
+//     I_q(x) = (x/2)^q / Gamma(q+1) * S,   S = sum_k t_k,  t_0 = 1,  t_k = t_{k-1} (x^2/4) / (k (k + q)),
+// whose terms are all positive (no cancellation: relative error ~ #terms * eps; #terms ~ x/2 + 40), rescaled on
+// the fly so that it never overflows:
+//     d log I / dx = q/x + 2 sum_k k t_k / (x S),      d log I / dq = log(x/2) - psi(q+1) - sum_k t_k h_k / S,
+//     h_k = sum_{j=1..k} 1/(j+q).
+// ---------------------------------------------------------------------------------------
+SSDE_HD double digamma_pos(double x) {   // psi(x), x > 0: recurrence up to x >= 8, then the asymptotic series
+    double r = 0.0;
+    while (x < 8.0) { r -= 1.0 / x; x += 1.0; }
+    const double i2 = 1.0 / (x * x);
+    // B_2n/(2n): 1/12, -1/120, 1/252, -1/240, 1/132, -691/32760, 1/12
+    const double s = i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0 -
+                     i2 * (691.0 / 32760.0 - i2 * (1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x - s;
+}
+
+SSDE_HD double log_bessel_i(double x, double q, double& dlog_dx, double& dlog_dq) {
+    const double y = 0.25 * x * x;
+    double t = 1.0, S = 1.0, A1 = 0.0, A2 = 0.0, hk = 0.0, off = 0.0;
+    const double kpeak = 0.5 * x;
+    for (int k = 1; k < 20000; k++) {
+        const double ik = 1.0 / ((double)k + q);
+        t *= y * ik / (double)k;
+        hk += ik;
+        S += t; A1 += (double)k * t; A2 += t * hk;
+        if ((double)k > kpeak && t < 1e-17 * S) break;
+        if (S > 1e200) { t *= 1e-200; S *= 1e-200; A1 *= 1e-200; A2 *= 1e-200; off += 460.51701859880916; }   // 200 ln 10
+    }
+    const double lx2 = log(0.5 * x);
+    dlog_dx = q / x + 2.0 * A1 / (x * S);
+    dlog_dq = lx2 - digamma_pos(q + 1.0) - A2 / S;
+    return q * lx2 - lgamma(q + 1.0) + log(S) + off;
+}
+
+// CIR: par = (log mu_a, log beta, log sigma).  Returns -log density, adds d/d(log mu_a, log beta, log sigma).
+SSDE_HD double cir_direct(double z0, double z1, double dt, double lmu, double lbeta, double lsig, double& g_lm,
+                          double& g_lb, double& g_ls) {
+    const double mu = exp(lmu), beta = exp(lbeta), s2 = exp(2.0 * lsig);
+    const double bd = beta * dt, em = exp(-bd);
+    const double c = 2.0 * beta / ((1.0 - em) * s2);               // tr_dens.hpp:60
+    const double q1 = 2.0 * beta * mu / s2, q = q1 - 1.0;           // :61
+    const double u = c * z0 * em, v = c * z1;                       // :62-63
+    const double x = 2.0 * sqrt(u * v);                             // :64
+    double dIx, dIq;
+    const double lI = log_bessel_i(x, q, dIx, dIq);
+    const double lvu = log(v) - log(u);
+    const double ld = log(c) - u - v + 0.5 * q * lvu + lI;          // :66
+    // log-derivatives w.r.t. (log mu, log beta, log sigma)
+    const double dlc_b = 1.0 - bd * em / (1.0 - em), dlc_s = -2.0;
+    const double dlu_b = dlc_b - bd, dlu_s = -2.0, dlv_b = dlc_b, dlv_s = -2.0;
+    const double dq_m = q1, dq_b = q1, dq_s = -2.0 * q1;
+    const double xI = x * dIx;
+    const double d_m = 0.5 * dq_m * lvu + dIq * dq_m;
+    const double d_b = dlc_b - u * dlu_b - v * dlv_b + 0.5 * dq_b * lvu + 0.5 * q * (dlv_b - dlu_b) + xI * 0.5 * (dlu_b + dlv_b) + dIq * dq_b;
+    const double d_s = dlc_s - u * dlu_s - v * dlv_s + 0.5 * dq_s * lvu + 0.5 * q * (dlv_s - dlu_s) + xI * 0.5 * (dlu_s + dlv_s) + dIq * dq_s;
+    g_lm -= d_m; g_lb -= d_b; g_ls -= d_s;
+    return -ld;
 }
 
 }  // namespace ssde

@@ -34,6 +34,7 @@ PAR_NAMES = {
     "ESEAL_SSM": lambda d: ["mu", "sigma"],              # R/sde.R:70
     "OU": lambda d: _mu_names(d) + ["tau", "kappa"],
     "OU_SSM": lambda d: _mu_names(d) + ["tau", "kappa"],
+    "CIR": lambda d: _mu_names(d) + ["beta", "sigma"],   # R/sde.R:66-67 (every parameter on the log scale)
     "CTCRW": lambda d: _mu_names(d) + ["tau", "nu"],
 }
 
@@ -182,7 +183,8 @@ class SDE:
                                  f"({', '.join(names)})")               # R/sde.R:147-151
             i0 = np.concatenate([[0], np.cumsum(self.terms_["ncol_fe"])[:-1]]).astype(int)
             for i, nm in enumerate(names):                               # link: identity for mu*, log otherwise
-                self.coeff_fe_[i0[i]] = par0[i] if nm.startswith("mu") else np.log(par0[i])
+                identity = nm.startswith("mu") and type != "CIR"          # CIR: log link for mu too (R/sde.R:66)
+                self.coeff_fe_[i0[i]] = par0[i] if identity else np.log(par0[i])
         self.tmb_obj_ = None
         self.tmb_obj_joint_ = None
         self.tmb_rep_ = None
@@ -411,5 +413,5 @@ class SDE:
             lp = (np.full(self.n_, cf[0]) if d.X_fe is None else d.X_fe @ cf)
             if d.X_re is not None:
                 lp = lp + d.X_re @ self.coeff_re_[re_off[j]:re_off[j + 1]]
-            out[nm] = lp if nm.startswith("mu") else np.exp(lp)
+            out[nm] = lp if (nm.startswith("mu") and self.type_ != "CIR") else np.exp(lp)
         return out

@@ -37,11 +37,13 @@ def _tracks(rng, model, d, lengths, irregular=True, scale=1.0):
             z = np.cumsum(vel * dts[:, None], axis=0) + 0.1 * steps
         elif model in ("OU", "OU_SSM"):
             z = 3.0 + steps
+        elif model == "CIR":
+            z = np.exp(0.4 * np.cumsum(steps * np.sqrt(dts[:, None]) * 0.5, axis=0))     # positive
         else:
             z = np.cumsum(steps, axis=0)
         ID += [float(k)] * T
         times += list(tt)
-        obs.append(z + 10.0 * k)
+        obs.append(z + (0.0 if model == "CIR" else 10.0 * k))
     return np.array(ID), np.array(times), np.vstack(obs)
 
 
@@ -50,6 +52,8 @@ def _par_const(rng, model, d, kalman):
     p = []
     if kalman:
         p.append(rng.uniform(-1.5, 0.0))  # log_sigma_obs
+    if model == "CIR":
+        return np.array(list(rng.uniform(-0.3, 0.5, size=d)) + [rng.uniform(-1.2, 0.0), rng.uniform(-1.2, -0.3)])  # log mu, log beta, log sigma
     p += list(rng.uniform(-0.5, 0.5, size=d) + (3.0 if model in ("OU", "OU_SSM") else 0.0))  # mu
     p += list(rng.uniform(-0.3, 0.7, size=q - d))  # log-scale parameters
     return np.array(p)
@@ -233,4 +237,7 @@ def all_specs():
     # elephant-seal state-space model (nllk_e_seal_ssm.hpp)
     specs.append(eseal_spec("ESEAL_const", 211, [14, 9, 11], na_rows=(4, 20)))
     specs.append(eseal_spec("ESEAL_tv", 212, [16, 12], variant="tv", na_rows=(6,)))
+    # Cox-Ingersoll-Ross (tr_dens.hpp:53-67)
+    specs.append(make_spec("CIR_d1_const", "CIR", 1, seed=221, lengths=[9, 2, 14, 6], na_rows=(3, 12)))
+    specs.append(make_spec("CIR_d2_tv", "CIR", 2, seed=222, lengths=[14, 10], variant="tv", na_rows=(5,)))
     return specs

@@ -159,6 +159,13 @@ int hostsim_kalman_iso(int model, int d, int mask, int any_nan, int64_t n, int64
     return 0;
 }
 
+// log I_q(x) and its derivatives w.r.t. x and q (CIR); out = [value, d/dx, d/dq]
+void hostsim_log_bessel_i(double x, double q, double* out) { out[0] = log_bessel_i(x, q, out[1], out[2]); }
+// CIR transition: returns nll and adds gradient wrt (log mu, log beta, log sigma)
+double hostsim_cir(double z0, double z1, double dt, double lmu, double lb, double ls, double* g) {
+    return cir_direct(z0, z1, dt, lmu, lb, ls, g[0], g[1], g[2]);
+}
+
 // direct families, one transition: returns nll and adds gradient wrt (mu, p1, p2)
 double hostsim_direct(int model, double z0, double z1, double dt, double mu, double p1, double p2, double* g) {
     if (model == M_BM) return bm_direct(z0, z1, dt, mu, p1, g[0], g[1]);

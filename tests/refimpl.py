@@ -232,6 +232,24 @@ def eseal_priors(pb: Problem, par: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _LogBesselI(torch.autograd.Function):
+    """log I_nu(x) with both derivatives from mpmath at 30 digits (independent of the series in oracle/)."""
+
+    @staticmethod
+    def forward(ctx, x, nu):
+        import mpmath as mp
+        mp.mp.dps = 30
+        xf, nf = mp.mpf(float(x)), mp.mpf(float(nu))
+        f = lambda a, b: mp.log(mp.besseli(b, a))
+        ctx.dx = float(mp.diff(lambda a: f(a, nf), xf))
+        ctx.dnu = float(mp.diff(lambda b: f(xf, b), nf))
+        return torch.tensor(float(f(xf, nf)), dtype=torch.float64)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.dx, g * ctx.dnu
+
+
 def direct_nllk(pb: Problem, par: torch.Tensor) -> torch.Tensor:
     """BM / OU transition densities (nllk_sde.hpp:77-84) via torch.distributions."""
     d, n = pb.n_dim, pb.n
@@ -245,6 +263,15 @@ def direct_nllk(pb: Problem, par: torch.Tensor) -> torch.Tensor:
         for a in range(d):
             z0, z1 = pb.obs[i - 1, a], pb.obs[i, a]
             if _is_na(z0, pb.na_mode) or _is_na(z1, pb.na_mode):
+                continue
+            if pb.model == "CIR":
+                # tr_dens.hpp:53-67: c Z1 is non-central chi-square; written with log I_q (mpmath) instead of besselI
+                mu, beta, sigma = torch.exp(p[a]), torch.exp(p[d]), torch.exp(p[d + 1])
+                c = 2 * beta / ((1 - torch.exp(-beta * dt)) * sigma ** 2)
+                q = 2 * beta * mu / sigma ** 2 - 1
+                u, v = c * z0 * torch.exp(-beta * dt), c * z1
+                ld = torch.log(c) - u - v + q / 2 * (torch.log(v) - torch.log(u)) + _LogBesselI.apply(2 * torch.sqrt(u * v), q)
+                total = total - ld
                 continue
             if pb.model == "BM_t":
                 # scaled Student-t increment (tr_dens.hpp:38-44): torch.distributions.StudentT(df, loc, scale)

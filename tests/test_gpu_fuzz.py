@@ -14,7 +14,7 @@ from smoothsde_amd.synth import bspline_basis, second_difference_penalty
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["CTCRW", "OU_SSM", "BM_SSM", "OU", "BM", "BM_t", "ESEAL_SSM"]
+MODELS = ["CTCRW", "OU_SSM", "BM_SSM", "OU", "BM", "BM_t", "ESEAL_SSM", "CIR"]
 
 
 def _oracle(pb, par):
@@ -44,6 +44,8 @@ def random_problem(seed):
     obs = np.cumsum(rng.standard_normal((n, d)) * scale, axis=0) + (3.0 if model in ("OU", "OU_SSM") else 0.0)
     if model in ("OU", "OU_SSM"):
         obs = 3.0 + rng.standard_normal((n, d))
+    if model == "CIR":
+        obs = np.exp(0.3 * np.cumsum(rng.standard_normal((n, d)) * 0.4, axis=0))       # positive
     first = np.r_[True, ID[1:] != ID[:-1]]
     kw = {}
     if model == "ESEAL_SSM":
@@ -93,6 +95,8 @@ def random_problem(seed):
     if model in ("OU", "OU_SSM"):
         for a in range(d):
             par[pb.off_fe + pb.fe_off[a]] += 3.0
+    if model == "CIR":
+        par[pb.off_fe + pb.fe_off[d + 1]] -= 0.6          # moderate sigma: keeps the Bessel argument in a sane range
     if model == "ESEAL_SSM":
         par[0:3] = [0.1, -0.58, np.log(1.2)]
         par[pb.off_fe + pb.fe_off[1]] -= 1.0
@@ -106,7 +110,7 @@ def random_problem(seed):
     return pb, par
 
 
-@pytest.mark.parametrize("seed", range(210))
+@pytest.mark.parametrize("seed", range(240))
 def test_random_problem_matches_oracle(seed):
     pb, par = random_problem(seed)
     eng = capi.Engine(pb)

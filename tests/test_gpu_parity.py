@@ -388,3 +388,26 @@ def test_stationary_lanes_with_slow_forgetting(ls, ln, expect_windows):
     oval, ograd = _oracle(pb, par)
     _close(v, g, oval, ograd)
     eng.close()
+
+
+def test_cir_medium_batch_vs_oracle():
+    """Cox-Ingersoll-Ross (tr_dens.hpp:53-67): 1500 ragged positive tracks, smooth on log mu, NA entries; the
+    Bessel arguments range over several orders of magnitude (sigma small on part of the covariate range)"""
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    rng = np.random.default_rng(25)
+    lens = rng.integers(2, 40, size=1500)
+    ID = np.repeat(np.arange(1500), lens).astype(float)
+    n = len(ID)
+    times = np.cumsum(rng.uniform(0.3, 1.5, size=n))
+    obs = np.exp(0.3 * np.cumsum(rng.standard_normal((n, 1)) * 0.4, axis=0) % 2.0)
+    obs[rng.random(n) < 0.03] = np.nan
+    x = (np.sin(np.arange(n) * 0.01) + 1) / 2
+    X_fe = [None, None, np.column_stack([np.ones(n), x])]
+    pb = capi.Problem("CIR", ID, times, obs, X_fe=X_fe, X_re=[bspline_basis(x, 5), None, None],
+                      S_list=[second_difference_penalty(5)])
+    par = np.r_[0.2, -0.5, -0.4, -1.6, 0.3, 0.2 * np.sin(np.arange(5))]      # sigma from 0.67 down to 0.14
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    eng.close()

@@ -61,8 +61,8 @@ def test_formula_list_checks_and_par0():
         SDE(data=dict(d, Y=d["Z"]), type="CTCRW", response=["Z", "Y"], par0=[0, 1])
     with pytest.raises(ValueError, match="Unknown SDE type"):
         SDE(data=d, type="XYZ", response="Z")
-    with pytest.raises(NotImplementedError):
-        SDE(data=d, type="CIR", response="Z")
+    cir = SDE(data=dict(d, Z=np.exp(0.1 * d["Z"])), type="CIR", response="Z", par0=[1.0, 0.5, 0.3])
+    assert np.allclose(cir.coeff_fe(), np.log([1.0, 0.5, 0.3]))        # log link for every CIR parameter (R/sde.R:66-67)
 
 
 def test_problem_layout_matches_tmb_parameter_order():
