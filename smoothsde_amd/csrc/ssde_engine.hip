@@ -4,190 +4,23 @@
 // Replaces, for the nllk/gradient path only, what TMB's MakeADFunObject / EvalADFunObject do
 // for the reference (/root/reference/src/init.c:6-8, R/sde.R:656-669, 694-697).
 // There is no CPU evaluation path in this library: without a gfx950 device ssde_create fails.
-#include <hip/hip_runtime.h>
+#include "ssde_engine.hpp"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "../../include/ssde.h"
-#include "ssde_device.hpp"
-#include "ssde_host.hpp"
-#include "ssde_tv.hpp"
-
-using namespace ssde;
-using namespace ssde_host;
-
-namespace {
-
+namespace ssde_engine {
 thread_local std::string g_create_error;
+}  // namespace ssde_engine
+using namespace ssde_engine;
 
-enum { PATH_DIRECT = 0, PATH_ISO = 1, PATH_DENSE = 2, PATH_TV = 3 };
-constexpr int PAR_RING = 8;
-constexpr double SSDE_WINDOW_TOL = 1e-11;  // largest tolerated relative hand-over disagreement
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    hipError_t alloc(size_t count) {
-        n = count;
-        if (count == 0) { p = nullptr; return hipSuccess; }
-        return hipMalloc((void**)&p, count * sizeof(T));
-    }
-    hipError_t upload(const std::vector<T>& v) {
-        hipError_t e = alloc(v.size());
-        if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
-}  // namespace
-
-struct ssde_handle {
-    std::string err;
-    int model = 0, d = 0, q = 0, sdim = 0, na_any = 0, device = 0, path = 0;
-    int64_t n = 0, n_seg = 0, n_steps = 0;
-    bool has_h = false, const_coeff = false, uniform_dt = false;
-    double dt_uniform = 0.0;
-    double tdf = 0.0, tconst = 0.0;     // BM_t: degrees of freedom, normalising constant of dt(., df)
-    double p0_iso[3] = {0, 0, 0};
-    double p0_full[16] = {0};
-    ParLayout L;
-    Penalty pen;
-    std::vector<Slot> slots;
-    int n_stream_cols = 0;
-    std::vector<uint8_t> fixed;
-    int n_free = 0;
-
-    // Kalman tiles
-    DevBuf<double> tiles, a0;
-    DevBuf<int64_t> group_off, lane_row0;
-    DevBuf<int32_t> group_len, lane_nsteps;
-    int n_groups = 0, C = 0;
-    int64_t tile_doubles = 0;
-
-    // direct families (long format, engine-owned copies)
-    DevBuf<double> times, obs, colbuf, tdecay;
-    DevBuf<uint32_t> scored;
-    DevBuf<const double*> colptr;
-    int direct_blocks = 0;
-
-    // fast direct kernel (<= 2 parameters with streamed columns)
-    bool direct_fast = false;
-    int64_t col_stride = 0;                        // doubles between consecutive streamed columns
-    int df_ja = -1, df_jb = -1;
-    std::vector<int> df_pidxA, df_pidxB;          // full-par indices of the streamed coefficients
-    int df_icpt[MAX_Q] = {-1, -1, -1, -1};         // full-par index of each parameter's intercept, or -1
-    const double *df_colA = nullptr, *df_colB = nullptr;
-    bool direct_uniform_dt = false;
-    double direct_dt = 0.0;
-
-    // dense / direct parameter plumbing
-    DevBuf<SlotTable> slot_table;
-    DevBuf<DenseDir> dirs;
-    std::vector<DenseDir> dirs_host;
-    int n_dirblocks = 0;
-    DevBuf<double> par_ring;
-    double* par_pinned = nullptr;
-    hipEvent_t par_ev[PAR_RING];
-    bool par_ev_ok = false;
-    int par_next = 0;
-
-    DevBuf<double> partials, out;
-    size_t partial_doubles = 0;
-
-    // iso time windows
-    DevBuf<double> bnd, chk;
-    int max_chunks = 1;            // allocation bound
-    int want_chunks = 1;           // planned number of equal windows (the transient window comes on top)
-    int glen_max = 0;              // steps of the longest track group
-    double dt_min = 0.0;           // smallest interval used inside a track
-    bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
-    int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
-    int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
-    int last_chunks = 1, last_window = 0;
-    double last_check = 0.0;
-    int n_retries = 0;
-
-    // shared-covariance path
-    DevBuf<int32_t> group_flags;
-    int n_clean_groups = 0;
-    bool use_shared = false;
-    std::vector<std::pair<int, int64_t>> clean_ns_hist;  // (scored rows, number of tracks) over NaN-free groups
-    DevBuf<double> gain_ring;
-    double* gain_pinned = nullptr;
-    size_t gain_rows_cap = 0;
-    int last_gain_rows = 0;
-
-    // side streams: the kernels of one evaluation that do not depend on each other run concurrently
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-
-    // timing of the dominant kernel (recorded on the stream it is launched on)
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
-    bool ev_k_valid = false;
-    std::vector<int32_t> glen_host, lane_ns_host;
-    int last_s_stat = 0, last_t0 = 0;
-    mutable int rows_key[3] = {-1, -1, -1};
-    mutable int64_t rows_cached = 0;
-
-    // iso direction split
-    int iso_parts = 1;
-    int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
-    int iso_free_mask = 0;
-
-    // row-varying isotropic path (k_tv.hip)
-    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats, tv_harr, tv_eh, tv_eR;
-    bool tv_dense = false;         // full-covariance lanes: per-row H_array and / or a P0 that is not block-identical
-    DevBuf<TvDir> tv_dirs;
-    DevBuf<int64_t> tv_row0;
-    DevBuf<int32_t> tv_ns;
-    DevBuf<TvItem> tv_items_g, tv_items_v;     // work items of a gradient / a value-only evaluation
-    std::vector<int32_t> tv_ns_host;
-    int tv_nd = 0, tv_ndp = 0, tv_lpt_shift = 0, tv_nb = 1;
-    int tv_n_items_g = 0, tv_n_items_v = 0, tv_window = -1, tv_max_nc = 1;
-    size_t tv_items_cap = 0;
-    double* tv_stats_pinned = nullptr;
-    hipEvent_t tv_stats_ev = nullptr;
-    bool tv_stats_valid = false;
-    int tv_stats_blocks = 0;
-    int16_t tv_dir_of_par[MAX_PAR];
-    // hipGraph replay of a synchronous tv evaluation (ssde_eval): upload, pre-pass, statistics read-back, filter,
-    // finalize and result read-back are captured once per plan and replayed with ONE launch call
-    hipStream_t tv_stream = nullptr;
-    hipGraphExec_t tv_gexec[2] = {nullptr, nullptr};    // [order]
-    int tv_graph_plan[2] = {-1, -1};                    // plan generation the executable was captured for
-    int tv_plan_gen = 0;
-    DevBuf<double> tv_par_dev;
-    double* tv_par_pinned = nullptr;
-    double* tv_out_pinned = nullptr;
-
-    int64_t hbm_bytes = 0;
-};
-
-namespace {
-
-#define HIPCHK(h, call)                                                                  \
-    do {                                                                                 \
-        hipError_t e__ = (call);                                                         \
-        if (e__ != hipSuccess) {                                                         \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);               \
-            return SSDE_ERR_HIP;                                                         \
-        }                                                                                \
-    } while (0)
-
+namespace ssde_engine {
 int fail(ssde_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
     g_create_error = msg;
     return code;
 }
+
+}  // namespace ssde_engine
+
+namespace {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
@@ -216,14 +49,6 @@ void destroy(ssde_handle* h) {
     if (h->par_ev_ok)
         for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
     delete h;
-}
-
-// copy a caller array (host or device) into a fresh device buffer
-template <class T>
-hipError_t stage(const T* src, size_t count, bool on_device, DevBuf<T>& dst) {
-    hipError_t e = dst.alloc(count);
-    if (e != hipSuccess || count == 0) return e;
-    return hipMemcpy(dst.p, src, count * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
 }
 
 int choose_iso_split(ssde_handle* h) {
@@ -269,354 +94,6 @@ int choose_iso_split(ssde_handle* h) {
     return 0;
 }
 
-int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev);
-
-// fill the static part of the tv argument block from the handle
-void tv_base_args(const ssde_handle* h, TvArgs& a) {
-    memset(&a, 0, sizeof(a));
-    a.times = h->times.p; a.obs = h->obs.p; a.colbuf = h->colbuf.p; a.col_stride = h->col_stride;
-    a.scored = h->scored.p; a.n = h->n; a.d = h->d; a.model = h->model; a.any_nan = h->na_any;
-    a.slots = h->slot_table.p; a.n_slots = (int)h->slots.size();
-    a.rec = h->tv_rec.p; a.wdir = h->tv_wdir.p; a.ndp = h->tv_ndp; a.lpt_shift = h->tv_lpt_shift;
-    a.dirs = h->tv_dirs.p; a.trk_row0 = h->tv_row0.p; a.trk_ns = h->tv_ns.p; a.a0 = h->tv_a0.p;
-    a.n_tracks = h->n_seg;
-    for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
-    a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
-    for (int i = 0; i < 16; i++) a.p0f[i] = h->p0_full[i];
-    a.eseal_h = h->tv_eh.p; a.eseal_R = h->tv_eR.p;
-    a.bnd = h->tv_bnd.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
-    a.stats = h->tv_stats.p; a.stats_blocks = h->tv_stats_blocks;
-    a.n_out = 1 + h->L.n_full;
-    for (int k = 0; k < MAX_PAR; k++) a.dir_of_par[k] = h->tv_dir_of_par[k];
-}
-
-// Row-varying isotropic Kalman path (k_tv.hip): long-format copies of the data, the streamed design
-// columns, one weight per (row, gradient direction), tracks sorted by length.
-int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& starts, bool on_dev) {
-    const int64_t n = d->n, M = h->n_seg;
-    h->path = PATH_TV;
-    h->max_chunks = 1 << 20;        // "1" means: forced to one sequential window (ssde_widen_windows / retries)
-    HIPCHK(h, stage(d->times, (size_t)n, on_dev, h->times));
-    HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, on_dev, h->obs));
-    if (h->has_h) HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, on_dev, h->tv_harr));
-    if (is_eseal(d->model)) {
-        HIPCHK(h, stage(d->eseal_h, (size_t)n, on_dev, h->tv_eh));
-        HIPCHK(h, stage(d->eseal_R, (size_t)n, on_dev, h->tv_eR));
-        // priors (nllk_e_seal_ssm.hpp:212-216): n and the design weights of log sigma at the first row
-        h->pen.eseal_n = n;
-        for (auto& sl : h->slots)
-            if (sl.par_j == 1) h->pen.eseal_sig0.push_back({sl.pidx, sl.col >= 0 ? sl.src[0] : 1.0});
-    }
-    h->col_stride = ((n + 63) / 64) * 64 + 160;
-    HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * h->n_stream_cols));
-    for (auto& sl : h->slots)
-        if (sl.col >= 0)
-            HIPCHK(h, hipMemcpy(h->colbuf.p + (size_t)sl.col * h->col_stride, sl.src, (size_t)n * 8,
-                                on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    {
-        DevBuf<double> idb;
-        const double* idp = d->id;
-        if (!on_dev) { HIPCHK(h, stage(d->id, (size_t)n, false, idb)); idp = idb.p; }
-        HIPCHK(h, h->scored.alloc((size_t)((n + 31) / 32)));
-        HIPCHK(h, launch_scored_mask(idp, n, h->scored.p, 0));
-        HIPCHK(h, hipDeviceSynchronize());
-        idb.release();
-    }
-    // tracks, longest first (stable): the tracks of one wave ("pack") then have similar lengths
-    std::vector<int64_t> order(M);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-        return (starts[a + 1] - starts[a]) > (starts[b + 1] - starts[b]);
-    });
-    std::vector<int64_t> row0(M), seg(M);
-    std::vector<int32_t> ns(M);
-    for (int64_t t = 0; t < M; t++) {
-        const int64_t sg = order[t], len = starts[sg + 1] - starts[sg];
-        if (len - 1 > INT32_MAX) return fail(h, SSDE_ERR_ARG, "track too long");
-        row0[t] = starts[sg]; seg[t] = sg; ns[t] = (int32_t)(len - 1);
-    }
-    HIPCHK(h, h->tv_row0.upload(row0));
-    HIPCHK(h, h->tv_ns.upload(ns));
-    h->tv_ns_host = ns;
-    h->glen_max = M > 0 ? ns[0] : 0;
-    // gradient directions: log_sigma_obs, then every free coefficient slot
-    std::vector<TvDir> dirs;
-    for (int k = 0; k < MAX_PAR; k++) h->tv_dir_of_par[k] = -1;
-    if (!h->fixed[0]) { h->tv_dir_of_par[0] = (int16_t)dirs.size(); dirs.push_back({TVK_SIG, 0, 0, -1}); }   // log_sigma_obs / log_tau
-    if (is_eseal(d->model)) {                                            // a1, log_a2 (nllk_e_seal_ssm.hpp:115-116)
-        if (!h->fixed[1]) { h->tv_dir_of_par[1] = (int16_t)dirs.size(); dirs.push_back({TVK_A1, 0, 1, -1}); }
-        if (!h->fixed[2]) { h->tv_dir_of_par[2] = (int16_t)dirs.size(); dirs.push_back({TVK_A2, 0, 2, -1}); }
-    }
-    for (size_t k = 0; k < h->slots.size(); k++) {
-        const Slot& sl = h->slots[k];
-        if (h->fixed[sl.pidx]) continue;
-        TvDir t;
-        t.kind = (int16_t)(sl.par_j < h->d ? TVK_MU : (sl.par_j == h->d ? TVK_P1 : TVK_P2));
-        t.dim = (int16_t)(sl.par_j < h->d ? sl.par_j : 0);
-        t.pidx = (int16_t)sl.pidx; t.slot = (int16_t)k;
-        h->tv_dir_of_par[sl.pidx] = (int16_t)dirs.size();
-        dirs.push_back(t);
-    }
-    h->tv_nd = (int)dirs.size();
-    int shift = 0;
-    while ((1 << shift) < h->tv_nd && shift < 6) shift++;
-    h->tv_lpt_shift = shift;
-    const int lpt = 1 << shift;
-    h->tv_nb = std::max(1, (h->tv_nd + lpt - 1) / lpt);
-    h->tv_ndp = h->tv_nb * lpt;
-    dirs.resize(h->tv_ndp, TvDir{TVK_NONE, 0, -1, -1});
-    HIPCHK(h, h->tv_dirs.upload(dirs));
-    // slot table (also uploaded by the common tail; the weights kernel needs it now)
-    {
-        SlotTable st;
-        memset(&st, 0, sizeof(st));
-        st.n_slots = (int)h->slots.size(); st.q = h->q;
-        for (size_t k = 0; k < h->slots.size(); k++) {
-            st.par_j[k] = (int16_t)h->slots[k].par_j; st.col[k] = (int16_t)h->slots[k].col;
-            st.pidx[k] = (int16_t)h->slots[k].pidx; st.is_free[k] = h->fixed[h->slots[k].pidx] ? 0 : 1;
-        }
-        HIPCHK(h, h->slot_table.upload(std::vector<SlotTable>(1, st)));
-    }
-    HIPCHK(h, h->tv_wdir.alloc((size_t)n * h->tv_ndp));
-    HIPCHK(h, h->tv_rec.alloc((size_t)n * TV_RS));
-    HIPCHK(h, h->tv_a0.alloc((size_t)M * h->sdim));
-    h->tv_stats_blocks = (int)std::min<int64_t>((n + 255) / 256, 256);
-    HIPCHK(h, h->tv_stats.alloc((size_t)h->tv_stats_blocks * TV_STATS));
-    HIPCHK(h, hipHostMalloc((void**)&h->tv_stats_pinned, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipHostMallocDefault));
-    HIPCHK(h, hipEventCreateWithFlags(&h->tv_stats_ev, hipEventDisableTiming));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->tv_stream, hipStreamNonBlocking));
-    HIPCHK(h, h->tv_par_dev.alloc(MAX_PAR));
-    HIPCHK(h, hipHostMalloc((void**)&h->tv_par_pinned, MAX_PAR * 8, hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void**)&h->tv_out_pinned, (MAX_PAR + 2) * 8, hipHostMallocDefault));
-    TvArgs a;
-    tv_base_args(h, a);
-    HIPCHK(h, launch_tv_weights(a, 0));
-    {
-        DevBuf<double> s_a0;
-        DevBuf<int64_t> s_seg;
-        if (d->a0) {
-            HIPCHK(h, stage(d->a0, (size_t)h->n_seg * h->sdim, false, s_a0));   // a0 is tiny: always a host array
-            HIPCHK(h, s_seg.upload(seg));
-        }
-        HIPCHK(h, launch_tv_a0(a, s_a0.p, s_seg.p, h->n_seg, h->sdim, h->tv_a0.p, 0));
-        HIPCHK(h, hipDeviceSynchronize());
-        s_a0.release(); s_seg.release();
-    }
-    h->hbm_bytes = (int64_t)(h->times.n + h->obs.n + h->colbuf.n + h->tv_wdir.n + h->tv_rec.n + h->tv_a0.n + h->tv_harr.n) * 8 +
-                   (int64_t)h->scored.n * 4;
-    return SSDE_OK;
-}
-
-// spectral radius of the stationary closed-loop matrix T - K Z for constant parameters (see plan_windows)
-double closed_loop_rho(int model, double dt, double p1, double p2, double hobs, const double* p0) {
-    if (!(dt > 0.0) || !std::isfinite(dt)) return 1.0;
-    if (model == SSDE_MODEL_CTCRW) {
-        const double tau = exp(p1), nu = exp(p2);
-        CtcrwTrans tr;
-        ctcrw_trans(dt, tau, 1.0 / tau, 2.0 * nu / sqrt(M_PI * tau), tr);
-        double p11 = p0[0], p12 = p0[1], p22 = p0[2], k1 = 0, k2 = 0;
-        for (int it = 0; it < 20000; it++) {
-            const double F = p11 + hobs, iF = 1.0 / F;
-            const double tp11 = p11 + tr.t12 * p12, tp12 = p12 + tr.t12 * p22, tp21 = tr.e * p12, tp22 = tr.e * p22;
-            k1 = tp11 * iF; k2 = tp21 * iF;
-            const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11, n12 = -tp11 * k2 + tp12 * tr.e + tr.q12,
-                         n22 = -tp21 * k2 + tp22 * tr.e + tr.q22;
-            const double ch = std::fabs(n11 - p11) + std::fabs(n12 - p12) + std::fabs(n22 - p22);
-            p11 = n11; p12 = n12; p22 = n22;
-            if (ch <= 1e-15 * (std::fabs(p11) + std::fabs(p22))) break;
-        }
-        const double trc = (1.0 - k1) + tr.e, det = (1.0 - k1) * tr.e + k2 * tr.t12;
-        const double disc = trc * trc - 4.0 * det;
-        return disc >= 0.0 ? std::max(std::fabs(0.5 * (trc + std::sqrt(disc))), std::fabs(0.5 * (trc - std::sqrt(disc))))
-                           : std::sqrt(std::fabs(det));
-    }
-    ScalTrans tr;
-    if (model == SSDE_MODEL_OU_SSM) ou_trans(dt, exp(p1), exp(p2), tr);
-    else bm_trans(dt, exp(p1), tr);
-    double p = p0[0], k = 0;
-    for (int it = 0; it < 20000; it++) {
-        const double F = p + hobs, tp = tr.t * p;
-        k = tp / F;
-        const double np_ = tp * (tr.t - k) + tr.q;
-        const double ch = std::fabs(np_ - p);
-        p = np_;
-        if (ch <= 1e-15 * std::fabs(p)) break;
-    }
-    return std::fabs(tr.t - k);
-}
-
-// Time windows of the tv path.  The warm-up length comes from the slowest-forgetting corner of the
-// parameter ranges the LAST evaluation's pre-pass saw (dt, par[d], par[d+1]); the device-side
-// hand-over check decides whether it was enough.  Rebuilds the work-item tables when the plan changes.
-int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2 (replaced by the largest diag(H) with H_array)
-    int W = 0;
-    if (h->max_chunks > 1 && h->tv_stats_valid && !is_eseal(h->model)) {   // ESEAL tracks: one sequential window
-        double lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int b = 0; b < h->tv_stats_blocks; b++)
-            for (int k = 0; k < 4; k++) {
-                lo[k] = std::min(lo[k], h->tv_stats_pinned[b * TV_STATS + 2 * k]);
-                hi[k] = std::max(hi[k], h->tv_stats_pinned[b * TV_STATS + 2 * k + 1]);
-            }
-        double rho = 0.0;
-        bool ok = std::isfinite(lo[0]) && std::isfinite(hi[0]) && std::isfinite(lo[1]) && std::isfinite(hi[1]) &&
-                  std::isfinite(lo[2]) && std::isfinite(hi[2]);
-        // per-row H_array: the largest observation variance forgets slowest
-        if (h->has_h) { ok = ok && std::isfinite(hi[3]) && hi[3] > 0.0; hobs = hi[3]; }
-        const double p0d[3] = {h->p0_full[0], h->model == SSDE_MODEL_CTCRW ? h->p0_full[1] : 0.0,
-                               h->model == SSDE_MODEL_CTCRW ? h->p0_full[1 + h->sdim] : 0.0};
-        if (ok)
-            for (int c = 0; c < 8; c++) {
-                const double r = closed_loop_rho(h->model, (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1],
-                                                 (c & 4) ? hi[2] : lo[2], hobs, p0d);
-                rho = std::max(rho, std::isfinite(r) ? r : 1.0);
-            }
-        if (ok && rho < 0.9995) {
-            int64_t w = (int64_t)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
-            w = std::max<int64_t>(w, 16);
-            if (const char* e = getenv("SSDE_WINDOW")) w = std::max(1, atoi(e));
-            w *= h->window_boost;
-            w = (w + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-            if (2 * w <= h->glen_max) W = (int)w;
-        }
-    }
-    // keep the current plan while it is at least as careful and not wastefully so
-    if (h->tv_window >= 0 && h->tv_n_items_g > 0 && ((W == 0) == (h->tv_window == 0)) && W <= h->tv_window &&
-        h->tv_window <= 2 * W + WIN_ALIGN)
-        return SSDE_OK;
-    const int tpw = WAVE >> h->tv_lpt_shift;
-    const int64_t n_packs = (h->n_seg + tpw - 1) / tpw;
-    int target = 2048;
-    if (const char* e = getenv("SSDE_TV_WAVES")) target = std::max(1, atoi(e));
-    const int nc_cap = (int)std::max<int64_t>(1, (target + n_packs * h->tv_nb - 1) / (n_packs * h->tv_nb));
-    std::vector<TvItem> ig, iv;
-    int max_nc = 1;
-    for (int64_t p = 0; p < n_packs; p++) {
-        const int L = h->tv_ns_host[(size_t)p * tpw];
-        int nc = 1;
-        // As many windows as the chip has room for (nc_cap): with idle SIMDs around, a window may be much
-        // shorter than its warm-up -- the redundant warm-up rows run in parallel, the serial chain of a wave
-        // is what the evaluation waits for.  SSDE_TV_MINLEN: shortest scored stretch of a window (rows).
-        int minlen = 2 * WIN_ALIGN;
-        if (const char* e = getenv("SSDE_TV_MINLEN")) minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
-        if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + minlen - 1) / minlen));
-        max_nc = std::max(max_nc, nc);
-        for (int b = 0; b < h->tv_nb; b++)
-            for (int c = 0; c < nc; c++) {
-                ig.push_back({(int32_t)p, c, nc, b});
-                if (b == 0) iv.push_back({(int32_t)p, c, nc, 0});
-            }
-    }
-    // earlier evaluations may still be reading the old tables
-    HIPCHK(h, hipStreamSynchronize(s));
-    if (ig.size() > h->tv_items_cap) {
-        h->tv_items_g.release(); h->tv_items_v.release(); h->tv_bnd.release(); h->tv_chk.release();
-        h->tv_gval.release(); h->tv_gdir.release();
-        h->tv_items_cap = ig.size() + ig.size() / 2;
-        HIPCHK(h, h->tv_items_g.alloc(h->tv_items_cap));
-        HIPCHK(h, h->tv_items_v.alloc(h->tv_items_cap));
-        HIPCHK(h, h->tv_bnd.alloc(h->tv_items_cap * 2 * TV_NSTATE * WAVE));
-        HIPCHK(h, h->tv_chk.alloc(h->tv_items_cap));
-        HIPCHK(h, h->tv_gval.alloc(h->tv_items_cap * WAVE));
-        HIPCHK(h, h->tv_gdir.alloc(h->tv_items_cap * WAVE));
-    }
-    HIPCHK(h, hipMemcpy(h->tv_items_g.p, ig.data(), ig.size() * sizeof(TvItem), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->tv_items_v.p, iv.data(), iv.size() * sizeof(TvItem), hipMemcpyHostToDevice));
-    h->tv_n_items_g = (int)ig.size(); h->tv_n_items_v = (int)iv.size();
-    h->tv_window = W; h->tv_max_nc = max_nc;
-    h->tv_plan_gen++;                                    // captured graphs of the old plan are stale
-    return SSDE_OK;
-}
-
-int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s) {
-    const double* pdev = nullptr;
-    int st = push_par(h, par, s, &pdev);
-    if (st) return st;
-    TvArgs a;
-    tv_base_args(h, a);
-    a.par = pdev;
-    a.out = out_dev;                                     // the pre-pass zeroes the hand-over check slot
-    const double sig = exp(par[0]);                      // nllk_ctcrw.hpp:136 (unused when H_array is supplied)
-    a.h = sig * sig;
-    const size_t stats_bytes = (size_t)h->tv_stats_blocks * TV_STATS * 8;
-    bool prepared = false;
-    if (!h->tv_stats_valid) {
-        // first evaluation: the planner needs the parameter ranges of THIS parameter vector
-        HIPCHK(h, launch_tv_prepare(a, s));
-        HIPCHK(h, hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, stats_bytes, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-        h->tv_stats_valid = true;
-        prepared = true;
-    } else {
-        HIPCHK(h, hipEventSynchronize(h->tv_stats_ev));  // ranges seen by the previous evaluation
-    }
-    st = tv_plan(h, a.h, s);
-    if (st) return st;
-    tv_base_args(h, a);                                  // the plan may have re-allocated the item buffers
-    a.par = pdev; a.h = sig * sig; a.out = out_dev;
-    a.h_from_par = 1;                                    // same arithmetic as the graph replay: bitwise-equal results
-    a.window = h->tv_window;
-    if (!prepared) {
-        HIPCHK(h, launch_tv_prepare(a, s));
-        HIPCHK(h, hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, stats_bytes, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(h, hipEventRecord(h->tv_stats_ev, s));
-    const bool grad = order >= 1;
-    a.items = grad ? h->tv_items_g.p : h->tv_items_v.p;
-    a.n_items = grad ? h->tv_n_items_g : h->tv_n_items_v;
-    a.out = out_dev;
-    HIPCHK(h, hipEventRecord(h->ev_k0, s));
-    HIPCHK(h, launch_tv_filter(a, grad, s));
-    HIPCHK(h, hipEventRecord(h->ev_k1, s));
-    h->ev_k_valid = true; h->last_s_stat = -1;
-    HIPCHK(h, launch_tv_finalize(a, s));
-    h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
-    return SSDE_OK;
-}
-
-// Synchronous tv evaluation replayed from a hipGraph: the evaluation is launch-bound (C1: 40 us of kernels,
-// seven stream operations), so the whole sequence is captured once per plan and direction order.  Needs the
-// parameter ranges of an earlier evaluation (the planner's input), so the first evaluation takes eval_tv.
-int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) {
-    const int n_full = h->L.n_full;
-    const int ord = order >= 1 ? 1 : 0;
-    const double sig = exp(par[0]);
-    int st = tv_plan(h, sig * sig, h->tv_stream);        // from the statistics of the previous evaluation
-    if (st) return st;
-    if (!h->tv_gexec[ord] || h->tv_graph_plan[ord] != h->tv_plan_gen) {
-        if (h->tv_gexec[ord]) { (void)hipGraphExecDestroy(h->tv_gexec[ord]); h->tv_gexec[ord] = nullptr; }
-        TvArgs a;
-        tv_base_args(h, a);
-        a.par = h->tv_par_dev.p; a.h_from_par = 1; a.h = 0.0; a.out = h->out.p; a.window = h->tv_window;
-        a.items = ord ? h->tv_items_g.p : h->tv_items_v.p;
-        a.n_items = ord ? h->tv_n_items_g : h->tv_n_items_v;
-        hipStream_t s = h->tv_stream;
-        hipGraph_t g = nullptr;
-        HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(h->tv_par_dev.p, h->tv_par_pinned, (size_t)n_full * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = launch_tv_prepare(a, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = launch_tv_filter(a, ord == 1, s);
-        if (e == hipSuccess) e = launch_tv_finalize(a, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_out_pinned, h->out.p, (size_t)(2 + n_full) * 8, hipMemcpyDeviceToHost, s);
-        hipError_t e2 = hipStreamEndCapture(s, &g);
-        if (e != hipSuccess || e2 != hipSuccess) {
-            if (g) (void)hipGraphDestroy(g);
-            h->err = std::string("hipGraph capture of the tv evaluation failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-            return SSDE_ERR_HIP;
-        }
-        e = hipGraphInstantiate(&h->tv_gexec[ord], g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e != hipSuccess) { h->tv_gexec[ord] = nullptr; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return SSDE_ERR_HIP; }
-        h->tv_graph_plan[ord] = h->tv_plan_gen;
-    }
-    memcpy(h->tv_par_pinned, par, (size_t)n_full * 8);
-    HIPCHK(h, hipGraphLaunch(h->tv_gexec[ord], h->tv_stream));
-    HIPCHK(h, hipStreamSynchronize(h->tv_stream));
-    memcpy(o_host, h->tv_out_pinned, (size_t)(2 + n_full) * 8);
-    h->ev_k_valid = false;                               // no per-kernel timing inside a replayed graph
-    h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
-    return SSDE_OK;
-}
 
 int build(const ssde_desc* d, ssde_handle* h) {
     // ---- descriptor checks -------------------------------------------------------------------
@@ -1168,6 +645,9 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     return SSDE_OK;
 }
 
+}  // namespace
+
+namespace ssde_engine {
 // upload the parameter vector for the dense / direct kernels; returns the device pointer
 int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev) {
     const int slot = h->par_next;
@@ -1181,6 +661,9 @@ int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** de
     *dev = devp;
     return SSDE_OK;
 }
+}  // namespace ssde_engine
+
+namespace {
 
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s) {
     HIPCHK(h, hipSetDevice(h->device));

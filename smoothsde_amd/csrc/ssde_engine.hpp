@@ -1,0 +1,211 @@
+// ssde_engine.hpp -- internals shared by the engine's translation units (ssde_engine.hip: C ABI, constant-coefficient
+// and direct paths; ssde_engine_tv.hip: the lane = gradient direction path).  Not part of the C ABI.
+#ifndef SSDE_ENGINE_HPP
+#define SSDE_ENGINE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/ssde.h"
+#include "ssde_device.hpp"
+#include "ssde_host.hpp"
+#include "ssde_tv.hpp"
+
+namespace ssde_engine {
+
+extern thread_local std::string g_create_error;   // message of the last failed ssde_create on this thread
+
+enum { PATH_DIRECT = 0, PATH_ISO = 1, PATH_DENSE = 2, PATH_TV = 3 };
+constexpr int PAR_RING = 8;
+constexpr double SSDE_WINDOW_TOL = 1e-11;  // largest tolerated relative hand-over disagreement
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) { p = nullptr; return hipSuccess; }
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace ssde_engine
+
+using ssde_engine::DevBuf;
+using ssde_engine::PAR_RING;
+using namespace ssde;
+using namespace ssde_host;
+
+struct ssde_handle {
+    std::string err;
+    int model = 0, d = 0, q = 0, sdim = 0, na_any = 0, device = 0, path = 0;
+    int64_t n = 0, n_seg = 0, n_steps = 0;
+    bool has_h = false, const_coeff = false, uniform_dt = false;
+    double dt_uniform = 0.0;
+    double tdf = 0.0, tconst = 0.0;     // BM_t: degrees of freedom, normalising constant of dt(., df)
+    double p0_iso[3] = {0, 0, 0};
+    double p0_full[16] = {0};
+    ParLayout L;
+    Penalty pen;
+    std::vector<Slot> slots;
+    int n_stream_cols = 0;
+    std::vector<uint8_t> fixed;
+    int n_free = 0;
+
+    // Kalman tiles
+    DevBuf<double> tiles, a0;
+    DevBuf<int64_t> group_off, lane_row0;
+    DevBuf<int32_t> group_len, lane_nsteps;
+    int n_groups = 0, C = 0;
+    int64_t tile_doubles = 0;
+
+    // direct families (long format, engine-owned copies)
+    DevBuf<double> times, obs, colbuf, tdecay;
+    DevBuf<uint32_t> scored;
+    DevBuf<const double*> colptr;
+    int direct_blocks = 0;
+
+    // fast direct kernel (<= 2 parameters with streamed columns)
+    bool direct_fast = false;
+    int64_t col_stride = 0;                        // doubles between consecutive streamed columns
+    int df_ja = -1, df_jb = -1;
+    std::vector<int> df_pidxA, df_pidxB;          // full-par indices of the streamed coefficients
+    int df_icpt[MAX_Q] = {-1, -1, -1, -1};         // full-par index of each parameter's intercept, or -1
+    const double *df_colA = nullptr, *df_colB = nullptr;
+    bool direct_uniform_dt = false;
+    double direct_dt = 0.0;
+
+    // dense / direct parameter plumbing
+    DevBuf<SlotTable> slot_table;
+    DevBuf<DenseDir> dirs;
+    std::vector<DenseDir> dirs_host;
+    int n_dirblocks = 0;
+    DevBuf<double> par_ring;
+    double* par_pinned = nullptr;
+    hipEvent_t par_ev[PAR_RING];
+    bool par_ev_ok = false;
+    int par_next = 0;
+
+    DevBuf<double> partials, out;
+    size_t partial_doubles = 0;
+
+    // iso time windows
+    DevBuf<double> bnd, chk;
+    int max_chunks = 1;            // allocation bound
+    int want_chunks = 1;           // planned number of equal windows (the transient window comes on top)
+    int glen_max = 0;              // steps of the longest track group
+    double dt_min = 0.0;           // smallest interval used inside a track
+    bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
+    int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
+    int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
+    int last_chunks = 1, last_window = 0;
+    double last_check = 0.0;
+    int n_retries = 0;
+
+    // shared-covariance path
+    DevBuf<int32_t> group_flags;
+    int n_clean_groups = 0;
+    bool use_shared = false;
+    std::vector<std::pair<int, int64_t>> clean_ns_hist;  // (scored rows, number of tracks) over NaN-free groups
+    DevBuf<double> gain_ring;
+    double* gain_pinned = nullptr;
+    size_t gain_rows_cap = 0;
+    int last_gain_rows = 0;
+
+    // side streams: the kernels of one evaluation that do not depend on each other run concurrently
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+
+    // timing of the dominant kernel (recorded on the stream it is launched on)
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    bool ev_k_valid = false;
+    std::vector<int32_t> glen_host, lane_ns_host;
+    int last_s_stat = 0, last_t0 = 0;
+    mutable int rows_key[3] = {-1, -1, -1};
+    mutable int64_t rows_cached = 0;
+
+    // iso direction split
+    int iso_parts = 1;
+    int iso_masks[MAX_PARTS] = {0, 0, 0, 0};
+    int iso_free_mask = 0;
+
+    // row-varying isotropic path (k_tv.hip)
+    DevBuf<double> tv_rec, tv_wdir, tv_a0, tv_bnd, tv_chk, tv_gval, tv_gdir, tv_stats, tv_harr, tv_eh, tv_eR;
+    bool tv_dense = false;         // full-covariance lanes: per-row H_array and / or a P0 that is not block-identical
+    DevBuf<TvDir> tv_dirs;
+    DevBuf<int64_t> tv_row0;
+    DevBuf<int32_t> tv_ns;
+    DevBuf<TvItem> tv_items_g, tv_items_v;     // work items of a gradient / a value-only evaluation
+    std::vector<int32_t> tv_ns_host;
+    int tv_nd = 0, tv_ndp = 0, tv_lpt_shift = 0, tv_nb = 1;
+    int tv_n_items_g = 0, tv_n_items_v = 0, tv_window = -1, tv_max_nc = 1;
+    size_t tv_items_cap = 0;
+    double* tv_stats_pinned = nullptr;
+    hipEvent_t tv_stats_ev = nullptr;
+    bool tv_stats_valid = false;
+    int tv_stats_blocks = 0;
+    int16_t tv_dir_of_par[MAX_PAR];
+    // hipGraph replay of a synchronous tv evaluation (ssde_eval): upload, pre-pass, statistics read-back, filter,
+    // finalize and result read-back are captured once per plan and replayed with ONE launch call
+    hipStream_t tv_stream = nullptr;
+    hipGraphExec_t tv_gexec[2] = {nullptr, nullptr};    // [order]
+    int tv_graph_plan[2] = {-1, -1};                    // plan generation the executable was captured for
+    int tv_plan_gen = 0;
+    DevBuf<double> tv_par_dev;
+    double* tv_par_pinned = nullptr;
+    double* tv_out_pinned = nullptr;
+
+    int64_t hbm_bytes = 0;
+};
+
+
+namespace ssde_engine {
+
+#define HIPCHK(h, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);               \
+            return SSDE_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+
+int fail(ssde_handle* h, int code, const std::string& msg);
+
+// copy a caller array (host or device) into a fresh device buffer
+template <class T>
+inline hipError_t stage(const T* src, size_t count, bool on_device, DevBuf<T>& dst) {
+    hipError_t e = dst.alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(dst.p, src, count * sizeof(T), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+}
+
+
+// upload the parameter vector for the dense / direct / tv kernels; returns the device pointer (ssde_engine.hip)
+int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** dev);
+
+// ---- lane = gradient direction path (ssde_engine_tv.hip) ------------------------------------------------------------
+void tv_base_args(const ssde_handle* h, TvArgs& a);
+int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& starts, bool on_dev);
+int tv_plan(ssde_handle* h, double hobs, hipStream_t s);
+int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s);
+int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host);
+
+}  // namespace ssde_engine
+#endif
