@@ -15,6 +15,8 @@
 // SHARED_U rows ahead into registers; the dt channel is never read (16 B/row actual traffic
 // for 24 B/row of algorithmic input).  Time windows and their hand-over check work exactly as
 // in k_iso.hip, except that only the mean state needs a warm-up (the gains are exact).
+#include <hip/hip_ext.h>
+
 #include "ssde_device.hpp"
 
 namespace ssde {
@@ -640,10 +642,12 @@ void fill_stat_consts(int model, int d, IsoArgs& a) {
 }
 
 template <int MODEL, int D>
-static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
+static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     dim3 block(WG_WAVES * WAVE);
     switch (a.part_mask[0]) {
-#define SSDE_CASE(M) case M: hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
+    // hipExtLaunchKernelGGL stamps ev0 / ev1 with the kernel's own begin / end (what rocprof reports), not with the
+    // stream position of separately recorded events
+#define SSDE_CASE(M) case M: hipExtLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, ev0, ev1, 0, a); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE
@@ -653,18 +657,18 @@ static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s) {
 }
 
 // the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0])
-hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s) {
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (a.n_parts != 1) return hipErrorInvalidValue;
     const int g8 = (a.tv.n_groups + 7) / 8;
     const int n_grid_chunks = a.t0 > 0 ? a.n_chunks - 1 : a.n_chunks;
     dim3 grid((g8 * 8 * n_grid_chunks + WG_WAVES - 1) / WG_WAVES);
     if (grid.x == 0) return hipSuccess;
-    if (model == M_CTCRW && d == 1) return launch_masks<M_CTCRW, 1>(a, grid, s);
-    if (model == M_CTCRW && d == 2) return launch_masks<M_CTCRW, 2>(a, grid, s);
-    if (model == M_OU_SSM && d == 1) return launch_masks<M_OU_SSM, 1>(a, grid, s);
-    if (model == M_OU_SSM && d == 2) return launch_masks<M_OU_SSM, 2>(a, grid, s);
-    if (model == M_BM_SSM && d == 1) return launch_masks<M_BM_SSM, 1>(a, grid, s);
-    if (model == M_BM_SSM && d == 2) return launch_masks<M_BM_SSM, 2>(a, grid, s);
+    if (model == M_CTCRW && d == 1) return launch_masks<M_CTCRW, 1>(a, grid, s, ev0, ev1);
+    if (model == M_CTCRW && d == 2) return launch_masks<M_CTCRW, 2>(a, grid, s, ev0, ev1);
+    if (model == M_OU_SSM && d == 1) return launch_masks<M_OU_SSM, 1>(a, grid, s, ev0, ev1);
+    if (model == M_OU_SSM && d == 2) return launch_masks<M_OU_SSM, 2>(a, grid, s, ev0, ev1);
+    if (model == M_BM_SSM && d == 1) return launch_masks<M_BM_SSM, 1>(a, grid, s, ev0, ev1);
+    if (model == M_BM_SSM && d == 2) return launch_masks<M_BM_SSM, 2>(a, grid, s, ev0, ev1);
     return hipErrorInvalidValue;
 }
 

@@ -101,7 +101,8 @@ __host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool ha
             ((mask & DIR_MU) ? 1 : 0)) * sd;
 }
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
-hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s);
+// ev0 / ev1 (may be NULL): stamped with the kernel's own begin / end
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
 struct ReduceArgs;
 // the hand-over checks and the final sums of an isotropic evaluation in ONE launch (the checks raise out[n_out])

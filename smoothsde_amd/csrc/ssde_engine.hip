@@ -759,9 +759,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                 HIPCHK(h, launch_iso(h->model, h->d, a, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
-            HIPCHK(h, hipEventRecord(h->ev_k0, s));
-            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s));
-            HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->ev_k0, h->ev_k1));
             h->ev_k_valid = true;
             h->last_s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
