@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 4
+#define SSDE_ABI_VERSION 5
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -96,6 +96,20 @@ enum {
 #define SSDE_FLAG_DEVICE_DATA   0x1u /* id/times/obs/x_fe/x_re/h_array pointers are HBM pointers on `device` */
 #define SSDE_FLAG_FORCE_DENSE   0x2u /* disable the isotropic register path (testing the dense path)         */
 #define SSDE_FLAG_NO_UNIFORM_DT 0x4u /* disable hoisting of the transition matrices on a regular time grid    */
+
+/* A random-effect design block given as a FUNCTION of one covariate instead of as n x K numbers: a piecewise-cubic
+ * table (regression-spline bases -- mgcv "cr", "cs", "bs", "ps" -- are exactly that; thin-plate bases are not and
+ * keep being streamed):
+ *     X[i, k] = sum_{m=0..3} coef[(iv * n_cols + k) * 4 + m] * t^m,   t = x[i] - knots[iv],
+ *     iv = the interval knots[iv] <= x[i] < knots[iv+1] (x outside the knot range uses the first / last interval).
+ * The direct families then read 8 B/row (x) where the streamed block costs 8 K B/row. */
+typedef struct ssde_ppbasis {
+    const double *x;              /* [n] covariate (host, or HBM with SSDE_FLAG_DEVICE_DATA) */
+    int32_t  n_knots;             /* breakpoints; n_knots - 1 intervals */
+    int32_t  n_cols;              /* K == ncol_re[j] */
+    const double *knots;          /* [n_knots] increasing (host) */
+    const double *coef;           /* [(n_knots - 1) * n_cols * 4] (host) */
+} ssde_ppbasis;
 
 typedef struct ssde_desc {
     int32_t  abi_version;     /* SSDE_ABI_VERSION */
@@ -150,6 +164,9 @@ typedef struct ssde_desc {
      * nllk_e_seal_ssm.hpp:100-101, R/sde.R:611-614 */
     const double *eseal_h;        /* [n] */
     const double *eseal_R;        /* [n] */
+    /* [q] or NULL.  basis_re[j] != NULL: the random-effect block of SDE parameter j is evaluated from this table
+     * (x_re[j] is then ignored by the engine and may be NULL). */
+    const ssde_ppbasis *const *basis_re;
 } ssde_desc;
 
 typedef struct ssde_handle ssde_handle;

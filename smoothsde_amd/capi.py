@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -30,6 +30,11 @@ FLAG_DEVICE_DATA, FLAG_FORCE_DENSE, FLAG_NO_UNIFORM_DT = 0x1, 0x2, 0x4
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
+
+
+class SsdePPBasis(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("n_knots", C.c_int32), ("n_cols", C.c_int32), ("knots", C.c_void_p),
+                ("coef", C.c_void_p)]
 
 
 class SsdeDesc(C.Structure):
@@ -48,6 +53,7 @@ class SsdeDesc(C.Structure):
         ("n_decay", C.c_int32), ("t_decay", C.c_void_p), ("n_decay_cols", C.c_int32), ("reserved3", C.c_int32),
         ("col_decay", C.c_void_p), ("ind_decay", C.c_void_p),
         ("eseal_h", C.c_void_p), ("eseal_R", C.c_void_p),
+        ("basis_re", C.POINTER(C.POINTER(SsdePPBasis))),
     ]
 
 
@@ -101,7 +107,7 @@ class Problem:
                  X_re: Optional[Sequence] = None, S_list: Optional[Sequence] = None,
                  a0=None, P0=None, H=None, par_fixed=None, include_penalty: int = 1,
                  na_mode: int = NA_ANY_NAN, device: int = -1, flags: int = 0, other_data=None,
-                 t_decay=None, col_decay=None, ind_decay=None, eseal_h=None, eseal_R=None):
+                 t_decay=None, col_decay=None, ind_decay=None, eseal_h=None, eseal_R=None, basis_re=None):
         if model in UNSUPPORTED_MODELS:
             raise NotImplementedError(f"SDE type {model!r} is outside this engine's scope")
         if model not in MODEL_CODES:
@@ -122,6 +128,15 @@ class Problem:
         if self.id.shape != (self.n,) or self.times.shape != (self.n,):
             raise ValueError("ID, times and obs must have the same number of rows")
 
+        # basis_re[j]: a synth.PPBasis -- the random-effect block of parameter j as a piecewise-cubic function of one
+        # covariate (include/ssde.h: ssde_ppbasis).  The dense block it stands for is kept in X_re[j] as well: the
+        # oracle and the generic kernels use it, the engine's fast direct kernel evaluates the table instead.
+        self.basis_re = [None] * self.q if basis_re is None else list(basis_re)
+        if any(b is not None for b in self.basis_re):
+            X_re = [None] * self.q if X_re is None else list(X_re)
+            for j, b in enumerate(self.basis_re):
+                if b is not None:
+                    X_re[j] = b.dense()
         self.X_fe, self.X_re = [], []
         ncol_fe, ncol_re = [], []
         for j in range(self.q):
@@ -232,7 +247,7 @@ class Problem:
 
     @classmethod
     def from_torch(cls, model: str, ID, times, obs, par_fixed=None, na_mode: int = NA_ANY_NAN, flags: int = 0,
-                   X_re=None, S_list=None):
+                   X_re=None, S_list=None, basis_re=None):
         """Problem whose data already live in HBM (torch CUDA tensors, fp64): the engine re-tiles /
         copies them on the device instead of uploading (SSDE_FLAG_DEVICE_DATA).  Fixed effects are
         intercept-only; `X_re[j]` may be an (n, k) CUDA tensor of streamed design columns for SDE
@@ -260,9 +275,15 @@ class Problem:
         self.n_fe, self.n_re = self.q, 0
         self.S_list, self.smooth_ncol, self.s_blocks, self.n_smooth = [], np.zeros(0, dtype=np.int32), None, 0
         self._t_xre = [None] * self.q
+        # basis_re[j]: synth.PPBasis whose covariate x is a CUDA tensor -- no n x K block exists anywhere
+        self.basis_re = [None] * self.q if basis_re is None else list(basis_re)
+        if X_re is None and any(b is not None for b in self.basis_re):
+            X_re = [None] * self.q
         if X_re is not None:
             for j in range(self.q):
-                if X_re[j] is not None:
+                if self.basis_re[j] is not None:
+                    self.ncol_re[j] = self.basis_re[j].n_cols
+                elif X_re[j] is not None:
                     xt = X_re[j].to(torch.float64)
                     self._t_xre[j] = xt.t().contiguous()          # (k, n) row-major == (n, k) column-major
                     self.ncol_re[j] = xt.shape[1]
@@ -363,6 +384,24 @@ class Problem:
             d.t_decay, d.n_decay_cols = ptr(self.t_decay), len(self.col_decay)
             d.col_decay, d.ind_decay = ptr(self.col_decay), ptr(self.ind_decay)
         d.eseal_h, d.eseal_R = ptr(getattr(self, "eseal_h", None)), ptr(getattr(self, "eseal_R", None))
+        bl = getattr(self, "basis_re", None)
+        if bl is not None and any(b is not None for b in bl):
+            arr = (C.POINTER(SsdePPBasis) * self.q)()
+            for j, b in enumerate(bl):
+                if b is None:
+                    continue
+                sb = SsdePPBasis()
+                if hasattr(b.x, "data_ptr"):
+                    sb.x = b.x.data_ptr()
+                    keep.append(b.x)
+                else:
+                    sb.x = ptr(_f64(b.x))
+                sb.n_knots, sb.n_cols = len(b.knots), b.n_cols
+                sb.knots, sb.coef = ptr(b.knots), ptr(b.coef)
+                keep.append(sb)
+                arr[j] = C.pointer(sb)
+            keep.append(arr)
+            d.basis_re = arr
         return d
 
 

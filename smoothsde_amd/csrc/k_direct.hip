@@ -13,6 +13,8 @@
 // coefficients and slot->parameter routing live in scalar registers, intercept-only parameters
 // are folded into per-parameter constants, and exp() of a log-scale parameter is evaluated once
 // when that parameter has no streamed column.
+#include <algorithm>
+
 #include "ssde_device.hpp"
 
 namespace ssde {
@@ -183,6 +185,39 @@ __global__ __launch_bounds__(256) void direct_kernel(const DirectArgs A) {
     }
 }
 
+// ---- design blocks given as piecewise-cubic functions of a covariate (ssde_ppbasis) ------------------------------
+__device__ __forceinline__ int pp_interval(const PPRef& P, const double* knots, double x) {
+    int iv;
+    if (P.uniform) {
+        iv = (int)floor((x - P.k0) * P.inv_h);
+        iv = iv < 0 ? 0 : (iv > P.nk - 2 ? P.nk - 2 : iv);
+        // the multiplication may land one interval off at a breakpoint: settle with the knots themselves
+        if (iv > 0 && x < knots[iv]) iv--;
+        else if (iv < P.nk - 2 && x >= knots[iv + 1]) iv++;
+    } else {
+        iv = 0;
+        for (int k = 1; k < P.nk - 1; k++) iv += (x >= knots[k]) ? 1 : 0;
+    }
+    return iv;
+}
+
+// one-off: the dense n x K block a table stands for (generic kernels, Kalman families)
+__global__ __launch_bounds__(256) void pp_materialise_kernel(const PPRef P, int K, int64_t n, double* dst, int64_t stride) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = P.x[i];
+        const int iv = pp_interval(P, P.knots, x);
+        const double t = x - P.knots[iv];
+        for (int c = 0; c < K; c++) {
+            const double* q = P.tab + ((int64_t)iv * K + c) * 4;
+            dst[(int64_t)c * stride + i] = fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
+        }
+    }
+}
+hipError_t launch_pp_materialise(const PPRef& pp, int K, int64_t n, double* dst, int64_t stride, hipStream_t s) {
+    hipLaunchKernelGGL(pp_materialise_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, pp, K, n, dst, stride);
+    return hipGetLastError();
+}
+
 // ---- fast kernel -------------------------------------------------------------------------------------
 // KA / KB: register capacity for the streamed columns of the (at most two) parameters that have any.
 template <int MODEL, int D, int KA, int KB>
@@ -198,6 +233,18 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     for (int c = 0; c < KB; c++) accB[c] = 0.0;
     double nll = 0.0;
     const bool varies1 = (ja == D) || (jb == D), varies2 = (ja == D + 1) || (jb == D + 1);
+    // groups given as basis tables: coefficients and knots into LDS once per workgroup
+    __shared__ double ldsA[(KA > 0) ? PP_LDS : 1], ldsB[(KB > 0) ? PP_LDS : 1];
+    const bool ppa = KA > 0 && A.ppA.x != nullptr, ppb = KB > 0 && A.ppB.x != nullptr;
+    if (ppa) {
+        const int nt = (A.ppA.nk - 1) * ncA * 4;
+        for (int k = threadIdx.x; k < nt + A.ppA.nk; k += 256) ldsA[k] = k < nt ? A.ppA.tab[k] : A.ppA.knots[k - nt];
+    }
+    if (ppb) {
+        const int nt = (A.ppB.nk - 1) * ncB * 4;
+        for (int k = threadIdx.x; k < nt + A.ppB.nk; k += 256) ldsB[k] = k < nt ? A.ppB.tab[k] : A.ppB.knots[k - nt];
+    }
+    if (ppa || ppb) __syncthreads();
     // natural-scale values / derived constants of parameters that have no streamed column
     const double nat_p1 = exp(A.base[D]);
     const double nat_p2 = (Q > D + 1) ? exp(A.base[D + 1]) : 0.0;
@@ -236,10 +283,34 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
         // ALL KA / KB register slots are loaded unconditionally (slots past the column count re-read the last
         // real column and carry a zero coefficient): a guard per slot would make hipcc branch around every load
         // and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
+        if (ppa) {          // uniform branch: the block is a function of one covariate, 8 B/row instead of 8 K
+            const double xr = __builtin_nontemporal_load(&A.ppA.x[r]);
+            const double* kn = ldsA + (A.ppA.nk - 1) * ncA * 4;
+            const int iv = pp_interval(A.ppA, kn, xr);
+            const double t = xr - kn[iv];
 #pragma unroll
-        for (int c = 0; c < KA; c++) wA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r]);
+            for (int c = 0; c < KA; c++) {
+                const double* q = ldsA + (iv * ncA + (c < ncA ? c : ncA - 1)) * 4;
+                wA[c] = fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
+            }
+        } else {
 #pragma unroll
-        for (int c = 0; c < KB; c++) wB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r]);
+            for (int c = 0; c < KA; c++) wA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r]);
+        }
+        if (ppb) {
+            const double xr = __builtin_nontemporal_load(&A.ppB.x[r]);
+            const double* kn = ldsB + (A.ppB.nk - 1) * ncB * 4;
+            const int iv = pp_interval(A.ppB, kn, xr);
+            const double t = xr - kn[iv];
+#pragma unroll
+            for (int c = 0; c < KB; c++) {
+                const double* q = ldsB + (iv * ncB + (c < ncB ? c : ncB - 1)) * 4;
+                wB[c] = fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < KB; c++) wB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r]);
+        }
 #pragma unroll
         for (int c = 0; c < KA; c++) sumA = fma(wA[c], A.coefA[c], sumA);
 #pragma unroll

@@ -201,6 +201,17 @@ hipError_t launch_direct(const DirectArgs& a, hipStream_t s);
 // two smooth terms); their column blocks are contiguous in the engine-owned column buffer, so a column
 // is base + c * n, and the slot -> parameter routing is static inside the kernel.
 constexpr int DIRECT_KCAP = 24;   // streamed columns per parameter the fast kernel can hold
+constexpr int PP_LDS = 1536;      // doubles of LDS per basis-evaluated group: (n_knots - 1) * K * 4 coefficients + the knots
+// a design block evaluated from a piecewise-cubic table (include/ssde.h: ssde_ppbasis) instead of streamed
+struct PPRef {
+    const double* x;              // [n] covariate in HBM, NULL = the group is streamed
+    const double* knots;          // [nk] (HBM)
+    const double* tab;            // [(nk - 1) * K * 4] (HBM)
+    int nk;
+    int uniform;                  // equally spaced knots: interval by multiplication
+    double k0, inv_h;
+};
+hipError_t launch_pp_materialise(const PPRef& pp, int K, int64_t n, double* dst, int64_t stride, hipStream_t s);
 struct DirectFastArgs {
     const double* times;
     const double* obs;
@@ -220,6 +231,7 @@ struct DirectFastArgs {
     int uniform_dt;               // every scored interval equals dt_uniform
     double dt_uniform;
     double tdf, tconst;           // BM_t
+    PPRef ppA, ppB;               // groups evaluated on the fly from a basis table (x != NULL)
 };
 hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s);
 hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t n, double* out2_per_block, int n_blocks,

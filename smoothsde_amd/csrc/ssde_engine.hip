@@ -42,6 +42,7 @@ void destroy(ssde_handle* h) {
     if (h->tv_stats_ev) (void)hipEventDestroy(h->tv_stats_ev);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();
     h->group_len.release(); h->lane_nsteps.release();
+    for (int j = 0; j < MAX_Q; j++) { h->pp_x[j].release(); h->pp_knots[j].release(); h->pp_tab[j].release(); h->pp_mat[j].release(); }
     h->tdecay.release(); h->times.release(); h->obs.release(); h->colbuf.release(); h->scored.release(); h->colptr.release();
     h->slot_table.release(); h->dirs.release(); h->par_ring.release();
     h->partials.release(); h->out.release();
@@ -131,8 +132,11 @@ int build(const ssde_desc* d, ssde_handle* h) {
         if (d->ncol_fe[j] < 1) return fail(h, SSDE_ERR_ARG, "every SDE parameter needs at least one fixed-effect column");
         if (!(d->x_fe && d->x_fe[j]) && d->ncol_fe[j] != 1)
             return fail(h, SSDE_ERR_ARG, "x_fe[j] == NULL means intercept-only: ncol_fe[j] must be 1");
-        if (d->ncol_re && d->ncol_re[j] > 0 && !(d->x_re && d->x_re[j]))
+        const ssde_ppbasis* pb = d->basis_re ? d->basis_re[j] : nullptr;
+        if (d->ncol_re && d->ncol_re[j] > 0 && !(d->x_re && d->x_re[j]) && !pb)
             return fail(h, SSDE_ERR_ARG, "x_re[j] missing for a parameter with random-effect columns");
+        if (pb && (!d->ncol_re || pb->n_cols != d->ncol_re[j] || pb->n_knots < 2 || !pb->x || !pb->knots || !pb->coef))
+            return fail(h, SSDE_ERR_ARG, "basis_re[j]: n_cols must equal ncol_re[j]; x, knots (>= 2) and coef are required");
     }
     if (d->n_decay > 0) {
         if (is_kalman(d->model)) return fail(h, SSDE_ERR_ARG, "decaying terms are a feature of the direct families (nllk_sde.hpp:47-58)");
@@ -170,6 +174,45 @@ int build(const ssde_desc* d, ssde_handle* h) {
         return fail(h, SSDE_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
     const bool on_dev = (d->flags & SSDE_FLAG_DEVICE_DATA) != 0;
     const int64_t n = d->n;
+    h->n_stream_cols_algo = h->n_stream_cols;
+
+    // ---- design blocks given as functions of a covariate (ssde_ppbasis) ---------------------------------------
+    // Fast route: a direct family whose fast kernel applies (<= 2 parameters with columns, no decay), the whole
+    // random-effect block of the parameter is the table and its fixed-effect part is the intercept: the kernel
+    // evaluates the block from x (8 B/row).  Everything else gets the dense block materialised once in HBM.
+    if (d->basis_re) {
+        std::vector<int> with_cols;
+        for (auto& sl : h->slots)
+            if (sl.col >= 0 && (with_cols.empty() || with_cols.back() != sl.par_j)) with_cols.push_back(sl.par_j);
+        const bool fast_family = !is_kalman(d->model) && !is_eseal(d->model) && h->L.n_decay == 0 && with_cols.size() <= 2 &&
+                                 !getenv("SSDE_NO_DIRECT_FAST") && !getenv("SSDE_NO_PP_FAST");
+        for (int j = 0; j < d->n_par; j++) {
+            const ssde_ppbasis* pb = d->basis_re[j];
+            if (!pb) continue;
+            const int K = pb->n_cols, nk = pb->n_knots;
+            for (int k = 1; k < nk; k++)
+                if (!(pb->knots[k] > pb->knots[k - 1])) return fail(h, SSDE_ERR_ARG, "basis_re[j]: knots must increase");
+            HIPCHK(h, stage(pb->knots, (size_t)nk, false, h->pp_knots[j]));
+            HIPCHK(h, stage(pb->coef, (size_t)(nk - 1) * K * 4, false, h->pp_tab[j]));
+            const double* xdev = pb->x;
+            if (!on_dev) { HIPCHK(h, stage(pb->x, (size_t)n, false, h->pp_x[j])); xdev = h->pp_x[j].p; }
+            PPRef& P = h->pp[j];
+            P.x = xdev; P.knots = h->pp_knots[j].p; P.tab = h->pp_tab[j].p; P.nk = nk;
+            const double hstep = (pb->knots[nk - 1] - pb->knots[0]) / (nk - 1);
+            P.uniform = 1;
+            for (int k = 0; k < nk; k++)
+                if (std::fabs(pb->knots[k] - (pb->knots[0] + k * hstep)) > 1e-12 * std::fabs(hstep) * nk) P.uniform = 0;
+            P.k0 = pb->knots[0]; P.inv_h = 1.0 / hstep;
+            h->pp_fast[j] = fast_family && !(d->x_fe && d->x_fe[j]) && K <= DIRECT_KCAP && (nk - 1) * K * 4 + nk <= PP_LDS;
+            if (!h->pp_fast[j]) {
+                HIPCHK(h, h->pp_mat[j].alloc((size_t)n * K));
+                HIPCHK(h, launch_pp_materialise(P, K, n, h->pp_mat[j].p, n, 0));
+                HIPCHK(h, hipDeviceSynchronize());
+                for (auto& sl : h->slots)
+                    if (sl.par_j == j && sl.basis_c >= 0) sl.src = h->pp_mat[j].p + (size_t)sl.basis_c * n;
+            }
+        }
+    }
 
     // ---- ID segments (nllk_ctcrw.hpp:196; R/sde.R:547,574) ---------------------------------------
     std::vector<int64_t> starts;
@@ -215,14 +258,19 @@ int build(const ssde_desc* d, ssde_handle* h) {
         // equal modulo a large power of two (all columns of a row are fetched together)
         h->col_stride = ((n + 63) / 64) * 64 + 160;
         if (const char* e = getenv("SSDE_COL_PAD")) h->col_stride = ((n + 63) / 64) * 64 + atoi(e);
-        HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * h->n_stream_cols));
-        std::vector<const double*> cp(h->n_stream_cols, nullptr);
+        // columns evaluated on the fly from a basis table need no copy: col = -2
+        int ncb = 0;
+        for (auto& s : h->slots)
+            if (s.col >= 0) s.col = s.src ? ncb++ : -2;
+        HIPCHK(h, h->colbuf.alloc((size_t)h->col_stride * ncb));
+        std::vector<const double*> cp(ncb, nullptr);
         for (auto& s : h->slots)
             if (s.col >= 0) {
                 double* dst = h->colbuf.p + (size_t)s.col * h->col_stride;
-                HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+                HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, hipMemcpyDefault));   // caller's array or a materialised basis block
                 cp[s.col] = dst;
             }
+        h->n_stream_cols = ncb;
         HIPCHK(h, h->colptr.upload(cp));
         if (h->L.n_decay > 0) HIPCHK(h, stage(d->t_decay, (size_t)n * d->n_par, on_dev, h->tdecay));
         {
@@ -254,16 +302,17 @@ int build(const ssde_desc* d, ssde_handle* h) {
             // which parameters have streamed columns (slots are ordered parameter by parameter)
             std::vector<int> streamed_par;
             for (auto& sl : h->slots) {
-                if (sl.col < 0) { h->df_icpt[sl.par_j] = sl.pidx; continue; }
+                if (sl.col == -1) { h->df_icpt[sl.par_j] = sl.pidx; continue; }
                 if (streamed_par.empty() || streamed_par.back() != sl.par_j) streamed_par.push_back(sl.par_j);
             }
             bool ok = streamed_par.size() <= 2 && !getenv("SSDE_NO_DIRECT_FAST") && h->L.n_decay == 0;   // decaying columns: generic kernel
             if (ok) {
                 for (auto& sl : h->slots) {
-                    if (sl.col < 0) continue;
+                    if (sl.col == -1) continue;
                     const bool isA = sl.par_j == streamed_par[0];
                     auto& pid = isA ? h->df_pidxA : h->df_pidxB;
                     const double*& base = isA ? h->df_colA : h->df_colB;
+                    if (sl.col == -2) { pid.push_back(sl.pidx); continue; }          // evaluated from the basis table
                     if (pid.empty()) base = h->colbuf.p + (size_t)sl.col * h->col_stride;
                     else if (h->colbuf.p + (size_t)sl.col * h->col_stride != base + pid.size() * (size_t)h->col_stride) ok = false;  // contiguous
                     pid.push_back(sl.pidx);
@@ -354,7 +403,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
                     if (on_dev) cp[s.col] = s.src;
                     else {
                         double* dst = s_cols.p + (size_t)s.col * n;
-                        HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, hipMemcpyHostToDevice));
+                        HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, hipMemcpyDefault));   // host array or materialised basis block
                         cp[s.col] = dst;
                     }
                 }
@@ -837,6 +886,8 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             f.uniform_dt = h->direct_uniform_dt ? 1 : 0;
             f.dt_uniform = h->direct_dt;
             f.tdf = h->tdf; f.tconst = h->tconst;
+            if (h->df_ja >= 0 && h->pp_fast[h->df_ja]) f.ppA = h->pp[h->df_ja];
+            if (h->df_jb >= 0 && h->pp_fast[h->df_jb]) f.ppB = h->pp[h->df_jb];
             HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_direct_fast(f, s));
             HIPCHK(h, hipEventRecord(h->ev_k1, s));
@@ -1041,7 +1092,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_rows = h->n;
     info->n_steps = h->n_steps;
     info->hbm_bytes = h->hbm_bytes;
-    info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols);
+    info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols_algo);
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
         info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * (h->last_t0 > 0 ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;

@@ -80,6 +80,13 @@ struct ssde_handle {
     DevBuf<const double*> colptr;
     int direct_blocks = 0;
 
+    // random-effect blocks given as piecewise-cubic functions of a covariate (ssde_ppbasis): tables in HBM; either
+    // evaluated on the fly by the fast direct kernel (pp_fast) or materialised once into dense columns (pp_mat)
+    PPRef pp[MAX_Q] = {};
+    bool pp_fast[MAX_Q] = {false, false, false, false};
+    DevBuf<double> pp_x[MAX_Q], pp_knots[MAX_Q], pp_tab[MAX_Q], pp_mat[MAX_Q];
+    int n_stream_cols_algo = 0;                    // streamed columns of the reference's data contract (algorithmic bytes)
+
     // fast direct kernel (<= 2 parameters with streamed columns)
     bool direct_fast = false;
     int64_t col_stride = 0;                        // doubles between consecutive streamed columns

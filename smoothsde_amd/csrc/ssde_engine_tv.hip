@@ -46,7 +46,7 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     for (auto& sl : h->slots)
         if (sl.col >= 0)
             HIPCHK(h, hipMemcpy(h->colbuf.p + (size_t)sl.col * h->col_stride, sl.src, (size_t)n * 8,
-                                on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+                                hipMemcpyDefault));   // caller's array (host / HBM) or a materialised basis block
     {
         DevBuf<double> idb;
         const double* idp = d->id;

@@ -67,6 +67,7 @@ struct Slot {
     int pidx;             // index in the full parameter vector
     const double* src;    // caller's column (length n) or NULL
     int decay = -1;       // index into log_decay of a decaying random-effect column (nllk_sde.hpp:47-57), -1 = none
+    int basis_c = -1;     // column inside the parameter's ssde_ppbasis when the block is given as a function, else -1
 };
 
 inline std::vector<Slot> make_slots(const ssde_desc* d, const ParLayout& L, int* n_stream_cols) {
@@ -85,7 +86,9 @@ inline std::vector<Slot> make_slots(const ssde_desc* d, const ParLayout& L, int*
             Slot t;
             t.par_j = j;
             t.pidx = L.off_re + L.re_off[j] + c;
-            t.src = d->x_re[j] + (int64_t)c * d->n;
+            const bool pp = d->basis_re && d->basis_re[j];
+            t.src = pp ? nullptr : d->x_re[j] + (int64_t)c * d->n;   // basis-backed blocks are materialised or evaluated by the engine
+            t.basis_c = pp ? c : -1;
             t.col = ncol++;
             if (L.n_decay > 0)
                 for (int k = 0; k < d->n_decay_cols; k++)

@@ -121,6 +121,49 @@ def bspline_basis(x, n_basis: int = 9, degree: int = 3):
     return np.asfortranarray(B[:, 1:] - B[:, 1:].mean(axis=0))
 
 
+class PPBasis:
+    """A design block as a piecewise-cubic function of one covariate (include/ssde.h: ssde_ppbasis):
+    X[i, k] = sum_m coef[iv, k, m] (x[i] - knots[iv])^m."""
+
+    def __init__(self, x, knots, coef):
+        self.x = x                                                   # (n,) numpy array or CUDA tensor
+        self.knots = np.ascontiguousarray(knots, dtype=np.float64)
+        self.coef = np.ascontiguousarray(coef, dtype=np.float64)     # (n_knots - 1, K, 4)
+        assert self.coef.shape[0] == len(self.knots) - 1 and self.coef.shape[2] == 4
+        self.n_cols = self.coef.shape[1]
+
+    def dense(self):
+        """the n x K matrix the table stands for (host evaluation, for the oracle and for comparisons)"""
+        x = np.asarray(self.x.cpu().numpy() if hasattr(self.x, "cpu") else self.x, dtype=np.float64)
+        iv = np.clip(np.searchsorted(self.knots, x, side="right") - 1, 0, len(self.knots) - 2)
+        t = x - self.knots[iv]
+        return np.asfortranarray(sum(self.coef[iv, :, m] * t[:, None] ** m for m in range(4)))
+
+
+def bspline_ppbasis(x, n_basis: int = 9, degree: int = 3, centre=None):
+    """`bspline_basis` as a PPBasis: the same clamped cubic B-spline block (first column dropped, columns centred),
+    as per-interval polynomial coefficients.  `centre`: column means to subtract (default: the means over x)."""
+    from scipy.interpolate import BSpline, PPoly
+    k = n_basis + 1
+    inner = np.linspace(0, 1, k - degree + 1)
+    knots = np.concatenate([[0.0] * degree, inner, [1.0] * degree])
+    tab = np.zeros((len(inner) - 1, k, 4))
+    for j in range(k):
+        c = np.zeros(k)
+        c[j] = 1.0
+        pp = PPoly.from_spline((knots, c, degree))
+        for iv in range(len(inner) - 1):
+            idx = np.where((pp.x[:-1] == inner[iv]) & (pp.x[1:] == inner[iv + 1]))[0][0]
+            tab[iv, j, :] = pp.c[::-1, idx]
+    tab = tab[:, 1:, :].copy()
+    xs = np.clip(np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, dtype=np.float64), 0.0, 1.0)
+    basis = PPBasis(x, inner, tab)
+    if centre is None:
+        centre = PPBasis(xs, inner, tab).dense().mean(axis=0)
+    basis.coef[:, :, 0] -= np.asarray(centre)[None, :]
+    return basis
+
+
 def second_difference_penalty(k: int):
     """S = D2' D2 + small ridge (full rank, like mgcv's shrinkage bases "ts"/"cs")."""
     D = np.diff(np.eye(k), n=2, axis=0)

@@ -117,6 +117,16 @@ def main():
     par = np.concatenate([[1.0, np.log(2.0), 0.0], [0.0], 0.05 * np.sin(np.arange(9))])
     report(f"C3: 1e4 OU x {T}, 9 streamed design columns", eng, par, n, 5)
     eng.close()
+    del B, pb
+
+    # C3 with the smooth given as a FUNCTION of the covariate (ssde_ppbasis: cubic B-spline table, 9 columns): the
+    # kernel reads x (8 B/row) and evaluates the block on the fly; algorithmic bytes stay those of the streamed contract
+    from smoothsde_amd.synth import bspline_ppbasis
+    basis = bspline_ppbasis(x, 9, centre=np.zeros(9))
+    pb = capi.Problem.from_torch("OU", ID, times, obs, basis_re=[basis, None, None], S_list=[second_difference_penalty(9)])
+    eng = capi.Engine(pb)
+    report(f"C3 with the design block evaluated on the device from its B-spline table: 1e4 OU x {T}", eng, par, n, 5)
+    eng.close()
 
 
 if __name__ == "__main__":
