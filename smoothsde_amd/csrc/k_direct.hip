@@ -272,8 +272,31 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     // The loop runs over the EARLIER row r of each transition (r -> r+1): the design columns, which are
     // read at the earlier row (Q6), are then fetched at 512-B-aligned wave addresses.  Streams are read
     // once: non-temporal loads.
+    // Inputs of the NEXT row of this thread (256 rows ahead) are requested before the current row is worked on: the
+    // covariate of a basis-evaluated block heads a dependent chain (x -> interval -> LDS table -> predictor) and the
+    // observations are only needed after it, so without the look-ahead every row exposed two HBM round trips.
+    const int64_t nlast = n - 1;
+    double zq0[D], zq1[D], xqA = 0.0, xqB = 0.0;
+    {
+        const int64_t r0 = row_lo + threadIdx.x < nlast ? row_lo + threadIdx.x : nlast, i0 = r0 + 1 < nlast ? r0 + 1 : nlast;
+#pragma unroll
+        for (int a = 0; a < D; a++) { zq0[a] = __builtin_nontemporal_load(&A.obs[r0 + (int64_t)a * n]); zq1[a] = A.obs[i0 + (int64_t)a * n]; }
+        if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[r0]);
+        if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[r0]);
+    }
     for (int64_t r = row_lo + threadIdx.x; r < row_hi; r += 256) {
         const int64_t i = r + 1;
+        double zc0[D], zc1[D];
+#pragma unroll
+        for (int a = 0; a < D; a++) { zc0[a] = zq0[a]; zc1[a] = zq1[a]; }
+        const double xcA = xqA, xcB = xqB;
+        {
+            const int64_t rn = r + 256 < nlast ? r + 256 : nlast, in = rn + 1 < nlast ? rn + 1 : nlast;
+#pragma unroll
+            for (int a = 0; a < D; a++) { zq0[a] = __builtin_nontemporal_load(&A.obs[rn + (int64_t)a * n]); zq1[a] = A.obs[in + (int64_t)a * n]; }
+            if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[rn]);
+            if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[rn]);
+        }
         if (i >= n || !((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
         const double dt = all_const ? A.dt_uniform
                                     : __builtin_nontemporal_load(&A.times[i]) - __builtin_nontemporal_load(&A.times[r]);  // dtimes(i-1)
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
         // real column and carry a zero coefficient): a guard per slot would make hipcc branch around every load
         // and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
         if (ppa) {          // uniform branch: the block is a function of one covariate, 8 B/row instead of 8 K
-            const double xr = __builtin_nontemporal_load(&A.ppA.x[r]);
+            const double xr = xcA;
             const double* kn = ldsA + (A.ppA.nk - 1) * ncA * 4;
             const int iv = pp_interval(A.ppA, kn, xr);
             const double t = xr - kn[iv];
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             for (int c = 0; c < KA; c++) wA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r]);
         }
         if (ppb) {
-            const double xr = __builtin_nontemporal_load(&A.ppB.x[r]);
+            const double xr = xcB;
             const double* kn = ldsB + (A.ppB.nk - 1) * ncB * 4;
             const int iv = pp_interval(A.ppB, kn, xr);
             const double t = xr - kn[iv];
@@ -321,13 +344,13 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
 
         double g[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
         if (MODEL == M_BM_T) {
-            const double z0 = __builtin_nontemporal_load(&A.obs[r]), z1 = A.obs[i];
+            const double z0 = zc0[0], z1 = zc1[0];
             if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan)))                       // tr_dens.hpp:31
                 nll += bmt_direct(z0, z1, dt, par[0], par[1], A.tdf, A.tconst, g[0], g[1]);   // :38-44
         } else if (MODEL == M_CIR) {
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
+                const double z0 = zc0[a], z1 = zc1[a];
                 if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;              // tr_dens.hpp:31
                 nll += cir_direct(z0, z1, dt, par[a], par[D], par[D + 1], g[a], g[D], g[D + 1]);   // :53-67
             }
@@ -339,7 +362,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             }
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
+                const double z0 = zc0[a], z1 = zc1[a];
                 if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;          // tr_dens.hpp:31
                 const double r = (z1 - (z0 + par[a] * dt)) * isd;                    // :35, :37
                 g[a] += -r * dt * isd;
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             }
 #pragma unroll
             for (int a = 0; a < D; a++) {
-                const double z0 = __builtin_nontemporal_load(&A.obs[r + (int64_t)a * n]), z1 = A.obs[i + (int64_t)a * n];
+                const double z0 = zc0[a], z1 = zc1[a];
                 if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;
                 const double mu = par[a];
                 const double r = (z1 - (mu + e * (z0 - mu))) * isd;                  // :49, :52
@@ -406,7 +429,7 @@ hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB>), grid, block, 0, s, a);   \
         return hipGetLastError();                                                           \
     }
-#define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
+#define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 9, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
     SSDE_FK(M_BM, 1) SSDE_FK(M_BM, 2) SSDE_FK(M_OU, 1) SSDE_FK(M_OU, 2) SSDE_FK(M_BM_T, 1) SSDE_FK(M_CIR, 1) SSDE_FK(M_CIR, 2)
 #undef SSDE_FK
 #undef SSDE_F
