@@ -277,12 +277,21 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     // observations are only needed after it, so without the look-ahead every row exposed two HBM round trips.
     const int64_t nlast = n - 1;
     double zq0[D], zq1[D], xqA = 0.0, xqB = 0.0;
+    double wqA[KA > 0 ? KA : 1], wqB[KB > 0 ? KB : 1];   // streamed columns of the next row
     {
         const int64_t r0 = row_lo + threadIdx.x < nlast ? row_lo + threadIdx.x : nlast, i0 = r0 + 1 < nlast ? r0 + 1 : nlast;
 #pragma unroll
         for (int a = 0; a < D; a++) { zq0[a] = __builtin_nontemporal_load(&A.obs[r0 + (int64_t)a * n]); zq1[a] = A.obs[i0 + (int64_t)a * n]; }
         if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[r0]);
         if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[r0]);
+        if (!ppa) {
+#pragma unroll
+            for (int c = 0; c < KA; c++) wqA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r0]);
+        }
+        if (!ppb) {
+#pragma unroll
+            for (int c = 0; c < KB; c++) wqB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r0]);
+        }
     }
     for (int64_t r = row_lo + threadIdx.x; r < row_hi; r += 256) {
         const int64_t i = r + 1;
@@ -297,15 +306,26 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
             if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[rn]);
             if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[rn]);
         }
+        // streamed columns of row i-1 (Q6): this row's values were requested one iteration ago, the next row's are
+        // requested now.  ALL KA / KB register slots are loaded unconditionally (slots past the column count re-read
+        // the last real column and carry a zero coefficient): a guard per slot would make hipcc branch around every
+        // load and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
+        double wA[KA > 0 ? KA : 1], wB[KB > 0 ? KB : 1];
+        if (!ppa) {
+            const int64_t rn = r + 256 < nlast ? r + 256 : nlast;
+#pragma unroll
+            for (int c = 0; c < KA; c++) { wA[c] = wqA[c]; wqA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + rn]); }
+        }
+        if (!ppb) {
+            const int64_t rn = r + 256 < nlast ? r + 256 : nlast;
+#pragma unroll
+            for (int c = 0; c < KB; c++) { wB[c] = wqB[c]; wqB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + rn]); }
+        }
         if (i >= n || !((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
         const double dt = all_const ? A.dt_uniform
                                     : __builtin_nontemporal_load(&A.times[i]) - __builtin_nontemporal_load(&A.times[r]);  // dtimes(i-1)
-        // streamed columns of row i-1 (Q6) and the two linear predictors they feed
-        double wA[KA > 0 ? KA : 1], wB[KB > 0 ? KB : 1];
+        // the two linear predictors the column groups feed
         double sumA = 0.0, sumB = 0.0;
-        // ALL KA / KB register slots are loaded unconditionally (slots past the column count re-read the last
-        // real column and carry a zero coefficient): a guard per slot would make hipcc branch around every load
-        // and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
         if (ppa) {          // uniform branch: the block is a function of one covariate, 8 B/row instead of 8 K
             const double xr = xcA;
             const double* kn = ldsA + (A.ppA.nk - 1) * ncA * 4;
@@ -316,9 +336,6 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
                 const double* q = ldsA + (iv * ncA + (c < ncA ? c : ncA - 1)) * 4;
                 wA[c] = fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < KA; c++) wA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r]);
         }
         if (ppb) {
             const double xr = xcB;
@@ -330,9 +347,6 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
                 const double* q = ldsB + (iv * ncB + (c < ncB ? c : ncB - 1)) * 4;
                 wB[c] = fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < KB; c++) wB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r]);
         }
 #pragma unroll
         for (int c = 0; c < KA; c++) sumA = fma(wA[c], A.coefA[c], sumA);
