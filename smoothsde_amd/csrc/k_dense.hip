@@ -20,7 +20,8 @@ __global__ __launch_bounds__(WAVE) void dense_kernel(const DenseArgs A) {
     const TileView& tv = A.tv;
     const SlotTable* __restrict__ T = A.slots;
     const int C = tv.C;
-    const int c0 = 1 + D + (A.has_h ? D * D : 0);
+    const int cy = tv.c_obs;                                   // first obs channel (0: no dt channel, regular grid)
+    const int c0 = cy + D + (A.has_h ? D * D : 0);
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
@@ -54,16 +55,19 @@ __global__ __launch_bounds__(WAVE) void dense_kernel(const DenseArgs A) {
     for (int s0 = 0; s0 < L; s0++) {
         if (s0 >= ns) continue;
         const double* o = base + (int64_t)s0 * C * WAVE;
-        const double dt = o[0];
+        // dtimes(i): the tile's dt channel, or the one interval of a globally regular grid (dtimes(n-1) = 1,
+        // nllk_ctcrw.hpp:126-129: only REPORT(aest_all) ever shows the state propagated with it)
+        double dt = cy ? o[0] : tv.dt_all;
+        if (REPORT && !cy && row0 + 1 + s0 == A.n - 1) dt = 1.0;
         double y[D];
 #pragma unroll
-        for (int a = 0; a < D; a++) y[a] = o[(1 + a) * WAVE];
+        for (int a = 0; a < D; a++) y[a] = o[(cy + a) * WAVE];
         DualN<N> H[D][D];
 #pragma unroll
         for (int i = 0; i < D; i++)
 #pragma unroll
             for (int j = 0; j < D; j++) {
-                if (A.has_h) H[i][j] = DualN<N>(o[(1 + D + i + j * D) * WAVE]);   // H_array[,,i] column-major
+                if (A.has_h) H[i][j] = DualN<N>(o[(cy + D + i + j * D) * WAVE]);   // H_array[,,i] column-major
                 else H[i][j] = (i == j) ? hiso : DualN<N>(0.0);
             }
         // linear predictors of the row and their tangents

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void dt_minmax_kernel(const double* times, con
     double mn = INFINITY, mx = -INFINITY;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (i >= 1 && ((scored[i >> 5] >> (i & 31)) & 1u)) {
+        if (i >= 1 && (!scored || ((scored[i >> 5] >> (i & 31)) & 1u))) {       // scored == NULL: every consecutive pair
             const double dt = times[i] - times[i - 1];
             mn = fmin(mn, dt); mx = fmax(mx, dt);
             if (dt != dt) mx = INFINITY;

@@ -26,20 +26,20 @@ __global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
             const int64_t i = row0 + 1 + s;
             // dtimes(i): nllk_ctcrw.hpp:126-129 (the cross-track value at a track's last row is kept:
             // the engine never uses that prediction for the likelihood, only ssde_report shows it)
-            o[0] = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
-            if (s < ns - 1) { dmin = fmin(dmin, o[0]); dmax = fmax(dmax, o[0]); if (o[0] != o[0]) dmax = INFINITY; }
+            const double dti = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
+            if (A.c_obs) o[0] = dti;
+            if (s < ns - 1) { dmin = fmin(dmin, dti); dmax = fmax(dmax, dti); if (dti != dti) dmax = INFINITY; }
             for (int a = 0; a < d; a++) {
                 const double yv = A.obs[i + (int64_t)a * A.n];
-                o[(1 + a) * WAVE] = yv;
+                o[(A.c_obs + a) * WAVE] = yv;
                 if (yv != yv) seen_nan = 1.0;
             }
-            int c = 1 + d;
+            int c = A.c_obs + d;
             if (A.h_array)
                 for (int k = 0; k < d * d; k++) o[(c++) * WAVE] = A.h_array[k + i * (int64_t)(d * d)];
             for (int k = 0; k < A.ncols; k++) o[(c++) * WAVE] = A.cols[k][i];
         } else {
-            o[0] = 1.0;
-            for (int c = 1; c < C; c++) o[c * WAVE] = 0.0;
+            for (int c = 0; c < C; c++) o[c * WAVE] = (c == 0 && A.c_obs) ? 1.0 : 0.0;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {

@@ -29,12 +29,16 @@
 
 namespace ssde {
 
+// register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
 template <int C>
-__device__ __forceinline__ void load_block(double (&dst)[TILE_U][C], const double* p) {
+__device__ __forceinline__ void load_block(double (&dst)[TILE_U][C], const double* p, int Cr, int c_obs) {
 #pragma unroll
-    for (int u = 0; u < TILE_U; u++)
+    for (int u = 0; u < TILE_U; u++) {
+        dst[u][0] = 0.0;
+        if (c_obs) dst[u][0] = p[(u * Cr) * WAVE];
 #pragma unroll
-        for (int c = 0; c < C; c++) dst[u][c] = p[(u * C + c) * WAVE];
+        for (int c = 1; c < C; c++) dst[u][c] = p[(u * Cr + c_obs + c - 1) * WAVE];
+    }
 }
 
 // ---- per-model lane policies --------------------------------------------------------------
@@ -126,6 +130,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     constexpr int SD = Ops::SD;
     const int lane = threadIdx.x & 63;
     const TileView& tv = A.tv;
+    const int Cr = tv.C, c_obs = tv.c_obs;     // channels per step in the tile, channel of the first obs column
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
@@ -133,7 +138,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 
     // this workgroup's window: rows [s_acc, s_end) are scored, rows [s_begin, s_acc) warm up
     int s_begin, s_acc, s_end;
-    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end);
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end, A.t0_delta);
 
     typename Ops::State S;
     typename Ops::Trans tr = Ops::hoisted(A);
@@ -149,7 +154,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 
     // two register blocks in ping-pong: while one is consumed the other is in flight (no copies)
     double bufA[TILE_U][C], bufB[TILE_U][C];
-    load_block<C>(bufA, base + (int64_t)s_begin * C * WAVE);
+    load_block<C>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
@@ -183,10 +188,10 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     };
     for (int s0 = s_begin; s0 < s_end; s0 += 2 * TILE_U) {
         // TILE_SPARE keeps the look-ahead loads inside the allocation
-        load_block<C>(bufB, base + (int64_t)(s0 + TILE_U) * C * WAVE);
+        load_block<C>(bufB, base + (int64_t)(s0 + TILE_U) * Cr * WAVE, Cr, c_obs);
         handover(s0);
         run_block(bufA, s0);
-        load_block<C>(bufA, base + (int64_t)(s0 + 2 * TILE_U) * C * WAVE);
+        load_block<C>(bufA, base + (int64_t)(s0 + 2 * TILE_U) * Cr * WAVE, Cr, c_obs);
         if (s0 + TILE_U < s_end) {
             handover(s0 + TILE_U);
             run_block(bufB, s0 + TILE_U);
@@ -275,7 +280,7 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
     const int ns = tv.lane_nsteps[g * WAVE + lane];
     const int nstate = (A.nstate_clean > 0 && (A.group_flags[g] & 1)) ? A.nstate_clean : nstate_full;
     int sb_, s_next, se_;
-    window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_);   // s_next = first scored row of window c+1
+    window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_, A.t0_delta);   // s_next = first scored row of window c+1
     const bool valid = (ns > s_next) && (s_next < L);
     const int pc0 = part * A.n_chunks + c, pc1 = pc0 + 1;
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;

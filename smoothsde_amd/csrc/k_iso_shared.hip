@@ -21,16 +21,16 @@
 
 namespace ssde {
 
+// C = channels per step of the tile, c_obs = channel of the first obs column (a dt channel, if present, is not read)
 template <int D>
-__device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const double* p) {
-    constexpr int C = 1 + D;
+__device__ __forceinline__ void load_obs_block(double (&dst)[SHARED_U][D], const double* p, int C, int c_obs) {
 #pragma unroll
     for (int u = 0; u < SHARED_U; u++)
 #pragma unroll
 #ifdef SSDE_DIAG_NOSTREAM   // timing-only diagnostic build (results are wrong): every block re-reads one 8-KB window
-        for (int a = 0; a < D; a++) dst[u][a] = p[((u * C + 1 + a) * WAVE) & 1023];
+        for (int a = 0; a < D; a++) dst[u][a] = p[((u * C + c_obs + a) * WAVE) & 1023];
 #else
-        for (int a = 0; a < D; a++) dst[u][a] = p[(u * C + 1 + a) * WAVE];  // the dt channel is not read
+        for (int a = 0; a < D; a++) dst[u][a] = __builtin_nontemporal_load(&p[(u * C + c_obs + a) * WAVE]);   // read once
 #endif
 }
 
@@ -474,7 +474,7 @@ __device__ __forceinline__ void run_block(Lane& S, const IsoArgs& A, const doubl
 template <bool STAT, int D, class Lane>
 __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const double* base, int sa, int sb, int ns,
                                             int ns_min, const double* mu) {
-    constexpr int C = 1 + D;
+    const int C = A.tv.C, c_obs = A.tv.c_obs;
     if (sa >= sb) return;
     double bufA[SHARED_U][D], bufB[SHARED_U][D];
 #ifdef SSDE_DIAG_NOSTREAM
@@ -482,12 +482,12 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 #else
 #define SSDE_ROWPTR(s) (base + (int64_t)(s) * C * WAVE)
 #endif
-    load_obs_block<D>(bufA, SSDE_ROWPTR(sa));
+    load_obs_block<D>(bufA, SSDE_ROWPTR(sa), C, c_obs);
     for (int s0 = sa; s0 < sb; s0 += 2 * SHARED_U) {
         // TILE_SPARE (>= 3 blocks) keeps the look-ahead loads inside the allocation
-        load_obs_block<D>(bufB, SSDE_ROWPTR(s0 + SHARED_U));
+        load_obs_block<D>(bufB, SSDE_ROWPTR(s0 + SHARED_U), C, c_obs);
         run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu);
-        load_obs_block<D>(bufA, SSDE_ROWPTR(s0 + 2 * SHARED_U));
+        load_obs_block<D>(bufA, SSDE_ROWPTR(s0 + 2 * SHARED_U), C, c_obs);
         if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu);
     }
 }
@@ -497,11 +497,11 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 template <int MODEL, int D, int MASK, bool STATONLY>
 __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int part, int chunk) {
     typedef typename SharedSel<MODEL, D, MASK, STATONLY>::type Lane;
-    constexpr int C = 1 + D;
     constexpr int NACC = 4 + D;
     constexpr int SD = Lane::SD;
     const int lane = threadIdx.x & 63;
     const TileView& tv = A.tv;
+    const int C = tv.C, c_obs = tv.c_obs;
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
@@ -512,7 +512,7 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
     const int pc = part * A.n_chunks + chunk;
 
     int s_begin, s_acc, s_end;
-    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end);
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end, A.t0_delta);
     // first row from which the stationary gains apply (gain_stat[0] == 0 would mean "never scored":
     // that degenerate case stays on the table path)
     int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
@@ -529,14 +529,14 @@ __device__ __forceinline__ void run_lane_shared(const IsoArgs& A, int g, int par
             // transfer-function lanes start from the observation of the row before the window (s_begin > 0:
             // stationary-only windows lie past the covariance transient)
 #pragma unroll
-            for (int a = 0; a < D; a++) a0[a] = base[((int64_t)(s_begin - 1) * C + 1 + a) * WAVE];
+            for (int a = 0; a < D; a++) a0[a] = base[((int64_t)(s_begin - 1) * C + c_obs + a) * WAVE];
         } else if (s_begin == 0) {
 #pragma unroll
             for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
         } else {
             double y0[D];
 #pragma unroll
-            for (int a = 0; a < D; a++) y0[a] = base[((int64_t)s_begin * C + 1 + a) * WAVE];
+            for (int a = 0; a < D; a++) y0[a] = base[((int64_t)s_begin * C + c_obs + a) * WAVE];
             Lane::warm_a0(y0, a0);
         }
         S.init(a0);

@@ -51,6 +51,9 @@ struct TileView {
     const double* a0;            // [n_groups][sdim][64] initial state per lane
     int n_groups;
     int C;                       // channels per step
+    int c_obs;                   // channel of the first obs column: 1, or 0 when the dt channel is left out (globally
+                                 // regular time grid: nobody would read it, and holes in the stream cost bandwidth)
+    double dt_all;               // the one interval of a globally regular grid (c_obs == 0)
 };
 
 // ---- constant-coefficient isotropic Kalman kernels (k_iso.hip) -----------------------------
@@ -78,6 +81,7 @@ struct IsoArgs {
     int n_chunks;                // time windows per track group (1 = plain sequential filter)
     int window;                  // warm-up rows of a window, multiple of WIN_ALIGN
     int t0;                      // > 0: window 0 is the covariance transient [0, t0) (shared-covariance path)
+    int t0_delta;                // stationary rows the transient window is worth (window 1 is shortened by it), multiple of WIN_ALIGN
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;
@@ -143,7 +147,7 @@ struct IngestArgs {
     const int32_t* lane_nsteps;
     const int64_t* group_off;
     const int32_t* group_len;
-    int n_groups, C;
+    int n_groups, C, c_obs;
     double* tiles;
     double* a0;                  // [n_groups][sdim][64] (written from obs when a0_src == NULL)
     const double* a0_src;        // caller-supplied a0 [n_seg x sdim] column-major or NULL
@@ -326,14 +330,15 @@ hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s);
 //             state) and windows 1..n_chunks-1 split [t0, L) equally
 // Rows [s_acc, s_end) are scored, rows [s_begin, s_acc) warm up.  All bounds are multiples of WIN_ALIGN
 // (except L itself).
+//             delta = how many stationary rows the transient window is worth (it runs on the wave of window 1)
 __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, int t0, int c, int& s_begin, int& s_acc,
-                                              int& s_end) {
+                                              int& s_end, int delta_rows = -1) {
     if (n_chunks <= 1) { s_begin = 0; s_acc = 0; s_end = L; return; }
     if (t0 > 0) {
         if (c == 0) { s_begin = 0; s_acc = 0; s_end = L < t0 ? L : t0; return; }
         // the wave that owns window 1 also runs window 0 first (and window 0's rows cost ~1.5x): window 1
         // is shortened by delta so that all waves finish together
-        const int delta = (3 * t0 / 2 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        const int delta = delta_rows >= 0 ? delta_rows : (3 * t0 / 2 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         const int rest = L > t0 ? L - t0 : 0;
         int cl = ((rest + delta + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         if (cl <= delta + WIN_ALIGN) cl = delta + 2 * WIN_ALIGN;

@@ -354,7 +354,26 @@ int build(const ssde_desc* d, ssde_handle* h) {
         });
         h->n_groups = (int)((M + WAVE - 1) / WAVE);
         const int G = h->n_groups;
-        h->C = 1 + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + h->n_stream_cols;
+        // stage the time stamps first: a GLOBALLY regular grid (every consecutive pair of rows, track boundaries
+        // included, is dt apart) needs no dt channel in the tiles -- nobody would read it, and a stream with holes
+        // costs HBM efficiency (2 of 3 channels read: 5.6 TB/s; contiguous: > 7 TB/s)
+        DevBuf<double> s_times;
+        const double* p_times = d->times;
+        if (!on_dev) { HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p; }
+        h->c_obs = 1;
+        if (!(d->flags & SSDE_FLAG_NO_UNIFORM_DT) && !getenv("SSDE_KEEP_DT_CHANNEL")) {
+            const int nb = 1024;
+            DevBuf<double> mm;
+            HIPCHK(h, mm.alloc((size_t)nb * 2));
+            HIPCHK(h, launch_dt_minmax(p_times, nullptr, n, mm.p, nb, 0));
+            std::vector<double> mmh((size_t)nb * 2);
+            HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
+            double lo = INFINITY, hi = -INFINITY;
+            for (int b = 0; b < nb; b++) { lo = std::min(lo, mmh[2 * b]); hi = std::max(hi, mmh[2 * b + 1]); }
+            mm.release();
+            if (lo == hi && std::isfinite(lo)) { h->c_obs = 0; h->dt_all = lo; }
+        }
+        h->C = h->c_obs + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + h->n_stream_cols;
         std::vector<int64_t> lane_row0((size_t)G * WAVE, -1), lane_seg((size_t)G * WAVE, 0), goff(G);
         std::vector<int32_t> lane_ns((size_t)G * WAVE, 0), glen(G);
         int64_t off = 0;
@@ -386,12 +405,11 @@ int build(const ssde_desc* d, ssde_handle* h) {
         h->glen_host = glen; h->lane_ns_host = lane_ns;
 
         // stage the caller's arrays (host data) -- freed again after tiling
-        DevBuf<double> s_times, s_obs, s_h, s_a0, s_cols;
+        DevBuf<double> s_obs, s_h, s_a0, s_cols;
         DevBuf<const double*> s_colptr;
         DevBuf<int64_t> s_lane_seg;
-        const double *p_times = d->times, *p_obs = d->obs, *p_h = d->h_array;
+        const double *p_obs = d->obs, *p_h = d->h_array;
         if (!on_dev) {
-            HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p;
             HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p;
             if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
         }
@@ -424,7 +442,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
         ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = n;
         ia.lane_row0 = h->lane_row0.p; ia.lane_nsteps = h->lane_nsteps.p;
         ia.group_off = h->group_off.p; ia.group_len = h->group_len.p;
-        ia.n_groups = G; ia.C = h->C; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
+        ia.n_groups = G; ia.C = h->C; ia.c_obs = h->c_obs; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
         ia.a0_src = p_a0; ia.lane_seg = s_lane_seg.p; ia.n_seg = h->n_seg;
         ia.sdim = h->sdim; ia.model = d->model; ia.dt_minmax = mm.p; ia.ychunks = ych;
         HIPCHK(h, launch_ingest(ia, 0));
@@ -731,7 +749,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         IsoArgs a;
         memset(&a, 0, sizeof(a));
         a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
-        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
         a.partials = h->partials.p;
         if (order >= 1) {
             a.n_parts = h->iso_parts;
@@ -795,7 +813,14 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
             h->last_chunks = a.n_chunks;
         }
-        h->last_t0 = a.t0;
+        // the transient window (gain table, direction form) runs on the wave that owns window 1: that window is
+        // shortened by what the transient rows cost, in stationary rows (SSDE_T0_COST x t0)
+        {
+            double cost = 3.0;
+            if (const char* e = getenv("SSDE_T0_COST")) cost = atof(e);
+            a.t0_delta = (int)(cost * a.t0 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        }
+        h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
         if (h->use_shared) {
             // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
             // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check
@@ -849,7 +874,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         DenseArgs a;
         memset(&a, 0, sizeof(a));
         a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
-        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+        a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
         a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
         for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
@@ -1060,7 +1085,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
-    a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C;
+    a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
     a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
     a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
     for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
@@ -1122,7 +1147,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
             const int L = h->glen_host[g];
             for (int c = 0; c < nc; c++) {
                 int s_begin, s_acc, s_end;
-                window_bounds(L, nc, h->last_window, h->last_t0, c, s_begin, s_acc, s_end);
+                window_bounds(L, nc, h->last_window, h->last_t0, c, s_begin, s_acc, s_end, h->last_t0_delta);
                 for (int l = 0; l < WAVE; l++) {
                     const int ns = h->lane_ns_host[(size_t)g * WAVE + l];
                     rows += std::max(0, std::min(ns, s_end) - s_acc);

@@ -72,6 +72,8 @@ struct ssde_handle {
     DevBuf<int64_t> group_off, lane_row0;
     DevBuf<int32_t> group_len, lane_nsteps;
     int n_groups = 0, C = 0;
+    int c_obs = 1;                 // tile channel of the first obs column (0: no dt channel, globally regular grid)
+    double dt_all = 0.0;
     int64_t tile_doubles = 0;
 
     // direct families (long format, engine-owned copies)
@@ -142,7 +144,7 @@ struct ssde_handle {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     bool ev_k_valid = false;
     std::vector<int32_t> glen_host, lane_ns_host;
-    int last_s_stat = 0, last_t0 = 0;
+    int last_s_stat = 0, last_t0 = 0, last_t0_delta = 0;
     mutable int rows_key[3] = {-1, -1, -1};
     mutable int64_t rows_cached = 0;
 
