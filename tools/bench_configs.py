@@ -62,7 +62,7 @@ def main():
                        par_fixed=np.r_[0, 1, 1, 0, 0, 1, 1, np.zeros(18)].astype(np.uint8))
     eng = capi.Engine(pb1)
     par1 = np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(18))]
-    report("C1: single elephant-like CTCRW track x 3672, tau/nu splines (dense kernel)", eng, par1, 3672, 5)
+    report("C1: single elephant-like CTCRW track x 3672, tau/nu splines (row-varying path, hipGraph replay)", eng, par1, 3672, 5)
     eng.close()
 
     # C2: 1e4 CTCRW tracks x 1e3 rows, constant coefficients, regular grid
