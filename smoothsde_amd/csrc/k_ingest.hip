@@ -6,40 +6,65 @@
 
 namespace ssde {
 
-// grid: (n_groups, step chunks); block: 64 lanes.  Reads are strided (one track per lane), writes
-// are coalesced; this runs once, the evaluation kernels run hundreds of times.
-__global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
+// grid: (n_groups, step chunks); block: 256 threads = 4 waves.  The long format is read along the tracks (64
+// consecutive rows of one track by one wave: coalesced), transposed through LDS and written lane = track (coalesced):
+// every fetched line is used whole.  (The first version read lane = track directly from the long format: one 8-byte
+// element per fetched line, 24x the traffic -- profiles/r01_j_pmc_bytes.csv.)
+__global__ __launch_bounds__(4 * WAVE) void ingest_kernel(const IngestArgs A) {
+    __shared__ double tile[WAVE][WAVE + 1];      // [track][step], padded: conflict-free both ways
+    __shared__ int64_t s_row0[WAVE];
+    __shared__ int s_ns[WAVE];
+    __shared__ double s_red[3][4];
     const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = A.group_len[g];
-    const int chunk = (L + gridDim.y - 1) / gridDim.y;
+    const int chunk = ((L + gridDim.y - 1) / gridDim.y + WAVE - 1) / WAVE * WAVE;
     const int s_lo = blockIdx.y * chunk;
     const int s_hi = min(L, s_lo + chunk);
-    const int64_t row0 = A.lane_row0[g * WAVE + lane];
-    const int ns = A.lane_nsteps[g * WAVE + lane];
-    double* out = A.tiles + A.group_off[g] + lane;
+    if (threadIdx.x < WAVE) { s_row0[threadIdx.x] = A.lane_row0[g * WAVE + threadIdx.x]; s_ns[threadIdx.x] = A.lane_nsteps[g * WAVE + threadIdx.x]; }
+    __syncthreads();
+    double* out = A.tiles + A.group_off[g];
     const int C = A.C, d = A.d;
+    const int n_src = (A.c_obs ? 1 : 0) + d + (A.h_array ? d * d : 0) + A.ncols;
     double dmin = INFINITY, dmax = -INFINITY, seen_nan = 0.0;
-    for (int s = s_lo; s < s_hi; s++) {
-        double* o = out + (int64_t)s * C * WAVE;
-        if (s < ns) {
-            const int64_t i = row0 + 1 + s;
-            // dtimes(i): nllk_ctcrw.hpp:126-129 (the cross-track value at a track's last row is kept:
-            // the engine never uses that prediction for the likelihood, only ssde_report shows it)
-            const double dti = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
-            if (A.c_obs) o[0] = dti;
-            if (s < ns - 1) { dmin = fmin(dmin, dti); dmax = fmax(dmax, dti); if (dti != dti) dmax = INFINITY; }
-            for (int a = 0; a < d; a++) {
-                const double yv = A.obs[i + (int64_t)a * A.n];
-                o[(A.c_obs + a) * WAVE] = yv;
-                if (yv != yv) seen_nan = 1.0;
+    for (int s0 = s_lo; s0 < s_hi; s0 += WAVE) {
+        // the interval channel is read even when it is not stored: its range decides whether the grid is regular
+        for (int c = A.c_obs ? 0 : -1; c < n_src; c++) {
+            const int ch = c;                                    // -1: intervals for the statistics only
+            const bool is_dt = (A.c_obs && ch == 0) || ch < 0;
+            const int k = ch - A.c_obs;                          // 0.. : obs columns, then H entries, then design columns
+            // ---- read phase: wave wv takes tracks wv, wv + 4, ...; lane = step within the block ------------------
+            for (int t = wv; t < WAVE; t += 4) {
+                const int s = s0 + lane;
+                const int ns = s_ns[t];
+                double v = (is_dt && A.c_obs) ? 1.0 : 0.0;
+                if (s < ns) {
+                    const int64_t i = s_row0[t] + 1 + s;
+                    if (is_dt) {
+                        // dtimes(i): nllk_ctcrw.hpp:126-129 (the cross-track value at a track's last row is kept: the
+                        // engine never uses that prediction for the likelihood, only ssde_report shows it)
+                        v = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
+                        if (s < ns - 1) { dmin = fmin(dmin, v); dmax = fmax(dmax, v); if (v != v) dmax = INFINITY; }
+                    } else if (k < d) {
+                        v = A.obs[i + (int64_t)k * A.n];
+                        if (v != v) seen_nan = 1.0;
+                    } else if (A.h_array && k < d + d * d) {
+                        v = A.h_array[(k - d) + i * (int64_t)(d * d)];
+                    } else {
+                        v = A.cols[k - d - (A.h_array ? d * d : 0)][i];
+                    }
+                }
+                tile[t][lane] = v;
             }
-            int c = A.c_obs + d;
-            if (A.h_array)
-                for (int k = 0; k < d * d; k++) o[(c++) * WAVE] = A.h_array[k + i * (int64_t)(d * d)];
-            for (int k = 0; k < A.ncols; k++) o[(c++) * WAVE] = A.cols[k][i];
-        } else {
-            for (int c = 0; c < C; c++) o[c * WAVE] = (c == 0 && A.c_obs) ? 1.0 : 0.0;
+            __syncthreads();
+            // ---- write phase: wave wv takes steps wv, wv + 4, ...; lane = track --------------------------------------
+            if (ch >= 0) {
+                for (int u = wv; u < WAVE; u += 4) {
+                    const int s = s0 + u;
+                    if (s < s_hi) out[((int64_t)s * C + ch) * WAVE + lane] = tile[lane][u];
+                }
+            }
+            __syncthreads();
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -47,13 +72,18 @@ __global__ __launch_bounds__(WAVE) void ingest_kernel(const IngestArgs A) {
         dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
         seen_nan = fmax(seen_nan, __shfl_xor(seen_nan, o, 64));
     }
-    if (lane == 0) {
-        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 0] = dmin;
-        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 1] = dmax;
-        A.dt_minmax[((int64_t)g * gridDim.y + blockIdx.y) * 3 + 2] = seen_nan;
+    if (lane == 0) { s_red[0][wv] = dmin; s_red[1][wv] = dmax; s_red[2][wv] = seen_nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t o3 = ((int64_t)g * gridDim.y + blockIdx.y) * 3;
+        A.dt_minmax[o3 + 0] = fmin(fmin(s_red[0][0], s_red[0][1]), fmin(s_red[0][2], s_red[0][3]));
+        A.dt_minmax[o3 + 1] = fmax(fmax(s_red[1][0], s_red[1][1]), fmax(s_red[1][2], s_red[1][3]));
+        A.dt_minmax[o3 + 2] = fmax(fmax(s_red[2][0], s_red[2][1]), fmax(s_red[2][2], s_red[2][3]));
     }
-    if (blockIdx.y == 0) {
+    if (blockIdx.y == 0 && threadIdx.x < WAVE) {
         // initial state: a0 = first observation (velocities 0 for CTCRW), R/sde.R:549, 576-580
+        const int64_t row0 = s_row0[lane];
+        const int ns = s_ns[lane];
         double* a0 = A.a0 + (int64_t)g * A.sdim * WAVE + lane;
         for (int c = 0; c < A.sdim; c++) {
             double v = 0.0;
@@ -75,7 +105,7 @@ int ingest_ychunks(int n_groups) {
 }
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s) {
     if (a.n_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(ingest_kernel, dim3(a.n_groups, a.ychunks), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(ingest_kernel, dim3(a.n_groups, a.ychunks), dim3(4 * WAVE), 0, s, a);
     return hipGetLastError();
 }
 
