@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
         const double w = window_check_block(A, nstate, g, c, part, sh);
         if (threadIdx.x == 0 && w > 0.0)
             atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
-        return;
+    } else {
+        reduce_slot(R, blockIdx.x - n_check, sh);
     }
-    reduce_slot(R, blockIdx.x - n_check, sh);
 }
 
 hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {

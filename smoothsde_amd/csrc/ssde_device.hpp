@@ -395,20 +395,30 @@ __device__ __forceinline__ void reduce_slot(const ReduceArgs& A, int slot, doubl
         if (tid == 0) A.out[slot] = sh[0];
         return;
     }
-    if (slot == 0) {
-        for (int part = 0; part < A.n_value_parts; part++) {
-            const double* p = A.partials + ((int64_t)part * A.nacc) * A.n_blocks;  // accumulator 0
-            for (int b = tid; b < A.n_blocks; b += 256) acc += p[b];
-        }
-    } else {
-        const int nk = A.nacc - 1;
-        for (int part = 0; part < A.n_parts; part++) {
-            for (int k = 1; k < A.nacc; k++) {
-                if (A.map[(part / A.chunks_per_part) * nk + (k - 1)] != slot) continue;
-                const double* p = A.partials + ((int64_t)part * A.nacc + k) * A.n_blocks;
-                for (int b = tid; b < A.n_blocks; b += 256) acc += p[b];
+    // a run = `chunks` parts that feed the same slot, n_blocks entries each, `stride` doubles apart; walked as one
+    // flat index range with four independent loads in flight per thread (fixed order: bitwise reproducible)
+    const int64_t stride = (int64_t)A.nacc * A.n_blocks;
+    auto sum_run = [&](const double* base, int chunks) {
+        const int total = chunks * A.n_blocks;
+        for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 256;
+                const int c = i / A.n_blocks, b = i - c * A.n_blocks;
+                v[u] = i < total ? base[c * stride + b] : 0.0;
             }
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
+    };
+    if (slot == 0) {
+        sum_run(A.partials, A.n_value_parts);                                        // accumulator 0
+    } else {
+        const int nk = A.nacc - 1, cpp = A.chunks_per_part;
+        for (int pg = 0; pg * cpp < A.n_parts; pg++)
+            for (int k = 1; k < A.nacc; k++)
+                if (A.map[pg * nk + (k - 1)] == slot)
+                    sum_run(A.partials + ((int64_t)pg * cpp * A.nacc + k) * A.n_blocks, cpp);
     }
     sh[tid] = acc;
     __syncthreads();
