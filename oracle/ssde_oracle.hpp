@@ -521,16 +521,31 @@ Type dnorm_log(Type x, Type mean, Type sd) {
 // with respect to x AND nu, as TMB's AD does.
 template <class Type>
 Type log_besselI(Type x, Type nu) {
+    // I_nu(x) = (x/2)^nu sum_k t_k, t_k = (x^2/4)^k / (k! Gamma(k+nu+1)) (all terms positive), summed outwards from
+    // the largest term k* in units of t_k*: the same sum in any order, ~sqrt(x) terms, never overflows
     Type y = x * x * Type(0.25);
-    Type t = Type(1.0), S = Type(1.0);
-    double off = 0.0;
-    for (int k = 1; k < 20000; k++) {
-        t = t * y / (Type((double)k) * (Type((double)k) + nu));
+    const double xd = asDouble(x), nd = asDouble(nu);
+    double ks = std::floor(0.5 * (std::sqrt(nd * nd + xd * xd) - nd));
+    if (!(ks >= 1.0)) ks = 0.0;
+    Type S = Type(1.0), t = Type(1.0);
+    double k = ks;
+    for (int it = 0; it < (1 << 22); it++) {
+        k += 1.0;
+        t = t * y / (Type(k) * (Type(k) + nu));
         S = S + t;
-        if ((double)k > 0.5 * asDouble(x) && asDouble(t) < 1e-18 * asDouble(S)) break;
-        if (asDouble(S) > 1e200) { t = t * 1e-200; S = S * 1e-200; off += 200.0 * std::log(10.0); }
+        if (!(asDouble(t) >= 1e-18 * asDouble(S))) break;
     }
-    return nu * log(x * Type(0.5)) - lgamma(nu + Type(1.0)) + log(S) + Type(off);
+    t = Type(1.0);
+    k = ks;
+    while (k >= 1.0) {
+        t = t * (Type(k) * (Type(k) + nu)) / y;
+        k -= 1.0;
+        S = S + t;
+        if (!(asDouble(t) >= 1e-18 * asDouble(S))) break;
+    }
+    Type lt = Type(-1.0) * lgamma(Type(ks + 1.0) + nu);
+    if (ks > 0.0) lt = lt + Type(ks) * log(y) - Type(std::lgamma(ks + 1.0));
+    return nu * log(x * Type(0.5)) + lt + log(S);
 }
 
 // nllk_sde (nllk_sde.hpp:16-127) with tr_dens' BM (tr_dens.hpp:32-37), BM_t (:38-44), OU (:45-52) and CIR (:53-67)

@@ -530,11 +530,11 @@ SSDE_HD double ou_direct(double z0, double z1, double dt, double mu, double ltau
 // with respect to x AND q (q = 2 beta mu / sigma^2 - 1 moves with every parameter).  The reference takes
 // log(besselI(x, q)) (TMB's bessel_i, AD through R's algorithm), which overflows to Inf for x > ~700; here the
 // logarithm is formed directly from the ascending series
-//     I_q(x) = (x/2)^q / Gamma(q+1) * S,   S = sum_k t_k,  t_0 = 1,  t_k = t_{k-1} (x^2/4) / (k (k + q)),
-// whose terms are all positive (no cancellation: relative error ~ #terms * eps; #terms ~ x/2 + 40), rescaled on
-// the fly so that it never overflows:
-//     d log I / dx = q/x + 2 sum_k k t_k / (x S),      d log I / dq = log(x/2) - psi(q+1) - sum_k t_k h_k / S,
-//     h_k = sum_{j=1..k} 1/(j+q).
+//     I_q(x) = (x/2)^q * sum_k t_k,     t_k = (x^2/4)^k / (k! Gamma(k + q + 1)),
+// whose terms are all positive (no cancellation).  The terms rise to k* = (sqrt(q^2 + x^2) - q) / 2 and fall off
+// on both sides of it like a Gaussian of width ~ sqrt(x/2), so the sum is walked outwards from k* in units of t_k*
+// (log t_k* from lgamma): ~ 12 sqrt(x) terms instead of x/2 + 40, nothing to rescale, any x.
+//     d log I / dx = q/x + 2 sum_k k t_k / (x S),      d log I / dq = log(x/2) - sum_k t_k psi(k + q + 1) / S.
 // ---------------------------------------------------------------------------------------
 SSDE_HD double digamma_pos(double x) {   // psi(x), x > 0: recurrence up to x >= 8, then the asymptotic series
     double r = 0.0;
@@ -548,20 +548,32 @@ SSDE_HD double digamma_pos(double x) {   // psi(x), x > 0: recurrence up to x >=
 
 SSDE_HD double log_bessel_i(double x, double q, double& dlog_dx, double& dlog_dq) {
     const double y = 0.25 * x * x;
-    double t = 1.0, S = 1.0, A1 = 0.0, A2 = 0.0, hk = 0.0, off = 0.0;
-    const double kpeak = 0.5 * x;
-    for (int k = 1; k < 20000; k++) {
-        const double ik = 1.0 / ((double)k + q);
-        t *= y * ik / (double)k;
-        hk += ik;
-        S += t; A1 += (double)k * t; A2 += t * hk;
-        if ((double)k > kpeak && t < 1e-17 * S) break;
-        if (S > 1e200) { t *= 1e-200; S *= 1e-200; A1 *= 1e-200; A2 *= 1e-200; off += 460.51701859880916; }   // 200 ln 10
+    double ks = floor(0.5 * (sqrt(q * q + x * x) - q));          // index of the largest term
+    if (!(ks >= 1.0)) ks = 0.0;
+    const double psi0 = digamma_pos(ks + q + 1.0);
+    double S = 1.0, A1 = ks, A2 = psi0;                          // sums in units of t_ks
+    double t = 1.0, psi = psi0, k = ks;
+    for (int it = 0; it < (1 << 22); it++) {                     // upwards: t_k = t_{k-1} y / (k (k + q))
+        k += 1.0;
+        const double ik = 1.0 / (k + q);
+        t *= y * ik / k;
+        psi += ik;
+        S += t; A1 += k * t; A2 += psi * t;
+        if (!(t >= 1e-17 * S)) break;                            // (also leaves on NaN)
+    }
+    t = 1.0; psi = psi0; k = ks;
+    while (k >= 1.0) {                                           // downwards: t_{k-1} = t_k k (k + q) / y
+        t *= k * (k + q) / y;
+        psi -= 1.0 / (k + q);
+        k -= 1.0;
+        S += t; A1 += k * t; A2 += psi * t;
+        if (!(t >= 1e-17 * S)) break;
     }
     const double lx2 = log(0.5 * x);
+    const double lt = (ks > 0.0 ? ks * log(y) - lgamma(ks + 1.0) : 0.0) - lgamma(ks + q + 1.0);
     dlog_dx = q / x + 2.0 * A1 / (x * S);
-    dlog_dq = lx2 - digamma_pos(q + 1.0) - A2 / S;
-    return q * lx2 - lgamma(q + 1.0) + log(S) + off;
+    dlog_dq = lx2 - A2 / S;
+    return q * lx2 + lt + log(S);
 }
 
 // CIR: par = (log mu_a, log beta, log sigma).  Returns -log density, adds d/d(log mu_a, log beta, log sigma).

@@ -413,6 +413,25 @@ def test_cir_medium_batch_vs_oracle():
     eng.close()
 
 
+def test_cir_weak_diffusion_large_bessel_arguments():
+    """sigma = 0.03-0.05: Bessel arguments of 10^3-10^5 and orders of 10^3-10^4 (an unscaled besselI overflows at
+    700); generic and fast direct kernels against the oracle, and a finite result where a capped series would not be"""
+    rng = np.random.default_rng(78)
+    ID, times, _ = simulate("BM", 300, 60, 1, seed=78)
+    n = len(ID)
+    obs = np.exp(1.0 + 0.04 * np.cumsum(rng.standard_normal((n, 1)), axis=0) % 1.5)
+    for X_fe, par in (([None, None, None], np.array([1.0, -0.3, np.log(0.05)])),
+                      ([None, None, np.column_stack([np.ones(n), np.linspace(0, 1, n)])],
+                       np.array([1.2, 0.1, np.log(0.05), np.log(0.6)]))):
+        pb = capi.Problem("CIR", ID, times, obs, X_fe=X_fe)
+        eng = capi.Engine(pb)
+        val, grad = eng.eval(par)
+        oval, ograd = _oracle(pb, par)
+        assert np.isfinite(oval)
+        _close(val, grad, oval, ograd)
+        eng.close()
+
+
 # ---- random-effect blocks given as piecewise-cubic functions of a covariate (ssde_ppbasis) ---------------------------
 def _pp_problem(model, seed, fe_slope=False, on_second=False, **kw):
     from smoothsde_amd.synth import bspline_ppbasis, second_difference_penalty

@@ -46,6 +46,25 @@ def test_independent_restatement_live(name):
     assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
 
 
+def test_cir_weak_diffusion_against_mpmath_restatement():
+    """CIR with sigma = 0.05: Bessel arguments of 10^3-10^4 and orders ~10^3, where the reference's unscaled
+    besselI has long overflowed.  The oracle's series (summed outwards from its largest term) against the
+    independent restatement whose log I_q and derivatives come from mpmath."""
+    from refimpl import ref_eval
+    from smoothsde_amd import capi
+    rng = np.random.default_rng(77)
+    n = 14
+    ID = np.repeat([0.0, 1.0], [8, 6])
+    times = np.cumsum(rng.uniform(0.5, 1.5, size=n))
+    obs = np.exp(1.0 + 0.05 * np.cumsum(rng.standard_normal((n, 1)), axis=0))
+    pb = capi.Problem("CIR", ID, times, obs)
+    par = np.array([1.0, -0.3, np.log(0.05)])
+    val, grad = oracle_eval(pb, par, order=1)
+    rval, rgrad = ref_eval(pb, par)
+    assert abs(val - rval) <= 1e-10 * max(1.0, abs(rval))
+    assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
+
+
 def test_oracle_threads_and_data_only():
     rec = next(r for r in GOLD if r["name"] == "CTCRW_d2_tv")
     pb = problem_from_spec(rec)
