@@ -527,9 +527,14 @@ Type log_besselI(Type x, Type nu) {
     const double xd = asDouble(x), nd = asDouble(nu);
     double ks = std::floor(0.5 * (std::sqrt(nd * nd + xd * xd) - nd));
     if (!(ks >= 1.0)) ks = 0.0;
+    // Gaussian fall-off around k* with variance k*(k*+nu)/(2k*+nu); NaN (a rejected step) beyond x ~ 3e7, where the
+    // walk would take > 36000 steps per side
+    const double sd = std::sqrt(ks * (ks + nd) / (2.0 * ks + nd + 1e-300));
+    if (!(sd < 3.0e3)) return Type(NAN) * x * nu;      // (NaN in the value and in every derivative)
+    const int cap = 100 + (int)(12.0 * sd);
     Type S = Type(1.0), t = Type(1.0);
     double k = ks;
-    for (int it = 0; it < (1 << 22); it++) {
+    for (int it = 0; it < cap; it++) {
         k += 1.0;
         t = t * y / (Type(k) * (Type(k) + nu));
         S = S + t;
@@ -537,7 +542,7 @@ Type log_besselI(Type x, Type nu) {
     }
     t = Type(1.0);
     k = ks;
-    while (k >= 1.0) {
+    for (int it = 0; it < cap && k >= 1.0; it++) {
         t = t * (Type(k) * (Type(k) + nu)) / y;
         k -= 1.0;
         S = S + t;

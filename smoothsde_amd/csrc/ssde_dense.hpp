@@ -170,7 +170,7 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
         if (D == 1) det = F[0][0];
         else det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                                // det(): nllk_ctcrw.hpp:16-19
         // CTCRW tests det <= 0; OU/BM take exp(logdet) = |det|, which fails the test only at 0
-        upd = (MODEL == M_CTCRW) ? (det.v > 0.0) : (fabs(det.v) > 0.0);
+        upd = (MODEL == M_CTCRW) ? !(det.v <= 0.0) : !(fabs(det.v) <= 0.0);   // (a NaN takes the update branch)
     }
     if (!upd) {
         // missing observation, or detF <= 0; Q3: CTCRW drops the drift in the latter case only

@@ -1020,6 +1020,9 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
         // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
         // until the windows agree with each other; 64x the estimate ends in one sequential window
         if (h->last_check <= SSDE_WINDOW_TOL || h->last_chunks <= 1) break;
+        // a non-finite nllk is rejected by the caller whatever the windows did: no retry, and no lasting
+        // widening of the plan because an optimiser probed an absurd parameter once
+        if (!std::isfinite(o[0])) break;
         if (attempt >= 3) { h->max_chunks = 1; h->want_chunks = 1; }   // give up on windows: sequential filter
         else h->window_boost *= 4;
         h->n_retries++;

@@ -151,7 +151,7 @@ template <int D, int MASK>
 SSDE_HD void ctcrw_cov_step(CtcrwCov<MASK>& C, const CtcrwTrans& tr, double h, bool na, CtcrwGain& G) {
     const double F = C.p11 + h;                                // F = Z P Z' + H (line 223), scalar per dimension
     const double detF = (D == 1) ? F : F * F;                  // det(): lines 16-19
-    const bool upd = !na && (detF > 0.0);                      // lines 214, 226
+    const bool upd = !na && !(detF <= 0.0);                    // lines 214, 226 (a NaN takes the update branch)
     const double iF = upd ? rcp(F) : 0.0;
     C.ld.mul(upd ? F : 1.0);                                   // log(detF) = D log|F| (line 234)
     C.nupd += upd ? 1.0 : 0.0;
@@ -361,7 +361,7 @@ struct ScalCov {
 template <int D, int MASK, bool HAS_P2>
 SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool na, ScalGain& G) {
     const double F = C.p + h;
-    const bool upd = !na && (fabs(F) > 0.0);
+    const bool upd = !na && !(fabs(F) <= 0.0);                 // (a NaN takes the update branch, as in the reference)
     const double iF = upd ? rcp(F) : 0.0;
     C.ld.mul(upd ? F : 1.0);
     C.nupd += upd ? 1.0 : 0.0;
@@ -550,10 +550,15 @@ SSDE_HD double log_bessel_i(double x, double q, double& dlog_dx, double& dlog_dq
     const double y = 0.25 * x * x;
     double ks = floor(0.5 * (sqrt(q * q + x * x) - q));          // index of the largest term
     if (!(ks >= 1.0)) ks = 0.0;
+    // the terms fall off around k* like a Gaussian of variance k*(k*+q)/(2k*+q): 1e-17 is reached 8.9 standard
+    // deviations out.  Beyond k* ~ 1.8e7 (x ~ 3e7) the walk would take > 36000 steps per side: NaN (a rejected step)
+    const double sd = sqrt(ks * (ks + q) / (2.0 * ks + q + 1e-300));
+    if (!(sd < 3.0e3)) { dlog_dx = dlog_dq = NAN; return NAN; }
+    const int cap = 100 + (int)(12.0 * sd);
     const double psi0 = digamma_pos(ks + q + 1.0);
     double S = 1.0, A1 = ks, A2 = psi0;                          // sums in units of t_ks
     double t = 1.0, psi = psi0, k = ks;
-    for (int it = 0; it < (1 << 22); it++) {                     // upwards: t_k = t_{k-1} y / (k (k + q))
+    for (int it = 0; it < cap; it++) {                           // upwards: t_k = t_{k-1} y / (k (k + q))
         k += 1.0;
         const double ik = 1.0 / (k + q);
         t *= y * ik / k;
@@ -562,11 +567,13 @@ SSDE_HD double log_bessel_i(double x, double q, double& dlog_dx, double& dlog_dq
         if (!(t >= 1e-17 * S)) break;                            // (also leaves on NaN)
     }
     t = 1.0; psi = psi0; k = ks;
-    while (k >= 1.0) {                                           // downwards: t_{k-1} = t_k k (k + q) / y
-        t *= k * (k + q) / y;
+    for (int it = 0; it < cap && k >= 1.0; it++) {               // downwards: t_{k-1} = t_k k (k + q) / y
+        const double tk = t * k / y;
+        t = tk * (k + q);
+        A2 += t * psi - tk;      // t_{k-1} psi_{k-1} with psi_{k-1} = psi_k - 1/(k+q), free of the pole at k + q = 0 (q -> -1)
         psi -= 1.0 / (k + q);
         k -= 1.0;
-        S += t; A1 += k * t; A2 += psi * t;
+        S += t; A1 += k * t;
         if (!(t >= 1e-17 * S)) break;
     }
     const double lx2 = log(0.5 * x);

@@ -103,7 +103,7 @@ SSDE_HD void tv_ctcrw_step(TvCtcrwLane<D>& L, const double* r, double h, int kin
     const bool na = is_na(r[TVR_Y], any_nan);                   // obs(i,0) only: nllk_ctcrw.hpp:214
     const double F = L.p11 + h;                                 // line 223
     const double detF = (D == 1) ? F : F * F;
-    const bool upd = !na && (detF > 0.0);                       // lines 214, 226
+    const bool upd = !na && !(detF <= 0.0);                     // lines 214, 226 (NaN: update branch)
     const double iF = upd ? rcp(F) : 0.0;
     const double bm = (na || upd) ? 1.0 : 0.0;                  // Q3
     L.ld.mul(upd ? F : 1.0);
@@ -191,7 +191,7 @@ SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind,
     const double t = r[0], b = r[1], q = r[2];
     const bool na = is_na(r[TVR_Y], any_nan);
     const double F = L.p + h;
-    const bool upd = !na && (fabs(F) > 0.0);                    // detF = exp(logdet F): nllk_ou_ssm.hpp:190-195
+    const bool upd = !na && !(fabs(F) <= 0.0);                  // detF = exp(logdet F): nllk_ou_ssm.hpp:190-195
     const double iF = upd ? rcp(F) : 0.0;
     L.ld.mul(upd ? F : 1.0);
     const double tp = t * L.p;
@@ -355,7 +355,7 @@ struct TvEsealOps {
         const double z = r[TVE_Z], H = r[TVE_H], drift = r[TVE_DRIFT], q = r[TVE_Q];
         const bool na = is_na(r[TVE_Y], any_nan);                      // line 175
         const double F = z * z * L.p + H;                              // line 184
-        const bool upd = !na && (F > 0.0);                             // line 187
+        const bool upd = !na && !(F <= 0.0);                           // line 188 (NaN: update branch)
         const double iF = upd ? rcp(F) : 0.0;
         L.ld.mul(upd ? F : 1.0);
         const double u = upd ? r[TVE_Y] - r[TVE_A1] - z * L.x : 0.0;   // line 182

@@ -114,3 +114,34 @@ def test_penalty_only_and_fixed_everything():
     eng.close()
     ov = _oracle(pb0, par)[0]
     assert abs(v0 - ov) <= 1e-10 * abs(ov)
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM", "BM_SSM", "OU", "BM", "BM_t", "CIR"])
+def test_extreme_and_nan_parameters_follow_the_oracle(model):
+    """What an optimiser's line search can throw at fn/gr: one coordinate at -100 ... +100 (exp() under- and
+    overflows, variances of 0 and Inf) or NaN.  The engine must return what the reference arithmetic returns --
+    the same finite number, or a non-finite one where the reference is non-finite (never an error, never a
+    finite value for a NaN parameter: `detF <= 0` is false for NaN, nllk_ctcrw.hpp:226)."""
+    d = 1 if model in ("BM_t", "CIR") else 2
+    sim = {"BM_t": "BM", "CIR": "BM"}.get(model, model)
+    for M, T in ((3, 50), (70, 300)):
+        ID, times, obs = simulate(sim, M, T, d, seed=5)
+        if model == "CIR":
+            obs = np.exp(0.2 * obs % 2.0)
+        kw = {"other_data": 4.0} if model == "BM_t" else {}
+        pb = capi.Problem(model, ID, times, obs, **kw)
+        eng = capi.Engine(pb)
+        for k in range(pb.n_par_full):
+            for delta in (-100.0, -30.0, 30.0, 100.0, np.nan):
+                par = np.zeros(pb.n_par_full)
+                par[k] = delta
+                v, g = eng.eval(par)
+                ov, og = _oracle(pb, par)
+                ctx = (model, M, k, delta, v, ov)
+                assert np.isfinite(v) == np.isfinite(ov), ctx
+                if np.isfinite(ov):
+                    assert abs(v - ov) <= 1e-9 * max(1.0, abs(ov)), ctx
+                assert np.all(np.isfinite(g)) == np.all(np.isfinite(og)), ctx + (g, og)
+                if np.all(np.isfinite(og)):
+                    assert np.max(np.abs(g - og)) <= 1e-7 * np.max(np.abs(og)) + 1e-9, ctx + (g, og)
+        eng.close()
