@@ -1,29 +1,42 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-from smoothsde_amd import capi
-from smoothsde_amd.synth import simulate
-from oracle_lib import oracle_eval
-bad=0
-for model in ["CTCRW","OU_SSM","BM_SSM","OU","BM","BM_t","CIR"]:
-    d = 1 if model in ("BM_t","CIR") else 2
-    sim = {"BM_t":"BM","CIR":"BM"}.get(model, model)
-    for (M,T) in [(3,50),(200,400)]:
-        ID,times,obs = simulate(sim, M, T, d, seed=5)
-        if model=="CIR": obs = np.exp(0.2*obs % 2.0)
-        kw = {"other_data":4.0} if model=="BM_t" else {}
-        pb = capi.Problem(model, ID, times, obs, **kw)
-        eng = capi.Engine(pb)
-        p0 = np.zeros(pb.n_par_full)
-        for k in range(pb.n_par_full):
-            for delta in (-100,-30,-10,10,30,100,np.nan):
-                par = p0.copy(); par[k] = delta
-                v,g = eng.eval(par)
-                ov,og = oracle_eval(pb, par, order=1, threads=4)
-                okv = (np.isfinite(v)==np.isfinite(ov)) and (not np.isfinite(ov) or abs(v-ov) <= 1e-9*max(1,abs(ov)))
-                gf = np.all(np.isfinite(g))==np.all(np.isfinite(og))
-                okg = gf and (not np.all(np.isfinite(og)) or np.max(np.abs(g-og)) <= 1e-7*np.max(np.abs(og))+1e-9)
-                if not (okv and okg):
-                    bad+=1
-                    print(model,M,T,"par",k,delta,"gpu",v,"oracle",ov, "path",eng.info()["path"], "g",g,"og",og)
-        eng.close()
-print("mismatches",bad)
+#!/usr/bin/env python3
+"""Probe (GPU box): random problems of the fuzz suite evaluated with one coordinate pushed to an extreme or NaN;
+prints every disagreement with the oracle in finiteness or value.  Progress goes to stdout line by line."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from smoothsde_amd import capi                      # noqa: E402
+from oracle_lib import oracle_eval                  # noqa: E402
+from test_gpu_fuzz import random_problem            # noqa: E402
+
+bad = 0
+t00 = time.time()
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 64):
+    pb, par0 = random_problem(seed)
+    eng = capi.Engine(pb)
+    rng = np.random.default_rng(1000 + seed)
+    free = np.flatnonzero(pb.par_fixed == 0)
+    for trial in range(6):
+        k = int(rng.choice(free))
+        delta = [-100.0, -30.0, 30.0, 100.0, np.nan, -12.0][trial]
+        par = par0.copy()
+        par[k] = delta
+        t0 = time.time()
+        v, g = eng.eval(par)
+        tg = time.time() - t0
+        ov, og = oracle_eval(pb, par, order=1, threads=4)
+        okv = (np.isfinite(v) == np.isfinite(ov)) and (not np.isfinite(ov) or abs(v - ov) <= 1e-9 * max(1, abs(ov)))
+        gf = np.all(np.isfinite(g)) == np.all(np.isfinite(og))
+        okg = gf and (not np.all(np.isfinite(og)) or np.max(np.abs(g - og)) <= 1e-7 * np.max(np.abs(og)) + 1e-9)
+        if not (okv and okg) or tg > 2.0:
+            bad += 1
+            print("MISMATCH" if not (okv and okg) else "SLOW", seed, pb.model, pb.n, "par", k, delta, "gpu", v, "oracle", ov,
+                  "path", eng.info()["path"], "t", round(tg, 2), "\n   g", g, "\n  og", og, flush=True)
+    eng.close()
+    print("seed", seed, pb.model, "done", round(time.time() - t00, 1), flush=True)
+print("issues", bad)
