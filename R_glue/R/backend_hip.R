@@ -6,6 +6,32 @@
 # make_hip_obj(...) instead when other_data$backend == "hip".  $fit() (optim BFGS on obj$fn / obj$gr,
 # R/sde.R:694-697) and logLik.SDE (obj_joint$fn, R/utility.R:118) stay as they are.
 
+#' Piecewise-cubic table of a univariate regression-spline smooth (ssde_ppbasis, include/ssde.h)
+#'
+#' mgcv's "cr", "cs", "bs" (m = 3) and "ps" bases are cubic polynomials of the covariate on every knot interval, also
+#' after the identifiability constraint has been absorbed (a linear map of the columns).  Four evaluations per interval
+#' therefore determine the block exactly; the engine then reads the covariate (8 B/row) instead of the n x K block.
+#' @param sm smooth object from smoothCon(..., absorb.cons = TRUE) -- gam_setup$smooth[[i]] in SDE$make_mat
+#' @param x covariate values of the rows (the column sm$term of the data)
+#' @return list(x, knots, coef) for spec$basis_re[[j]], or NULL when the smooth is not of that kind
+pp_table <- function(sm, x) {
+    if(length(sm$term) != 1 || sm$by != "NA") return(NULL)
+    br <- if(inherits(sm, "cr.smooth") || inherits(sm, "cs.smooth")) sm$xp
+          else if(inherits(sm, "Bspline.smooth") || inherits(sm, "pspline.smooth")) sort(unique(sm$knots))
+          else return(NULL)
+    if(!is.null(sm$m) && inherits(sm, c("Bspline.smooth", "pspline.smooth")) && sm$m[1] != 3 && sm$m[1] != 2) return(NULL)
+    br <- br[br > min(x) & br < max(x)]
+    br <- c(min(x), br, max(x))                       # "cr" extrapolates linearly outside xp: never needed inside range(x)
+    K <- ncol(mgcv::PredictMat(sm, setNames(data.frame(x[1]), sm$term)))
+    coef <- array(0, dim = c(4, K, length(br) - 1))
+    for(iv in seq_len(length(br) - 1)) {
+        t <- (br[iv + 1] - br[iv]) * c(0.1, 0.37, 0.63, 0.9)
+        B <- mgcv::PredictMat(sm, setNames(data.frame(br[iv] + t), sm$term))      # 4 x K
+        coef[, , iv] <- solve(outer(t, 0:3, "^"), B)                               # B = V c, V = Vandermonde in t
+    }
+    list(x = as.numeric(x), knots = as.numeric(br), coef = coef)
+}
+
 #' Build a MakeADFun-like object backed by the HIP engine
 #'
 #' @param sde SDE object (after initialize)
@@ -44,7 +70,10 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
                  other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL,
                  eseal_h = if(eseal) as.numeric(tmb_dat$h) else NULL, eseal_R = if(eseal) as.numeric(tmb_dat$R) else NULL,
                  t_decay = if(length(tmb_dat$t_decay) > 1) as.numeric(tmb_dat$t_decay) else NULL,
-                 col_decay = as.integer(tmb_dat$col_decay), ind_decay = as.integer(tmb_dat$ind_decay))
+                 col_decay = as.integer(tmb_dat$col_decay), ind_decay = as.integer(tmb_dat$ind_decay),
+                 # optional: list of length q (NULL entries = streamed block); the caller builds entry j with
+                 # pp_table(gam_setup$smooth[[i]], data[[term]]) when parameter j has exactly one such smooth
+                 basis_re = sde$other_data()$basis_re)
     # one penalty matrix per smooth: the diagonal blocks of S, sizes terms()$ncol_re (R/sde.R:424-447)
     if(has_re) {
         ncol_re <- sde$terms()$ncol_re; off <- cumsum(c(0, ncol_re)); S <- as.matrix(sde$mats()$S)

@@ -48,7 +48,7 @@ static int model_code(const char *type) {
 
 /* spec: list(type, ID (numeric codes), times, obs (n x d matrix), X_list_fe, X_list_re (lists of
  * matrices or NULL), S_list (list of matrices), a0, P0, H (d x d x n array) or NULL, par_fixed (logical),
- * include_penalty, device) -- exactly the objects SDE$setup already has in hand (R/sde.R:496-598). */
+ * include_penalty, device, basis_re) -- exactly the objects SDE$setup already has in hand (R/sde.R:496-598). */
 SEXP ssdeR_create(SEXP spec) {
     ssde_desc d;
     memset(&d, 0, sizeof(d));
@@ -117,6 +117,27 @@ SEXP ssdeR_create(SEXP spec) {
             if (i0[k] + 1 > nrate) nrate = i0[k] + 1;
         }
         d.t_decay = REAL(td); d.n_decay_cols = nc; d.col_decay = c0; d.ind_decay = i0; d.n_decay = nrate;
+    }
+    /* basis_re: list of length q, element j NULL or list(x = covariate (n), knots = breakpoints, coef = array
+     * 4 x K x (n_knots - 1)): the random-effect block of parameter j as a piecewise-cubic table (ssde_ppbasis) */
+    SEXP bre = get_elt(spec, "basis_re");
+    if (bre != R_NilValue) {
+        const ssde_ppbasis **pb = (const ssde_ppbasis **)R_alloc(q, sizeof(ssde_ppbasis *));
+        for (int j = 0; j < q; j++) {
+            SEXP b = VECTOR_ELT(bre, j);
+            pb[j] = NULL;
+            if (b == R_NilValue) continue;
+            ssde_ppbasis *t = (ssde_ppbasis *)R_alloc(1, sizeof(ssde_ppbasis));
+            SEXP kn = get_elt(b, "knots"), cf = get_elt(b, "coef");
+            t->x = REAL(get_elt(b, "x"));
+            t->n_knots = (int32_t)Rf_xlength(kn);
+            t->n_cols = ncol_re[j];
+            t->knots = REAL(kn);
+            if (Rf_xlength(cf) != (R_xlen_t)4 * t->n_cols * (t->n_knots - 1)) Rf_error("basis_re[[%d]]$coef has the wrong size", j + 1);
+            t->coef = REAL(cf);          /* [iv][k][m] with m fastest == R array dim c(4, K, n_knots - 1) */
+            pb[j] = t;
+        }
+        d.basis_re = pb;
     }
     d.na_mode = SSDE_NA_R_ONLY;                                     /* R_IsNA semantics (nllk_ctcrw.hpp:214) */
     SEXP dev = get_elt(spec, "device");
