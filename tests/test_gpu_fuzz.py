@@ -6,6 +6,8 @@ fixed (TMB's `map`), and optionally H_array / P0 / a0 / BM_t's df / decaying col
 finishes in milliseconds), many shapes: this is the net for rare indexing / masking bugs, not a throughput test.
 
 Tolerances (fp64): value 1e-10 * max(1,|v|); gradient 1e-8 * max|g| + 1e-10."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,7 +24,7 @@ def _oracle(pb, par):
     return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4)
 
 
-def random_problem(seed):
+def random_problem(seed, big=False):
     rng = np.random.default_rng(seed)
     model = MODELS[seed % len(MODELS)]
     d = 1 if model in ("BM_t", "ESEAL_SSM") else int(rng.integers(1, 3))
@@ -32,6 +34,10 @@ def random_problem(seed):
     lens = rng.integers(1, 12, size=n_tracks) if not long_tracks else rng.integers(150, 700, size=n_tracks)
     if n_tracks > 20:
         lens = rng.integers(1, 40, size=n_tracks)
+    if big:      # long ragged tracks: several time windows per track, full and partial lane groups
+        n_tracks = int(rng.integers(30, 400))
+        lens = rng.integers(2, int(rng.choice([300, 1500, 5000])), size=n_tracks)
+        lens[: max(1, n_tracks // 8)] = rng.integers(2000, 6000, size=max(1, n_tracks // 8))
     if lens.sum() < 2:
         lens[0] = 3
     if model == "ESEAL_SSM":
@@ -110,7 +116,11 @@ def random_problem(seed):
     return pb, par
 
 
-@pytest.mark.parametrize("seed", range(240))
+# SSDE_FUZZ_SEEDS="lo:hi" widens the net for a one-off hunt (the default 240 seeds run in the suite)
+_LO, _HI = (int(v) for v in os.environ.get("SSDE_FUZZ_SEEDS", "0:240").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_problem_matches_oracle(seed):
     pb, par = random_problem(seed)
     eng = capi.Engine(pb)
@@ -126,4 +136,26 @@ def test_random_problem_matches_oracle(seed):
         assert np.all(grad[pb.par_fixed != 0] == 0.0)
         v0 = eng.eval(par, order=0)
         assert abs(v0 - val) <= 1e-12 * max(1.0, abs(val)), ctx
+    eng.close()
+
+
+_BLO, _BHI = (int(v) for v in os.environ.get("SSDE_FUZZ_BIG_SEEDS", "0:16").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_BLO, _BHI))
+def test_random_long_ragged_problem_matches_oracle(seed):
+    """The same generator with 30-400 ragged tracks of up to 6000 rows: time windows, the transient split, partial
+    lane groups and the window hand-over check all come into play."""
+    pb, par = random_problem(10_000 + seed, big=True)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    oval, ograd = _oracle(pb, par)
+    info = eng.info()
+    ctx = (pb.model, pb.n_dim, pb.n, pb.n_seg, info["path"], info["window"], info["window_retries"])
+    if not np.isfinite(oval):
+        assert not np.isfinite(val), ctx
+    else:
+        assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (val, oval, ctx)
+        assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd, ctx)
+        assert info["window_check"] <= capi.WINDOW_TOL, ctx
     eng.close()
