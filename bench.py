@@ -157,6 +157,7 @@ def main():
     sync_api = world == 1 and not os.environ.get("SSDE_BENCH_ASYNC")
 
     last_info = [None]
+    d2h_blocking = os.environ.get("SSDE_BENCH_D2H", "blocking") == "blocking"   # ("pinned": async copy + stream sync, 2-3 % slower)
 
     def step(k, events=None, force_async=False):
         th = thetas[k]
@@ -173,6 +174,8 @@ def main():
             events[1].record(stream)
         if world > 1:
             dist.all_reduce(out)          # RCCL sum of [nllk, grad] over xGMI: 1+p doubles
+        if d2h_blocking:
+            return out.cpu().numpy()                 # blocking D2H (one hipMemcpy, its own synchronisation)
         out_pinned.copy_(out, non_blocking=True)   # D2H of the result into pinned memory ...
         stream.synchronize()                         # ... and the one synchronisation of the step
         return out_pinned.numpy().copy()
