@@ -226,7 +226,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 // One kernel per direction mask when the whole launch uses a single mask (n_parts == 1, the default):
 // a kernel's register allocation is the worst case over everything it contains.
 template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoArgs A) {
+__device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
@@ -235,6 +235,21 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoA
     constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
     if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), DERJ>(A, g, part, chunk);
     else run_lane<MODEL, D, MASK>(A, g, part, chunk);
+}
+
+// CTCRW: one wave per SIMD with the whole register file (its 20 + 12 recursions spill under any cap, and that
+// many independent chains keep the fp64 pipe busy from a single wave).
+template <int MODEL, int D, int MASK>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoArgs A) {
+    iso_mask_body<MODEL, D, MASK>(A);
+}
+
+// BM_SSM / OU_SSM: a scalar covariance and few chains per row -- one wave leaves the pipe idle behind its
+// dependent instructions and its loads, so these run two waves per SIMD (256 registers each; the engine plans
+// twice as many time windows for them, ssde_engine.hip).
+template <int MODEL, int D, int MASK>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_light_kernel(const IsoArgs A) {
+    iso_mask_body<MODEL, D, MASK>(A);
 }
 
 // Direction-split launches (several parts with different masks) keep the masks in one kernel.
@@ -259,7 +274,11 @@ template <int MODEL, int D>
 static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
     dim3 block(WG_WAVES * WAVE);
     switch (a.part_mask[0]) {
-#define SSDE_CASE(M) case M: hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
+#define SSDE_CASE(M)                                                                                          \
+    case M:                                                                                                   \
+        if (MODEL == M_CTCRW) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((iso_mask_light_kernel<MODEL, D, M>), grid, block, 0, s, a);                   \
+        break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE

@@ -486,6 +486,10 @@ int build(const ssde_desc* d, ssde_handle* h) {
             // one wave per SIMD (1024 work items INCLUDING the padding of the group count to a multiple of 8):
             // a lone wave already issues fp64 at the SIMD's rate, and fewer windows mean fewer warm-up rows
             int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
+            // ... except for the scalar-covariance models on the general kernel (irregular grid or missing rows in
+            // most groups): too few independent chains per row for one wave, so two waves per SIMD (k_iso.hip)
+            if (h->model != SSDE_MODEL_CTCRW && (!h->uniform_dt || 2 * h->n_clean_groups < G) && !getenv("SSDE_NO_LIGHT2"))
+                want = std::max(1, 2048 / (((G + 7) / 8 * 8) * h->iso_parts));
             if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
             h->want_chunks = std::max(1, std::min(want, h->max_chunks));

@@ -23,8 +23,9 @@ eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, t_irr, obs, par_fixed=[0,
 report("CTCRW 1e4 x 1e4, irregular grid, mu fixed", eng, np.array([np.log(0.1), 0, 0, np.log(2.0), 0.0]), M * T, 5)
 eng.close()
 del t_irr
-for model, par in (("CTCRW", [np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0]), ("OU_SSM", [np.log(0.1), 5.0, -5.0, np.log(2.0), 0.0])):
-    ID, times, obs = simulate(model, M, T, 2, mu=[5.0, -5.0] if model == "OU_SSM" else 0.0, tau=2.0, nu=1.0, kappa=1.0,
+for model, par in (("CTCRW", [np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0]), ("OU_SSM", [np.log(0.1), 5.0, -5.0, np.log(2.0), 0.0]),
+                   ("BM_SSM", [np.log(0.1), 0.1, 0.1, 0.0])):
+    ID, times, obs = simulate(model, M, T, 2, mu=[5.0, -5.0] if model == "OU_SSM" else 0.1 if model == "BM_SSM" else 0.0, sigma=1.0, tau=2.0, nu=1.0, kappa=1.0,
                               sigma_obs=0.1, seed=4, backend="torch", device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     na = torch.rand(len(ID), device=dev, generator=gen) < 0.05
