@@ -150,6 +150,108 @@ def test_additivity_over_track_shards_full_size_tracks():
         x.close()
 
 
+def test_full_bench_size_properties():
+    """BASELINE.json's configuration itself (10^4 CTCRW tracks x 10^4 rows, d = 2, mu fixed; 10^8 rows, built in HBM
+    like bench.py does), where the oracle would take minutes -- size-independent properties instead:
+      * additivity: the batch equals the sum of its two halves (disjoint track shards) in value and gradient;
+      * the gradient is the derivative of the value (central difference along a random direction, 1e-7 relative);
+      * repeated evaluations are bitwise identical; the window hand-over check passes;
+      * a random sample of 24 whole tracks, evaluated on its own, matches the oracle at the usual tolerance."""
+    import torch
+    M, T = 10_000, 10_000
+    ID, times, obs = simulate("CTCRW", M, T, 2, mu=0.0, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1, backend="torch",
+                              device="cuda:0")
+    fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
+    par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.05])
+    full = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=fixed))
+    vf, gf = full.eval(par)
+    info = full.info()
+    assert info["n_rows"] == M * T and info["window_check"] <= capi.WINDOW_TOL
+    v2, g2 = full.eval(par)
+    assert v2 == vf and np.array_equal(g2, gf)
+    # additivity over two track shards
+    cut = 3_700 * T
+    va = vb = 0.0
+    ga = np.zeros_like(gf)
+    for sl in (slice(0, cut), slice(cut, M * T)):
+        e = capi.Engine(capi.Problem.from_torch("CTCRW", ID[sl], times[sl], obs[sl], par_fixed=fixed))
+        v, g = e.eval(par)
+        va += v
+        ga += g
+        e.close()
+    assert abs(vf - va) <= 1e-12 * abs(vf), (vf, va)
+    assert np.max(np.abs(gf - ga)) <= 1e-11 * np.max(np.abs(gf)), (gf, ga)
+    # gradient = derivative of the value
+    rng = np.random.default_rng(0)
+    free = np.flatnonzero(fixed == 0)
+    dirn = np.zeros_like(par)
+    dirn[free] = rng.standard_normal(len(free))
+    h = 1e-5
+    fd = (full.eval(par + h * dirn, order=0) - full.eval(par - h * dirn, order=0)) / (2 * h)
+    assert abs(fd - gf @ dirn) <= 1e-7 * abs(gf @ dirn) + 1e-7 * np.max(np.abs(gf)), (fd, gf @ dirn)
+    assert np.all(gf[fixed != 0] == 0.0)
+    full.close()
+    # a random sample of whole tracks against the oracle
+    pick = np.sort(rng.choice(M, size=24, replace=False))
+    rows = torch.cat([torch.arange(k * T, (k + 1) * T, device=ID.device) for k in pick])
+    pbh = capi.Problem("CTCRW", ID[rows].cpu().numpy(), times[rows].cpu().numpy(), obs[rows].cpu().numpy(), par_fixed=fixed)
+    e = capi.Engine(pbh)
+    v, g = e.eval(par)
+    oval, ograd = _oracle(pbh, par)
+    _close(v, g, oval, ograd)
+    e.close()
+
+
+def test_full_size_properties_streamed_design_config():
+    """SURVEY 8(d) C3 at full size (10^4 OU tracks x 10^4 rows, d = 1, a 9-column design block streamed for mu,
+    88 B/row, 10^8 rows): additivity over two track shards, gradient = derivative of the value, determinism, and
+    a random sample of 16 whole tracks against the oracle."""
+    import torch
+    from smoothsde_amd.synth import second_difference_penalty
+    M, T, K = 10_000, 10_000, 9
+    ID, times, obs = simulate("OU", M, T, 1, mu=1.0, tau=2.0, kappa=1.0, seed=2, backend="torch", device="cuda:0")
+    n = ID.numel()
+    x = torch.cumsum(torch.randn(n, device=ID.device, dtype=torch.float64) * 0.01, 0)
+    x = (x - x.min()) / (x.max() - x.min())
+    B = torch.stack([torch.cos((k + 1) * np.pi * x) for k in range(K)], dim=1)
+    S = [second_difference_penalty(K)]
+    par = np.concatenate([[1.0, np.log(2.0), 0.0], [0.3], 0.05 * np.sin(np.arange(K))])
+
+    def engine(sl):
+        return capi.Engine(capi.Problem.from_torch("OU", ID[sl], times[sl], obs[sl], X_re=[B[sl], None, None], S_list=S))
+
+    full = engine(slice(0, n))
+    vf, gf = full.eval(par)
+    v2, g2 = full.eval(par)
+    assert v2 == vf and np.array_equal(g2, gf)
+    pen, gpen = full.penalty(par)
+    cut = 4_100 * T
+    va, ga = -pen, -gpen            # every engine adds the (parameter-only) penalty once: count it once
+    for sl in (slice(0, cut), slice(cut, n)):
+        e = engine(sl)
+        v, g = e.eval(par)
+        va += v
+        ga = ga + g
+        e.close()
+    assert abs(vf - va) <= 1e-12 * abs(vf), (vf, va)
+    assert np.max(np.abs(gf - ga)) <= 1e-11 * np.max(np.abs(gf)), (gf, ga)
+    rng = np.random.default_rng(1)
+    dirn = rng.standard_normal(len(par))
+    h = 1e-6
+    fd = (full.eval(par + h * dirn, order=0) - full.eval(par - h * dirn, order=0)) / (2 * h)
+    assert abs(fd - gf @ dirn) <= 1e-6 * abs(gf @ dirn) + 1e-7 * np.max(np.abs(gf)), (fd, gf @ dirn)
+    full.close()
+    pick = np.sort(rng.choice(M, size=16, replace=False))
+    rows = torch.cat([torch.arange(k * T, (k + 1) * T, device=ID.device) for k in pick])
+    pbh = capi.Problem("OU", ID[rows].cpu().numpy(), times[rows].cpu().numpy(), obs[rows].cpu().numpy(),
+                       X_re=[B[rows].cpu().numpy(), None, None], S_list=S)
+    e = capi.Engine(pbh)
+    v, g = e.eval(par)
+    oval, ograd = _oracle(pbh, par)
+    _close(v, g, oval, ograd)
+    e.close()
+
+
 def test_direct_large_vs_oracle():
     from smoothsde_amd.synth import bspline_basis, second_difference_penalty
     ID, times, obs = simulate("OU", 500, 400, 1, mu=1.0, seed=21)
