@@ -150,20 +150,19 @@ def test_additivity_over_track_shards_full_size_tracks():
         x.close()
 
 
-def test_full_bench_size_properties():
-    """BASELINE.json's configuration itself (10^4 CTCRW tracks x 10^4 rows, d = 2, mu fixed; 10^8 rows, built in HBM
-    like bench.py does), where the oracle would take minutes -- size-independent properties instead:
-      * additivity: the batch equals the sum of its two halves (disjoint track shards) in value and gradient;
-      * the gradient is the derivative of the value (central difference along a random direction, 1e-7 relative);
-      * repeated evaluations are bitwise identical; the window hand-over check passes;
-      * a random sample of 24 whole tracks, evaluated on its own, matches the oracle at the usual tolerance."""
+def _full_size_check(model, par, fixed, na_frac, sim_kw):
     import torch
     M, T = 10_000, 10_000
-    ID, times, obs = simulate("CTCRW", M, T, 2, mu=0.0, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1, backend="torch",
-                              device="cuda:0")
-    fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
-    par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.05])
-    full = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=fixed))
+    ID, times, obs = simulate(model, M, T, 2, seed=1, backend="torch", device="cuda:0", **sim_kw)
+    if na_frac > 0:
+        gen = torch.Generator(device=ID.device)
+        gen.manual_seed(7)
+        na = torch.rand(ID.numel(), device=ID.device, generator=gen) < na_frac
+        na[::T] = False
+        obs[na] = float("nan")
+    fixed = np.asarray(fixed, dtype=np.uint8)
+    par = np.asarray(par, dtype=float)
+    full = capi.Engine(capi.Problem.from_torch(model, ID, times, obs, par_fixed=fixed))
     vf, gf = full.eval(par)
     info = full.info()
     assert info["n_rows"] == M * T and info["window_check"] <= capi.WINDOW_TOL
@@ -171,16 +170,19 @@ def test_full_bench_size_properties():
     assert v2 == vf and np.array_equal(g2, gf)
     # additivity over two track shards
     cut = 3_700 * T
-    va = vb = 0.0
+    va = 0.0
     ga = np.zeros_like(gf)
     for sl in (slice(0, cut), slice(cut, M * T)):
-        e = capi.Engine(capi.Problem.from_torch("CTCRW", ID[sl], times[sl], obs[sl], par_fixed=fixed))
+        e = capi.Engine(capi.Problem.from_torch(model, ID[sl], times[sl], obs[sl], par_fixed=fixed))
         v, g = e.eval(par)
         va += v
         ga += g
         e.close()
     assert abs(vf - va) <= 1e-12 * abs(vf), (vf, va)
-    assert np.max(np.abs(gf - ga)) <= 1e-11 * np.max(np.abs(gf)), (gf, ga)
+    # The variance-direction entries are differences of two sums that are each ~10^3 times larger (sum dF/F against
+    # sum u^2 dF/F^2): the rounding of those sums (1e-13 relative, and it depends on how many rows one accumulator
+    # sees, i.e. on the window plan, which differs between the batch and its shards) shows as ~1e-10 in the entries.
+    assert np.max(np.abs(gf - ga)) <= 1e-9 * np.max(np.abs(gf)), (gf, ga)
     # gradient = derivative of the value
     rng = np.random.default_rng(0)
     free = np.flatnonzero(fixed == 0)
@@ -194,12 +196,35 @@ def test_full_bench_size_properties():
     # a random sample of whole tracks against the oracle
     pick = np.sort(rng.choice(M, size=24, replace=False))
     rows = torch.cat([torch.arange(k * T, (k + 1) * T, device=ID.device) for k in pick])
-    pbh = capi.Problem("CTCRW", ID[rows].cpu().numpy(), times[rows].cpu().numpy(), obs[rows].cpu().numpy(), par_fixed=fixed)
+    pbh = capi.Problem(model, ID[rows].cpu().numpy(), times[rows].cpu().numpy(), obs[rows].cpu().numpy(), par_fixed=fixed)
     e = capi.Engine(pbh)
     v, g = e.eval(par)
     oval, ograd = _oracle(pbh, par)
     _close(v, g, oval, ograd)
     e.close()
+    return info
+
+
+def test_full_bench_size_properties():
+    """BASELINE.json's configuration itself (10^4 CTCRW tracks x 10^4 rows, d = 2, mu fixed; 10^8 rows, built in HBM
+    like bench.py does), where the oracle would take minutes -- size-independent properties instead:
+      * additivity: the batch equals the sum of its two halves (disjoint track shards) in value and gradient;
+      * the gradient is the derivative of the value (central difference along a random direction, 1e-7 relative);
+      * repeated evaluations are bitwise identical; the window hand-over check passes;
+      * a random sample of 24 whole tracks, evaluated on its own, matches the oracle at the usual tolerance."""
+    info = _full_size_check("CTCRW", [np.log(0.1), 0.0, 0.0, np.log(2.0), 0.05], [0, 1, 1, 0, 0], 0.0,
+                            dict(mu=0.0, tau=2.0, nu=1.0, sigma_obs=0.1))
+    assert info["uniform_dt"] == 1 and info["window"] > 0
+
+
+@pytest.mark.parametrize("model,par,sim_kw", [
+    ("BM_SSM", [np.log(0.1), 0.1, 0.1, 0.0], dict(mu=0.1, sigma=1.0, sigma_obs=0.1)),
+    ("OU_SSM", [np.log(0.1), 5.0, -5.0, np.log(2.0), 0.0], dict(mu=[5.0, -5.0], tau=2.0, kappa=1.0, sigma_obs=0.1)),
+    ("CTCRW", [np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0], dict(mu=0.0, tau=2.0, nu=1.0, sigma_obs=0.1))])
+def test_full_size_properties_missing_rows(model, par, sim_kw):
+    """The pieces of SURVEY 8(d) C5 at full size (10^4 tracks x 10^4 rows, 5 % missing rows, every parameter free):
+    the general register kernel (two waves per SIMD for the scalar-covariance models) under the same properties."""
+    _full_size_check(model, par, [0] * len(par), 0.05, sim_kw)
 
 
 def test_full_size_properties_streamed_design_config():
