@@ -190,7 +190,9 @@ def _full_size_check(model, par, fixed, na_frac, sim_kw):
     dirn[free] = rng.standard_normal(len(free))
     h = 1e-5
     fd = (full.eval(par + h * dirn, order=0) - full.eval(par - h * dirn, order=0)) / (2 * h)
-    assert abs(fd - gf @ dirn) <= 1e-7 * abs(gf @ dirn) + 1e-7 * np.max(np.abs(gf)), (fd, gf @ dirn)
+    # what a central difference can resolve at 10^8 rows: rounding eps |f| / h ~ 1e-3 and truncation h^2 f''' / 6 ~ 1e-3
+    # against entries of 10^3-10^4, i.e. six digits of the gradient
+    assert abs(fd - gf @ dirn) <= 1e-6 * np.max(np.abs(gf)), (fd, gf @ dirn)
     assert np.all(gf[fixed != 0] == 0.0)
     full.close()
     # a random sample of whole tracks against the oracle
@@ -262,9 +264,9 @@ def test_full_size_properties_streamed_design_config():
     assert np.max(np.abs(gf - ga)) <= 1e-11 * np.max(np.abs(gf)), (gf, ga)
     rng = np.random.default_rng(1)
     dirn = rng.standard_normal(len(par))
-    h = 1e-6
+    h = 1e-5
     fd = (full.eval(par + h * dirn, order=0) - full.eval(par - h * dirn, order=0)) / (2 * h)
-    assert abs(fd - gf @ dirn) <= 1e-6 * abs(gf @ dirn) + 1e-7 * np.max(np.abs(gf)), (fd, gf @ dirn)
+    assert abs(fd - gf @ dirn) <= 1e-6 * np.max(np.abs(gf)), (fd, gf @ dirn)      # (six digits: see _full_size_check)
     full.close()
     pick = np.sort(rng.choice(M, size=16, replace=False))
     rows = torch.cat([torch.arange(k * T, (k + 1) * T, device=ID.device) for k in pick])
