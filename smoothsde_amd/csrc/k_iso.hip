@@ -276,7 +276,7 @@ static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
     switch (a.part_mask[0]) {
 #define SSDE_CASE(M)                                                                                          \
     case M:                                                                                                   \
-        if (MODEL == M_CTCRW) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a);        \
+        if constexpr (MODEL == M_CTCRW) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((iso_mask_light_kernel<MODEL, D, M>), grid, block, 0, s, a);                   \
         break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
