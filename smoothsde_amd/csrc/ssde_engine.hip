@@ -1009,7 +1009,8 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     std::vector<double> o(2 + h->L.n_full);
     const bool use_graph = h->path == PATH_TV && !getenv("SSDE_NO_GRAPH");
-    for (int attempt = 0;; attempt++) {
+    int attempt = 0;
+    for (;; attempt++) {
         if (use_graph && h->tv_stats_valid) {
             HIPCHK(h, hipSetDevice(h->device));
             int st = eval_tv_graph(h, par, order, o.data());
@@ -1027,9 +1028,40 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
         // a non-finite nllk is rejected by the caller whatever the windows did: no retry, and no lasting
         // widening of the plan because an optimiser probed an absurd parameter once
         if (!std::isfinite(o[0])) break;
-        if (attempt >= 3) { h->max_chunks = 1; h->want_chunks = 1; }   // give up on windows: sequential filter
-        else h->window_boost *= 4;
         h->n_retries++;
+        h->calm = 0;
+        if (h->probing && attempt == 0) {
+            // the narrower plan tried on probation does not hold here: back to the one that worked, and wait twice
+            // as long before the next try
+            h->probing = false;
+            h->cooldown = std::min(h->cooldown * 2, 1 << 14);
+            if (h->probe_from == 0) { h->max_chunks = 1; h->want_chunks = 1; h->gave_up = true; }
+            else h->window_boost = h->probe_from;
+            continue;
+        }
+        if (attempt >= 3) {                                            // give up on windows: sequential filter
+            if (!h->gave_up) { h->saved_max_chunks = h->max_chunks; h->saved_want_chunks = h->want_chunks; h->gave_up = true; }
+            h->max_chunks = 1; h->want_chunks = 1;
+        } else {
+            h->window_boost *= 4;
+        }
+    }
+    // A widened plan is not for life: one slow-forgetting parameter vector in a line search would otherwise tax every
+    // later evaluation.  Every evaluation is checked, so narrowing on probation is safe -- a failure costs one retry.
+    if (attempt == 0 && !h->chunks_forced) {
+        h->calm++;
+        if (h->probing && h->calm >= 4) h->probing = false;           // the narrower plan holds
+        if (h->calm >= h->cooldown && (h->gave_up || h->window_boost > 1)) {
+            h->calm = 0;
+            h->probing = true;
+            if (h->gave_up) {
+                h->probe_from = 0;
+                h->max_chunks = h->saved_max_chunks; h->want_chunks = h->saved_want_chunks; h->gave_up = false;
+            } else {
+                h->probe_from = h->window_boost;
+                h->window_boost = std::max(1, h->window_boost / 2);
+            }
+        }
     }
     double pen = 0.0;
     int st;

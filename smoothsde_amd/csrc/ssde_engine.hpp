@@ -125,6 +125,11 @@ struct ssde_handle {
     int last_chunks = 1, last_window = 0;
     double last_check = 0.0;
     int n_retries = 0;
+    // recovery from a widened plan (ssde_eval): after `cooldown` evaluations accepted at the first try the boost is
+    // halved (or a given-up window plan restored) on probation; a failure on probation restores the level that worked
+    // and doubles the cooldown
+    int calm = 0, cooldown = 32, probe_from = 0, saved_max_chunks = 0, saved_want_chunks = 0;
+    bool probing = false, gave_up = false;
 
     // shared-covariance path
     DevBuf<int32_t> group_flags;

@@ -353,6 +353,40 @@ def test_short_overlap_is_detected_and_repaired(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("row_varying", [False, True])
+def test_widened_plan_recovers(row_varying):
+    """A warm-up widened after a failed hand-over check (here: through ssde_widen_windows) is not for life: after 32
+    evaluations accepted at the first try it is halved on probation, and again, until the planned length is back --
+    with every evaluation still checked.  Values do not move by more than rounding."""
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty
+    if row_varying:
+        ID, times, obs = simulate("CTCRW", 1, 6000, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=11)
+        B = bspline_basis((np.sin(np.arange(6000) * 0.01) + 1) / 2, 6)
+        pb = capi.Problem("CTCRW", ID, times, obs, X_re=[None, None, B, None], S_list=[second_difference_penalty(6)])
+        par = np.zeros(pb.n_par_full)
+        par[0] = np.log(0.05)
+    else:
+        ID, times, obs = simulate("CTCRW", 70, 6000, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=11)
+        pb = capi.Problem("CTCRW", ID, times, obs)
+        par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0])
+    eng = capi.Engine(pb)
+    v0, g0 = eng.eval(par)
+    eng.eval(par)
+    w0 = eng.info()["window"]
+    assert w0 > 0
+    eng.widen_windows(4)
+    eng.eval(par)
+    assert eng.info()["window"] >= 3 * w0
+    seen = set()
+    for k in range(80):
+        v, g = eng.eval(par)
+        seen.add(eng.info()["window"])
+        assert abs(v - v0) <= 1e-12 * abs(v0) and np.max(np.abs(g - g0)) <= 1e-9 * np.max(np.abs(g0))
+    assert eng.info()["window"] == w0, sorted(seen)
+    assert eng.info()["window_check"] <= capi.WINDOW_TOL
+    eng.close()
+
+
 def test_no_forgetting_falls_back_to_sequential():
     ID, times, obs = _long_tracks(M=70, T=2000)
     par = np.array([6.0, 0.0, 0.0, 0.5, 0.0])      # sigma_obs = 400: the filter barely updates
