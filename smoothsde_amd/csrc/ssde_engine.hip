@@ -1039,6 +1039,9 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
             else h->window_boost = h->probe_from;
             continue;
         }
+        // the row-varying path plans from the parameter ranges its pre-pass saw in the PREVIOUS evaluation: after a
+        // jump in the parameters the first retry needs no boost, just this evaluation's own ranges
+        if (h->path == PATH_TV && attempt == 0) continue;
         if (attempt >= 3) {                                            // give up on windows: sequential filter
             if (!h->gave_up) { h->saved_max_chunks = h->max_chunks; h->saved_want_chunks = h->want_chunks; h->gave_up = true; }
             h->max_chunks = 1; h->want_chunks = 1;
