@@ -125,6 +125,12 @@ int build(const ssde_desc* d, ssde_handle* h) {
     if (d->n < 2) return fail(h, SSDE_ERR_ARG, "need at least two rows");
     if (!d->id || !d->times || !d->obs || !d->ncol_fe) return fail(h, SSDE_ERR_ARG, "id/times/obs/ncol_fe must be non-NULL");
     h->model = d->model; h->d = d->n_dim; h->q = d->n_par; h->n = d->n;
+    if (const char* e = getenv("SSDE_WINDOW")) h->env_window = std::max(1, atoi(e));     // testing: deliberately short overlaps
+    if (const char* e = getenv("SSDE_TV_WAVES")) h->env_tv_waves = std::max(1, atoi(e));
+    if (const char* e = getenv("SSDE_TV_MINLEN")) h->env_tv_minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
+    if (const char* e = getenv("SSDE_T0_COST")) h->env_t0_cost = atof(e);
+    h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
+    h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
     h->sdim = state_dim(d->model, d->n_dim);
     h->na_any = d->na_mode == SSDE_NA_ANY_NAN;
     h->has_h = is_kalman(d->model) && d->h_array != nullptr;
@@ -607,7 +613,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     if (h->use_shared && h->model == SSDE_MODEL_CTCRW && rho > 0.97) return;
     W = (int)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
     W = std::max(W, 16);
-    if (const char* e = getenv("SSDE_WINDOW")) W = std::max(1, atoi(e));  // testing: deliberately short overlaps
+    if (h->env_window > 0) W = h->env_window;                             // testing: deliberately short overlaps
     if ((int64_t)W * h->window_boost > (int64_t)h->glen_max) return;     // longer than a track: sequential filter
     W *= h->window_boost;
     W = (W + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
@@ -786,7 +792,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         plan_windows(h, a, &a.n_chunks, &a.window);
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         a.chk_out = out_dev + (1 + L.n_full);
-        a.derive = getenv("SSDE_NO_DERIVE") ? 0 : 1;
+        a.derive = h->env_no_derive ? 0 : 1;
         a.nstate_clean = h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
         a.group_flags = h->group_flags.p;
@@ -820,8 +826,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         // the transient window (gain table, direction form) runs on the wave that owns window 1: that window is
         // shortened by what the transient rows cost, in stationary rows (SSDE_T0_COST x t0)
         {
-            double cost = 3.0;
-            if (const char* e = getenv("SSDE_T0_COST")) cost = atof(e);
+            const double cost = h->env_t0_cost;
             a.t0_delta = (int)(cost * a.t0 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         }
         h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
@@ -1008,7 +1013,7 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
     if (!h || !par || !value) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     std::vector<double> o(2 + h->L.n_full);
-    const bool use_graph = h->path == PATH_TV && !getenv("SSDE_NO_GRAPH");
+    const bool use_graph = h->path == PATH_TV && !h->env_no_graph;
     int attempt = 0;
     for (;; attempt++) {
         if (use_graph && h->tv_stats_valid) {

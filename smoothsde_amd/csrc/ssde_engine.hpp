@@ -125,6 +125,10 @@ struct ssde_handle {
     int last_chunks = 1, last_window = 0;
     double last_check = 0.0;
     int n_retries = 0;
+    // testing / tuning knobs, read once at create: nothing calls getenv per evaluation
+    int env_window = 0, env_tv_waves = 0, env_tv_minlen = 0;
+    bool env_no_derive = false, env_no_graph = false;
+    double env_t0_cost = 3.0;
     // recovery from a widened plan (ssde_eval): after `cooldown` evaluations accepted at the first try the boost is
     // halved (or a given-up window plan restored) on probation; a failure on probation restores the level that worked
     // and doubles the cooldown

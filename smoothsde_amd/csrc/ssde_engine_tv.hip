@@ -207,7 +207,7 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
         if (ok && rho < 0.9995) {
             int64_t w = (int64_t)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
             w = std::max<int64_t>(w, 16);
-            if (const char* e = getenv("SSDE_WINDOW")) w = std::max(1, atoi(e));
+            if (h->env_window > 0) w = h->env_window;
             w *= h->window_boost;
             w = (w + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
             if (2 * w <= h->glen_max) W = (int)w;
@@ -220,7 +220,7 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
     const int tpw = WAVE >> h->tv_lpt_shift;
     const int64_t n_packs = (h->n_seg + tpw - 1) / tpw;
     int target = 2048;
-    if (const char* e = getenv("SSDE_TV_WAVES")) target = std::max(1, atoi(e));
+    if (h->env_tv_waves > 0) target = h->env_tv_waves;
     const int nc_cap = (int)std::max<int64_t>(1, (target + n_packs * h->tv_nb - 1) / (n_packs * h->tv_nb));
     std::vector<TvItem> ig, iv;
     int max_nc = 1;
@@ -231,7 +231,7 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
         // shorter than its warm-up -- the redundant warm-up rows run in parallel, the serial chain of a wave
         // is what the evaluation waits for.  SSDE_TV_MINLEN: shortest scored stretch of a window (rows).
         int minlen = 2 * WIN_ALIGN;
-        if (const char* e = getenv("SSDE_TV_MINLEN")) minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
+        if (h->env_tv_minlen > 0) minlen = h->env_tv_minlen;
         if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + minlen - 1) / minlen));
         max_nc = std::max(max_nc, nc);
         for (int b = 0; b < h->tv_nb; b++)
