@@ -82,6 +82,37 @@ def _oracle(pb, par, **kw):
 
 @pytest.mark.parametrize("model,par", [
     ("CTCRW", [-1.0, 0.1, -0.1, 0.5, 0.2]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]), ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
+@pytest.mark.parametrize("row_varying", [False, True])
+def test_report_aest_all_ragged_batch(model, par, row_varying):
+    """REPORT(aest_all) (nllk_ctcrw.hpp:192-194, 246, 249) on 300 ragged tracks of 2-600 rows with missing rows, on
+    an irregular grid, with constant coefficients and with a covariate on par[d]: every row of the n x sdim matrix
+    against the oracle (rows the template never writes stay 0 in both)."""
+    rng = np.random.default_rng(13)
+    lens = rng.integers(2, 600, size=300)
+    ID = np.repeat(np.arange(300), lens).astype(float)
+    n = len(ID)
+    _, _, obs = simulate(model, 1, n, 2, seed=6)
+    times = np.cumsum(rng.uniform(0.5, 1.5, size=n))
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    obs[(rng.random(n) < 0.05) & ~first] = np.nan
+    q = capi.n_sde_par(model, 2)
+    X_fe = [None] * q
+    par = list(par)
+    if row_varying:
+        X_fe[2] = np.column_stack([np.ones(n), np.sin(np.arange(n) * 0.02)])
+        par = par[:4] + [0.3] + par[4:]
+    pb = capi.Problem(model, ID, times, obs, X_fe=X_fe)
+    eng = capi.Engine(pb)
+    aest = eng.report(np.array(par))
+    _, _, oaest = _oracle(pb, np.array(par), report=True)
+    assert aest.shape == oaest.shape == (n, pb.sdim)
+    scale = np.nanmax(np.abs(oaest))
+    assert np.allclose(aest, oaest, rtol=1e-10, atol=1e-10 * scale, equal_nan=True)
+    eng.close()
+
+
+@pytest.mark.parametrize("model,par", [
+    ("CTCRW", [-1.0, 0.1, -0.1, 0.5, 0.2]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]), ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
 def test_medium_batch_vs_oracle(model, par):
     """3000 ragged tracks (47 wavefronts, several TILE_U blocks), 5 % NA rows, irregular time grid"""
     rng = np.random.default_rng(11)
