@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""tools/chunk_probe.py -- how the value and the gradient of one batch (2000 tracks x 1e4 rows, 5 % missing rows) depend
+on the time-window plan: 1 window (sequential filter) against 6 / 12 / 32 windows, a longer warm-up, and without the
+derived variance direction.  One engine per child process (the knobs are read at create).  Result: DESIGN.md section 4,
+"Summation"."""
 import os, sys, numpy as np, torch, subprocess, json
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from smoothsde_amd import capi
 from smoothsde_amd.synth import simulate
 if len(sys.argv) > 1:
