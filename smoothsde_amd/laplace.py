@@ -76,10 +76,15 @@ class LaplaceObjective:
         H = None
         for _ in range(self.max_newton):
             H = self._hess_uu(theta, u)
+            # Away from the inner optimum the joint nllk need not be convex in u (a penalty with a null space leaves
+            # those directions to the data): shift an indefinite Hessian to positive definite for the STEP
+            # (Levenberg), so that the iteration keeps descending towards a minimum, where H itself is positive
+            w = np.linalg.eigvalsh(H)
+            Hs = H if w[0] > 1e-8 * max(1.0, abs(w[-1])) else H + (abs(w[0]) + 1e-3 * max(1.0, abs(w[-1]))) * np.eye(len(u))
             try:
-                step = np.linalg.solve(H, gu)
+                step = np.linalg.solve(Hs, gu)
             except np.linalg.LinAlgError:
-                step = np.linalg.lstsq(H, gu, rcond=None)[0]
+                step = np.linalg.lstsq(Hs, gu, rcond=None)[0]
             # backtracking: the joint is close to quadratic in u, a full step almost always passes
             t = 1.0
             for _ in range(20):

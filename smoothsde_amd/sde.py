@@ -84,9 +84,21 @@ def _parse_formula(form: str, data: Dict[str, np.ndarray], n: int) -> Design:
                 x = np.asarray(data[var], dtype=np.float64)
                 lo, hi = np.nanmin(x), np.nanmax(x)
                 xs = (x - lo) / (hi - lo) if hi > lo else np.zeros_like(x)
-                B = bspline_basis(xs, n_basis=k - 1)
-                X_re.append(B)
-                S.append(second_difference_penalty(k - 1))
+                # k B-splines with the sum-to-zero constraint absorbed as mgcv does (k - 1 columns): without it the
+                # columns add up to the intercept and the marginal likelihood is flat along that direction
+                B = bspline_basis(xs, n_basis=k)
+                Sk = second_difference_penalty(k)
+                Q, _ = np.linalg.qr(B.sum(axis=0)[:, None], mode="complete")
+                Z = Q[:, 1:]                                   # null space of the constraint 1'B c = 0
+                Sz = Z.T @ Sk @ Z
+                if re.search(r"bs\s*=\s*[\"'](ts|cs)[\"']", opts):
+                    # shrinkage smooths (the vignette's bs = "ts"): the penalty's null space gets a small eigenvalue
+                    w, V = np.linalg.eigh(0.5 * (Sz + Sz.T))
+                    pos = w > 1e-8 * w[-1]
+                    w = np.where(pos, w, 0.1 * w[pos].min())
+                    Sz = (V * w) @ V.T
+                X_re.append(B @ Z)
+                S.append(Sz)
                 names_re += [f"s({var}).{i + 1}" for i in range(k - 1)]
         else:
             if t not in data:
@@ -302,8 +314,14 @@ class SDE:
             self.tmb_obj_joint_ = TmbObj(self.engine_joint_, self._par_full(pbj), pbj.free_index())
         return self.tmb_obj_
 
-    def fit(self, silent=True, map=None, maxiter=200):
-        from scipy.optimize import minimize
+    def fit(self, silent=True, map=None, maxiter=200, optimizer="scipy", staged=True):
+        """optimizer = "scipy": scipy's BFGS; "optim": R's optim(method = "BFGS") restated (smoothsde_amd/optim.py, the
+        reference's own call, R/sde.R:694-697 -- pure backtracking from a unit step along -g, which on n >> 10^3 rows
+        first jumps to absurd log-scale values exactly as it does in R).
+        staged: with random effects, first fit the fixed effects alone (coeff_re = 0, log_lambda at its start) and
+        start the Laplace fit from there.  The reference starts the Laplace fit directly from par0 with
+        log_sigma_obs = 0; with a finite-difference Laplace layer that start is outside the region where the inner
+        problem is well conditioned."""
         if self.tmb_obj_ is None:
             self.setup(silent=silent, map=map)
         if self.problem_.n_smooth > 0 and not self.laplace_:
@@ -311,16 +329,51 @@ class SDE:
                           "parameters fixed (setup(laplace=False)); the default integrates them out (Laplace)")
         obj = self.tmb_obj_
         t0 = time.perf_counter()
-        res = minimize(obj.fn, obj.par, jac=obj.gr, method="BFGS", options=dict(maxiter=maxiter))  # optim(..., "BFGS")
-        self.out_ = dict(par=res.x, value=res.fun, counts=(res.nfev, res.njev), convergence=int(not res.success),
-                         message=res.message, systime=time.perf_counter() - t0)
+
+        def _minimise(fn, gr, x0):
+            if optimizer == "scipy":
+                from scipy.optimize import minimize
+                r = minimize(fn, x0, jac=gr, method="BFGS", options=dict(maxiter=maxiter))
+                return dict(par=r.x, value=r.fun, counts=(r.nfev, r.njev), convergence=int(not r.success), message=r.message)
+            from .optim import optim_bfgs
+            out = optim_bfgs(fn, gr, x0, maxit=maxiter)
+            out["message"] = None
+            return out
+
+        if self.laplace_ and staged:
+            pbk = self.problem_
+            not_lam = np.array([not (pbk.off_lambda <= k < pbk.off_lambda + pbk.n_smooth) for k in obj.io])
+            if not_lam.any():
+                u0 = np.zeros(len(obj.ir))
+                memo = {}
+
+                def _j1(x):
+                    key = x.tobytes()
+                    if key not in memo:
+                        memo.clear()
+                        th = obj.par.copy()
+                        th[not_lam] = x
+                        v, g = obj.joint(obj._full(th, u0))
+                        memo[key] = (v, g[obj.io][not_lam])
+                    return memo[key]
+                r1 = _minimise(lambda x: _j1(np.asarray(x, dtype=np.float64))[0],
+                               lambda x: _j1(np.asarray(x, dtype=np.float64))[1], obj.par[not_lam].copy())
+                if np.isfinite(r1["value"]):
+                    obj.par[not_lam] = r1["par"]
+                    obj.u_hat = u0.copy()
+        if optimizer not in ("scipy", "optim"):
+            raise ValueError("optimizer must be 'scipy' or 'optim'")
+        self.out_ = _minimise(obj.fn, obj.gr, obj.par)
+        self.out_["systime"] = time.perf_counter() - t0
+
+        xhat = np.asarray(self.out_["par"], dtype=np.float64)
         full = obj.par_full.copy()
         if self.laplace_:
-            full[obj.io] = res.x
-            obj.fn(res.x)
+            full[obj.io] = xhat
+            obj.fn(xhat)
             full[obj.ir] = obj.u_hat
         else:
-            full[obj.free] = res.x
+            full[obj.free] = xhat
         pb = self.problem_
         self.par_full_ = full
         self.tmb_rep_ = None

@@ -85,3 +85,20 @@ def test_design_objects_are_accepted():
     sde = SDE(formulas={"mu": des, "sigma": "~1"}, data=d, type="BM", response="Z")
     assert len(sde.coeff_fe()) == 3 and len(sde.coeff_re()) == 3 and len(sde.lambda_()) == 1
     assert np.allclose(sde.par()["sigma"], 1.0)
+
+
+def test_optim_bfgs_reproduces_r_documented_example():
+    """`optim(c(-1.2, 1), fr, grr, method = "BFGS")` of R's ?optim (the Rosenbrock banana with its gradient): R prints
+    $value 9.594956e-18 and $counts function 110, gradient 43 -- the restated vmmin must walk the same path."""
+    from smoothsde_amd.optim import optim_bfgs
+    fr = lambda x: 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+    grr = lambda x: np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)])
+    r = optim_bfgs(fr, grr, [-1.2, 1.0])
+    assert r["counts"] == (110, 43) and r["convergence"] == 0
+    assert abs(r["value"] - 9.594956e-18) < 1e-23
+    assert np.allclose(r["par"], [1.0, 1.0], atol=1e-7)
+    # a non-finite region is backed away from, never entered (accpoint needs a finite value)
+    f2 = lambda x: np.inf if x[0] < -3 else (x[0] - 1) ** 2 + np.exp(x[1]) - x[1]
+    g2 = lambda x: np.array([2 * (x[0] - 1), np.exp(x[1]) - 1])
+    r2 = optim_bfgs(f2, g2, [50.0, 8.0])
+    assert r2["convergence"] == 0 and np.allclose(r2["par"], [1.0, 0.0], atol=1e-6)
