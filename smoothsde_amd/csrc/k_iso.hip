@@ -2,7 +2,7 @@
 //
 // One wavefront lane = one track; a workgroup is ONE wave (64 lanes).  State, covariance and
 // all forward sensitivities stay in VGPRs; observations stream from the tiled HBM layout
-// (ssde_device.hpp) with coalesced 512-B wave loads, prefetched one TILE_U-step block ahead
+// (ssde_device.hpp) with coalesced 512-B wave loads, prefetched one ISO_U-step block ahead
 // into registers.  fp64 throughout, no MFMA: per lane the recursion is a serial chain of
 // scalar fp64 FMAs, so the kernel is bound by fp64 VALU issue, and a lone wave on a SIMD can
 // only issue every other fp64 slot.  A 10^4-track batch is just 157 waves for 1024 SIMDs, so
@@ -29,11 +29,19 @@
 
 namespace ssde {
 
+// Steps per prefetch block of THIS kernel (the tiles are padded to TILE_U = 4 rows and end with 64 spare rows; windows
+// are multiples of 16 rows): the look-ahead is one block, so the block length is the distance the loads lead by.
+#ifndef SSDE_ISO_U
+#define SSDE_ISO_U 4
+#endif
+constexpr int ISO_U = SSDE_ISO_U;
+static_assert(ISO_U % TILE_U == 0 && WIN_ALIGN % (2 * ISO_U) == 0 && 3 * ISO_U <= TILE_SPARE, "prefetch block");
+
 // register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
 template <int C>
-__device__ __forceinline__ void load_block(double (&dst)[TILE_U][C], const double* p, int Cr, int c_obs) {
+__device__ __forceinline__ void load_block(double (&dst)[ISO_U][C], const double* p, int Cr, int c_obs) {
 #pragma unroll
-    for (int u = 0; u < TILE_U; u++) {
+    for (int u = 0; u < ISO_U; u++) {
         dst[u][0] = 0.0;
         if (c_obs) dst[u][0] = p[(u * Cr) * WAVE];
 #pragma unroll
@@ -153,7 +161,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     ns_min = __builtin_amdgcn_readfirstlane(ns_min);
 
     // two register blocks in ping-pong: while one is consumed the other is in flight (no copies)
-    double bufA[TILE_U][C], bufB[TILE_U][C];
+    double bufA[ISO_U][C], bufB[ISO_U][C];
     load_block<C>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
     if (s_begin == 0) {
         double a0[SD];
@@ -164,13 +172,13 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         Ops::warm_init(S, &bufA[0][1], A);
     }
 
-    auto run_block = [&](const double (&blk)[TILE_U][C], int s0) {
-        if (s0 + TILE_U <= ns_min) {          // every lane's track covers the block: no per-row predication
+    auto run_block = [&](const double (&blk)[ISO_U][C], int s0) {
+        if (s0 + ISO_U <= ns_min) {          // every lane's track covers the block: no per-row predication
 #pragma unroll
-            for (int u = 0; u < TILE_U; u++) Ops::step(S, tr, A, uni, mu, blk[u]);
+            for (int u = 0; u < ISO_U; u++) Ops::step(S, tr, A, uni, mu, blk[u]);
         } else {
 #pragma unroll
-            for (int u = 0; u < TILE_U; u++)
+            for (int u = 0; u < ISO_U; u++)
                 if (s0 + u < ns) Ops::step(S, tr, A, uni, mu, blk[u]);
         }
     };
@@ -186,15 +194,15 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
             S.reset_acc();
         }
     };
-    for (int s0 = s_begin; s0 < s_end; s0 += 2 * TILE_U) {
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * ISO_U) {
         // TILE_SPARE keeps the look-ahead loads inside the allocation
-        load_block<C>(bufB, base + (int64_t)(s0 + TILE_U) * Cr * WAVE, Cr, c_obs);
+        load_block<C>(bufB, base + (int64_t)(s0 + ISO_U) * Cr * WAVE, Cr, c_obs);
         handover(s0);
         run_block(bufA, s0);
-        load_block<C>(bufA, base + (int64_t)(s0 + 2 * TILE_U) * Cr * WAVE, Cr, c_obs);
-        if (s0 + TILE_U < s_end) {
-            handover(s0 + TILE_U);
-            run_block(bufB, s0 + TILE_U);
+        load_block<C>(bufA, base + (int64_t)(s0 + 2 * ISO_U) * Cr * WAVE, Cr, c_obs);
+        if (s0 + ISO_U < s_end) {
+            handover(s0 + ISO_U);
+            run_block(bufB, s0 + ISO_U);
         }
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
