@@ -242,6 +242,27 @@ int build(const ssde_desc* d, ssde_handle* h) {
     if (d->a0 && d->n_seg != h->n_seg) return fail(h, SSDE_ERR_ARG, "a0 rows do not match the number of ID segments");
     h->n_steps = n - h->n_seg;
     starts.push_back(n);
+    if (is_kalman(d->model)) {
+        // a track of one row is initialised and never stepped: the kernels have no lane for it, but the reference's
+        // aest_all carries its initial state (a0 row, or the default of R/sde.R:576-580: first observation, velocity 0)
+        for (int64_t seg = 0; seg < h->n_seg; seg++) {
+            if (starts[seg + 1] - starts[seg] != 1) continue;
+            const int64_t row = starts[seg];
+            h->single_rows.push_back(row);
+            for (int c = 0; c < h->sdim; c++) {
+                double v = 0.0;
+                if (d->a0) {
+                    v = d->a0[seg + (int64_t)c * h->n_seg];
+                } else if (d->model != SSDE_MODEL_CTCRW || c % 2 == 0) {
+                    const int a = d->model == SSDE_MODEL_CTCRW ? c / 2 : c;
+                    const double* src = d->obs + row + (int64_t)a * n;
+                    if (on_dev) HIPCHK(h, hipMemcpy(&v, src, 8, hipMemcpyDeviceToHost));
+                    else v = *src;
+                }
+                h->single_a0.push_back(v);
+            }
+        }
+    }
 
     HIPCHK(h, h->out.alloc(2 + h->L.n_full));
     HIPCHK(h, hipEventCreate(&h->ev_k0));
@@ -1083,6 +1104,13 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
     return st;
 }
 
+namespace {
+void fill_single_rows(const ssde_handle* h, double* aest_all) {
+    for (size_t k = 0; k < h->single_rows.size(); k++)
+        for (int c = 0; c < h->sdim; c++) aest_all[h->single_rows[k] + (int64_t)c * h->n] = h->single_a0[k * h->sdim + c];
+}
+}  // namespace
+
 int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* aest_all) {
     if (!h || !par || !aest_all) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
@@ -1112,6 +1140,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
         HIPCHK(h, launch_tv_prepare(a, 0));
         HIPCHK(h, launch_tv_filter(a, false, 0));
         HIPCHK(h, hipMemcpy(aest_all, rep.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
+        fill_single_rows(h, aest_all);
         h->tv_stats_valid = false;                   // the stats buffer now describes this parameter vector
         ib.release(); rep.release();
         return SSDE_OK;
@@ -1141,6 +1170,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = h->n;
     HIPCHK(h, launch_dense(a, false, 0));
     HIPCHK(h, hipMemcpy(aest_all, rep.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
+    fill_single_rows(h, aest_all);
     rep.release(); pbuf.release(); stb.release();
     return SSDE_OK;
 }

@@ -139,6 +139,9 @@ struct ssde_handle {
     DevBuf<int32_t> group_flags;
     int n_clean_groups = 0;
     bool use_shared = false;
+    // one-row tracks never reach a kernel; REPORT(aest_all) still shows their a0 (nllk_ctcrw.hpp:196-200, 246)
+    std::vector<int64_t> single_rows;
+    std::vector<double> single_a0;       // [single_rows.size()][sdim]
     std::vector<std::pair<int, int64_t>> clean_ns_hist;  // (scored rows, number of tracks) over NaN-free groups
     DevBuf<double> gain_ring;
     double* gain_pinned = nullptr;

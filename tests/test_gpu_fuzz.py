@@ -136,6 +136,12 @@ def test_random_problem_matches_oracle(seed):
         assert np.all(grad[pb.par_fixed != 0] == 0.0)
         v0 = eng.eval(par, order=0)
         assert abs(v0 - val) <= 1e-12 * max(1.0, abs(val)), ctx
+        if pb.model in ("CTCRW", "OU_SSM", "BM_SSM"):        # REPORT(aest_all), one-row tracks and user a0 included
+            from oracle_lib import oracle_eval
+            aest = eng.report(par)
+            _, _, oaest = oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4, report=True)
+            sc = max(1.0, np.nanmax(np.abs(oaest)))
+            assert aest.shape == oaest.shape and np.allclose(aest, oaest, rtol=1e-9, atol=1e-9 * sc, equal_nan=True), ctx
     eng.close()
 
 

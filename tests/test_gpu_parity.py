@@ -89,6 +89,7 @@ def test_report_aest_all_ragged_batch(model, par, row_varying):
     against the oracle (rows the template never writes stay 0 in both)."""
     rng = np.random.default_rng(13)
     lens = rng.integers(2, 600, size=300)
+    lens[::17] = 1                      # one-row tracks: initialised, never stepped, still reported (their a0)
     ID = np.repeat(np.arange(300), lens).astype(float)
     n = len(ID)
     _, _, obs = simulate(model, 1, n, 2, seed=6)
@@ -101,7 +102,10 @@ def test_report_aest_all_ragged_batch(model, par, row_varying):
     if row_varying:
         X_fe[2] = np.column_stack([np.ones(n), np.sin(np.arange(n) * 0.02)])
         par = par[:4] + [0.3] + par[4:]
-    pb = capi.Problem(model, ID, times, obs, X_fe=X_fe)
+    kw = {}
+    if row_varying:                     # ... and with a user-supplied a0 (one row per ID segment, R/sde.R:574)
+        kw["a0"] = rng.standard_normal((300, capi.state_dim(model, 2)))
+    pb = capi.Problem(model, ID, times, obs, X_fe=X_fe, **kw)
     eng = capi.Engine(pb)
     aest = eng.report(np.array(par))
     _, _, oaest = _oracle(pb, np.array(par), report=True)
