@@ -142,6 +142,22 @@ def test_random_problem_matches_oracle(seed):
             _, _, oaest = oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4, report=True)
             sc = max(1.0, np.nanmax(np.abs(oaest)))
             assert aest.shape == oaest.shape and np.allclose(aest, oaest, rtol=1e-9, atol=1e-9 * sc, equal_nan=True), ctx
+        d = pb.desc()
+        if (pb.model in ("BM", "OU", "BM_SSM", "OU_SSM", "CTCRW") and not (d.h_array or d.p0 or d.a0) and
+                all(x is None for x in pb.X_fe) and not getattr(pb, "n_decay", 0)):
+            # the same problem handed over as HBM-resident tensors (SSDE_FLAG_DEVICE_DATA, what bench.py does): bitwise
+            import torch
+            dev = "cuda:0"
+            X_re = None
+            if any(x is not None for x in pb.X_re):
+                X_re = [None if x is None else torch.tensor(np.ascontiguousarray(x), device=dev) for x in pb.X_re]
+            pbd = capi.Problem.from_torch(pb.model, torch.tensor(pb.id, device=dev), torch.tensor(pb.times, device=dev),
+                                          torch.tensor(pb.obs, device=dev), par_fixed=pb.par_fixed, na_mode=pb.na_mode,
+                                          X_re=X_re, S_list=pb.S_list or None)
+            ed = capi.Engine(pbd)
+            vd, gd = ed.eval(par, order=1)
+            ed.close()
+            assert vd == val and np.array_equal(gd, grad), ctx
     eng.close()
 
 
