@@ -69,3 +69,14 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace(
                     "oracle/ is test", "").replace("under oracle/", ""), os.path.join(dirpath, f)
+
+
+def test_scripts_compile():
+    """bench.py, __graft_entry__.py and every tools/*.py at least parse (they only run on the GPU box)."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(files) > 8
+    for f in files:
+        py_compile.compile(f, doraise=True)
