@@ -229,6 +229,11 @@ int ssde_report(ssde_handle *h, const double *par, int32_t n_par_full, double *a
  * (factor <= 0: force one sequential window). */
 int ssde_widen_windows(ssde_handle *h, int32_t factor);
 
+/* Halve that multiplier again (never below 1).  ssde_eval does this by itself after 32 evaluations accepted at the
+ * first try; asynchronous callers that re-evaluate after ssde_widen_windows use this for the same policy.  Every
+ * evaluation is checked, so a narrower overlap that does not hold shows in window_check. */
+int ssde_relax_windows(ssde_handle *h);
+
 int ssde_info(const ssde_handle *h, ssde_info_t *info);
 
 void ssde_destroy(ssde_handle *h);

@@ -449,6 +449,8 @@ def load_library():
     lib.ssde_report.restype = C.c_int
     lib.ssde_widen_windows.argtypes = [C.c_void_p, C.c_int32]
     lib.ssde_widen_windows.restype = C.c_int
+    lib.ssde_relax_windows.argtypes = [C.c_void_p]
+    lib.ssde_relax_windows.restype = C.c_int
     lib.ssde_info.argtypes = [C.c_void_p, C.POINTER(SsdeInfo)]
     lib.ssde_info.restype = C.c_int
     lib.ssde_destroy.argtypes = [C.c_void_p]
@@ -465,7 +467,7 @@ def load_library():
 
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
-EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows",
+EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
                     "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version")
 
 
@@ -509,6 +511,9 @@ class Engine:
 
     def widen_windows(self, factor: int = 4):
         self._check(self.lib.ssde_widen_windows(self._h, factor))
+
+    def relax_windows(self):
+        self._check(self.lib.ssde_relax_windows(self._h))
 
     def eval_device(self, par, out_ptr: int, order: int = 1, stream: int = 0):
         """Asynchronous evaluation of the data term into an HBM buffer of 2+n_par_full doubles:

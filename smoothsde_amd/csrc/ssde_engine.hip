@@ -1182,6 +1182,12 @@ int ssde_widen_windows(ssde_handle* h, int32_t factor) {
     return SSDE_OK;
 }
 
+int ssde_relax_windows(ssde_handle* h) {
+    if (!h) return SSDE_ERR_ARG;
+    h->window_boost = std::max(1, h->window_boost / 2);
+    return SSDE_OK;
+}
+
 int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     if (!h || !info) return SSDE_ERR_ARG;
     memset(info, 0, sizeof(*info));

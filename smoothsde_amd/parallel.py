@@ -36,9 +36,16 @@ class ShardedObjective:
     """
 
     def __init__(self, local_eval: Callable, n_par_full: int, penalty: Optional[Callable] = None, group=None,
-                 on_window_failure: Optional[Callable] = None, window_tol: float = 1e-11):
+                 on_window_failure: Optional[Callable] = None, window_tol: float = 1e-11,
+                 on_window_calm: Optional[Callable] = None, cooldown: int = 32, relax_per_widen: int = 2):
+        """on_window_failure: widen the warm-up (Engine.widen_windows) before the re-evaluation;
+        on_window_calm: narrow it again (Engine.relax_windows) after `cooldown` evaluations accepted at the first
+        try -- ssde_eval's own policy, taken identically on every rank because every rank sees the reduced check."""
         self.local_eval, self.n_par_full, self.penalty = local_eval, n_par_full, penalty
         self.group, self.on_window_failure, self.window_tol = group, on_window_failure, window_tol
+        self.on_window_calm, self.cooldown = on_window_calm, cooldown
+        self.relax_per_widen = relax_per_widen      # widen_windows(4) is undone by two relax_windows() (halvings)
+        self._calm, self._widened = 0, 0
 
     def eval(self, par):
         import torch.distributed as dist
@@ -53,6 +60,15 @@ class ShardedObjective:
             if res[-1] <= self.window_tol * world or self.on_window_failure is None:
                 break
             self.on_window_failure()
+            self._widened += self.relax_per_widen
+        if attempt == 0:
+            self._calm += 1
+            if self._widened > 0 and self.on_window_calm is not None and self._calm >= self.cooldown:
+                self.on_window_calm()
+                self._calm, self._widened = 0, self._widened - 1
+        else:
+            self._calm = 0
+            self.cooldown = min(2 * self.cooldown, 1 << 14)
         value, grad = float(res[0]), res[1:1 + self.n_par_full].copy()
         if self.penalty is not None:
             pv, pg = self.penalty(par)

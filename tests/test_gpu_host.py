@@ -103,7 +103,8 @@ def test_sharded_objective_single_rank_on_device():
         eng.eval_device(par, out.data_ptr(), order=1, stream=torch.cuda.current_stream().cuda_stream)
         return out
 
-    obj = ShardedObjective(local_eval, pb.n_par_full, lambda p: eng.penalty(p), on_window_failure=eng.widen_windows)
+    obj = ShardedObjective(local_eval, pb.n_par_full, lambda p: eng.penalty(p), on_window_failure=eng.widen_windows,
+                           on_window_calm=eng.relax_windows)
     par = np.array([-1.0, 0.0, 0.1, 0.4, 0.0])
     v, g = obj.eval(par)
     v2, g2 = eng.eval(par)

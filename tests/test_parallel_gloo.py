@@ -84,3 +84,40 @@ def test_two_rank_gloo_matches_single_process():
     for rank, val, grad in res:
         assert abs(val - rec["expected"]["value"]) <= 1e-11 * abs(rec["expected"]["value"])
         assert np.max(np.abs(grad - rec["expected"]["grad"])) <= 1e-10 * np.max(np.abs(rec["expected"]["grad"]))
+
+
+def test_sharded_objective_widens_and_relaxes():
+    """Window policy of the sharded objective (single process, injected local evaluation): a failed hand-over check
+    calls on_window_failure and re-evaluates; after `cooldown` evaluations accepted at the first try on_window_calm is
+    called once per earlier widening; a failure doubles the cooldown."""
+    import torch
+    from smoothsde_amd.parallel import ShardedObjective
+    state = dict(boost=1, calls=0, fail_next=False)
+
+    def local_eval(par):
+        state["calls"] += 1
+        bad = state["fail_next"] and state["boost"] == 1
+        return torch.tensor([1.0 + par[0], 2.0, 1e-3 if bad else 1e-14], dtype=torch.float64)
+
+    def widen():
+        state["boost"] *= 4
+
+    def relax():
+        state["boost"] = max(1, state["boost"] // 2)
+
+    obj = ShardedObjective(local_eval, 1, None, on_window_failure=widen, on_window_calm=relax, cooldown=5)
+    state["fail_next"] = True
+    v, g = obj.eval(np.array([0.5]))
+    assert v == 1.5 and state["boost"] == 4 and state["calls"] == 2 and obj.cooldown == 10
+    state["fail_next"] = False
+    for k in range(9):
+        obj.eval(np.array([0.5]))
+    assert state["boost"] == 4
+    obj.eval(np.array([0.5]))                       # the 10th clean evaluation: one halving back
+    assert state["boost"] == 2 and obj._widened == 1
+    for k in range(10):
+        obj.eval(np.array([0.5]))
+    assert state["boost"] == 1 and obj._widened == 0
+    for k in range(30):
+        obj.eval(np.array([0.5]))
+    assert state["boost"] == 1                      # nothing more to undo
