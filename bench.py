@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- track-timesteps/s of one nllk + gradient evaluation (BASELINE.json metric).
 
-A "step" is one evaluation of the hot path (value + full gradient, one ssde_eval_device, the
-RCCL all-reduce of the 1+p doubles when N > 1, and the D2H of the result) over one resident
-batch of synthetic tracks, each step at a different parameter vector.  Workload at every N:
-10^4 two-dimensional CTCRW tracks x 10^4 rows PER GPU (constant coefficients, sigma_obs free,
-mu fixed as in the vignette) -- weak scaling: tracks shard over ranks with no data-path
-collective other than the scalar all-reduce.
+A "step" is one synchronous evaluation of the hot path through the C ABI (ssde_eval, order 1: value + full
+gradient, the hand-over check of the time windows, the reduction, at N > 1 the in-engine ncclAllReduce of the
+2 + p doubles over xGMI, and the D2H of the result) over one resident batch of synthetic tracks, each step at a
+different parameter vector (the engine memoises the last one).  Workload at every N: 10^4 two-dimensional CTCRW
+tracks x 10^4 rows PER GPU (constant coefficients, sigma_obs free, mu fixed as in the vignette) -- weak scaling:
+tracks shard over ranks with no data-path collective other than that all-reduce.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+One process per GPU; the ranks' engines are joined by ssde_comm_init_rank (the ncclUniqueId travels over a gloo
+group, which also carries the barriers and the max-over-ranks of the elapsed time: torch.distributed is plumbing
+here, the collective of the data path is the engine's own).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -82,6 +85,76 @@ def cpu_baseline(seconds_target=15.0):
                       f"oracle/liboracle.so (g++ -O2, {cores} threads over track shards)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run) and relay rank 0's JSON line.  This parent never imports torch and never touches a GPU."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    sys.exit(proc.returncode if proc.returncode else (0 if line else 1))
+
+
+def theta_for(npar, d, q, k):
+    base = np.zeros(npar)
+    base[0] = np.log(0.1)            # log sigma_obs
+    base[1 + d] = np.log(2.0)        # log tau (log sigma for BM_SSM)
+    if q > d + 1:
+        base[2 + d] = 0.0            # log nu / log kappa
+    return base + 0.01 * np.sin(np.arange(npar) + 0.7 * k)
+
+
+def secondary_workload(name, model, M, T, dev, steps, mutate):
+    """The same batch shape with what real data have -- an irregular time grid, missing rows -- so that the driver's
+    run times the general per-lane kernel too (BASELINE's metric configuration is the engine's best case)."""
+    import torch
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import simulate
+    d = 2
+    ID, times, obs = simulate(model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=11,
+                              backend="torch", device=dev)
+    times, obs = mutate(ID, times, obs)
+    q = capi.n_sde_par(model, d)
+    fixed = np.zeros(1 + q, dtype=np.uint8)
+    fixed[1:1 + d] = 1
+    eng = capi.Engine(capi.Problem.from_torch(model, ID, times, obs, par_fixed=fixed))
+    del ID, times, obs
+    npar = 1 + q
+    for k in range(2):
+        eng.eval(theta_for(npar, d, q, -1 - k))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kms, chk = [], 0.0
+    for k in range(steps):
+        eng.eval(theta_for(npar, d, q, k))
+        inf = eng.info()
+        kms.append(inf["main_kernel_ms"])
+        chk = max(chk, inf["window_check"])
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    rows = inf["n_rows"]
+    eng.close()
+    kern = float(np.mean(kms))
+    return {"workload": name, "value": rows * steps / el, "unit": "track-timesteps/s", "steps": steps,
+            "ms_per_step": 1e3 * el / steps, "kernel_ms": kern,
+            "required_bytes_per_row": inf["required_bytes_per_row"],
+            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "window_check_max": chk, "window_retries": inf["window_retries"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +164,11 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000, help="rows per track")
     ap.add_argument("--model", default="CTCRW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the irregular-grid / missing-row workloads")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # before anything touches the GPU (the children are fresh processes)
 
     import torch
     import torch.distributed as dist
@@ -99,25 +176,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if args.gpus > 1 and world == 1:
-            sys.exit(2)
-    # rehearsal on a one-GPU box (never used by the driver): SSDE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
-    # SSDE_BENCH_BACKEND=gloo carries the all-reduce (RCCL refuses two ranks on one device)
-    if os.environ.get("SSDE_BENCH_SHARE_GPU"):
-        local_rank = 0
-    backend = os.environ.get("SSDE_BENCH_BACKEND", "nccl")
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # plumbing: id exchange, barriers, max of the clock
 
     from smoothsde_amd import capi
     from smoothsde_amd.synth import simulate
@@ -132,103 +197,79 @@ def main():
     pb = capi.Problem.from_torch(args.model, ID, times, obs, par_fixed=fixed)
     eng = capi.Engine(pb)
     del ID, times, obs
-    info = eng.info()
     npar = pb.n_par_full
-    out = torch.zeros(2 + npar, dtype=torch.float64, device=dev)  # [nllk, grad..., window_check]
-    stream = torch.cuda.current_stream(dev)
-    out_pinned = torch.zeros(2 + npar, dtype=torch.float64).pin_memory()
+    if world > 1:
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(world, rank, box[0])                # ncclCommInitRank: the engines of all ranks, one communicator
 
-    def theta(k):
-        base = np.zeros(npar)
-        base[0] = np.log(0.1)            # log sigma_obs
-        base[1 + d] = np.log(2.0)        # log tau
-        if q > d + 1:
-            base[2 + d] = 0.0            # log nu
-        return base + 0.01 * np.sin(np.arange(npar) + 0.7 * k)
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    host_enqueue_s = []
-
-    thetas = {k: theta(k) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
-
-    # N = 1: the synchronous C-ABI call the reference's fn/gr pair maps to (ssde_eval: kernels, hand-over check,
-    # reduction, result in host memory when it returns).  N > 1: ssde_eval_device + RCCL all-reduce + D2H.
-    sync_api = world == 1 and not os.environ.get("SSDE_BENCH_ASYNC")
-
-    last_info = [None]
-    d2h_blocking = os.environ.get("SSDE_BENCH_D2H", "blocking") == "blocking"   # ("pinned": async copy + stream sync, 2-3 % slower)
-
-    def step(k, events=None, force_async=False):
-        th = thetas[k]
-        if sync_api and not force_async:
-            val, grad = eng.eval(th, order=1)
-            last_info[0] = eng.info()
-            return np.concatenate([[val], grad, [last_info[0]["window_check"]]])
-        if events:
-            events[0].record(stream)
-        t_h = time.perf_counter()
-        eng.eval_device(th, out.data_ptr(), order=1, stream=stream.cuda_stream)
-        host_enqueue_s.append(time.perf_counter() - t_h)
-        if events:
-            events[1].record(stream)
-        if world > 1:
-            dist.all_reduce(out)          # RCCL sum of [nllk, grad] over xGMI: 1+p doubles
-        if d2h_blocking:
-            return out.cpu().numpy()                 # blocking D2H (one hipMemcpy, its own synchronisation)
-        out_pinned.copy_(out, non_blocking=True)   # D2H of the result into pinned memory ...
-        stream.synchronize()                         # ... and the one synchronisation of the step
-        return out_pinned.numpy().copy()
+    thetas = {k: theta_for(npar, d, q, k) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
 
     for k in range(args.warmup):
-        res = step(-1 - k)
-        for _ in range(4):  # overlapping time windows must agree (k_iso.hip); widen the overlap if not
-            if res[-1] <= capi.WINDOW_TOL * world or os.environ.get("SSDE_DIAG_TIMING_ONLY"):
-                break
-            eng.widen_windows(4)
-            res = step(-1 - k)
+        eng.eval(thetas[-1 - k], order=1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    main_ms = []
+    main_ms, check_max = [], 0.0
     for k in range(args.steps):
-        res = step(k, None if sync_api else ev[k])
-        main_ms.append((last_info[0] if sync_api else eng.info())["main_kernel_ms"])   # HIP events around the dominant kernel, on its own stream
+        val, grad = eng.eval(thetas[k], order=1)          # ssde_eval: kernels, check, reduction, all-reduce, D2H
+        inf = eng.info()
+        main_ms.append(inf["main_kernel_ms"])             # HIP events around the dominant kernel, on its own stream
+        check_max = max(check_max, inf["window_check"])  # every timed step's hand-over check, not just the last one
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    if sync_api:   # GPU time of a whole evaluation: the same evaluations again, asynchronously, between HIP events
-        for k in range(args.steps):
-            step(k, ev[k], force_async=True)
-        torch.cuda.synchronize(dev)
-    if not os.environ.get("SSDE_DIAG_TIMING_ONLY"):   # (timing-only diagnostic kernels produce wrong numbers)
-        assert np.all(np.isfinite(res)), res
-        assert res[-1] <= capi.WINDOW_TOL * world, f"window hand-over check failed: {res[-1]}"
     info = eng.info()
+    assert np.isfinite(val) and np.all(np.isfinite(grad)), (val, grad)
+    assert check_max <= capi.WINDOW_TOL, f"window hand-over check failed: {check_max}"
+    assert info["n_memo_hits"] == 0, "a timed step was answered from the memo"
+
+    # GPU span of a whole evaluation: the same evaluations again, asynchronously, between HIP events (N = 1 only)
+    eval_ms = host_enq_ms = None
+    if world == 1:
+        out = torch.zeros(2 + npar, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        enq = []
+        for k in range(args.steps):
+            ev[k][0].record(stream)
+            t_h = time.perf_counter()
+            eng.eval_device(thetas[k], out.data_ptr(), order=1, stream=stream.cuda_stream)
+            enq.append(time.perf_counter() - t_h)
+            ev[k][1].record(stream)
+        torch.cuda.synchronize(dev)
+        eval_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        host_enq_ms = 1e3 * float(np.mean(enq))
 
     rows_per_gpu = info["n_rows"]
     total_rows = rows_per_gpu * world
     value = total_rows * args.steps / elapsed
-    eval_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # all kernels of one evaluation
     kern_ms = float(np.mean(main_ms))                                   # the dominant kernel alone
-    algo_bytes = info["algo_bytes_per_row"] * info["main_kernel_rows"]  # bytes of the rows that launch scores
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    eval_achieved = info["algo_bytes_per_row"] * rows_per_gpu / (eval_ms * 1e-3) / 1e9
-    traffic = traffic_eval = None
+    # Bytes of the rows that launch scores.  `required`: what the resident layout has to read (the `times` stream is
+    # not even stored on a globally regular grid: 16 of the 24 algorithmic B/row) -- the honest numerator of a
+    # fraction of peak.  `algorithmic`: SURVEY 8(d)'s 24 B/row, kept for comparison; it can exceed the peak
+    # precisely because 8 of those bytes are never moved.
+    req_bytes = info["required_bytes_per_row"] * info["main_kernel_rows"]
+    algo_bytes = info["algo_bytes_per_row"] * info["main_kernel_rows"]
+    achieved = req_bytes / (kern_ms * 1e-3) / 1e9
+    achieved_algo = algo_bytes / (kern_ms * 1e-3) / 1e9
+    profiled = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            traffic = pj.get("main_kernel_bytes")          # PMC bytes of the dominant kernel (profiles/pmc_latest.json)
-            traffic_eval = pj.get("hbm_bytes_per_launch")  # ... and of all kernels of one evaluation
+            profiled = {"main_kernel_bytes": pj.get("main_kernel_bytes"), "evaluation_bytes": pj.get("hbm_bytes_per_launch"),
+                        "source": "profiles/pmc_latest.json", "tag": pj.get("tag"),
+                        "note": "PMC counters of an EARLIER rocprofv3 --pmc run of this command (committed profile), "
+                                "not measured in this run"}
         except Exception:
-            traffic = None
+            profiled = None
     line = {
         "metric": "track-timesteps/s nllk+grad",
         "value": value, "unit": "track-timesteps/s",
@@ -242,21 +283,52 @@ def main():
                    "engine_path": capi.PATH_NAMES[info["path"]],
                    "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
                    "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
-                   "window_check": float(res[-1]), "parallelism": f"tracks x{world}"},
+                   "window_check": check_max, "window_retries": info["window_retries"],
+                   "parallelism": f"tracks x{world}" + (", in-engine ncclAllReduce of 2+p doubles" if world > 1 else ""),
+                   "api": "ssde_eval (synchronous C ABI call)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": profiled,
+                     "required_bytes_per_row": info["required_bytes_per_row"],
+                     "algo_bytes_per_row": info["algo_bytes_per_row"],
+                     "achieved_algorithmic": achieved_algo, "frac_algorithmic": achieved_algo / HBM_PEAK_GBS,
                      "kernel": "iso_shared_kernel<stationary>" if info["uniform_dt"] else "iso_kernel",
-                     "kernel_ms": kern_ms, "algo_bytes_per_launch": algo_bytes,
+                     "kernel_ms": kern_ms, "required_bytes_per_launch": req_bytes, "algo_bytes_per_launch": algo_bytes,
                      "rows_in_launch": info["main_kernel_rows"],
-                     "whole_evaluation": {"gpu_ms": eval_ms, "achieved": eval_achieved,
-                                          "frac": eval_achieved / HBM_PEAK_GBS, "traffic": traffic_eval,
-                                          "host_enqueue_ms": 1e3 * float(np.mean(host_enqueue_s[-args.steps:])),
-                                          "api": "ssde_eval (synchronous); gpu_ms / host_enqueue_ms from an untimed "
-                                                 "ssde_eval_device pass over the same evaluations"
-                                                 if sync_api else "ssde_eval_device + D2H",
-                                          "note": "all kernels of one evaluation incl. the concurrent transient-window "
-                                                  "launch, the hand-over check and the reduction"}},
+                     "whole_evaluation": None if eval_ms is None else {
+                         "gpu_ms": eval_ms,
+                         "achieved": info["required_bytes_per_row"] * rows_per_gpu / (eval_ms * 1e-3) / 1e9,
+                         "frac": info["required_bytes_per_row"] * rows_per_gpu / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "host_enqueue_ms": host_enq_ms,
+                         "note": "all kernels of one evaluation incl. the concurrent transient-window launch, the "
+                                 "hand-over check and the reduction; from an untimed ssde_eval_device pass over the "
+                                 "same evaluations between HIP events"}},
     }
+    eng.close()
+    del eng, pb
+    if rank == 0 and world == 1 and not args.no_secondary and args.model == "CTCRW":
+        # outside the timed region of `value`: the same batch shape on an irregular grid and with 5 % missing rows
+        sec = []
+        try:
+            def irregular(ID, times, obs):
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(5)
+                return torch.cumsum(0.5 + torch.rand(len(ID), device=dev, dtype=torch.float64, generator=gen), 0), obs
+
+            def missing(ID, times, obs):
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(7)
+                na = torch.rand(len(ID), device=dev, generator=gen) < 0.05
+                na[::T] = False                       # first rows stay observed (they initialise the state)
+                obs[na] = float("nan")
+                return times, obs
+
+            sec.append(secondary_workload(f"{M} CTCRW x {T}, irregular time grid (dt ~ U[0.5, 1.5] per row)", "CTCRW", M, T,
+                                          dev, max(3, args.steps // 2), irregular))
+            sec.append(secondary_workload(f"{M} CTCRW x {T}, regular grid, 5 % missing rows", "CTCRW", M, T, dev,
+                                          max(3, args.steps // 2), missing))
+        except Exception as e:  # the secondary numbers must never take the bench line down
+            sec.append({"workload": "failed", "error": str(e)})
+        line["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline()
@@ -265,8 +337,8 @@ def main():
                                     "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
-    eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

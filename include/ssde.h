@@ -25,6 +25,11 @@
  *                                                nllk_ou_ssm.hpp:215, nllk_bm_ssm.hpp:177)
  *   ssde_penalty       <- smoothing penalty     (nllk_ctcrw.hpp:254-280, nllk_sde.hpp:89-124)
  *   ssde_info          <- InfoADFunObject       (src/init.c:7)
+ *   ssde_comm_unique_id / ssde_comm_init_rank
+ *                      <- (new) one process per GPU: joins the handles of all ranks into one RCCL communicator, after
+ *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
+ *   ssde_laplace_eval  <- what `random = "coeff_re"` makes TMB's fn/gr do (R/sde.R:510-525, 656-658): the Laplace
+ *                         approximation of the marginal likelihood over the random-effect coefficients
  *   ssde_destroy       <- external-pointer finalizer of the ADFun object
  *   ssde_last_error    <- Rf_error text         (src/smoothSDE.cpp:25)
  *
@@ -58,7 +63,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 5
+#define SSDE_ABI_VERSION 6
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -167,6 +172,16 @@ typedef struct ssde_desc {
     /* [q] or NULL.  basis_re[j] != NULL: the random-effect block of SDE parameter j is evaluated from this table
      * (x_re[j] is then ignored by the engine and may be NULL). */
     const ssde_ppbasis *const *basis_re;
+    /* Single-process multi-GPU (the reference's host is ONE R process, R/sde.R:656-669): n_devices > 1 shards whole
+     * tracks (contiguous ID segments, balanced by rows) over devices[0..n_devices), one engine per device; every
+     * ssde_eval then runs all shards concurrently and sums their 2 + p doubles with one ncclAllReduce per device
+     * inside ncclGroupStart/End (communicators from ncclCommInitAll).  Host arrays only (no SSDE_FLAG_DEVICE_DATA).
+     * n_devices <= 1 or devices == NULL: the single device `device`.  A device listed more than once is accepted for
+     * rehearsal on a one-GPU machine: its shards are then summed by a small kernel instead of RCCL (which refuses
+     * two ranks on one device). */
+    int32_t  n_devices;
+    int32_t  reserved4;
+    const int32_t *devices;       /* [n_devices] HIP device ordinals */
 } ssde_desc;
 
 typedef struct ssde_handle ssde_handle;
@@ -193,6 +208,13 @@ typedef struct ssde_info_t {
     double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval */
     double  main_kernel_ms; /* HIP-event duration of the dominant kernel launch of the last evaluation */
     int64_t main_kernel_rows;/* rows scored by that launch (the rest belong to the small concurrent launches) */
+    double  required_bytes_per_row; /* bytes per row the engine's resident layout really has to read: algo_bytes_per_row
+                                       minus the 8 B/row of `times` when the grid is globally regular and the dt channel
+                                       is not even stored (24 -> 16 for 2-D constant-coefficient models) */
+    int64_t n_evals;        /* evaluations that ran on the device (window retries included) */
+    int64_t n_memo_hits;    /* ssde_eval calls answered from the memoised last result (same par, bitwise) */
+    int32_t n_devices;      /* shards of a single-process multi-GPU handle (1 otherwise) */
+    int32_t comm_ranks;     /* ranks of the RCCL communicator joined with ssde_comm_init_rank (1 = none) */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the
@@ -203,7 +225,10 @@ int ssde_create(const ssde_desc *desc, ssde_handle **out);
 
 /* fn(par) / gr(par).  order 0: *value only.  order 1: *value and grad[n_par_full].
  * value = nllk including the smoothing penalty exactly as the reference adds it.
- * A non-finite nllk is RETURNED (status SSDE_OK), not raised. */
+ * A non-finite nllk is RETURNED (status SSDE_OK), not raised.
+ * The last result is memoised on the bit pattern of `par`: optim's fn(x); gr(x) pair (R/sde.R:694-696) costs ONE
+ * device evaluation on the paths where the gradient rides along with the value at no extra memory traffic (shared-
+ * covariance and direct kernels: an order-0 call evaluates order 1 there), and a repeated call costs none. */
 int ssde_eval(ssde_handle *h, const double *par, int32_t n_par_full, int32_t order,
               double *value, double *grad);
 
@@ -235,6 +260,16 @@ int ssde_widen_windows(ssde_handle *h, int32_t factor);
 int ssde_relax_windows(ssde_handle *h);
 
 int ssde_info(const ssde_handle *h, ssde_info_t *info);
+
+/* One process per GPU (torchrun / mpirun style hosts).  Rank 0 calls ssde_comm_unique_id (128 bytes, an
+ * ncclUniqueId), the host ships it to the other ranks by its own means, then EVERY rank calls ssde_comm_init_rank
+ * on its own single-device handle (collective call).  From then on ssde_eval / ssde_eval_device sum
+ * [nllk_data, grad..., window_check] over the ranks with one ncclAllReduce (RCCL over xGMI) on the evaluation's
+ * stream before anything is read back, so every rank returns the batch value; the penalty is added once, after
+ * the sum.  Window retries are decided on the reduced check value, i.e. identically on every rank. */
+#define SSDE_COMM_ID_BYTES 128
+int ssde_comm_unique_id(void *id128);
+int ssde_comm_init_rank(ssde_handle *h, int32_t n_ranks, int32_t rank, const void *id128);
 
 void ssde_destroy(ssde_handle *h);
 

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -54,6 +54,7 @@ class SsdeDesc(C.Structure):
         ("col_decay", C.c_void_p), ("ind_decay", C.c_void_p),
         ("eseal_h", C.c_void_p), ("eseal_R", C.c_void_p),
         ("basis_re", C.POINTER(C.POINTER(SsdePPBasis))),
+        ("n_devices", C.c_int32), ("reserved4", C.c_int32), ("devices", _ip),
     ]
 
 
@@ -65,6 +66,8 @@ class SsdeInfo(C.Structure):
         ("algo_bytes_per_row", C.c_double), ("n_kernel_blocks", C.c_int32), ("lanes_per_track", C.c_int32),
         ("window", C.c_int32), ("window_retries", C.c_int32), ("window_check", C.c_double),
         ("main_kernel_ms", C.c_double), ("main_kernel_rows", C.c_int64),
+        ("required_bytes_per_row", C.c_double), ("n_evals", C.c_int64), ("n_memo_hits", C.c_int64),
+        ("n_devices", C.c_int32), ("comm_ranks", C.c_int32),
     ]
 
     def as_dict(self):
@@ -459,30 +462,53 @@ def load_library():
     lib.ssde_last_error.restype = C.c_char_p
     lib.ssde_abi_version.argtypes = []
     lib.ssde_abi_version.restype = C.c_int
+    lib.ssde_comm_unique_id.argtypes = [C.c_void_p]
+    lib.ssde_comm_unique_id.restype = C.c_int
+    lib.ssde_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.ssde_comm_init_rank.restype = C.c_int
     if lib.ssde_abi_version() != ABI_VERSION:
         raise RuntimeError("libssde_hip.so ABI version mismatch")
     _LIB = lib
     return lib
 
 
-WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
-
-EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
-                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version")
-
-
 class EngineError(RuntimeError):
     pass
 
 
-class Engine:
-    """One created engine (= one `MakeADFun` object of the reference) on one GPU."""
+WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
-    def __init__(self, problem: Problem):
+EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank")
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """An ncclUniqueId (rank 0 makes it, the host ships it to the other ranks, every rank passes it to
+    Engine.comm_init)."""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    st = lib.ssde_comm_unique_id(buf)
+    if st != 0:
+        msg = lib.ssde_last_error(None)
+        raise EngineError(f"ssde_comm_unique_id failed ({st}): {msg.decode() if msg else ''}")
+    return buf.raw
+
+
+class Engine:
+    """One created engine (= one `MakeADFun` object of the reference): on one GPU, or -- `devices=[...]` -- sharded
+    by whole tracks over several GPUs of this process (ssde_desc.n_devices; one RCCL all-reduce per evaluation)."""
+
+    def __init__(self, problem: Problem, devices: Optional[Sequence[int]] = None):
         self.lib = load_library()
         self.problem = problem
         self._h = C.c_void_p()
         d = problem.desc()
+        if devices is not None and len(devices) > 1:
+            self._devices = np.ascontiguousarray(devices, dtype=np.int32)
+            d.n_devices = len(self._devices)
+            d.devices = self._devices.ctypes.data_as(_ip)
         st = self.lib.ssde_create(C.byref(d), C.byref(self._h))
         if st != 0:
             msg = self.lib.ssde_last_error(None)
@@ -508,6 +534,13 @@ class Engine:
         self._check(self.lib.ssde_eval(self._h, par.ctypes.data_as(_dp), self.n_par_full, order,
                                        C.byref(val), grad.ctypes.data_as(_dp)))
         return (val.value, grad) if order >= 1 else val.value
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: bytes):
+        """Join this rank's engine with the other ranks' (one process per GPU): every later eval / eval_device returns
+        the RCCL all-reduced batch result.  Collective: every rank calls it with the same id."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(unique_id, COMM_ID_BYTES)
+        self._check(self.lib.ssde_comm_init_rank(self._h, n_ranks, rank, buf))
 
     def widen_windows(self, factor: int = 4):
         self._check(self.lib.ssde_widen_windows(self._h, factor))

@@ -15,4 +15,18 @@ hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// dst[i] += src[i]: sums the result vectors of shards that share one device (the rehearsal mode of a multi-device
+// handle on a one-GPU machine, where RCCL refuses two ranks on a device); fixed order, one thread per entry
+__global__ __launch_bounds__(256) void sum_into_kernel(double* dst, const double* src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 }  // namespace ssde
+
+namespace ssde_engine {
+hipError_t launch_sum_into(double* dst, const double* src, int n, hipStream_t s) {
+    hipLaunchKernelGGL(ssde::sum_into_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+}  // namespace ssde_engine

@@ -20,10 +20,11 @@ int fail(ssde_handle* h, int code, const std::string& msg) {
 
 }  // namespace ssde_engine
 
-namespace {
+namespace ssde_engine {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
+    destroy_dist(h);
     h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
@@ -51,6 +52,9 @@ void destroy(ssde_handle* h) {
         for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
     delete h;
 }
+}  // namespace ssde_engine
+
+namespace {
 
 int choose_iso_split(ssde_handle* h) {
     // Which gradient directions are wanted at all
@@ -96,6 +100,9 @@ int choose_iso_split(ssde_handle* h) {
 }
 
 
+}  // namespace
+
+namespace ssde_engine {
 int build(const ssde_desc* d, ssde_handle* h) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
@@ -107,8 +114,6 @@ int build(const ssde_desc* d, ssde_handle* h) {
         if (!d->a0 || !d->eseal_h || !d->eseal_R) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM needs a0, eseal_h and eseal_R");
         if (d->p0 && (d->p0[0] != 0.0 || d->p0[1] != 0.0 || d->p0[2] != 0.0))
             return fail(h, SSDE_ERR_ARG, "ESEAL_SSM: P0 must be diag(0, p0) (R/sde.R:603)");
-        for (int64_t sgi = 0; sgi < d->n_seg; sgi++)
-            if (d->a0[sgi] != 1.0) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM: the first column of a0 must be 1 (R/sde.R:602)");
         if (d->flags & SSDE_FLAG_DEVICE_DATA) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM takes host arrays");
     }
     if (d->model == SSDE_MODEL_BM_T) {
@@ -152,6 +157,17 @@ int build(const ssde_desc* d, ssde_handle* h) {
             if (d->ind_decay[c] < 0 || d->ind_decay[c] >= d->n_decay) return fail(h, SSDE_ERR_ARG, "ind_decay out of range");
     }
     h->L = make_layout(d);
+    if (d->n_decay > 0) {
+        // a column index that matches no random-effect column would silently not decay while log_decay stays a
+        // free parameter with a zero gradient (the reference stops on an unknown name, R/sde.R:637-640)
+        std::vector<uint8_t> seen((size_t)std::max(h->L.n_re, 1), 0);
+        for (int c = 0; c < d->n_decay_cols; c++) {
+            const int k = d->col_decay[c];
+            if (k < 0 || k >= h->L.n_re) return fail(h, SSDE_ERR_ARG, "col_decay out of range (0-based index into coeff_re)");
+            if (seen[k]) return fail(h, SSDE_ERR_ARG, "col_decay names a column twice");
+            seen[k] = 1;
+        }
+    }
     if (h->L.n_full > MAX_PAR) return fail(h, SSDE_ERR_ARG, "too many parameters for the kernel argument block");
     int nsm = 0;
     for (int s = 0; s < d->n_smooth; s++) nsm += d->smooth_ncol[s];
@@ -190,8 +206,16 @@ int build(const ssde_desc* d, ssde_handle* h) {
         std::vector<int> with_cols;
         for (auto& sl : h->slots)
             if (sl.col >= 0 && (with_cols.empty() || with_cols.back() != sl.par_j)) with_cols.push_back(sl.par_j);
+        // the on-the-fly route exists in the FAST direct kernel only, so everything that later decides direct_fast is
+        // decided here already: at most two parameters with columns, none of them with more than DIRECT_KCAP, no decay
+        // (a table-backed block left without a resident column on the generic kernel would be scored as an intercept)
+        int cols_of[MAX_Q] = {0, 0, 0, 0};
+        for (auto& sl : h->slots)
+            if (sl.col >= 0) cols_of[sl.par_j]++;
+        bool kcap_ok = true;
+        for (int j = 0; j < MAX_Q; j++) kcap_ok = kcap_ok && cols_of[j] <= DIRECT_KCAP;
         const bool fast_family = !is_kalman(d->model) && !is_eseal(d->model) && h->L.n_decay == 0 && with_cols.size() <= 2 &&
-                                 !getenv("SSDE_NO_DIRECT_FAST") && !getenv("SSDE_NO_PP_FAST");
+                                 kcap_ok && !getenv("SSDE_NO_DIRECT_FAST") && !getenv("SSDE_NO_PP_FAST");
         for (int j = 0; j < d->n_par; j++) {
             const ssde_ppbasis* pb = d->basis_re[j];
             if (!pb) continue;
@@ -200,8 +224,9 @@ int build(const ssde_desc* d, ssde_handle* h) {
                 if (!(pb->knots[k] > pb->knots[k - 1])) return fail(h, SSDE_ERR_ARG, "basis_re[j]: knots must increase");
             HIPCHK(h, stage(pb->knots, (size_t)nk, false, h->pp_knots[j]));
             HIPCHK(h, stage(pb->coef, (size_t)(nk - 1) * K * 4, false, h->pp_tab[j]));
-            const double* xdev = pb->x;
-            if (!on_dev) { HIPCHK(h, stage(pb->x, (size_t)n, false, h->pp_x[j])); xdev = h->pp_x[j].p; }
+            // engine-owned copy in either case: ssde.h promises that nothing of the caller's is aliased after create
+            HIPCHK(h, stage(pb->x, (size_t)n, on_dev, h->pp_x[j]));
+            const double* xdev = h->pp_x[j].p;
             PPRef& P = h->pp[j];
             P.x = xdev; P.knots = h->pp_knots[j].p; P.tab = h->pp_tab[j].p; P.nk = nk;
             const double hstep = (pb->knots[nk - 1] - pb->knots[0]) / (nk - 1);
@@ -240,6 +265,9 @@ int build(const ssde_desc* d, ssde_handle* h) {
     }
     h->n_seg = (int64_t)starts.size();
     if (d->a0 && d->n_seg != h->n_seg) return fail(h, SSDE_ERR_ARG, "a0 rows do not match the number of ID segments");
+    if (is_eseal(d->model))   // (after the row count of a0 is known to be right)
+        for (int64_t sgi = 0; sgi < h->n_seg; sgi++)
+            if (d->a0[sgi] != 1.0) return fail(h, SSDE_ERR_ARG, "ESEAL_SSM: the first column of a0 must be 1 (R/sde.R:602)");
     h->n_steps = n - h->n_seg;
     starts.push_back(n);
     if (is_kalman(d->model)) {
@@ -347,6 +375,9 @@ int build(const ssde_desc* d, ssde_handle* h) {
                 if ((int)h->df_pidxA.size() > DIRECT_KCAP || (int)h->df_pidxB.size() > DIRECT_KCAP) ok = false;
             }
             h->direct_fast = ok;
+            if (!ok)
+                for (int j = 0; j < MAX_Q; j++)
+                    if (h->pp_fast[j]) return fail(h, SSDE_ERR_ARG, "internal: a basis table was left unmaterialised for the generic direct kernel");
             if (ok) {
                 h->df_ja = streamed_par.size() > 0 ? streamed_par[0] : -1;
                 h->df_jb = streamed_par.size() > 1 ? streamed_par[1] : -1;
@@ -577,6 +608,9 @@ int build(const ssde_desc* d, ssde_handle* h) {
     h->hbm_bytes += (int64_t)h->partial_doubles * 8;
     return SSDE_OK;
 }
+}  // namespace ssde_engine
+
+namespace {
 
 // Warm-up length of a time window: iterate the (data-independent) covariance recursion on the
 // host at the smallest interval of the batch until it is stationary, take the spectral radius
@@ -761,10 +795,11 @@ int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** de
 }
 }  // namespace ssde_engine
 
-namespace {
+namespace ssde_engine {
 
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s) {
     HIPCHK(h, hipSetDevice(h->device));
+    h->n_evals++;
     if (h->path == PATH_TV) return eval_tv(h, par, order, out_dev, s);
     const ParLayout& L = h->L;
     ReduceArgs ra;
@@ -987,7 +1022,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
     return SSDE_OK;
 }
 
-}  // namespace
+}  // namespace ssde_engine
 
 extern "C" {
 
@@ -998,7 +1033,8 @@ int ssde_create(const ssde_desc* desc, ssde_handle** out) {
     *out = nullptr;
     ssde_handle* h = new (std::nothrow) ssde_handle();
     if (!h) { g_create_error = "out of host memory"; return SSDE_ERR_ALLOC; }
-    int st = build(desc, h);
+    const bool sharded = desc->abi_version == SSDE_ABI_VERSION && desc->n_devices > 1 && desc->devices;
+    int st = sharded ? create_sharded(desc, h) : build(desc, h);
     if (st != SSDE_OK) {
         g_create_error = h->err;
         destroy(h);
@@ -1016,7 +1052,10 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
                      void* stream) {
     if (!h || !par || !out_dev) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
-    return eval_device(h, par, order, out_dev, (hipStream_t)stream);
+    if (!h->shards.empty()) { h->err = "ssde_eval_device: a multi-device handle is evaluated with ssde_eval"; return SSDE_ERR_ARG; }
+    int st = eval_device(h, par, order, out_dev, (hipStream_t)stream);
+    if (st || h->comms.empty()) return st;
+    return reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
 }
 
 int ssde_penalty(ssde_handle* h, const double* par, int32_t n_par_full, double* value, double* grad) {
@@ -1030,27 +1069,84 @@ int ssde_penalty(ssde_handle* h, const double* par, int32_t n_par_full, double* 
     return SSDE_OK;
 }
 
-int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* value, double* grad) {
-    if (!h || !par || !value) return SSDE_ERR_ARG;
-    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
-    std::vector<double> o(2 + h->L.n_full);
-    const bool use_graph = h->path == PATH_TV && !h->env_no_graph;
+}  // extern "C"
+
+namespace {
+
+// the engines one evaluation runs on: the handle itself, or the shards of a multi-device parent
+template <class F>
+void each_engine(ssde_handle* h, F fn) {
+    if (h->shards.empty()) fn(h);
+    else for (ssde_handle* s : h->shards) fn(s);
+}
+
+// Is the gradient free where the value is computed?  On the shared-covariance and direct kernels the
+// sensitivities ride along in registers with the HBM stream that bounds the kernel, so an order-0 call evaluates
+// order 1 and memoises it: optim's fn(x); gr(x) (R/sde.R:694-696) then costs one evaluation.
+bool grad_rides_along(const ssde_handle* h) {
+    const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
+    return e->path == PATH_DIRECT || (e->path == PATH_ISO && e->use_shared);
+}
+
+// One evaluation of every engine of the handle + the sum over shards / ranks, result [nllk_data, grad..., check]
+// in host memory.  Nothing of the retry policy lives here.
+int run_once(ssde_handle* h, const double* par, int order, double* o) {
+    const size_t nout = 2 + (size_t)h->L.n_full;
+    if (!h->shards.empty()) {
+        for (ssde_handle* sh : h->shards) {
+            int st = eval_device(sh, par, order, sh->out.p, sh->own_stream);
+            if (st) { h->err = sh->err; return st; }
+        }
+        int st = reduce_shards(h);
+        if (st) return st;
+        ssde_handle* s0 = h->shards[0];
+        HIPCHK(h, hipSetDevice(s0->device));
+        HIPCHK(h, hipMemcpyAsync(o, s0->out.p, nout * 8, hipMemcpyDeviceToHost, s0->own_stream));
+        // every device has to be done before the next evaluation overwrites what the collective reads
+        for (ssde_handle* sh : h->shards) {
+            HIPCHK(h, hipSetDevice(sh->device));
+            HIPCHK(h, hipStreamSynchronize(sh->own_stream));
+        }
+        return SSDE_OK;
+    }
+    if (!h->comms.empty()) {
+        int st = eval_device(h, par, order, h->out.p, h->own_stream);
+        if (st) return st;
+        st = reduce_ranks(h, h->out.p, h->own_stream);
+        if (st) return st;
+        HIPCHK(h, hipMemcpyAsync(o, h->out.p, nout * 8, hipMemcpyDeviceToHost, h->own_stream));
+        HIPCHK(h, hipStreamSynchronize(h->own_stream));
+        return SSDE_OK;
+    }
+    if (h->path == PATH_TV && !h->env_no_graph && h->tv_stats_valid) {
+        HIPCHK(h, hipSetDevice(h->device));
+        h->n_evals++;
+        return eval_tv_graph(h, par, order, o);
+    }
+    int st = eval_device(h, par, order, h->out.p, 0);
+    if (st) return st;
+    // (a host-mapped mirror written by the finalising launch was tried instead of this copy: 20 us slower)
+    HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
+    return SSDE_OK;
+}
+
+// An evaluation with the window policy around it: re-evaluate with a wider warm-up until the time
+// windows agree, narrow again on probation after `cooldown` calm evaluations.  Every decision is taken on the
+// REDUCED check value (a sum of non-negative per-shard / per-rank maxima, compared with the single-engine
+// tolerance: conservative), so the shards of a parent and the ranks of a communicator move in lockstep and the
+// collective inside run_once is entered by everyone the same number of times.
+int run_checked(ssde_handle* h, const double* par, int order, std::vector<double>& o) {
+    const bool dist = !h->shards.empty() || !h->comms.empty();
     int attempt = 0;
     for (;; attempt++) {
-        if (use_graph && h->tv_stats_valid) {
-            HIPCHK(h, hipSetDevice(h->device));
-            int st = eval_tv_graph(h, par, order, o.data());
-            if (st) return st;
-        } else {
-            int st = eval_device(h, par, order, h->out.p, 0);
-            if (st) return st;
-            // (a host-mapped mirror written by the finalising launch was tried instead of this copy: 20 us slower)
-            HIPCHK(h, hipMemcpy(o.data(), h->out.p, o.size() * 8, hipMemcpyDeviceToHost));
-        }
+        int st = run_once(h, par, order, o.data());
+        if (st) return st;
         h->last_check = o[1 + h->L.n_full];
+        each_engine(h, [&](ssde_handle* e) { e->last_check = h->last_check; });
         // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
         // until the windows agree with each other; 64x the estimate ends in one sequential window
-        if (h->last_check <= SSDE_WINDOW_TOL || h->last_chunks <= 1) break;
+        if (h->last_check <= SSDE_WINDOW_TOL) break;
+        if (!dist && h->last_chunks <= 1) break;
         // a non-finite nllk is rejected by the caller whatever the windows did: no retry, and no lasting
         // widening of the plan because an optimiser probed an absurd parameter once
         if (!std::isfinite(o[0])) break;
@@ -1061,23 +1157,31 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
             // as long before the next try
             h->probing = false;
             h->cooldown = std::min(h->cooldown * 2, 1 << 14);
-            if (h->probe_from == 0) { h->max_chunks = 1; h->want_chunks = 1; h->gave_up = true; }
+            if (h->probe_from == 0) each_engine(h, [](ssde_handle* e) { e->max_chunks = 1; e->want_chunks = 1; e->gave_up = true; });
+            else each_engine(h, [&](ssde_handle* e) { e->window_boost = h->probe_from; });
+            if (h->probe_from == 0) h->gave_up = true;
             else h->window_boost = h->probe_from;
             continue;
         }
         // the row-varying path plans from the parameter ranges its pre-pass saw in the PREVIOUS evaluation: after a
         // jump in the parameters the first retry needs no boost, just this evaluation's own ranges
-        if (h->path == PATH_TV && attempt == 0) continue;
+        const int path0 = h->shards.empty() ? h->path : h->shards[0]->path;
+        if (path0 == PATH_TV && attempt == 0) continue;
         if (attempt >= 3) {                                            // give up on windows: sequential filter
-            if (!h->gave_up) { h->saved_max_chunks = h->max_chunks; h->saved_want_chunks = h->want_chunks; h->gave_up = true; }
-            h->max_chunks = 1; h->want_chunks = 1;
+            each_engine(h, [](ssde_handle* e) {
+                if (!e->gave_up) { e->saved_max_chunks = e->max_chunks; e->saved_want_chunks = e->want_chunks; e->gave_up = true; }
+                e->max_chunks = 1; e->want_chunks = 1;
+            });
+            h->gave_up = true;
         } else {
-            h->window_boost *= 4;
+            each_engine(h, [](ssde_handle* e) { e->window_boost *= 4; });
+            if (!h->shards.empty()) h->window_boost *= 4;
         }
     }
     // A widened plan is not for life: one slow-forgetting parameter vector in a line search would otherwise tax every
     // later evaluation.  Every evaluation is checked, so narrowing on probation is safe -- a failure costs one retry.
-    if (attempt == 0 && !h->chunks_forced) {
+    const bool forced = h->shards.empty() ? h->chunks_forced : h->shards[0]->chunks_forced;
+    if (attempt == 0 && !forced) {
         h->calm++;
         if (h->probing && h->calm >= 4) h->probing = false;           // the narrower plan holds
         if (h->calm >= h->cooldown && (h->gave_up || h->window_boost > 1)) {
@@ -1085,22 +1189,51 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
             h->probing = true;
             if (h->gave_up) {
                 h->probe_from = 0;
-                h->max_chunks = h->saved_max_chunks; h->want_chunks = h->saved_want_chunks; h->gave_up = false;
+                each_engine(h, [](ssde_handle* e) { e->max_chunks = e->saved_max_chunks; e->want_chunks = e->saved_want_chunks; e->gave_up = false; });
+                h->gave_up = false;
             } else {
                 h->probe_from = h->window_boost;
-                h->window_boost = std::max(1, h->window_boost / 2);
+                each_engine(h, [](ssde_handle* e) { e->window_boost = std::max(1, e->window_boost / 2); });
+                if (!h->shards.empty()) h->window_boost = std::max(1, h->window_boost / 2);
             }
         }
     }
+    return SSDE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* value, double* grad) {
+    if (!h || !par || !value) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    const size_t np = (size_t)h->L.n_full;
+    const bool want_grad = order >= 1 && grad;
+    // memo: same bit pattern as the last evaluated vector, and what is asked for was computed then
+    if (h->memo_order >= (want_grad ? 1 : 0) && memcmp(par, h->memo_par.data(), np * 8) == 0) {
+        *value = h->memo_value;
+        if (want_grad) memcpy(grad, h->memo_grad.data(), np * 8);
+        h->n_memo_hits++;
+        return SSDE_OK;
+    }
+    const int eval_order = (want_grad || grad_rides_along(h)) ? 1 : 0;
+    std::vector<double> o(2 + np);
+    int st = run_checked(h, par, eval_order, o);
+    if (st) return st;
     double pen = 0.0;
-    int st;
-    if (order >= 1 && grad) {
-        for (int k = 0; k < h->L.n_full; k++) grad[k] = o[1 + k];
-        st = ssde_penalty(h, par, n_par_full, &pen, grad);
+    h->memo_order = -1;
+    h->memo_par.assign(par, par + np);
+    h->memo_grad.assign(np, 0.0);
+    if (eval_order >= 1) {
+        for (size_t k = 0; k < np; k++) h->memo_grad[k] = o[1 + k];
+        st = ssde_penalty(h, par, n_par_full, &pen, h->memo_grad.data());
+        if (want_grad) memcpy(grad, h->memo_grad.data(), np * 8);
     } else {
         st = ssde_penalty(h, par, n_par_full, &pen, nullptr);
     }
-    *value = o[0] + pen;
+    *value = h->memo_value = o[0] + pen;
+    if (st == SSDE_OK) h->memo_order = eval_order;
     return st;
 }
 
@@ -1115,6 +1248,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     if (!h || !par || !aest_all) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     if (!is_kalman(h->model)) { h->err = "aest_all is reported by the Kalman families only (the ESEAL template has no REPORT)"; return SSDE_ERR_MODEL; }
+    if (!h->shards.empty()) return report_sharded(h, par, aest_all);
     HIPCHK(h, hipSetDevice(h->device));
     if (h->path == PATH_TV) {
         // one sequential window per track, direction block 0, states written straight to the long format
@@ -1177,13 +1311,16 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
 
 int ssde_widen_windows(ssde_handle* h, int32_t factor) {
     if (!h) return SSDE_ERR_ARG;
+    for (ssde_handle* s : h->shards) ssde_widen_windows(s, factor);
     if (factor <= 0) { h->max_chunks = 1; h->want_chunks = 1; }
     else if (h->window_boost < (1 << 20)) h->window_boost *= factor;
+    h->memo_order = -1;
     return SSDE_OK;
 }
 
 int ssde_relax_windows(ssde_handle* h) {
     if (!h) return SSDE_ERR_ARG;
+    for (ssde_handle* s : h->shards) ssde_relax_windows(s);
     h->window_boost = std::max(1, h->window_boost / 2);
     return SSDE_OK;
 }
@@ -1191,6 +1328,26 @@ int ssde_relax_windows(ssde_handle* h) {
 int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     if (!h || !info) return SSDE_ERR_ARG;
     memset(info, 0, sizeof(*info));
+    if (!h->shards.empty()) {
+        // a multi-device parent: totals over the shards, plan and path of shard 0, the slowest shard's kernel time
+        ssde_info_t si;
+        for (size_t k = 0; k < h->shards.size(); k++) {
+            ssde_info(h->shards[k], &si);
+            if (k == 0) *info = si;
+            else {
+                info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps;
+                info->hbm_bytes += si.hbm_bytes; info->main_kernel_rows += si.main_kernel_rows;
+                info->n_kernel_blocks += si.n_kernel_blocks; info->n_evals += si.n_evals;
+                info->main_kernel_ms = std::max(info->main_kernel_ms, si.main_kernel_ms);
+                info->uniform_dt = info->uniform_dt && si.uniform_dt;
+                info->required_bytes_per_row = std::max(info->required_bytes_per_row, si.required_bytes_per_row);
+            }
+        }
+        info->window_check = h->last_check; info->window_retries = h->n_retries;
+        info->n_memo_hits = h->n_memo_hits;
+        info->n_devices = (int32_t)h->shards.size(); info->comm_ranks = 1;
+        return SSDE_OK;
+    }
     info->n_par_full = h->L.n_full;
     info->n_free = h->n_free;
     info->sdim = h->sdim;
@@ -1202,6 +1359,13 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_steps = h->n_steps;
     info->hbm_bytes = h->hbm_bytes;
     info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols_algo);
+    // what the resident layout has to read per row: the `times` stream is not even stored when the grid is globally
+    // regular (Kalman tiles without a dt channel); the direct families do not read it on a regular grid either
+    info->required_bytes_per_row = info->algo_bytes_per_row -
+        (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
+          h->df_ja != h->d + 1 && h->df_jb != h->d + 1 && h->model != SSDE_MODEL_BM_T && h->model != SSDE_MODEL_CIR) ? 8.0 : 0.0);
+    info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
+    info->n_devices = 1; info->comm_ranks = h->comm_ranks;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
         info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * (h->last_t0 > 0 ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;

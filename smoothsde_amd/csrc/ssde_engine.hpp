@@ -192,6 +192,20 @@ struct ssde_handle {
     double* tv_out_pinned = nullptr;
 
     int64_t hbm_bytes = 0;
+
+    // ---- distributed evaluation (ssde_engine_dist.hip) -------------------------------------------------------------
+    // single-process multi-GPU parent (ssde_desc.n_devices > 1): one engine per device, this handle owns no device data
+    std::vector<ssde_handle*> shards;
+    std::vector<int64_t> shard_row0;          // first global row of each shard (+ n at the end)
+    std::vector<void*> comms;                 // ncclComm_t: one per shard (parent), or one (ssde_comm_init_rank)
+    bool shards_share_device = false;         // rehearsal on a one-GPU machine: shards summed by a kernel, not RCCL
+    int comm_ranks = 1;                       // ranks of a multi-process communicator
+    hipStream_t own_stream = nullptr;         // stream of the synchronous evaluation when a collective follows it
+    // ---- memo of the last ssde_eval (include/ssde.h) ---------------------------------------------------------------
+    std::vector<double> memo_par, memo_grad;
+    double memo_value = 0.0;
+    int memo_order = -1;                      // -1 = nothing memoised
+    int64_t n_evals = 0, n_memo_hits = 0;
 };
 
 
@@ -208,6 +222,21 @@ namespace ssde_engine {
 
 
 int fail(ssde_handle* h, int code, const std::string& msg);
+
+// ssde_engine.hip
+int build(const ssde_desc* d, ssde_handle* h);
+void destroy(ssde_handle* h);
+int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s);
+
+// ---- distributed evaluation (ssde_engine_dist.hip) --------------------------------------------------------------------
+int create_sharded(const ssde_desc* d, ssde_handle* parent);
+// sum the shards' [nllk, grad..., check] buffers (RCCL all-reduce, or the rehearsal kernel) -- enqueue only
+int reduce_shards(ssde_handle* parent);
+// all-reduce one handle's out buffer over its multi-process communicator -- enqueue only
+int reduce_ranks(ssde_handle* h, double* buf, hipStream_t s);
+int report_sharded(ssde_handle* parent, const double* par, double* aest_all);
+void destroy_dist(ssde_handle* h);
+hipError_t launch_sum_into(double* dst, const double* src, int n, hipStream_t s);   // k_reduce.hip
 
 // copy a caller array (host or device) into a fresh device buffer
 template <class T>

@@ -365,27 +365,30 @@ SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool
     const double iF = upd ? rcp(F) : 0.0;
     C.ld.mul(upd ? F : 1.0);
     C.nupd += upd ? 1.0 : 0.0;
-    const double tp = tr.t * C.p;
-    const double k = tp * iF;
+    // The literal update P = T P (T - K Z)' + Q (nllk_ou_ssm.hpp:205-206) is t p (t - k) + q with t - k = t (1 - p/F):
+    // once p >> h the difference cancels to nothing and the next p is rounding noise times p.  The same numbers
+    // without the cancellation: with a = h/F, b = p/F (a + b = 1)
+    //     p'  = t^2 p a + q                                 k  = t b
+    //     dp' = t^2 (a^2 dp + b^2 dh) + 2 t dt p a + dq      dk = dt b + t (a dp - b dh) / F
+    // (d[p h / F] = (h^2 dp + p^2 dh) / F^2).  A missing row has a = 1, b = 0.
+    const double a = upd ? h * iF : 1.0, b = C.p * iF;
+    const double k = tr.t * b;
+    const double t2 = tr.t * tr.t, ta2 = t2 * a * a, tiF = tr.t * iF;
     G.iF = iF; G.k = k;
     for (int j = 0; j < NDIRP; j++) {
         if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) { G.diF[j] = G.dk[j] = 0.0; continue; }
-        const double dh = (j == 0) ? 2.0 * h : 0.0;
-        const double dt_ = (j == 1) ? tr.dt_ : 0.0;
-        const double dq = (j == 1) ? tr.dq : (j == 2 ? tr.q : 0.0);
-        const double dF = (j == 0) ? C.dp[j] + dh : C.dp[j];
-        const double diF = -iF * iF * dF;
+        const double dF = (j == 0) ? C.dp[j] + 2.0 * h : C.dp[j];
+        G.diF[j] = -iF * iF * dF;
         C.gld[j] += dF * iF;
-        double dtp = tr.t * C.dp[j];
-        if (j == 1) dtp += dt_ * C.p;
-        const double dk = dtp * iF + tp * diF;
-        G.diF[j] = diF; G.dk[j] = dk;
-        double np_ = dtp * (tr.t - k) - tp * dk;
-        if (j == 1) np_ += tp * dt_;
-        if (j != 0) np_ += dq;
+        double dk = tiF * a * C.dp[j];
+        double np_ = ta2 * C.dp[j];
+        if (j == 0) { dk -= tiF * b * (2.0 * h); np_ += t2 * b * b * (2.0 * h); }
+        if (j == 1) { dk += tr.dt_ * b; np_ += 2.0 * tr.t * tr.dt_ * C.p * a + tr.dq; }
+        if (j == 2) np_ += tr.q;
+        G.dk[j] = dk;
         C.dp[j] = np_;
     }
-    C.p = tp * (tr.t - k) + tr.q;
+    C.p = t2 * C.p * a + tr.q;
 }
 
 template <int D, int MASK>

@@ -194,8 +194,10 @@ SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind,
     const bool upd = !na && !(fabs(F) <= 0.0);                  // detF = exp(logdet F): nllk_ou_ssm.hpp:190-195
     const double iF = upd ? rcp(F) : 0.0;
     L.ld.mul(upd ? F : 1.0);
-    const double tp = t * L.p;
-    const double k = tp * iF;
+    // cancellation-free form of P = T P (T - K Z)' + Q and of its derivative: see scal_cov_step (ssde_math.hpp)
+    const double ha = upd ? h * iF : 1.0, pb = L.p * iF;         // h/F, p/F
+    const double k = t * pb;
+    const double t2 = t * t;
     double u[D], su2 = 0.0;
     for (int a = 0; a < D; a++) { u[a] = upd ? r[TVR_Y + a] - L.x[a] : 0.0; su2 += u[a] * u[a]; }
     L.accq += iF * su2;
@@ -206,9 +208,8 @@ SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind,
         const double dF = L.dp + dh;
         const double diF = -iF * iF * dF;
         L.gld += dF * iF;
-        const double dtp = t * L.dp + dt_ * L.p;
-        const double dk = dtp * iF + tp * diF;
-        L.dp = dtp * (t - k) - tp * dk + tp * dt_ + dq;
+        const double dk = dt_ * pb + t * iF * (ha * L.dp - pb * dh);
+        const double ndp = t2 * (ha * ha * L.dp + pb * pb * dh) + 2.0 * t * dt_ * L.p * ha + dq;
         double sud = 0.0;
         for (int a = 0; a < D; a++) {
             const double du = upd ? -L.tx[a] : 0.0;
@@ -217,9 +218,10 @@ SSDE_HD void tv_scal_step(TvScalLane<D>& L, const double* r, double h, int kind,
             L.tx[a] = t * L.tx[a] + dk * u[a] + k * du + dt_ * L.x[a] + db * r[TVR_MU + a] + b * dmu;
         }
         L.gq += 0.5 * diF * su2 + iF * sud;
+        L.dp = ndp;
     }
     for (int a = 0; a < D; a++) L.x[a] = t * L.x[a] + k * u[a] + b * r[TVR_MU + a];
-    L.p = tp * (t - k) + q;
+    L.p = t2 * L.p * ha + q;
 }
 
 // model -> lane type / step
@@ -360,6 +362,7 @@ struct TvEsealOps {
         L.ld.mul(upd ? F : 1.0);
         const double u = upd ? r[TVE_Y] - r[TVE_A1] - z * L.x : 0.0;   // line 182
         const double k = L.p * z * iF;                                 // K = T P Z' F^-1, second row (line 197)
+        const double c = upd ? H * iF : 1.0;                           // 1 - k z = H / F, without the cancellation of the literal form
         L.accq += iF * u * u;
         if (GRAD) {
             const double dz = (kind == TVK_A2) ? z : 0.0, dH = (kind == TVK_SIG) ? 2.0 * H : 0.0;
@@ -372,10 +375,10 @@ struct TvEsealOps {
             L.gq += 0.5 * diF * u * u + iF * u * du;
             const double dk = (L.dp * z + L.p * dz) * iF + L.p * z * diF;
             L.tx = L.tx + ddrift + dk * u + k * du;
-            L.dp = L.dp * (1.0 - k * z) - L.p * (dk * z + k * dz) + dq;
+            L.dp = L.dp * c - L.p * (dk * z + k * dz) + dq;
         }
         L.x = L.x + drift + k * u;                                     // lines 176, 188, 199
-        L.p = L.p * (1.0 - k * z) + q;                                 // lines 177, 189, 201-202
+        L.p = L.p * c + q;                                             // lines 177, 189, 201-202
     }
 };
 

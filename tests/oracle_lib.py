@@ -40,6 +40,30 @@ def load_oracle():
     return _LIB
 
 
+_QLIB = None
+
+
+def oracle_eval_quad(problem: Problem, par, order: int = 1, fd_step: float = 1e-10):
+    """The same restated templates evaluated in IEEE binary128 (oracle/oracle_quad.cpp): value rounded to double once,
+    gradient by central differences of the binary128 function.  Slow (single thread, software quad arithmetic):
+    the arbiter for cases where the double-precision oracle and the engine disagree."""
+    global _QLIB
+    if _QLIB is None:
+        path = os.path.join(_ORACLE_DIR, "liboracle_quad.so")
+        if not os.path.exists(path):
+            build_oracle()
+        _QLIB = C.CDLL(path)
+        _QLIB.oracle_eval_quad.argtypes = [C.POINTER(SsdeDesc), _dp, C.c_int, _dp, _dp, C.c_double]
+        _QLIB.oracle_eval_quad.restype = C.c_int
+    d = problem.desc()
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    val = C.c_double()
+    grad = np.zeros(problem.n_par_full)
+    st = _QLIB.oracle_eval_quad(C.byref(d), par.ctypes.data_as(_dp), order, C.byref(val), grad.ctypes.data_as(_dp), fd_step)
+    assert st == 0
+    return (val.value, grad) if order >= 1 else val.value
+
+
 def oracle_eval(problem: Problem, par, order: int = 1, threads: int = 1, report: bool = False,
                 data_only: bool = False):
     """nllk (+ penalty unless data_only), gradient over the full parameter vector, and
