@@ -25,6 +25,7 @@
  *                                                nllk_ou_ssm.hpp:215, nllk_bm_ssm.hpp:177)
  *   ssde_penalty       <- smoothing penalty     (nllk_ctcrw.hpp:254-280, nllk_sde.hpp:89-124)
  *   ssde_info          <- InfoADFunObject       (src/init.c:7)
+ *   ssde_forget        <- (new) drops the memo of ssde_eval
  *   ssde_comm_unique_id / ssde_comm_init_rank
  *                      <- (new) one process per GPU: joins the handles of all ranks into one RCCL communicator, after
  *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
@@ -260,6 +261,31 @@ int ssde_widen_windows(ssde_handle *h, int32_t factor);
 int ssde_relax_windows(ssde_handle *h);
 
 int ssde_info(const ssde_handle *h, ssde_info_t *info);
+
+/* Drop the memoised last result: the next ssde_eval runs on the device whatever its argument (determinism checks). */
+int ssde_forget(ssde_handle *h);
+
+/* fn / gr of the MARGINAL negative log-likelihood: coeff_re integrated out by the Laplace approximation, which is
+ * what tmb_obj$fn / tmb_obj$gr are when SDE$setup passes random = "coeff_re" (R/sde.R:510-525, 656-658):
+ *     f(theta) = g(theta, u^) + 1/2 log det H_uu(theta, u^) - n_u/2 log(2 pi),   u^ = argmin_u g(theta, u),
+ * g = ssde_eval's joint penalised nllk, u = the coeff_re entries that are not fixed, theta = every other free entry
+ * (log_sigma_obs, coeff_fe, log_lambda, log_decay).
+ *   par     [n_par_full] IN/OUT: outer parameters and the starting values of coeff_re (warm start); on return the
+ *           coeff_re entries hold u^ (TMB's par.random / env$last.par)
+ *   order   0: *value;  1: also grad[n_par_full] = df/dtheta (zeros at coeff_re and at fixed entries)
+ *   hess_uu NULL or [n_u x n_u] column-major: H_uu at u^ (the random-effect block of sdreport's jointPrecision)
+ * H_uu comes from central differences of the device gradient, the inner problem is solved by Newton iterations, the
+ * gradient is the exact dg/dtheta at u^ plus a differenced 1/2 d log det H_uu / dtheta along the implicit-function
+ * tangent of u^ (ssde_laplace.hip).  A joint nllk that has no minimum in u gives *value = +Inf (a rejected step). */
+typedef struct ssde_laplace_opts {
+    double hess_step;      /* relative step of the Hessian differences   (<= 0: 1e-4) */
+    double fd_step;        /* relative step of the log-determinant term  (<= 0: 1e-4) */
+    double newton_tol;     /* inner convergence: largest step component  (<= 0: 1e-8) */
+    int32_t max_newton;    /* inner iterations                           (<= 0: 30)   */
+    int32_t reserved;
+} ssde_laplace_opts;
+int ssde_laplace_eval(ssde_handle *h, double *par, int32_t n_par_full, int32_t order, double *value, double *grad,
+                      double *hess_uu, const ssde_laplace_opts *opts);
 
 /* One process per GPU (torchrun / mpirun style hosts).  Rank 0 calls ssde_comm_unique_id (128 bytes, an
  * ncclUniqueId), the host ships it to the other ranks by its own means, then EVERY rank calls ssde_comm_init_rank

@@ -58,6 +58,11 @@ class SsdeDesc(C.Structure):
     ]
 
 
+class SsdeLaplaceOpts(C.Structure):
+    _fields_ = [("hess_step", C.c_double), ("fd_step", C.c_double), ("newton_tol", C.c_double),
+                ("max_newton", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SsdeInfo(C.Structure):
     _fields_ = [
         ("n_par_full", C.c_int32), ("n_free", C.c_int32), ("sdim", C.c_int32), ("path", C.c_int32),
@@ -462,6 +467,10 @@ def load_library():
     lib.ssde_last_error.restype = C.c_char_p
     lib.ssde_abi_version.argtypes = []
     lib.ssde_abi_version.restype = C.c_int
+    lib.ssde_laplace_eval.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, C.POINTER(SsdeLaplaceOpts)]
+    lib.ssde_laplace_eval.restype = C.c_int
+    lib.ssde_forget.argtypes = [C.c_void_p]
+    lib.ssde_forget.restype = C.c_int
     lib.ssde_comm_unique_id.argtypes = [C.c_void_p]
     lib.ssde_comm_unique_id.restype = C.c_int
     lib.ssde_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -479,7 +488,7 @@ class EngineError(RuntimeError):
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
-                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank")
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval")
 
 COMM_ID_BYTES = 128
 
@@ -541,6 +550,29 @@ class Engine:
         assert len(unique_id) == COMM_ID_BYTES
         buf = C.create_string_buffer(unique_id, COMM_ID_BYTES)
         self._check(self.lib.ssde_comm_init_rank(self._h, n_ranks, rank, buf))
+
+    def laplace_eval(self, par, order: int = 1, want_hessian: bool = False, hess_step: float = 0.0, fd_step: float = 0.0,
+                     newton_tol: float = 0.0, max_newton: int = 0):
+        """Marginal nllk (coeff_re integrated out by the Laplace approximation, ssde_laplace_eval) at the outer entries
+        of `par`, warm-started at its coeff_re entries.  Returns (value, grad, par_with_u_hat[, H_uu])."""
+        p = np.array(par, dtype=np.float64)
+        if p.shape != (self.n_par_full,):
+            raise ValueError(f"par must have length {self.n_par_full}")
+        val = C.c_double()
+        grad = np.zeros(self.n_par_full)
+        pb = self.problem
+        nu = int(np.sum(pb.par_fixed[pb.off_re:pb.off_re + pb.n_re] == 0))
+        H = np.zeros((nu, nu), order="F") if want_hessian else None
+        opts = SsdeLaplaceOpts(hess_step, fd_step, newton_tol, max_newton, 0)
+        self._check(self.lib.ssde_laplace_eval(self._h, p.ctypes.data_as(_dp), self.n_par_full, order, C.byref(val),
+                                               grad.ctypes.data_as(_dp), None if H is None else H.ctypes.data_as(_dp),
+                                               C.byref(opts)))
+        out = (val.value, grad, p)
+        return out + (H,) if want_hessian else out
+
+    def forget(self):
+        """Drop the memoised last result: the next eval runs on the device even at the same par."""
+        self._check(self.lib.ssde_forget(self._h))
 
     def widen_windows(self, factor: int = 4):
         self._check(self.lib.ssde_widen_windows(self._h, factor))

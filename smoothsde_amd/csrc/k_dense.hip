@@ -58,7 +58,7 @@ __global__ __launch_bounds__(WAVE) void dense_kernel(const DenseArgs A) {
         // dtimes(i): the tile's dt channel, or the one interval of a globally regular grid (dtimes(n-1) = 1,
         // nllk_ctcrw.hpp:126-129: only REPORT(aest_all) ever shows the state propagated with it)
         double dt = cy ? o[0] : tv.dt_all;
-        if (REPORT && !cy && row0 + 1 + s0 == A.n - 1) dt = 1.0;
+        if (REPORT && !cy && row0 + 1 + s0 == A.n - 1) dt = A.last_dt;
         double y[D];
 #pragma unroll
         for (int a = 0; a < D; a++) y[a] = o[(cy + a) * WAVE];

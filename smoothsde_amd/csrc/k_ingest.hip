@@ -43,7 +43,7 @@ __global__ __launch_bounds__(4 * WAVE) void ingest_kernel(const IngestArgs A) {
                     if (is_dt) {
                         // dtimes(i): nllk_ctcrw.hpp:126-129 (the cross-track value at a track's last row is kept: the
                         // engine never uses that prediction for the likelihood, only ssde_report shows it)
-                        v = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : 1.0;
+                        v = (i < A.n - 1) ? A.times[i + 1] - A.times[i] : A.last_dt;
                         if (s < ns - 1) { dmin = fmin(dmin, v); dmax = fmax(dmax, v); if (v != v) dmax = INFINITY; }
                     } else if (k < d) {
                         v = A.obs[i + (int64_t)k * A.n];

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
         // to the next track (Q4): the filter state it produces is discarded, but REPORT(aest_all) shows it, so
         // the record follows the reference there too; only the planner's statistics skip those rows
         const bool used = (i + 1 < A.n) && ((A.scored[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
-        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : 1.0;
+        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : A.last_dt;
         double y[D];
 #pragma unroll
         for (int a = 0; a < D; a++) y[a] = A.obs[i + (int64_t)a * A.n];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void tv_prepare_eseal_kernel(const TvArgs A) {
             const double t = ((col >= 0) ? A.colbuf[(int64_t)col * A.col_stride + i] : 1.0) * A.par[T->pidx[k]];
             par[0] += (j == 0) ? t : 0.0; par[1] += (j == 1) ? t : 0.0;
         }
-        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : 1.0;       // :104-107
+        const double dt = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : A.last_dt;       // :104-107
         const double sigma = exp(par[1]);
         double r[TV_RS];
 #pragma unroll

@@ -156,6 +156,7 @@ struct IngestArgs {
     int sdim, model;
     double* dt_minmax;           // [n_groups * ychunks * 3]: min / max of the intervals used INSIDE tracks, NaN seen
     int ychunks;
+    double last_dt;              // dtimes(n-1): 1 (nllk_ctcrw.hpp:126-129), or the interval to the next shard's first row
 };
 int ingest_ychunks(int n_groups);
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
@@ -262,6 +263,7 @@ struct DenseArgs {
     double* report;              // optional aest_all
     const int64_t* lane_row0;
     int64_t n;
+    double last_dt;              // dtimes(n-1), see IngestArgs
 };
 hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 
@@ -313,6 +315,7 @@ struct TvArgs {
     int stats_blocks;
     double* report;              // optional aest_all [n x sdim]
     int n_out;                   // 1 + n_par_full
+    double last_dt;              // dtimes(n-1), see IngestArgs
     int16_t dir_of_par[MAX_PAR]; // full-par index -> direction, -1 = no gradient (fixed, or not in the data term)
     double* out;                 // n_out + 1 doubles
 };

@@ -502,7 +502,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
         ia.group_off = h->group_off.p; ia.group_len = h->group_len.p;
         ia.n_groups = G; ia.C = h->C; ia.c_obs = h->c_obs; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
         ia.a0_src = p_a0; ia.lane_seg = s_lane_seg.p; ia.n_seg = h->n_seg;
-        ia.sdim = h->sdim; ia.model = d->model; ia.dt_minmax = mm.p; ia.ychunks = ych;
+        ia.sdim = h->sdim; ia.model = d->model; ia.dt_minmax = mm.p; ia.ychunks = ych; ia.last_dt = h->last_dt;
         HIPCHK(h, launch_ingest(ia, 0));
         std::vector<double> mmh((size_t)G * ych * 3);
         HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));  // also syncs
@@ -944,7 +944,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
         for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
         a.n_dirblocks = h->n_dirblocks; a.dirs = h->dirs.p; a.partials = h->partials.p;
-        a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n;
+        a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
         HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_dense(a, order >= 1, s));
         HIPCHK(h, hipEventRecord(h->ev_k1, s));
@@ -1301,7 +1301,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
     for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
     a.n_dirblocks = 1; a.dirs = nullptr; a.partials = nullptr;
-    a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = h->n;
+    a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
     HIPCHK(h, launch_dense(a, false, 0));
     HIPCHK(h, hipMemcpy(aest_all, rep.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
     fill_single_rows(h, aest_all);
@@ -1314,6 +1314,12 @@ int ssde_widen_windows(ssde_handle* h, int32_t factor) {
     for (ssde_handle* s : h->shards) ssde_widen_windows(s, factor);
     if (factor <= 0) { h->max_chunks = 1; h->want_chunks = 1; }
     else if (h->window_boost < (1 << 20)) h->window_boost *= factor;
+    h->memo_order = -1;
+    return SSDE_OK;
+}
+
+int ssde_forget(ssde_handle* h) {
+    if (!h) return SSDE_ERR_ARG;
     h->memo_order = -1;
     return SSDE_OK;
 }

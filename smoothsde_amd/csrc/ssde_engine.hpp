@@ -192,6 +192,9 @@ struct ssde_handle {
     double* tv_out_pinned = nullptr;
 
     int64_t hbm_bytes = 0;
+    // dtimes(n-1) of the reference is 1 (nllk_ctcrw.hpp:126-129); a shard of a multi-device handle that is not the last
+    // one carries the real interval to the next shard's first row there (only REPORT(aest_all) ever shows it)
+    double last_dt = 1.0;
 
     // ---- distributed evaluation (ssde_engine_dist.hip) -------------------------------------------------------------
     // single-process multi-GPU parent (ssde_desc.n_devices > 1): one engine per device, this handle owns no device data

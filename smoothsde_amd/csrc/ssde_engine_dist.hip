@@ -139,6 +139,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
         ssde_handle* sh = new (std::nothrow) ssde_handle();
         if (!sh) return fail(parent, SSDE_ERR_ALLOC, "out of host memory");
         parent->shards.push_back(sh);
+        if (hi < n) sh->last_dt = d->times[hi] - d->times[hi - 1];   // the reference's dtimes at this row: the next track's first time
         parent->shard_row0.push_back(lo);
         int st = build(&sd, sh);
         if (st != SSDE_OK) return fail(parent, st, "shard " + std::to_string(k) + " (device " + std::to_string(sd.device) + "): " + sh->err);

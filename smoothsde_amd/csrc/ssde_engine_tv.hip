@@ -21,6 +21,7 @@ void tv_base_args(const ssde_handle* h, TvArgs& a) {
     a.bnd = h->tv_bnd.p; a.gval = h->tv_gval.p; a.gdir = h->tv_gdir.p;
     a.stats = h->tv_stats.p; a.stats_blocks = h->tv_stats_blocks;
     a.n_out = 1 + h->L.n_full;
+    a.last_dt = h->last_dt;
     for (int k = 0; k < MAX_PAR; k++) a.dir_of_par[k] = h->tv_dir_of_par[k];
 }
 

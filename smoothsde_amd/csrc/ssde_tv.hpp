@@ -362,7 +362,9 @@ struct TvEsealOps {
         L.ld.mul(upd ? F : 1.0);
         const double u = upd ? r[TVE_Y] - r[TVE_A1] - z * L.x : 0.0;   // line 182
         const double k = L.p * z * iF;                                 // K = T P Z' F^-1, second row (line 197)
-        const double c = upd ? H * iF : 1.0;                           // 1 - k z = H / F, without the cancellation of the literal form
+        // 1 - k z = H / F and the derivatives of p H / F and p z / F without the cancellations of the literal forms
+        // (a = H/F, b = p/F):  d[p H/F] = a^2 dp + z^2 b^2 dH - 2 z p a b dz,  dk = (z a dp + p (a - z^2 b) dz - z b dH) / F
+        const double c = upd ? H * iF : 1.0, pb = L.p * iF;
         L.accq += iF * u * u;
         if (GRAD) {
             const double dz = (kind == TVK_A2) ? z : 0.0, dH = (kind == TVK_SIG) ? 2.0 * H : 0.0;
@@ -373,9 +375,9 @@ struct TvEsealOps {
             const double diF = -iF * iF * dF;
             L.gld += dF * iF;
             L.gq += 0.5 * diF * u * u + iF * u * du;
-            const double dk = (L.dp * z + L.p * dz) * iF + L.p * z * diF;
+            const double dk = iF * (z * c * L.dp + L.p * (c - z * z * pb) * dz - z * pb * dH);
             L.tx = L.tx + ddrift + dk * u + k * du;
-            L.dp = L.dp * c - L.p * (dk * z + k * dz) + dq;
+            L.dp = L.dp * c * c + dH * z * z * pb * pb - 2.0 * z * dz * L.p * pb * c + dq;
         }
         L.x = L.x + drift + k * u;                                     // lines 176, 188, 199
         L.p = L.p * c + q;                                             // lines 177, 189, 201-202

@@ -1,0 +1,115 @@
+"""GPU suite: rows (f)1 / (f)2 at parity grade -- the Laplace marginal through the C ABI (ssde_laplace_eval, what
+`random = "coeff_re"` makes tmb_obj$fn / $gr be, R/sde.R:510-525, 656-658) and the sdreport quantities built on the
+device gradient, against EXACT references that share nothing with the engine: the dense joint-Gaussian / Normal-density
+restatements of tests/refimpl.py under torch autograd (exact Hessians, tight inner solves).
+
+Tolerances: marginal value 1e-6 relative (the engine's H_uu is a central difference of the device gradient), u_hat 1e-5,
+marginal gradient 1e-4 of its largest entry (its log-determinant term is a difference of differenced Hessians),
+Hessian blocks 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from cases import problem_from_spec
+from golden_io import load_golden
+from refimpl import direct_nllk, kalman_dense_nllk, penalty
+from smoothsde_amd import capi
+from smoothsde_amd.report import sdreport
+from test_laplace import _exact_laplace
+
+pytestmark = pytest.mark.gpu
+GOLD = {r["name"]: r for r in load_golden()}
+
+
+def _split(pb):
+    ir = [k for k in range(pb.off_re, pb.off_re + pb.n_re) if not pb.par_fixed[k]]
+    io = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and k not in ir]
+    return io, ir
+
+
+@pytest.mark.parametrize("name", ["OU_d1_tv", "BM_SSM_d1_tv", "CTCRW_d1_tv"])
+def test_laplace_marginal_through_the_c_abi_matches_exact_laplace(name):
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    io, ir = _split(pb)
+    eng = capi.Engine(pb)
+    f, g, p_hat, H = eng.laplace_eval(par, order=1, want_hessian=True)
+    f_exact, u_exact = _exact_laplace(pb, par, ir)
+    assert abs(f - f_exact) <= 1e-6 * max(1.0, abs(f_exact)), (f, f_exact)
+    assert np.max(np.abs(p_hat[ir] - u_exact)) <= 1e-5
+    assert np.array_equal(p_hat[io], par[io])                      # outer entries untouched
+    assert np.all(g[ir] == 0.0) and np.all(g[pb.par_fixed != 0] == 0.0)
+    # H_uu at u_hat against the autograd Hessian of the dense restatement
+    p0 = torch.tensor(p_hat)
+
+    def joint_u(u):
+        p = p0.clone()
+        p[ir] = u
+        return (kalman_dense_nllk(pb, p) if pb.kalman else direct_nllk(pb, p)) + penalty(pb, p)
+
+    H_exact = torch.autograd.functional.hessian(joint_u, torch.tensor(p_hat[ir])).numpy()
+    assert np.allclose(H, H_exact, rtol=1e-5, atol=1e-6 * np.max(np.abs(H_exact)))
+    # gradient of the marginal: central differences of the EXACT marginal (each with its own exact inner solve)
+    g_exact = np.zeros(len(io))
+    for j, k in enumerate(io):
+        e = 1e-3 * max(1.0, abs(par[k]))
+        pp, pm = p_hat.copy(), p_hat.copy()
+        pp[k] += e
+        pm[k] -= e
+        g_exact[j] = (_exact_laplace(pb, pp, ir)[0] - _exact_laplace(pb, pm, ir)[0]) / (2 * e)
+    assert np.max(np.abs(g[io] - g_exact)) <= 1e-4 * max(1.0, np.max(np.abs(g_exact))), (g[io], g_exact)
+    # warm start: a second call from u_hat needs far fewer evaluations and returns the same marginal
+    n0 = eng.info()["n_evals"]
+    f2, _, _ = eng.laplace_eval(p_hat, order=0)
+    assert abs(f2 - f) <= 1e-9 * max(1.0, abs(f)) and eng.info()["n_evals"] - n0 <= 2 * (2 * len(ir) + 4)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["OU_d1_tv", "CTCRW_d1_tv"])
+def test_sdreport_quantities_on_the_device_gradient_match_autograd_hessians(name):
+    """cov.fixed / jointPrecision (R/sde.R:702-704, 871-882, 1360-1375) from finite differences of the HIP gradient
+    against the exact joint Hessian (torch autograd of the dense restatement)."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    free = pb.free_index()
+    ir = np.array([k for k in free if pb.off_re <= k < pb.off_re + pb.n_re])
+    io = np.array([k for k in free if k not in set(ir.tolist()) and not (pb.off_lambda <= k < pb.off_lambda + pb.n_smooth)])
+    eng = capi.Engine(pb)
+    rep = sdreport(pb, lambda p: eng.eval(p, order=1), par, io, ir, marginal_fn=None)
+    idx = np.concatenate([io, ir])
+    p0 = torch.tensor(par)
+
+    def joint_t(x):
+        p = p0.clone()
+        p[list(idx)] = x
+        return (kalman_dense_nllk(pb, p) if pb.kalman else direct_nllk(pb, p)) + penalty(pb, p)
+
+    H = torch.autograd.functional.hessian(joint_t, torch.tensor(par[idx])).numpy()
+    nf = len(io)
+    scale = np.max(np.abs(H))
+    assert np.allclose(rep.jointPrecision[nf:, nf:], H[nf:, nf:], rtol=1e-5, atol=1e-6 * scale)
+    assert np.allclose(rep.jointPrecision[:nf, nf:], H[:nf, nf:], rtol=1e-5, atol=1e-6 * scale)
+    schur = H[:nf, :nf] - H[:nf, nf:] @ np.linalg.solve(H[nf:, nf:], H[nf:, :nf])
+    assert np.allclose(rep.hessian_fixed, schur, rtol=1e-4, atol=1e-5 * scale)
+    assert np.allclose(rep.cov_fixed, np.linalg.inv(schur), rtol=1e-3, atol=1e-5 * np.max(np.abs(np.linalg.inv(schur))))
+    eng.close()
+    # without random effects cov.fixed is the inverse Hessian of the objective itself
+    rec = GOLD["CTCRW_d2_const"] if "CTCRW_d2_const" in GOLD else next(r for r in GOLD.values() if r["name"].startswith("CTCRW") and "const" in r["name"])
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    io = pb.free_index()
+    eng = capi.Engine(pb)
+    rep = sdreport(pb, lambda p: eng.eval(p, order=1), par, io, np.array([], dtype=int))
+    p0 = torch.tensor(par)
+
+    def obj(x):
+        p = p0.clone()
+        p[list(io)] = x
+        return kalman_dense_nllk(pb, p) + penalty(pb, p)
+
+    H = torch.autograd.functional.hessian(obj, torch.tensor(par[io])).numpy()
+    assert np.allclose(rep.hessian_fixed, H, rtol=1e-5, atol=1e-6 * np.max(np.abs(H)))
+    assert np.allclose(rep.cov_fixed, np.linalg.inv(H), rtol=1e-4, atol=1e-6 * np.max(np.abs(np.linalg.inv(H))))
+    eng.close()

@@ -80,8 +80,10 @@ def test_single_long_track_uses_verified_windows(na_frac):
     oval, ograd = _oracle(pb, par)
     _close(val, grad, oval, ograd)
     # repeated and value-only evaluations are bitwise identical / consistent
+    eng.forget()
     v2, g2 = eng.eval(par)
     assert v2 == val and np.array_equal(g2, grad)
+    eng.forget()
     assert abs(eng.eval(par, order=0) - val) <= 1e-12 * abs(val)
     # a different parameter vector (the plan of the previous evaluation is reused)
     par2 = par + 0.05 * np.cos(np.arange(len(par)))
@@ -168,6 +170,7 @@ def test_custom_a0_and_report():
     _close(val, grad, oval, ograd)
     aest = eng.report(par)
     assert np.allclose(aest, oaest, rtol=1e-10, atol=1e-10, equal_nan=True)
+    eng.forget()
     v2, g2 = eng.eval(par)       # evaluating after a report gives the same answer
     assert v2 == val and np.array_equal(g2, grad)
     eng.close()
