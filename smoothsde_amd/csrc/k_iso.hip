@@ -35,6 +35,12 @@ namespace ssde {
 #define SSDE_ISO_U 4
 #endif
 constexpr int ISO_U = SSDE_ISO_U;
+#ifndef SSDE_ISO_WAVES
+#define SSDE_ISO_WAVES 2        // waves per SIMD the general kernels are built for
+#endif
+#ifndef SSDE_ISO_WAVES_SCAL
+#define SSDE_ISO_WAVES_SCAL 2   // ... the scalar-covariance models (OU_SSM, BM_SSM)
+#endif
 static_assert(ISO_U % TILE_U == 0 && WIN_ALIGN % (2 * ISO_U) == 0 && 3 * ISO_U <= TILE_SPARE, "prefetch block");
 
 // register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
@@ -68,10 +74,16 @@ struct LaneOps<M_CTCRW, D, MASK> {
         for (int a = 0; a < D; a++) { a0[2 * a] = (y[a] == y[a]) ? y[a] : 0.0; a0[2 * a + 1] = 0.0; }
         S.init(a0, A.p0[0], A.p0[1], A.p0[2]);
     }
-    __device__ static __forceinline__ void step(State& S, Trans& tr, const IsoArgs& A, bool uni, const double* mu,
-                                                const double* row) {
-        if (!uni) ctcrw_trans(row[0], A.tau, A.beta, A.sigma, tr);
-        ctcrw_step<D, MASK>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+    // UNI: regular grid -- the transition is the one of the kernel arguments (scalar registers), the dt slot is not read
+    template <bool UNI>
+    __device__ static __forceinline__ void step(State& S, const IsoArgs& A, const double* mu, const double* row) {
+        if (UNI) {
+            ctcrw_step<D, MASK>(S, A.ctr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+        } else {
+            Trans tr;
+            ctcrw_trans(row[0], A.tau, A.beta, A.sigma, tr);
+            ctcrw_step<D, MASK>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+        }
     }
     __device__ static __forceinline__ void finish(const State& S, double* out) { ctcrw_finish<D, MASK>(S, out); }
 };
@@ -89,13 +101,16 @@ struct LaneOps {  // OU_SSM / BM_SSM
         for (int a = 0; a < D; a++) a0[a] = (y[a] == y[a]) ? y[a] : 0.0;
         S.init(a0, A.p0[0]);
     }
-    __device__ static __forceinline__ void step(State& S, Trans& tr, const IsoArgs& A, bool uni, const double* mu,
-                                                const double* row) {
-        if (!uni) {
+    template <bool UNI>
+    __device__ static __forceinline__ void step(State& S, const IsoArgs& A, const double* mu, const double* row) {
+        if (UNI) {
+            scal_step<D, MASK, MODEL == M_OU_SSM>(S, A.str, A.h, mu, row + 1, is_na(row[1], A.any_nan));
+        } else {
+            Trans tr;
             if (MODEL == M_OU_SSM) ou_trans(row[0], A.tau, A.sigma, tr);
             else bm_trans(row[0], A.sigma, tr);
+            scal_step<D, MASK, MODEL == M_OU_SSM>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
         }
-        scal_step<D, MASK, MODEL == M_OU_SSM>(S, tr, A.h, mu, row + 1, is_na(row[1], A.any_nan));
     }
     __device__ static __forceinline__ void finish(const State& S, double* out) { scal_finish<D, MASK>(S, out); }
 };
@@ -130,7 +145,7 @@ struct DeriveOps {
     }
 };
 
-template <int MODEL, int D, int MASK, int DER = -1>
+template <int MODEL, int D, int MASK, bool UNI, int DER = -1>
 __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
     typedef LaneOps<MODEL, D, MASK> Ops;
     constexpr int C = 1 + D;
@@ -149,8 +164,6 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end, A.t0_delta);
 
     typename Ops::State S;
-    typename Ops::Trans tr = Ops::hoisted(A);
-    const bool uni = A.uniform_dt != 0;
     double mu[D];
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
@@ -175,11 +188,11 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     auto run_block = [&](const double (&blk)[ISO_U][C], int s0) {
         if (s0 + ISO_U <= ns_min) {          // every lane's track covers the block: no per-row predication
 #pragma unroll
-            for (int u = 0; u < ISO_U; u++) Ops::step(S, tr, A, uni, mu, blk[u]);
+            for (int u = 0; u < ISO_U; u++) Ops::template step<UNI>(S, A, mu, blk[u]);
         } else {
 #pragma unroll
             for (int u = 0; u < ISO_U; u++)
-                if (s0 + u < ns) Ops::step(S, tr, A, uni, mu, blk[u]);
+                if (s0 + u < ns) Ops::template step<UNI>(S, A, mu, blk[u]);
         }
     };
     auto handover = [&](int s0) {
@@ -231,9 +244,9 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     }
 }
 
-// One kernel per direction mask when the whole launch uses a single mask (n_parts == 1, the default):
-// a kernel's register allocation is the worst case over everything it contains.
-template <int MODEL, int D, int MASK>
+// One kernel per (direction mask, regular / irregular grid) when the whole launch uses a single mask (n_parts == 1, the
+// default): a kernel's register allocation is the worst case over everything it contains.
+template <int MODEL, int D, int MASK, bool UNI>
 __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
@@ -241,26 +254,23 @@ __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (!group_selected(A, g)) return;
     constexpr int DERJ = (MODEL == M_BM_SSM) ? 1 : 2;
     constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
-    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), DERJ>(A, g, part, chunk);
-    else run_lane<MODEL, D, MASK>(A, g, part, chunk);
+    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), UNI, DERJ>(A, g, part, chunk);
+    else run_lane<MODEL, D, MASK, UNI>(A, g, part, chunk);
 }
 
-// CTCRW: one wave per SIMD with the whole register file (its 20 + 12 recursions spill under any cap, and that
-// many independent chains keep the fp64 pipe busy from a single wave).
-template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_mask_kernel(const IsoArgs A) {
-    iso_mask_body<MODEL, D, MASK>(A);
+// Two waves per SIMD (256 registers each): a lone wave leaves the fp64 pipe idle behind its dependent instructions
+// and its loads (measured 4.5-5.4 cycles per wave-instruction against the pipe's 4); the engine plans twice as many
+// time windows for the general kernel (ssde_engine.hip).  With the transition of a regular grid in scalar registers
+// and the fused step of ssde_math.hpp the CTCRW lanes fit as well (they did not in round 1: one wave, 416 + 160
+// registers, a fifth of the issue slots spent on AGPR copies).
+// (CTCRW on an irregular grid carries a per-row transition -- 16 more doubles per lane and an exp -- and spills under
+// that cap: one wave per SIMD with the whole register file, as before.)
+template <int MODEL, int D, int MASK, bool UNI>
+__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_ISO_WAVES : 1) : SSDE_ISO_WAVES_SCAL) void iso_mask_kernel(const IsoArgs A) {
+    iso_mask_body<MODEL, D, MASK, UNI>(A);
 }
 
-// BM_SSM / OU_SSM: a scalar covariance and few chains per row -- one wave leaves the pipe idle behind its
-// dependent instructions and its loads, so these run two waves per SIMD (256 registers each; the engine plans
-// twice as many time windows for them, ssde_engine.hip).
-template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void iso_mask_light_kernel(const IsoArgs A) {
-    iso_mask_body<MODEL, D, MASK>(A);
-}
-
-// Direction-split launches (several parts with different masks) keep the masks in one kernel.
+// Direction-split launches (several parts with different masks; a testing path) keep the masks in one kernel.
 template <int MODEL, int D>
 __global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
@@ -269,8 +279,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
     if (!group_selected(A, g)) return;
     // (no dynamic indexing into the by-value argument block: that would force a scratch copy)
     const int mask = part == 0 ? A.part_mask[0] : part == 1 ? A.part_mask[1] : part == 2 ? A.part_mask[2] : A.part_mask[3];
+    const bool uni = A.uniform_dt != 0;
     switch (mask) {
-#define SSDE_CASE(M) case M: run_lane<MODEL, D, M>(A, g, part, chunk); break;
+#define SSDE_CASE(M) case M: if (uni) run_lane<MODEL, D, M, true>(A, g, part, chunk); else run_lane<MODEL, D, M, false>(A, g, part, chunk); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE
@@ -281,11 +292,12 @@ __global__ __launch_bounds__(WG_WAVES * WAVE) void iso_kernel(const IsoArgs A) {
 template <int MODEL, int D>
 static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
     dim3 block(WG_WAVES * WAVE);
+    const bool uni = a.uniform_dt != 0;
     switch (a.part_mask[0]) {
 #define SSDE_CASE(M)                                                                                          \
     case M:                                                                                                   \
-        if constexpr (MODEL == M_CTCRW) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((iso_mask_light_kernel<MODEL, D, M>), grid, block, 0, s, a);                   \
+        if (uni) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M, true>), grid, block, 0, s, a);              \
+        else hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M, false>), grid, block, 0, s, a);                 \
         break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)

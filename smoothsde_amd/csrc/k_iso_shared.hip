@@ -175,7 +175,7 @@ struct SharedScal {
     }
     __device__ __forceinline__ void step_table(const double* __restrict__ row, const double* mu, const double* y) {
         ScalGain G;
-        G.iF = row[0]; G.k = row[1];
+        G.iF = row[0]; G.k = row[1]; G.c = row[2];
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) { G.diF[j] = row[4 + j]; G.dk[j] = row[7 + j]; }
         scal_mean_step<D, MASK, HAS_P2>(M, tr, G, mu, y, G.iF != 0.0);
@@ -635,7 +635,7 @@ void fill_stat_consts(int model, int d, IsoArgs& a) {
         c[47] = 1.0 - k2 * dt / D1;                           // d v / d mu_a
     } else {
         const ScalTrans& tr = a.str;
-        c[0] = r[0]; c[1] = r[1]; c[2] = tr.t - r[1]; c[3] = tr.t; c[4] = tr.b; c[5] = tr.dt_;
+        c[0] = r[0]; c[1] = r[1]; c[2] = r[2]; c[3] = tr.t; c[4] = tr.b; c[5] = tr.dt_;
         for (int j = 0; j < NDIRP; j++) { c[10 + j] = 0.5 * r[4 + j]; c[13 + j] = r[7 + j]; }
         for (int k = 0; k < d; k++) { c[19 + k] = tr.b * a.mu[k]; c[21 + k] = tr.db * a.mu[k]; }
     }

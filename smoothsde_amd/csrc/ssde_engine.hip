@@ -6,6 +6,8 @@
 // There is no CPU evaluation path in this library: without a gfx950 device ssde_create fails.
 #include "ssde_engine.hpp"
 
+#include <chrono>
+
 namespace ssde_engine {
 thread_local std::string g_create_error;
 }  // namespace ssde_engine
@@ -24,6 +26,11 @@ namespace ssde_engine {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
+    if (h->trace && h->trace_n > 0)
+        fprintf(stderr, "[ssde trace] %lld isotropic evaluations, host us per evaluation: plan %.1f | gain table %.1f | main launch %.1f | "
+                        "finalize launch %.1f | read-back (blocks until the GPU is done) %.1f\n", (long long)h->trace_n,
+                h->trace_us[0] / h->trace_n, h->trace_us[1] / h->trace_n, h->trace_us[2] / h->trace_n, h->trace_us[3] / h->trace_n,
+                h->trace_us[4] / h->trace_n);
     destroy_dist(h);
     h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
@@ -136,6 +143,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
     if (const char* e = getenv("SSDE_T0_COST")) h->env_t0_cost = atof(e);
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
+    h->trace = getenv("SSDE_TRACE") != nullptr;
     h->sdim = state_dim(d->model, d->n_dim);
     h->na_any = d->na_mode == SSDE_NA_ANY_NAN;
     h->has_h = is_kalman(d->model) && d->h_array != nullptr;
@@ -546,7 +554,8 @@ int build(const ssde_desc* d, ssde_handle* h) {
             int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
             // ... except for the scalar-covariance models on the general kernel (irregular grid or missing rows in
             // most groups): too few independent chains per row for one wave, so two waves per SIMD (k_iso.hip)
-            if (h->model != SSDE_MODEL_CTCRW && (!h->uniform_dt || 2 * h->n_clean_groups < G) && !getenv("SSDE_NO_LIGHT2"))
+            // (k_iso.hip: every general kernel but CTCRW's irregular-grid one is built for two waves per SIMD)
+            if (!(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || 2 * h->n_clean_groups < G) && !getenv("SSDE_NO_LIGHT2"))
                 want = std::max(1, 2048 / (((G + 7) / 8 * 8) * h->iso_parts));
             if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
@@ -740,7 +749,7 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
             else scal_cov_step<D, 15, false>(C, a.str, a.h, false, G);
             double* r = host + (size_t)t * GAIN_ROW;
             for (int k = 0; k < GAIN_ROW; k++) r[k] = 0.0;
-            r[0] = G.iF; r[1] = G.k;
+            r[0] = G.iF; r[1] = G.k; r[2] = G.c;
             for (int j = 0; j < NDIRP; j++) { r[4 + j] = G.diF[j]; r[7 + j] = G.dk[j]; }
             ld += (G.iF != 0.0) ? std::log(std::fabs(F)) : 0.0;
             cum_ld.push_back(ld);
@@ -845,7 +854,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             a.sigma = exp(p1);
             if (h->uniform_dt) bm_trans(h->dt_uniform, a.sigma, a.str);
         }
+        auto tick = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tk0 = h->trace ? tick() : 0.0;
         plan_windows(h, a, &a.n_chunks, &a.window);
+        if (h->trace) { const double t = tick(); h->trace_us[0] += t - tk0; tk0 = t; }
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         a.chk_out = out_dev + (1 + L.n_full);
         a.derive = h->env_no_derive ? 0 : 1;
@@ -858,6 +870,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             int st = (h->d == 1) ? build_gain_table<1>(h, a, h->iso_free_mask, s, add)
                                  : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
             if (st) return st;
+            if (h->trace) { const double t = tick(); h->trace_us[1] += t - tk0; tk0 = t; }
             a.group_mode = 3;
             // the covariance transient gets its own short window [0, t0): every other window (warm-up
             // included) then lies in the stationary regime and runs the lean kernel
@@ -909,6 +922,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             h->ev_k_valid = true;
             h->last_s_stat = -1;
         }
+        if (h->trace) { const double t = tick(); h->trace_us[2] += t - tk0; tk0 = t; }
         for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
         if (h->use_shared) {
             ra.add_slot[0] = 0;
@@ -931,6 +945,14 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         }
         // the hand-over checks and the final sums in one launch
         HIPCHK(h, launch_iso_finalize(h->model, h->d, a, ra, s));
+        if (h->trace) {
+            const double t = tick(); h->trace_us[3] += t - tk0; h->trace_n++;
+            if (h->trace_skip < 8) {                        // the first calls load code objects: not what is being measured
+                h->trace_skip++;
+                for (double& v : h->trace_us) v = 0.0;
+                h->trace_n = 0;
+            }
+        }
         return SSDE_OK;
     } else if (h->path == PATH_DENSE) {
         const double* pdev = nullptr;
@@ -1125,8 +1147,12 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
     }
     int st = eval_device(h, par, order, h->out.p, 0);
     if (st) return st;
-    // (a host-mapped mirror written by the finalising launch was tried instead of this copy: 20 us slower)
+    const auto t0 = std::chrono::steady_clock::now();
+    // Measured twice (rounds 1 and 2) and slower both times by ~10 us: letting the finalising launch write the result
+    // into host-visible pinned memory -- as a mirror read after a synchronisation, or with a sequence word the host
+    // spins on ("last workgroup publishes", system-scope release) -- instead of this blocking 48-byte copy.
     HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
+    if (h->trace) h->trace_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return SSDE_OK;
 }
 

@@ -209,6 +209,12 @@ struct ssde_handle {
     double memo_value = 0.0;
     int memo_order = -1;                      // -1 = nothing memoised
     int64_t n_evals = 0, n_memo_hits = 0;
+    // host-side phase clock of the isotropic path (SSDE_TRACE=1 at create; printed at destroy): plan, gain table,
+    // main launch(es), finalize launch, read-back
+    bool trace = false;
+    double trace_us[6] = {0, 0, 0, 0, 0, 0};
+    int64_t trace_n = 0;
+    int trace_skip = 0;
 };
 
 

@@ -87,6 +87,9 @@ struct CtcrwTrans {
     double e, t12, b1, b2, q11, q12, q22;  // makeT/B/Q_ctcrw entries for one interval
     double de, dt12, dq11, dq12, dq22;     // d/d(log tau); db1 = -dt12, db2 = -de
                                            // d/d(log nu): dq = 2 q, everything else 0
+    // products the fused step (ctcrw_step) uses every row: on a regular grid they arrive with the kernel arguments
+    // and stay in scalar registers
+    double e2, dt12x2, dt12e, edex2;       // e^2, 2 dt12, dt12 e, 2 e de
 };
 
 // tau = exp(par_tau), beta = 1/tau, sigma = 2 nu / sqrt(pi tau)   (nllk_ctcrw.hpp:152-156)
@@ -112,6 +115,7 @@ SSDE_HD void ctcrw_trans(double dt, double tau, double beta, double sigma, Ctcrw
     o.dq11 = o.q11 + A * tau * dG;
     o.dq12 = o.q12 - A * ome * edt;
     o.dq22 = -A * e2 * beta * dt;
+    o.e2 = e2; o.dt12x2 = 2.0 * o.dt12; o.dt12e = o.dt12 * e; o.edex2 = 2.0 * e * o.de;
 }
 
 // The step is split in two halves:
@@ -288,12 +292,108 @@ struct CtcrwLane {
 
 // One row of a track: score y (unless NA), then propagate over the interval described by tr.
 //   h = sigma_obs^2; mu[a] = mean velocity; na = obs(i,0) is NA (nllk_ctcrw.hpp:214)
+// The general register kernel's step (k_iso.hip): both halves fused and arranged for fp64 issue, which is what bounds
+// that kernel.  Same numbers as ctcrw_cov_step + ctcrw_mean_step up to rounding, but
+//   * the covariance update is taken in the filtered form  P~ = P - P z z' P / F,  P' = T P~ T' + Q  with
+//     P~11 = p11 h/F, P~12 = p12 h/F, P~22 = p22 - p12^2/F  (nllk_ctcrw.hpp:236-241 multiplied out): fewer products
+//     than T P (T - K Z)', and no 1 - k1 cancellation once P >> H;
+//   * its sensitivities in the Joseph form  dP~ = A dP A' + kk' dh,  A = I - k z' = [[a, 0], [-k2~, 1]], a = h/F,
+//     then dP' = T dP~ T' + (dT P~ T' + T P~ dT') + dQ;
+//   * a missing row needs no per-quantity select: iF = 0 makes k~, every gain and every gain sensitivity vanish and
+//     a = 1, so the update formulas ARE the prediction formulas; only F, the 0/1 flag and y are selected;
+//   * d/d mu_a of the state is the same (data-independent) number for every dimension a: one chain.
 template <int D, int MASK>
 SSDE_HD void ctcrw_step(CtcrwLane<D, MASK>& L, const CtcrwTrans& tr, double h, const double* mu, const double* y,
                         bool na) {
-    CtcrwGain G;
-    ctcrw_cov_step<D, MASK>(L.C, tr, h, na, G);
-    ctcrw_mean_step<D, MASK>(L.M, tr, G, mu, y, G.iF != 0.0);
+    CtcrwCov<MASK>& C = L.C;
+    CtcrwMean<D, MASK>& M = L.M;
+    const double F = C.p11 + h;                                // F = Z P Z' + H (line 223), scalar per dimension
+    const double detF = (D == 1) ? F : F * F;                  // det(): lines 16-19
+    const bool upd = !na && !(detF <= 0.0);                    // lines 214, 226 (a NaN takes the update branch)
+    const double updf = upd ? 1.0 : 0.0;
+    const double Fe = upd ? F : 1.0;
+    const double iF = rcp(Fe) * updf;
+    C.ld.mul(Fe);                                              // log(detF) = D log|F| (line 234)
+    C.nupd += updf;
+    const double bm = (na || upd) ? 1.0 : 0.0;                 // Q3: detF <= 0 predicts WITHOUT B mu (lines 226-228)
+    const double e = tr.e, t12 = tr.t12, e2 = tr.e2;
+    // ---- covariance, primal ------------------------------------------------------------------------------------
+    const double a = fma(h, iF, 1.0 - updf);                   // h / F (1 on a row that is not scored)
+    const double kf1 = C.p11 * iF, kf2 = C.p12 * iF;           // filter gain P z / F
+    const double f11 = C.p11 * a, f12 = C.p12 * a, f22 = fma(-C.p12, kf2, C.p22);   // P~
+    const double m = fma(t12, f22, f12);
+    const double k1 = fma(t12, kf2, kf1), k2 = e * kf2;        // K = T P z / F (line 236)
+    const double c1 = 1.0 - k1;
+    // ---- residuals ------------------------------------------------------------------------------------------------
+    double u[D], mue[D];
+    double su2 = 0.0;
+    for (int a_ = 0; a_ < D; a_++) {
+        const double ys = upd ? y[a_] : M.x[a_];               // (a missing y is NaN: keep it out of the arithmetic)
+        u[a_] = ys - M.x[a_];                                  // line 221
+        su2 = fma(u[a_], u[a_], su2);
+        mue[a_] = bm * mu[a_];
+    }
+    M.accq = fma(iF, su2, M.accq);                             // u' F^-1 u
+    const double w2 = -0.5 * iF * iF, aiF = a * iF;
+    // ---- covariance-affecting directions ----------------------------------------------------------------------
+    for (int j = 0; j < NDIRP; j++) {
+        if (!(MASK & dir_bit(j))) continue;
+        const double d11 = C.d11[j], d12 = C.d12[j], d22 = C.d22[j];
+        const double h2 = 2.0 * h;
+        const double dF = (j == 0) ? d11 + h2 : d11;
+        C.gld[j] = fma(dF, iF, C.gld[j]);
+        const double w = fma(-kf2, d11, d12);
+        double g11 = a * a * d11, g12 = a * w, g22 = fma(-kf2, d12 + w, d22);        // dP~ = A dP A'
+        double dkf1 = d11 * aiF, dkf2 = w * iF;                                      // d(P z / F)
+        if (j == 0) {                                                               // ... + k k' dh, - k dh / F
+            const double q1 = kf1 * h2, q2 = kf2 * h2;
+            g11 = fma(kf1, q1, g11); g12 = fma(kf2, q1, g12); g22 = fma(kf2, q2, g22);
+            dkf1 = fma(-q1, iF, dkf1); dkf2 = fma(-q2, iF, dkf2);
+        }
+        const double dm = fma(t12, g22, g12);
+        double n11 = fma(t12, g12 + dm, g11), n12 = e * dm, n22 = e2 * g22;          // T dP~ T'
+        double dk1 = fma(t12, dkf2, dkf1), dk2 = e * dkf2;
+        if (j == 1) {                                                               // only log tau moves T
+            const double dt12 = tr.dt12, de = tr.de;
+            n11 = fma(tr.dt12x2, m, n11) + tr.dq11;
+            n12 = fma(tr.dt12e, f22, fma(de, m, n12)) + tr.dq12;
+            n22 = fma(tr.edex2, f22, n22) + tr.dq22;
+            dk1 = fma(dt12, kf2, dk1); dk2 = fma(de, kf2, dk2);
+        }
+        if (j == 2) { n11 = fma(2.0, tr.q11, n11); n12 = fma(2.0, tr.q12, n12); n22 = fma(2.0, tr.q22, n22); }
+        C.d11[j] = n11; C.d12[j] = n12; C.d22[j] = n22;
+        // mean half of the direction (lines 221, 231-234, 238 differentiated)
+        double sud = 0.0;
+        for (int a_ = 0; a_ < D; a_++) {
+            const double tx = M.tx[j][a_], tv = M.tv[j][a_];
+            sud = fma(u[a_], tx, sud);
+            double nx = fma(dk1, u[a_], fma(t12, tv, c1 * tx));
+            double nv = fma(dk2, u[a_], fma(e, tv, -k2 * tx));
+            if (j == 1) {                                      // d(B mu) = -(dt12, de) mu
+                const double wv = M.v[a_] - mue[a_];
+                nx = fma(tr.dt12, wv, nx); nv = fma(tr.de, wv, nv);
+            }
+            M.tx[j][a_] = nx; M.tv[j][a_] = nv;
+        }
+        M.gq[j] = fma(w2 * dF, su2, fma(-iF, sud, M.gq[j]));     // 1/2 dF^-1 |u|^2 + F^-1 u' du,  du = -tx
+    }
+    if (MASK & DIR_MU) {
+        const double mx = M.mx[0], mv = M.mv[0], imx = iF * mx;
+        const double nx = fma(bm, tr.b1, fma(t12, mv, c1 * mx)), nv = fma(bm, tr.b2, fma(e, mv, -k2 * mx));
+        for (int a_ = 0; a_ < D; a_++) {
+            M.gmu[a_] = fma(-imx, u[a_], M.gmu[a_]);
+            M.mx[a_] = nx; M.mv[a_] = nv;
+        }
+    }
+    // ---- state and covariance, primal update ------------------------------------------------------------------
+    for (int a_ = 0; a_ < D; a_++) {                           // a = T a + K u + B mu (line 238)
+        const double nx = fma(tr.b1, mue[a_], fma(k1, u[a_], fma(t12, M.v[a_], M.x[a_])));
+        const double nv = fma(tr.b2, mue[a_], fma(k2, u[a_], e * M.v[a_]));
+        M.x[a_] = nx; M.v[a_] = nv;
+    }
+    C.p11 = fma(t12, f12 + m, f11) + tr.q11;                   // P = T P~ T' + Q (lines 240-241)
+    C.p12 = fma(e, m, tr.q12);
+    C.p22 = fma(e2, f22, tr.q22);
 }
 
 // totals: nllk contribution and gradient slots [sig, mu_0..mu_{D-1}, p1, p2]; the covariance
@@ -342,7 +442,7 @@ SSDE_HD void bm_trans(double dt, double sigma, ScalTrans& o) {
 }
 
 struct ScalGain {
-    double iF, k;
+    double iF, k, c;                 // c = t - k, the closed-loop factor (in its cancellation-free form t h / F)
     double diF[NDIRP], dk[NDIRP];
 };
 
@@ -362,33 +462,42 @@ template <int D, int MASK, bool HAS_P2>
 SSDE_HD void scal_cov_step(ScalCov<MASK>& C, const ScalTrans& tr, double h, bool na, ScalGain& G) {
     const double F = C.p + h;
     const bool upd = !na && !(fabs(F) <= 0.0);                 // (a NaN takes the update branch, as in the reference)
-    const double iF = upd ? rcp(F) : 0.0;
-    C.ld.mul(upd ? F : 1.0);
-    C.nupd += upd ? 1.0 : 0.0;
+    const double updf = upd ? 1.0 : 0.0;
+    const double Fe = upd ? F : 1.0;
+    const double iF = rcp(Fe) * updf;
+    C.ld.mul(Fe);
+    C.nupd += updf;
     // The literal update P = T P (T - K Z)' + Q (nllk_ou_ssm.hpp:205-206) is t p (t - k) + q with t - k = t (1 - p/F):
     // once p >> h the difference cancels to nothing and the next p is rounding noise times p.  The same numbers
-    // without the cancellation: with a = h/F, b = p/F (a + b = 1)
-    //     p'  = t^2 p a + q                                 k  = t b
-    //     dp' = t^2 (a^2 dp + b^2 dh) + 2 t dt p a + dq      dk = dt b + t (a dp - b dh) / F
-    // (d[p h / F] = (h^2 dp + p^2 dh) / F^2).  A missing row has a = 1, b = 0.
-    const double a = upd ? h * iF : 1.0, b = C.p * iF;
-    const double k = tr.t * b;
-    const double t2 = tr.t * tr.t, ta2 = t2 * a * a, tiF = tr.t * iF;
-    G.iF = iF; G.k = k;
+    // without the cancellation: with a = h/F, b = p/F (a + b = 1), c = t a the closed-loop factor
+    //     p'  = t c p + q                                    k  = t b
+    //     dp' = t c a dp + t^2 b^2 dh + 2 dt c p + dq         dk = (t/F) (a dp - b dh) + dt b
+    // (d[p h / F] = (h^2 dp + p^2 dh) / F^2).  A row that is not scored has iF = 0: a = 1, b = 0, and the update
+    // formulas are the prediction formulas -- no select beyond F and the 0/1 flag.
+    // (BM_SSM -- the model without a second scale parameter -- has t = 1 and dt = db = 0: folded at compile time)
+    const double t = HAS_P2 ? tr.t : 1.0, dt_ = HAS_P2 ? tr.dt_ : 0.0;
+    const double a = fma(h, iF, 1.0 - updf), b = C.p * iF;
+    const double c = t * a, k = t * b, tc = t * c;
+    const double tiF = t * iF, ca = tiF * a, tca = tc * a, cp = c * C.p;
+    G.iF = iF; G.k = k; G.c = c;
+    const double w2 = -iF * iF;
     for (int j = 0; j < NDIRP; j++) {
         if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) { G.diF[j] = G.dk[j] = 0.0; continue; }
-        const double dF = (j == 0) ? C.dp[j] + 2.0 * h : C.dp[j];
-        G.diF[j] = -iF * iF * dF;
-        C.gld[j] += dF * iF;
-        double dk = tiF * a * C.dp[j];
-        double np_ = ta2 * C.dp[j];
-        if (j == 0) { dk -= tiF * b * (2.0 * h); np_ += t2 * b * b * (2.0 * h); }
-        if (j == 1) { dk += tr.dt_ * b; np_ += 2.0 * tr.t * tr.dt_ * C.p * a + tr.dq; }
+        const double dp = C.dp[j];
+        const double dF = (j == 0) ? dp + 2.0 * h : dp;
+        G.diF[j] = w2 * dF;
+        C.gld[j] = fma(dF, iF, C.gld[j]);
+        double dk = ca * dp, np_ = tca * dp;
+        if (j == 0) { const double bh = b * (2.0 * h); dk = fma(-tiF, bh, dk); np_ = fma(k * t, bh, np_); }
+        if (j == 1) {
+            if (HAS_P2) { dk = fma(dt_, b, dk); np_ = fma(2.0 * dt_, cp, np_); }
+            np_ += tr.dq;
+        }
         if (j == 2) np_ += tr.q;
         G.dk[j] = dk;
         C.dp[j] = np_;
     }
-    C.p = t2 * C.p * a + tr.q;
+    C.p = fma(tc, C.p, tr.q);
 }
 
 template <int D, int MASK>
@@ -415,29 +524,33 @@ SSDE_HD void scal_mean_step(ScalMean<D, MASK>& M, const ScalTrans& tr, const Sca
                             const double* y, bool scored) {
     double u[D];
     double su2 = 0.0;
-    for (int a = 0; a < D; a++) { u[a] = scored ? y[a] - M.x[a] : 0.0; su2 += u[a] * u[a]; }
-    M.accq += G.iF * su2;
+    for (int a = 0; a < D; a++) {
+        const double ys = scored ? y[a] : M.x[a];              // (a missing y is NaN: keep it out of the arithmetic)
+        u[a] = ys - M.x[a];
+        su2 = fma(u[a], u[a], su2);
+    }
+    M.accq = fma(G.iF, su2, M.accq);
+    // x' = t x + k u + b mu;  tx' = (t - k) tx + dk u [+ dt_ x + db mu]: a row that is not scored has k = dk = 0
     for (int j = 0; j < NDIRP; j++) {
         if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
-        const double dt_ = (j == 1) ? tr.dt_ : 0.0, db = (j == 1) ? tr.db : 0.0;
         double sud = 0.0;
-        double du[D];
-        for (int a = 0; a < D; a++) { du[a] = scored ? -M.tx[j][a] : 0.0; sud += u[a] * du[a]; }
-        M.gq[j] += 0.5 * G.diF[j] * su2 + G.iF * sud;
         for (int a = 0; a < D; a++) {
-            double nx = tr.t * M.tx[j][a] + G.dk[j] * u[a] + G.k * du[a];
-            if (j == 1) nx += dt_ * M.x[a] + db * mu[a];
+            const double tx = M.tx[j][a];
+            sud = fma(u[a], tx, sud);
+            double nx = fma(G.dk[j], u[a], G.c * tx);
+            if (j == 1 && HAS_P2) nx = fma(tr.dt_, M.x[a], fma(tr.db, mu[a], nx));   // (BM_SSM: T = I, B = dt: no parameter in them)
             M.tx[j][a] = nx;
         }
+        M.gq[j] = fma(0.5 * G.diF[j], su2, fma(-G.iF, sud, M.gq[j]));
     }
-    if (MASK & DIR_MU) {
+    if (MASK & DIR_MU) {                                       // d x_a / d mu_a: the same number for every dimension
+        const double mx = M.mx[0], imx = G.iF * mx, nx = fma(G.c, mx, tr.b);
         for (int a = 0; a < D; a++) {
-            const double du = scored ? -M.mx[a] : 0.0;
-            M.gmu[a] += G.iF * u[a] * du;
-            M.mx[a] = tr.t * M.mx[a] + G.k * du + tr.b;
+            M.gmu[a] = fma(-imx, u[a], M.gmu[a]);
+            M.mx[a] = nx;
         }
     }
-    for (int a = 0; a < D; a++) M.x[a] = tr.t * M.x[a] + G.k * u[a] + tr.b * mu[a];
+    for (int a = 0; a < D; a++) M.x[a] = fma(tr.b, mu[a], fma(G.k, u[a], HAS_P2 ? tr.t * M.x[a] : M.x[a]));
 }
 
 template <int D, int MASK>

@@ -9,12 +9,12 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1
 echo "[collect] kernel stats done"
 find "$OUT/stats" -name "*kernel_trace*" -delete        # 10^5 records of the synthetic-data generator's kernels
-PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+PMCBENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ssde" -d "$OUT/pmc_fetch" -o fetch --output-format csv -- $PMCBENCH > "$OUT/pmc_fetch.log" 2>&1 || echo "[collect] FETCH_SIZE pass exited non-zero"
 echo "[collect] FETCH_SIZE done"
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ssde" -d "$OUT/pmc_write" -o write --output-format csv -- $PMCBENCH > "$OUT/pmc_write.log" 2>&1 || echo "[collect] WRITE_SIZE pass exited non-zero"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/summarise_profiles.py TAG -- turn gpurun_out/prof_TAG/ (written by tools/collect_profiles.sh on the GPU box)
 into the small files kept under profiles/: kernel statistics of this engine's kernels, per-dispatch PMC bytes,
-pmc_latest.json (read by bench.py for `roofline.traffic`), the bench line and the other configurations' timings."""
+pmc_latest.json (quoted by bench.py as `roofline.traffic_profiled`, with its tag), the bench line and the other configurations' timings."""
 import collections
 import csv
 import json
@@ -50,6 +50,7 @@ for k in fetch:
 main_bytes = per[main]["fetch_corrected"] + per[main]["write"]
 line = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
 pj = {
+    "tag": tag,
     "source": f"tools/collect_profiles.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, "
               "--kernel-include-regex ssde) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline; MI355X",
     "calibration": "tools/microbench_fetch.hip: 1 GiB read once with coalesced 8-B/lane loads -> FETCH_SIZE = 0.5 of the "
@@ -62,8 +63,10 @@ pj = {
     "note": "traffic < algorithmic because on a regular grid the dt channel (8 of the 24 B/row) is never read",
 }
 json.dump(pj, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
-line["roofline"]["traffic"] = main_bytes
-line["roofline"]["whole_evaluation"]["traffic"] = pj["hbm_bytes_per_launch"]
+# the PMC passes of THIS session (same box, same command minus the CPU baseline): recorded next to the line, under a
+# name that says where it comes from; bench.py itself never claims a traffic it did not measure
+line["roofline"]["traffic_profiled"] = {"main_kernel_bytes": main_bytes, "evaluation_bytes": pj["hbm_bytes_per_launch"],
+                                        "source": f"rocprofv3 --pmc passes of the same session ({tag})", "tag": tag}
 json.dump(line, open(pre + "bench_line.json", "w"))
 shutil.copy(os.path.join(src, "other_configs.txt"), pre + "other_configs.txt")
 shutil.copy(os.path.join(src, "tv_configs.txt"), pre + "tv_configs.txt")
