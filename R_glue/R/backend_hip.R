@@ -37,7 +37,13 @@ pp_table <- function(sm, x) {
 #' @param sde SDE object (after initialize)
 #' @param tmb_dat,tmb_par,map the lists SDE$setup has just assembled (R/sde.R:504-536, 621-632)
 #' @return list(par, fn, gr, he, report, env) shaped like TMB::MakeADFun's value
-make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
+#' @param random NULL (joint objective: every free entry is optimised, what tmb_obj_joint is, R/sde.R:666-668) or
+#'   "coeff_re": the returned fn / gr are the Laplace marginal over coeff_re (ssde_laplace_eval), log_lambda is a free
+#'   outer parameter, and env$last.par holds c(theta, u_hat) after every call -- the semantics of
+#'   MakeADFun(..., random = "coeff_re") at R/sde.R:656-658
+#' @param devices integer vector of HIP device ordinals: one R process, several GPUs (tracks sharded inside the engine,
+#'   one RCCL all-reduce per evaluation); NULL = the single device `device`
+make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NULL, devices = NULL) {
     mats <- sde$make_mat()                      # X_list_fe / X_list_re / S_list (R/sde.R:452-454)
     kalman <- sde$type() %in% c("BM_SSM", "OU_SSM", "CTCRW")
     eseal <- sde$type() == "ESEAL_SSM"          # leading parameters log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
@@ -51,11 +57,14 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
     off_fe <- if(kalman) 1 else if(eseal) 3 else 0
     if(!is.null(map$coeff_fe)) fixed[off_fe + which(is.na(map$coeff_fe))] <- TRUE
     if(kalman && !is.null(map$log_sigma_obs)) fixed[1] <- TRUE
-    if(has_re) {
-        # no Laplace layer in the engine (SURVEY 8(f)-1): smoothing parameters are held fixed
-        off_l <- off_fe + length(tmb_par$coeff_fe)
+    laplace <- has_re && identical(random, "coeff_re")
+    off_l <- off_fe + length(tmb_par$coeff_fe)
+    off_re <- length(par_full) - length(tmb_par$coeff_re)
+    if(has_re && !laplace) {
+        # joint objective at fixed smoothing parameters (log_lambda is not identifiable from the joint likelihood)
         fixed[off_l + seq_along(tmb_par$log_lambda)] <- TRUE
     }
+    if(has_re && !is.null(map$log_lambda)) fixed[off_l + which(is.na(map$log_lambda))] <- TRUE
     spec <- list(type = sde$type(), ID = as.numeric(sde$data()$ID), times = as.numeric(sde$data()$time),
                  obs = as.matrix(sde$obs()),
                  X_list_fe = lapply(seq_along(sde$formulas()), function(j) {
@@ -67,6 +76,7 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
                  a0 = tmb_dat$a0, P0 = tmb_dat$P0,
                  H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
                  par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device,
+                 devices = if(is.null(devices)) NULL else as.integer(devices),
                  other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL,
                  eseal_h = if(eseal) as.numeric(tmb_dat$h) else NULL, eseal_R = if(eseal) as.numeric(tmb_dat$R) else NULL,
                  t_decay = if(length(tmb_dat$t_decay) > 1) as.numeric(tmb_dat$t_decay) else NULL,
@@ -80,18 +90,31 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL) {
         spec$S_list <- lapply(seq_along(ncol_re), function(s) S[off[s] + seq_len(ncol_re[s]), off[s] + seq_len(ncol_re[s]), drop = FALSE])
     }
     ptr <- .Call("ssdeR_create", spec, PACKAGE = "smoothSDE")
-    free <- which(!fixed)
+    env <- new.env()
+    # with random = "coeff_re" the optimiser sees the outer parameters only; the engine integrates coeff_re out
+    is_u <- rep(FALSE, length(par_full))
+    if(laplace) is_u[off_re + seq_along(tmb_par$coeff_re)] <- !fixed[off_re + seq_along(tmb_par$coeff_re)]
+    free <- which(!fixed & !is_u)
     last <- new.env()
     eval_at <- function(x) {                    # fn(x) and gr(x) arrive separately with the same x
         if(is.null(last$x) || !identical(x, last$x)) {
             full <- par_full; full[free] <- x
-            last$res <- .Call("ssdeR_eval", ptr, full, 1L, PACKAGE = "smoothSDE")
+            if(laplace) {
+                if(!is.null(last$u)) full[is_u] <- last$u                          # warm start of the inner Newton solve
+                last$res <- .Call("ssdeR_laplace", ptr, full, 1L, PACKAGE = "smoothSDE")
+                last$u <- last$res$par[is_u]
+                env$last.par <- c(x, last$u)                                       # TMB's env$last.par: fixed, then random
+                if(is.null(env$value.best) || last$res$value < env$value.best) {
+                    env$value.best <- last$res$value; env$last.par.best <- env$last.par
+                }
+            } else {
+                last$res <- .Call("ssdeR_eval", ptr, full, 1L, PACKAGE = "smoothSDE")  # (the engine memoises on x as well)
+            }
             last$x <- x
         }
         last$res
     }
-    env <- new.env()
-    env$last.par.best <- par_full[free]
+    env$last.par.best <- c(par_full[free], par_full[is_u])
     list(par = par_full[free],
          fn = function(x = par_full[free]) eval_at(x)$value,
          gr = function(x = par_full[free]) matrix(eval_at(x)$gradient[free], nrow = 1),

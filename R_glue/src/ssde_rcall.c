@@ -11,6 +11,9 @@
  *   ssdeR_create(spec)              -> external pointer        (replaces MakeADFunObject)
  *   ssdeR_eval(ptr, par, order)     -> list(value=, gradient=) (replaces EvalADFunObject)
  *   ssdeR_report(ptr, par)          -> n x sdim matrix aest_all (replaces obj$report()$aest_all)
+ *   ssdeR_laplace(ptr, par, order)  -> list(value=, gradient=, par=, hessian.random=): the Laplace marginal over
+ *                                      coeff_re, i.e. what fn / gr ARE when MakeADFun gets random = "coeff_re"
+ *                                      (R/sde.R:510-525, 656-658); par comes back with coeff_re at u_hat
  *   ssdeR_info(ptr)                 -> named list
  */
 #include <R.h>
@@ -142,6 +145,15 @@ SEXP ssdeR_create(SEXP spec) {
     d.na_mode = SSDE_NA_R_ONLY;                                     /* R_IsNA semantics (nllk_ctcrw.hpp:214) */
     SEXP dev = get_elt(spec, "device");
     d.device = (dev == R_NilValue) ? -1 : Rf_asInteger(dev);
+    /* devices = c(0, 1, ..., 7): one R process, several GPUs -- whole tracks are sharded over them inside the engine
+     * and every evaluation ends in one ncclAllReduce of the 2 + p doubles (include/ssde.h: n_devices) */
+    SEXP devs = get_elt(spec, "devices");
+    if (devs != R_NilValue && Rf_xlength(devs) > 1) {
+        int nd = (int)Rf_xlength(devs);
+        int32_t *dl = (int32_t *)R_alloc(nd, sizeof(int32_t));
+        for (int k = 0; k < nd; k++) dl[k] = INTEGER(devs)[k];
+        d.n_devices = nd; d.devices = dl;
+    }
     ssde_handle *h = NULL;
     int st = ssde_create(&d, &h);
     if (st != SSDE_OK) Rf_error("ssde_create failed (%d): %s", st, ssde_last_error(NULL));
@@ -163,6 +175,28 @@ SEXP ssdeR_eval(SEXP ptr, SEXP par, SEXP order) {
     SET_VECTOR_ELT(out, 0, val); SET_VECTOR_ELT(out, 1, grad);
     Rf_setAttrib(out, R_NamesSymbol, nm);
     UNPROTECT(4);
+    return out;
+}
+
+SEXP ssdeR_laplace(SEXP ptr, SEXP par, SEXP order) {
+    ssde_handle *h = (ssde_handle *)R_ExternalPtrAddr(ptr);
+    if (!h) Rf_error("engine handle was destroyed (call $setup() again)");
+    int np = (int)Rf_xlength(par), ord = Rf_asInteger(order);
+    ssde_info_t inf;
+    ssde_info(h, &inf);
+    SEXP val = PROTECT(Rf_allocVector(REALSXP, 1)), grad = PROTECT(Rf_allocVector(REALSXP, np));
+    SEXP pout = PROTECT(Rf_duplicate(par));                         /* in/out: coeff_re <- u_hat */
+    /* n_u <= number of coeff_re entries; the engine fills the leading n_u x n_u block */
+    SEXP hess = PROTECT(Rf_allocMatrix(REALSXP, np, np));
+    memset(REAL(hess), 0, sizeof(double) * (size_t)np * np);
+    int st = ssde_laplace_eval(h, REAL(pout), np, ord, REAL(val), REAL(grad), REAL(hess), NULL);
+    if (st != SSDE_OK) { UNPROTECT(4); Rf_error("ssde_laplace_eval failed (%d): %s", st, ssde_last_error(h)); }
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 4)), nm = PROTECT(Rf_allocVector(STRSXP, 4));
+    SET_STRING_ELT(nm, 0, Rf_mkChar("value")); SET_STRING_ELT(nm, 1, Rf_mkChar("gradient"));
+    SET_STRING_ELT(nm, 2, Rf_mkChar("par")); SET_STRING_ELT(nm, 3, Rf_mkChar("hessian.random.packed"));
+    SET_VECTOR_ELT(out, 0, val); SET_VECTOR_ELT(out, 1, grad); SET_VECTOR_ELT(out, 2, pout); SET_VECTOR_ELT(out, 3, hess);
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(6);
     return out;
 }
 
@@ -196,6 +230,7 @@ SEXP ssdeR_info(SEXP ptr) {
 static const R_CallMethodDef ssde_calldefs[] = {
     {"ssdeR_create", (DL_FUNC)&ssdeR_create, 1},
     {"ssdeR_eval", (DL_FUNC)&ssdeR_eval, 3},
+    {"ssdeR_laplace", (DL_FUNC)&ssdeR_laplace, 3},
     {"ssdeR_report", (DL_FUNC)&ssdeR_report, 2},
     {"ssdeR_info", (DL_FUNC)&ssdeR_info, 1},
     {NULL, NULL, 0}};

@@ -216,6 +216,7 @@ typedef struct ssde_info_t {
     int64_t n_memo_hits;    /* ssde_eval calls answered from the memoised last result (same par, bitwise) */
     int32_t n_devices;      /* shards of a single-process multi-GPU handle (1 otherwise) */
     int32_t comm_ranks;     /* ranks of the RCCL communicator joined with ssde_comm_init_rank (1 = none) */
+    double  window_check_max; /* largest ACCEPTED hand-over disagreement over every ssde_eval since ssde_create */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the

@@ -72,7 +72,7 @@ class SsdeInfo(C.Structure):
         ("window", C.c_int32), ("window_retries", C.c_int32), ("window_check", C.c_double),
         ("main_kernel_ms", C.c_double), ("main_kernel_rows", C.c_int64),
         ("required_bytes_per_row", C.c_double), ("n_evals", C.c_int64), ("n_memo_hits", C.c_int64),
-        ("n_devices", C.c_int32), ("comm_ranks", C.c_int32),
+        ("n_devices", C.c_int32), ("comm_ranks", C.c_int32), ("window_check_max", C.c_double),
     ]
 
     def as_dict(self):

@@ -1204,6 +1204,7 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
             if (!h->shards.empty()) h->window_boost *= 4;
         }
     }
+    if (std::isfinite(o[0]) && !(h->last_check <= h->check_max)) h->check_max = h->last_check;
     // A widened plan is not for life: one slow-forgetting parameter vector in a line search would otherwise tax every
     // later evaluation.  Every evaluation is checked, so narrowing on probation is safe -- a failure costs one retry.
     const bool forced = h->shards.empty() ? h->chunks_forced : h->shards[0]->chunks_forced;
@@ -1375,7 +1376,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
                 info->required_bytes_per_row = std::max(info->required_bytes_per_row, si.required_bytes_per_row);
             }
         }
-        info->window_check = h->last_check; info->window_retries = h->n_retries;
+        info->window_check = h->last_check; info->window_retries = h->n_retries; info->window_check_max = h->check_max;
         info->n_memo_hits = h->n_memo_hits;
         info->n_devices = (int32_t)h->shards.size(); info->comm_ranks = 1;
         return SSDE_OK;
@@ -1397,7 +1398,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
           h->df_ja != h->d + 1 && h->df_jb != h->d + 1 && h->model != SSDE_MODEL_BM_T && h->model != SSDE_MODEL_CIR) ? 8.0 : 0.0);
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
-    info->n_devices = 1; info->comm_ranks = h->comm_ranks;
+    info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
         info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * (h->last_t0 > 0 ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;
