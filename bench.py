@@ -172,6 +172,12 @@ def main():
     if (args.gpus > 1 or os.environ.get("SSDE_BENCH_SELF_LAUNCH")) and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # before anything touches the GPU (the children are fresh processes)
 
+    # stdout carries ONE line, rank 0's JSON: everything any library prints there (gloo announces its connections on
+    # stdout) is sent to stderr; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -339,8 +345,10 @@ def main():
         except Exception as e:  # the baseline must never take the bench line down
             line["cpu_baseline"] = {"value": None, "unit": "track-timesteps/s", "cores": os.cpu_count(),
                                     "kind": "port", "sample": f"failed: {e}"}
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if use_comm:
         dist.barrier()
         dist.destroy_process_group()

@@ -1132,12 +1132,13 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         return SSDE_OK;
     }
     if (!h->comms.empty()) {
-        int st = eval_device(h, par, order, h->out.p, h->own_stream);
+        // same stream discipline as the single-GPU call (null stream + the blocking 48-byte copy, which returns sooner
+        // than an asynchronous copy followed by a stream synchronisation): the collective sits between the two
+        int st = eval_device(h, par, order, h->out.p, 0);
         if (st) return st;
-        st = reduce_ranks(h, h->out.p, h->own_stream);
+        st = reduce_ranks(h, h->out.p, 0);
         if (st) return st;
-        HIPCHK(h, hipMemcpyAsync(o, h->out.p, nout * 8, hipMemcpyDeviceToHost, h->own_stream));
-        HIPCHK(h, hipStreamSynchronize(h->own_stream));
+        HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
         return SSDE_OK;
     }
     if (h->path == PATH_TV && !h->env_no_graph && h->tv_stats_valid) {
