@@ -140,8 +140,7 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
     kms = []
     for k in range(steps):
         eng.eval(theta_for(npar, d, q, k))
-        if k % 4 == 0:
-            kms.append(eng.info()["main_kernel_ms"])
+        kms.append(eng.last_kernel_ms())
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     inf = eng.info()
@@ -224,8 +223,7 @@ def main():
     main_ms = []
     for k in range(args.steps):
         val, grad = eng.eval(thetas[k], order=1)          # ssde_eval: kernels, check, reduction, all-reduce, D2H
-        if k % 4 == 0:                                    # HIP events around the dominant kernel, on its own stream: read on
-            main_ms.append(eng.info()["main_kernel_ms"])  # every 4th step (the query itself costs ~10 us of the step)
+        main_ms.append(eng.last_kernel_ms())              # HIP events around the dominant kernel, on its own stream
     torch.cuda.synchronize(dev)
     if use_comm:
         dist.barrier()

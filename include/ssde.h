@@ -26,6 +26,7 @@
  *   ssde_penalty       <- smoothing penalty     (nllk_ctcrw.hpp:254-280, nllk_sde.hpp:89-124)
  *   ssde_info          <- InfoADFunObject       (src/init.c:7)
  *   ssde_forget        <- (new) drops the memo of ssde_eval
+ *   ssde_last_kernel_ms <- (new) measurement hook: duration of the last dominant kernel launch
  *   ssde_comm_unique_id / ssde_comm_init_rank
  *                      <- (new) one process per GPU: joins the handles of all ranks into one RCCL communicator, after
  *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
@@ -262,6 +263,10 @@ int ssde_widen_windows(ssde_handle *h, int32_t factor);
 int ssde_relax_windows(ssde_handle *h);
 
 int ssde_info(const ssde_handle *h, ssde_info_t *info);
+
+/* HIP-event duration (ms) of the dominant kernel launch of the last evaluation (== ssde_info().main_kernel_ms, without
+ * filling the rest of the structure: cheap enough to be read after every timed step of a benchmark); 0 if unknown. */
+double ssde_last_kernel_ms(const ssde_handle *h);
 
 /* Drop the memoised last result: the next ssde_eval runs on the device whatever its argument (determinism checks). */
 int ssde_forget(ssde_handle *h);

@@ -469,6 +469,8 @@ def load_library():
     lib.ssde_abi_version.restype = C.c_int
     lib.ssde_laplace_eval.argtypes = [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, C.POINTER(SsdeLaplaceOpts)]
     lib.ssde_laplace_eval.restype = C.c_int
+    lib.ssde_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.ssde_last_kernel_ms.restype = C.c_double
     lib.ssde_forget.argtypes = [C.c_void_p]
     lib.ssde_forget.restype = C.c_int
     lib.ssde_comm_unique_id.argtypes = [C.c_void_p]
@@ -488,7 +490,7 @@ class EngineError(RuntimeError):
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
-                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval")
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms")
 
 COMM_ID_BYTES = 128
 
@@ -569,6 +571,9 @@ class Engine:
                                                C.byref(opts)))
         out = (val.value, grad, p)
         return out + (H,) if want_hessian else out
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.ssde_last_kernel_ms(self._h))
 
     def forget(self):
         """Drop the memoised last result: the next eval runs on the device even at the same par."""

@@ -556,7 +556,10 @@ int build(const ssde_desc* d, ssde_handle* h) {
             // most groups): too few independent chains per row for one wave, so two waves per SIMD (k_iso.hip)
             // (k_iso.hip: every general kernel but CTCRW's irregular-grid one is built for two waves per SIMD)
             if (!(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || 2 * h->n_clean_groups < G) && !getenv("SSDE_NO_LIGHT2"))
-                want = std::max(1, 2048 / (((G + 7) / 8 * 8) * h->iso_parts));
+                // measured (tools/bench_na.py, SSDE_CHUNKS sweep 12 .. 32): the scalar-covariance models run best with
+                // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
+                // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
+                want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
             if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
             h->want_chunks = std::max(1, std::min(want, h->max_chunks));
@@ -1344,6 +1347,18 @@ int ssde_widen_windows(ssde_handle* h, int32_t factor) {
     else if (h->window_boost < (1 << 20)) h->window_boost *= factor;
     h->memo_order = -1;
     return SSDE_OK;
+}
+
+double ssde_last_kernel_ms(const ssde_handle* h) {
+    if (!h) return 0.0;
+    if (!h->shards.empty()) {
+        double m = 0.0;
+        for (const ssde_handle* s : h->shards) m = std::max(m, ssde_last_kernel_ms(s));
+        return m;
+    }
+    float ms = 0.f;
+    if (h->ev_k_valid && hipEventQuery(h->ev_k1) == hipSuccess && hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) return ms;
+    return 0.0;
 }
 
 int ssde_forget(ssde_handle* h) {
