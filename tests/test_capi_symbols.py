@@ -80,3 +80,23 @@ def test_scripts_compile():
     assert len(files) > 8
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_descriptor_checks_precede_the_device():
+    """Malformed descriptors are rejected before anything touches a GPU (so this runs on the CPU box too): a decaying
+    column index outside coeff_re would otherwise silently not decay while log_decay stayed a free parameter with a
+    zero gradient (the reference stops on an unknown name, R/sde.R:637-640); a duplicate likewise."""
+    rng = np.random.default_rng(0)
+    n = 40
+    ID = np.repeat([0, 1], 20)
+    X = rng.standard_normal((n, 3))
+    S = np.eye(3)
+    td = np.tile(np.linspace(0, 1, n), 3)
+    pb = capi.Problem("OU", ID, np.arange(1.0, n + 1), rng.standard_normal((n, 1)), X_re=[X, None, None], S_list=[S],
+                      t_decay=td, col_decay=[0, 1], ind_decay=[0, 0])
+    pb.col_decay = np.array([0, 7], dtype=np.int32)            # past the three columns of coeff_re
+    with pytest.raises(capi.EngineError, match="col_decay out of range"):
+        capi.Engine(pb)
+    pb.col_decay = np.array([1, 1], dtype=np.int32)
+    with pytest.raises(capi.EngineError, match="twice"):
+        capi.Engine(pb)

@@ -246,3 +246,31 @@ def test_memo_fn_then_gr_is_one_evaluation():
     inf = eng.info()
     assert inf["n_memo_hits"] == 1 and inf["n_evals"] >= 2
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(0, 64))
+def test_multi_device_handle_on_random_problems(seed):
+    """The fuzz generator of tests/test_gpu_fuzz.py (every model; ragged and one-row tracks, a0 / P0 / H_array, design
+    columns and smooths, decaying columns, ESEAL's h / R, fixed parameters) through a three-shard handle: create_sharded
+    has to cut every per-row array the descriptor can carry at the same track boundaries.  Against the single engine:
+    value 1e-11, gradient 1e-9 of its largest entry (shards plan their own time windows), aest_all 1e-12."""
+    from test_gpu_fuzz import random_problem
+    pb, par = random_problem(seed)
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    em = capi.Engine(pb, devices=[0, 0, 0])
+    vm, gm = em.eval(par)
+    inf = em.info()
+    ctx = (pb.model, pb.n, pb.n_seg, inf["n_devices"], inf["path"])
+    assert inf["n_rows"] == pb.n and inf["n_tracks"] == pb.n_seg, ctx
+    if not np.isfinite(v1):
+        assert not np.isfinite(vm), ctx
+    else:
+        assert abs(vm - v1) <= 1e-11 * max(1.0, abs(v1)), (vm, v1, ctx)
+        assert np.max(np.abs(gm - g1)) <= 1e-9 * max(np.max(np.abs(g1)), 1e-3), (gm, g1, ctx)
+        assert np.all(gm[pb.par_fixed != 0] == 0.0)
+        if pb.model in ("CTCRW", "OU_SSM", "BM_SSM"):
+            a1, am = e1.report(par), em.report(par)
+            assert np.allclose(am, a1, rtol=1e-12, atol=1e-12 * max(1.0, np.nanmax(np.abs(a1))), equal_nan=True), ctx
+    e1.close()
+    em.close()

@@ -684,3 +684,27 @@ def test_basis_tables_match_streamed_blocks_and_oracle(model, kw):
         assert e1.info()["hbm_bytes"] < e2.info()["hbm_bytes"] - 0.8 * 7 * pb.n * 8
     assert e1.info()["algo_bytes_per_row"] == e2.info()["algo_bytes_per_row"]
     e1.close(); e2.close()
+
+
+def test_basis_table_next_to_a_block_too_wide_for_the_fast_kernel():
+    """mu as a basis table while tau carries 25 streamed smooth columns (more than the fast direct kernel
+    holds per parameter): the table must be materialised for the generic kernel, never scored as an intercept."""
+    from smoothsde_amd.synth import bspline_basis, bspline_ppbasis, second_difference_penalty
+    rng = np.random.default_rng(5)
+    ID, times, obs = simulate("OU", 30, 150, 1, mu=1.0, seed=5)
+    n = len(ID)
+    x = np.clip(0.5 + 0.45 * np.sin(np.arange(n) * 0.011) + 0.03 * rng.standard_normal(n), 0, 1)
+    basis = [bspline_ppbasis(x, 7), None, None]
+    wide = bspline_basis(np.clip(x ** 1.5, 0, 1), 25)
+    S = [second_difference_penalty(7), second_difference_penalty(25)]
+    pb = capi.Problem("OU", ID, times, obs, X_re=[None, wide, None], S_list=S, basis_re=basis)
+    dense = capi.Problem("OU", ID, times, obs, X_re=[basis[0].dense(), wide, None], S_list=S)
+    par = 0.05 * rng.standard_normal(pb.n_par_full)
+    par[0] = 1.0
+    e1, e2 = capi.Engine(pb), capi.Engine(dense)
+    v1, g1 = e1.eval(par)
+    v2, g2 = e2.eval(par)
+    oval, ograd = _oracle(dense, par)
+    _close(v1, g1, oval, ograd)
+    _close(v2, g2, oval, ograd)
+    e1.close(); e2.close()
