@@ -1118,6 +1118,9 @@ bool grad_rides_along(const ssde_handle* h) {
 int run_once(ssde_handle* h, const double* par, int order, double* o) {
     const size_t nout = 2 + (size_t)h->L.n_full;
     if (!h->shards.empty()) {
+        int dev_before = 0;
+        (void)hipGetDevice(&dev_before);                   // the caller's current device is left as it was found
+        struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{dev_before};
         for (ssde_handle* sh : h->shards) {
             int st = eval_device(sh, par, order, sh->out.p, sh->own_stream);
             if (st) { h->err = sh->err; return st; }

@@ -64,6 +64,9 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(parent, SSDE_ERR_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
+    int dev_before = 0;
+    (void)hipGetDevice(&dev_before);                        // the caller's current device is left as it was found
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{dev_before};
     bool distinct = true, same = true;
     for (int i = 0; i < d->n_devices; i++) {
         if (d->devices[i] < 0 || d->devices[i] >= ndev) return fail(parent, SSDE_ERR_ARG, "devices[]: no such HIP device");

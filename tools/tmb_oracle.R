@@ -1,38 +1,114 @@
 #!/usr/bin/env Rscript
-# tools/tmb_oracle.R -- dump the TRUE reference numbers (TMB fn / gr) for the committed fixtures.
+# tools/tmb_oracle.R -- dump the TRUE reference numbers (TMB fn / gr of the compiled smoothSDE template) for EVERY
+# committed fixture of tests/golden/cases.json, so that the parity-unpinned oracle can be pinned on any machine that has
+# R + TMB + smoothSDE.
 #
 # Written blind: this image has no R / TMB / smoothSDE.  On a machine that has them
-# (install.packages(c("TMB","mgcv","R6","jsonlite")); devtools::install_github("TheoMichelot/smoothSDE")):
+# (install.packages(c("TMB","Matrix","jsonlite")); devtools::install_github("TheoMichelot/smoothSDE")):
 #     Rscript tools/tmb_oracle.R tests/golden/cases.json tmb_dump.json
 # then compare tmb_dump.json with the "expected" blocks of cases.json (value rel <= 1e-8, gradient
-# |d| <= 1e-8 * max|g| + 1e-10).  Only constant-coefficient cases are dumped (the fixtures' spline
-# blocks are this repository's B-spline stand-in, not an mgcv basis).
-suppressMessages({library(smoothSDE); library(jsonlite)})
+# |d| <= 1e-8 * max|g| + 1e-10): python tools/compare_tmb_dump.py tmb_dump.json
+#
+# The SDE class (formulas, mgcv) is bypassed on purpose: the fixtures carry their own design blocks (this repository's
+# B-spline stand-in, not an mgcv basis), and what has to be pinned is the compiled objective.  The script therefore
+# calls TMB::MakeADFun(DLL = "smoothSDE") itself with a `tmb_dat` / `tmb_par` / `map` assembled from the fixture arrays
+# under the names the package's own setup uses (/root/reference/R/sde.R:504-536, 542-658): type, ID, times, obs,
+# X_fe / X_re (block-diagonal dgTMatrix), S (block-diagonal), ncol_re, include_penalty, a0, P0, H_array, other_data,
+# t_decay / col_decay / ind_decay, h, R.  No `random`: the joint objective (value + full gradient), which is what the
+# engine's ssde_eval returns.
+suppressMessages({library(TMB); library(Matrix); library(jsonlite); library(smoothSDE)})
 args <- commandArgs(trailingOnly = TRUE)
 cases <- fromJSON(args[1], simplifyVector = FALSE)
+
 hex2dbl <- function(h) {
     raw <- as.raw(strtoi(substring(h, seq(1, 15, 2), seq(2, 16, 2)), 16L))
-    readBin(rev(raw), "double", n = 1, size = 8, endian = "little")
+    readBin(rev(raw), "double", n = 1, size = 8, endian = "little")          # NA payloads survive (R_IsNA tests bits)
 }
-dec <- function(x) { v <- vapply(x$hex, hex2dbl, 0.0); if(length(x$shape) == 2) matrix(v, x$shape[[1]], x$shape[[2]], byrow = TRUE) else v }
+dec <- function(x) {
+    if(is.null(x)) return(NULL)
+    v <- vapply(unlist(x$hex), hex2dbl, 0.0)
+    shp <- unlist(x$shape)
+    if(length(shp) <= 1) return(v)
+    aperm(array(v, dim = rev(shp)))                                           # the fixtures are row-major (numpy C order)
+}
+as_T <- function(m) as(as(as(Matrix(m, sparse = TRUE), "dMatrix"), "generalMatrix"), "TsparseMatrix")
+
+kalman <- c("BM_SSM", "OU_SSM", "CTCRW")
 out <- list()
 for(cs in cases) {
-    if(!is.null(cs$X_fe) || !is.null(cs$H) || !is.null(cs$P0)) next
-    obs <- dec(cs$obs); d <- ncol(obs)
-    resp <- paste0("z", seq_len(d))
-    dat <- data.frame(ID = dec(cs$ID), time = dec(cs$times)); dat[resp] <- obs
-    fix <- NULL
-    sde <- SDE$new(data = dat, type = cs$model, response = resp)
-    sde$setup()
-    obj <- sde$tmb_obj()
-    par <- dec(cs$par)
-    if(!is.null(cs$par_fixed)) {   # re-setup with the same fixed coefficients
-        nm <- names(sde$formulas())[which(unlist(cs$par_fixed$u8)[-1][seq_along(sde$formulas())] == 1)]
-        sde <- SDE$new(data = dat, type = cs$model, response = resp, fixpar = nm,
-                       par0 = NULL); sde$setup(); obj <- sde$tmb_obj()
+    obs <- dec(cs$obs); if(is.null(dim(obs))) obs <- matrix(obs, ncol = 1)
+    n <- nrow(obs); d <- ncol(obs); type <- cs$model
+    q <- if(type %in% c("BM", "BM_SSM", "BM_t", "ESEAL_SSM")) d + 1 else d + 2
+    # per-parameter blocks: NULL fixed-effect block = intercept column of ones
+    Xfe <- lapply(seq_len(q), function(j) { b <- dec(cs$X_fe[[j]]); if(is.null(b)) matrix(1, n, 1) else matrix(b, nrow = n) })
+    Xre <- lapply(seq_len(q), function(j) { b <- if(is.null(cs$X_re)) NULL else dec(cs$X_re[[j]]); if(is.null(b)) matrix(0, n, 0) else matrix(b, nrow = n) })
+    ncol_fe <- vapply(Xfe, ncol, 0L); n_re <- sum(vapply(Xre, ncol, 0L))
+    has_re <- n_re > 0
+    X_fe <- as_T(bdiag(Xfe))
+    X_re <- if(has_re) as_T(bdiag(Xre)) else as_T(matrix(0, n * q, 1))
+    S_list <- lapply(cs$S_list, dec)
+    S <- if(has_re) as_T(bdiag(S_list)) else as_T(matrix(0, 1, 1))
+    ncol_re <- if(has_re) vapply(S_list, ncol, 0L) else 0
+    ID <- dec(cs$ID)
+    dat <- list(type = type, ID = factor(ID, levels = unique(ID)), times = dec(cs$times), obs = obs, X_fe = X_fe, X_re = X_re,
+                S = S, ncol_re = ncol_re, include_penalty = as.integer(cs$include_penalty))
+    par_full <- dec(cs$par)
+    map <- list()
+    off <- 0
+    par <- list()
+    if(type %in% kalman) { par$log_sigma_obs <- par_full[1]; off <- 1 }
+    if(type == "ESEAL_SSM") { par$log_tau <- par_full[1]; par$a1 <- par_full[2]; par$log_a2 <- par_full[3]; off <- 3 }
+    n_fe <- sum(ncol_fe)
+    par$coeff_fe <- par_full[off + seq_len(n_fe)]
+    n_sm <- length(S_list)
+    par$log_lambda <- if(has_re) par_full[off + n_fe + seq_len(n_sm)] else 0
+    n_dec <- if(!is.null(cs$t_decay)) max(unlist(dec(cs$ind_decay))) + 1 else 0
+    if(type %in% c("BM", "BM_t", "OU", "CIR")) par$log_decay <- if(n_dec > 0) par_full[off + n_fe + n_sm + seq_len(n_dec)] else 0
+    par$coeff_re <- if(has_re) par_full[off + n_fe + n_sm + n_dec + seq_len(n_re)] else 0
+    if(!has_re) map <- c(map, list(coeff_re = factor(NA), log_lambda = factor(NA)))
+    # model-specific data (R/sde.R:538-619)
+    i0 <- c(1, which(ID[-n] != ID[-1]) + 1)
+    if(type == "BM_t") dat$other_data <- dec(cs$other_data)
+    else if(type %in% kalman) {
+        a0 <- dec(cs$a0)
+        if(is.null(a0)) {
+            if(type == "CTCRW") { a0 <- matrix(0, length(i0), 2 * d); for(i in seq_len(d)) a0[, 2 * (i - 1) + 1] <- obs[i0, i] }
+            else a0 <- as.matrix(obs[i0, , drop = FALSE])
+        }
+        dat$a0 <- matrix(a0, nrow = length(i0))
+        P0 <- dec(cs$P0)
+        dat$P0 <- if(is.null(P0)) (if(type == "CTCRW") diag(rep(c(1, 10), d)) else diag(rep(10, d))) else P0
+        H <- dec(cs$H)
+        if(is.null(H)) dat$H_array <- array(0) else { dat$H_array <- H; map <- c(map, list(log_sigma_obs = factor(NA))) }
+    } else if(type == "ESEAL_SSM") {
+        dat$a0 <- matrix(dec(cs$a0), nrow = length(i0)); dat$P0 <- diag(c(0, 10))
+        dat$h <- dec(cs$eseal_h); dat$R <- dec(cs$eseal_R)
+    } else dat$other_data <- 0
+    if(type %in% c("BM", "BM_t", "OU", "CIR")) {
+        if(n_dec > 0) {
+            dat$t_decay <- dec(cs$t_decay); dat$col_decay <- unlist(dec(cs$col_decay)) + 1; dat$ind_decay <- unlist(dec(cs$ind_decay)) + 1
+        } else { dat$t_decay <- 0; dat$col_decay <- 0; dat$ind_decay <- 0; map <- c(map, list(log_decay = factor(NA))) }
     }
-    free <- if(is.null(cs$par_fixed)) seq_along(par) else which(unlist(cs$par_fixed$u8) == 0)
-    x <- par[free]
-    out[[cs$name]] <- list(value = obj$fn(x), gradient = as.numeric(obj$gr(x)), free = free)
+    # fixed entries of the fixture -> map (NA levels), block by block in template order
+    fixed <- if(is.null(cs$par_fixed)) rep(0L, length(par_full)) else as.integer(unlist(cs$par_fixed$u8))
+    blocks <- list()
+    pos <- 0
+    for(nm in names(par)) {
+        len <- length(par[[nm]])
+        # the template's dummy blocks (no random effects / no decaying columns) have no entry in the fixture's vector
+        dummy <- (!has_re && nm %in% c("coeff_re", "log_lambda")) || (n_dec == 0 && nm == "log_decay")
+        if(!dummy) {
+            f <- fixed[pos + seq_len(len)]
+            if(nm %in% names(map)) f[] <- 1L              # mapped wholesale above (log_sigma_obs with a supplied H_array)
+            else if(any(f == 1)) { m <- seq_len(len); m[f == 1] <- NA; map[[nm]] <- factor(m) }
+            blocks[[nm]] <- pos + which(f == 0)
+            pos <- pos + len
+        }
+    }
+    obj <- MakeADFun(data = dat, parameters = par, DLL = "smoothSDE", map = map, silent = TRUE)
+    free <- unlist(blocks, use.names = FALSE)
+    x <- obj$par
+    grad_full <- rep(0, length(par_full)); grad_full[free] <- as.numeric(obj$gr(x))
+    out[[cs$name]] <- list(value = obj$fn(x), gradient = grad_full, free = free)
 }
 writeLines(toJSON(out, digits = 17, auto_unbox = TRUE), args[2])
