@@ -135,11 +135,13 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
     npar = 1 + q
     for k in range(2):
         eng.eval(theta_for(npar, d, q, -1 - k))
+    ssde_eval = eng.bound_eval(order=1)
+    ths = [np.ascontiguousarray(theta_for(npar, d, q, k)) for k in range(steps)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     kms = []
     for k in range(steps):
-        eng.eval(theta_for(npar, d, q, k))
+        ssde_eval(ths[k])
         kms.append(eng.last_kernel_ms())
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
@@ -212,7 +214,7 @@ def main():
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(world, rank, box[0])                # ncclCommInitRank: the engines of all ranks, one communicator
 
-    thetas = {k: theta_for(npar, d, q, k) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
+    thetas = {k: np.ascontiguousarray(theta_for(npar, d, q, k)) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
 
     for k in range(args.warmup):
         eng.eval(thetas[-1 - k], order=1)
@@ -221,8 +223,9 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     main_ms = []
+    ssde_eval = eng.bound_eval(order=1)                   # the C ABI call itself (preallocated outputs, no per-call conversions)
     for k in range(args.steps):
-        val, grad = eng.eval(thetas[k], order=1)          # ssde_eval: kernels, check, reduction, all-reduce, D2H
+        val, grad = ssde_eval(thetas[k])                  # ssde_eval: kernels, check, reduction, all-reduce, D2H
         main_ms.append(eng.last_kernel_ms())              # HIP events around the dominant kernel, on its own stream
     torch.cuda.synchronize(dev)
     if use_comm:

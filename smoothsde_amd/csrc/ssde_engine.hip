@@ -1389,7 +1389,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
             else {
                 info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps;
                 info->hbm_bytes += si.hbm_bytes; info->main_kernel_rows += si.main_kernel_rows;
-                info->n_kernel_blocks += si.n_kernel_blocks; info->n_evals += si.n_evals;
+                info->n_kernel_blocks += si.n_kernel_blocks;   // (n_evals: shard 0's count -- every shard runs every evaluation)
                 info->main_kernel_ms = std::max(info->main_kernel_ms, si.main_kernel_ms);
                 info->uniform_dt = info->uniform_dt && si.uniform_dt;
                 info->required_bytes_per_row = std::max(info->required_bytes_per_row, si.required_bytes_per_row);
