@@ -325,9 +325,21 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
     const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
     double worst = 0.0;
-    for (int k = wv; k < nstate; k += 4) {           // the block's 4 waves take every 4th component
-        double a = valid ? out_c[k * WAVE] : 0.0, b = valid ? in_n[k * WAVE] : 0.0;
-        double err = fabs(a - b), sc = fmax(fabs(a), fabs(b));
+    // the block's 4 waves take every 4th component; all of a wave's loads (at most NSTATE_MAX / 4 pairs) are issued
+    // before the first reduction, so that one HBM round trip covers them instead of one per component
+    constexpr int KMAX = NSTATE_MAX / 4;
+    double av[KMAX], bv[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+        const int k = wv + 4 * i;
+        const bool on = valid && k < nstate;
+        av[i] = on ? out_c[k * WAVE] : 0.0;
+        bv[i] = on ? in_n[k * WAVE] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+        if (wv + 4 * i >= nstate) break;             // (wave-uniform)
+        double err = fabs(av[i] - bv[i]), sc = fmax(fabs(av[i]), fabs(bv[i]));
         if (valid && !(err == err)) err = INFINITY;  // NaN on either side must not pass
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {

@@ -705,7 +705,9 @@ template <int D>
 int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double add[4]) {
     const int slot = h->par_next;
     h->par_next = (h->par_next + 1) % PAR_RING;
-    HIPCHK(h, hipEventSynchronize(h->par_ev[slot]));
+    // the ring protects the pinned slot of an ASYNCHRONOUS caller's earlier evaluation (ssde_eval_device); a
+    // synchronous ssde_eval has read its result back before the next call: no event traffic on that path
+    if (!h->sync_call || h->par_ev_pending[slot]) { HIPCHK(h, hipEventSynchronize(h->par_ev[slot])); h->par_ev_pending[slot] = false; }
     double* host = h->gain_pinned + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
@@ -767,7 +769,7 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     const int rows = last + 1;
     h->last_gain_rows = rows;
     HIPCHK(h, hipMemcpyAsync(dev, host, (size_t)rows * GAIN_ROW * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipEventRecord(h->par_ev[slot], s));
+    if (!h->sync_call) { HIPCHK(h, hipEventRecord(h->par_ev[slot], s)); h->par_ev_pending[slot] = true; }
     a.gain = dev;
     a.gain_last = last;
     for (int k = 0; k < GAIN_ROW; k++) a.gain_stat[k] = host[(size_t)last * GAIN_ROW + k];
@@ -1152,7 +1154,9 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         h->n_evals++;
         return eval_tv_graph(h, par, order, o);
     }
+    h->sync_call = true;
     int st = eval_device(h, par, order, h->out.p, 0);
+    h->sync_call = false;
     if (st) return st;
     const auto t0 = std::chrono::steady_clock::now();
     // Measured twice (rounds 1 and 2) and slower both times by ~10 us: letting the finalising launch write the result

@@ -147,6 +147,8 @@ struct ssde_handle {
     double* gain_pinned = nullptr;
     size_t gain_rows_cap = 0;
     int last_gain_rows = 0;
+    bool par_ev_pending[PAR_RING] = {false, false, false, false, false, false, false, false};   // slot last used by an asynchronous call
+    bool sync_call = false;        // set around the evaluation of a synchronous ssde_eval (single engine, null stream)
 
     // side streams: the kernels of one evaluation that do not depend on each other run concurrently
     hipStream_t aux[2] = {nullptr, nullptr};
