@@ -1142,7 +1142,9 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
     if (!h->comms.empty()) {
         // same stream discipline as the single-GPU call (null stream + the blocking 48-byte copy, which returns sooner
         // than an asynchronous copy followed by a stream synchronisation): the collective sits between the two
+        h->sync_call = true;
         int st = eval_device(h, par, order, h->out.p, 0);
+        h->sync_call = false;
         if (st) return st;
         st = reduce_ranks(h, h->out.p, 0);
         if (st) return st;
