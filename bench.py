@@ -51,38 +51,62 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(seconds_target=15.0):
-    """The CPU oracle (port of the reference arithmetic, forward-mode gradient) on a bounded
-    sample of the same workload, on all host cores of this box.  Baseline, not the target."""
-    from oracle_lib import oracle_eval
+def cpu_baseline(seconds_target=12.0):
+    """The CPU restatement SURVEY 8(d)(i) asks for -- fp64, analytic gradient, threads over tracks on the cores this box
+    grants (oracle/cpu_fast.cpp: the hand-derived step compiled for the host, -O3 with hardware FMA) -- on a bounded
+    sample of the same workload; the literal dual-number oracle (the checker) is timed next to it on a smaller sample.
+    A baseline, not the target."""
+    from oracle_lib import cpu_fast_eval, oracle_eval
     from smoothsde_amd import capi
     from smoothsde_amd.synth import simulate
     cores = _usable_cores()
-    tracks, rows = 8 * cores, 2000
-    ID, times, obs = simulate("CTCRW", tracks, rows, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
     fixed = np.array([0, 1, 1, 0, 0], dtype=np.uint8)
+    par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0])
+
+    def busy_cores(fn):
+        # the affinity mask can promise more cores than the box's CPU share grants: measure how many the threads
+        # really got (process CPU time / wall time)
+        w0, c0 = time.perf_counter(), time.process_time()
+        fn()
+        return (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)
+
+    # --- the analytic-gradient restatement: 64 tracks per core x 10^4 rows (the bench's track length) ----------------
+    tracks, rows = 64 * cores, 10_000
+    ID, times, obs = simulate("CTCRW", tracks, rows, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
     pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed)
-    par = np.array([0.0, 0.0, 0.0, 0.0, 0.0])
-    # the affinity mask can promise more cores than the box's CPU share grants: measure how many
-    # cores the threads really got (process CPU time / wall time) and size the pool to that
-    oracle_eval(pb, par, order=1, threads=cores)  # warm (library load, first-touch)
-    w0, c0 = time.perf_counter(), time.process_time()
-    oracle_eval(pb, par, order=1, threads=cores)
-    busy = (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)
+    cpu_fast_eval(pb, par, threads=cores)                      # warm (library load, first touch)
+    busy = busy_cores(lambda: cpu_fast_eval(pb, par, threads=cores))
     if busy < 0.6 * cores:
         cores = max(1, int(round(busy)))
     t0 = time.perf_counter()
     reps = 0
     while True:
-        oracle_eval(pb, par + 0.01 * reps, order=1, threads=cores)
+        cpu_fast_eval(pb, par + 0.01 * reps, threads=cores)
         reps += 1
         el = time.perf_counter() - t0
-        if el > seconds_target or reps >= 50:
+        if el > seconds_target or reps >= 200:
             break
     rate = tracks * rows * reps / el
-    return {"value": rate, "unit": "track-timesteps/s", "cores": cores, "kind": "port",
-            "sample": f"{tracks} CTCRW tracks x {rows} rows, {reps} nllk+grad evaluations, "
-                      f"oracle/liboracle.so (g++ -O2, {cores} threads over track shards)"}
+    out = {"value": rate, "unit": "track-timesteps/s", "cores": cores, "kind": "port",
+           "sample": f"{tracks} CTCRW tracks x {rows} rows, regular grid, {reps} nllk+grad evaluations, oracle/libcpu_fast.so "
+                     f"(analytic forward-sensitivity gradient, transition hoisted, g++ -O3 -mfma, {cores} threads over tracks)"}
+    # --- the literal restatement (dual numbers over dense matrices): what the tests check against -------------------------
+    try:
+        t2, r2 = 8 * cores, 2000
+        ID, times, obs = simulate("CTCRW", t2, r2, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=1)
+        pb2 = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed)
+        oracle_eval(pb2, par, order=1, threads=cores)
+        t0 = time.perf_counter()
+        n2 = 0
+        while time.perf_counter() - t0 < 4.0 and n2 < 50:
+            oracle_eval(pb2, par + 0.01 * n2, order=1, threads=cores)
+            n2 += 1
+        out["literal_oracle"] = {"value": t2 * r2 * n2 / (time.perf_counter() - t0), "unit": "track-timesteps/s",
+                                 "sample": f"{t2} tracks x {r2} rows, {n2} evaluations, oracle/liboracle.so (forward-mode duals "
+                                           f"over 8x8 dense matrices, g++ -O2, {cores} threads)"}
+    except Exception as e:  # noqa: BLE001
+        out["literal_oracle"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 def self_launch(args):

@@ -64,6 +64,54 @@ def oracle_eval_quad(problem: Problem, par, order: int = 1, fd_step: float = 1e-
     return (val.value, grad) if order >= 1 else val.value
 
 
+_FLIB = None
+
+
+def cpu_fast_eval(problem: Problem, par, threads: int = 1):
+    """bench.py's CPU baseline (oracle/cpu_fast.cpp: analytic gradient, threads over tracks; constant-coefficient
+    isotropic Kalman families only): data-term nllk and gradient over the full parameter vector."""
+    global _FLIB
+    from smoothsde_amd.capi import MODEL_CODES
+    if _FLIB is None:
+        path = os.path.join(_ORACLE_DIR, "libcpu_fast.so")
+        if not os.path.exists(path):
+            build_oracle()
+        _FLIB = C.CDLL(path)
+        _lp = C.POINTER(C.c_int64)
+        _FLIB.cpu_fast_kalman.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp, _dp,
+                                          C.c_int, C.c_double, C.c_int, _dp]
+        _FLIB.cpu_fast_kalman.restype = C.c_int
+    pb = problem
+    assert pb.model in ("CTCRW", "OU_SSM", "BM_SSM") and pb.n_re == 0 and all(x is None for x in pb.X_fe) and pb.H is None
+    d = pb.n_dim
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    theta = np.zeros(3 + d)
+    theta[:len(par)] = par
+    free = pb.par_fixed == 0
+    mask = (1 if free[0] else 0) | (2 if free[1:1 + d].any() else 0) | (4 if free[1 + d] else 0) | \
+           (8 if len(par) > 2 + d and free[2 + d] else 0)
+    row0 = np.ascontiguousarray(pb.seg_start, dtype=np.int64)
+    nrows = np.diff(np.append(pb.seg_start, pb.n)).astype(np.int64)
+    p0 = np.array([1.0, 0.0, 10.0]) if pb.model == "CTCRW" else np.array([10.0, 0.0, 0.0])
+    assert pb.P0 is None and pb.a0 is None
+    inner = np.ones(pb.n - 1, dtype=bool)
+    inner[pb.seg_start[1:] - 1] = False                    # intervals that span to the next track are never used
+    dts = np.diff(pb.times)[inner]
+    uni = len(dts) > 0 and np.all(dts == dts[0])
+    out = np.zeros(4 + d)
+    _lp = C.POINTER(C.c_int64)
+    st = _FLIB.cpu_fast_kalman(MODEL_CODES[pb.model], d, mask, int(pb.na_mode == 1), pb.n, pb.n_seg, row0.ctypes.data_as(_lp),
+                               nrows.ctypes.data_as(_lp), pb.times.ctypes.data_as(_dp), pb.obs.ctypes.data_as(_dp),
+                               theta.ctypes.data_as(_dp), p0.ctypes.data_as(_dp), int(uni), float(dts[0]) if uni else 0.0,
+                               threads, out.ctypes.data_as(_dp))
+    if st != 0:
+        raise RuntimeError(f"cpu_fast_kalman returned {st} (2 = this host CPU has no FMA)")
+    grad = np.zeros(pb.n_par_full)
+    grad[:len(par)] = out[1:1 + len(par)]
+    grad[pb.par_fixed != 0] = 0.0
+    return out[0], grad
+
+
 def oracle_eval(problem: Problem, par, order: int = 1, threads: int = 1, report: bool = False,
                 data_only: bool = False):
     """nllk (+ penalty unless data_only), gradient over the full parameter vector, and

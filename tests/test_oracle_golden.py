@@ -98,3 +98,25 @@ def test_first_observation_never_scored():
     obs2[pb.seg_start, 0] += 123.0
     pb2 = problem_from_spec(dict(rec, obs=obs2), a0=a0)
     assert abs(oracle_eval(pb, rec["par"], 0) - oracle_eval(pb2, rec["par"], 0)) < 1e-12
+
+
+def test_cpu_fast_matches_the_oracle():
+    """bench.py's CPU baseline (oracle/cpu_fast.cpp: the engine's hand-derived step compiled for the host, threads over
+    tracks) against the oracle: it is a timing baseline, not a checker, and is itself checked here."""
+    import numpy as np
+    from oracle_lib import cpu_fast_eval, oracle_eval
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import simulate
+    for model, par, fixed in (("CTCRW", [-1.0, 0.05, -0.02, 0.4, 0.1], [0, 0, 0, 0, 0]), ("CTCRW", [-2.3, 0.0, 0.0, 0.7, 0.0], [0, 1, 1, 0, 0]),
+                              ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1], [0, 0, 0, 0, 0]), ("BM_SSM", [-1.0, 0.05, 0.0, 0.2], [0, 0, 0, 0])):
+        for irregular in (False, True):
+            ID, times, obs = simulate(model, 37, 120, 2, seed=3)
+            if irregular:
+                times = np.cumsum(np.random.default_rng(1).uniform(0.5, 1.5, len(ID)))
+            obs[11::29] = np.nan
+            obs[::120] = np.where(np.isnan(obs[::120]), 0.0, obs[::120])
+            pb = capi.Problem(model, ID, times, obs, par_fixed=fixed)
+            v, g = cpu_fast_eval(pb, np.array(par), threads=3)
+            ov, og = oracle_eval(pb, np.array(par), order=1, data_only=True)
+            assert abs(v - ov) <= 1e-11 * abs(ov), (model, irregular, v, ov)
+            assert np.max(np.abs(g - og)) <= 1e-9 * np.max(np.abs(og)), (model, irregular, g, og)
