@@ -274,3 +274,25 @@ def test_multi_device_handle_on_random_problems(seed):
             assert np.allclose(am, a1, rtol=1e-12, atol=1e-12 * max(1.0, np.nanmax(np.abs(a1))), equal_nan=True), ctx
     e1.close()
     em.close()
+
+
+def test_multi_device_descriptor_errors():
+    import torch
+    ID, t, o = simulate("CTCRW", 8, 30, 2, seed=1)
+    pb = capi.Problem("CTCRW", ID, t, o)
+    with pytest.raises(capi.EngineError, match="no such HIP device"):
+        capi.Engine(pb, devices=[0, 4096])
+    nd = torch.cuda.device_count()
+    if nd >= 2:
+        with pytest.raises(capi.EngineError, match="all different"):
+            capi.Engine(pb, devices=[0, 0, 1])
+    IDt, tt, ot = (torch.tensor(x, device="cuda:0") for x in (ID, t, o))
+    pbd = capi.Problem.from_torch("CTCRW", IDt, tt, ot)
+    with pytest.raises(capi.EngineError, match="host arrays"):
+        capi.Engine(pbd, devices=[0, 0])
+    # a parent is evaluated with ssde_eval; the asynchronous entry point says so instead of doing something else
+    em = capi.Engine(pb, devices=[0, 0])
+    out = torch.zeros(2 + pb.n_par_full, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(capi.EngineError, match="ssde_eval"):
+        em.eval_device(np.zeros(pb.n_par_full), out.data_ptr())
+    em.close()
