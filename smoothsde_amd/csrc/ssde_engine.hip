@@ -141,6 +141,7 @@ int build(const ssde_desc* d, ssde_handle* h) {
     if (const char* e = getenv("SSDE_TV_WAVES")) h->env_tv_waves = std::max(1, atoi(e));
     if (const char* e = getenv("SSDE_TV_MINLEN")) h->env_tv_minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
     if (const char* e = getenv("SSDE_T0_COST")) h->env_t0_cost = atof(e);
+    if (const char* e = getenv("SSDE_W0_RATIO")) h->env_w0_ratio = atof(e);     // 0 = equal windows on the general kernel
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
@@ -903,6 +904,20 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             const double cost = h->env_t0_cost;
             a.t0_delta = (int)(cost * a.t0 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         }
+        if (!h->use_shared && a.n_chunks > 1 && h->env_w0_ratio > 0.0) {
+            // General kernel, every window on its own wave: window 0 carries EVERY direction (windows >= 1 derive one,
+            // k_iso.hip) but has no warm-up rows.  With equal windows its waves are the last to finish and the whole
+            // launch waits for them (CTCRW: 212 against 163 instructions per row).  Balance: window 0 = [0, L0) with
+            // r L0 = L1 + W, the others split [L0, L) equally -- the geometry window_bounds already has for a transient
+            // window (t0 = L0), with nothing to subtract from window 1 (t0_delta = 0: it has a wave of its own).
+            const bool can_derive = order >= 1 && a.derive && (a.part_mask[0] & DIR_SIG) &&
+                                    (a.part_mask[0] & (h->model == SSDE_MODEL_BM_SSM ? DIR_P1 : DIR_P2));
+            const double r = can_derive ? h->env_w0_ratio : 1.0;
+            const int nc = a.n_chunks;
+            const double L0 = ((double)h->glen_max / (nc - 1) + a.window) / (r + 1.0 / (nc - 1));
+            const int t0 = (int)(L0 / WIN_ALIGN) * WIN_ALIGN;
+            if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) { a.t0 = t0; a.t0_delta = 0; }
+        }
         h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
         if (h->use_shared) {
             // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
@@ -1425,7 +1440,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
-        info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * (h->last_t0 > 0 ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
+        info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * ((h->use_shared && h->last_t0 > 0) ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;
     else if (h->path == PATH_TV) info->n_kernel_blocks = (h->tv_n_items_g + WG_WAVES - 1) / WG_WAVES;
     else info->n_kernel_blocks = h->direct_blocks;
