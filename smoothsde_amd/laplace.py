@@ -130,3 +130,43 @@ class LaplaceObjective:
             g[k] = (fp - fm) / (2 * e[k])
         self.u_hat, self.last_hessian, self._cache_x, self._cache_f = u_keep, H_keep, cx, cf
         return g
+
+
+class EngineLaplaceObjective(LaplaceObjective):
+    """The same objective with fn / gr taken from the engine's own entry point, `ssde_laplace_eval` (include/ssde.h;
+    csrc/ssde_laplace.hip) -- the code an R or C host runs for `random = "coeff_re"`: inner Newton solve and differenced
+    H_uu in C++ on the device gradient, outer gradient = exact dg/dtheta at u_hat + a differenced log-determinant term
+    (no inner solves per outer coordinate).  `joint`, `inner`, `_hess_uu` of the base class stay available (sdreport)."""
+
+    def __init__(self, engine, par_full, idx_outer, idx_random, **kw):
+        super().__init__(lambda p: engine.eval(p, order=1), par_full, idx_outer, idx_random, **kw)
+        self.engine = engine
+        self._cache_gx = None
+        self._cache_g = None
+
+    def _call(self, theta, order):
+        p = self._full(theta, self.u_hat)
+        f, g, p_hat, H = self.engine.laplace_eval(p, order=order, want_hessian=True, hess_step=self.hess_step,
+                                                   fd_step=self.fd_step, newton_tol=self.newton_tol, max_newton=self.max_newton)
+        return f, g[self.io], p_hat[self.ir], H
+
+    def fn(self, theta=None, update_warm_start=True):
+        theta = self.par if theta is None else np.asarray(theta, dtype=np.float64)
+        if self._cache_x is not None and np.array_equal(theta, self._cache_x):
+            return self._cache_f
+        f, _, u, H = self._call(theta, 0)
+        if update_warm_start and np.isfinite(f):
+            self.u_hat, self.last_hessian = u, H
+            self._cache_x, self._cache_f = theta.copy(), f
+        return f
+
+    def gr(self, theta=None):
+        theta = self.par if theta is None else np.asarray(theta, dtype=np.float64)
+        if self._cache_gx is not None and np.array_equal(theta, self._cache_gx):
+            return self._cache_g
+        f, g, u, H = self._call(theta, 1)
+        if np.isfinite(f):
+            self.u_hat, self.last_hessian = u, H
+            self._cache_x, self._cache_f = theta.copy(), f
+        self._cache_gx, self._cache_g = theta.copy(), g
+        return g

@@ -299,11 +299,12 @@ class SDE:
         self.joint_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())   # all free parameters, fixed + random
         self.tmb_obj_ = self.joint_obj_
         if self.laplace_:
-            from .laplace import LaplaceObjective
+            from .laplace import EngineLaplaceObjective
             free = set(pb.free_index().tolist())
             idx_r = [k for k in range(pb.off_re, pb.off_re + pb.n_re) if k in free]
             idx_o = [k for k in sorted(free) if k not in set(idx_r)]
-            self.tmb_obj_ = LaplaceObjective(lambda p: self.engine_.eval(p, order=1), self._par_full(pb), idx_o, idx_r)
+            # fn / gr = ssde_laplace_eval: the entry point an R or C host uses for random = "coeff_re"
+            self.tmb_obj_ = EngineLaplaceObjective(self.engine_, self._par_full(pb), idx_o, idx_r)
         # joint object "excluding penalty" (R/sde.R:663-669): include_penalty = 0 is honoured by the
         # direct families only (Q7); the Kalman families share the same engine
         if pb.kalman or pb.n_smooth == 0:
