@@ -29,7 +29,7 @@ t2 = time.perf_counter()
 rep = sde.report()
 t3 = time.perf_counter()
 obj = sde.tmb_obj()
-print(f"setup {t1 - t0:.2f} s, fit {t2 - t1:.2f} s ({out['counts']} outer fn/gr calls, {getattr(obj, 'n_joint_eval', getattr(obj, 'n_eval', '?'))} GPU evaluations of "
+print(f"setup {t1 - t0:.2f} s, fit {t2 - t1:.2f} s ({out['counts']} outer fn/gr calls, {sde.engine_.info()['n_evals']} GPU evaluations of "
       f"the joint nllk+gradient), report {t3 - t2:.2f} s; value {out['value']:.4f}, convergence {out['convergence']}")
 print("tau(temp) range", np.round(np.percentile(sde.par()["tau"], [0, 50, 100]), 3), " nu(temp) range",
       np.round(np.percentile(sde.par()["nu"], [0, 50, 100]), 3), " sigma_obs", round(float(np.exp(sde.log_sigma_obs_)), 4),
