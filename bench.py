@@ -330,6 +330,7 @@ def main():
                    "api": "ssde_eval (synchronous C ABI call)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": profiled,
+                     "frac_of_measured_copy_6290": achieved / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s measured copy
                      "required_bytes_per_row": info["required_bytes_per_row"],
                      "algo_bytes_per_row": info["algo_bytes_per_row"],
                      "achieved_algorithmic": achieved_algo, "frac_algorithmic": achieved_algo / HBM_PEAK_GBS,
