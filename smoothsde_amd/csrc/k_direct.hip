@@ -220,7 +220,14 @@ hipError_t launch_pp_materialise(const PPRef& pp, int K, int64_t n, double* dst,
 
 // ---- fast kernel -------------------------------------------------------------------------------------
 // KA / KB: register capacity for the streamed columns of the (at most two) parameters that have any.
-template <int MODEL, int D, int KA, int KB>
+// PPA: group A is KNOWN to be table-backed (and there is no group B): a kernel of its own, without the registers of the
+// streamed-column look-ahead, which it spends on a deeper ring of its three-doubles-per-row inputs instead -- the
+// table variant is bound by occupancy x round-trip latency (167 VGPRs = three waves per SIMD, one row ahead: ~4.7 MB in
+// flight chip-wide where 6 TB/s x 1.5 us want ~9 MB), not by its arithmetic.
+#ifndef SSDE_PP_PF
+#define SSDE_PP_PF 2          // rows of look-ahead per thread in the table-backed kernel
+#endif
+template <int MODEL, int D, int KA, int KB, bool PPA>
 __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A) {
     constexpr int Q = (MODEL == M_BM || MODEL == M_BM_T) ? D + 1 : D + 2;
     const int ncA = A.ncA, ncB = A.ncB, ja = A.ja, jb = A.jb;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     const bool varies1 = (ja == D) || (jb == D), varies2 = (ja == D + 1) || (jb == D + 1);
     // groups given as basis tables: coefficients and knots into LDS once per workgroup
     __shared__ double ldsA[(KA > 0) ? PP_LDS : 1], ldsB[(KB > 0) ? PP_LDS : 1];
-    const bool ppa = KA > 0 && A.ppA.x != nullptr, ppb = KB > 0 && A.ppB.x != nullptr;
+    const bool ppa = PPA || (KA > 0 && A.ppA.x != nullptr), ppb = KB > 0 && A.ppB.x != nullptr;
     if (ppa) {
         const int nt = (A.ppA.nk - 1) * ncA * 4;
         for (int k = threadIdx.x; k < nt + A.ppA.nk; k += 256) ldsA[k] = k < nt ? A.ppA.tab[k] : A.ppA.knots[k - nt];
@@ -276,52 +283,63 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
     // covariate of a basis-evaluated block heads a dependent chain (x -> interval -> LDS table -> predictor) and the
     // observations are only needed after it, so without the look-ahead every row exposed two HBM round trips.
     const int64_t nlast = n - 1;
-    double zq0[D], zq1[D], xqA = 0.0, xqB = 0.0;
+    constexpr int PF = PPA ? SSDE_PP_PF : 1;               // rows of look-ahead per thread
+    double zq0[PF][D], zq1[PF][D], xqA[PF], xqB[PF];
     // ... and so are the word of the scored mask that holds row r + 1 and, where dt is not hoisted, the two time stamps:
     // they used to be fetched inside the row (a dependent L2 / HBM round trip per row: 0.90 -> 0.71 ms on C3's table variant)
-    uint32_t sq = 0u;
-    double tq0 = 0.0, tq1 = 0.0;
-    double wqA[KA > 0 ? KA : 1], wqB[KB > 0 ? KB : 1];   // streamed columns of the next row
-    {
-        const int64_t r0 = row_lo + threadIdx.x < nlast ? row_lo + threadIdx.x : nlast, i0 = r0 + 1 < nlast ? r0 + 1 : nlast;
+    uint32_t sq[PF];
+    double tq0[PF], tq1[PF];
+    double wqA[(KA > 0 && !PPA) ? KA : 1], wqB[KB > 0 ? KB : 1];   // streamed columns of the next row
 #pragma unroll
-        for (int a = 0; a < D; a++) { zq0[a] = __builtin_nontemporal_load(&A.obs[r0 + (int64_t)a * n]); zq1[a] = A.obs[i0 + (int64_t)a * n]; }
-        if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[r0]);
-        if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[r0]);
-        sq = A.scored[i0 >> 5];
-        if (!all_const) { tq0 = __builtin_nontemporal_load(&A.times[r0]); tq1 = A.times[i0]; }
-        if (!ppa) {
+    for (int k = 0; k < PF; k++) {
+        const int64_t rr = row_lo + threadIdx.x + (int64_t)256 * k;
+        const int64_t r0 = rr < nlast ? rr : nlast, i0 = r0 + 1 < nlast ? r0 + 1 : nlast;
 #pragma unroll
-            for (int c = 0; c < KA; c++) wqA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r0]);
+        for (int a = 0; a < D; a++) { zq0[k][a] = __builtin_nontemporal_load(&A.obs[r0 + (int64_t)a * n]); zq1[k][a] = A.obs[i0 + (int64_t)a * n]; }
+        xqA[k] = ppa ? __builtin_nontemporal_load(&A.ppA.x[r0]) : 0.0;
+        xqB[k] = ppb ? __builtin_nontemporal_load(&A.ppB.x[r0]) : 0.0;
+        sq[k] = A.scored[i0 >> 5];
+        tq0[k] = all_const ? 0.0 : __builtin_nontemporal_load(&A.times[r0]);
+        tq1[k] = all_const ? 0.0 : A.times[i0];
+        if constexpr (!PPA) {
+            if (k == 0 && !ppa) {
+#pragma unroll
+                for (int c = 0; c < KA; c++) wqA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + r0]);
+            }
         }
-        if (!ppb) {
+        if (k == 0 && !ppb) {
 #pragma unroll
             for (int c = 0; c < KB; c++) wqB[c] = __builtin_nontemporal_load(&A.colB[(int64_t)(c < ncB ? c : ncB - 1) * A.col_stride + r0]);
         }
     }
-    for (int64_t r = row_lo + threadIdx.x; r < row_hi; r += 256) {
+    for (int64_t rbase = row_lo + threadIdx.x; rbase < row_hi; rbase += (int64_t)256 * PF) {
+#pragma unroll
+    for (int kpf = 0; kpf < PF; kpf++) {
+        const int64_t r = rbase + (int64_t)256 * kpf;
+        if (r >= row_hi) continue;
         const int64_t i = r + 1;
         double zc0[D], zc1[D];
 #pragma unroll
-        for (int a = 0; a < D; a++) { zc0[a] = zq0[a]; zc1[a] = zq1[a]; }
-        const double xcA = xqA, xcB = xqB;
-        const uint32_t sc = sq;
-        const double tc0 = tq0, tc1 = tq1;
+        for (int a = 0; a < D; a++) { zc0[a] = zq0[kpf][a]; zc1[a] = zq1[kpf][a]; }
+        const double xcA = xqA[kpf], xcB = xqB[kpf];
+        const uint32_t sc = sq[kpf];
+        const double tc0 = tq0[kpf], tc1 = tq1[kpf];
         {
-            const int64_t rn = r + 256 < nlast ? r + 256 : nlast, in = rn + 1 < nlast ? rn + 1 : nlast;
+            const int64_t rq = r + (int64_t)256 * PF;
+            const int64_t rn = rq < nlast ? rq : nlast, in = rn + 1 < nlast ? rn + 1 : nlast;
 #pragma unroll
-            for (int a = 0; a < D; a++) { zq0[a] = __builtin_nontemporal_load(&A.obs[rn + (int64_t)a * n]); zq1[a] = A.obs[in + (int64_t)a * n]; }
-            if (ppa) xqA = __builtin_nontemporal_load(&A.ppA.x[rn]);
-            if (ppb) xqB = __builtin_nontemporal_load(&A.ppB.x[rn]);
-            sq = A.scored[in >> 5];
-            if (!all_const) { tq0 = __builtin_nontemporal_load(&A.times[rn]); tq1 = A.times[in]; }
+            for (int a = 0; a < D; a++) { zq0[kpf][a] = __builtin_nontemporal_load(&A.obs[rn + (int64_t)a * n]); zq1[kpf][a] = A.obs[in + (int64_t)a * n]; }
+            if (ppa) xqA[kpf] = __builtin_nontemporal_load(&A.ppA.x[rn]);
+            if (ppb) xqB[kpf] = __builtin_nontemporal_load(&A.ppB.x[rn]);
+            sq[kpf] = A.scored[in >> 5];
+            if (!all_const) { tq0[kpf] = __builtin_nontemporal_load(&A.times[rn]); tq1[kpf] = A.times[in]; }
         }
         // streamed columns of row i-1 (Q6): this row's values were requested one iteration ago, the next row's are
         // requested now.  ALL KA / KB register slots are loaded unconditionally (slots past the column count re-read
         // the last real column and carry a zero coefficient): a guard per slot would make hipcc branch around every
         // load and wait for it (one dependent HBM round trip per column; cdna_hip_programming.md section 5, trap (c)).
         double wA[KA > 0 ? KA : 1], wB[KB > 0 ? KB : 1];
-        if (!ppa) {
+        if constexpr (!PPA) if (!ppa) {
             const int64_t rn = r + 256 < nlast ? r + 256 : nlast;
 #pragma unroll
             for (int c = 0; c < KA; c++) { wA[c] = wqA[c]; wqA[c] = __builtin_nontemporal_load(&A.colA[(int64_t)(c < ncA ? c : ncA - 1) * A.col_stride + rn]); }
@@ -423,6 +441,7 @@ __global__ __launch_bounds__(256) void direct_fast_kernel(const DirectFastArgs A
 #pragma unroll
         for (int c = 0; c < KB; c++) accB[c] = fma(wB[c], gB, accB[c]);
     }
+    }
 
     // workgroup reduction: accumulator order = [nll | Q intercept slots | ncA | ncB]
     constexpr int NMAX = 1 + MAX_Q + KA + KB;
@@ -449,7 +468,10 @@ hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s) {
     dim3 grid(a.n_blocks), block(256);
 #define SSDE_F(MODEL, D, KA, KB)                                                            \
     if (a.model == MODEL && a.d == D && a.ncA <= KA && a.ncB <= KB && (KA == 0 || a.ncA > 0) && (KB == 0 || a.ncB > 0)) { \
-        hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB>), grid, block, 0, s, a);   \
+        if constexpr (KA > 0 && KB == 0) {                                                  \
+            if (a.ppA.x != nullptr) { hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB, true>), grid, block, 0, s, a); return hipGetLastError(); } \
+        }                                                                                   \
+        hipLaunchKernelGGL((direct_fast_kernel<MODEL, D, KA, KB, false>), grid, block, 0, s, a);   \
         return hipGetLastError();                                                           \
     }
 #define SSDE_FK(MODEL, D) SSDE_F(MODEL, D, 0, 0) SSDE_F(MODEL, D, 9, 0) SSDE_F(MODEL, D, 12, 0) SSDE_F(MODEL, D, 24, 0) SSDE_F(MODEL, D, 12, 12) SSDE_F(MODEL, D, 24, 24)
