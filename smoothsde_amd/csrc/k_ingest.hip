@@ -138,4 +138,26 @@ hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipSt
     return hipGetLastError();
 }
 
+// Dimension parts of a Kalman problem wider than two columns (ssde_engine_dist.hip): the reference decides "missing" on
+// column 0 of the WHOLE response (nllk_ctcrw.hpp:214), a part other than the first one reads it off its own first column.
+// Rewrites that column so that the two agree: missing where the lead column is, and an OBSERVED NaN (not R's NA payload)
+// where the lead column is observed and this one is not a number -- the reference then scores a NaN innovation.  With
+// SSDE_NA_ANY_NAN there is no NaN that is not "missing": such a row raises *poison and the parent returns NaN.
+// First rows of a track are only ever read through the default a0 (nllk_ctcrw.hpp:196-200) and stay as they are.
+__global__ void na_follow_kernel(const double* id, const double* lead, double* col, int64_t n, int any_nan, int* poison) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i == 0 || id[i] != id[i - 1]) return;
+    const double v = col[i];
+    if (is_na(lead[i], any_nan)) col[i] = __longlong_as_double(0x7FF00000000007A2ll);        // NA_real_
+    else if (v != v) {
+        if (any_nan) atomicOr(poison, 1);
+        else col[i] = __longlong_as_double(0x7FF8000000000000ll);
+    }
+}
+hipError_t launch_na_follow(const double* id, const double* lead, double* col, int64_t n, int any_nan, int* poison, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(na_follow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, id, lead, col, n, any_nan, poison);
+    return hipGetLastError();
+}
+
 }  // namespace ssde

@@ -165,6 +165,7 @@ hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 hipError_t launch_scored_mask(const double* id, int64_t n, uint32_t* mask, hipStream_t s);
 // first-row flags for segment discovery on device data
 hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipStream_t s);
+hipError_t launch_na_follow(const double* id, const double* lead, double* col, int64_t n, int any_nan, int* poison, hipStream_t s);
 
 // ---- general parameter description for the dense / direct kernels -------------------------------
 // Every coefficient of the linear predictor (nllk_ctcrw.hpp:143-149) is a "slot": SDE parameter

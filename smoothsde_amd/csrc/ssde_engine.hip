@@ -7,6 +7,7 @@
 #include "ssde_engine.hpp"
 
 #include <chrono>
+#include <limits>
 
 namespace ssde_engine {
 thread_local std::string g_create_error;
@@ -69,9 +70,9 @@ int choose_iso_split(ssde_handle* h) {
     const ParLayout& L = h->L;
     if (!h->fixed[0]) m |= DIR_SIG;
     for (int a = 0; a < h->d; a++)
-        if (!h->fixed[L.off_fe + a]) m |= DIR_MU;
-    if (!h->fixed[L.off_fe + h->d]) m |= DIR_P1;
-    if (h->q > h->d + 1 && !h->fixed[L.off_fe + h->d + 1]) m |= DIR_P2;
+        if (!h->fixed[L.off_fe + L.fe_off[a]]) m |= DIR_MU;         // (fe_off[j] == j here: constant coefficients; a dimension
+    if (!h->fixed[L.off_fe + L.fe_off[h->d]]) m |= DIR_P1;          //  part indexes the whole problem's vector, child_layout)
+    if (h->q > h->d + 1 && !h->fixed[L.off_fe + L.fe_off[h->d + 1]]) m |= DIR_P2;
     h->iso_free_mask = m;
     // Direction split: a 10^4-track batch is only ~160 waves for 1024 SIMDs; give every
     // covariance-affecting direction its own wave (each recomputes the cheap primal) until
@@ -110,7 +111,7 @@ int choose_iso_split(ssde_handle* h) {
 }  // namespace
 
 namespace ssde_engine {
-int build(const ssde_desc* d, ssde_handle* h) {
+int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
     if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_CIR) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
@@ -165,8 +166,10 @@ int build(const ssde_desc* d, ssde_handle* h) {
         for (int c = 0; c < d->n_decay_cols; c++)
             if (d->ind_decay[c] < 0 || d->ind_decay[c] >= d->n_decay) return fail(h, SSDE_ERR_ARG, "ind_decay out of range");
     }
-    h->L = make_layout(d);
-    if (d->n_decay > 0) {
+    // a dimension part of a wider problem (ssde_engine_dist.hip) indexes the WHOLE problem's parameter vector: its layout,
+    // the decay / smooth bookkeeping and the penalty are the parent's, validated there
+    h->L = part_layout ? *part_layout : make_layout(d);
+    if (d->n_decay > 0 && !part_layout) {
         // a column index that matches no random-effect column would silently not decay while log_decay stays a
         // free parameter with a zero gradient (the reference stops on an unknown name, R/sde.R:637-640)
         std::vector<uint8_t> seen((size_t)std::max(h->L.n_re, 1), 0);
@@ -178,10 +181,12 @@ int build(const ssde_desc* d, ssde_handle* h) {
         }
     }
     if (h->L.n_full > MAX_PAR) return fail(h, SSDE_ERR_ARG, "too many parameters for the kernel argument block");
-    int nsm = 0;
-    for (int s = 0; s < d->n_smooth; s++) nsm += d->smooth_ncol[s];
-    if (nsm != h->L.n_re) return fail(h, SSDE_ERR_ARG, "smooth_ncol does not add up to the random-effect columns");
-    h->pen.setup(d);
+    if (!part_layout) {
+        int nsm = 0;
+        for (int s = 0; s < d->n_smooth; s++) nsm += d->smooth_ncol[s];
+        if (nsm != h->L.n_re) return fail(h, SSDE_ERR_ARG, "smooth_ncol does not add up to the random-effect columns");
+        h->pen.setup(d);
+    }
     h->slots = make_slots(d, h->L, &h->n_stream_cols);
     if ((int)h->slots.size() > MAX_COLS || h->n_stream_cols > MAX_COLS)
         return fail(h, SSDE_ERR_ARG, "too many design columns (limit 96)");
@@ -842,10 +847,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.uniform_dt = h->uniform_dt ? 1 : 0;
         const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
         a.h = sig * sig;                                    // makeH: sigma_obs * sigma_obs
-        for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + i];
+        for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + L.fe_off[i]];
         for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
-        const double p1 = par[L.off_fe + h->d];
-        const double p2 = (h->q > h->d + 1) ? par[L.off_fe + h->d + 1] : 0.0;
+        const double p1 = par[L.off_fe + L.fe_off[h->d]];
+        const double p2 = (h->q > h->d + 1) ? par[L.off_fe + L.fe_off[h->d + 1]] : 0.0;
         if (h->model == SSDE_MODEL_CTCRW) {
             a.tau = exp(p1);                                // :153
             const double nu = exp(p2);                      // :154
@@ -947,7 +952,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         if (h->use_shared) {
             ra.add_slot[0] = 0;
             if (order >= 1) {
-                const int pj[NDIRP] = {0, L.off_fe + h->d, L.off_fe + h->d + 1};
+                const int pj[NDIRP] = {0, L.off_fe + L.fe_off[h->d], h->q > h->d + 1 ? L.off_fe + L.fe_off[h->d + 1] : 0};
                 for (int j = 0; j < NDIRP; j++)
                     if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
             }
@@ -959,7 +964,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         if (order >= 1) {
             for (int p = 0; p < a.n_parts; p++)
                 for (int k = 1; k < nacc; k++) {
-                    const int pidx = k - 1;  // accumulators are ordered like the parameter vector
+                    // accumulators are ordered like the constant-coefficient parameter vector: sigma_obs, one per SDE parameter
+                    const int j = k - 2;     // SDE parameter of accumulator k (k == 1: log_sigma_obs)
+                    if (j >= h->q) continue;
+                    const int pidx = j < 0 ? 0 : L.off_fe + L.fe_off[j];
                     if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
                 }
         }
@@ -1075,7 +1083,9 @@ int ssde_create(const ssde_desc* desc, ssde_handle** out) {
     *out = nullptr;
     ssde_handle* h = new (std::nothrow) ssde_handle();
     if (!h) { g_create_error = "out of host memory"; return SSDE_ERR_ALLOC; }
-    const bool sharded = desc->abi_version == SSDE_ABI_VERSION && desc->n_devices > 1 && desc->devices;
+    // several engines behind one handle: whole tracks over several devices, and / or a response wider than two columns
+    // evaluated as pairs of columns (the likelihood is a sum over dimensions whenever P0 and H do not couple them)
+    const bool sharded = desc->abi_version == SSDE_ABI_VERSION && ((desc->n_devices > 1 && desc->devices) || desc->n_dim > 2);
     int st = sharded ? create_sharded(desc, h) : build(desc, h);
     if (st != SSDE_OK) {
         g_create_error = h->err;
@@ -1094,7 +1104,25 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
                      void* stream) {
     if (!h || !par || !out_dev) return SSDE_ERR_ARG;
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
-    if (!h->shards.empty()) { h->err = "ssde_eval_device: a multi-device handle is evaluated with ssde_eval"; return SSDE_ERR_ARG; }
+    if (!h->shards.empty()) {
+        if (h->n_track_shards > 1) { h->err = "ssde_eval_device: a multi-device handle is evaluated with ssde_eval"; return SSDE_ERR_ARG; }
+        // the dimension parts of a wide response, all on one device: evaluate them on the caller's stream and sum them there
+        const size_t count = 2 + (size_t)h->L.n_full;
+        HIPCHK(h, hipSetDevice(h->device));
+        for (ssde_handle* sh : h->shards) {
+            int st = eval_device(sh, par, order, sh->out.p, (hipStream_t)stream);
+            if (st) { h->err = sh->err; return st; }
+        }
+        HIPCHK(h, hipMemcpyAsync(out_dev, h->shards[0]->out.p, count * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        for (size_t e = 1; e < h->shards.size(); e++)
+            HIPCHK(h, launch_sum_into(out_dev, h->shards[e]->out.p, (int)count, (hipStream_t)stream));
+        if (h->poison) {
+            static const double nan_value = std::numeric_limits<double>::quiet_NaN();
+            HIPCHK(h, hipMemcpyAsync(out_dev, &nan_value, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+        }
+        if (h->comms.empty()) return SSDE_OK;
+        return reduce_ranks(h, out_dev, (hipStream_t)stream);
+    }
     int st = eval_device(h, par, order, out_dev, (hipStream_t)stream);
     if (st || h->comms.empty()) return st;
     return reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
@@ -1276,6 +1304,8 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
     std::vector<double> o(2 + np);
     int st = run_checked(h, par, eval_order, o);
     if (st) return st;
+    if (h->poison)                     // SSDE_NA_ANY_NAN, wide response: a NaN outside column 0 of an observed row (a NaN innovation
+        for (size_t k = 0; k < 1 + np; k++) o[k] = (k == 0 || !h->fixed[k - 1]) ? std::numeric_limits<double>::quiet_NaN() : 0.0;   // in the reference)
     double pen = 0.0;
     h->memo_order = -1;
     h->memo_par.assign(par, par + np);
@@ -1403,22 +1433,37 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     memset(info, 0, sizeof(*info));
     if (!h->shards.empty()) {
         // a multi-device parent: totals over the shards, plan and path of shard 0, the slowest shard's kernel time
+        // Engine k = track shard k / P, dimension part k % P.  Rows and tracks are counted once per track shard; the bytes a
+        // row costs add up over its dimension parts (each part streams its own columns; the time stamp is counted once).
         ssde_info_t si;
+        const int P = h->n_dim_parts;
+        double algo = 8.0, required = 0.0, ms_shard = 0.0;
         for (size_t k = 0; k < h->shards.size(); k++) {
             ssde_info(h->shards[k], &si);
+            const bool first_part = k % P == 0;
             if (k == 0) *info = si;
             else {
-                info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps;
-                info->hbm_bytes += si.hbm_bytes; info->main_kernel_rows += si.main_kernel_rows;
+                if (first_part) { info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps; info->main_kernel_rows += si.main_kernel_rows; }
+                info->hbm_bytes += si.hbm_bytes;
                 info->n_kernel_blocks += si.n_kernel_blocks;   // (n_evals: shard 0's count -- every shard runs every evaluation)
-                info->main_kernel_ms = std::max(info->main_kernel_ms, si.main_kernel_ms);
                 info->uniform_dt = info->uniform_dt && si.uniform_dt;
-                info->required_bytes_per_row = std::max(info->required_bytes_per_row, si.required_bytes_per_row);
+                info->const_coeff = info->const_coeff && si.const_coeff;
             }
+            // the parts of one track shard run one after the other on their device; the shards side by side
+            ms_shard = first_part ? si.main_kernel_ms : ms_shard + si.main_kernel_ms;
+            if (k == 0 || ms_shard > info->main_kernel_ms) info->main_kernel_ms = ms_shard;
+            if (k < (size_t)P) { algo += si.algo_bytes_per_row - 8.0; required += si.required_bytes_per_row; }
+        }
+        if (P > 1) {
+            // SURVEY 8(d)'s figure counts the time stamp once; what the parts really read counts it once per part that
+            // reads it at all (none does on a globally regular grid)
+            info->algo_bytes_per_row = algo;
+            info->required_bytes_per_row = required;
+            info->sdim = h->sdim;
         }
         info->window_check = h->last_check; info->window_retries = h->n_retries; info->window_check_max = h->check_max;
         info->n_memo_hits = h->n_memo_hits;
-        info->n_devices = (int32_t)h->shards.size(); info->comm_ranks = 1;
+        info->n_devices = h->n_track_shards; info->comm_ranks = h->comm_ranks;
         return SSDE_OK;
     }
     info->n_par_full = h->L.n_full;

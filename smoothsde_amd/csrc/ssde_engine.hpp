@@ -202,7 +202,13 @@ struct ssde_handle {
     // ---- distributed evaluation (ssde_engine_dist.hip) -------------------------------------------------------------
     // single-process multi-GPU parent (ssde_desc.n_devices > 1): one engine per device, this handle owns no device data
     std::vector<ssde_handle*> shards;
-    std::vector<int64_t> shard_row0;          // first global row of each shard (+ n at the end)
+    std::vector<int64_t> shard_row0;          // first global row of each engine
+    std::vector<int64_t> shard_nrows;         // its rows
+    std::vector<int> shard_col0;              // first column of aest_all it reports (dimension parts: 2 or 4 columns each)
+    std::vector<int> shard_leader;            // index of the first engine on the same device (its stream and out buffer
+                                              // collect that device's engines before the collective)
+    int n_track_shards = 1, n_dim_parts = 1;
+    bool poison = false;                      // SSDE_NA_ANY_NAN, n_dim > 2: an observed row with a NaN outside column 0
     std::vector<void*> comms;                 // ncclComm_t: one per shard (parent), or one (ssde_comm_init_rank)
     bool shards_share_device = false;         // rehearsal on a one-GPU machine: shards summed by a kernel, not RCCL
     int comm_ranks = 1;                       // ranks of a multi-process communicator
@@ -237,7 +243,7 @@ namespace ssde_engine {
 int fail(ssde_handle* h, int code, const std::string& msg);
 
 // ssde_engine.hip
-int build(const ssde_desc* d, ssde_handle* h);
+int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout = nullptr);
 void destroy(ssde_handle* h);
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s);
 

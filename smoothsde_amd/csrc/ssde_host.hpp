@@ -60,6 +60,20 @@ inline ParLayout make_layout(const ssde_desc* d) {
     return L;
 }
 
+// Layout of a DIMENSION PART (responses wider than two columns are evaluated as pairs of columns, ssde_engine_dist.hip):
+// the part sees the SDE parameters jmap[0..) of the whole problem -- its own mu's and the shared ones -- but indexes them
+// inside the WHOLE problem's vector, so that its gradient lands where the parent's does and the parts can simply be summed.
+inline ParLayout child_layout(const ParLayout& P, const std::vector<int>& jmap) {
+    ParLayout L = P;
+    L.q = (int)jmap.size();
+    L.fe_off.clear(); L.re_off.clear(); L.ncol_fe.clear(); L.ncol_re.clear();
+    for (int j : jmap) {
+        L.fe_off.push_back(P.fe_off[j]); L.ncol_fe.push_back(P.ncol_fe[j]);
+        L.re_off.push_back(P.re_off[j]); L.ncol_re.push_back(P.ncol_re[j]);
+    }
+    return L;
+}
+
 // One coefficient of the linear predictor par_vec = X_fe coeff_fe + X_re coeff_re (nllk_ctcrw.hpp:143)
 struct Slot {
     int par_j;            // SDE parameter

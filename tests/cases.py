@@ -240,4 +240,11 @@ def all_specs():
     # Cox-Ingersoll-Ross (tr_dens.hpp:53-67)
     specs.append(make_spec("CIR_d1_const", "CIR", 1, seed=221, lengths=[9, 2, 14, 6], na_rows=(3, 12)))
     specs.append(make_spec("CIR_d2_tv", "CIR", 2, seed=222, lengths=[14, 10], variant="tv", na_rows=(5,)))
+    # responses wider than two columns (nllk_ctcrw.hpp:12-24: log-determinant beyond n_dim = 2; nllk_sde.hpp:77-84)
+    specs.append(make_spec("CTCRW_d3_const", "CTCRW", 3, seed=231, lengths=[9, 2, 14, 6, 11], na_rows=(3, 16, 17, 30)))
+    specs.append(make_spec("CTCRW_d4_const_regular_RNA", "CTCRW", 4, seed=232, lengths=[12, 12, 12], irregular=False, na_rows=(7,), na_mode=0))
+    specs.append(make_spec("OU_SSM_d3_tv", "OU_SSM", 3, seed=233, lengths=[13, 8, 10], variant="tv", na_rows=(5,)))
+    specs.append(make_spec("BM_SSM_d5_const", "BM_SSM", 5, seed=234, lengths=[10, 7, 9]))
+    specs.append(make_spec("OU_d3_tv2", "OU", 3, seed=235, lengths=[16, 11], variant="tv2", na_rows=(5,)))
+    specs.append(make_spec("BM_d4_const", "BM", 4, seed=236, lengths=[9, 2, 14, 6], na_rows=(3, 12)))
     return specs

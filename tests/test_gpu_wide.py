@@ -1,0 +1,179 @@
+"""GPU suite (-m gpu): responses wider than two columns (n_dim > 2).
+
+The reference takes any n_dim (nllk_ctcrw.hpp:12-24 switches to a log-determinant beyond two dimensions; nllk_sde.hpp:77-84
+loops over them); the engine evaluates such a response as pairs of columns behind one handle (csrc/ssde_engine_dist.hip).
+Checked here against the oracle, which runs the reference's full n_dim-dimensional matrix recursion.
+
+Tolerances as in test_gpu_parity.py: value 1e-10 relative, gradient 1e-8 * max|g| + 1e-10."""
+import numpy as np
+import pytest
+
+from cases import make_spec, problem_from_spec
+from oracle_lib import oracle_eval
+from smoothsde_amd import capi
+from smoothsde_amd.capi import na_real
+
+pytestmark = pytest.mark.gpu
+
+VT = 1e-10
+LENGTHS = [40, 7, 23, 2, 61, 1, 30]
+
+
+def _close(val, grad, eval_, egrad):
+    assert abs(val - eval_) <= VT * max(1.0, abs(eval_)), (val, eval_)
+    assert np.max(np.abs(grad - egrad)) <= 1e-8 * np.max(np.abs(egrad)) + 1e-10, (grad, egrad)
+
+
+CASES = [
+    ("CTCRW", 3, "const", {}), ("CTCRW", 4, "const", dict(irregular=False)), ("CTCRW", 3, "tv", {}), ("CTCRW", 3, "const", dict(fix_mu=True)),
+    ("OU_SSM", 3, "const", {}), ("OU_SSM", 5, "tv2", {}), ("OU_SSM", 8, "const", dict(irregular=False)),
+    ("BM_SSM", 3, "const", {}), ("BM_SSM", 4, "tv", {}),
+    ("OU", 3, "const", {}), ("OU", 3, "tv2", {}), ("OU", 5, "tv", dict(decay=True)),
+    ("BM", 4, "tv", {}), ("BM", 3, "const", dict(irregular=False)), ("CIR", 3, "const", {}), ("CIR", 4, "tv", {}),
+]
+
+
+@pytest.mark.parametrize("na_mode", [0, 1])
+@pytest.mark.parametrize("model,d,variant,kw", CASES, ids=[f"{m}_d{d}_{v}{'_' + '_'.join(k) if k else ''}" for m, d, v, k in CASES])
+def test_wide_response_matches_the_oracle(model, d, variant, kw, na_mode):
+    spec = make_spec("wide", model, d, seed=100 + d, lengths=LENGTHS, variant=variant, na_rows=(5, 17, 50, 90),
+                     na_mode=na_mode, **kw)
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    assert np.isfinite(oval)
+    _close(val, grad, oval, ograd)
+    assert eng.eval(spec["par"], order=0) == val
+    info = eng.info()
+    assert info["n_rows"] == pb.n and info["n_tracks"] == len(LENGTHS) and info["sdim"] == pb.sdim
+    assert info["n_par_full"] == pb.n_par_full and info["n_devices"] == 1
+    if model in ("CTCRW", "OU_SSM", "BM_SSM"):
+        aest = eng.report(spec["par"])
+        _, _, oaest = oracle_eval(pb, spec["par"], order=1, report=True)
+        assert np.allclose(aest, oaest, rtol=1e-10, atol=1e-10, equal_nan=True)
+    eng.close()
+
+
+@pytest.mark.parametrize("model,d", [("CTCRW", 3), ("OU_SSM", 3), ("BM_SSM", 5)])
+@pytest.mark.parametrize("na_mode", [0, 1])
+def test_missing_rows_are_decided_on_column_zero_of_the_whole_response(model, d, na_mode):
+    """nllk_ctcrw.hpp:214 tests obs(i, 0) only: a row whose column 0 is missing is skipped for every dimension, whatever
+    the other columns hold; a NaN elsewhere in an OBSERVED row is a NaN innovation (the result is NaN)."""
+    spec = make_spec("wide_na", model, d, seed=7, lengths=[30, 12, 25], na_mode=na_mode)
+    na = na_real() if na_mode == 0 else float("nan")
+    obs = spec["obs"]
+    obs[4, 0] = na                       # column 0 only: the row is missing although columns 1.. hold numbers
+    obs[9, :] = na
+    obs[33, 0] = na; obs[33, d - 1] = na
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    assert np.isfinite(oval)
+    _close(val, grad, oval, ograd)
+    eng.close()
+    # an NA in the last column of an observed row
+    obs[20, d - 1] = na
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    oval = oracle_eval(pb, spec["par"], order=0)
+    assert np.isnan(oval) and np.isnan(val)
+    eng.close()
+
+
+def test_block_diagonal_P0_and_supplied_a0():
+    d, model = 3, "CTCRW"
+    spec = make_spec("wide_p0", model, d, seed=11, lengths=[25, 14, 31])
+    rng = np.random.default_rng(3)
+    P0 = np.zeros((6, 6))
+    A = rng.standard_normal((4, 4)); P0[:4, :4] = A @ A.T + np.eye(4)       # columns (0, 1) coupled with each other: their own pair
+    B = rng.standard_normal((2, 2)); P0[4:, 4:] = B @ B.T + np.eye(2)
+    spec["P0"] = P0
+    spec["a0"] = rng.standard_normal((3, 6))
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    _close(val, grad, oval, ograd)
+    aest = eng.report(spec["par"])
+    _, _, oaest = oracle_eval(pb, spec["par"], order=1, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-10, atol=1e-10, equal_nan=True)
+    eng.close()
+
+
+def test_what_couples_the_pairs_is_refused_with_a_reason():
+    spec = make_spec("wide_bad", "CTCRW", 3, seed=5, lengths=[20, 20])
+    P0 = np.eye(6); P0[0, 4] = P0[4, 0] = 0.1
+    with pytest.raises(capi.EngineError, match="P0 must not couple"):
+        capi.Engine(problem_from_spec(dict(spec, P0=P0)))
+    spec = make_spec("wide_bad", "OU_SSM", 3, seed=5, lengths=[20, 20], with_H=True)
+    with pytest.raises(capi.EngineError, match="H_array"):
+        capi.Engine(problem_from_spec(spec))
+
+
+@pytest.mark.parametrize("model,d", [("CTCRW", 3), ("OU", 4), ("OU_SSM", 5)])
+def test_wide_response_over_several_engines_per_device_and_device_resident_data(model, d):
+    """track shards x dimension parts (the one-GPU rehearsal of a multi-device handle), and construction from HBM arrays"""
+    import torch
+    spec = make_spec("wide_md", model, d, seed=21, lengths=[40, 7, 23, 18, 61, 30], na_rows=(5, 50))
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    eng.close()
+    eng2 = capi.Engine(pb, devices=[0, 0, 0])
+    v2, g2 = eng2.eval(spec["par"], order=1)
+    info = eng2.info()
+    assert info["n_devices"] == 3 and info["n_rows"] == pb.n and info["n_tracks"] == 6
+    assert abs(v2 - val) <= 1e-12 * max(1.0, abs(val)) and np.max(np.abs(g2 - grad)) <= 1e-11 * max(1.0, np.max(np.abs(grad)))
+    if model != "OU":
+        assert np.allclose(eng2.report(spec["par"]), capi.Engine(pb).report(spec["par"]), rtol=1e-12, atol=1e-12, equal_nan=True)
+    eng2.close()
+    dev = torch.device("cuda:0")
+    pbd = capi.Problem.from_torch(model, torch.as_tensor(spec["ID"], device=dev), torch.as_tensor(spec["times"], device=dev),
+                                  torch.as_tensor(spec["obs"], device=dev), na_mode=spec["na_mode"])
+    eng3 = capi.Engine(pbd)
+    v3, g3 = eng3.eval(spec["par"], order=1)
+    assert v3 == val and np.array_equal(g3, grad)
+    eng3.close()
+
+
+def test_asynchronous_evaluation_and_rank_communicator_on_a_wide_response():
+    """ssde_eval_device sums the dimension parts on the caller's stream; a one-rank communicator joined on top of them
+    leaves the numbers alone"""
+    import torch
+    spec = make_spec("wide_async", "CTCRW", 3, seed=31, lengths=[50, 33, 64])
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    out = torch.zeros(2 + pb.n_par_full, dtype=torch.float64, device="cuda:0")
+    eng.eval_device(spec["par"], out.data_ptr(), order=1, stream=0)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    pen, pgrad = eng.penalty(spec["par"])
+    assert abs(o[0] + pen - val) <= 1e-12 * max(1.0, abs(val))
+    assert np.max(np.abs(o[1:-1] + pgrad - grad)) <= 1e-11 * max(1.0, np.max(np.abs(grad)))
+    eng.comm_init(1, 0, capi.comm_unique_id())
+    eng.forget()
+    v2, g2 = eng.eval(spec["par"], order=1)
+    assert v2 == val and np.array_equal(g2, grad)
+    assert eng.info()["comm_ranks"] == 1
+    eng.close()
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM", "BM_SSM"])
+def test_wide_batch_on_the_shared_covariance_path_full_windows(model):
+    """enough rows for time windows and the shared-covariance kernels in every dimension part; tracks sampled against the oracle"""
+    from smoothsde_amd.synth import simulate
+    M, T, d = 256, 1500, 3
+    ID, times, obs = simulate(model, M, T, d, seed=4)
+    pb = capi.Problem(model, ID, times, obs)
+    par = np.array([-1.0, 0.1, -0.2, 0.3, 0.2, 0.1])[: pb.n_par_full] if model != "BM_SSM" else np.array([-1.0, 0.1, -0.2, 0.3, 0.1])
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    info = eng.info()
+    assert info["path"] == 1 and info["window_check"] <= 1e-11
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+    eng.close()
