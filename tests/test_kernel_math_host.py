@@ -11,7 +11,7 @@ from oracle_lib import oracle_eval
 
 GOLD = {r["name"]: r for r in load_golden()}
 ISO = [n for n in GOLD if n.endswith("_const") or n.endswith("_const_regular_fixmu") or n == "elephant6_ctcrw"]
-ISO = [n for n in ISO if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM")]
+ISO = [n for n in ISO if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and GOLD[n]["n_dim"] <= 2]   # lanes hold d <= 2
 
 
 @pytest.mark.parametrize("name", ISO)
@@ -27,7 +27,7 @@ def test_iso_lane_math_matches_golden(name):
 
 
 TV = [n for n in GOLD if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and GOLD[n].get("H") is None
-      and GOLD[n].get("P0") is None]
+      and GOLD[n].get("P0") is None and GOLD[n]["n_dim"] <= 2]
 
 
 @pytest.mark.parametrize("name", TV)
