@@ -24,10 +24,15 @@ def _oracle(pb, par):
     return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4)
 
 
-def random_problem(seed, big=False):
+WIDE_MODELS = ["CTCRW", "OU_SSM", "BM_SSM", "OU", "BM", "CIR"]
+
+
+def random_problem(seed, big=False, wide=False):
     rng = np.random.default_rng(seed)
-    model = MODELS[seed % len(MODELS)]
+    model = MODELS[seed % len(MODELS)] if not wide else WIDE_MODELS[seed % len(WIDE_MODELS)]
     d = 1 if model in ("BM_t", "ESEAL_SSM") else int(rng.integers(1, 3))
+    if wide:                              # responses wider than two columns: column pairs behind one handle
+        d = 3 + (seed // len(WIDE_MODELS)) % 2
     kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
     n_tracks = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(60, 140))
     long_tracks = rng.random() < 0.35
@@ -78,13 +83,16 @@ def random_problem(seed, big=False):
             k = int(rng.integers(3, 7))
             X_re[j] = bspline_basis(np.clip(x ** (1 + 0.5 * j), 0, 1), n_basis=k)
             S_list.append(second_difference_penalty(k))
-    if kalman and rng.random() < 0.25:
+    if kalman and rng.random() < 0.25 and not wide:         # (a per-row H couples the dimensions: d <= 2 only)
         A = rng.standard_normal((n, d, d)) * 0.2
         kw["H"] = np.einsum("nij,nkj->ikn", A, A) + 0.05 * np.eye(d)[:, :, None]
     sdim = capi.state_dim(model, d)
     if kalman and rng.random() < 0.25:
         A = rng.standard_normal((sdim, sdim))
         kw["P0"] = A @ A.T + np.eye(sdim)
+        if wide:                          # no entries between different column pairs
+            pair = np.arange(sdim) // (4 if model == "CTCRW" else 2)
+            kw["P0"] = kw["P0"] * (pair[:, None] == pair[None, :])
     if kalman and rng.random() < 0.2:
         kw["a0"] = rng.standard_normal((n_tracks, sdim)) + (3.0 if model == "OU_SSM" else 0.0)
     if model == "BM_t":
@@ -114,6 +122,29 @@ def random_problem(seed, big=False):
         fixed[-1] = 0
     pb.par_fixed = fixed
     return pb, par
+
+
+_WLO, _WHI = (int(v) for v in os.environ.get("SSDE_FUZZ_WIDE_SEEDS", "0:96").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_WLO, _WHI))
+def test_random_wide_problem_matches_oracle(seed):
+    """n_dim in {3, 4}: the engine's column pairs against the oracle's full n_dim-dimensional matrix recursion"""
+    pb, par = random_problem(seed, wide=True)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    oval, ograd = _oracle(pb, par)
+    ctx = (pb.model, pb.n_dim, pb.n, pb.n_seg, eng.info()["path"])
+    if not np.isfinite(oval):
+        assert not np.isfinite(val), ctx
+    else:
+        assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (ctx, val, oval)
+        assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (ctx, grad, ograd)
+    if pb.kalman:
+        from oracle_lib import oracle_eval
+        _, _, oaest = oracle_eval(pb, par, order=1, report=True, threads=4)
+        assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True), ctx
+    eng.close()
 
 
 # SSDE_FUZZ_SEEDS="lo:hi" widens the net for a one-off hunt (the default 240 seeds run in the suite)
