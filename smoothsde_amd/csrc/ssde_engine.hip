@@ -37,6 +37,7 @@ void destroy(ssde_handle* h) {
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_async) (void)hipEventDestroy(h->ev_async);
     if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
     if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
     h->tv_eh.release(); h->tv_eR.release(); h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
@@ -56,6 +57,7 @@ void destroy(ssde_handle* h) {
     h->slot_table.release(); h->dirs.release(); h->par_ring.release();
     h->partials.release(); h->out.release();
     if (h->par_pinned) (void)hipHostFree(h->par_pinned);
+    if (h->out_pinned) (void)hipHostFree(h->out_pinned);
     if (h->par_ev_ok)
         for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
     delete h;
@@ -145,6 +147,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     if (const char* e = getenv("SSDE_W0_RATIO")) h->env_w0_ratio = atof(e);     // 0 = equal windows on the general kernel
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
+    h->env_own_stream = getenv("SSDE_SYNC_OWN_STREAM") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
     h->sdim = state_dim(d->model, d->n_dim);
     h->na_any = d->na_mode == SSDE_NA_ANY_NAN;
@@ -307,6 +310,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     }
 
     HIPCHK(h, h->out.alloc(2 + h->L.n_full));
+    HIPCHK(h, hipHostMalloc((void**)&h->out_pinned, (size_t)(2 + h->L.n_full) * 8, hipHostMallocDefault));
     HIPCHK(h, hipEventCreate(&h->ev_k0));
     HIPCHK(h, hipEventCreate(&h->ev_k1));
 
@@ -624,6 +628,9 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     }
     HIPCHK(h, h->partials.alloc(h->partial_doubles));
     h->hbm_bytes += (int64_t)h->partial_doubles * 8;
+    // evaluations run on non-blocking streams, which the null stream's work above does not order itself against
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_async, hipEventDisableTiming));
+    HIPCHK(h, hipDeviceSynchronize());
     return SSDE_OK;
 }
 }  // namespace ssde_engine
@@ -1124,8 +1131,12 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
         return reduce_ranks(h, out_dev, (hipStream_t)stream);
     }
     int st = eval_device(h, par, order, out_dev, (hipStream_t)stream);
-    if (st || h->comms.empty()) return st;
-    return reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
+    if (st == SSDE_OK && !h->comms.empty()) st = reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
+    if (st) return st;
+    // a later synchronous ssde_eval runs on the handle's own stream and shares this evaluation's work buffers
+    HIPCHK(h, hipEventRecord(h->ev_async, (hipStream_t)stream));
+    h->async_pending = true;
+    return SSDE_OK;
 }
 
 int ssde_penalty(ssde_handle* h, const double* par, int32_t n_par_full, double* value, double* grad) {
@@ -1182,9 +1193,20 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         }
         return SSDE_OK;
     }
+    // Stream discipline of the synchronous call: the NULL stream and a blocking 48-byte read-back.  The alternative --
+    // the handle's own non-blocking stream, an asynchronous copy into pinned memory and one stream synchronisation --
+    // saves 7.5 us in isolation (tools/microbench_graph.hip: 24 against 31.5 us of fixed overhead for copy + two
+    // launches + read-back; a hipGraph of the same four operations measures the same 24 us) but NOT inside the engine:
+    // same-session A/B (SSDE_SYNC_OWN_STREAM=1, tools/bench_c2.py) C2 0.0875 against 0.0872 ms; headline 0.315 against
+    // 0.3035 ms in one session, 0.3025 against 0.3029 ms in another.  No gain to be had: the null stream stays.
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->async_pending) {              // an ssde_eval_device still running on the caller's stream shares the work buffers
+        HIPCHK(h, hipStreamWaitEvent(0, h->ev_async, 0));
+        if (h->tv_stream) HIPCHK(h, hipStreamWaitEvent(h->tv_stream, h->ev_async, 0));
+        h->async_pending = false;
+    }
     if (!h->comms.empty()) {
-        // same stream discipline as the single-GPU call (null stream + the blocking 48-byte copy, which returns sooner
-        // than an asynchronous copy followed by a stream synchronisation): the collective sits between the two
+        // the collective sits between the finalize launch and the read-back, on the same stream
         h->sync_call = true;
         int st = eval_device(h, par, order, h->out.p, 0);
         h->sync_call = false;
@@ -1199,14 +1221,24 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         h->n_evals++;
         return eval_tv_graph(h, par, order, o);
     }
+    if (h->env_own_stream) {             // A/B (see above): own non-blocking stream, asynchronous read-back into pinned memory
+        if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->sync_call = true;
+        int st1 = eval_device(h, par, order, h->out.p, h->own_stream);
+        h->sync_call = false;
+        if (st1) return st1;
+        HIPCHK(h, hipMemcpyAsync(h->out_pinned, h->out.p, nout * 8, hipMemcpyDeviceToHost, h->own_stream));
+        HIPCHK(h, hipStreamSynchronize(h->own_stream));
+        memcpy(o, h->out_pinned, nout * 8);
+        return SSDE_OK;
+    }
     h->sync_call = true;
     int st = eval_device(h, par, order, h->out.p, 0);
     h->sync_call = false;
     if (st) return st;
     const auto t0 = std::chrono::steady_clock::now();
-    // Measured twice (rounds 1 and 2) and slower both times by ~10 us: letting the finalising launch write the result
-    // into host-visible pinned memory -- as a mirror read after a synchronisation, or with a sequence word the host
-    // spins on ("last workgroup publishes", system-scope release) -- instead of this blocking 48-byte copy.
+    // (Measured twice and slower both times by ~10 us: letting the finalising launch write the result into host-visible
+    // pinned memory itself -- as a mirror, or with a sequence word the host spins on -- instead of this blocking copy.)
     HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
     if (h->trace) h->trace_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return SSDE_OK;

@@ -154,6 +154,9 @@ struct ssde_handle {
     // side streams: the kernels of one evaluation that do not depend on each other run concurrently
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipEvent_t ev_async = nullptr;            // end of the last ssde_eval_device on the caller's stream: a synchronous call waits for it
+    bool async_pending = false;
+    bool env_own_stream = false;
 
     // timing of the dominant kernel (recorded on the stream it is launched on)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
@@ -193,6 +196,7 @@ struct ssde_handle {
     DevBuf<double> tv_par_dev;
     double* tv_par_pinned = nullptr;
     double* tv_out_pinned = nullptr;
+    double* out_pinned = nullptr;             // read-back target of the synchronous ssde_eval (2 + n_full doubles)
 
     int64_t hbm_bytes = 0;
     // dtimes(n-1) of the reference is 1 (nllk_ctcrw.hpp:126-129); a shard of a multi-device handle that is not the last
