@@ -41,9 +41,10 @@ pp_table <- function(sm, x) {
 #'   "coeff_re": the returned fn / gr are the Laplace marginal over coeff_re (ssde_laplace_eval), log_lambda is a free
 #'   outer parameter, and env$last.par holds c(theta, u_hat) after every call -- the semantics of
 #'   MakeADFun(..., random = "coeff_re") at R/sde.R:656-658
+#' @param free_lambda joint object only: leave log_lambda free (what sdreport_hip needs for the joint Hessian)
 #' @param devices integer vector of HIP device ordinals: one R process, several GPUs (tracks sharded inside the engine,
 #'   one RCCL all-reduce per evaluation); NULL = the single device `device`
-make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NULL, devices = NULL) {
+make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NULL, devices = NULL, free_lambda = FALSE) {
     mats <- sde$make_mat()                      # X_list_fe / X_list_re / S_list (R/sde.R:452-454)
     kalman <- sde$type() %in% c("BM_SSM", "OU_SSM", "CTCRW")
     eseal <- sde$type() == "ESEAL_SSM"          # leading parameters log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
@@ -60,8 +61,9 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
     laplace <- has_re && identical(random, "coeff_re")
     off_l <- off_fe + length(tmb_par$coeff_fe)
     off_re <- length(par_full) - length(tmb_par$coeff_re)
-    if(has_re && !laplace) {
-        # joint objective at fixed smoothing parameters (log_lambda is not identifiable from the joint likelihood)
+    if(has_re && !laplace && !free_lambda) {
+        # joint objective at fixed smoothing parameters (log_lambda is not identifiable from the joint likelihood);
+        # free_lambda = TRUE keeps it free: the joint object sdreport_hip differentiates at (theta_hat, u_hat)
         fixed[off_l + seq_along(tmb_par$log_lambda)] <- TRUE
     }
     if(has_re && !is.null(map$log_lambda)) fixed[off_l + which(is.na(map$log_lambda))] <- TRUE
@@ -115,7 +117,11 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
         last$res
     }
     env$last.par.best <- c(par_full[free], par_full[is_u])
-    list(par = par_full[free],
+    # TMB names obj$par by parameter block
+    nm_full <- c(if(kalman) "log_sigma_obs", if(eseal) c("log_tau", "a1", "log_a2"), rep("coeff_fe", length(tmb_par$coeff_fe)),
+                 if(has_re) rep("log_lambda", length(tmb_par$log_lambda)), if(has_decay) rep("log_decay", length(tmb_par$log_decay)),
+                 if(has_re) rep("coeff_re", length(tmb_par$coeff_re)))
+    list(par = setNames(par_full[free], nm_full[free]),
          fn = function(x = par_full[free]) eval_at(x)$value,
          gr = function(x = par_full[free]) matrix(eval_at(x)$gradient[free], nrow = 1),
          he = function(x = par_full[free]) {     # finite differences of the GPU gradient
@@ -132,4 +138,51 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
              list(aest_all = .Call("ssdeR_report", ptr, full, PACKAGE = "smoothSDE"))
          },
          env = env, ptr = ptr)
+}
+
+#' sdreport() for an object made by make_hip_obj (TMB::sdreport needs the tape inside a MakeADFun object)
+#'
+#' Returns the parts of TMB's report that the package reads (R/sde.R:707-719, 871-882, 1360-1375; R/utility.R:115-123):
+#' par.fixed, par.random, cov.fixed, jointPrecision (names = TMB's parameter block names), plus value / gradient.fixed.
+#' The assembly is TMB's own (sdreport with getJointPrecision = TRUE), with finite differences of the DEVICE gradient
+#' where TMB has tapes (the same code as smoothsde_amd/report.py, which the GPU tests check against autograd Hessians):
+#'   H       = d2 g / d(theta, u)^2 of the JOINT penalised nllk at (theta_hat, u_hat): central differences of obj_joint$gr
+#'   Hfix    = Hessian of the marginal: stats::optimHess(par, obj$fn, obj$gr)  (obj = the random = "coeff_re" object)
+#'   cov.fixed = Hfix^-1
+#'   jointPrecision = [ Hfix + Htu Huu^-1 Hut , Htu ; Hut , Huu ]
+#' @param obj        make_hip_obj(..., random = "coeff_re") after optim (obj$env$last.par.best = c(theta_hat, u_hat)),
+#'                   or the joint object when the model has no random effects
+#' @param obj_joint  make_hip_obj(..., random = NULL, free_lambda = TRUE) on the SAME tmb_dat as `obj` (penalty included),
+#'                   or NULL without random effects
+#' @param par_fixed  optim()$par
+#' @param names_fixed,names_random  TMB block names of the entries ("coeff_fe", "log_lambda", ..., "coeff_re")
+sdreport_hip <- function(obj, obj_joint = NULL, par_fixed, names_fixed, names_random = character(0), rel_step = 1e-4) {
+    fd_hessian <- function(gr, x) {
+        p <- length(x); H <- matrix(0, p, p)
+        for(k in seq_len(p)) {
+            e <- rep(0, p); e[k] <- rel_step * max(1, abs(x[k]))
+            H[, k] <- (as.numeric(gr(x + e)) - as.numeric(gr(x - e))) / (2 * e[k])
+        }
+        (H + t(H)) / 2
+    }
+    nf <- length(par_fixed)
+    if(is.null(obj_joint) || length(names_random) == 0) {
+        H <- fd_hessian(obj$gr, par_fixed)
+        cov <- solve(H); dimnames(cov) <- list(names_fixed, names_fixed)
+        return(list(par.fixed = setNames(par_fixed, names_fixed), par.random = NULL, cov.fixed = cov, jointPrecision = NULL,
+                    value = obj$fn(par_fixed), gradient.fixed = obj$gr(par_fixed), pdHess = all(eigen(H, TRUE, TRUE)$values > 0)))
+    }
+    u_hat <- obj$env$last.par.best[nf + seq_along(names_random)]
+    x_joint <- c(par_fixed, u_hat)                      # obj_joint's free vector is ordered (theta, u) like TMB's last.par
+    H <- fd_hessian(obj_joint$gr, x_joint)
+    it <- seq_len(nf); iu <- nf + seq_along(u_hat)
+    Htu <- H[it, iu, drop = FALSE]; Huu <- H[iu, iu, drop = FALSE]
+    Hfix <- stats::optimHess(par_fixed, obj$fn, function(x) as.numeric(obj$gr(x)))
+    cov <- solve(Hfix); dimnames(cov) <- list(names_fixed, names_fixed)
+    Q <- H
+    Q[it, it] <- Hfix + Htu %*% solve(Huu, t(Htu))
+    nm <- c(names_fixed, names_random); dimnames(Q) <- list(nm, nm)
+    list(par.fixed = setNames(par_fixed, names_fixed), par.random = setNames(u_hat, names_random), cov.fixed = cov,
+         jointPrecision = Matrix::Matrix(Q, sparse = TRUE), value = obj$fn(par_fixed), gradient.fixed = obj$gr(par_fixed),
+         pdHess = all(eigen(Hfix, TRUE, TRUE)$values > 0))
 }
