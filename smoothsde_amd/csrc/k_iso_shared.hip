@@ -445,25 +445,44 @@ struct SharedSel<MODEL, D, MASK, true> { typedef BasisScal<MODEL, D, MASK> type;
 template <int D, int MASK>
 struct SharedSel<M_CTCRW, D, MASK, true> { typedef TfCtcrw<D, MASK> type; };
 
-// rows [s0, s0 + SHARED_U) from a register block
+// The gain table in the table phase.  Its rows used to be fetched row by row with wave-uniform vector loads (13 per row,
+// an L2 round trip each, competing with the observation prefetch for the 63 outstanding-load slots): 600 cycles per row
+// for a ~70-instruction step, and the transient window (~100 such rows, one wave per track group) was a fixed ~30 us in
+// EVERY evaluation of this path -- most of C2's 50 us kernel.  Now every wave stages GAIN_SLAB_ROWS rows at a time into
+// its own LDS slab with coalesced loads (one round trip per slab) and the steps read them as LDS broadcasts.
+constexpr int GAIN_SLAB_ROWS = 64;      // multiple of 2 * SHARED_U
+static_assert(GAIN_SLAB_ROWS % (2 * SHARED_U) == 0, "gain slab");
+
+__device__ __forceinline__ void stage_gain(const IsoArgs& A, double* slab, int row0) {
+    const int lane = threadIdx.x & 63, glast = A.gain_last;
+    const double* __restrict__ gain = A.gain;
+#pragma unroll 4
+    for (int r = 0; r < GAIN_SLAB_ROWS; r += WAVE / GAIN_ROW) {          // 4 rows of 16 doubles per wave load
+        const int rr = r + lane / GAIN_ROW;
+        slab[rr * GAIN_ROW + (lane % GAIN_ROW)] = gain[(int64_t)min(row0 + rr, glast) * GAIN_ROW + (lane % GAIN_ROW)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// rows [s0, s0 + SHARED_U) from a register block; `grow` = the slab row of s0 (table phase)
 template <bool STAT, int D, class Lane>
 __device__ __forceinline__ void run_block(Lane& S, const IsoArgs& A, const double (&blk)[SHARED_U][D], int s0, int ns,
-                                          int ns_min, const double* mu) {
-    const double* __restrict__ gain = A.gain;
-    const int glast = A.gain_last;
+                                          int ns_min, const double* mu, const double* grow) {
     if (s0 + SHARED_U <= ns_min) {
         // every lane's track covers the whole block: no per-row predication
 #pragma unroll
         for (int u = 0; u < SHARED_U; u++) {
             if (STAT) S.step_stat(blk[u]);
-            else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, blk[u]);
+            else S.step_table(grow + u * GAIN_ROW, mu, blk[u]);
         }
     } else {
 #pragma unroll
         for (int u = 0; u < SHARED_U; u++) {
             if (s0 + u < ns) {
                 if (STAT) S.step_stat(blk[u]);
-                else S.step_table(gain + (int64_t)min(s0 + u, glast) * GAIN_ROW, mu, blk[u]);
+                else S.step_table(grow + u * GAIN_ROW, mu, blk[u]);
             }
         }
     }
@@ -482,13 +501,17 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 #else
 #define SSDE_ROWPTR(s) (base + (int64_t)(s) * C * WAVE)
 #endif
+    __shared__ double gain_slab[STAT ? 1 : WG_WAVES][STAT ? 1 : GAIN_SLAB_ROWS * GAIN_ROW];
+    double* slab = gain_slab[STAT ? 0 : (threadIdx.x >> 6)];
     load_obs_block<D>(bufA, SSDE_ROWPTR(sa), C, c_obs);
     for (int s0 = sa; s0 < sb; s0 += 2 * SHARED_U) {
         // TILE_SPARE (>= 3 blocks) keeps the look-ahead loads inside the allocation
         load_obs_block<D>(bufB, SSDE_ROWPTR(s0 + SHARED_U), C, c_obs);
-        run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu);
+        const int srow = (s0 - sa) % GAIN_SLAB_ROWS;
+        if (!STAT && srow == 0) stage_gain(A, slab, s0);
+        run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu, slab + srow * GAIN_ROW);
         load_obs_block<D>(bufA, SSDE_ROWPTR(s0 + 2 * SHARED_U), C, c_obs);
-        if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu);
+        if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu, slab + (srow + SHARED_U) * GAIN_ROW);
     }
 }
 

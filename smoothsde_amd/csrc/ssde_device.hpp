@@ -345,9 +345,19 @@ __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, i
         const int delta = delta_rows >= 0 ? delta_rows : (3 * t0 / 2 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         const int rest = L > t0 ? L - t0 : 0;
         int cl = ((rest + delta + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-        if (cl <= delta + WIN_ALIGN) cl = delta + 2 * WIN_ALIGN;
-        s_acc = (c == 1) ? t0 : t0 + (c - 1) * cl - delta; if (s_acc > L) s_acc = L;
-        s_end = t0 + c * cl - delta; if (s_end > L) s_end = L; if (s_end < s_acc) s_end = s_acc;
+        if (cl <= delta + WIN_ALIGN) {
+            // Short tracks (C2: 10^3 rows): the transient is worth more than a whole window.  Its wave gets a token
+            // window 1 and windows 2.. share the rest EQUALLY (the geometry above would leave the last ones empty).
+            const int w1 = rest < 2 * WIN_ALIGN ? rest : 2 * WIN_ALIGN;
+            const int cl2 = n_chunks > 2 ? ((rest - w1 + n_chunks - 3) / (n_chunks - 2) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN : 0;
+            if (c == 1) { s_acc = t0; s_end = n_chunks > 2 ? t0 + w1 : L; }
+            else { s_acc = t0 + w1 + (c - 2) * cl2; s_end = s_acc + cl2; }
+            if (s_acc > L) s_acc = L;
+            if (s_end > L) s_end = L;
+        } else {
+            s_acc = (c == 1) ? t0 : t0 + (c - 1) * cl - delta; if (s_acc > L) s_acc = L;
+            s_end = t0 + c * cl - delta; if (s_end > L) s_end = L; if (s_end < s_acc) s_end = s_acc;
+        }
     } else {
         const int cl = ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         s_acc = c * cl; if (s_acc > L) s_acc = L;
