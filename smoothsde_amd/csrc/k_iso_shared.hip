@@ -503,6 +503,26 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 #endif
     __shared__ double gain_slab[STAT ? 1 : WG_WAVES][STAT ? 1 : GAIN_SLAB_ROWS * GAIN_ROW];
     double* slab = gain_slab[STAT ? 0 : (threadIdx.x >> 6)];
+#ifndef SSDE_D1_DEEP
+#define SSDE_D1_DEEP 1
+#endif
+    if constexpr (D == 1 && STAT && SSDE_D1_DEEP) {
+        // One response column is 8 B per lane and row: a block in flight is half the bytes of the two-column case, and the
+        // stream sat at 4.7 TB/s against 5.7-6.2.  Three register blocks in rotation keep TWO blocks (16 rows) in flight.
+        static_assert(5 * SHARED_U <= TILE_SPARE, "look-ahead of the three-block rotation");
+        double bufC[SHARED_U][D];
+        load_obs_block<D>(bufA, SSDE_ROWPTR(sa), C, c_obs);
+        load_obs_block<D>(bufB, SSDE_ROWPTR(sa + SHARED_U), C, c_obs);
+        for (int s0 = sa; s0 < sb; s0 += 3 * SHARED_U) {       // TILE_SPARE (64 rows) covers the 5 blocks of look-ahead
+            load_obs_block<D>(bufC, SSDE_ROWPTR(s0 + 2 * SHARED_U), C, c_obs);
+            run_block<STAT, D>(S, A, bufA, s0, ns, ns_min, mu, slab);
+            load_obs_block<D>(bufA, SSDE_ROWPTR(s0 + 3 * SHARED_U), C, c_obs);
+            if (s0 + SHARED_U < sb) run_block<STAT, D>(S, A, bufB, s0 + SHARED_U, ns, ns_min, mu, slab);
+            load_obs_block<D>(bufB, SSDE_ROWPTR(s0 + 4 * SHARED_U), C, c_obs);
+            if (s0 + 2 * SHARED_U < sb) run_block<STAT, D>(S, A, bufC, s0 + 2 * SHARED_U, ns, ns_min, mu, slab);
+        }
+        return;
+    }
     load_obs_block<D>(bufA, SSDE_ROWPTR(sa), C, c_obs);
     for (int s0 = sa; s0 < sb; s0 += 2 * SHARED_U) {
         // TILE_SPARE (>= 3 blocks) keeps the look-ahead loads inside the allocation
