@@ -506,7 +506,10 @@ __device__ __forceinline__ void run_segment(Lane& S, const IsoArgs& A, const dou
 #ifndef SSDE_D1_DEEP
 #define SSDE_D1_DEEP 1
 #endif
-    if constexpr (D == 1 && STAT && SSDE_D1_DEEP) {
+#ifndef SSDE_DEEP_MAXD
+#define SSDE_DEEP_MAXD 1        // two columns: measured, no gain (0.280-0.285 against 0.256-0.274 ms in one session)
+#endif
+    if constexpr (D <= SSDE_DEEP_MAXD && STAT && SSDE_D1_DEEP) {
         // One response column is 8 B per lane and row: a block in flight is half the bytes of the two-column case, and the
         // stream sat at 4.7 TB/s against 5.7-6.2.  Three register blocks in rotation keep TWO blocks (16 rows) in flight.
         static_assert(5 * SHARED_U <= TILE_SPARE, "look-ahead of the three-block rotation");
