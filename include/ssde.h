@@ -27,6 +27,7 @@
  *   ssde_info          <- InfoADFunObject       (src/init.c:7)
  *   ssde_forget        <- (new) drops the memo of ssde_eval
  *   ssde_last_kernel_ms <- (new) measurement hook: duration of the last dominant kernel launch
+ *   ssde_kernel_ms_history <- (new) the same for the last n evaluations, read after a timed region
  *   ssde_comm_unique_id / ssde_comm_init_rank
  *                      <- (new) one process per GPU: joins the handles of all ranks into one RCCL communicator, after
  *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
@@ -270,6 +271,12 @@ int ssde_info(const ssde_handle *h, ssde_info_t *info);
 /* HIP-event duration (ms) of the dominant kernel launch of the last evaluation (== ssde_info().main_kernel_ms, without
  * filling the rest of the structure: cheap enough to be read after every timed step of a benchmark); 0 if unknown. */
 double ssde_last_kernel_ms(const ssde_handle *h);
+
+/* The same for the last n evaluations at once: ms[0] = the last one, ms[1] the one before, ... (0 where no stamp exists:
+ * more than 64 evaluations ago, or an evaluation replayed from a hipGraph).  Every evaluation stamps its dominant kernel
+ * with an event pair of its own, so a caller can time K <= 64 evaluations back to back and read their kernel durations
+ * AFTER the timed region (bench.py) instead of querying events between them. */
+int ssde_kernel_ms_history(const ssde_handle *h, double *ms, int32_t n);
 
 /* Drop the memoised last result: the next ssde_eval runs on the device whatever its argument (determinism checks). */
 int ssde_forget(ssde_handle *h);

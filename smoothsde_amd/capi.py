@@ -471,6 +471,8 @@ def load_library():
     lib.ssde_laplace_eval.restype = C.c_int
     lib.ssde_last_kernel_ms.argtypes = [C.c_void_p]
     lib.ssde_last_kernel_ms.restype = C.c_double
+    lib.ssde_kernel_ms_history.argtypes = [C.c_void_p, _dp, C.c_int32]
+    lib.ssde_kernel_ms_history.restype = C.c_int
     lib.ssde_forget.argtypes = [C.c_void_p]
     lib.ssde_forget.restype = C.c_int
     lib.ssde_comm_unique_id.argtypes = [C.c_void_p]
@@ -490,7 +492,7 @@ class EngineError(RuntimeError):
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
-                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms")
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms", "ssde_kernel_ms_history")
 
 COMM_ID_BYTES = 128
 
@@ -589,6 +591,12 @@ class Engine:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.ssde_last_kernel_ms(self._h))
+
+    def kernel_ms_history(self, n: int) -> np.ndarray:
+        """Dominant-kernel durations of the last n (<= 64) evaluations, most recent first; 0 where there is no stamp."""
+        out = np.zeros(int(n))
+        self._check(self.lib.ssde_kernel_ms_history(self._h, out.ctypes.data_as(_dp), int(n)))
+        return out
 
     def forget(self):
         """Drop the memoised last result: the next eval runs on the device even at the same par."""

@@ -38,8 +38,7 @@ void destroy(ssde_handle* h) {
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_async) (void)hipEventDestroy(h->ev_async);
-    if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
-    if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
+    for (auto& pr : h->ev_ring) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     h->tv_eh.release(); h->tv_eR.release(); h->tv_harr.release(); h->tv_rec.release(); h->tv_wdir.release(); h->tv_a0.release(); h->tv_bnd.release(); h->tv_chk.release();
     h->tv_gval.release(); h->tv_gdir.release(); h->tv_stats.release(); h->tv_dirs.release(); h->tv_row0.release();
     h->tv_ns.release(); h->tv_items_g.release(); h->tv_items_v.release();
@@ -311,8 +310,8 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
 
     HIPCHK(h, h->out.alloc(2 + h->L.n_full));
     HIPCHK(h, hipHostMalloc((void**)&h->out_pinned, (size_t)(2 + h->L.n_full) * 8, hipHostMallocDefault));
-    HIPCHK(h, hipEventCreate(&h->ev_k0));
-    HIPCHK(h, hipEventCreate(&h->ev_k1));
+    for (auto& pr : h->ev_ring) { HIPCHK(h, hipEventCreate(&pr[0])); HIPCHK(h, hipEventCreate(&pr[1])); }
+    h->ev_k0 = h->ev_ring[0][0]; h->ev_k1 = h->ev_ring[0][1];
 
     // ---- ESEAL_SSM: the lane = direction kernels with the scalar lipid-mass lanes ----------------------------
     if (is_eseal(d->model)) {
@@ -824,9 +823,19 @@ int push_par(ssde_handle* h, const double* par, hipStream_t s, const double** de
 
 namespace ssde_engine {
 
+// this evaluation's stamp pair (the previous evaluations' stay readable: ssde_kernel_ms_history)
+static void next_stamp_pair(ssde_handle* h) {
+    if (h->ev_idx >= 0) h->ev_ring_valid[h->ev_idx % ssde_handle::EV_RING] = h->ev_k_valid;
+    h->ev_idx++;
+    const int slot = (int)(h->ev_idx % ssde_handle::EV_RING);
+    h->ev_k0 = h->ev_ring[slot][0]; h->ev_k1 = h->ev_ring[slot][1];
+    h->ev_k_valid = false; h->ev_ring_valid[slot] = false;
+}
+
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s) {
     HIPCHK(h, hipSetDevice(h->device));
     h->n_evals++;
+    next_stamp_pair(h);
     if (h->path == PATH_TV) return eval_tv(h, par, order, out_dev, s);
     const ParLayout& L = h->L;
     ReduceArgs ra;
@@ -1219,6 +1228,7 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
     if (h->path == PATH_TV && !h->env_no_graph && h->tv_stats_valid) {
         HIPCHK(h, hipSetDevice(h->device));
         h->n_evals++;
+        next_stamp_pair(h);                                    // (a replayed graph carries no stamps: the slot stays invalid)
         return eval_tv_graph(h, par, order, o);
     }
     if (h->env_own_stream) {             // A/B (see above): own non-blocking stream, asynchronous read-back into pinned memory
@@ -1445,6 +1455,32 @@ double ssde_last_kernel_ms(const ssde_handle* h) {
     float ms = 0.f;
     if (h->ev_k_valid && hipEventQuery(h->ev_k1) == hipSuccess && hipEventElapsedTime(&ms, h->ev_k0, h->ev_k1) == hipSuccess) return ms;
     return 0.0;
+}
+
+int ssde_kernel_ms_history(const ssde_handle* h, double* ms, int32_t n) {
+    if (!h || !ms || n < 0) return SSDE_ERR_ARG;
+    if (!h->shards.empty()) {                        // the slowest shard, evaluation by evaluation
+        std::vector<double> tmp((size_t)n);
+        for (int k = 0; k < n; k++) ms[k] = 0.0;
+        for (const ssde_handle* sh : h->shards) {
+            int st = ssde_kernel_ms_history(sh, tmp.data(), n);
+            if (st) return st;
+            for (int k = 0; k < n; k++) ms[k] = std::max(ms[k], tmp[k]);
+        }
+        return SSDE_OK;
+    }
+    // ms[0] = the last evaluation, ms[1] the one before, ...; 0 where no stamp exists (older than the ring, a replayed graph)
+    for (int k = 0; k < n; k++) {
+        ms[k] = 0.0;
+        const int64_t idx = h->ev_idx - k;
+        if (idx < 0 || k >= ssde_handle::EV_RING) continue;
+        const int slot = (int)(idx % ssde_handle::EV_RING);
+        const bool valid = k == 0 ? h->ev_k_valid : h->ev_ring_valid[slot];
+        float f = 0.f;
+        if (valid && hipEventQuery(h->ev_ring[slot][1]) == hipSuccess &&
+            hipEventElapsedTime(&f, h->ev_ring[slot][0], h->ev_ring[slot][1]) == hipSuccess) ms[k] = f;
+    }
+    return SSDE_OK;
 }
 
 int ssde_forget(ssde_handle* h) {

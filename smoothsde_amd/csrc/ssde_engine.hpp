@@ -159,8 +159,14 @@ struct ssde_handle {
     bool env_own_stream = false;
 
     // timing of the dominant kernel (recorded on the stream it is launched on)
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // the CURRENT evaluation's pair: ev_ring[ev_idx % EV_RING]
     bool ev_k_valid = false;
+    // Every evaluation stamps its dominant kernel with a pair of its own, so that a caller can time K evaluations and read
+    // the K kernel durations AFTERWARDS (ssde_kernel_ms_history) instead of paying an event query between them.
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev_ring[EV_RING][2] = {};
+    bool ev_ring_valid[EV_RING] = {};
+    int64_t ev_idx = -1;
     std::vector<int32_t> glen_host, lane_ns_host;
     int last_s_stat = 0, last_t0 = 0, last_t0_delta = 0;
     mutable int rows_key[3] = {-1, -1, -1};

@@ -296,3 +296,21 @@ def test_multi_device_descriptor_errors():
     with pytest.raises(capi.EngineError, match="ssde_eval"):
         em.eval_device(np.zeros(pb.n_par_full), out.data_ptr())
     em.close()
+
+
+def test_kernel_stamp_history_covers_every_evaluation():
+    """every evaluation stamps its dominant kernel with an event pair of its own: the durations of the last n evaluations
+    can be read after a timed region (bench.py) -- most recent first, equal to what ssde_last_kernel_ms said each time"""
+    ID, t, o = simulate("CTCRW", 256, 500, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=3)
+    eng = capi.Engine(capi.Problem("CTCRW", ID, t, o, par_fixed=[0, 1, 1, 0, 0]))
+    par = np.array([np.log(0.1), 0.0, 0.0, np.log(2.0), 0.0])
+    seen = []
+    for k in range(70):
+        eng.eval(par + 1e-3 * k)
+        seen.append(eng.last_kernel_ms())
+    hist = eng.kernel_ms_history(70)
+    assert np.all(hist[:64] > 0) and np.all(hist[64:] == 0)          # the ring holds 64 pairs
+    assert np.allclose(hist[:64], seen[::-1][:64], rtol=0, atol=0)
+    eng.eval(par)                                                      # answered from... a new vector: one more stamp
+    assert eng.kernel_ms_history(2)[1] == hist[0]
+    eng.close()
