@@ -138,6 +138,43 @@ hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipSt
     return hipGetLastError();
 }
 
+// ---- lattice padding (ssde_engine.hip: lattice_pad) --------------------------------------------------------------------
+// pos[i] = lattice row of the caller's row i.  One thread per caller row: its own time stamp and observations go to pos[i];
+// the lattice rows between it and the previous row of the same track (fixes absent from the data) get interpolated time
+// stamps -- the observation columns were pre-filled with NA_real_.
+__global__ void lattice_scatter_kernel(const int64_t* pos, const double* id, const double* times, const double* obs, int64_t n, int d,
+                                       int64_t np, double delta, double* times_p, double* obs_p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t p = pos[i];
+    times_p[p] = times[i];
+    for (int a = 0; a < d; a++) obs_p[p + (int64_t)a * np] = obs[i + (int64_t)a * n];
+    if (i > 0 && id[i] == id[i - 1]) {
+        const int64_t p0 = pos[i - 1];
+        for (int64_t j = p0 + 1; j < p; j++) times_p[j] = times[i - 1] + (double)(j - p0) * delta;
+    }
+}
+__global__ void fill_bits_kernel(double* x, int64_t n, unsigned long long bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = __longlong_as_double((long long)bits);
+}
+hipError_t launch_lattice_scatter(const int64_t* pos, const double* id, const double* times, const double* obs, int64_t n, int d,
+                                  int64_t np, double delta, double* times_p, double* obs_p, hipStream_t s) {
+    hipLaunchKernelGGL(fill_bits_kernel, dim3((unsigned)((np * d + 255) / 256)), dim3(256), 0, s, obs_p, np * d, 0x7FF00000000007A2ull);   // NA_real_
+    hipLaunchKernelGGL(lattice_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, id, times, obs, n, d, np, delta, times_p, obs_p);
+    return hipGetLastError();
+}
+// aest_all of the caller's rows out of the lattice rows' (ssde_report)
+__global__ void lattice_gather_kernel(const int64_t* pos, const double* src, int64_t n, int64_t np, int ncol, double* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < ncol; c++) dst[i + (int64_t)c * n] = src[pos[i] + (int64_t)c * np];
+}
+hipError_t launch_lattice_gather(const int64_t* pos, const double* src, int64_t n, int64_t np, int ncol, double* dst, hipStream_t s) {
+    hipLaunchKernelGGL(lattice_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, src, n, np, ncol, dst);
+    return hipGetLastError();
+}
+
 // Dimension parts of a Kalman problem wider than two columns (ssde_engine_dist.hip): the reference decides "missing" on
 // column 0 of the WHOLE response (nllk_ctcrw.hpp:214), a part other than the first one reads it off its own first column.
 // Rewrites that column so that the two agree: missing where the lead column is, and an OBSERVED NaN (not R's NA payload)

@@ -33,7 +33,7 @@ void destroy(ssde_handle* h) {
                 h->trace_us[0] / h->trace_n, h->trace_us[1] / h->trace_n, h->trace_us[2] / h->trace_n, h->trace_us[3] / h->trace_n,
                 h->trace_us[4] / h->trace_n);
     destroy_dist(h);
-    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release();
+    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -108,6 +108,79 @@ int choose_iso_split(ssde_handle* h) {
     return 0;
 }
 
+
+}  // namespace
+
+namespace {
+
+// Is the time grid a lattice -- every scored interval a small whole multiple of the smallest one -- and is laying the
+// tracks out on it cheap enough?  If so: pad_pos / n_pad in the handle, the lattice's segment starts, time stamps and
+// observation columns (NA_real_ where the data have no row) in device buffers.  Otherwise h->n_pad stays 0.
+constexpr int LATTICE_MAX_MULT = 16;           // longest run of absent fixes that is still padded
+constexpr double LATTICE_MAX_GROWTH = 1.35;    // break-even of the two general kernels is ~1.45 lattice rows per data row
+int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& starts, bool on_dev,
+                std::vector<int64_t>& starts_pad, DevBuf<double>& times_p, DevBuf<double>& obs_p) {
+    const int64_t n = d->n, n_seg = (int64_t)starts.size() - 1;
+    std::vector<double> th_own;
+    const double* th = d->times;
+    if (on_dev) {
+        th_own.resize((size_t)n);
+        HIPCHK(h, hipMemcpy(th_own.data(), d->times, (size_t)n * 8, hipMemcpyDeviceToHost));
+        th = th_own.data();
+    }
+    // (a track's FIRST interval is never used -- a0 is the prediction for the second row as it stands, nllk_ctcrw.hpp:195-200,
+    //  SURVEY Q1 -- so it is neither part of the lattice test nor padded: a lattice row there would be a prediction step
+    //  the reference does not take)
+    double delta = INFINITY, dmax = 0.0;
+    for (int64_t sg = 0; sg < n_seg; sg++)
+        for (int64_t i = starts[sg] + 2; i < starts[sg + 1]; i++) {
+            const double dt = th[i] - th[i - 1];
+            if (!(dt > 0.0) || !std::isfinite(dt)) return SSDE_OK;         // not a grid at all: the general path deals with it
+            delta = std::min(delta, dt); dmax = std::max(dmax, dt);
+        }
+    if (!std::isfinite(delta) || dmax == delta || dmax > (LATTICE_MAX_MULT + 0.5) * delta) return SSDE_OK;   // regular, or too wide
+    std::vector<int64_t> pos((size_t)n);
+    starts_pad.assign((size_t)n_seg + 1, 0);
+    int64_t run = 0;
+    for (int64_t sg = 0; sg < n_seg; sg++) {
+        starts_pad[sg] = run;
+        pos[starts[sg]] = run++;
+        if (starts[sg] + 1 < starts[sg + 1]) pos[starts[sg] + 1] = run++;
+        for (int64_t i = starts[sg] + 2; i < starts[sg + 1]; i++) {
+            const double r = (th[i] - th[i - 1]) / delta;
+            const double k = std::nearbyint(r);
+            if (std::fabs(r - k) > 1e-10 * k) return SSDE_OK;               // not a lattice
+            run += (int64_t)k;
+            pos[i] = run - 1;
+        }
+        if ((double)run > LATTICE_MAX_GROWTH * (double)starts[sg + 1] + 64.0) return SSDE_OK;
+    }
+    starts_pad[n_seg] = run;
+    const int64_t np = run;
+    if (np == n) return SSDE_OK;
+    // the caller's arrays on the device
+    DevBuf<double> s_times, s_obs, s_id;
+    const double *p_times = d->times, *p_obs = d->obs, *p_id = d->id;
+    if (!on_dev) {
+        HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p;
+        HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p;
+        HIPCHK(h, stage(d->id, (size_t)n, false, s_id)); p_id = s_id.p;
+    }
+    DevBuf<int64_t> pos_dev;
+    HIPCHK(h, pos_dev.upload(pos));
+    HIPCHK(h, times_p.alloc((size_t)np));
+    HIPCHK(h, obs_p.alloc((size_t)np * d->n_dim));
+    HIPCHK(h, launch_lattice_scatter(pos_dev.p, p_id, p_times, p_obs, n, d->n_dim, np, delta, times_p.p, obs_p.p, 0));
+    HIPCHK(h, hipDeviceSynchronize());
+    s_times.release(); s_obs.release(); s_id.release(); pos_dev.release();
+    // REPORT(aest_all): row i of the reference holds the state AFTER row i's step, i.e. predicted to the time of row i + 1
+    // (nllk_ctcrw.hpp:246) -- on the lattice that is the row just before row i + 1's (a track's last row: its own)
+    for (int64_t sg = 0; sg < n_seg; sg++)
+        for (int64_t i = starts[sg] + 1; i + 1 < starts[sg + 1]; i++) pos[i] = pos[i + 1] - 1;
+    HIPCHK(h, h->pad_pos.upload(pos));
+    h->n_pad = np; h->pad_step = delta;
+    return SSDE_OK;
+}
 
 }  // namespace
 
@@ -420,12 +493,32 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         }
         if (h->path != PATH_TV) {
 
+        // ---- what gets tiled: the caller's rows, or -- lattice_pad() -- the same tracks on their regular lattice -------------
+        // A time grid whose intervals are small whole multiples of one step (a regular schedule with fixes MISSING FROM THE DATA,
+        // not NA-padded) would run the irregular-grid kernel: a per-lane transition and an exp per row, one wave per SIMD
+        // (1.1 ms per 1e8 rows).  The transition over k steps is the k-fold product of the one-step transition
+        // (makeT/makeQ/makeB are the exact discretisation: nllk_ctcrw.hpp:45-91, nllk_ou_ssm.hpp:35-66, nllk_bm_ssm.hpp:33),
+        // and a row whose observation is missing is exactly one prediction step (nllk_ctcrw.hpp:214-228): so the tracks are
+        // laid out on the lattice with NA rows where fixes are absent, and run as a regular grid with missing rows (hoisted
+        // transition, two waves per SIMD, 0.75 ms per 1e8 lattice rows; groups without a gap take the shared-covariance path).
+        int64_t tn = n;
+        std::vector<int64_t> tstarts_pad;
+        DevBuf<double> pad_times, pad_obs;
+        const double *t_times = d->times, *t_obs = d->obs;
+        bool t_on_dev = on_dev;
+        if (h->path == PATH_ISO && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT) && !getenv("SSDE_NO_LATTICE")) {
+            int st = lattice_pad(d, h, starts, on_dev, tstarts_pad, pad_times, pad_obs);
+            if (st) return st;
+            if (h->n_pad > 0) { tn = h->n_pad; t_times = pad_times.p; t_obs = pad_obs.p; t_on_dev = true; }
+        }
+        const std::vector<int64_t>& tstarts = h->n_pad > 0 ? tstarts_pad : starts;
+
         // tracks -> lanes: longest first (stable), 64 per wavefront
         const int64_t M = h->n_seg;
         std::vector<int64_t> order(M);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-            return (starts[a + 1] - starts[a]) > (starts[b + 1] - starts[b]);
+            return (tstarts[a + 1] - tstarts[a]) > (tstarts[b + 1] - tstarts[b]);
         });
         h->n_groups = (int)((M + WAVE - 1) / WAVE);
         const int G = h->n_groups;
@@ -433,14 +526,14 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         // included, is dt apart) needs no dt channel in the tiles -- nobody would read it, and a stream with holes
         // costs HBM efficiency (2 of 3 channels read: 5.6 TB/s; contiguous: > 7 TB/s)
         DevBuf<double> s_times;
-        const double* p_times = d->times;
-        if (!on_dev) { HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p; }
+        const double* p_times = t_times;
+        if (!t_on_dev) { HIPCHK(h, stage(t_times, (size_t)tn, false, s_times)); p_times = s_times.p; }
         h->c_obs = 1;
         if (!(d->flags & SSDE_FLAG_NO_UNIFORM_DT) && !getenv("SSDE_KEEP_DT_CHANNEL")) {
             const int nb = 1024;
             DevBuf<double> mm;
             HIPCHK(h, mm.alloc((size_t)nb * 2));
-            HIPCHK(h, launch_dt_minmax(p_times, nullptr, n, mm.p, nb, 0));
+            HIPCHK(h, launch_dt_minmax(p_times, nullptr, tn, mm.p, nb, 0));
             std::vector<double> mmh((size_t)nb * 2);
             HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
             double lo = INFINITY, hi = -INFINITY;
@@ -458,9 +551,9 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
                 int64_t t = (int64_t)g * WAVE + l;
                 if (t >= M) break;
                 int64_t seg = order[t];
-                int64_t len = starts[seg + 1] - starts[seg];
+                int64_t len = tstarts[seg + 1] - tstarts[seg];
                 if (len - 1 > INT32_MAX) return fail(h, SSDE_ERR_ARG, "track too long");
-                lane_row0[t] = starts[seg];
+                lane_row0[t] = tstarts[seg];
                 lane_seg[t] = seg;
                 lane_ns[t] = (int32_t)(len - 1);
                 mx = std::max(mx, lane_ns[t]);
@@ -483,20 +576,20 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         DevBuf<double> s_obs, s_h, s_a0, s_cols;
         DevBuf<const double*> s_colptr;
         DevBuf<int64_t> s_lane_seg;
-        const double *p_obs = d->obs, *p_h = d->h_array;
-        if (!on_dev) {
-            HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p;
-            if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)n * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
+        const double *p_obs = t_obs, *p_h = d->h_array;
+        if (!t_on_dev) {
+            HIPCHK(h, stage(t_obs, (size_t)tn * d->n_dim, false, s_obs)); p_obs = s_obs.p;
+            if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)tn * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
         }
         std::vector<const double*> cp(h->n_stream_cols, nullptr);
         if (h->n_stream_cols > 0) {
-            if (!on_dev) HIPCHK(h, s_cols.alloc((size_t)n * h->n_stream_cols));
+            if (!t_on_dev) HIPCHK(h, s_cols.alloc((size_t)tn * h->n_stream_cols));
             for (auto& s : h->slots)
                 if (s.col >= 0) {
-                    if (on_dev) cp[s.col] = s.src;
+                    if (t_on_dev) cp[s.col] = s.src;
                     else {
-                        double* dst = s_cols.p + (size_t)s.col * n;
-                        HIPCHK(h, hipMemcpy(dst, s.src, (size_t)n * 8, hipMemcpyDefault));   // host array or materialised basis block
+                        double* dst = s_cols.p + (size_t)s.col * tn;
+                        HIPCHK(h, hipMemcpy(dst, s.src, (size_t)tn * 8, hipMemcpyDefault));   // host array or materialised basis block
                         cp[s.col] = dst;
                     }
                 }
@@ -514,7 +607,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         HIPCHK(h, mm.alloc((size_t)G * ych * 3));
         IngestArgs ia;
         ia.times = p_times; ia.obs = p_obs; ia.h_array = h->has_h ? p_h : nullptr;
-        ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = n;
+        ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = tn;
         ia.lane_row0 = h->lane_row0.p; ia.lane_nsteps = h->lane_nsteps.p;
         ia.group_off = h->group_off.p; ia.group_len = h->group_len.p;
         ia.n_groups = G; ia.C = h->C; ia.c_obs = h->c_obs; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
@@ -530,10 +623,16 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             if (mmh[k + 2] != 0.0) gflags[(k / 3) / ych] = 0;   // a NaN observation somewhere in the group
         }
         h->uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
+        if (h->n_pad > 0) {
+            // the lattice was verified to 1e-10 of its step: every scored interval IS the step (an interpolated time stamp
+            // may differ from it in the last bits)
+            h->uniform_dt = true; dmin = h->pad_step;
+        }
         h->dt_uniform = h->uniform_dt ? dmin : 0.0;
         h->dt_min = std::isfinite(dmin) ? dmin : 0.0;
         mm.release(); s_times.release(); s_obs.release(); s_h.release(); s_a0.release(); s_cols.release();
         s_colptr.release(); s_lane_seg.release();
+        pad_times.release(); pad_obs.release();
         h->hbm_bytes = h->tile_doubles * 8;
 
         if (h->path == PATH_ISO) {
@@ -1409,8 +1508,9 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     // ssde_report always runs the general kernel (value only) and un-tiles on the fly
     DevBuf<double> rep, pbuf;
     DevBuf<SlotTable> stb;
-    HIPCHK(h, rep.alloc((size_t)h->n * h->sdim));
-    HIPCHK(h, hipMemset(rep.p, 0, (size_t)h->n * h->sdim * 8));
+    const int64_t nt = h->n_pad > 0 ? h->n_pad : h->n;          // rows of the tiled (possibly lattice-padded) layout
+    HIPCHK(h, rep.alloc((size_t)nt * h->sdim));
+    HIPCHK(h, hipMemset(rep.p, 0, (size_t)nt * h->sdim * 8));
     HIPCHK(h, pbuf.upload(std::vector<double>(par, par + h->L.n_full)));
     SlotTable st;
     memset(&st, 0, sizeof(st));
@@ -1428,8 +1528,15 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
     for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
     a.n_dirblocks = 1; a.dirs = nullptr; a.partials = nullptr;
-    a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
+    a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = nt; a.last_dt = h->last_dt;
     HIPCHK(h, launch_dense(a, false, 0));
+    if (h->n_pad > 0) {                                          // the caller's rows out of the lattice's
+        DevBuf<double> rows;
+        HIPCHK(h, rows.alloc((size_t)h->n * h->sdim));
+        HIPCHK(h, launch_lattice_gather(h->pad_pos.p, rep.p, h->n, nt, h->sdim, rows.p, 0));
+        HIPCHK(h, hipMemcpy(aest_all, rows.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
+        rows.release();
+    } else
     HIPCHK(h, hipMemcpy(aest_all, rep.p, (size_t)h->n * h->sdim * 8, hipMemcpyDeviceToHost));
     fill_single_rows(h, aest_all);
     rep.release(); pbuf.release(); stb.release();

@@ -208,6 +208,11 @@ struct ssde_handle {
     // dtimes(n-1) of the reference is 1 (nllk_ctcrw.hpp:126-129); a shard of a multi-device handle that is not the last
     // one carries the real interval to the next shard's first row there (only REPORT(aest_all) ever shows it)
     double last_dt = 1.0;
+    // lattice padding (ssde_engine.hip: lattice_pad): the tiles hold n_pad > n rows; pad_pos[i] = the lattice row whose
+    // reported state is caller row i's (ssde_report)
+    int64_t n_pad = 0;
+    DevBuf<int64_t> pad_pos;
+    double pad_step = 0.0;
 
     // ---- distributed evaluation (ssde_engine_dist.hip) -------------------------------------------------------------
     // single-process multi-GPU parent (ssde_desc.n_devices > 1): one engine per device, this handle owns no device data
