@@ -157,7 +157,7 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
     d = 2
     ID, times, obs = simulate(model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=11,
                               backend="torch", device=dev)
-    times, obs = mutate(ID, times, obs)
+    ID, times, obs = mutate(ID, times, obs)
     q = capi.n_sde_par(model, d)
     fixed = np.zeros(1 + q, dtype=np.uint8)
     fixed[1:1 + d] = 1
@@ -361,7 +361,7 @@ def main():
             def irregular(ID, times, obs):
                 gen = torch.Generator(device=dev)
                 gen.manual_seed(5)
-                return torch.cumsum(0.5 + torch.rand(len(ID), device=dev, dtype=torch.float64, generator=gen), 0), obs
+                return ID, torch.cumsum(0.5 + torch.rand(len(ID), device=dev, dtype=torch.float64, generator=gen), 0), obs
 
             def missing(ID, times, obs):
                 gen = torch.Generator(device=dev)
@@ -369,12 +369,22 @@ def main():
                 na = torch.rand(len(ID), device=dev, generator=gen) < 0.05
                 na[::T] = False                       # first rows stay observed (they initialise the state)
                 obs[na] = float("nan")
-                return times, obs
+                return ID, times, obs
+
+            def absent(ID, times, obs):                # the same schedule, but the missing fixes are simply not in the data
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(9)
+                keep = torch.rand(len(ID), device=dev, generator=gen) >= 0.05
+                keep[::T] = True
+                return ID[keep].contiguous(), times[keep].contiguous(), obs[keep].contiguous()
 
             sec.append(secondary_workload(f"{M} CTCRW x {T}, irregular time grid (dt ~ U[0.5, 1.5] per row)", "CTCRW", M, T,
                                           dev, max(3, args.steps // 2), irregular))
             sec.append(secondary_workload(f"{M} CTCRW x {T}, regular grid, 5 % missing rows", "CTCRW", M, T, dev,
                                           max(3, args.steps // 2), missing))
+            sec.append(secondary_workload(f"{M} CTCRW x {T} slots of a regular schedule, 5 % of the fixes absent from the data "
+                                          f"(intervals of 1-4 steps; laid out on the lattice at create)", "CTCRW", M, T, dev,
+                                          max(3, args.steps // 2), absent))
         except Exception as e:  # the secondary numbers must never take the bench line down
             sec.append({"workload": "failed", "error": str(e)})
         line["secondary"] = sec
