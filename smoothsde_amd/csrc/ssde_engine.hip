@@ -1654,9 +1654,12 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols_algo);
     // what the resident layout has to read per row: the `times` stream is not even stored when the grid is globally
     // regular (Kalman tiles without a dt channel); the direct families do not read it on a regular grid either
+    // (on the isotropic path with a hoisted transition nobody reads the dt slot even where it is stored -- a grid that is
+    //  regular within the tracks but not across their boundaries, or a lattice layout: its rows are counted per CALLER row)
     info->required_bytes_per_row = info->algo_bytes_per_row -
-        (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
+        (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_ISO && h->uniform_dt) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
           h->df_ja != h->d + 1 && h->df_jb != h->d + 1 && h->model != SSDE_MODEL_BM_T && h->model != SSDE_MODEL_CIR) ? 8.0 : 0.0);
+    if (h->n_pad > 0) info->required_bytes_per_row *= (double)h->n_pad / (double)h->n;
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
@@ -1695,6 +1698,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
                 }
             }
         }
+        if (h->n_pad > 0) rows = (int64_t)((double)rows * (double)h->n / (double)h->n_pad);   // lattice rows -> caller rows
         info->main_kernel_rows = rows;
         h->rows_cached = rows;
         h->rows_key[0] = h->last_chunks; h->rows_key[1] = h->last_window; h->rows_key[2] = h->last_s_stat + 100000 * h->last_t0;

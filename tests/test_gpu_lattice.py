@@ -176,3 +176,18 @@ def test_random_lattice_problems(seed):
     assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (ctx, grad, ograd)
     assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True), ctx
     eng.close()
+
+
+def test_lattice_composes_with_wide_responses_and_track_shards():
+    """every engine behind a handle (dimension parts, track shards) lays its own rows out on the lattice"""
+    ID, times, obs = lattice_tracks("CTCRW", 3, [70, 31, 52, 44, 66, 23], 0.5, 0.1, seed=6, na_frac=0.03)
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    par = np.array([-0.9, 0.02, -0.03, 0.04, 0.3, 0.1])
+    oval, ograd, oaest = oracle_eval(pb, par, order=1, report=True)
+    for devices in (None, [0, 0, 0]):
+        eng = capi.Engine(pb, devices=devices)
+        assert eng.info()["uniform_dt"] == 1
+        val, grad = eng.eval(par, order=1)
+        _close(val, grad, oval, ograd)
+        assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
+        eng.close()
