@@ -138,6 +138,23 @@ hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipSt
     return hipGetLastError();
 }
 
+// ---- which tracks have a row that is not a number (ssde_engine.hip: tracks are dealt to wavefronts clean ones first) ----
+__global__ void seg_nan_kernel(const double* obs, int64_t n, int d, const int64_t* starts, int64_t n_seg, int* flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool bad = false;
+    for (int a = 0; a < d; a++) { const double v = obs[i + (int64_t)a * n]; bad = bad || (v != v); }
+    if (!bad) return;
+    int64_t lo = 0, hi = n_seg;                     // the segment with starts[lo] <= i < starts[lo + 1]
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
+    flags[lo] = 1;
+}
+hipError_t launch_seg_nan(const double* obs, int64_t n, int d, const int64_t* starts, int64_t n_seg, int* flags, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_nan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, obs, n, d, starts, n_seg, flags);
+    return hipGetLastError();
+}
+
 // ---- lattice padding (ssde_engine.hip: lattice_pad) --------------------------------------------------------------------
 // pos[i] = lattice row of the caller's row i.  One thread per caller row: its own time stamp and observations go to pos[i];
 // the lattice rows between it and the previous row of the same track (fixes absent from the data) get interpolated time

@@ -165,6 +165,7 @@ hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 hipError_t launch_scored_mask(const double* id, int64_t n, uint32_t* mask, hipStream_t s);
 // first-row flags for segment discovery on device data
 hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipStream_t s);
+hipError_t launch_seg_nan(const double* obs, int64_t n, int d, const int64_t* starts, int64_t n_seg, int* flags, hipStream_t s);
 hipError_t launch_lattice_scatter(const int64_t* pos, const double* id, const double* times, const double* obs, int64_t n, int d,
                                   int64_t np, double delta, double* times_p, double* obs_p, hipStream_t s);
 hipError_t launch_lattice_gather(const int64_t* pos, const double* src, int64_t n, int64_t np, int ncol, double* dst, hipStream_t s);

@@ -513,11 +513,37 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         }
         const std::vector<int64_t>& tstarts = h->n_pad > 0 ? tstarts_pad : starts;
 
-        // tracks -> lanes: longest first (stable), 64 per wavefront
+        // tracks -> lanes, 64 per wavefront: tracks WITHOUT a missing row first, longest first within each class (stable).
+        // A wavefront whose 64 tracks have every row runs the shared-covariance kernel, one missing row anywhere in it
+        // sends all 64 to the general kernel (3x the time): dealing the tracks that have missing rows (or, on a lattice
+        // layout, absent fixes) to wavefronts of their own keeps everybody else on the fast path.
         const int64_t M = h->n_seg;
+        std::vector<uint8_t> seg_dirty((size_t)M, 0);
+        if (h->path == PATH_ISO && !getenv("SSDE_NO_REGROUP")) {
+            if (t_on_dev) {
+                DevBuf<int64_t> sd;
+                DevBuf<int> fl;
+                HIPCHK(h, sd.upload(tstarts));
+                HIPCHK(h, fl.alloc((size_t)M));
+                HIPCHK(h, hipMemset(fl.p, 0, (size_t)M * sizeof(int)));
+                HIPCHK(h, launch_seg_nan(t_obs, tn, d->n_dim, sd.p, M, fl.p, 0));
+                std::vector<int> flh((size_t)M);
+                HIPCHK(h, hipMemcpy(flh.data(), fl.p, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
+                for (int64_t k = 0; k < M; k++) seg_dirty[k] = flh[k] != 0;
+                sd.release(); fl.release();
+            } else {
+                for (int64_t k = 0; k < M; k++)
+                    for (int a = 0; a < d->n_dim && !seg_dirty[k]; a++) {
+                        const double* col = t_obs + (size_t)a * tn;
+                        for (int64_t i = tstarts[k]; i < tstarts[k + 1]; i++)
+                            if (col[i] != col[i]) { seg_dirty[k] = 1; break; }
+                    }
+            }
+        }
         std::vector<int64_t> order(M);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            if (seg_dirty[a] != seg_dirty[b]) return seg_dirty[a] < seg_dirty[b];
             return (tstarts[a + 1] - tstarts[a]) > (tstarts[b + 1] - tstarts[b]);
         });
         h->n_groups = (int)((M + WAVE - 1) / WAVE);
@@ -668,6 +694,18 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
                 // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
                 // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
                 want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
+            else if (h->use_shared && h->n_clean_groups < G) {
+                // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows
+                // on the general kernel -- both launches share ONE window plan, and with the shared kernel's few long windows
+                // the general launch is a handful of waves each running a seventh of a track at 0.5 us per row: its critical
+                // path, not its share of the rows, set the evaluation's time (0.75-0.9 ms with 5-30 % of the tracks affected).
+                // Enough windows for the general launch to fill its two waves per SIMD, capped so that the shared kernel's
+                // warm-up overhead stays moderate (plan_windows keeps every window at least two warm-ups long).
+                const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
+                int cap = 24;
+                if (const char* e = getenv("SSDE_MIXED_CAP")) cap = std::max(1, atoi(e));
+                want = std::max(want, std::min(cap, std::max(1, 2048 / (gd8 * h->iso_parts))));
+            }
             if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
             h->want_chunks = std::max(1, std::min(want, h->max_chunks));

@@ -191,3 +191,30 @@ def test_lattice_composes_with_wide_responses_and_track_shards():
         _close(val, grad, oval, ograd)
         assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
         eng.close()
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_tracks_with_missing_rows_get_wavefronts_of_their_own(model, monkeypatch):
+    """a third of the tracks (every third one) have missing rows: dealt to wavefronts of their own, the others keep the
+    shared-covariance kernel; same numbers as with the caller's order of tracks (SSDE_NO_REGROUP=1) and as the oracle"""
+    from smoothsde_amd.synth import simulate
+    M, T, d = 384, 700, 2
+    ID, times, obs = simulate(model, M, T, d, seed=9)
+    rng = np.random.default_rng(1)
+    for k in range(0, M, 3):
+        rows = k * T + rng.integers(1, T, size=5)
+        obs[rows, :] = np.nan
+    pb = capi.Problem(model, ID, times, obs)
+    par = _par(model, d, rng)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    aest = eng.report(par)
+    eng.close()
+    monkeypatch.setenv("SSDE_NO_REGROUP", "1")
+    e2 = capi.Engine(pb)
+    v2, g2 = e2.eval(par, order=1)
+    assert abs(v2 - val) <= 1e-12 * abs(val) and np.max(np.abs(g2 - grad)) <= 1e-10 * max(1.0, np.max(np.abs(grad)))
+    assert np.allclose(e2.report(par), aest, rtol=1e-12, atol=1e-12, equal_nan=True)
+    e2.close()
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
