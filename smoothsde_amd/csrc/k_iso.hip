@@ -318,10 +318,14 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
     const int nstate = (A.nstate_clean > 0 && (A.group_flags[g] & 1)) ? A.nstate_clean : nstate_full;
+    // the group's window plan: the launch's, or -- mixed batch, group on the general kernel -- that launch's own
+    int nc = A.n_chunks, win = A.window, t0 = A.t0, t0d = A.t0_delta;
+    if (A.dual && !(A.group_flags[g] & 1)) { nc = A.n_chunks_d; win = A.window_d; t0 = A.t0_d; t0d = A.t0_delta_d; }
+    if (c + 1 >= nc) return 0.0;                       // (workgroup-uniform) no such boundary in this group's plan
     int sb_, s_next, se_;
-    window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_, A.t0_delta);   // s_next = first scored row of window c+1
+    window_bounds(L, nc, win, t0, c + 1, sb_, s_next, se_, t0d);   // s_next = first scored row of window c+1
     const bool valid = (ns > s_next) && (s_next < L);
-    const int pc0 = part * A.n_chunks + c, pc1 = pc0 + 1;
+    const int pc0 = part * nc + c, pc1 = pc0 + 1;
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
     const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
     double worst = 0.0;
@@ -397,7 +401,7 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
 __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, const ReduceArgs R, int nstate, int n_check) {
     __shared__ double sh[256];
     if ((int)blockIdx.x < n_check) {
-        const int G = A.tv.n_groups, nb = A.n_chunks - 1;
+        const int G = A.tv.n_groups, nb = ((A.dual && A.n_chunks_d > A.n_chunks) ? A.n_chunks_d : A.n_chunks) - 1;
         const int g = blockIdx.x % G, c = (blockIdx.x / G) % nb, part = blockIdx.x / (G * nb);
         const double w = window_check_block(A, nstate, g, c, part, sh);
         if (threadIdx.x == 0 && w > 0.0)
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
 }
 
 hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {
-    const int n_check = a.n_chunks > 1 ? a.tv.n_groups * (a.n_chunks - 1) * a.n_parts : 0;
+    const int ncm = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;
+    const int n_check = ncm > 1 ? a.tv.n_groups * (ncm - 1) * a.n_parts : 0;
     hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, r, iso_nstate(model, d), n_check);
     return hipGetLastError();
 }

@@ -82,6 +82,12 @@ struct IsoArgs {
     int window;                  // warm-up rows of a window, multiple of WIN_ALIGN
     int t0;                      // > 0: window 0 is the covariance transient [0, t0) (shared-covariance path)
     int t0_delta;                // stationary rows the transient window is worth (window 1 is shortened by it), multiple of WIN_ALIGN
+    // Mixed batch (some track groups on the shared-covariance kernel, the others on the general kernel): the two launches
+    // have window plans of their own -- the shared kernel wants few long windows (every window costs it a warm-up), the
+    // general launch enough of them to fill two waves per SIMD.  The launches get their plan in the fields above; the
+    // finalize launch, which checks the hand-overs of both, reads the general launch's plan here (dual != 0).
+    int dual;
+    int n_chunks_d, window_d, t0_d, t0_delta_d;
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;

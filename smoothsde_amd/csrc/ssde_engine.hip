@@ -694,30 +694,32 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
                 // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
                 // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
                 want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
-            else if (h->use_shared && h->n_clean_groups < G) {
-                // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows
-                // on the general kernel -- both launches share ONE window plan, and with the shared kernel's few long windows
-                // the general launch is a handful of waves each running a seventh of a track at 0.5 us per row: its critical
-                // path, not its share of the rows, set the evaluation's time (0.75-0.9 ms with 5-30 % of the tracks affected).
-                // Enough windows for the general launch to fill its two waves per SIMD, capped so that the shared kernel's
-                // warm-up overhead stays moderate (plan_windows keeps every window at least two warm-ups long).
-                const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
-                int cap = 24;
-                if (const char* e = getenv("SSDE_MIXED_CAP")) cap = std::max(1, atoi(e));
-                want = std::max(want, std::min(cap, std::max(1, 2048 / (gd8 * h->iso_parts))));
-            }
             if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
             h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
             h->want_chunks = std::max(1, std::min(want, h->max_chunks));
+            // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows on
+            // the general kernel.  With ONE plan -- the shared kernel's few long windows -- the general launch is a handful of
+            // waves each running a seventh of a track at 0.5 us per row, and its critical path, not its share of the rows,
+            // sets the evaluation's time (0.75-0.9 ms with 1-30 % of the tracks affected).  The general launch gets a plan of
+            // its own: enough windows to fill its two waves per SIMD (plan_windows keeps them at least two warm-ups long).
+            int buf_chunks = h->max_chunks;
+            if (h->use_shared && h->n_clean_groups < G && !h->chunks_forced && !getenv("SSDE_ONE_PLAN")) {
+                const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
+                const int want_d = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / gd8);
+                // (the hand-over dumps are sized for every group x the longer plan: keep them under ~0.5 GB)
+                const int by_mem = std::max(2, (int)(512e6 / ((double)G * 2.0 * NSTATE_MAX * WAVE * 8.0)) - 1);
+                h->want_chunks_d = std::max(1, std::min(std::min(std::min(want_d, 64), by_mem), std::max(1, glmax / (4 * WIN_ALIGN))));
+                buf_chunks = std::max(buf_chunks, h->want_chunks_d + 1);
+            }
             if (h->use_shared) {
                 h->gain_rows_cap = (size_t)glmax + 1;
                 HIPCHK(h, h->gain_ring.alloc((size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW));
                 HIPCHK(h, hipHostMalloc((void**)&h->gain_pinned, (size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW * 8,
                                         hipHostMallocDefault));
             }
-            HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * h->max_chunks * G * 2 * NSTATE_MAX * WAVE));
-            HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * h->max_chunks * G));
-            h->partial_doubles = (size_t)MAX_PARTS * h->max_chunks * NACC_MAX * G;
+            HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * NSTATE_MAX * WAVE));
+            HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
+            h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * NACC_MAX * G;
             h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
         } else {
             // gradient directions of the dense kernel: free parameters that reach the data term
@@ -1080,13 +1082,31 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         if (h->use_shared) {
             // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
             // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check
+            const bool any_dirty = h->n_clean_groups < h->n_groups;
+            IsoArgs ad = a;                      // the general launch: this plan, or -- mixed batch -- one of its own
+            if (any_dirty && h->want_chunks_d > 0 && a.n_chunks > 1 && h->max_chunks > 1 && !h->gave_up) {
+                int nc = h->want_chunks_d;
+                while (nc > 1 && (h->glen_max / nc) < 2 * a.window) nc--;
+                if (nc > 1) {
+                    ad.n_chunks = nc; ad.t0 = 0; ad.t0_delta = 0;
+                    // window 0 carries every direction and has no warm-up: the balance of the all-general case (below)
+                    const bool can_derive = order >= 1 && a.derive && (a.part_mask[0] & DIR_SIG) &&
+                                            (a.part_mask[0] & (h->model == SSDE_MODEL_BM_SSM ? DIR_P1 : DIR_P2));
+                    const double r = (can_derive && h->env_w0_ratio > 0.0) ? h->env_w0_ratio : 1.0;
+                    const double L0 = ((double)h->glen_max / (nc - 1) + a.window) / (r + 1.0 / (nc - 1));
+                    const int t0 = (int)(L0 / WIN_ALIGN) * WIN_ALIGN;
+                    if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) ad.t0 = t0;
+                    a.dual = 1; a.n_chunks_d = ad.n_chunks; a.window_d = ad.window; a.t0_d = ad.t0; a.t0_delta_d = ad.t0_delta;
+                    // the final sums run over the longer of the two plans: the slots the shorter one does not write must be zero
+                    HIPCHK(h, hipMemsetAsync(h->partials.p, 0, (size_t)std::max(a.n_chunks, ad.n_chunks) * (4 + h->d) * h->n_groups * 8, s));
+                }
+            }
             IsoArgs b = a;
             b.group_mode = 2;
-            const bool any_dirty = h->n_clean_groups < h->n_groups;
             if (any_dirty) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, s));
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
-                HIPCHK(h, launch_iso(h->model, h->d, a, true, h->aux[1]));
+                HIPCHK(h, launch_iso(h->model, h->d, ad, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
             HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->ev_k0, h->ev_k1));
@@ -1111,8 +1131,9 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
         }
         const int nacc = 4 + h->d;
-        ra.n_parts = a.n_parts * a.n_chunks; ra.nacc = nacc; ra.n_blocks = h->n_groups;
-        ra.n_value_parts = a.n_chunks; ra.chunks_per_part = a.n_chunks;
+        const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
+        ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+        ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
         ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
         if (order >= 1) {
             for (int p = 0; p < a.n_parts; p++)

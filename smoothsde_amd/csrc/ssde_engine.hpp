@@ -117,6 +117,7 @@ struct ssde_handle {
     DevBuf<double> bnd, chk;
     int max_chunks = 1;            // allocation bound
     int want_chunks = 1;           // planned number of equal windows (the transient window comes on top)
+    int want_chunks_d = 0;         // mixed batch: windows of the general launch's own plan (0 = one plan for everything)
     int glen_max = 0;              // steps of the longest track group
     double dt_min = 0.0;           // smallest interval used inside a track
     bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
