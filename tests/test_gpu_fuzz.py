@@ -212,3 +212,46 @@ def test_random_long_ragged_problem_matches_oracle(seed):
         assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd, ctx)
         assert info["window_check"] <= capi.WINDOW_TOL, ctx
     eng.close()
+
+
+_MLO, _MHI = (int(v) for v in os.environ.get("SSDE_FUZZ_MIXED_SEEDS", "0:18").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_MLO, _MHI))
+def test_random_mixed_batch_matches_oracle(seed):
+    """enough long tracks for time windows, missing rows (or absent fixes) in SOME of them: clean tracks dealt to
+    wavefronts of their own, the shared-covariance and the general launch each with its own window plan"""
+    rng = np.random.default_rng(5000 + seed)
+    model = ["CTCRW", "OU_SSM", "BM_SSM"][seed % 3]
+    d = 1 + (seed // 3) % 2
+    n_tracks = int(rng.integers(130, 420))
+    lens = rng.integers(300, 1800, size=n_tracks)
+    ID = np.repeat(np.arange(n_tracks), lens).astype(float)
+    n = len(ID)
+    times = np.arange(1.0, n + 1)
+    obs = np.cumsum(rng.standard_normal((n, d)) * (1.0 if model == "CTCRW" else 0.3), axis=0)
+    if model == "OU_SSM":
+        obs = 3.0 + rng.standard_normal((n, d))
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    dirty_track = rng.random(n_tracks) < rng.choice([0.02, 0.2, 0.5])
+    if seed % 2 == 0:      # missing rows
+        na = (rng.random(n) < 0.04) & np.repeat(dirty_track, lens) & ~first
+        obs[na, :] = np.nan
+    else:                  # absent fixes: a lattice with gaps in some tracks
+        keep = ~((rng.random(n) < 0.04) & np.repeat(dirty_track, lens) & ~first)
+        keep[np.r_[first[1:], True]] = True
+        ID, times, obs = ID[keep], times[keep], obs[keep]
+    pb = capi.Problem(model, ID, times, obs)
+    par = 0.2 * rng.standard_normal(pb.n_par_full)
+    par[0] = rng.uniform(-1.5, 0.0)
+    if model == "OU_SSM":
+        par[1:1 + d] += 3.0
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    info = eng.info()
+    oval, ograd = _oracle(pb, par)
+    ctx = (model, d, pb.n, pb.n_seg, info["path"], info["window"], info["lanes_per_track"], info["window_retries"])
+    assert info["window_check"] <= 1e-11, ctx
+    assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (ctx, val, oval)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (ctx, grad, ograd)
+    eng.close()
