@@ -518,27 +518,22 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         // sends all 64 to the general kernel (3x the time): dealing the tracks that have missing rows (or, on a lattice
         // layout, absent fixes) to wavefronts of their own keeps everybody else on the fast path.
         const int64_t M = h->n_seg;
+        // the observations on the device (host data: staged here, freed again after tiling)
+        DevBuf<double> s_obs;
+        const double* p_obs = t_obs;
+        if (!t_on_dev) { HIPCHK(h, stage(t_obs, (size_t)tn * d->n_dim, false, s_obs)); p_obs = s_obs.p; }
         std::vector<uint8_t> seg_dirty((size_t)M, 0);
         if (h->path == PATH_ISO && !getenv("SSDE_NO_REGROUP")) {
-            if (t_on_dev) {
-                DevBuf<int64_t> sd;
-                DevBuf<int> fl;
-                HIPCHK(h, sd.upload(tstarts));
-                HIPCHK(h, fl.alloc((size_t)M));
-                HIPCHK(h, hipMemset(fl.p, 0, (size_t)M * sizeof(int)));
-                HIPCHK(h, launch_seg_nan(t_obs, tn, d->n_dim, sd.p, M, fl.p, 0));
-                std::vector<int> flh((size_t)M);
-                HIPCHK(h, hipMemcpy(flh.data(), fl.p, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
-                for (int64_t k = 0; k < M; k++) seg_dirty[k] = flh[k] != 0;
-                sd.release(); fl.release();
-            } else {
-                for (int64_t k = 0; k < M; k++)
-                    for (int a = 0; a < d->n_dim && !seg_dirty[k]; a++) {
-                        const double* col = t_obs + (size_t)a * tn;
-                        for (int64_t i = tstarts[k]; i < tstarts[k + 1]; i++)
-                            if (col[i] != col[i]) { seg_dirty[k] = 1; break; }
-                    }
-            }
+            DevBuf<int64_t> sd;
+            DevBuf<int> fl;
+            HIPCHK(h, sd.upload(tstarts));
+            HIPCHK(h, fl.alloc((size_t)M));
+            HIPCHK(h, hipMemset(fl.p, 0, (size_t)M * sizeof(int)));
+            HIPCHK(h, launch_seg_nan(p_obs, tn, d->n_dim, sd.p, M, fl.p, 0));
+            std::vector<int> flh((size_t)M);
+            HIPCHK(h, hipMemcpy(flh.data(), fl.p, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < M; k++) seg_dirty[k] = flh[k] != 0;
+            sd.release(); fl.release();
         }
         std::vector<int64_t> order(M);
         std::iota(order.begin(), order.end(), 0);
@@ -599,12 +594,11 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         h->glen_host = glen; h->lane_ns_host = lane_ns;
 
         // stage the caller's arrays (host data) -- freed again after tiling
-        DevBuf<double> s_obs, s_h, s_a0, s_cols;
+        DevBuf<double> s_h, s_a0, s_cols;
         DevBuf<const double*> s_colptr;
         DevBuf<int64_t> s_lane_seg;
-        const double *p_obs = t_obs, *p_h = d->h_array;
+        const double* p_h = d->h_array;
         if (!t_on_dev) {
-            HIPCHK(h, stage(t_obs, (size_t)tn * d->n_dim, false, s_obs)); p_obs = s_obs.p;
             if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)tn * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
         }
         std::vector<const double*> cp(h->n_stream_cols, nullptr);
