@@ -138,7 +138,17 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
             if (!(dt > 0.0) || !std::isfinite(dt)) return SSDE_OK;         // not a grid at all: the general path deals with it
             delta = std::min(delta, dt); dmax = std::max(dmax, dt);
         }
-    if (!std::isfinite(delta) || dmax == delta || dmax > (LATTICE_MAX_MULT + 0.5) * delta) return SSDE_OK;   // regular, or too wide
+    // How far an interval may be from a whole multiple of the step and still count as one.  Time stamps with a decimal step
+    // (0.1, 1/24 ...) are regular only to the last bits of the stamps; taking such a grid as exactly regular moves every dt
+    // by at most this relative amount, and the nllk by no more (each row's term has an O(1) log-derivative in dt): the
+    // default leaves two orders of magnitude to the 1e-10 parity bar.  Long series with inexact steps (stamp / step > ~5000)
+    // are beyond it and keep the per-row transition; SSDE_GRID_RTOL loosens it at the caller's own risk.
+    double rtol = 1e-12;
+    if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
+    if (!std::isfinite(delta)) return SSDE_OK;
+    if (dmax == delta) return SSDE_OK;                                             // exactly regular: nothing to do here
+    if (dmax <= delta * (1.0 + rtol)) { h->snap_dt = 0.5 * (delta + dmax); return SSDE_OK; }   // regular to the last bits
+    if (dmax > (LATTICE_MAX_MULT + 0.5) * delta) return SSDE_OK;                   // too wide
     std::vector<int64_t> pos((size_t)n);
     starts_pad.assign((size_t)n_seg + 1, 0);
     int64_t run = 0;
@@ -149,7 +159,7 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
         for (int64_t i = starts[sg] + 2; i < starts[sg + 1]; i++) {
             const double r = (th[i] - th[i - 1]) / delta;
             const double k = std::nearbyint(r);
-            if (std::fabs(r - k) > 1e-10 * k) return SSDE_OK;               // not a lattice
+            if (std::fabs(r - k) > rtol * k) return SSDE_OK;                // not a lattice
             run += (int64_t)k;
             pos[i] = run - 1;
         }
@@ -440,8 +450,11 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
             double dmin = INFINITY, dmax = -INFINITY;
             for (int b = 0; b < nb; b++) { dmin = std::min(dmin, mmh[2 * b]); dmax = std::max(dmax, mmh[2 * b + 1]); }
-            h->direct_uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
-            h->direct_dt = h->direct_uniform_dt ? dmin : 0.0;
+            // regular to the last bits counts as regular (the tolerance and its argument: lattice_pad)
+            double rtol = 1e-12;
+            if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
+            h->direct_uniform_dt = (dmax <= dmin * (1.0 + rtol)) && dmin > 0.0 && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
+            h->direct_dt = h->direct_uniform_dt ? 0.5 * (dmin + dmax) : 0.0;
             h->uniform_dt = h->direct_uniform_dt;
             mm.release();
             // which parameters have streamed columns (slots are ordered parameter by parameter)
@@ -644,9 +657,11 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         }
         h->uniform_dt = (dmin == dmax) && std::isfinite(dmin) && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT);
         if (h->n_pad > 0) {
-            // the lattice was verified to 1e-10 of its step: every scored interval IS the step (an interpolated time stamp
-            // may differ from it in the last bits)
+            // the lattice was verified to SSDE_GRID_RTOL of its step: every scored interval IS the step (an interpolated
+            // time stamp may differ from it in the last bits)
             h->uniform_dt = true; dmin = h->pad_step;
+        } else if (h->snap_dt > 0.0) {
+            h->uniform_dt = true; dmin = h->snap_dt;
         }
         h->dt_uniform = h->uniform_dt ? dmin : 0.0;
         h->dt_min = std::isfinite(dmin) ? dmin : 0.0;

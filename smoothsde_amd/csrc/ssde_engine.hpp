@@ -214,6 +214,7 @@ struct ssde_handle {
     int64_t n_pad = 0;
     DevBuf<int64_t> pad_pos;
     double pad_step = 0.0;
+    double snap_dt = 0.0;          // > 0: a grid that is regular to SSDE_GRID_RTOL (last-bit jitter of decimal steps): this step is hoisted
 
     // ---- distributed evaluation (ssde_engine_dist.hip) -------------------------------------------------------------
     // single-process multi-GPU parent (ssde_desc.n_devices > 1): one engine per device, this handle owns no device data

@@ -36,7 +36,7 @@ def lattice_tracks(model, d, lengths, step, drop, seed, max_gap=3, na_frac=0.0, 
                 gap = 0
         idx = np.flatnonzero(keep)
         tt = t0 + step * idx                    # (step = 0.1: multiples of the step to rounding, not bitwise)
-        t0 = tt[-1] + 7.3                       # the interval to the next track is NOT on the lattice
+        t0 = tt[-1] + 7.25                      # the interval to the next track is NOT on the lattice (but exact in binary)
         z = np.cumsum(rng.standard_normal((T, d)) * (1.0 if model == "CTCRW" else 0.3), axis=0)[idx]
         if model == "OU_SSM":
             z = 3.0 + rng.standard_normal((len(idx), d))
@@ -218,3 +218,29 @@ def test_tracks_with_missing_rows_get_wavefronts_of_their_own(model, monkeypatch
     e2.close()
     oval, ograd = oracle_eval(pb, par, order=1, threads=8)
     _close(val, grad, oval, ograd)
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_decimal_step_is_regular_to_the_last_bits(model, monkeypatch):
+    """times = 0.1 * (0, 1, 2, ...): the intervals differ in their last bits.  Within 1e-12 of one step the grid is taken as
+    regular (hoisted transition); the numbers stay within the parity tolerance of the oracle, which uses every row's own dt"""
+    rng = np.random.default_rng(3)
+    lens = [120, 64, 200]
+    ID = np.repeat(np.arange(3.0), lens)
+    times = 0.1 * np.arange(len(ID))
+    assert len(np.unique(np.diff(times))) > 1                     # not bitwise regular
+    obs = np.cumsum(rng.standard_normal((len(ID), 2)) * 0.3, axis=0) + (3.0 if model == "OU_SSM" else 0.0)
+    pb = capi.Problem(model, ID, times, obs)
+    par = _par(model, 2, rng)
+    eng = capi.Engine(pb)
+    assert eng.info()["uniform_dt"] == 1
+    val, grad = eng.eval(par, order=1)
+    oval, ograd = oracle_eval(pb, par, order=1)
+    _close(val, grad, oval, ograd)
+    eng.close()
+    monkeypatch.setenv("SSDE_GRID_RTOL", "0")                     # strict: the per-row transition
+    eng = capi.Engine(pb)
+    assert eng.info()["uniform_dt"] == 0
+    v2, g2 = eng.eval(par, order=1)
+    _close(v2, g2, oval, ograd)
+    eng.close()
