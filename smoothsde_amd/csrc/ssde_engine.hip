@@ -573,7 +573,9 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             double lo = INFINITY, hi = -INFINITY;
             for (int b = 0; b < nb; b++) { lo = std::min(lo, mmh[2 * b]); hi = std::max(hi, mmh[2 * b + 1]); }
             mm.release();
-            if (lo == hi && std::isfinite(lo)) { h->c_obs = 0; h->dt_all = lo; }
+            double rtol = 1e-12;                                    // (regular to the last bits counts as regular: lattice_pad)
+            if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
+            if (std::isfinite(lo) && lo > 0.0 && hi <= lo * (1.0 + rtol)) { h->c_obs = 0; h->dt_all = 0.5 * (lo + hi); }
         }
         h->C = h->c_obs + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + h->n_stream_cols;
         std::vector<int64_t> lane_row0((size_t)G * WAVE, -1), lane_seg((size_t)G * WAVE, 0), goff(G);
