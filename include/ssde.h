@@ -130,7 +130,11 @@ typedef struct ssde_desc {
     int64_t  n;               /* rows of the long-format data (all tracks concatenated) */
     const double *id;         /* [n] track codes (TMB passes the factor as doubles); only
                                  id[i] != id[i-1] is ever used (nllk_ctcrw.hpp:196)     */
-    const double *times;      /* [n]   DATA_VECTOR(times) */
+    const double *times;      /* [n]   DATA_VECTOR(times).  Any increasing stamps; recognised at create (the numbers are the
+                                 reference's either way): a regular grid (transition hoisted), and a regular
+                                 schedule whose failed fixes are absent from the data -- intervals that are small whole
+                                 multiples of one step -- which is laid out on its lattice and run as a regular grid with
+                                 missing rows */
     const double *obs;        /* [n*d] DATA_MATRIX(obs), column-major */
 
     /* design blocks, one per SDE parameter j = 0..q-1: the X_list_fe[[j]] /
