@@ -146,7 +146,7 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
     double rtol = 1e-12;
     if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
     if (!std::isfinite(delta)) return SSDE_OK;
-    if (dmax == delta) return SSDE_OK;                                             // exactly regular: nothing to do here
+    if (dmax == delta) { h->snap_dt = delta; return SSDE_OK; }                     // regular (whatever the unused first intervals are)
     if (dmax <= delta * (1.0 + rtol)) { h->snap_dt = 0.5 * (delta + dmax); return SSDE_OK; }   // regular to the last bits
     if (dmax > (LATTICE_MAX_MULT + 0.5) * delta) return SSDE_OK;                   // too wide
     std::vector<int64_t> pos((size_t)n);

@@ -244,3 +244,22 @@ def test_decimal_step_is_regular_to_the_last_bits(model, monkeypatch):
     v2, g2 = eng.eval(par, order=1)
     _close(v2, g2, oval, ograd)
     eng.close()
+
+
+def test_a_tracks_first_interval_does_not_decide_regularity():
+    """the first interval of a track is never used (a0 is the prediction for the second row as it stands): a grid that is
+    regular from the second row on gets the hoisted transition whatever the first stamps are"""
+    rng = np.random.default_rng(12)
+    ID = np.repeat(np.arange(4.0), 80)
+    times = np.arange(320.0)
+    times[::80] -= rng.uniform(0.1, 5.0, size=4)          # every track's first stamp is somewhere earlier
+    obs = np.cumsum(rng.standard_normal((320, 2)), axis=0)
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    par = _par("CTCRW", 2, rng)
+    eng = capi.Engine(pb)
+    assert eng.info()["uniform_dt"] == 1
+    val, grad = eng.eval(par, order=1)
+    oval, ograd, oaest = oracle_eval(pb, par, order=1, report=True)
+    _close(val, grad, oval, ograd)
+    assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
+    eng.close()
