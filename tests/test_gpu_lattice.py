@@ -151,7 +151,10 @@ def test_what_is_not_a_cheap_lattice_keeps_the_irregular_kernel(kind):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(48))
+_LLO, _LHI = (int(v) for v in __import__("os").environ.get("SSDE_FUZZ_LATTICE_SEEDS", "0:48").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_LLO, _LHI))
 def test_random_lattice_problems(seed):
     rng = np.random.default_rng(1000 + seed)
     model = ["CTCRW", "OU_SSM", "BM_SSM"][seed % 3]
