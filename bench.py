@@ -184,7 +184,8 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
             "ms_per_step": 1e3 * el / steps, "kernel_ms": kern,
             "required_bytes_per_row": inf["required_bytes_per_row"],
             "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "window_check_max": chk, "window_retries": inf["window_retries"]}
+            "window_check_max": chk, "window_retries": inf["window_retries"],
+            "rows_tiled": inf["n_rows_tiled"], "groups": inf["n_groups"], "clean_groups": inf["n_clean_groups"]}
 
 
 def main():

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 6
+#define SSDE_ABI_VERSION 7
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -226,6 +226,11 @@ typedef struct ssde_info_t {
     int32_t n_devices;      /* shards of a single-process multi-GPU handle (1 otherwise) */
     int32_t comm_ranks;     /* ranks of the RCCL communicator joined with ssde_comm_init_rank (1 = none) */
     double  window_check_max; /* largest ACCEPTED hand-over disagreement over every ssde_eval since ssde_create */
+    /* how the engine laid the batch out (Kalman register path; 0 elsewhere) -- ABI 7 */
+    int64_t n_rows_tiled;   /* rows of the resident layout: n_rows, or more when a schedule with absent fixes was laid out
+                               on its lattice */
+    int32_t n_groups;       /* 64-track wavefront groups */
+    int32_t n_clean_groups; /* ... of which every track has every row: the shared-covariance kernel's share on a regular grid */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the

@@ -1690,6 +1690,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
             else {
                 if (first_part) { info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps; info->main_kernel_rows += si.main_kernel_rows; }
                 info->hbm_bytes += si.hbm_bytes;
+                info->n_rows_tiled += si.n_rows_tiled; info->n_groups += si.n_groups; info->n_clean_groups += si.n_clean_groups;
                 info->n_kernel_blocks += si.n_kernel_blocks;   // (n_evals: shard 0's count -- every shard runs every evaluation)
                 info->uniform_dt = info->uniform_dt && si.uniform_dt;
                 info->const_coeff = info->const_coeff && si.const_coeff;
@@ -1730,6 +1731,10 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_ISO && h->uniform_dt) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
           h->df_ja != h->d + 1 && h->df_jb != h->d + 1 && h->model != SSDE_MODEL_BM_T && h->model != SSDE_MODEL_CIR) ? 8.0 : 0.0);
     if (h->n_pad > 0) info->required_bytes_per_row *= (double)h->n_pad / (double)h->n;
+    if (h->path == PATH_ISO || h->path == PATH_DENSE) {
+        info->n_rows_tiled = h->n_pad > 0 ? h->n_pad : h->n;
+        info->n_groups = h->n_groups; info->n_clean_groups = h->path == PATH_ISO ? h->n_clean_groups : 0;
+    }
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only

@@ -68,7 +68,7 @@ def test_lattice_with_absent_fixes_matches_the_oracle_on_the_callers_rows(model,
     eng = capi.Engine(pb)
     info = eng.info()
     assert info["path"] == 1 and info["uniform_dt"] == 1, info            # laid out on the lattice: the hoisted transition
-    assert info["n_rows"] == pb.n
+    assert info["n_rows"] == pb.n and pb.n < info["n_rows_tiled"] <= 1.35 * pb.n + 64
     val, grad = eng.eval(par, order=1)
     _close(val, grad, oval, ograd)
     assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
@@ -210,11 +210,14 @@ def test_tracks_with_missing_rows_get_wavefronts_of_their_own(model, monkeypatch
     pb = capi.Problem(model, ID, times, obs)
     par = _par(model, d, rng)
     eng = capi.Engine(pb)
+    info = eng.info()
+    assert info["n_groups"] == 6 and info["n_clean_groups"] == 4          # 256 complete tracks = four wavefronts of their own
     val, grad = eng.eval(par, order=1)
     aest = eng.report(par)
     eng.close()
     monkeypatch.setenv("SSDE_NO_REGROUP", "1")
     e2 = capi.Engine(pb)
+    assert e2.info()["n_clean_groups"] == 0                               # every third track: no wavefront without one
     v2, g2 = e2.eval(par, order=1)
     assert abs(v2 - val) <= 1e-12 * abs(val) and np.max(np.abs(g2 - grad)) <= 1e-10 * max(1.0, np.max(np.abs(grad)))
     assert np.allclose(e2.report(par), aest, rtol=1e-12, atol=1e-12, equal_nan=True)
