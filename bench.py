@@ -331,6 +331,7 @@ def main():
                    "tracks_per_gpu": M, "rows_per_track": T, "n_free_par": info["n_free"],
                    "engine_path": capi.PATH_NAMES[info["path"]],
                    "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
+                   "rows_tiled": info["n_rows_tiled"], "groups": info["n_groups"], "clean_groups": info["n_clean_groups"],
                    "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
                    "window_check": check_max, "window_retries": info["window_retries"],
                    "parallelism": f"tracks x{world}" + (", in-engine ncclAllReduce of 2+p doubles" if use_comm else ""),
