@@ -124,6 +124,20 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
     std::vector<double> th_own;
     const double* th = d->times;
     if (on_dev) {
+        // (a grid that is regular across the whole array -- the common case of device-resident batches -- is recognised on
+        //  the device: no copy of the stamps to the host)
+        const int nb = 1024;
+        DevBuf<double> mm;
+        HIPCHK(h, mm.alloc((size_t)nb * 2));
+        HIPCHK(h, launch_dt_minmax(d->times, nullptr, n, mm.p, nb, 0));
+        std::vector<double> mmh((size_t)nb * 2);
+        HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
+        mm.release();
+        double lo = INFINITY, hi = -INFINITY;
+        for (int b = 0; b < nb; b++) { lo = std::min(lo, mmh[2 * b]); hi = std::max(hi, mmh[2 * b + 1]); }
+        if (lo == hi && std::isfinite(lo)) return SSDE_OK;
+    }
+    if (on_dev) {
         th_own.resize((size_t)n);
         HIPCHK(h, hipMemcpy(th_own.data(), d->times, (size_t)n * 8, hipMemcpyDeviceToHost));
         th = th_own.data();
