@@ -172,6 +172,10 @@ hipError_t launch_scored_mask(const double* id, int64_t n, uint32_t* mask, hipSt
 // first-row flags for segment discovery on device data
 hipError_t launch_first_flags(const double* id, int64_t n, uint8_t* flags, hipStream_t s);
 hipError_t launch_seg_nan(const double* obs, int64_t n, int d, const int64_t* starts, int64_t n_seg, int* flags, hipStream_t s);
+hipError_t launch_used_dt_minmax(const double* id, const double* times, int64_t n, double* out, int n_blocks, hipStream_t s);   // k_lattice.hip
+hipError_t lattice_positions(const double* id, const double* times, int64_t n, double delta, double rtol, int64_t* inc, int64_t* pos,
+                             int64_t* rep, int* bad_dev, int64_t* n_lattice, int* bad_host, hipStream_t s);
+hipError_t launch_gather_i64(const int64_t* src, const int64_t* idx, int64_t m, int64_t* dst, hipStream_t s);
 hipError_t launch_lattice_scatter(const int64_t* pos, const double* id, const double* times, const double* obs, int64_t n, int d,
                                   int64_t np, double delta, double* times_p, double* obs_p, hipStream_t s);
 hipError_t launch_lattice_gather(const int64_t* pos, const double* src, int64_t n, int64_t np, int ncol, double* dst, hipStream_t s);

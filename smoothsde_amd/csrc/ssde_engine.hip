@@ -121,37 +121,28 @@ constexpr double LATTICE_MAX_GROWTH = 1.35;    // break-even of the two general 
 int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& starts, bool on_dev,
                 std::vector<int64_t>& starts_pad, DevBuf<double>& times_p, DevBuf<double>& obs_p) {
     const int64_t n = d->n, n_seg = (int64_t)starts.size() - 1;
-    std::vector<double> th_own;
-    const double* th = d->times;
-    if (on_dev) {
-        // (a grid that is regular across the whole array -- the common case of device-resident batches -- is recognised on
-        //  the device: no copy of the stamps to the host)
-        const int nb = 1024;
-        DevBuf<double> mm;
-        HIPCHK(h, mm.alloc((size_t)nb * 2));
-        HIPCHK(h, launch_dt_minmax(d->times, nullptr, n, mm.p, nb, 0));
-        std::vector<double> mmh((size_t)nb * 2);
-        HIPCHK(h, hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
-        mm.release();
-        double lo = INFINITY, hi = -INFINITY;
-        for (int b = 0; b < nb; b++) { lo = std::min(lo, mmh[2 * b]); hi = std::max(hi, mmh[2 * b + 1]); }
-        if (lo == hi && std::isfinite(lo)) return SSDE_OK;
-    }
-    if (on_dev) {
-        th_own.resize((size_t)n);
-        HIPCHK(h, hipMemcpy(th_own.data(), d->times, (size_t)n * 8, hipMemcpyDeviceToHost));
-        th = th_own.data();
+    // Everything below runs on the device (k_lattice.hip): what a short fit has to amortise is this function's time.
+    DevBuf<double> s_times, s_obs, s_id, mm;
+    DevBuf<int64_t> inc, pos, rep, sidx, spos;
+    DevBuf<int> bad;
+    auto cleanup = [&]() { s_times.release(); s_obs.release(); s_id.release(); mm.release(); inc.release(); pos.release(); rep.release();
+                           sidx.release(); spos.release(); bad.release(); };
+#define LP_CHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); h->err = std::string(#call) + ": " + hipGetErrorString(e__); return SSDE_ERR_HIP; } } while (0)
+    const double *p_times = d->times, *p_obs = d->obs, *p_id = d->id;
+    if (!on_dev) {
+        LP_CHK(stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p;
+        LP_CHK(stage(d->id, (size_t)n, false, s_id)); p_id = s_id.p;
     }
     // (a track's FIRST interval is never used -- a0 is the prediction for the second row as it stands, nllk_ctcrw.hpp:195-200,
     //  SURVEY Q1 -- so it is neither part of the lattice test nor padded: a lattice row there would be a prediction step
     //  the reference does not take)
-    double delta = INFINITY, dmax = 0.0;
-    for (int64_t sg = 0; sg < n_seg; sg++)
-        for (int64_t i = starts[sg] + 2; i < starts[sg + 1]; i++) {
-            const double dt = th[i] - th[i - 1];
-            if (!(dt > 0.0) || !std::isfinite(dt)) return SSDE_OK;         // not a grid at all: the general path deals with it
-            delta = std::min(delta, dt); dmax = std::max(dmax, dt);
-        }
+    const int nb = 1024;
+    LP_CHK(mm.alloc((size_t)nb * 2));
+    LP_CHK(launch_used_dt_minmax(p_id, p_times, n, mm.p, nb, 0));
+    std::vector<double> mmh((size_t)nb * 2);
+    LP_CHK(hipMemcpy(mmh.data(), mm.p, mmh.size() * 8, hipMemcpyDeviceToHost));
+    double delta = INFINITY, dmax = -INFINITY;
+    for (int b = 0; b < nb; b++) { delta = std::min(delta, mmh[2 * b]); dmax = std::max(dmax, mmh[2 * b + 1]); }
     // How far an interval may be from a whole multiple of the step and still count as one.  Time stamps with a decimal step
     // (0.1, 1/24 ...) are regular only to the last bits of the stamps; taking such a grid as exactly regular moves every dt
     // by at most this relative amount, and the nllk by no more (each row's term has an O(1) log-derivative in dt): the
@@ -159,50 +150,33 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
     // are beyond it and keep the per-row transition; SSDE_GRID_RTOL loosens it at the caller's own risk.
     double rtol = 1e-12;
     if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
-    if (!std::isfinite(delta)) return SSDE_OK;
-    if (dmax == delta) { h->snap_dt = delta; return SSDE_OK; }                     // regular (whatever the unused first intervals are)
-    if (dmax <= delta * (1.0 + rtol)) { h->snap_dt = 0.5 * (delta + dmax); return SSDE_OK; }   // regular to the last bits
-    if (dmax > (LATTICE_MAX_MULT + 0.5) * delta) return SSDE_OK;                   // too wide
-    std::vector<int64_t> pos((size_t)n);
-    starts_pad.assign((size_t)n_seg + 1, 0);
-    int64_t run = 0;
-    for (int64_t sg = 0; sg < n_seg; sg++) {
-        starts_pad[sg] = run;
-        pos[starts[sg]] = run++;
-        if (starts[sg] + 1 < starts[sg + 1]) pos[starts[sg] + 1] = run++;
-        for (int64_t i = starts[sg] + 2; i < starts[sg + 1]; i++) {
-            const double r = (th[i] - th[i - 1]) / delta;
-            const double k = std::nearbyint(r);
-            if (std::fabs(r - k) > rtol * k) return SSDE_OK;                // not a lattice
-            run += (int64_t)k;
-            pos[i] = run - 1;
-        }
-        if ((double)run > LATTICE_MAX_GROWTH * (double)starts[sg + 1] + 64.0) return SSDE_OK;
-    }
-    starts_pad[n_seg] = run;
-    const int64_t np = run;
-    if (np == n) return SSDE_OK;
-    // the caller's arrays on the device
-    DevBuf<double> s_times, s_obs, s_id;
-    const double *p_times = d->times, *p_obs = d->obs, *p_id = d->id;
-    if (!on_dev) {
-        HIPCHK(h, stage(d->times, (size_t)n, false, s_times)); p_times = s_times.p;
-        HIPCHK(h, stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p;
-        HIPCHK(h, stage(d->id, (size_t)n, false, s_id)); p_id = s_id.p;
-    }
-    DevBuf<int64_t> pos_dev;
-    HIPCHK(h, pos_dev.upload(pos));
-    HIPCHK(h, times_p.alloc((size_t)np));
-    HIPCHK(h, obs_p.alloc((size_t)np * d->n_dim));
-    HIPCHK(h, launch_lattice_scatter(pos_dev.p, p_id, p_times, p_obs, n, d->n_dim, np, delta, times_p.p, obs_p.p, 0));
-    HIPCHK(h, hipDeviceSynchronize());
-    s_times.release(); s_obs.release(); s_id.release(); pos_dev.release();
+    if (!std::isfinite(delta) || !std::isfinite(dmax) || !(delta > 0.0)) { cleanup(); return SSDE_OK; }   // no used interval, or not a grid
+    if (dmax == delta) { h->snap_dt = delta; cleanup(); return SSDE_OK; }           // regular (whatever the unused first intervals are)
+    if (dmax <= delta * (1.0 + rtol)) { h->snap_dt = 0.5 * (delta + dmax); cleanup(); return SSDE_OK; }   // regular to the last bits
+    if (dmax > (LATTICE_MAX_MULT + 0.5) * delta) { cleanup(); return SSDE_OK; }     // too wide
+    LP_CHK(inc.alloc((size_t)n)); LP_CHK(pos.alloc((size_t)n)); LP_CHK(rep.alloc((size_t)n)); LP_CHK(bad.alloc(1));
+    int64_t np = 0;
+    int bad_h = 0;
+    LP_CHK(lattice_positions(p_id, p_times, n, delta, rtol, inc.p, pos.p, rep.p, bad.p, &np, &bad_h, 0));
+    if (bad_h || np <= n || (double)np > LATTICE_MAX_GROWTH * (double)n + 64.0) { cleanup(); return SSDE_OK; }   // not a (cheap) lattice
+    // the lattice's segment starts
+    LP_CHK(sidx.upload(std::vector<int64_t>(starts.begin(), starts.begin() + n_seg)));
+    LP_CHK(spos.alloc((size_t)n_seg));
+    LP_CHK(launch_gather_i64(pos.p, sidx.p, n_seg, spos.p, 0));
+    starts_pad.assign((size_t)n_seg + 1, np);
+    LP_CHK(hipMemcpy(starts_pad.data(), spos.p, (size_t)n_seg * 8, hipMemcpyDeviceToHost));
+    // the lattice's time stamps and observation columns
+    if (!on_dev) { LP_CHK(stage(d->obs, (size_t)n * d->n_dim, false, s_obs)); p_obs = s_obs.p; }
+    LP_CHK(times_p.alloc((size_t)np));
+    LP_CHK(obs_p.alloc((size_t)np * d->n_dim));
+    LP_CHK(launch_lattice_scatter(pos.p, p_id, p_times, p_obs, n, d->n_dim, np, delta, times_p.p, obs_p.p, 0));
+    LP_CHK(hipDeviceSynchronize());
     // REPORT(aest_all): row i of the reference holds the state AFTER row i's step, i.e. predicted to the time of row i + 1
-    // (nllk_ctcrw.hpp:246) -- on the lattice that is the row just before row i + 1's (a track's last row: its own)
-    for (int64_t sg = 0; sg < n_seg; sg++)
-        for (int64_t i = starts[sg] + 1; i + 1 < starts[sg + 1]; i++) pos[i] = pos[i + 1] - 1;
-    HIPCHK(h, h->pad_pos.upload(pos));
+    // (nllk_ctcrw.hpp:246) -- on the lattice that is the row just before row i + 1's (lattice_maps_kernel)
+    h->pad_pos.p = rep.p; h->pad_pos.n = rep.n; rep.p = nullptr; rep.n = 0;
     h->n_pad = np; h->pad_step = delta;
+    cleanup();
+#undef LP_CHK
     return SSDE_OK;
 }
 
