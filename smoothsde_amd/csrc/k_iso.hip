@@ -401,8 +401,23 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipSt
 __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, const ReduceArgs R, int nstate, int n_check) {
     __shared__ double sh[256];
     if ((int)blockIdx.x < n_check) {
-        const int G = A.tv.n_groups, nb = ((A.dual && A.n_chunks_d > A.n_chunks) ? A.n_chunks_d : A.n_chunks) - 1;
-        const int g = blockIdx.x % G, c = (blockIdx.x / G) % nb, part = blockIdx.x / (G * nb);
+        const int G = A.tv.n_groups;
+        int g, c, part = 0;
+        if (A.dual) {
+            // two plans (n_parts == 1): every group's boundaries under the shared launch's plan first -- the general launch's groups
+            // have none there and leave --, then the general launch's groups under theirs, through the list of those groups
+            const int nA = G * (A.n_chunks - 1);
+            if ((int)blockIdx.x < nA) {
+                g = blockIdx.x % G; c = blockIdx.x / G;
+                if (!(A.group_flags[g] & 1)) return;
+            } else {
+                const int k = blockIdx.x - nA;
+                g = A.dirty_groups[k % A.n_dirty_groups]; c = k / A.n_dirty_groups;
+            }
+        } else {
+            const int nb = A.n_chunks - 1;
+            g = blockIdx.x % G; c = (blockIdx.x / G) % nb; part = blockIdx.x / (G * nb);
+        }
         const double w = window_check_block(A, nstate, g, c, part, sh);
         if (threadIdx.x == 0 && w > 0.0)
             atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
@@ -412,8 +427,8 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
 }
 
 hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {
-    const int ncm = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;
-    const int n_check = ncm > 1 ? a.tv.n_groups * (ncm - 1) * a.n_parts : 0;
+    const int n_check = a.dual ? a.tv.n_groups * (a.n_chunks - 1) + a.n_dirty_groups * (a.n_chunks_d - 1)
+                               : (a.n_chunks > 1 ? a.tv.n_groups * (a.n_chunks - 1) * a.n_parts : 0);
     hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, r, iso_nstate(model, d), n_check);
     return hipGetLastError();
 }

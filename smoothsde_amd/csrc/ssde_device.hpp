@@ -88,6 +88,8 @@ struct IsoArgs {
     // finalize launch, which checks the hand-overs of both, reads the general launch's plan here (dual != 0).
     int dual;
     int n_chunks_d, window_d, t0_d, t0_delta_d;
+    const int32_t* dirty_groups; // [n_dirty_groups] the groups of the general launch (dual != 0: their hand-over checks are enumerated through it)
+    int n_dirty_groups;
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;

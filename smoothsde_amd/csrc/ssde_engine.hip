@@ -33,7 +33,7 @@ void destroy(ssde_handle* h) {
                 h->trace_us[0] / h->trace_n, h->trace_us[1] / h->trace_n, h->trace_us[2] / h->trace_n, h->trace_us[3] / h->trace_n,
                 h->trace_us[4] / h->trace_n);
     destroy_dist(h);
-    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release();
+    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release(); h->dirty_groups.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -664,6 +664,13 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             choose_iso_split(h);
             // shared-covariance path: regular grid + groups without missing rows
             HIPCHK(h, h->group_flags.upload(gflags));
+            {
+                std::vector<int32_t> dl;
+                for (int g = 0; g < G; g++)
+                    if (!gflags[g]) dl.push_back(g);
+                h->n_dirty_groups = (int)dl.size();
+                if (!dl.empty()) HIPCHK(h, h->dirty_groups.upload(dl));
+            }
             std::vector<int64_t> cnt;
             for (int g = 0; g < G; g++) {
                 if (!gflags[g]) continue;
@@ -1096,6 +1103,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                     const int t0 = (int)(L0 / WIN_ALIGN) * WIN_ALIGN;
                     if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) ad.t0 = t0;
                     a.dual = 1; a.n_chunks_d = ad.n_chunks; a.window_d = ad.window; a.t0_d = ad.t0; a.t0_delta_d = ad.t0_delta;
+                    a.dirty_groups = h->dirty_groups.p; a.n_dirty_groups = h->n_dirty_groups;
                     // the final sums run over the longer of the two plans: the slots the shorter one does not write must be zero
                     HIPCHK(h, hipMemsetAsync(h->partials.p, 0, (size_t)std::max(a.n_chunks, ad.n_chunks) * (4 + h->d) * h->n_groups * 8, s));
                 }

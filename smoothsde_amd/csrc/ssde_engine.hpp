@@ -139,6 +139,8 @@ struct ssde_handle {
 
     // shared-covariance path
     DevBuf<int32_t> group_flags;
+    DevBuf<int32_t> dirty_groups;   // the groups that hold a track with a missing row (mixed batch: the general launch's)
+    int n_dirty_groups = 0;
     int n_clean_groups = 0;
     bool use_shared = false;
     // one-row tracks never reach a kernel; REPORT(aest_all) still shows their a0 (nllk_ctcrw.hpp:196-200, 246)
