@@ -370,7 +370,7 @@ int iso_nstate(int model, int d) { return model == M_CTCRW ? 4 * (2 * d + 3) + 2
 // (launch_iso_shared, issued by the engine on its side streams) own the NaN-free groups and this
 // launch runs the general kernel on the others (only when `any_dirty`)
 hipError_t launch_iso(int model, int d, const IsoArgs& a0, bool any_dirty, hipStream_t s) {
-    const int g8 = (a0.tv.n_groups + 7) / 8;
+    const int g8 = ((a0.use_group_list ? a0.n_dirty_groups : a0.tv.n_groups) + 7) / 8;
     dim3 grid((g8 * 8 * a0.n_parts * a0.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
     bool done = false;

@@ -90,6 +90,7 @@ struct IsoArgs {
     int n_chunks_d, window_d, t0_d, t0_delta_d;
     const int32_t* dirty_groups; // [n_dirty_groups] the groups of the general launch (dual != 0: their hand-over checks are enumerated through it)
     int n_dirty_groups;
+    int use_group_list;          // this launch's grid enumerates dirty_groups[] instead of every group (the general launch of a mixed batch)
     int n_parts;
     int part_mask[MAX_PARTS];    // DIR_* bits handled by each part
     int any_nan;
@@ -394,6 +395,11 @@ __device__ __forceinline__ bool decode_block(const IsoArgs& A, int nc, int& g, i
     part = hi % np;
     chunk = (hi / np) % nc;
     g = (hi / (np * nc)) * 8 + (id & 7);
+    if (A.use_group_list) {
+        if (g >= A.n_dirty_groups) return false;
+        g = A.dirty_groups[g];
+        return true;
+    }
     return g < A.tv.n_groups;
 }
 

@@ -1104,6 +1104,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                     if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) ad.t0 = t0;
                     a.dual = 1; a.n_chunks_d = ad.n_chunks; a.window_d = ad.window; a.t0_d = ad.t0; a.t0_delta_d = ad.t0_delta;
                     a.dirty_groups = h->dirty_groups.p; a.n_dirty_groups = h->n_dirty_groups;
+                    ad.dirty_groups = h->dirty_groups.p; ad.n_dirty_groups = h->n_dirty_groups; ad.use_group_list = 1;
                     // the final sums run over the longer of the two plans: the slots the shorter one does not write must be zero
                     HIPCHK(h, hipMemsetAsync(h->partials.p, 0, (size_t)std::max(a.n_chunks, ad.n_chunks) * (4 + h->d) * h->n_groups * 8, s));
                 }
