@@ -241,15 +241,47 @@ def main():
     eng = capi.Engine(pb)
     del ID, times, obs
     npar = pb.n_par_full
+    host_reduce = None                                    # set only if RCCL could not be brought up (see below)
     if use_comm:
-        box = [capi.comm_unique_id() if rank == 0 else None]
+        # ncclCommInitRank: the engines of all ranks, one communicator.  If RCCL cannot be brought up on this node (an
+        # exception on ANY rank -- agreed on over the gloo group), the run still produces a line, with the sum over ranks
+        # done by the host over gloo after every evaluation and SAID SO in config.parallelism: a slower collective, the same
+        # per-rank engine.  (The engine itself has no such fallback: ssde_comm_init_rank fails loudly.)
+        err = ""
+        try:
+            if os.environ.get("SSDE_BENCH_FAKE_RCCL_FAILURE"):        # rehearsal of the fallback on a one-GPU box
+                raise RuntimeError("faked for a rehearsal")
+            box = [capi.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                            # rank 0 could not even make an id
+            box, err = [None], f"ssde_comm_unique_id: {e}"
         dist.broadcast_object_list(box, src=0)
-        eng.comm_init(world, rank, box[0])                # ncclCommInitRank: the engines of all ranks, one communicator
+        if box[0] is not None:
+            try:
+                eng.comm_init(world, rank, box[0])
+            except Exception as e:
+                err = f"ssde_comm_init_rank: {e}"
+        else:
+            err = err or "no communicator id from rank 0"
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            if not err:                                   # this rank joined a communicator the others did not: start over without one
+                eng.close()
+                eng = capi.Engine(pb)
+            host_reduce = err or "RCCL initialisation failed on another rank"
+            print(f"[bench rank {rank}] RCCL not available ({host_reduce}); summing over ranks on the host (gloo)", file=sys.stderr, flush=True)
 
     thetas = {k: np.ascontiguousarray(theta_for(npar, d, q, k)) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
 
+    def reduce_on_host(val, grad):                        # the fallback collective: [value, gradient] summed over ranks by gloo
+        buf = torch.from_numpy(np.concatenate([[val], grad]))
+        dist.all_reduce(buf)
+        return float(buf[0]), buf[1:].numpy()
+
     for k in range(args.warmup):
-        eng.eval(thetas[-1 - k], order=1)
+        v_, g_ = eng.eval(thetas[-1 - k], order=1)
+        if host_reduce:
+            reduce_on_host(v_, g_)
     if use_comm:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -261,6 +293,8 @@ def main():
     # longer runs) instead of paying an event query + a ctypes call between the steps.
     for k in range(args.steps):
         val, grad = ssde_eval(thetas[k])                  # ssde_eval: kernels, check, reduction, all-reduce, D2H
+        if host_reduce:
+            val, grad = reduce_on_host(val, grad)
         if (k + 1) % 64 == 0 and k + 1 < args.steps:
             main_ms.extend(eng.kernel_ms_history(64)[::-1])
     torch.cuda.synchronize(dev)
@@ -334,7 +368,9 @@ def main():
                    "rows_tiled": info["n_rows_tiled"], "groups": info["n_groups"], "clean_groups": info["n_clean_groups"],
                    "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
                    "window_check": check_max, "window_retries": info["window_retries"],
-                   "parallelism": f"tracks x{world}" + (", in-engine ncclAllReduce of 2+p doubles" if use_comm else ""),
+                   "parallelism": f"tracks x{world}" + ("" if not use_comm else
+                                                         (", in-engine ncclAllReduce of 2+p doubles" if not host_reduce else
+                                                          f", HOST all-reduce over gloo after every evaluation (RCCL could not be brought up: {host_reduce})")),
                    "api": "ssde_eval (synchronous C ABI call)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": profiled,
