@@ -28,7 +28,10 @@ def _tracks(rng, model, d, lengths, irregular=True, scale=1.0):
     ID, times, obs = [], [], []
     t0 = 0.0
     for k, T in enumerate(lengths):
-        dts = rng.uniform(0.3, 2.0, size=T) if irregular else np.ones(T)
+        if isinstance(irregular, str) and irregular == "lattice":    # a schedule of 0.5 with fixes absent (runs of 1-2)
+            dts = 0.5 * rng.choice([1, 1, 1, 1, 2, 3], size=T)
+        else:
+            dts = rng.uniform(0.3, 2.0, size=T) if irregular else np.ones(T)
         tt = t0 + np.cumsum(dts)
         t0 = tt[-1] + 5.0
         steps = rng.standard_normal((T, d)) * scale
@@ -247,4 +250,8 @@ def all_specs():
     specs.append(make_spec("BM_SSM_d5_const", "BM_SSM", 5, seed=234, lengths=[10, 7, 9]))
     specs.append(make_spec("OU_d3_tv2", "OU", 3, seed=235, lengths=[16, 11], variant="tv2", na_rows=(5,)))
     specs.append(make_spec("BM_d4_const", "BM", 4, seed=236, lengths=[9, 2, 14, 6], na_rows=(3, 12)))
+    # a regular schedule with fixes absent from the data: intervals of 1-3 steps (laid out on the lattice by the engine)
+    specs.append(make_spec("CTCRW_d2_lattice", "CTCRW", 2, seed=241, lengths=[19, 3, 24, 12], irregular="lattice", na_rows=(5, 30)))
+    specs.append(make_spec("OU_SSM_d1_lattice_fixmu", "OU_SSM", 1, seed=242, lengths=[22, 15], irregular="lattice", fix_mu=True))
+    specs.append(make_spec("BM_SSM_d3_lattice", "BM_SSM", 3, seed=243, lengths=[14, 18, 9], irregular="lattice", na_rows=(7,), na_mode=0))
     return specs
