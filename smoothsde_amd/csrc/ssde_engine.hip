@@ -685,6 +685,9 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             for (size_t ns = 1; ns < cnt.size(); ns++)
                 if (cnt[ns]) h->clean_ns_hist.push_back({(int)ns, cnt[ns]});
             h->use_shared = h->uniform_dt && h->n_clean_groups > 0 && h->iso_parts == 1 && !getenv("SSDE_NO_SHARED");
+            // (two concurrent launches, a fork / join and a longer finalize cost ~40 us: with fewer than a quarter of the groups on
+            //  the shared kernel that is more than it wins -- measured 0.82 against 0.78 ms at one tenth -- and everything stays general)
+            if (h->use_shared && h->n_clean_groups < G && 4 * h->n_clean_groups < G && !getenv("SSDE_SHARED_ALWAYS")) h->use_shared = false;
             // time windows: enough (group, window, part) workgroups for ~2 waves on each of the 1024 SIMDs
             int glmax = 0;
             for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
@@ -695,7 +698,10 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
             // ... except for the scalar-covariance models on the general kernel (irregular grid or missing rows in
             // most groups): too few independent chains per row for one wave, so two waves per SIMD (k_iso.hip)
             // (k_iso.hip: every general kernel but CTCRW's irregular-grid one is built for two waves per SIMD)
-            if (!(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || 2 * h->n_clean_groups < G) && !getenv("SSDE_NO_LIGHT2"))
+            // (a mixed batch whose general launch gets a plan of its own, below, keeps the shared kernel's plan here whatever the
+            //  share of its groups)
+            const bool own_plans = h->use_shared && h->n_clean_groups < G && !getenv("SSDE_CHUNKS") && !getenv("SSDE_ONE_PLAN");
+            if (!(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || (2 * h->n_clean_groups < G && !own_plans)) && !getenv("SSDE_NO_LIGHT2"))
                 // measured (tools/bench_na.py, SSDE_CHUNKS sweep 12 .. 32): the scalar-covariance models run best with
                 // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
                 // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
