@@ -205,6 +205,7 @@ struct ssde_handle {
     DevBuf<double> tv_par_dev;
     double* tv_par_pinned = nullptr;
     double* tv_out_pinned = nullptr;
+    DevBuf<double> lap_out;                   // ssde_laplace_eval: result vectors of a batch of asynchronous evaluations
     double* out_pinned = nullptr;             // read-back target of the synchronous ssde_eval (2 + n_full doubles)
 
     int64_t hbm_bytes = 0;
