@@ -104,8 +104,9 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
             if(laplace) {
                 if(!is.null(last$u)) full[is_u] <- last$u                          # warm start of the inner Newton solve
                 last$res <- .Call("ssdeR_laplace", ptr, full, 1L, PACKAGE = "smoothSDE")
-                last$u <- last$res$par[is_u]
-                env$last.par <- c(x, last$u)                                       # TMB's env$last.par: fixed, then random
+                # (a rejected probe -- value +Inf -- leaves the engine's coeff_re untouched; keep the last accepted u as the warm start)
+                if(is.finite(last$res$value)) last$u <- last$res$par[is_u]
+                env$last.par <- c(x, if(is.null(last$u)) full[is_u] else last$u)   # TMB's env$last.par: fixed, then random
                 if(is.null(env$value.best) || last$res$value < env$value.best) {
                     env$value.best <- last$res$value; env$last.par.best <- env$last.par
                 }

@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- track-timesteps/s of one nllk + gradient evaluation (BASELINE.json metric).
 
-A "step" is one synchronous evaluation of the hot path through the C ABI (ssde_eval, order 1: value + full
-gradient, the hand-over check of the time windows, the reduction, at N > 1 the in-engine ncclAllReduce of the
-2 + p doubles over xGMI, and the D2H of the result) over one resident batch of synthetic tracks, each step at a
-different parameter vector (the engine memoises the last one).  Workload at every N: 10^4 two-dimensional CTCRW
-tracks x 10^4 rows PER GPU (constant coefficients, sigma_obs free, mu fixed as in the vignette) -- weak scaling:
-tracks shard over ranks with no data-path collective other than that all-reduce.
+A "step" is one evaluation of the hot path through the C ABI (order 1: value + full gradient, the hand-over check of the
+time windows, the reduction, at N > 1 the in-engine ncclAllReduce of the 2 + p doubles over xGMI, and the result on the
+host) over one resident batch of synthetic tracks, each step at a different parameter vector (the engine memoises the
+last one).  Workloads (`--config`):
+
+    c2p (default)  BASELINE's metric configuration, SURVEY 8(d) C2': 10^4 two-dimensional CTCRW tracks x 10^4 rows,
+                   constant coefficients, sigma_obs / tau / nu free, mu fixed as in the vignette; synchronous ssde_eval
+    c4             BASELINE config 4: 10^5 such tracks x 10^4 rows
+    c5             BASELINE config 5: three sub-batches (BM_SSM, OU_SSM, CTCRW; 3 10^4 tracks each, ragged lengths
+                   U[0.5 T, T], T = 10^4, 5 % of the rows missing -- half in column 0 only, half in every column),
+                   one handle per model with its own parameter vector and its own communicator, the three
+                   evaluated CONCURRENTLY (ssde_eval_device on three streams); throughput = all rows / wall time
+
+`--scaling strong` (the default: the metric names ONE batch "on 1/2/4/8 GPUs") cuts the batch into whole-track shards,
+rank r of N owning tracks [r M / N, (r + 1) M / N) -- the same batch at every N, because the simulator's numbers are a
+function of (seed, global track index, row) and of nothing else (ssde_simulate, csrc/k_sim.hip); `--scaling weak` gives
+every rank the whole configuration's track count (N times the work at N ranks).
 
     python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU; the ranks' engines are joined by ssde_comm_init_rank (the ncclUniqueId travels over a gloo
-group, which also carries the barriers and the max-over-ranks of the elapsed time: torch.distributed is plumbing
-here, the collective of the data path is the engine's own).  Prints ONE JSON line on rank 0.
-"""
+One process per GPU; the ranks' engines are joined by ssde_comm_init_rank (the ncclUniqueId travels over a gloo group,
+which also carries the barriers and the max-over-ranks of the elapsed time: torch.distributed is plumbing here, the
+collective of the data path is the engine's own).  Prints ONE JSON line on rank 0.
+
+Timing: the K timed steps run with plain kernel launches (ssde_set_option(SSDE_OPT_KERNEL_STAMPS, 0): what a fitting
+host runs); the dominant kernel's duration comes from a second, untimed pass over the SAME K parameter vectors with
+every launch stamped by HIP events on its own stream (`roofline.kernel_ms`; `ms_per_step_stamped` is that pass's wall
+time per step, for comparison)."""
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -30,6 +46,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+CONFIGS = {
+    "c2p": {"tracks": 10_000, "rows": 10_000, "label": "SURVEY 8(d) C2' (BASELINE metric)"},
+    "c4": {"tracks": 100_000, "rows": 10_000, "label": "SURVEY 8(d) C4 (BASELINE config 4)"},
+    "c5": {"tracks": 30_000, "rows": 10_000, "label": "SURVEY 8(d) C5 (BASELINE config 5)"},
+}
+C5_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
 
 
 def _usable_cores():
@@ -148,16 +171,140 @@ def theta_for(npar, d, q, k):
     return base + 0.01 * np.sin(np.arange(npar) + 0.7 * k)
 
 
+def shard_range(M, world, rank, scaling):
+    """Tracks [m0, m1) of the batch this rank owns.  strong: the M tracks of the configuration cut into whole-track
+    shards; weak: every rank M tracks of an N M-track batch."""
+    if scaling == "weak":
+        return rank * M, (rank + 1) * M
+    return rank * M // world, (rank + 1) * M // world
+
+
+def track_lengths(M_total, T, seed):
+    """C5: ragged lengths U[0.5 T, T] of EVERY track of the batch (a function of the seed only: any rank can slice it)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(T // 2, T + 1, size=M_total, dtype=np.int64)
+
+
+def missing_rows(obs, row_offset, first_rows, frac=0.05):
+    """C5: `frac` of the rows missing, half of them in column 0 only and half in every column (the reference tests
+    column 0: nllk_ctcrw.hpp:214); a track's first row stays observed (it initialises the state).  Which rows is a
+    hash of the GLOBAL row index, so the batch does not depend on how it is cut over ranks."""
+    import torch
+    n = obs.shape[0]
+    P = 2147483647
+    g = (torch.arange(n, device=obs.device, dtype=torch.int64) + int(row_offset)) % P
+    x = (g * 48271 + 11) % P
+    x = (x * 69621 + (g // 7) % P) % P
+    x = (x * 16807 + 12345) % P
+    u = x.to(torch.float64) / float(P)
+    col0 = u < 0.5 * frac
+    allc = (u >= 0.5 * frac) & (u < frac)
+    col0[first_rows] = False
+    allc[first_rows] = False
+    obs[col0, 0] = float("nan")
+    obs[allc, :] = float("nan")
+    return int(col0.sum() + allc.sum())
+
+
+class Handle:
+    """One engine of the workload on this rank, with its parameter vectors and its result buffer."""
+
+    def __init__(self, name, model, eng, pb, d, rows_local, rows_total, k_lo, k_hi):
+        from smoothsde_amd import capi
+        self.name, self.model, self.eng, self.pb, self.d = name, model, eng, pb, d
+        self.q = capi.n_sde_par(model, d)
+        self.npar = pb.n_par_full
+        self.rows_local, self.rows_total = rows_local, rows_total
+        self.thetas = {k: np.ascontiguousarray(theta_for(self.npar, d, self.q, k)) for k in range(k_lo, k_hi)}
+        self.ptrs = {k: v.ctypes.data_as(C.POINTER(C.c_double)) for k, v in self.thetas.items()}
+        self.kernel_ms = None
+        self.out = None
+        self.stream = None
+
+
+def build_handles(args, dev, rank, world):
+    """The configuration's engines on this rank (data simulated in HBM by the engine's own simulator kernel)."""
+    import torch
+    from smoothsde_amd import capi
+    cfg = args.config
+    M, T, d = args.tracks, args.rows, 2
+    k_lo, k_hi = -args.warmup - 1, args.steps
+    handles = []
+    if cfg in ("c2p", "c4"):
+        model = args.model
+        m0, m1 = shard_range(M, world, rank, args.scaling)
+        M_total = M * world if args.scaling == "weak" else M
+        # SURVEY.md 8(d) C2' / C4: tau=2, nu=1, mu=0, sigma_obs=0.1, dt=1, time increasing over the whole batch
+        ID, times, obs = capi.simulate_device(model, m1 - m0, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0,
+                                              sigma_obs=0.1, seed=args.seed, track0=m0, device=dev)
+        q = capi.n_sde_par(model, d)
+        fixed = np.zeros(1 + q, dtype=np.uint8)
+        fixed[1:1 + d] = 1  # fixpar = c("mu1","mu2") as in the vignette (smoothSDE.rmd:486-490)
+        pb = capi.Problem.from_torch(model, ID, times, obs, par_fixed=fixed)
+        eng = capi.Engine(pb)
+        del ID, times, obs
+        handles.append(Handle(model, model, eng, pb, d, (m1 - m0) * T, M_total * T, k_lo, k_hi))
+    else:
+        for i, model in enumerate(C5_MODELS):
+            M_total = M * world if args.scaling == "weak" else M
+            m0, m1 = shard_range(M, world, rank, args.scaling)
+            lens = track_lengths(M_total, T, args.seed + 100 * (i + 1))
+            row0_all = np.concatenate([[0], np.cumsum(lens)])
+            # BM_SSM (mu = 0.1, sigma = 1), OU_SSM (mu = (5, -5), tau = 2, kappa = 1: smoothSDE.rmd:346-350), CTCRW as C2
+            kw = {"BM_SSM": dict(mu=0.1, sigma=1.0), "OU_SSM": dict(mu=[5.0, -5.0], tau=2.0, kappa=1.0, z0=[5.0, -5.0]),
+                  "CTCRW": dict(mu=0.0, tau=2.0, nu=1.0)}[model]
+            ID, times, obs = capi.simulate_device(model, m1 - m0, T, d, sigma_obs=0.1, seed=args.seed + 100 * (i + 1), track0=m0,
+                                                  lengths=lens[m0:m1], row_offset=int(row0_all[m0]), device=dev, **kw)
+            first = torch.as_tensor(row0_all[m0:m1] - row0_all[m0], device=dev)
+            missing_rows(obs, int(row0_all[m0]), first)
+            pb = capi.Problem.from_torch(model, ID, times, obs)              # every parameter free (the full Kalman update path)
+            eng = capi.Engine(pb)
+            del ID, times, obs
+            handles.append(Handle(model, model, eng, pb, d, int(row0_all[m1] - row0_all[m0]), int(row0_all[-1]), k_lo, k_hi))
+    return handles
+
+
+def join_ranks(handles, rank, world, dist):
+    """ncclCommInitRank: the engines of all ranks, one communicator per handle.  If RCCL cannot be brought up on this
+    node (an exception on ANY rank -- agreed on over the gloo group), the run still produces a line, with the sum over
+    ranks done by the host over gloo after every evaluation and SAID SO in config.parallelism: a slower collective, the
+    same per-rank engine.  (The engine itself has no such fallback: ssde_comm_init_rank fails loudly.)"""
+    import torch
+    from smoothsde_amd import capi
+    err = ""
+    for h in handles:
+        try:
+            if os.environ.get("SSDE_BENCH_FAKE_RCCL_FAILURE"):        # rehearsal of the fallback on a one-GPU box
+                raise RuntimeError("faked for a rehearsal")
+            box = [capi.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                            # rank 0 could not even make an id
+            box, err = [None], f"ssde_comm_unique_id: {e}"
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is not None and not err:
+            try:
+                h.eng.comm_init(world, rank, box[0])
+            except Exception as e:
+                err = f"ssde_comm_init_rank: {e}"
+        else:
+            err = err or "no communicator id from rank 0"
+    flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if flag.item() > 0:
+        for h in handles:                                 # some engine joined a communicator others did not: start over without
+            h.eng.close()
+            h.eng = capi.Engine(h.pb)
+        return err or "RCCL initialisation failed on another rank"
+    return None
+
+
 def secondary_workload(name, model, M, T, dev, steps, mutate):
     """The same batch shape with what real data have -- an irregular time grid, missing rows -- so that the driver's
     run times the general per-lane kernel too (BASELINE's metric configuration is the engine's best case)."""
     import torch
     from smoothsde_amd import capi
-    from smoothsde_amd.synth import simulate
     d = 2
-    ID, times, obs = simulate(model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=11,
-                              backend="torch", device=dev)
-    ID, times, obs = mutate(ID, times, obs)
+    ID, times, obs = capi.simulate_device(model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=11, device=dev)
+    ID, times, obs = mutate(ID, times, obs.contiguous())
     q = capi.n_sde_par(model, d)
     fixed = np.zeros(1 + q, dtype=np.uint8)
     fixed[1:1 + d] = 1
@@ -193,12 +340,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tracks", type=int, default=10_000, help="tracks per GPU")
-    ap.add_argument("--rows", type=int, default=10_000, help="rows per track")
-    ap.add_argument("--model", default="CTCRW")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2p")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: the configuration's batch split over the ranks; weak: that many tracks PER rank")
+    ap.add_argument("--tracks", type=int, default=None, help="tracks of the batch (c5: per sub-batch); default: the configuration's")
+    ap.add_argument("--rows", type=int, default=None, help="rows per track (c5: of the longest track)")
+    ap.add_argument("--model", default="CTCRW", help="c2p / c4 only")
+    ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the irregular-grid / missing-row workloads")
     args = ap.parse_args()
+    args.tracks = args.tracks or CONFIGS[args.config]["tracks"]
+    args.rows = args.rows or CONFIGS[args.config]["rows"]
 
     # (SSDE_BENCH_SELF_LAUNCH / SSDE_BENCH_FORCE_COMM: rehearse the N > 1 plumbing -- own launcher, gloo group,
     # ncclCommInitRank, the all-reduce inside ssde_eval -- with ONE rank on a one-GPU box)
@@ -228,123 +381,164 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)     # plumbing: id exchange, barriers, max of the clock
 
     from smoothsde_amd import capi
-    from smoothsde_amd.synth import simulate
 
-    M, T, d = args.tracks, args.rows, 2
-    # synthetic batch built directly in HBM (SURVEY.md 8(d) C2': tau=2, nu=1, mu=0, sigma_obs=0.1, dt=1)
-    ID, times, obs = simulate(args.model, M, T, d, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1,
-                              seed=1 + rank, backend="torch", device=dev)
-    q = capi.n_sde_par(args.model, d)
-    fixed = np.zeros(1 + q, dtype=np.uint8)
-    fixed[1:1 + d] = 1  # fixpar = c("mu1","mu2") as in the vignette (smoothSDE.rmd:486-490)
-    pb = capi.Problem.from_torch(args.model, ID, times, obs, par_fixed=fixed)
-    eng = capi.Engine(pb)
-    del ID, times, obs
-    npar = pb.n_par_full
-    host_reduce = None                                    # set only if RCCL could not be brought up (see below)
-    if use_comm:
-        # ncclCommInitRank: the engines of all ranks, one communicator.  If RCCL cannot be brought up on this node (an
-        # exception on ANY rank -- agreed on over the gloo group), the run still produces a line, with the sum over ranks
-        # done by the host over gloo after every evaluation and SAID SO in config.parallelism: a slower collective, the same
-        # per-rank engine.  (The engine itself has no such fallback: ssde_comm_init_rank fails loudly.)
-        err = ""
-        try:
-            if os.environ.get("SSDE_BENCH_FAKE_RCCL_FAILURE"):        # rehearsal of the fallback on a one-GPU box
-                raise RuntimeError("faked for a rehearsal")
-            box = [capi.comm_unique_id() if rank == 0 else None]
-        except Exception as e:                            # rank 0 could not even make an id
-            box, err = [None], f"ssde_comm_unique_id: {e}"
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is not None:
-            try:
-                eng.comm_init(world, rank, box[0])
-            except Exception as e:
-                err = f"ssde_comm_init_rank: {e}"
-        else:
-            err = err or "no communicator id from rank 0"
-        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if flag.item() > 0:
-            if not err:                                   # this rank joined a communicator the others did not: start over without one
-                eng.close()
-                eng = capi.Engine(pb)
-            host_reduce = err or "RCCL initialisation failed on another rank"
-            print(f"[bench rank {rank}] RCCL not available ({host_reduce}); summing over ranks on the host (gloo)", file=sys.stderr, flush=True)
-
-    thetas = {k: np.ascontiguousarray(theta_for(npar, d, q, k)) for k in range(-args.warmup - 1, args.steps)}   # built outside the timed region
+    handles = build_handles(args, dev, rank, world)
+    host_reduce = join_ranks(handles, rank, world, dist) if use_comm else None
+    if host_reduce:
+        print(f"[bench rank {rank}] RCCL not available ({host_reduce}); summing over ranks on the host (gloo)", file=sys.stderr, flush=True)
+    concurrent = len(handles) > 1
+    npmax = max(h.npar for h in handles)
+    outs = torch.zeros(len(handles), 2 + npmax, dtype=torch.float64, device=dev)
+    for i, h in enumerate(handles):
+        h.out = outs[i]
+        h.stream = torch.cuda.Stream(dev) if concurrent else torch.cuda.current_stream(dev)
+        h.eng.set_option(capi.OPT_KERNEL_STAMPS, 0)       # the timed steps: plain launches
 
     def reduce_on_host(val, grad):                        # the fallback collective: [value, gradient] summed over ranks by gloo
         buf = torch.from_numpy(np.concatenate([[val], grad]))
         dist.all_reduce(buf)
         return float(buf[0]), buf[1:].numpy()
 
+    last = {}
+
+    if not concurrent:
+        h0 = handles[0]
+        f, hp, n = h0.eng.lib.ssde_eval, h0.eng._h, h0.npar
+        val_c = C.c_double()
+        grad = np.zeros(n)
+        gp, vp = grad.ctypes.data_as(C.POINTER(C.c_double)), C.byref(val_c)
+
+        def step(k):                                      # ssde_eval: kernels, check, reduction, all-reduce, result on the host
+            st = f(hp, h0.ptrs[k], n, 1, vp, gp)
+            if st != 0:
+                h0.eng._check(st)
+            if host_reduce:
+                last["val"], last["grad"] = reduce_on_host(val_c.value, grad)
+            else:
+                last["val"], last["grad"] = val_c.value, grad
+    else:
+        def step(k):                                      # the three handles side by side, each on its own stream
+            for h in handles:
+                h.eng.eval_device(h.thetas[k], h.out.data_ptr(), order=1, stream=h.stream.cuda_stream)
+            for h in handles:
+                h.stream.synchronize()
+            host = outs.cpu().numpy()
+            for i, h in enumerate(handles):
+                if not host[i, 1 + h.npar] <= capi.WINDOW_TOL:     # (rare) a hand-over check failed: widen and repeat this handle
+                    for _ in range(4):
+                        h.eng.widen_windows(4)
+                        h.eng.eval_device(h.thetas[k], h.out.data_ptr(), order=1, stream=h.stream.cuda_stream)
+                        h.stream.synchronize()
+                        host[i] = h.out.cpu().numpy()
+                        if host[i, 1 + h.npar] <= capi.WINDOW_TOL:
+                            break
+            if host_reduce:
+                t = torch.from_numpy(host[:, :1 + npmax].copy())
+                dist.all_reduce(t)
+                host[:, :1 + npmax] = t.numpy()
+            last["val"] = float(sum(host[i, 0] for i in range(len(handles))))
+            last["grad"] = np.concatenate([host[i, 1:1 + h.npar] for i, h in enumerate(handles)])
+            last["check"] = float(max(host[i, 1 + h.npar] for i, h in enumerate(handles)))
+
     for k in range(args.warmup):
-        v_, g_ = eng.eval(thetas[-1 - k], order=1)
-        if host_reduce:
-            reduce_on_host(v_, g_)
+        step(-1 - k)
     if use_comm:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    main_ms = []
-    ssde_eval = eng.bound_eval(order=1)                   # the C ABI call itself (preallocated outputs, no per-call conversions)
-    # Every evaluation stamps its dominant kernel with HIP events of its own, on the stream it is launched on; the engine
-    # keeps the last 64 pairs, so the durations of the timed steps are read AFTER the timed region (in batches of 64 for
-    # longer runs) instead of paying an event query + a ctypes call between the steps.
     for k in range(args.steps):
-        val, grad = ssde_eval(thetas[k])                  # ssde_eval: kernels, check, reduction, all-reduce, D2H
-        if host_reduce:
-            val, grad = reduce_on_host(val, grad)
-        if (k + 1) % 64 == 0 and k + 1 < args.steps:
-            main_ms.extend(eng.kernel_ms_history(64)[::-1])
+        step(k)
     torch.cuda.synchronize(dev)
     if use_comm:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    main_ms.extend(eng.kernel_ms_history(args.steps - len(main_ms))[::-1])     # the remaining (<= 64) timed steps
-    assert len(main_ms) == args.steps and all(m > 0 for m in main_ms), "a timed step has no kernel stamp"
     if use_comm:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    info = eng.info()
-    check_max = info["window_check_max"]                  # over EVERY evaluation since create, kept by the engine
-    assert np.isfinite(val) and np.all(np.isfinite(grad)), (val, grad)
+    val, grad_last = last["val"], np.array(last["grad"])
+    infos = [h.eng.info() for h in handles]
+    check_max = max([i["window_check_max"] for i in infos] + [last.get("check", 0.0)])   # over EVERY evaluation since create
+    assert np.isfinite(val) and np.all(np.isfinite(grad_last)), (val, grad_last)
     assert check_max <= capi.WINDOW_TOL, f"window hand-over check failed: {check_max}"
-    assert info["n_memo_hits"] == 0, "a timed step was answered from the memo"
+    assert all(i["n_memo_hits"] == 0 for i in infos), "a timed step was answered from the memo"
+
+    # ---- second pass, untimed for `value`: the same K evaluations with every dominant kernel stamped by HIP events on its own
+    # stream; the engine keeps the last 64 pairs, read in batches after the calls
+    for h in handles:
+        h.eng.set_option(capi.OPT_KERNEL_STAMPS, 1)
+        h.eng.forget()                                    # (K = 1: the memo holds that very vector)
+        h.ms = []
+    torch.cuda.synchronize(dev)
+    if use_comm:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)                                           # the same parameter vectors
+        if (k + 1) % 64 == 0 or k + 1 == args.steps:
+            cnt = (k % 64) + 1
+            for h in handles:
+                h.ms.extend(h.eng.kernel_ms_history(cnt)[::-1])
+    torch.cuda.synchronize(dev)
+    stamped_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    if use_comm:
+        dist.barrier()
+    for h in handles:
+        assert len(h.ms) == args.steps and all(m > 0 for m in h.ms), "a stamped step has no kernel stamp"
+        h.kernel_ms = float(np.mean(h.ms))
+    infos = [h.eng.info() for h in handles]
 
     # GPU span of a whole evaluation: the same evaluations again, asynchronously, between HIP events (N = 1 only)
     eval_ms = host_enq_ms = None
-    if not use_comm:
-        out = torch.zeros(2 + npar, dtype=torch.float64, device=dev)
+    if not use_comm and not concurrent:
+        h0 = handles[0]
         stream = torch.cuda.current_stream(dev)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         enq = []
         for k in range(args.steps):
             ev[k][0].record(stream)
             t_h = time.perf_counter()
-            eng.eval_device(thetas[k], out.data_ptr(), order=1, stream=stream.cuda_stream)
+            h0.eng.eval_device(h0.thetas[k], h0.out.data_ptr(), order=1, stream=stream.cuda_stream)
             enq.append(time.perf_counter() - t_h)
             ev[k][1].record(stream)
         torch.cuda.synchronize(dev)
         eval_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         host_enq_ms = 1e3 * float(np.mean(enq))
 
-    rows_per_gpu = info["n_rows"]
-    total_rows = rows_per_gpu * world
+    rows_rank = sum(h.rows_local for h in handles)
+    rows_t = torch.tensor([float(rows_rank)], dtype=torch.float64)
+    if use_comm:
+        dist.all_reduce(rows_t)
+    total_rows = int(rows_t.item())
     value = total_rows * args.steps / elapsed
-    kern_ms = float(np.mean(main_ms))                                   # the dominant kernel alone
-    # Bytes of the rows that launch scores.  `required`: what the resident layout has to read (the `times` stream is
-    # not even stored on a globally regular grid: 16 of the 24 algorithmic B/row) -- the honest numerator of a
-    # fraction of peak.  `algorithmic`: SURVEY 8(d)'s 24 B/row, kept for comparison; it can exceed the peak
-    # precisely because 8 of those bytes are never moved.
-    req_bytes = info["required_bytes_per_row"] * info["main_kernel_rows"]
-    algo_bytes = info["algo_bytes_per_row"] * info["main_kernel_rows"]
-    achieved = req_bytes / (kern_ms * 1e-3) / 1e9
-    achieved_algo = algo_bytes / (kern_ms * 1e-3) / 1e9
+
+    def roof(h, info):
+        # Bytes of the rows that launch scores.  `required`: what the resident layout has to read (the `times` stream is
+        # not even stored on a globally regular grid: 16 of the 24 algorithmic B/row) -- the honest numerator of a
+        # fraction of peak.  `algorithmic`: SURVEY 8(d)'s 24 B/row, kept for comparison; it can exceed the peak
+        # precisely because 8 of those bytes are never moved.
+        req = info["required_bytes_per_row"] * info["main_kernel_rows"]
+        algo = info["algo_bytes_per_row"] * info["main_kernel_rows"]
+        ach = req / (h.kernel_ms * 1e-3) / 1e9
+        ach_a = algo / (h.kernel_ms * 1e-3) / 1e9
+        shared = info["path"] == 1 and info["uniform_dt"] and info["n_clean_groups"] * 4 >= info["n_groups"]
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac_of_measured_copy_6290": ach / 6290.0,       # MI355X_MICROARCH.md: 6.29 TB/s measured copy
+                "required_bytes_per_row": info["required_bytes_per_row"], "algo_bytes_per_row": info["algo_bytes_per_row"],
+                "achieved_algorithmic": ach_a, "frac_algorithmic": ach_a / HBM_PEAK_GBS,
+                "kernel": ("iso_shared_kernel<stationary>" if shared else "iso_mask_kernel") + f" ({h.model})",
+                "kernel_ms": h.kernel_ms, "required_bytes_per_launch": req, "algo_bytes_per_launch": algo,
+                "rows_in_launch": info["main_kernel_rows"], "clean_groups": info["n_clean_groups"], "groups": info["n_groups"],
+                "kernel_ms_source": "untimed second pass over the same parameter vectors, every launch stamped with HIP events on its stream"}
+
+    roofs = [roof(h, i) for h, i in zip(handles, infos)]
+    dom = int(np.argmax([h.kernel_ms for h in handles]))
+    roofline = dict(roofs[dom])
+    if concurrent:
+        roofline["handles"] = roofs
     profiled = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.config == "c2p":
         try:
             pj = json.load(open(pmc))
             profiled = {"main_kernel_bytes": pj.get("main_kernel_bytes"), "evaluation_bytes": pj.get("hbm_bytes_per_launch"),
@@ -353,46 +547,53 @@ def main():
                                 "not measured in this run"}
         except Exception:
             profiled = None
+    roofline["traffic_profiled"] = profiled
+    info0 = infos[dom]
+    roofline["whole_evaluation"] = None if eval_ms is None else {
+        "gpu_ms": eval_ms,
+        "achieved": info0["required_bytes_per_row"] * rows_rank / (eval_ms * 1e-3) / 1e9,
+        "frac": info0["required_bytes_per_row"] * rows_rank / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "host_enqueue_ms": host_enq_ms,
+        "note": "all kernels of one evaluation incl. the hand-over check and the reduction; from an untimed ssde_eval_device "
+                "pass over the same evaluations between HIP events"}
+    M, T = args.tracks, args.rows
+    if args.config == "c5":
+        wl = (f"{CONFIGS['c5']['label']}: BM_SSM + OU_SSM + CTCRW sub-batches of {M} tracks each, ragged lengths U[{T // 2}, {T}], d=2, "
+              f"sigma_obs=0.1, 5 % of the rows missing (column 0 only / every column), every parameter free, three handles evaluated "
+              f"concurrently; {total_rows} rows in total")
+    else:
+        wl = (f"{CONFIGS[args.config]['label']}: {M} {args.model} tracks x {T} rows, d=2, constant coefficients, sigma_obs/tau/nu free, "
+              f"mu fixed, dt=1")
+    wl += (f"; {args.scaling} scaling: " + ("the batch split into whole-track shards over the ranks" if args.scaling == "strong"
+                                             else "that many tracks on EVERY rank"))
     line = {
         "metric": "track-timesteps/s nllk+grad",
         "value": value, "unit": "track-timesteps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_stamped": stamped_ms,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{M} {args.model} tracks x {T} rows per GPU, d=2, constant coefficients, "
-                               f"sigma_obs/tau/nu free, mu fixed, dt=1 (SURVEY 8(d) C2')",
-                   "tracks_per_gpu": M, "rows_per_track": T, "n_free_par": info["n_free"],
-                   "engine_path": capi.PATH_NAMES[info["path"]],
-                   "uniform_dt": info["uniform_dt"], "workgroups": info["n_kernel_blocks"],
-                   "rows_tiled": info["n_rows_tiled"], "groups": info["n_groups"], "clean_groups": info["n_clean_groups"],
-                   "lanes_per_track": info["lanes_per_track"], "window_rows": info["window"],
-                   "window_check": check_max, "window_retries": info["window_retries"],
+        "config": {"workload": wl, "config": args.config, "tracks": M, "rows_per_track": T, "total_rows": total_rows,
+                   "rows_this_rank": rows_rank, "seed": args.seed,
+                   "nllk_at_last_step": val,                # the same number at every N under strong scaling (same batch, same theta)
+                   "n_free_par": [i["n_free"] for i in infos] if concurrent else info0["n_free"],
+                   "engine_path": capi.PATH_NAMES[info0["path"]],
+                   "uniform_dt": info0["uniform_dt"], "workgroups": info0["n_kernel_blocks"],
+                   "rows_tiled": info0["n_rows_tiled"], "groups": info0["n_groups"], "clean_groups": info0["n_clean_groups"],
+                   "lanes_per_track": info0["lanes_per_track"], "window_rows": info0["window"],
+                   "window_check": check_max, "window_retries": sum(i["window_retries"] for i in infos),
                    "parallelism": f"tracks x{world}" + ("" if not use_comm else
-                                                         (", in-engine ncclAllReduce of 2+p doubles" if not host_reduce else
+                                                         (", in-engine ncclAllReduce of 2+p doubles" + (" per handle" if concurrent else "")
+                                                          if not host_reduce else
                                                           f", HOST all-reduce over gloo after every evaluation (RCCL could not be brought up: {host_reduce})")),
-                   "api": "ssde_eval (synchronous C ABI call)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_profiled": profiled,
-                     "frac_of_measured_copy_6290": achieved / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s measured copy
-                     "required_bytes_per_row": info["required_bytes_per_row"],
-                     "algo_bytes_per_row": info["algo_bytes_per_row"],
-                     "achieved_algorithmic": achieved_algo, "frac_algorithmic": achieved_algo / HBM_PEAK_GBS,
-                     "kernel": "iso_shared_kernel<stationary>" if info["uniform_dt"] else "iso_kernel",
-                     "kernel_ms": kern_ms, "required_bytes_per_launch": req_bytes, "algo_bytes_per_launch": algo_bytes,
-                     "rows_in_launch": info["main_kernel_rows"],
-                     "whole_evaluation": None if eval_ms is None else {
-                         "gpu_ms": eval_ms,
-                         "achieved": info["required_bytes_per_row"] * rows_per_gpu / (eval_ms * 1e-3) / 1e9,
-                         "frac": info["required_bytes_per_row"] * rows_per_gpu / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "host_enqueue_ms": host_enq_ms,
-                         "note": "all kernels of one evaluation incl. the concurrent transient-window launch, the "
-                                 "hand-over check and the reduction; from an untimed ssde_eval_device pass over the "
-                                 "same evaluations between HIP events"}},
+                   "api": "ssde_eval_device on one stream per handle + one read-back" if concurrent else "ssde_eval (synchronous C ABI call)",
+                   "data_generator": "ssde_simulate (HIP, Philox4x32-10 keyed by seed / global track / row)"},
+        "roofline": roofline,
     }
-    eng.close()
-    del eng, pb
-    if rank == 0 and world == 1 and not args.no_secondary and args.model == "CTCRW":
+    for h in handles:
+        h.eng.close()
+    del handles
+    if rank == 0 and world == 1 and not args.no_secondary and args.config == "c2p" and args.model == "CTCRW":
         # outside the timed region of `value`: the same batch shape on an irregular grid and with 5 % missing rows
         sec = []
         try:

@@ -33,6 +33,9 @@
  *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
  *   ssde_laplace_eval  <- what `random = "coeff_re"` makes TMB's fn/gr do (R/sde.R:510-525, 656-658): the Laplace
  *                         approximation of the marginal likelihood over the random-effect coefficients
+ *   ssde_simulate      <- SDE$simulate          (R/sde.R:1393-1500; CTCRW_cov, R/utility.R:188-196): exact-transition
+ *                         simulation of a batch of tracks, written straight into HBM in the reference's long format
+ *   ssde_set_option    <- (new) per-handle switches of the measurement hooks
  *   ssde_destroy       <- external-pointer finalizer of the ADFun object
  *   ssde_last_error    <- Rf_error text         (src/smoothSDE.cpp:25)
  *
@@ -66,7 +69,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 7
+#define SSDE_ABI_VERSION 8
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -321,6 +324,47 @@ int ssde_laplace_eval(ssde_handle *h, double *par, int32_t n_par_full, int32_t o
 #define SSDE_COMM_ID_BYTES 128
 int ssde_comm_unique_id(void *id128);
 int ssde_comm_init_rank(ssde_handle *h, int32_t n_ranks, int32_t rank, const void *id128);
+
+/* Per-handle options.
+ *   SSDE_OPT_KERNEL_STAMPS (default 1): every evaluation stamps its dominant kernel with a HIP event pair
+ *       (ssde_last_kernel_ms / ssde_kernel_ms_history).  0 = plain launches: a few microseconds less per evaluation,
+ *       which is what a fitting host wants; measurement passes switch it back on. */
+enum { SSDE_OPT_KERNEL_STAMPS = 1 };
+int ssde_set_option(ssde_handle *h, int32_t option, int64_t value);
+
+/* Synthetic track batches in HBM: the exact-transition simulator of SDE$simulate (R/sde.R:1434-1478: BM increments,
+ * OU transition density, CTCRW joint (velocity, position) transition with CTCRW_cov of R/utility.R:188-196), one
+ * wavefront lane per track, plus N(0, sigma_obs^2) observation error for the state-space families (BM_SSM, OU_SSM,
+ * CTCRW).  Every normal deviate is a pure function of (seed, GLOBAL track index, row, dimension) -- Philox4x32-10
+ * counters + Box-Muller --, so tracks [track0, track0 + n_tracks) of a batch are the same numbers whichever process
+ * generates them: ranks of a multi-GPU run each generate their own shard of ONE batch.
+ *   obs_dev   [n_rows x n_dim] column-major (HBM), the reference's DATA_MATRIX(obs) layout
+ *   id_dev    NULL or [n_rows]: the global track index of every row (as doubles, like TMB's factor codes)
+ *   times_dev NULL or [n_rows]: (row_offset + i + 1) * dt -- increasing over the whole batch (inst/example.R:17)
+ * Rows: track m (local index) owns rows [m * n_steps, (m + 1) * n_steps), or [row0[m], row0[m + 1]) when the HBM
+ * array row0 [n_tracks + 1] is given (ragged tracks; n_steps is then the longest track).  Enqueues on `stream` and
+ * returns; ssde_last_error(NULL) holds the message of a failure. */
+typedef struct ssde_sim_desc {
+    int32_t  abi_version;     /* SSDE_ABI_VERSION */
+    int32_t  model;           /* SSDE_MODEL_BM, _OU, _BM_SSM, _OU_SSM, _CTCRW (R/sde.R:1434-1478; the others: SSDE_ERR_MODEL) */
+    int32_t  n_dim;           /* response columns, 1..8 */
+    int32_t  n_steps;         /* rows per track (the longest track when row0 is given) */
+    int64_t  track0;          /* global index of the first track generated by this call */
+    int64_t  n_tracks;        /* tracks generated by this call */
+    const int64_t *row0;      /* NULL, or HBM [n_tracks + 1] first local row of every track */
+    int64_t  n_rows;          /* rows of the local long format (column stride of obs_dev) */
+    int64_t  row_offset;      /* global index of local row 0 (only `times` uses it) */
+    double   mu[8], z0[8];    /* drift / long-term mean and first value per dimension (simulate's z0, R/sde.R:1388) */
+    double   tau, nu;         /* CTCRW (beta = 1 / tau, sigma = 2 nu / sqrt(pi tau): R/sde.R:1455-1458); OU: tau */
+    double   kappa;           /* OU variance parameter (R/sde.R:1445) */
+    double   sigma;           /* BM diffusion (R/sde.R:1437) */
+    double   sigma_obs;       /* sd of the observation error (state-space families; 0 = none) */
+    double   dt;              /* the regular time step */
+    uint64_t seed;
+    int32_t  device;          /* HIP device ordinal, -1 = current device */
+    int32_t  reserved;
+} ssde_sim_desc;
+int ssde_simulate(const ssde_sim_desc *desc, double *id_dev, double *times_dev, double *obs_dev, void *stream);
 
 void ssde_destroy(ssde_handle *h);
 

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -61,6 +61,18 @@ class SsdeDesc(C.Structure):
 class SsdeLaplaceOpts(C.Structure):
     _fields_ = [("hess_step", C.c_double), ("fd_step", C.c_double), ("newton_tol", C.c_double),
                 ("max_newton", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SsdeSimDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("n_dim", C.c_int32), ("n_steps", C.c_int32),
+                ("track0", C.c_int64), ("n_tracks", C.c_int64), ("row0", C.c_void_p), ("n_rows", C.c_int64),
+                ("row_offset", C.c_int64), ("mu", C.c_double * 8), ("z0", C.c_double * 8),
+                ("tau", C.c_double), ("nu", C.c_double), ("kappa", C.c_double), ("sigma", C.c_double),
+                ("sigma_obs", C.c_double), ("dt", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+OPT_KERNEL_STAMPS = 1
 
 
 class SsdeInfo(C.Structure):
@@ -480,6 +492,10 @@ def load_library():
     lib.ssde_comm_unique_id.restype = C.c_int
     lib.ssde_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.ssde_comm_init_rank.restype = C.c_int
+    lib.ssde_simulate.argtypes = [C.POINTER(SsdeSimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ssde_simulate.restype = C.c_int
+    lib.ssde_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    lib.ssde_set_option.restype = C.c_int
     if lib.ssde_abi_version() != ABI_VERSION:
         raise RuntimeError("libssde_hip.so ABI version mismatch")
     _LIB = lib
@@ -493,7 +509,8 @@ class EngineError(RuntimeError):
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
-                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms", "ssde_kernel_ms_history")
+                    "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms", "ssde_kernel_ms_history",
+                    "ssde_simulate", "ssde_set_option")
 
 COMM_ID_BYTES = 128
 
@@ -508,6 +525,53 @@ def comm_unique_id() -> bytes:
         msg = lib.ssde_last_error(None)
         raise EngineError(f"ssde_comm_unique_id failed ({st}): {msg.decode() if msg else ''}")
     return buf.raw
+
+
+def simulate_device(model: str, n_tracks: int, n_steps: int, n_dim: int = 2, *, mu=0.0, tau=2.0, nu=1.0, kappa=1.0,
+                    sigma=1.0, sigma_obs=0.1, dt: float = 1.0, z0=0.0, seed: int = 1, track0: int = 0, row_offset=None,
+                    lengths=None, device=None, want_id_times: bool = True):
+    """ssde_simulate: tracks [track0, track0 + n_tracks) of the batch `seed` names, generated in HBM by the HIP
+    simulator (exact transitions of R/sde.R:1434-1478 + observation error; counter-based, so a shard of a batch is the
+    same numbers whoever generates it).  Returns torch CUDA tensors (ID, times, obs) with obs of shape (n, d) (a view of
+    the column-major buffer the engine takes as it is).  `lengths`: per-track row counts (ragged batch, <= n_steps).
+    Raises without a GPU: there is no CPU fallback."""
+    import torch
+    lib = load_library()
+    if model not in MODEL_CODES:
+        raise ValueError("Unknown SDE type")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    M, T, d = int(n_tracks), int(n_steps), int(n_dim)
+    row0 = None
+    if lengths is not None:
+        ln = torch.as_tensor(lengths, dtype=torch.int64, device=dev)
+        if ln.numel() != M or int(ln.max()) > T or int(ln.min()) < 1:
+            raise ValueError("lengths: one entry per track, 1 <= length <= n_steps")
+        row0 = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+        row0[1:] = torch.cumsum(ln, 0)
+        n = int(row0[-1])
+    else:
+        n = M * T
+    sd = SsdeSimDesc()
+    sd.abi_version, sd.model, sd.n_dim, sd.n_steps = ABI_VERSION, MODEL_CODES[model], d, T
+    sd.track0, sd.n_tracks, sd.n_rows = int(track0), M, n
+    sd.row0 = None if row0 is None else row0.data_ptr()
+    sd.row_offset = int(track0) * T if row_offset is None else int(row_offset)
+    for k, v in enumerate(np.broadcast_to(np.asarray(mu, dtype=np.float64), (d,))):
+        sd.mu[k] = float(v)
+    for k, v in enumerate(np.broadcast_to(np.asarray(z0, dtype=np.float64), (d,))):
+        sd.z0[k] = float(v)
+    sd.tau, sd.nu, sd.kappa, sd.sigma, sd.sigma_obs, sd.dt = float(tau), float(nu), float(kappa), float(sigma), float(sigma_obs), float(dt)
+    sd.seed, sd.device = int(seed) & 0xFFFFFFFFFFFFFFFF, int(dev.index or 0)
+    obs = torch.empty((d, n), dtype=torch.float64, device=dev)
+    ID = torch.empty(n, dtype=torch.float64, device=dev) if want_id_times else None
+    times = torch.empty(n, dtype=torch.float64, device=dev) if want_id_times else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    st = lib.ssde_simulate(C.byref(sd), None if ID is None else ID.data_ptr(), None if times is None else times.data_ptr(),
+                           obs.data_ptr(), stream)
+    if st != 0:
+        msg = lib.ssde_last_error(None)
+        raise EngineError(f"ssde_simulate failed ({st}): {msg.decode() if msg else ''}")
+    return ID, times, obs.t()
 
 
 class Engine:
@@ -598,6 +662,9 @@ class Engine:
         out = np.zeros(int(n))
         self._check(self.lib.ssde_kernel_ms_history(self._h, out.ctypes.data_as(_dp), int(n)))
         return out
+
+    def set_option(self, option: int, value: int):
+        self._check(self.lib.ssde_set_option(self._h, option, value))
 
     def forget(self):
         """Drop the memoised last result: the next eval runs on the device even at the same par."""

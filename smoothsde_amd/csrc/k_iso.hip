@@ -317,15 +317,16 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
     const TileView& tv = A.tv;
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
-    const int nstate = (A.nstate_clean > 0 && (A.group_flags[g] & 1)) ? A.nstate_clean : nstate_full;
+    // (all_clean: the compact layout everywhere -- known from the arguments, so that the dump loads below do not wait for a flag)
+    const int nstate = A.all_clean ? A.nstate_clean : (A.nstate_clean > 0 && (A.group_flags[g] & 1)) ? A.nstate_clean : nstate_full;
     // the group's window plan: the launch's, or -- mixed batch, group on the general kernel -- that launch's own
     int nc = A.n_chunks, win = A.window, t0 = A.t0, t0d = A.t0_delta;
     if (A.dual && !(A.group_flags[g] & 1)) { nc = A.n_chunks_d; win = A.window_d; t0 = A.t0_d; t0d = A.t0_delta_d; }
     if (c + 1 >= nc) return 0.0;                       // (workgroup-uniform) no such boundary in this group's plan
     int sb_, s_next, se_;
     window_bounds(L, nc, win, t0, c + 1, sb_, s_next, se_, t0d);   // s_next = first scored row of window c+1
-    const bool valid = (ns > s_next) && (s_next < L);
-    const int pc0 = part * nc + c, pc1 = pc0 + 1;
+    const bool valid = (ns > s_next) && (s_next < L);      // (applied AFTER the loads: their addresses do not depend on it, and
+    const int pc0 = part * nc + c, pc1 = pc0 + 1;          //  one memory round trip then covers the lengths and the dumps)
     const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
     const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
     double worst = 0.0;
@@ -336,9 +337,14 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
         const int k = wv + 4 * i;
-        const bool on = valid && k < nstate;
+        const bool on = k < nstate;
         av[i] = on ? out_c[k * WAVE] : 0.0;
         bv[i] = on ? in_n[k * WAVE] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {          // a lane without that row: nothing to compare (what it loaded may be stale)
+        av[i] = valid ? av[i] : 0.0;
+        bv[i] = valid ? bv[i] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
             const int nA = G * (A.n_chunks - 1);
             if ((int)blockIdx.x < nA) {
                 g = blockIdx.x % G; c = blockIdx.x / G;
-                if (!(A.group_flags[g] & 1)) return;
+                if (!(A.group_flags[g] & 1)) { publish_if_last(R); return; }
             } else {
                 const int k = blockIdx.x - nA;
                 g = A.dirty_groups[k % A.n_dirty_groups]; c = k / A.n_dirty_groups;
@@ -424,12 +430,15 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
     } else {
         reduce_slot(R, blockIdx.x - n_check, sh);
     }
+    publish_if_last(R);
 }
 
 hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {
     const int n_check = a.dual ? a.tv.n_groups * (a.n_chunks - 1) + a.n_dirty_groups * (a.n_chunks_d - 1)
                                : (a.n_chunks > 1 ? a.tv.n_groups * (a.n_chunks - 1) * a.n_parts : 0);
-    hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, r, iso_nstate(model, d), n_check);
+    ReduceArgs rr = r;
+    rr.pub_blocks = n_check + r.n_out;
+    hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, rr, iso_nstate(model, d), n_check);
     return hipGetLastError();
 }
 

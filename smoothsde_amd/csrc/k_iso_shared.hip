@@ -693,7 +693,9 @@ static hipError_t launch_masks(const IsoArgs& a, dim3 grid, hipStream_t s, hipEv
     switch (a.part_mask[0]) {
     // hipExtLaunchKernelGGL stamps ev0 / ev1 with the kernel's own begin / end (what rocprof reports), not with the
     // stream position of separately recorded events
-#define SSDE_CASE(M) case M: hipExtLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, ev0, ev1, 0, a); break;
+    // (ev0 == NULL: a plain launch -- SSDE_OPT_KERNEL_STAMPS off -- which costs the host and the queue a few microseconds less)
+#define SSDE_CASE(M) case M: if (ev0) hipExtLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, ev0, ev1, 0, a); \
+                             else hipLaunchKernelGGL((iso_shared_kernel<MODEL, D, M>), grid, block, 0, s, a); break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
         SSDE_CASE(8) SSDE_CASE(9) SSDE_CASE(10) SSDE_CASE(11) SSDE_CASE(12) SSDE_CASE(13) SSDE_CASE(14) SSDE_CASE(15)
 #undef SSDE_CASE

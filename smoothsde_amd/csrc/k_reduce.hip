@@ -8,10 +8,13 @@ namespace ssde {
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs A) {
     __shared__ double sh[256];
     reduce_slot(A, blockIdx.x, sh);
+    publish_if_last(A);
 }
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_kernel, dim3(a.n_out + 1), dim3(256), 0, s, a);
+    ReduceArgs r = a;
+    r.pub_blocks = a.n_out + 1;
+    hipLaunchKernelGGL(reduce_kernel, dim3(a.n_out + 1), dim3(256), 0, s, r);
     return hipGetLastError();
 }
 

@@ -104,6 +104,7 @@ struct IsoArgs {
     // hand-over dumps of the shared-covariance kernels are compact (state + the sensitivities of the wanted
     // directions only, no covariance part): components per lane, 0 = no group uses that layout
     int nstate_clean;
+    int all_clean;               // every group dumps the compact layout (no group on the general kernel): the hand-over check need not read group_flags
     int derive;                  // windows >= 1 of the general kernel derive one variance direction from log sigma_obs (k_iso.hip)
     double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
 };
@@ -140,6 +141,15 @@ struct ReduceArgs {
     int16_t add_slot[4];          // out[add_slot[i]] (slot -1 = unused)
     int16_t map[MAX_PAR + 16];    // -> output slot (1 + full-par index) or -1
     double* out;                  // n_out + 1 doubles
+    // Publication of the result to the host (synchronous ssde_eval): the LAST workgroup of the reducing launch to finish copies
+    // out[0 .. n_out] into host-visible pinned memory and then stores the evaluation's sequence number, which the host
+    // spins on -- no read-back copy, no synchronisation call (tools/microbench_latency.hip: 5 us less than a stream
+    // synchronisation, 7 us less than an asynchronous copy + synchronisation).  pub == NULL: not wanted.
+    double* pub;                  // pinned, n_out + 1 doubles
+    unsigned long long* pub_flag; // pinned
+    unsigned long long pub_seq;
+    unsigned int* pub_count;      // device, zero between launches: workgroups of this launch that have finished
+    int pub_blocks;               // workgroups of this launch
 };
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s);
 
@@ -384,6 +394,25 @@ __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, i
 }
 
 #if defined(__HIPCC__)
+// Every workgroup of a reducing launch calls this when it is done (ALL its threads; thread 0 has written the block's
+// result -- out[slot], or the atomicMax of a hand-over check).  The last one to arrive publishes (ReduceArgs.pub).
+__device__ __forceinline__ void publish_if_last(const ReduceArgs& R) {
+    if (!R.pub) return;
+    if (threadIdx.x >= WAVE) return;               // wave 0 (thread 0 wrote the block's result)
+    unsigned old = 0;
+    // release: this block's result is visible device-wide before the count; acquire: the last arriver sees everyone's
+    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(R.pub_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, 0, WAVE);
+    if (old != (unsigned)R.pub_blocks - 1u) return;
+    for (int k = threadIdx.x; k <= R.n_out; k += WAVE)       // one coalesced round trip
+        R.pub[k] = __hip_atomic_load(&R.out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();                        // the wave's stores have reached the host before the flag does
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(R.pub_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        __hip_atomic_store(R.pub_flag, R.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
 // XCDs, so ids that are equal mod 8 share an XCD (and its L2): the parts of one (group, window)
 // get such ids because they stream the same rows.

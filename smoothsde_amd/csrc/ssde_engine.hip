@@ -57,6 +57,8 @@ void destroy(ssde_handle* h) {
     h->partials.release(); h->out.release();
     if (h->par_pinned) (void)hipHostFree(h->par_pinned);
     if (h->out_pinned) (void)hipHostFree(h->out_pinned);
+    if (h->pub_pinned) (void)hipHostFree(h->pub_pinned);
+    h->pub_count.release();
     if (h->par_ev_ok)
         for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
     delete h;
@@ -381,6 +383,15 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
 
     HIPCHK(h, h->out.alloc(2 + h->L.n_full));
     HIPCHK(h, hipHostMalloc((void**)&h->out_pinned, (size_t)(2 + h->L.n_full) * 8, hipHostMallocDefault));
+    {
+        const size_t words = ((size_t)(2 + h->L.n_full) + 15) / 16 * 16;           // the sequence word gets a 128-byte line of its own
+        HIPCHK(h, hipHostMalloc((void**)&h->pub_pinned, (words + 16) * 8, hipHostMallocDefault));
+        memset(h->pub_pinned, 0, (words + 16) * 8);
+        h->pub_flag = (unsigned long long*)(h->pub_pinned + words);
+        HIPCHK(h, h->pub_count.alloc(1));
+        HIPCHK(h, hipMemset(h->pub_count.p, 0, sizeof(unsigned int)));
+        h->pub_ok = getenv("SSDE_NO_PUBLISH") == nullptr;
+    }
     for (auto& pr : h->ev_ring) { HIPCHK(h, hipEventCreate(&pr[0])); HIPCHK(h, hipEventCreate(&pr[1])); }
     h->ev_k0 = h->ev_ring[0][0]; h->ev_k1 = h->ev_ring[0][1];
 
@@ -874,7 +885,10 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     double* host = h->gain_pinned + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
-    std::vector<double> cum_ld, cum_g[NDIRP];
+    // running sums of log F and of its derivatives, row by row (member buffers: no allocation per evaluation)
+    std::vector<double>& cum_ld = h->gain_cum[0];
+    std::vector<double>* cum_g = &h->gain_cum[1];
+    for (int j = 0; j < 1 + NDIRP; j++) { if ((int)h->gain_cum[j].capacity() < tmax) h->gain_cum[j].reserve(tmax); h->gain_cum[j].clear(); }
     int last = 0, stable = 0;
     (void)mask;
     // Stationarity test.  In floating point the recursion ends in a last-bit limit cycle rather than a
@@ -987,7 +1001,8 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
     HIPCHK(h, hipSetDevice(h->device));
     h->n_evals++;
     next_stamp_pair(h);
-    if (h->path == PATH_TV) return eval_tv(h, par, order, out_dev, s);
+    h->pub_armed = false;
+    if (h->path == PATH_TV) { h->pub_request = false; return eval_tv(h, par, order, out_dev, s); }
     const ParLayout& L = h->L;
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -997,6 +1012,12 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
     ra.n_out = 1 + L.n_full;
     ra.out = out_dev;
     for (int k = 0; k < MAX_PAR + 16; k++) ra.map[k] = -1;
+    if (h->pub_request && h->pub_ok && out_dev == h->out.p) {
+        // a synchronous evaluation: the reducing launch publishes the result itself (ssde_device.hpp: ReduceArgs.pub)
+        ra.pub = h->pub_pinned; ra.pub_flag = h->pub_flag; ra.pub_seq = ++h->pub_seq; ra.pub_count = h->pub_count.p;
+        h->pub_armed = true;
+    }
+    h->pub_request = false;
 
     if (h->path == PATH_ISO) {
         IsoArgs a;
@@ -1039,6 +1060,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         a.chk_out = out_dev + (1 + L.n_full);
         a.derive = h->env_no_derive ? 0 : 1;
+        a.all_clean = (h->use_shared && h->n_clean_groups == h->n_groups) ? 1 : 0;
         a.nstate_clean = h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
         a.group_flags = h->group_flags.p;
@@ -1123,15 +1145,15 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                 HIPCHK(h, launch_iso(h->model, h->d, ad, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
-            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->ev_k0, h->ev_k1));
-            h->ev_k_valid = true;
+            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+            h->ev_k_valid = h->stamps;
             h->last_s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
         } else {
-            HIPCHK(h, hipEventRecord(h->ev_k0, s));
+            if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
-            HIPCHK(h, hipEventRecord(h->ev_k1, s));
-            h->ev_k_valid = true;
+            if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            h->ev_k_valid = h->stamps;
             h->last_s_stat = -1;
         }
         if (h->trace) { const double t = tick(); h->trace_us[2] += t - tk0; tk0 = t; }
@@ -1183,10 +1205,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         for (int i = 0; i < 16; i++) a.p0[i] = h->p0_full[i];
         a.n_dirblocks = h->n_dirblocks; a.dirs = h->dirs.p; a.partials = h->partials.p;
         a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
-        HIPCHK(h, hipEventRecord(h->ev_k0, s));
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_dense(a, order >= 1, s));
-        HIPCHK(h, hipEventRecord(h->ev_k1, s));
-        h->ev_k_valid = true; h->last_s_stat = -1;
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+        h->ev_k_valid = h->stamps; h->last_s_stat = -1;
         if (order >= 1) {
             ra.n_parts = h->n_dirblocks; ra.nacc = 1 + DENSE_NT;
             for (size_t k = 0; k < h->dirs_host.size(); k++)
@@ -1216,10 +1238,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             f.tdf = h->tdf; f.tconst = h->tconst;
             if (h->df_ja >= 0 && h->pp_fast[h->df_ja]) f.ppA = h->pp[h->df_ja];
             if (h->df_jb >= 0 && h->pp_fast[h->df_jb]) f.ppB = h->pp[h->df_jb];
-            HIPCHK(h, hipEventRecord(h->ev_k0, s));
+            if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_direct_fast(f, s));
-            HIPCHK(h, hipEventRecord(h->ev_k1, s));
-            h->ev_k_valid = true; h->last_s_stat = -1;
+            if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+            h->ev_k_valid = h->stamps; h->last_s_stat = -1;
             ra.n_parts = 1; ra.nacc = 1 + MAX_Q + f.ncA + f.ncB; ra.n_blocks = h->direct_blocks;
             if (order >= 1) {
                 for (int j = 0; j < MAX_Q; j++)
@@ -1244,10 +1266,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.tdf = h->tdf; a.tconst = h->tconst;
         a.t_decay = h->tdecay.p; a.n_decay = L.n_decay; a.off_decay = L.off_decay;
         if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
-        HIPCHK(h, hipEventRecord(h->ev_k0, s));
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_direct(a, s));
-        HIPCHK(h, hipEventRecord(h->ev_k1, s));
-        h->ev_k_valid = true; h->last_s_stat = -1;
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+        h->ev_k_valid = h->stamps; h->last_s_stat = -1;
         ra.n_parts = 1; ra.nacc = 1 + a.n_slots + L.n_decay; ra.n_blocks = h->direct_blocks;
         if (order >= 1) {
             for (int k = 0; k < a.n_slots; k++)
@@ -1305,11 +1327,22 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
         for (size_t e = 1; e < h->shards.size(); e++)
             HIPCHK(h, launch_sum_into(out_dev, h->shards[e]->out.p, (int)count, (hipStream_t)stream));
         if (h->poison) {
-            static const double nan_value = std::numeric_limits<double>::quiet_NaN();
-            HIPCHK(h, hipMemcpyAsync(out_dev, &nan_value, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+            // SSDE_NA_ANY_NAN, wide response: a NaN outside column 0 of an observed row is a NaN innovation in the reference:
+            // value AND every free gradient entry (what ssde_eval returns for such a handle)
+            std::vector<double>& nan_vec = h->poison_vec;          // (a member: it outlives the asynchronous copy)
+            if (nan_vec.size() < count) nan_vec.assign(count, 0.0);
+            for (size_t k = 0; k + 1 < count; k++) nan_vec[k] = (k == 0 || !h->fixed[k - 1]) ? std::numeric_limits<double>::quiet_NaN() : 0.0;
+            HIPCHK(h, hipMemcpyAsync(out_dev, nan_vec.data(), (count - 1) * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
         }
-        if (h->comms.empty()) return SSDE_OK;
-        return reduce_ranks(h, out_dev, (hipStream_t)stream);
+        int stw = SSDE_OK;
+        if (!h->comms.empty()) stw = reduce_ranks(h, out_dev, (hipStream_t)stream);
+        if (stw) return stw;
+        // a later synchronous ssde_eval runs the parts on their own stream and shares their work buffers with this evaluation
+        for (ssde_handle* sh : h->shards) {
+            HIPCHK(h, hipEventRecord(sh->ev_async, (hipStream_t)stream));
+            sh->async_pending = true;
+        }
+        return SSDE_OK;
     }
     int st = eval_device(h, par, order, out_dev, (hipStream_t)stream);
     if (st == SSDE_OK && !h->comms.empty()) st = reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
@@ -1346,6 +1379,9 @@ void each_engine(ssde_handle* h, F fn) {
 // sensitivities ride along in registers with the HBM stream that bounds the kernel, so an order-0 call evaluates
 // order 1 and memoises it: optim's fn(x); gr(x) (R/sde.R:694-696) then costs one evaluation.
 bool grad_rides_along(const ssde_handle* h) {
+    // ranks of a communicator: what ALL of them can do (a rank that memoised a gradient the others never computed would
+    // answer the following gr(x) from its memo while the others enter the collective alone)
+    if (!h->comms.empty() && h->comm_rides >= 0 && (h->shards.empty() || h->n_track_shards <= 1)) return h->comm_rides != 0;
     const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
     return e->path == PATH_DIRECT || (e->path == PATH_ISO && e->use_shared);
 }
@@ -1359,6 +1395,11 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         (void)hipGetDevice(&dev_before);                   // the caller's current device is left as it was found
         struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{dev_before};
         for (ssde_handle* sh : h->shards) {
+            if (sh->async_pending) {         // an ssde_eval_device of this handle still running on the caller's stream shares the work buffers
+                HIPCHK(h, hipSetDevice(sh->device));
+                HIPCHK(h, hipStreamWaitEvent(sh->own_stream, sh->ev_async, 0));
+                sh->async_pending = false;
+            }
             int st = eval_device(sh, par, order, sh->out.p, sh->own_stream);
             if (st) { h->err = sh->err; return st; }
         }
@@ -1415,13 +1456,35 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         return SSDE_OK;
     }
     h->sync_call = true;
+    h->pub_request = true;
     int st = eval_device(h, par, order, h->out.p, 0);
     h->sync_call = false;
     if (st) return st;
     const auto t0 = std::chrono::steady_clock::now();
-    // (Measured twice and slower both times by ~10 us: letting the finalising launch write the result into host-visible
-    // pinned memory itself -- as a mirror, or with a sequence word the host spins on -- instead of this blocking copy.)
-    HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
+    // The reducing launch's last workgroup has been told to copy the result into pinned memory and to store this
+    // evaluation's sequence number after it: spin on that word.  (tools/microbench_latency.hip, 40-us kernel: 12.7 us of
+    // fixed overhead against 17.9 with the blocking 48-byte copy this replaces and 25.7 with the copy and event-stamped
+    // launches.  Rounds 1 and 2 had measured a pinned mirror as SLOWER; that was with the stamps on and a host that
+    // synchronised the stream first.)  SSDE_NO_PUBLISH=1 keeps the blocking copy for A/B.
+    if (h->pub_armed) {
+        h->pub_armed = false;
+        const unsigned long long want = h->pub_seq;
+        bool seen = false;
+        for (uint64_t spins = 1;; spins++) {
+            if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+            if ((spins & 0xFFFF) == 0) {
+                // a launch that failed never publishes: ask the runtime now and then instead of spinning for ever
+                const hipError_t q = hipStreamQuery(0);
+                if (q == hipSuccess) { seen = __atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == want; break; }
+                if (q != hipErrorNotReady) { h->err = std::string("evaluation failed on the device: ") + hipGetErrorString(q); return SSDE_ERR_HIP; }
+            }
+            __builtin_ia32_pause();
+        }
+        if (seen) memcpy(o, h->pub_pinned, nout * 8);
+        else HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));     // (stream drained without the word: read the device buffer)
+    } else {
+        HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
+    }
     if (h->trace) h->trace_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     return SSDE_OK;
 }
@@ -1515,7 +1578,8 @@ int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t ord
         return SSDE_OK;
     }
     const int eval_order = (want_grad || grad_rides_along(h)) ? 1 : 0;
-    std::vector<double> o(2 + np);
+    std::vector<double>& o = h->eval_out;
+    o.resize(2 + np);
     int st = run_checked(h, par, eval_order, o);
     if (st) return st;
     if (h->poison)                     // SSDE_NA_ANY_NAN, wide response: a NaN outside column 0 of an observed row (a NaN innovation
@@ -1661,6 +1725,17 @@ int ssde_kernel_ms_history(const ssde_handle* h, double* ms, int32_t n) {
             hipEventElapsedTime(&f, h->ev_ring[slot][0], h->ev_ring[slot][1]) == hipSuccess) ms[k] = f;
     }
     return SSDE_OK;
+}
+
+int ssde_set_option(ssde_handle* h, int32_t option, int64_t value) {
+    if (!h) return SSDE_ERR_ARG;
+    if (option == SSDE_OPT_KERNEL_STAMPS) {
+        h->stamps = value != 0;
+        for (ssde_handle* s : h->shards) s->stamps = h->stamps;
+        return SSDE_OK;
+    }
+    h->err = "ssde_set_option: unknown option";
+    return SSDE_ERR_ARG;
 }
 
 int ssde_forget(ssde_handle* h) {

@@ -164,6 +164,7 @@ struct ssde_handle {
     // timing of the dominant kernel (recorded on the stream it is launched on)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // the CURRENT evaluation's pair: ev_ring[ev_idx % EV_RING]
     bool ev_k_valid = false;
+    bool stamps = true;                            // SSDE_OPT_KERNEL_STAMPS: 0 = plain launches, no event pair per evaluation
     // Every evaluation stamps its dominant kernel with a pair of its own, so that a caller can time K evaluations and read
     // the K kernel durations AFTERWARDS (ssde_kernel_ms_history) instead of paying an event query between them.
     static constexpr int EV_RING = 64;
@@ -207,6 +208,17 @@ struct ssde_handle {
     double* tv_out_pinned = nullptr;
     DevBuf<double> lap_out;                   // ssde_laplace_eval: result vectors of a batch of asynchronous evaluations
     double* out_pinned = nullptr;             // read-back target of the synchronous ssde_eval (2 + n_full doubles)
+    // publication of a synchronous evaluation's result by its reducing launch (ReduceArgs.pub, ssde_device.hpp): the host spins
+    // on a sequence word in pinned memory instead of issuing a read-back copy
+    double* pub_pinned = nullptr;             // [2 + n_full] result, then (128-byte aligned) the sequence word
+    unsigned long long* pub_flag = nullptr;
+    unsigned long long pub_seq = 0;
+    DevBuf<unsigned int> pub_count;
+    bool pub_ok = false;                      // buffers exist and SSDE_NO_PUBLISH is not set
+    bool pub_request = false;                 // run_once asks the next eval_device to publish
+    std::vector<double> gain_cum[4];          // build_gain_table's running sums
+    bool pub_armed = false;                   // the evaluation just enqueued will publish (set by eval_device, consumed by run_once)
+    std::vector<double> eval_out;             // ssde_eval's result vector (no allocation per call)
 
     int64_t hbm_bytes = 0;
     // dtimes(n-1) of the reference is 1 (nllk_ctcrw.hpp:126-129); a shard of a multi-device handle that is not the last
@@ -228,10 +240,16 @@ struct ssde_handle {
     std::vector<int> shard_leader;            // index of the first engine on the same device (its stream and out buffer
                                               // collect that device's engines before the collective)
     int n_track_shards = 1, n_dim_parts = 1;
+    std::vector<double> poison_vec;           // the NaN result vector of a poisoned handle (ssde_eval_device)
     bool poison = false;                      // SSDE_NA_ANY_NAN, n_dim > 2: an observed row with a NaN outside column 0
     std::vector<void*> comms;                 // ncclComm_t: one per shard (parent), or one (ssde_comm_init_rank)
     bool shards_share_device = false;         // rehearsal on a one-GPU machine: shards summed by a kernel, not RCCL
     int comm_ranks = 1;                       // ranks of a multi-process communicator
+    // Decisions that shape the SEQUENCE of collectives must be the same on every rank, whatever each rank's own data look
+    // like (one rank's shard on a regular grid, another's with missing rows): agreed on once, at ssde_comm_init_rank
+    // (min over ranks), and used instead of the local facts while a communicator is joined.  -1 = no communicator.
+    int comm_rides = -1;                      // an order-0 ssde_eval evaluates order 1 (grad_rides_along) on every rank, or on none
+    int comm_async_ok = -1;                   // ssde_laplace_eval batches its evaluations through ssde_eval_device on every rank, or on none
     hipStream_t own_stream = nullptr;         // stream of the synchronous evaluation when a collective follows it
     // ---- memo of the last ssde_eval (include/ssde.h) ---------------------------------------------------------------
     std::vector<double> memo_par, memo_grad;

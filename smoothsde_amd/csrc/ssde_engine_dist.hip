@@ -427,6 +427,37 @@ int ssde_comm_init_rank(ssde_handle* h, int32_t n_ranks, int32_t rank, const voi
     h->comm_ranks = n_ranks;
     if (h->shards.empty() && !h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->memo_order = -1;
+    // ---- what the ranks have to agree on (collective: every rank is here) ------------------------------------------
+    // [0] the gradient rides along with the value on this rank's kernels (grad_rides_along, ssde_engine.hip)
+    // [1] this rank can batch evaluations through ssde_eval_device (ssde_laplace.hip: joint_batch)
+    // -> min over ranks.  ESEAL_SSM's priors are functions of the WHOLE data (nllk_e_seal_ssm.hpp:212-216: the total row
+    // count n and sigma(0), the first row's sigma): [2] rows -> sum; [3..] rank 0's first design row of sigma -> sum of
+    // (rank 0's row, zeros elsewhere).
+    {
+        const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
+        const size_t ns0 = e->pen.eseal_sig0.size();
+        std::vector<double> fl = {(e->path == PATH_DIRECT || (e->path == PATH_ISO && e->use_shared)) ? 1.0 : 0.0,
+                                  e->path == PATH_TV ? 0.0 : 1.0};
+        std::vector<double> sm(1 + ns0, 0.0);
+        sm[0] = (double)h->n;
+        if (rank == 0) for (size_t k = 0; k < ns0; k++) sm[1 + k] = e->pen.eseal_sig0[k].second;
+        DevBuf<double> dfl, dsm;
+        HIPCHK(h, dfl.upload(fl));
+        HIPCHK(h, dsm.upload(sm));
+        hipStream_t s = h->shards.empty() ? h->own_stream : h->shards[0]->own_stream;
+        NCCLCHK(h, rccl().AllReduce(dfl.p, dfl.p, fl.size(), ncclDouble, ncclMin, c, s));
+        if (is_eseal(h->model)) NCCLCHK(h, rccl().AllReduce(dsm.p, dsm.p, sm.size(), ncclDouble, ncclSum, c, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        HIPCHK(h, hipMemcpy(fl.data(), dfl.p, fl.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(sm.data(), dsm.p, sm.size() * 8, hipMemcpyDeviceToHost));
+        dfl.release(); dsm.release();
+        h->comm_rides = fl[0] > 0.5 ? 1 : 0;
+        h->comm_async_ok = fl[1] > 0.5 ? 1 : 0;
+        if (is_eseal(h->model)) {
+            h->pen.eseal_n = (int64_t)llround(sm[0]);
+            for (size_t k = 0; k < ns0 && k < h->pen.eseal_sig0.size(); k++) h->pen.eseal_sig0[k].second = sm[1 + k];
+        }
+    }
     return SSDE_OK;
 }
 

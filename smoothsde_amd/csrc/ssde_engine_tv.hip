@@ -299,10 +299,10 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     a.items = grad ? h->tv_items_g.p : h->tv_items_v.p;
     a.n_items = grad ? h->tv_n_items_g : h->tv_n_items_v;
     a.out = out_dev;
-    HIPCHK(h, hipEventRecord(h->ev_k0, s));
+    if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
     HIPCHK(h, launch_tv_filter(a, grad, s));
-    HIPCHK(h, hipEventRecord(h->ev_k1, s));
-    h->ev_k_valid = true; h->last_s_stat = -1;
+    if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+    h->ev_k_valid = h->stamps; h->last_s_stat = -1;
     HIPCHK(h, launch_tv_finalize(a, s));
     h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
     return SSDE_OK;

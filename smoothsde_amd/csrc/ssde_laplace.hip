@@ -91,6 +91,9 @@ struct Laplace {
         //  evaluation's statistics before it can plan the next: measured, 0.137 ms per evaluation batched against 0.106 ms one by one)
         const ssde_handle* e0 = h->shards.empty() ? h : h->shards[0];
         if (e0->path == ssde_engine::PATH_TV) async_ok = false;
+        // ranks of a communicator take the same route (agreed on at ssde_comm_init_rank): the batched route pairs its
+        // k-th all-reduce with the other ranks' k-th, the one-by-one route interleaves retries
+        if (!h->comms.empty() && h->comm_async_ok >= 0 && (h->shards.empty() || h->n_track_shards <= 1)) async_ok = h->comm_async_ok != 0;
         if (async_ok && K > 1) {
             if (h->lap_out.n < K * nout) {
                 h->lap_out.release();
@@ -227,10 +230,11 @@ extern "C" int ssde_laplace_eval(ssde_handle* h, double* par, int32_t n_par_full
     double val = 0.0;
     int st = lp.inner(p, &val, &g, H);
     if (st) return st;
-    for (int i = 0; i < nu; i++) par[lp.ir[i]] = p[lp.ir[i]];          // u^ back to the caller (warm start / par.random)
     if (hess_uu) memcpy(hess_uu, H.data(), (size_t)nu * nu * 8);
     std::vector<double> Lm = H;
-    if (!std::isfinite(val) || !cholesky(Lm, nu)) { *value = INFINITY; return SSDE_OK; }   // not a minimum: rejected step
+    // not a minimum: a rejected step -- and the caller's coeff_re stay what they were (a line-search probe must not move the warm start)
+    if (!std::isfinite(val) || !cholesky(Lm, nu)) { *value = INFINITY; return SSDE_OK; }
+    for (int i = 0; i < nu; i++) par[lp.ir[i]] = p[lp.ir[i]];          // u^ back to the caller (warm start / par.random)
     const double half_ld0 = 0.5 * chol_logdet(Lm, nu);
     *value = val + half_ld0 - 0.5 * nu * std::log(2.0 * M_PI);
     if (order < 1 || !grad) return SSDE_OK;

@@ -4,7 +4,8 @@ The generators follow the reference's exact-transition simulator
 (/root/reference/R/sde.R:1434-1478, CTCRW covariance /root/reference/R/utility.R:188-196),
 vectorised over tracks instead of looping over IDs.  `backend="torch"` builds the batch
 directly in HBM on the current GPU (no 2.4 GB host->device copy for the 1e4 x 1e4 case);
-`backend="numpy"` builds it on the host.
+`backend="numpy"` builds it on the host; `backend="hip"` is the engine's own simulator kernel
+(ssde_simulate, csrc/k_sim.hip: counter-based, so any shard of a batch can be generated on its own).
 
 Output is the reference's long format: all tracks concatenated, `ID` constant within a
 track, `time` increasing globally (1..n scaled by dt, like /root/reference/inst/example.R:17,
@@ -40,6 +41,10 @@ def simulate(model: str, n_tracks: int, n_steps: int, n_dim: int = 2, *, mu=0.0,
     (n,), (n,), (n, d), n = n_tracks * n_steps, as numpy arrays or torch tensors.
     """
     M, T, d = int(n_tracks), int(n_steps), int(n_dim)
+    if backend == "hip":
+        from . import capi
+        return capi.simulate_device(model, M, T, d, mu=mu, tau=tau, nu=nu, kappa=kappa, sigma=sigma, sigma_obs=sigma_obs,
+                                    dt=dt, z0=z0, seed=seed, device=device)
     mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), (d,))
     z0 = np.broadcast_to(np.asarray(z0, dtype=np.float64), (d,))
     use_torch = backend == "torch"

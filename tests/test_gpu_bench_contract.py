@@ -28,7 +28,7 @@ def test_bench_line_has_what_the_driver_reads():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert d["unit"] == "track-timesteps/s" and d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(d["value"] - 640 * 800 * 5 / (d["ms_per_step"] * 5e-3)) <= 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -38,6 +38,7 @@ def test_bench_line_has_what_the_driver_reads():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["required_bytes_per_row"] == 16.0 and r["algo_bytes_per_row"] == 24.0 and r["kernel_ms"] > 0
+    assert d["ms_per_step_stamped"] > 0 and "strong scaling" in d["config"]["workload"] and d["config"]["total_rows"] == 640 * 800
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -54,3 +55,27 @@ def test_one_rank_communicator_rehearsal_prints_one_line_too():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "ncclAllReduce" in d["config"]["parallelism"]
+
+
+def test_strong_and_weak_modes_with_one_rank_time_the_same_batch():
+    """One rank: both modes cut nothing; the line says which one ran and both see the same batch (same nllk at the last step)."""
+    a = _run("--no-cpu-baseline", "--no-secondary", "--scaling", "strong")
+    b = _run("--no-cpu-baseline", "--no-secondary", "--scaling", "weak")
+    assert a["scaling"] == "strong" and b["scaling"] == "weak"
+    assert a["config"]["nllk_at_last_step"] == b["config"]["nllk_at_last_step"]
+    assert a["config"]["total_rows"] == b["config"]["total_rows"] == 640 * 800
+
+
+def test_config_c4_and_c5_lines():
+    d = _run("--no-cpu-baseline", "--config", "c4")
+    assert d["config"]["config"] == "c4" and "C4" in d["config"]["workload"] and 0 < d["roofline"]["frac"] <= 1.0
+    d = _run("--no-cpu-baseline", "--config", "c5")
+    c = d["config"]
+    assert c["config"] == "c5" and "concurrently" in c["workload"] and len(c["n_free_par"]) == 3
+    # ragged lengths U[T/2, T]: three sub-batches of 640 tracks
+    assert 3 * 640 * 400 <= c["total_rows"] <= 3 * 640 * 800
+    hs = d["roofline"]["handles"]
+    assert [h["kernel"].split("(")[1].rstrip(")") for h in hs] == ["BM_SSM", "OU_SSM", "CTCRW"]
+    assert all(0 < h["frac"] <= 1.0 and h["kernel_ms"] > 0 for h in hs)
+    assert c["window_check"] <= 1e-11 and d["value"] > 0
+    assert abs(d["value"] - c["total_rows"] * 5 / (d["ms_per_step"] * 5e-3)) <= 1e-6 * d["value"]

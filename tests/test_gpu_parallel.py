@@ -164,6 +164,94 @@ def test_one_rank_communicator_runs_the_collective():
     eng.close()
 
 
+def test_one_rank_communicator_keeps_the_eseal_priors_and_the_agreed_decisions():
+    """ESEAL_SSM's priors use the total row count and sigma(0) of the WHOLE data (nllk_e_seal_ssm.hpp:212-216):
+    ssde_comm_init_rank sums the rows and takes rank 0's sigma(0) row over the communicator -- with one rank that must
+    leave every number as it was."""
+    from cases import eseal_spec, problem_from_spec
+    spec = eseal_spec("x", 3, [300, 180, 240], variant="tv", na_rows=(7, 50, 51))
+    pb = problem_from_spec(spec)
+    par = np.asarray(spec["par"], dtype=float)
+    eng = capi.Engine(pb)
+    v1, g1 = eng.eval(par)
+    p1 = eng.penalty(par)
+    eng.comm_init(1, 0, capi.comm_unique_id())
+    v2, g2 = eng.eval(par)
+    p2 = eng.penalty(par)
+    assert v1 == v2 and np.array_equal(g1, g2) and p1[0] == p2[0] and np.array_equal(p1[1], p2[1])
+    eng.close()
+
+
+def _hetero_rank_main(rank, world, port, q):
+    """Rank 0: complete tracks on a regular grid (shared-covariance kernel: the gradient rides along with the value);
+    rank 1: tracks with missing rows (general kernel: it does not).  fn(x); gr(x) must still be ONE consistent batch."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(rank)
+    ID, t, o, lo, hi = _hetero_batch(rank)
+    pb = capi.Problem("CTCRW", ID[lo:hi], t[lo:hi], o[lo:hi], device=rank)
+    eng = capi.Engine(pb)
+    box = [capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    eng.comm_init(world, rank, box[0])
+    par = np.array([np.log(0.1), 0.01, -0.02, np.log(2.0), 0.05])
+    v0 = eng.eval(par, order=0)                     # fn(x)
+    v1, g1 = eng.eval(par, order=1)                 # gr(x) at the same x
+    par2 = par + 0.01
+    v2, g2 = eng.eval(par2, order=1)
+    q.put((rank, v0, v1, g1, v2, g2, eng.info()["n_evals"]))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def _hetero_batch(rank=None):
+    ID, t, o = simulate("CTCRW", 256, 500, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=5)
+    half = 128 * 500
+    o = o.copy()
+    o[half + 7::53] = np.nan                        # missing rows in the second half of the tracks only
+    o[::500] = np.where(np.isnan(o[::500]), 0.0, o[::500])
+    lo, hi = (0, half) if rank == 0 else (half, len(ID))
+    return ID, t, o, lo, hi
+
+
+def test_two_ranks_with_different_kernels_agree_on_the_order_of_evaluations():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU: two ranks need two")
+    import torch.multiprocessing as mp
+    ID, t, o, _, _ = _hetero_batch()
+    e1 = capi.Engine(capi.Problem("CTCRW", ID, t, o))
+    par = np.array([np.log(0.1), 0.01, -0.02, np.log(2.0), 0.05])
+    w1, h1 = e1.eval(par)
+    w2, h2 = e1.eval(par + 0.01)
+    e1.close()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hetero_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_evals = set()
+    for rank, v0, v1, g1, v2, g2, ne in res:
+        assert v0 == v1 and abs(v1 - w1) <= 1e-12 * abs(w1) and np.max(np.abs(g1 - h1)) <= 1e-10 * np.max(np.abs(h1))
+        assert abs(v2 - w2) <= 1e-12 * abs(w2) and np.max(np.abs(g2 - h2)) <= 1e-10 * np.max(np.abs(h2))
+        n_evals.add(ne)
+    assert len(n_evals) == 1                        # every rank entered the collective the same number of times
+
+
 def _rank_main(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
