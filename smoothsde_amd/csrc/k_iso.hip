@@ -201,7 +201,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
             double st[Ops::State::NSTATE];
             S.dump(st);
             if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
-            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
+            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
 #pragma unroll
             for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
             S.reset_acc();
@@ -223,7 +223,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         double st[Ops::State::NSTATE];
         S.dump(st);
         if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
-        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
 #pragma unroll
         for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
     }
@@ -327,36 +327,39 @@ __device__ __forceinline__ double window_check_block(const IsoArgs& A, int nstat
     window_bounds(L, nc, win, t0, c + 1, sb_, s_next, se_, t0d);   // s_next = first scored row of window c+1
     const bool valid = (ns > s_next) && (s_next < L);      // (applied AFTER the loads: their addresses do not depend on it, and
     const int pc0 = part * nc + c, pc1 = pc0 + 1;          //  one memory round trip then covers the lengths and the dumps)
-    const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * NSTATE_MAX * WAVE + lane;
-    const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * NSTATE_MAX * WAVE + lane;
+    const double* out_c = A.bnd + (((int64_t)pc0 * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+    const double* in_n = A.bnd + (((int64_t)pc1 * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
     double worst = 0.0;
-    // the block's 4 waves take every 4th component; all of a wave's loads (at most NSTATE_MAX / 4 pairs) are issued
-    // before the first reduction, so that one HBM round trip covers them instead of one per component
+    // the block's 4 waves take every 4th component; all of a wave's loads (at most NSTATE_MAX / 4 pairs per pass) are issued
+    // before the first reduction, so that one HBM round trip covers them instead of one per component; dumps wider than
+    // NSTATE_MAX components (drift columns, k_iso_drift.hip) take further passes
     constexpr int KMAX = NSTATE_MAX / 4;
-    double av[KMAX], bv[KMAX];
+    for (int k0 = 0; k0 < nstate; k0 += NSTATE_MAX) {
+        double av[KMAX], bv[KMAX];
 #pragma unroll
-    for (int i = 0; i < KMAX; i++) {
-        const int k = wv + 4 * i;
-        const bool on = k < nstate;
-        av[i] = on ? out_c[k * WAVE] : 0.0;
-        bv[i] = on ? in_n[k * WAVE] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < KMAX; i++) {          // a lane without that row: nothing to compare (what it loaded may be stale)
-        av[i] = valid ? av[i] : 0.0;
-        bv[i] = valid ? bv[i] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < KMAX; i++) {
-        if (wv + 4 * i >= nstate) break;             // (wave-uniform)
-        double err = fabs(av[i] - bv[i]), sc = fmax(fabs(av[i]), fabs(bv[i]));
-        if (valid && !(err == err)) err = INFINITY;  // NaN on either side must not pass
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            err = fmax(err, __shfl_xor(err, o, 64));
-            sc = fmax(sc, __shfl_xor(sc, o, 64));
+        for (int i = 0; i < KMAX; i++) {
+            const int k = k0 + wv + 4 * i;
+            const bool on = k < nstate;
+            av[i] = on ? out_c[k * WAVE] : 0.0;
+            bv[i] = on ? in_n[k * WAVE] : 0.0;
         }
-        if (err > 0.0) worst = fmax(worst, err / sc);
+#pragma unroll
+        for (int i = 0; i < KMAX; i++) {          // a lane without that row: nothing to compare (what it loaded may be stale)
+            av[i] = valid ? av[i] : 0.0;
+            bv[i] = valid ? bv[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; i++) {
+            if (k0 + wv + 4 * i >= nstate) break;             // (wave-uniform)
+            double err = fabs(av[i] - bv[i]), sc = fmax(fabs(av[i]), fabs(bv[i]));
+            if (valid && !(err == err)) err = INFINITY;  // NaN on either side must not pass
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                err = fmax(err, __shfl_xor(err, o, 64));
+                sc = fmax(sc, __shfl_xor(sc, o, 64));
+            }
+            if (err > 0.0) worst = fmax(worst, err / sc);
+        }
     }
     if (lane == 0) sh[wv] = worst;
     __syncthreads();
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
             const int nA = G * (A.n_chunks - 1);
             if ((int)blockIdx.x < nA) {
                 g = blockIdx.x % G; c = blockIdx.x / G;
-                if (!(A.group_flags[g] & 1)) { publish_if_last(R); return; }
+                if (!(A.group_flags[g] & 1)) { publish_if_last(R, 0ull); return; }
             } else {
                 const int k = blockIdx.x - nA;
                 g = A.dirty_groups[k % A.n_dirty_groups]; c = k / A.n_dirty_groups;
@@ -425,12 +428,13 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
             g = blockIdx.x % G; c = (blockIdx.x / G) % nb; part = blockIdx.x / (G * nb);
         }
         const double w = window_check_block(A, nstate, g, c, part, sh);
+        unsigned long long dep = 0ull;
         if (threadIdx.x == 0 && w > 0.0)
-            atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
+            dep = atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
+        publish_if_last(R, dep);
     } else {
-        reduce_slot(R, blockIdx.x - n_check, sh);
+        publish_if_last(R, reduce_slot(R, blockIdx.x - n_check, sh));
     }
-    publish_if_last(R);
 }
 
 hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s) {

@@ -1,0 +1,9 @@
+// k_iso_shared_bm.hip -- the shared-covariance kernels of BM_SSM (k_iso_shared.inc), one translation unit per model.
+#define SSDE_SHARED_HAS_P2 0
+#include "k_iso_shared.inc"
+
+namespace ssde {
+hipError_t launch_iso_shared_bm(int d, const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep) {
+    return launch_shared_model<M_BM_SSM>(d, a, grid, s, ev0, ev1, deep);
+}
+}  // namespace ssde

@@ -7,8 +7,7 @@ namespace ssde {
 
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs A) {
     __shared__ double sh[256];
-    reduce_slot(A, blockIdx.x, sh);
-    publish_if_last(A);
+    publish_if_last(A, reduce_slot(A, blockIdx.x, sh));
 }
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t s) {

@@ -42,6 +42,7 @@ constexpr int MAX_PARTS = 4;     // direction split: at most one part per direct
 constexpr int MAX_PAR = 320;     // parameters passed by value in the kernel argument block
 constexpr int MAX_COLS = 96;     // streamed design columns (dense / direct kernels)
 constexpr int MAX_Q = 4;         // SDE parameters per row (d + 2, d <= 2)
+constexpr int DRIFT_KMAX = 24;   // streamed drift columns of the shared-covariance kernel with a row-varying drift (k_iso_drift.hip)
 
 struct TileView {
     const double* tiles;
@@ -107,6 +108,16 @@ struct IsoArgs {
     int all_clean;               // every group dumps the compact layout (no group on the general kernel): the hand-over check need not read group_flags
     int derive;                  // windows >= 1 of the general kernel derive one variance direction from log sigma_obs (k_iso.hip)
     double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
+    int deep_prefetch;           // shared-covariance kernel, d = 2: three-block rotation (two blocks in flight) instead of the ping-pong pair
+    int bnd_stride;              // components per hand-over dump in `bnd` (NSTATE_MAX, or more with drift columns)
+    // Row-varying DRIFT on the shared-covariance path (k_iso_drift.hip): mu_a(i) = mu[a] + sum_k coef_k X_k(i) over the
+    // streamed design columns that feed dimension a (nllk_ctcrw.hpp:143-149, 211-212; nllk_ou_ssm.hpp:113-124); tau,
+    // nu / kappa / sigma and sigma_obs constant.  Tile channels c_col .. c_col + drift_k - 1 hold the columns.
+    int drift_k;                 // streamed columns (0 = constant drift: the other kernels)
+    int c_col;                   // tile channel of column 0
+    double coefA[DRIFT_KMAX];    // coefficient of column k if it feeds dimension 0, else 0
+    double coefB[DRIFT_KMAX];    // ... dimension 1
+    unsigned drift_dim1;         // bit k: column k feeds dimension 1
 };
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance
 // direction, one block for mu
@@ -117,6 +128,9 @@ __host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool ha
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
 // ev0 / ev1 (may be NULL): stamped with the kernel's own begin / end
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+// shared-covariance lanes with a streamed row-varying drift (k_iso_drift.hip); partials [n_chunks][4 + d + drift_k][n_groups]
+hipError_t launch_iso_drift(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int drift_nstate(int model, int d, int k);
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
 struct ReduceArgs;
 // the hand-over checks and the final sums of an isotropic evaluation in ONE launch (the checks raise out[n_out])
@@ -394,23 +408,33 @@ __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, i
 }
 
 #if defined(__HIPCC__)
-// Every workgroup of a reducing launch calls this when it is done (ALL its threads; thread 0 has written the block's
-// result -- out[slot], or the atomicMax of a hand-over check).  The last one to arrive publishes (ReduceArgs.pub).
-__device__ __forceinline__ void publish_if_last(const ReduceArgs& R) {
+// Every workgroup of a reducing launch calls this when it is done (ALL its threads).  `dep` is what thread 0 got back from
+// the device-scope atomic that carried the block's result (publish_store / publish_max below): the count is made to
+// depend on it, so the result has been performed at the device's coherence point before the block is counted -- without
+// a release fence, i.e. without the L2 write-back + invalidate that ~800 workgroups would each pay (measured: that
+// version was 6-10 us SLOWER than a blocking read-back copy).  The last workgroup to arrive publishes (ReduceArgs.pub).
+__device__ __forceinline__ void publish_if_last(const ReduceArgs& R, unsigned long long dep) {
     if (!R.pub) return;
-    if (threadIdx.x >= WAVE) return;               // wave 0 (thread 0 wrote the block's result)
+    if (threadIdx.x >= WAVE) return;               // wave 0 (thread 0 carried the block's result)
     unsigned old = 0;
-    // release: this block's result is visible device-wide before the count; acquire: the last arriver sees everyone's
-    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(R.pub_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        const unsigned one = 1u + (unsigned)(dep & 0ull);     // (a data dependency on the atomic's return value)
+        old = __hip_atomic_fetch_add(R.pub_count, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     old = __shfl(old, 0, WAVE);
     if (old != (unsigned)R.pub_blocks - 1u) return;
-    for (int k = threadIdx.x; k <= R.n_out; k += WAVE)       // one coalesced round trip
+    for (int k = threadIdx.x; k <= R.n_out; k += WAVE)       // one coalesced round trip, past this XCD's L2
         R.pub[k] = __hip_atomic_load(&R.out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();                        // the wave's stores have reached the host before the flag does
     if (threadIdx.x == 0) {
         __hip_atomic_store(R.pub_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
         __hip_atomic_store(R.pub_flag, R.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+// a block's result slot, written where every other workgroup of the device will see it; returns the dependency token
+__device__ __forceinline__ unsigned long long publish_store(double* p, double v) {
+    return (unsigned long long)__hip_atomic_exchange((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Workgroup id -> (track group, window, part).  Workgroups are dealt round-robin over the 8
@@ -446,7 +470,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 // one output slot by one 256-thread workgroup: 0 = nllk, 1.. = gradient entries, n_out = hand-over check
-__device__ __forceinline__ void reduce_slot(const ReduceArgs& A, int slot, double* sh) {
+__device__ __forceinline__ unsigned long long reduce_slot(const ReduceArgs& A, int slot, double* sh) {
     const int tid = threadIdx.x;
     double acc = 0.0;
     if (slot == A.n_out) {
@@ -457,8 +481,7 @@ __device__ __forceinline__ void reduce_slot(const ReduceArgs& A, int slot, doubl
             if (tid < o) sh[tid] = fmax(sh[tid], sh[tid + o]);
             __syncthreads();
         }
-        if (tid == 0) A.out[slot] = sh[0];
-        return;
+        return tid == 0 ? publish_store(&A.out[slot], sh[0]) : 0ull;
     }
     // a run = `chunks` parts that feed the same slot, n_blocks entries each, `stride` doubles apart; walked as one
     // flat index range with four independent loads in flight per thread (fixed order: bitwise reproducible)
@@ -495,8 +518,9 @@ __device__ __forceinline__ void reduce_slot(const ReduceArgs& A, int slot, doubl
         double r = sh[0];
         for (int i = 0; i < 4; i++)
             if (A.add_slot[i] == slot) r += A.add[i];
-        A.out[slot] = r;
+        return publish_store(&A.out[slot], r);
     }
+    return 0ull;
 }
 #endif
 

@@ -25,8 +25,8 @@ int fail(ssde_handle* h, int code, const std::string& msg) {
 
 namespace ssde_engine {
 
-void destroy(ssde_handle* h) {
-    if (!h) return;
+// everything the handle holds on the device and in pinned memory (the handle itself stays)
+static void release_device(ssde_handle* h) {
     if (h->trace && h->trace_n > 0)
         fprintf(stderr, "[ssde trace] %lld isotropic evaluations, host us per evaluation: plan %.1f | gain table %.1f | main launch %.1f | "
                         "finalize launch %.1f | read-back (blocks until the GPU is done) %.1f\n", (long long)h->trace_n,
@@ -61,6 +61,11 @@ void destroy(ssde_handle* h) {
     h->pub_count.release();
     if (h->par_ev_ok)
         for (int i = 0; i < PAR_RING; i++) (void)hipEventDestroy(h->par_ev[i]);
+}
+
+void destroy(ssde_handle* h) {
+    if (!h) return;
+    release_device(h);
     delete h;
 }
 }  // namespace ssde_engine
@@ -185,7 +190,20 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
 }  // namespace
 
 namespace ssde_engine {
+constexpr int SSDE_RETRY_WITHOUT_DRIFT = -77;     // internal: the drift layout was tried and the data do not qualify
+static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout, bool allow_drift);
 int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
+    int st = build_impl(d, h, part_layout, true);
+    if (st == SSDE_RETRY_WITHOUT_DRIFT) {
+        // the row-varying-drift layout needs a regular grid and no missing row, which only the tiling pass finds out:
+        // start over on the path such a batch takes otherwise
+        release_device(h);
+        *h = ssde_handle();
+        st = build_impl(d, h, part_layout, false);
+    }
+    return st;
+}
+static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout, bool allow_drift) {
     // ---- descriptor checks -------------------------------------------------------------------
     if (d->abi_version != SSDE_ABI_VERSION) return fail(h, SSDE_ERR_ARG, "ssde_desc.abi_version mismatch");
     if (d->model < SSDE_MODEL_BM || d->model > SSDE_MODEL_CIR) return fail(h, SSDE_ERR_MODEL, "Unknown SDE type");
@@ -219,6 +237,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     if (const char* e = getenv("SSDE_W0_RATIO")) h->env_w0_ratio = atof(e);     // 0 = equal windows on the general kernel
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
+    if (const char* e = getenv("SSDE_SHARED_DEEP")) h->env_shared_deep = atoi(e) != 0;
     h->env_own_stream = getenv("SSDE_SYNC_OWN_STREAM") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
     h->sdim = state_dim(d->model, d->n_dim);
@@ -493,10 +512,24 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         const bool iso_ok = !h->has_h && h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
                             !(d->flags & SSDE_FLAG_FORCE_DENSE);
         h->path = iso_ok ? PATH_ISO : PATH_DENSE;
+        // Row-varying DRIFT only (design columns in the rows of mu_1 .. mu_d, everything else constant), many tracks: the
+        // covariance half is as data-independent as with constant coefficients -- the shared-covariance lanes with the
+        // design columns streamed next to the observations (k_iso_drift.hip).  Needs a regular grid and complete tracks,
+        // which the tiling pass below finds out (SSDE_RETRY_WITHOUT_DRIFT otherwise).  Few tracks (C1: one animal) stay on
+        // the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
+        if (!iso_ok && allow_drift && !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) && !(d->flags & (SSDE_FLAG_FORCE_DENSE | SSDE_FLAG_NO_UNIFORM_DT)) &&
+            !getenv("SSDE_NO_DRIFT") && !getenv("SSDE_NO_SHARED") && h->n_stream_cols <= DRIFT_KMAX) {
+            bool mu_only = true;
+            for (auto& sl : h->slots)
+                if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;
+            int min_tracks = 32;
+            if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
+            if (mu_only && h->n_seg >= min_tracks) { h->drift = true; h->path = PATH_ISO; }
+        }
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
         // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic
         // lanes), per-row H_array or a P0 that is not block-identical (full-covariance lanes)
-        const bool tv_ok = !iso_ok && !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
+        const bool tv_ok = !iso_ok && !h->drift && !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
                            (double)n * (TV_RS + 64) * 8.0 < 150e9;
         if (tv_ok) {
             h->tv_dense = h->has_h || !p0_is_isotropic(d, h->p0_iso);
@@ -518,7 +551,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         DevBuf<double> pad_times, pad_obs;
         const double *t_times = d->times, *t_obs = d->obs;
         bool t_on_dev = on_dev;
-        if (h->path == PATH_ISO && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT) && !getenv("SSDE_NO_LATTICE")) {
+        if (h->path == PATH_ISO && !h->drift && !(d->flags & SSDE_FLAG_NO_UNIFORM_DT) && !getenv("SSDE_NO_LATTICE")) {
             int st = lattice_pad(d, h, starts, on_dev, tstarts_pad, pad_times, pad_obs);
             if (st) return st;
             if (h->n_pad > 0) { tn = h->n_pad; t_times = pad_times.p; t_obs = pad_obs.p; t_on_dev = true; }
@@ -535,7 +568,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         const double* p_obs = t_obs;
         if (!t_on_dev) { HIPCHK(h, stage(t_obs, (size_t)tn * d->n_dim, false, s_obs)); p_obs = s_obs.p; }
         std::vector<uint8_t> seg_dirty((size_t)M, 0);
-        if (h->path == PATH_ISO && !getenv("SSDE_NO_REGROUP")) {
+        if (h->path == PATH_ISO && !h->drift && !getenv("SSDE_NO_REGROUP")) {
             DevBuf<int64_t> sd;
             DevBuf<int> fl;
             HIPCHK(h, sd.upload(tstarts));
@@ -671,8 +704,15 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
         pad_times.release(); pad_obs.release();
         h->hbm_bytes = h->tile_doubles * 8;
 
+        if (h->drift) {
+            bool all_clean = h->uniform_dt;
+            for (int g = 0; g < G; g++) all_clean = all_clean && gflags[g] != 0;
+            if (!all_clean) return SSDE_RETRY_WITHOUT_DRIFT;
+            h->drift_nstate = drift_nstate(h->model, h->d, h->n_stream_cols);
+        }
         if (h->path == PATH_ISO) {
-            choose_iso_split(h);
+            if (h->drift) { h->iso_parts = 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+            else choose_iso_split(h);
             // shared-covariance path: regular grid + groups without missing rows
             HIPCHK(h, h->group_flags.upload(gflags));
             {
@@ -740,7 +780,7 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
                 HIPCHK(h, hipHostMalloc((void**)&h->gain_pinned, (size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW * 8,
                                         hipHostMallocDefault));
             }
-            HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * NSTATE_MAX * WAVE));
+            HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
             HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
             h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * NACC_MAX * G;
             h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
@@ -851,7 +891,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     // The stationary CTCRW lanes run the filter as 1/D(q)^2 recursions (k_iso_shared.hip): with closed-loop poles
     // close to 1 their intermediate signals grow like 1/(1-rho)^2 and cancel in the innovation -- below rho = 0.97
     // that costs < 1e-12 relative; above, the evaluation stays on the sequential direction-form filter
-    if (h->use_shared && h->model == SSDE_MODEL_CTCRW && rho > 0.97) return;
+    if (h->use_shared && !h->drift && h->model == SSDE_MODEL_CTCRW && rho > 0.97) return;
     W = (int)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
     W = std::max(W, 16);
     if (h->env_window > 0) W = h->env_window;                             // testing: deliberately short overlaps
@@ -1037,6 +1077,17 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.h = sig * sig;                                    // makeH: sigma_obs * sigma_obs
         for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + L.fe_off[i]];
         for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+        if (h->drift) {
+            // mu_a(i) = intercept + sum_k coef_k X_k(i) (nllk_ctcrw.hpp:143-149): the intercept slot (if any) goes where the
+            // constant-drift kernels keep mu, the streamed columns get their coefficients by the dimension they feed
+            for (int i = 0; i < h->d; i++) a.mu[i] = 0.0;
+            for (auto& sl : h->slots) {
+                if (sl.col < 0) { if (sl.par_j < h->d) a.mu[sl.par_j] = par[sl.pidx]; continue; }
+                if (sl.par_j == 0) a.coefA[sl.col] = par[sl.pidx];
+                else { a.coefB[sl.col] = par[sl.pidx]; a.drift_dim1 |= 1u << sl.col; }
+            }
+            a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+        }
         const double p1 = par[L.off_fe + L.fe_off[h->d]];
         const double p2 = (h->q > h->d + 1) ? par[L.off_fe + L.fe_off[h->d + 1]] : 0.0;
         if (h->model == SSDE_MODEL_CTCRW) {
@@ -1058,10 +1109,12 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         plan_windows(h, a, &a.n_chunks, &a.window);
         if (h->trace) { const double t = tick(); h->trace_us[0] += t - tk0; tk0 = t; }
         a.bnd = h->bnd.p; a.chk = h->chk.p;
+        a.bnd_stride = h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX;
         a.chk_out = out_dev + (1 + L.n_full);
         a.derive = h->env_no_derive ? 0 : 1;
         a.all_clean = (h->use_shared && h->n_clean_groups == h->n_groups) ? 1 : 0;
-        a.nstate_clean = h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
+        a.nstate_clean = h->drift ? h->drift_nstate
+                       : h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
         a.group_flags = h->group_flags.p;
         a.group_mode = 0;
@@ -1077,6 +1130,10 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             // A batch with more track groups than SIMDs needs no time windows to fill the chip, but the lean
             // stationary kernel only exists for windows past the covariance transient: split every track into
             // the transient window and ONE stationary window (same wave, so no extra work items)
+            if (h->drift) {
+                // every row costs the same here (HBM-bound; the table rows and the stationary rows run the same step): plain equal windows
+                a.t0 = 0;
+            } else
             if (a.n_chunks == 1 && h->plan_warmup > 0 && h->max_chunks >= 2 && !h->chunks_forced) {
                 a.n_chunks = 1; a.window = h->plan_warmup;
                 const int s_stat0 = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
@@ -1139,15 +1196,19 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
             IsoArgs b = a;
             b.group_mode = 2;
+            // two response columns: the deeper prefetch rotation when the windows are short (k_iso_shared.inc: run_segment) --
+            // a wave's rate is bytes in flight over latency, and only ~1000 waves with > 1000 rows each reach the read ceiling without it
+            b.deep_prefetch = h->env_shared_deep >= 0 ? h->env_shared_deep : (h->glen_max / std::max(1, a.n_chunks - (a.t0 > 0 ? 1 : 0)) <= 800 ? 1 : 0);
             if (any_dirty) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, s));
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
                 HIPCHK(h, launch_iso(h->model, h->d, ad, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
             }
-            HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+            if (h->drift) HIPCHK(h, launch_iso_drift(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+            else HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
             h->ev_k_valid = h->stamps;
-            h->last_s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+            h->last_s_stat = h->drift ? -1 : (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
         } else {
             if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
@@ -1166,11 +1227,20 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                     if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
             }
         }
-        const int nacc = 4 + h->d;
+        const int nacc = 4 + h->d + (h->drift ? h->n_stream_cols : 0);
         const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
         ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
         ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
         ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
+        if (order >= 1 && h->drift) {
+            // accumulators of k_iso_drift.hip: [value | sigma_obs | mu intercepts | par d | par d+1 | streamed columns]
+            if (!h->fixed[0]) ra.map[0] = 1;
+            for (auto& sl : h->slots) {
+                if (h->fixed[sl.pidx]) continue;
+                const int k = sl.col >= 0 ? 4 + h->d + sl.col : (sl.par_j < h->d ? 2 + sl.par_j : sl.par_j == h->d ? 2 + h->d : 3 + h->d);
+                ra.map[k - 1] = (int16_t)(1 + sl.pidx);
+            }
+        } else
         if (order >= 1) {
             for (int p = 0; p < a.n_parts; p++)
                 for (int k = 1; k < nacc; k++) {

@@ -129,6 +129,7 @@ struct ssde_handle {
     // testing / tuning knobs, read once at create: nothing calls getenv per evaluation
     int env_window = 0, env_tv_waves = 0, env_tv_minlen = 0;
     bool env_no_derive = false, env_no_graph = false;
+    int env_shared_deep = -1;      // SSDE_SHARED_DEEP=0|1: force the prefetch depth of the shared-covariance kernel (d = 2); -1 = by window length
     double env_t0_cost = 3.0;
     double env_w0_ratio = 1.2;     // (measured: 0 .. 1.45 swept, 3 % on CTCRW at 1.2, nothing on the scalar models) cost of a row of window 0 (every direction) over a row of a later window (one derived)
     // recovery from a widened plan (ssde_eval): after `cooldown` evaluations accepted at the first try the boost is
@@ -143,6 +144,8 @@ struct ssde_handle {
     int n_dirty_groups = 0;
     int n_clean_groups = 0;
     bool use_shared = false;
+    bool drift = false;            // row-varying drift on the shared-covariance path (k_iso_drift.hip)
+    int drift_nstate = 0;          // components of its hand-over dumps
     // one-row tracks never reach a kernel; REPORT(aest_all) still shows their a0 (nllk_ctcrw.hpp:196-200, 246)
     std::vector<int64_t> single_rows;
     std::vector<double> single_a0;       // [single_rows.size()][sdim]

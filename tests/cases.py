@@ -140,6 +140,40 @@ def make_spec(name, model, d, *, seed, lengths, variant="const", na_rows=(), irr
     return spec
 
 
+def drift_spec(name, model, d, *, seed, n_tracks=34, lo=6, hi=15, fe_slope=False, smooth_dims=(0,), fix=()):
+    """Row-varying DRIFT only (mu smooth in a covariate; tau, nu / kappa / sigma, sigma_obs constant), many short tracks on
+    a regular grid without missing rows: the configuration the shared-covariance kernel with streamed drift columns takes
+    (k_iso_drift.hip; nllk_ctcrw.hpp:143-149, 211-212, nllk_ou_ssm.hpp:113-124)."""
+    rng = np.random.default_rng(seed)
+    lengths = list(rng.integers(lo, hi, size=n_tracks))
+    ID, times, obs = _tracks(rng, model, d, lengths, irregular=False)
+    n = len(ID)
+    q = n_sde_par(model, d)
+    x = np.clip((np.sin(np.linspace(0, 9, n)) + 1) / 2 + 0.05 * rng.standard_normal(n), 0, 1)
+    X_fe, X_re, S_list = [None] * q, [None] * q, []
+    if fe_slope:
+        X_fe[0] = np.column_stack([np.ones(n), x])
+    for a in smooth_dims:
+        k = 4 + a
+        X_re[a] = bspline_basis(np.clip(x ** (1 + a), 0, 1), n_basis=k)
+        S_list.append(second_difference_penalty(k))
+    spec = dict(name=name, model=model, n_dim=d, ID=ID, times=times, obs=obs, X_fe=X_fe, X_re=X_re if S_list else None,
+                S_list=S_list or None, a0=None, P0=None, H=None, par_fixed=None, na_mode=1, include_penalty=1)
+    p = [rng.uniform(-1.5, 0.0)]
+    for j in range(q):
+        base = rng.uniform(-0.3, 0.5) + (3.0 if (j < d and model == "OU_SSM") else 0.0)
+        p += [base] + ([rng.uniform(-0.4, 0.4)] if (j == 0 and fe_slope) else [])
+    p += list(rng.uniform(-0.5, 1.0, size=len(S_list)))
+    p += list(rng.uniform(-0.3, 0.3, size=sum(s_.shape[0] for s_ in S_list)))
+    spec["par"] = np.array(p)
+    if fix:
+        pb = problem_from_spec(spec)
+        fixed = np.zeros(pb.n_par_full, dtype=np.uint8)
+        fixed[list(fix)] = 1
+        spec["par_fixed"] = fixed
+    return spec
+
+
 def elephant_spec():
     """6-row CTCRW micro-fixture at the vignette's initial parameters
     (par0 = c(0, 0, 1, 1), fixpar = c("mu1", "mu2"): smoothSDE.rmd:476-490)."""
@@ -254,4 +288,9 @@ def all_specs():
     specs.append(make_spec("CTCRW_d2_lattice", "CTCRW", 2, seed=241, lengths=[19, 3, 24, 12], irregular="lattice", na_rows=(5, 30)))
     specs.append(make_spec("OU_SSM_d1_lattice_fixmu", "OU_SSM", 1, seed=242, lengths=[22, 15], irregular="lattice", fix_mu=True))
     specs.append(make_spec("BM_SSM_d3_lattice", "BM_SSM", 3, seed=243, lengths=[14, 18, 9], irregular="lattice", na_rows=(7,), na_mode=0))
+    # row-varying drift on the shared-covariance path (>= 32 complete tracks on a regular grid: k_iso_drift.hip)
+    specs.append(drift_spec("OU_SSM_d1_drift", "OU_SSM", 1, seed=251))
+    specs.append(drift_spec("CTCRW_d2_drift", "CTCRW", 2, seed=252, smooth_dims=(0, 1)))
+    specs.append(drift_spec("BM_SSM_d2_drift_fixsig", "BM_SSM", 2, seed=253, smooth_dims=(1,), fix=(0,)))
+    specs.append(drift_spec("CTCRW_d1_drift_fe", "CTCRW", 1, seed=254, fe_slope=True, smooth_dims=()))
     return specs

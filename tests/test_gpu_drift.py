@@ -1,0 +1,188 @@
+"""GPU suite: shared-covariance Kalman lanes with a ROW-VARYING DRIFT (csrc/k_iso_drift.hip) -- mu smooth in covariates,
+tau / nu / kappa / sigma and sigma_obs constant, regular grid, complete tracks -- against the oracle, the golden vectors
+and the lane = direction path on the same problems.  Reference: nllk_ctcrw.hpp:143-149, 211-212, 238;
+nllk_ou_ssm.hpp:113-124, 174-207; nllk_bm_ssm.hpp:80-86, 138-169.
+
+Tolerances (fp64): value 1e-10 * max(1,|v|); gradient 1e-8 * max|g| + 1e-10 (north-star bar: 1e-8)."""
+import numpy as np
+import pytest
+
+from cases import problem_from_spec
+from golden_io import load_golden
+from smoothsde_amd import capi
+from smoothsde_amd.synth import bspline_basis, second_difference_penalty, simulate
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden()
+PATH_ISO, PATH_TV = 1, 3
+
+
+def _oracle(pb, par, **kw):
+    from oracle_lib import oracle_eval
+    return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=8, **kw)
+
+
+def _close(val, grad, oval, ograd):
+    assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (val, oval)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd)
+
+
+def _is_drift(eng):
+    inf = eng.info()
+    return inf["path"] == PATH_ISO and inf["const_coeff"] == 0
+
+
+DRIFT_GOLD = [r for r in GOLD if "drift" in r["name"]]
+
+
+@pytest.mark.parametrize("rec", DRIFT_GOLD, ids=[r["name"] for r in DRIFT_GOLD])
+def test_golden_drift_cases_take_the_shared_covariance_path(rec, monkeypatch):
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert _is_drift(eng)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    assert eng.eval(rec["par"], order=0) == val
+    aest = eng.report(rec["par"])
+    assert np.allclose(aest, rec["expected"]["aest_all"], rtol=1e-10, atol=1e-10)
+    # the lane = direction kernels on the same problem
+    monkeypatch.setenv("SSDE_NO_DRIFT", "1")
+    engt = capi.Engine(problem_from_spec(rec))
+    assert engt.info()["path"] == PATH_TV
+    vt, gt = engt.eval(rec["par"], order=1)
+    _close(val, grad, vt, gt)
+    eng.close(); engt.close()
+
+
+def _batch(model, d, M, T, ks, seed, fe_slope=False, ragged=False, dt=1.0):
+    """M tracks x T rows; mu_a gets a ks[a]-column spline of a per-row covariate (ks[a] = 0: constant mu_a)."""
+    kw = dict(CTCRW=dict(tau=1.5, nu=0.8), OU_SSM=dict(mu=2.0, tau=2.0, kappa=1.0, z0=2.0), BM_SSM=dict(sigma=0.7))[model]
+    ID, t, o = simulate(model, M, T, d, sigma_obs=0.1, dt=dt, seed=seed, **kw)
+    if ragged:
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(T // 3, T + 1, size=M)
+        keep = np.concatenate([np.arange(T) < L for L in lens])
+        ID, o = ID[keep], o[keep]
+        t = dt * np.arange(1.0, len(ID) + 1)
+    n = len(ID)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 37) + 0.05 * np.random.default_rng(seed + 1).standard_normal(n), 0, 1)
+    q = capi.n_sde_par(model, d)
+    X_fe, X_re, S = [None] * q, [None] * q, []
+    if fe_slope:
+        X_fe[0] = np.column_stack([np.ones(n), x])
+    for a in range(d):
+        if ks[a]:
+            X_re[a] = bspline_basis(np.clip(x ** (1 + a), 0, 1), ks[a])
+            S.append(second_difference_penalty(ks[a]))
+    pb = capi.Problem(model, ID, t, o, X_fe=X_fe, X_re=X_re if S else None, S_list=S or None)
+    rng = np.random.default_rng(seed + 2)
+    par = []
+    for nm in pb.par_names():
+        if nm == "log_sigma_obs":
+            par.append(np.log(0.12))
+        elif nm.startswith("log_lambda"):
+            par.append(0.3)
+        elif nm.startswith("coeff_re"):
+            par.append(0.2 * rng.standard_normal())
+        else:
+            par.append(0.1 * rng.standard_normal() + (2.0 if model == "OU_SSM" and nm.startswith("coeff_fe[0]") else 0.0))
+    par = np.array(par)
+    par[pb.off_fe + pb.fe_off[d]] = np.log(2.0 if model != "BM_SSM" else 0.7)
+    return pb, par
+
+
+@pytest.mark.parametrize("model,d,ks,fe", [("OU_SSM", 1, (9,), False), ("CTCRW", 2, (9, 9), False), ("CTCRW", 1, (5,), True),
+                                            ("BM_SSM", 2, (0, 6), False), ("OU_SSM", 2, (12, 12), True), ("CTCRW", 2, (4, 0), False)])
+def test_long_tracks_with_time_windows_vs_oracle(model, d, ks, fe):
+    pb, par = _batch(model, d, 96, 1500, ks, seed=11, fe_slope=fe)
+    eng = capi.Engine(pb)
+    assert _is_drift(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["window"] > 0 and inf["window_check"] <= 1e-11      # several verified windows
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    # bitwise repeatable, and the value-only call agrees
+    eng.forget()
+    v2, g2 = eng.eval(par)
+    assert v2 == val and np.array_equal(g2, grad)
+    eng.close()
+
+
+def test_ragged_tracks_fixed_parameters_and_a_short_step():
+    pb, par = _batch("CTCRW", 2, 150, 400, (7, 5), seed=5, ragged=True, dt=0.25)
+    fixed = np.zeros(pb.n_par_full, dtype=np.uint8)
+    fixed[[0, pb.off_fe + pb.fe_off[2], pb.off_re + 3]] = 1                    # sigma_obs, tau and one spline coefficient held
+    pb = capi.Problem("CTCRW", pb.id, pb.times, pb.obs, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, par_fixed=fixed)
+    eng = capi.Engine(pb)
+    assert _is_drift(eng)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert grad[0] == 0.0 and grad[pb.off_re + 3] == 0.0
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb, par, report=True)
+    assert np.max(np.abs(aest - oaest)) <= 1e-9 * max(1.0, np.max(np.abs(oaest)))
+    eng.close()
+
+
+def test_missing_rows_or_an_irregular_grid_fall_back_to_the_lane_direction_path():
+    pb, par = _batch("OU_SSM", 1, 64, 300, (6,), seed=7)
+    o = pb.obs.copy()
+    o[1234] = np.nan
+    pbn = capi.Problem("OU_SSM", pb.id, pb.times, o, X_re=pb.X_re, S_list=pb.S_list)
+    eng = capi.Engine(pbn)
+    assert eng.info()["path"] == PATH_TV
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pbn, par))
+    eng.close()
+    t = pb.times.copy()
+    t[5000:] += 0.25
+    t[5001:] += 0.5                                                              # one odd interval inside a track
+    pbi = capi.Problem("OU_SSM", pb.id, t, pb.obs, X_re=pb.X_re, S_list=pb.S_list)
+    eng = capi.Engine(pbi)
+    assert eng.info()["path"] == PATH_TV
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pbi, par))
+    eng.close()
+    # few tracks (one animal): the lane = direction path by design
+    pb1, par1 = _batch("CTCRW", 2, 3, 600, (5, 5), seed=9)
+    eng = capi.Engine(pb1)
+    assert eng.info()["path"] == PATH_TV
+    eng.close()
+
+
+def test_smooths_on_other_parameters_do_not_take_the_drift_path():
+    pb, par = _batch("CTCRW", 1, 64, 200, (5,), seed=3)
+    n = pb.n
+    B = bspline_basis(np.clip(np.linspace(0, 1, n), 0, 1), 4)
+    pb2 = capi.Problem("CTCRW", pb.id, pb.times, pb.obs, X_re=[pb.X_re[0], B, None],
+                       S_list=[second_difference_penalty(5), second_difference_penalty(4)])
+    eng = capi.Engine(pb2)
+    assert eng.info()["path"] == PATH_TV
+    eng.close()
+
+
+def test_sharded_handle_and_one_rank_communicator_on_the_drift_path():
+    pb, par = _batch("OU_SSM", 1, 130, 500, (9,), seed=13)
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    em = capi.Engine(pb, devices=[0, 0, 0])
+    vm, gm = em.eval(par)
+    assert abs(vm - v1) <= 1e-11 * abs(v1) and np.max(np.abs(gm - g1)) <= 1e-9 * np.max(np.abs(g1))
+    e1.comm_init(1, 0, capi.comm_unique_id())
+    v2, g2 = e1.eval(par + 0.0)
+    assert v2 == v1 and np.array_equal(g2, g1)
+    e1.close(); em.close()
+
+
+def test_forced_short_warm_up_is_caught_and_repaired(monkeypatch):
+    pb, par = _batch("CTCRW", 1, 64, 2000, (6,), seed=17)
+    monkeypatch.setenv("SSDE_WINDOW", "2")
+    eng = capi.Engine(pb)
+    assert _is_drift(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["window_retries"] >= 1 and inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb, par))
+    eng.close()
