@@ -33,6 +33,8 @@
  *                         which ssde_eval / ssde_eval_device return the all-reduced batch result on every rank
  *   ssde_laplace_eval  <- what `random = "coeff_re"` makes TMB's fn/gr do (R/sde.R:510-525, 656-658): the Laplace
  *                         approximation of the marginal likelihood over the random-effect coefficients
+ *   ssde_hess          <- MakeADHessObject2 / tmb_obj_joint$he(x) (src/init.c:13; R/sde.R:1363): second derivatives of the
+ *                         joint penalised nllk -- exact for the Gaussian direct families (BM, OU)
  *   ssde_simulate      <- SDE$simulate          (R/sde.R:1393-1500; CTCRW_cov, R/utility.R:188-196): exact-transition
  *                         simulation of a batch of tracks, written straight into HBM in the reference's long format
  *   ssde_set_option    <- (new) per-handle switches of the measurement hooks
@@ -302,9 +304,11 @@ int ssde_forget(ssde_handle *h);
  *           coeff_re entries hold u^ (TMB's par.random / env$last.par)
  *   order   0: *value;  1: also grad[n_par_full] = df/dtheta (zeros at coeff_re and at fixed entries)
  *   hess_uu NULL or [n_u x n_u] column-major: H_uu at u^ (the random-effect block of sdreport's jointPrecision)
- * H_uu comes from central differences of the device gradient, the inner problem is solved by Newton iterations, the
- * gradient is the exact dg/dtheta at u^ plus a differenced 1/2 d log det H_uu / dtheta along the implicit-function
- * tangent of u^ (ssde_laplace.hip).  A joint nllk that has no minimum in u gives *value = +Inf (a rejected step). */
+ * Direct families BM / OU: H_uu and H_u,theta are EXACT (ssde_hess), only 1/2 d log det H_uu / dtheta is a central
+ * difference -- of exact Hessians, along the implicit-function tangent of u^.  Elsewhere H_uu comes from central
+ * differences of the device gradient.  The inner problem is solved by Newton iterations; the gradient is the exact
+ * dg/dtheta at u^ plus that log-determinant term (ssde_laplace.hip).  A joint nllk that has no minimum in u gives
+ * *value = +Inf (a rejected step; `par` is then left untouched). */
 typedef struct ssde_laplace_opts {
     double hess_step;      /* relative step of the Hessian differences   (<= 0: 1e-4) */
     double fd_step;        /* relative step of the log-determinant term  (<= 0: 1e-4) */
@@ -314,6 +318,15 @@ typedef struct ssde_laplace_opts {
 } ssde_laplace_opts;
 int ssde_laplace_eval(ssde_handle *h, double *par, int32_t n_par_full, int32_t order, double *value, double *grad,
                       double *hess_uu, const ssde_laplace_opts *opts);
+
+/* Second derivatives of the joint penalised nllk (ssde_eval's value) over the parameter entries idx[0 .. n_idx):
+ * hess [n_idx x n_idx] column-major.  EXACT -- no differencing -- for the direct families "BM" and "OU" (tr_dens.hpp:32-37,
+ * 45-52) with resident design columns and no decaying terms: the SDE parameters are linear in coeff_fe / coeff_re, so
+ * the data term's Hessian is X' D X with a closed-form per-row D, and the penalty is exp(log_lambda) times a quadratic
+ * form (nllk_sde.hpp:91-124).  idx may name coeff_fe, coeff_re and log_lambda entries, fixed or free.  Every other
+ * model returns SSDE_ERR_MODEL (difference ssde_eval's gradient there, as ssde_laplace_eval does).  Works on
+ * single-device, multi-device and communicator handles (the shards' / ranks' Hessians are summed). */
+int ssde_hess(ssde_handle *h, const double *par, int32_t n_par_full, const int32_t *idx, int32_t n_idx, double *hess);
 
 /* One process per GPU (torchrun / mpirun style hosts).  Rank 0 calls ssde_comm_unique_id (128 bytes, an
  * ncclUniqueId), the host ships it to the other ranks by its own means, then EVERY rank calls ssde_comm_init_rank

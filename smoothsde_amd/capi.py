@@ -494,6 +494,8 @@ def load_library():
     lib.ssde_comm_init_rank.restype = C.c_int
     lib.ssde_simulate.argtypes = [C.POINTER(SsdeSimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ssde_simulate.restype = C.c_int
+    lib.ssde_hess.argtypes = [C.c_void_p, _dp, C.c_int32, _ip, C.c_int32, _dp]
+    lib.ssde_hess.restype = C.c_int
     lib.ssde_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     lib.ssde_set_option.restype = C.c_int
     if lib.ssde_abi_version() != ABI_VERSION:
@@ -510,7 +512,7 @@ WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between 
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
                     "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms", "ssde_kernel_ms_history",
-                    "ssde_simulate", "ssde_set_option")
+                    "ssde_simulate", "ssde_set_option", "ssde_hess")
 
 COMM_ID_BYTES = 128
 
@@ -662,6 +664,16 @@ class Engine:
         out = np.zeros(int(n))
         self._check(self.lib.ssde_kernel_ms_history(self._h, out.ctypes.data_as(_dp), int(n)))
         return out
+
+    def hess(self, par, idx):
+        """ssde_hess: exact second derivatives of the joint penalised nllk over the full-parameter indices `idx` (direct
+        families BM / OU; EngineError with status 2 elsewhere).  Returns an (len(idx), len(idx)) array."""
+        par = np.ascontiguousarray(par, dtype=np.float64)
+        ix = np.ascontiguousarray(idx, dtype=np.int32)
+        H = np.zeros((len(ix), len(ix)), order="F")
+        self._check(self.lib.ssde_hess(self._h, par.ctypes.data_as(_dp), self.n_par_full, ix.ctypes.data_as(_ip), len(ix),
+                                       H.ctypes.data_as(_dp)))
+        return H
 
     def set_option(self, option: int, value: int):
         self._check(self.lib.ssde_set_option(self._h, option, value))

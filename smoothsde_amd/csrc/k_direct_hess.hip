@@ -1,0 +1,163 @@
+// k_direct_hess.hip -- EXACT second derivatives of the data term of the direct families "BM" and "OU" with respect to
+// coefficients of the linear predictor (nllk_sde.hpp:61-84 with tr_dens.hpp:32-37, 45-52), for gfx950.
+//
+// What the reference gets from TMB's second-order AD (tmb_obj_joint$he, R/sde.R:1363; the Laplace approximation's
+// H_uu behind random = "coeff_re", R/sde.R:510-525, 656-658).  The SDE parameters of a row are LINEAR in the
+// coefficients, par_j(i) = sum_k X_k(i) coef_k, so
+//     d2 nllk / d coef_k d coef_l = sum_i X_k(i) X_l(i) D_i[j(k), j(l)],      D_i = d2 (-log dens_i) / d par d par'
+// exactly (the Gauss-Newton form IS the Hessian here), and D_i is closed-form for the Gaussian transitions:
+//   BM   r = (z1 - z0 - mu dt) / sd, sd = e^{ls} sqrt(dt):   D[mu,mu] = dt^2 / sd^2,  D[mu,ls] = 2 r dt / sd,  D[ls,ls] = 2 r^2
+//   OU   l = log(v)/2 + delta^2 / (2 v),  delta = z1 - mu - e (z0 - mu),  v = kappa (1 - e^2),  e = exp(-dt / tau):  chain rule
+//        through (delta, v) with  d e / d log tau = e z,  d2 e / d log tau^2 = e z (z - 1),  z = dt / tau.
+// Lane = row on the long format (the layout of k_direct.hip); the wanted coefficient pairs are cut into HT x HT tiles,
+// one tile per blockIdx.y, accumulated in registers and reduced in a fixed order (bitwise reproducible).  Not a hot
+// kernel: it runs a handful of times per marginal-likelihood evaluation.
+#include "ssde_device.hpp"
+
+namespace ssde {
+
+template <int MODEL, int D>
+__device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, double dt, const double* par, double (&Dm)[MAX_Q][MAX_Q]) {
+#pragma unroll
+    for (int p = 0; p < MAX_Q; p++)
+#pragma unroll
+        for (int q = 0; q < MAX_Q; q++) Dm[p][q] = 0.0;
+    if (MODEL == M_BM) {
+        const double sd = exp(par[D]) * sqrt(dt), isd = 1.0 / sd;
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double z0 = A.obs[(i - 1) + (int64_t)a * A.n], z1 = A.obs[i + (int64_t)a * A.n];
+            if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;          // tr_dens.hpp:31
+            const double r = (z1 - (z0 + par[a] * dt)) * isd;
+            Dm[a][a] = dt * dt * isd * isd;
+            Dm[a][D] = Dm[D][a] = 2.0 * r * dt * isd;
+            Dm[D][D] += 2.0 * r * r;
+        }
+    } else {
+        const double tau = exp(par[D]), kap = exp(par[D + 1]);
+        const double z = dt / tau, e = exp(-z);
+        const double e1 = e * z, e2 = e * z * (z - 1.0);                           // d e / d log tau, d2 e / d log tau^2
+        const double w = 1.0 - e * e, v = kap * w, iv = 1.0 / v;
+        const double v_t = -2.0 * kap * e * e1, v_tt = -2.0 * kap * (e1 * e1 + e * e2);   // v_k = v_kk = v, v_tk = v_t
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double z0 = A.obs[(i - 1) + (int64_t)a * A.n], z1 = A.obs[i + (int64_t)a * A.n];
+            if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;
+            const double mu = par[a];
+            const double dl = z1 - (mu + e * (z0 - mu));
+            const double d_m = -(1.0 - e), d_t = -(z0 - mu) * e1, d_mt = e1, d_tt = -(z0 - mu) * e2;
+            const double L_d = dl * iv, L_v = 0.5 * iv - 0.5 * dl * dl * iv * iv;
+            const double L_dd = iv, L_dv = -dl * iv * iv, L_vv = -0.5 * iv * iv + dl * dl * iv * iv * iv;
+            Dm[a][a] = L_dd * d_m * d_m;
+            const double h_mt = L_dd * d_m * d_t + L_dv * d_m * v_t + L_d * d_mt;
+            const double h_mk = L_dv * d_m * v;
+            Dm[a][D] = Dm[D][a] = h_mt;
+            Dm[a][D + 1] = Dm[D + 1][a] = h_mk;
+            Dm[D][D] += L_dd * d_t * d_t + 2.0 * L_dv * d_t * v_t + L_vv * v_t * v_t + L_d * d_tt + L_v * v_tt;
+            const double h_tk = L_dv * d_t * v + L_vv * v_t * v + L_v * v_t;
+            Dm[D][D + 1] += h_tk;
+            Dm[D + 1][D + 1] += L_vv * v * v + L_v * v;
+        }
+        Dm[D + 1][D] = Dm[D][D + 1];
+    }
+}
+
+__device__ __forceinline__ double pick4(const double (&r)[MAX_Q], int j) {      // (uniform j: scalar selects, no scratch)
+    return j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
+}
+
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A) {
+    const SlotTable* __restrict__ T = A.slots;
+    const int ns = A.n_slots;
+    const int tile = blockIdx.y, ti = A.tile_i[tile], tj = A.tile_j[tile];
+    double acc[HESS_T][HESS_T];
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) acc[a][b] = 0.0;
+    // the tile's coefficients: slot, parameter, column pointer (NULL = intercept: X = 1)
+    int ja[HESS_T], jb[HESS_T];
+    const double *ca[HESS_T], *cb[HESS_T];
+    bool oa[HESS_T], ob[HESS_T];
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++) {
+        const int ka = ti * HESS_T + a, kb = tj * HESS_T + a;
+        oa[a] = ka < A.nu; ob[a] = kb < A.nu;
+        const int sa = oa[a] ? A.uslot[ka] : 0, sb = ob[a] ? A.uslot[kb] : 0;
+        ja[a] = T->par_j[sa]; jb[a] = T->par_j[sb];
+        ca[a] = T->col[sa] >= 0 ? A.cols[T->col[sa]] : nullptr;
+        cb[a] = T->col[sb] >= 0 ? A.cols[T->col[sb]] : nullptr;
+    }
+    const int64_t per_block = ((A.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t row_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t row_hi = row_lo + per_block < A.n ? row_lo + per_block : A.n;
+    for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
+        if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
+        const double dt = A.times[i] - A.times[i - 1];                             // dtimes(i-1), nllk_sde.hpp:37, 80
+        double par[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < ns; k++) {                                             // the linear predictor of row i-1 (Q6)
+            const int c = T->col[k], j = T->par_j[k];
+            const double x = c >= 0 ? A.cols[c][i - 1] : 1.0;
+            const double t = x * A.par[T->pidx[k]];
+            par[0] += j == 0 ? t : 0.0; par[1] += j == 1 ? t : 0.0; par[2] += j == 2 ? t : 0.0; par[3] += j == 3 ? t : 0.0;
+        }
+        double Dm[MAX_Q][MAX_Q];
+        row_hessian<MODEL, D>(A, i, dt, par, Dm);
+        double xb[HESS_T];
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) xb[b] = !ob[b] ? 0.0 : (cb[b] ? cb[b][i - 1] : 1.0);
+#pragma unroll
+        for (int a = 0; a < HESS_T; a++) {
+            if (!oa[a]) continue;                                                  // (uniform)
+            const double xa = ca[a] ? ca[a][i - 1] : 1.0;
+            double row[MAX_Q];                                                     // X_a D[j_a, .]
+#pragma unroll
+            for (int q = 0; q < MAX_Q; q++) row[q] = xa * (ja[a] == 0 ? Dm[0][q] : ja[a] == 1 ? Dm[1][q] : ja[a] == 2 ? Dm[2][q] : Dm[3][q]);
+#pragma unroll
+            for (int b = 0; b < HESS_T; b++) acc[a][b] = fma(pick4(row, jb[b]), xb[b], acc[a][b]);
+        }
+    }
+    // workgroup sums in a fixed order: [tile][a * HESS_T + b][block]
+    __shared__ double sh[256];
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) {
+            sh[threadIdx.x] = acc[a][b];
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) A.partials[((int64_t)tile * HESS_T * HESS_T + a * HESS_T + b) * gridDim.x + blockIdx.x] = sh[0];
+            __syncthreads();
+        }
+}
+
+// H[k + l nu] (and its mirror) = sum over blocks of the tile's partials, in block order
+__global__ __launch_bounds__(64) void direct_hess_reduce_kernel(const DirectHessArgs A, int n_blocks) {
+    const int tile = blockIdx.x, e = blockIdx.y, a = e / HESS_T, b = e % HESS_T;
+    const int k = A.tile_i[tile] * HESS_T + a, l = A.tile_j[tile] * HESS_T + b;
+    if (k >= A.nu || l >= A.nu) return;
+    const double* p = A.partials + ((int64_t)tile * HESS_T * HESS_T + e) * n_blocks;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) { A.hess[k + (int64_t)l * A.nu] = s; A.hess[l + (int64_t)k * A.nu] = s; }
+}
+
+hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks, hipStream_t s) {
+    dim3 grid(n_blocks, n_tiles), block(256);
+    if (a.model == M_BM && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 1>), grid, block, 0, s, a);
+    else if (a.model == M_BM && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 2>), grid, block, 0, s, a);
+    else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 1>), grid, block, 0, s, a);
+    else if (a.model == M_OU && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 2>), grid, block, 0, s, a);
+    else return hipErrorInvalidValue;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(direct_hess_reduce_kernel, dim3(n_tiles, HESS_T * HESS_T), dim3(64), 0, s, a, n_blocks);
+    return hipGetLastError();
+}
+
+}  // namespace ssde

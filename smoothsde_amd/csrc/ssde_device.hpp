@@ -281,6 +281,26 @@ struct DirectFastArgs {
     PPRef ppA, ppB;               // groups evaluated on the fly from a basis table (x != NULL)
 };
 hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s);
+// exact Hessian of the data term over coefficients of the linear predictor, BM / OU (k_direct_hess.hip)
+constexpr int HESS_T = 8;         // coefficient pairs are cut into HESS_T x HESS_T tiles
+struct DirectHessArgs {
+    const double* times;
+    const double* obs;
+    const double* const* cols;
+    const uint32_t* scored;
+    int64_t n;
+    int d, model, any_nan;
+    const SlotTable* slots;      // device
+    const double* par;           // device, full parameter vector
+    int n_slots;
+    int nu;                      // wanted coefficients
+    const int16_t* uslot;        // device [nu]: slot of every wanted coefficient
+    const int16_t* tile_i;       // device [n_tiles]: tile (ti, tj), ti <= tj
+    const int16_t* tile_j;
+    double* partials;            // [n_tiles][HESS_T * HESS_T][n_blocks]
+    double* hess;                // [nu x nu] column-major
+};
+hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks, hipStream_t s);
 hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t n, double* out2_per_block, int n_blocks,
                             hipStream_t s);
 

@@ -409,7 +409,9 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         h->pub_flag = (unsigned long long*)(h->pub_pinned + words);
         HIPCHK(h, h->pub_count.alloc(1));
         HIPCHK(h, hipMemset(h->pub_count.p, 0, sizeof(unsigned int)));
-        h->pub_ok = getenv("SSDE_NO_PUBLISH") == nullptr;
+        // measured in the engine (tools/bench_strong.py, same session): 27-30 us outside the kernel either way -- the read-back
+        // copy it saves is paid back in the counting and the system-scope store; opt-in, for the record
+        h->pub_ok = getenv("SSDE_PUBLISH") != nullptr;
     }
     for (auto& pr : h->ev_ring) { HIPCHK(h, hipEventCreate(&pr[0])); HIPCHK(h, hipEventCreate(&pr[1])); }
     h->ev_k0 = h->ev_ring[0][0]; h->ev_k1 = h->ev_ring[0][1];
@@ -1535,7 +1537,8 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
     // evaluation's sequence number after it: spin on that word.  (tools/microbench_latency.hip, 40-us kernel: 12.7 us of
     // fixed overhead against 17.9 with the blocking 48-byte copy this replaces and 25.7 with the copy and event-stamped
     // launches.  Rounds 1 and 2 had measured a pinned mirror as SLOWER; that was with the stamps on and a host that
-    // synchronised the stream first.)  SSDE_NO_PUBLISH=1 keeps the blocking copy for A/B.
+    // synchronised the stream first.)  In the engine the two measure the same (round 3, fence-free counting); the blocking copy
+    // stays the default and SSDE_PUBLISH=1 selects the spin.
     if (h->pub_armed) {
         h->pub_armed = false;
         const unsigned long long want = h->pub_seq;
@@ -1878,6 +1881,11 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->required_bytes_per_row = info->algo_bytes_per_row -
         (((h->path == PATH_ISO || h->path == PATH_DENSE) && h->c_obs == 0) || (h->path == PATH_ISO && h->uniform_dt) || (h->path == PATH_DIRECT && h->direct_fast && h->direct_uniform_dt && h->df_ja != h->d && h->df_jb != h->d &&
           h->df_ja != h->d + 1 && h->df_jb != h->d + 1 && h->model != SSDE_MODEL_BM_T && h->model != SSDE_MODEL_CIR) ? 8.0 : 0.0);
+    if (h->path == PATH_DIRECT && h->direct_fast) {
+        // a block evaluated on the fly from its basis table is read as 8 B/row of covariate, not as its K streamed columns
+        if (h->df_ja >= 0 && h->pp_fast[h->df_ja]) info->required_bytes_per_row -= 8.0 * ((double)h->df_pidxA.size() - 1.0);
+        if (h->df_jb >= 0 && h->pp_fast[h->df_jb]) info->required_bytes_per_row -= 8.0 * ((double)h->df_pidxB.size() - 1.0);
+    }
     if (h->n_pad > 0) info->required_bytes_per_row *= (double)h->n_pad / (double)h->n;
     if (h->path == PATH_ISO || h->path == PATH_DENSE) {
         info->n_rows_tiled = h->n_pad > 0 ? h->n_pad : h->n;

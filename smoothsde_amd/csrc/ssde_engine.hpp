@@ -298,6 +298,10 @@ int report_sharded(ssde_handle* parent, const double* par, double* aest_all);
 void destroy_dist(ssde_handle* h);
 hipError_t launch_sum_into(double* dst, const double* src, int n, hipStream_t s);   // k_reduce.hip
 
+// ---- exact second derivatives, direct families BM / OU (ssde_hess.hip) -------------------------------------------------
+bool hess_exact_available(const ssde_handle* h);
+int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H);
+
 // copy a caller array (host or device) into a fresh device buffer
 template <class T>
 inline hipError_t stage(const T* src, size_t count, bool on_device, DevBuf<T>& dst) {

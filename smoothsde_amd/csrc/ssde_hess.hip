@@ -1,0 +1,159 @@
+// ssde_hess.hip -- ssde_hess: second derivatives of the joint penalised nllk, the counterpart of tmb_obj_joint$he(x)
+// (MakeADHessObject2, src/init.c:13; used at R/sde.R:1363) and of the H_uu block TMB's Laplace approximation needs
+// (random = "coeff_re", R/sde.R:510-525, 656-658).
+//
+// EXACT for the Gaussian direct families BM and OU: their SDE parameters are linear in the coefficients, so the Hessian
+// of the data term is X' D X with the closed-form per-row D of k_direct_hess.hip, and the smoothing penalty is a
+// quadratic form in coeff_re times exp(log_lambda) (nllk_sde.hpp:91-124): nothing is differenced.  Every other model
+// returns SSDE_ERR_MODEL: the documented route there is central differences of ssde_eval's gradient (what
+// ssde_laplace_eval, smoothsde_amd/report.py and R_glue's he() do).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ssde_comm.hpp"
+#include "ssde_engine.hpp"
+
+namespace ssde_engine {
+
+bool hess_exact_available(const ssde_handle* h) {
+    const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
+    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return false;
+    for (const ssde_handle* s : h->shards) if (s->path != PATH_DIRECT) return false;
+    auto resident = [](const ssde_handle* g) {
+        for (auto& sl : g->slots) if (sl.col == -2) return false;          // a block evaluated from its basis table has no columns to read
+        return true;
+    };
+    if (h->shards.empty()) return resident(h);
+    for (const ssde_handle* s : h->shards) if (!resident(s)) return false;
+    return h->n_dim_parts <= 1;
+}
+
+// data-term Hessian of ONE engine over the coefficients with full-parameter indices idx[] (slots only), left in the
+// device buffer `hess_dev` (nu x nu, column-major) on stream s
+static int hess_data_device(ssde_handle* h, const double* par, const std::vector<int>& idx, DevBuf<double>& hess_dev, hipStream_t s) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nu = (int)idx.size();
+    std::vector<int16_t> uslot(nu, 0);
+    for (int k = 0; k < nu; k++) {
+        int found = -1;
+        for (size_t t = 0; t < h->slots.size(); t++) if (h->slots[t].pidx == idx[k]) found = (int)t;
+        if (found < 0) { h->err = "ssde_hess: internal: index without a coefficient slot"; return SSDE_ERR_ARG; }
+        uslot[k] = (int16_t)found;
+    }
+    const int nt = (nu + HESS_T - 1) / HESS_T;
+    std::vector<int16_t> ti, tj;
+    for (int a = 0; a < nt; a++) for (int b = a; b < nt; b++) { ti.push_back((int16_t)a); tj.push_back((int16_t)b); }
+    const int n_tiles = (int)ti.size();
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->n + 2047) / 2048));
+    DevBuf<int16_t> d_us, d_ti, d_tj;
+    DevBuf<double> partials;
+    HIPCHK(h, d_us.upload(uslot)); HIPCHK(h, d_ti.upload(ti)); HIPCHK(h, d_tj.upload(tj));
+    HIPCHK(h, partials.alloc((size_t)n_tiles * HESS_T * HESS_T * n_blocks));
+    HIPCHK(h, hess_dev.alloc((size_t)nu * nu));
+    const double* pdev = nullptr;
+    int st = push_par(h, par, s, &pdev);
+    if (st) return st;
+    DirectHessArgs a;
+    memset(&a, 0, sizeof(a));
+    a.times = h->times.p; a.obs = h->obs.p; a.cols = h->colptr.p; a.scored = h->scored.p; a.n = h->n;
+    a.d = h->d; a.model = h->model; a.any_nan = h->na_any; a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
+    a.nu = nu; a.uslot = d_us.p; a.tile_i = d_ti.p; a.tile_j = d_tj.p; a.partials = partials.p; a.hess = hess_dev.p;
+    HIPCHK(h, launch_direct_hess(a, n_tiles, n_blocks, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    d_us.release(); d_ti.release(); d_tj.release(); partials.release();
+    return SSDE_OK;
+}
+
+// H (n_idx x n_idx, column-major, host) of the joint penalised nllk over the full-parameter indices idx[]
+int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H) {
+    if (!hess_exact_available(h)) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU with resident design columns and no decaying terms"; return SSDE_ERR_MODEL; }
+    const ParLayout& L = h->L;
+    const int np = L.n_full;
+    for (int k = 0; k < n_idx; k++)
+        if (idx[k] < 0 || idx[k] >= np) { h->err = "ssde_hess: index out of range"; return SSDE_ERR_ARG; }
+    for (size_t k = 0; k < (size_t)n_idx * n_idx; k++) H[k] = 0.0;
+    // ---- data term: the entries that are coefficients of the linear predictor -------------------------------------
+    std::vector<int> cidx, cpos;
+    for (int k = 0; k < n_idx; k++) {
+        const bool is_coef = (idx[k] >= L.off_fe && idx[k] < L.off_fe + L.n_fe) || (idx[k] >= L.off_re && idx[k] < L.off_re + L.n_re);
+        if (is_coef) { cidx.push_back(idx[k]); cpos.push_back(k); }
+    }
+    const int nu = (int)cidx.size();
+    if (nu > MAX_COLS) { h->err = "ssde_hess: more than 96 coefficients"; return SSDE_ERR_ARG; }
+    if (nu > 0) {
+        std::vector<double> Hd((size_t)nu * nu, 0.0), tmp((size_t)nu * nu);
+        auto one = [&](ssde_handle* e, bool all_reduce) -> int {
+            DevBuf<double> hd;
+            hipStream_t s = e->own_stream ? e->own_stream : 0;
+            int st = hess_data_device(e, par, cidx, hd, s);
+            if (st) { h->err = e->err; hd.release(); return st; }
+            if (all_reduce) {
+                // ranks of a communicator: the batch's Hessian is the sum of the ranks' (tracks are independent)
+                ncclResult_t r = rccl().AllReduce(hd.p, hd.p, (size_t)nu * nu, ncclDouble, ncclSum, (ncclComm_t)h->comms[0], s);
+                if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + rccl().GetErrorString(r); hd.release(); return SSDE_ERR_HIP; }
+                if (hipStreamSynchronize(s) != hipSuccess) { h->err = "ssde_hess: stream synchronisation failed"; hd.release(); return SSDE_ERR_HIP; }
+            }
+            hipError_t ce = hipMemcpy(tmp.data(), hd.p, (size_t)nu * nu * 8, hipMemcpyDeviceToHost);
+            hd.release();
+            if (ce != hipSuccess) { h->err = "ssde_hess: read-back failed"; return SSDE_ERR_HIP; }
+            for (size_t k = 0; k < tmp.size(); k++) Hd[k] += tmp[k];
+            return SSDE_OK;
+        };
+        if (h->shards.empty()) {
+            int st = one(h, !h->comms.empty());
+            if (st) return st;
+        } else {
+            int dev_before = 0;
+            (void)hipGetDevice(&dev_before);
+            for (ssde_handle* sh : h->shards) {
+                int st = one(sh, false);
+                if (st) { (void)hipSetDevice(dev_before); return st; }
+            }
+            (void)hipSetDevice(dev_before);
+        }
+        for (int a = 0; a < nu; a++)
+            for (int b = 0; b < nu; b++) H[cpos[a] + (size_t)cpos[b] * n_idx] = Hd[a + (size_t)b * nu];
+    }
+    // ---- smoothing penalty (nllk_sde.hpp:91-124): sum_s [ -Sn/2 log_lambda_s + exp(log_lambda_s)/2 b_s' S_s b_s ] -----
+    const Penalty& P = h->pen;
+    if (!P.ncol.empty() && P.include_penalty) {
+        std::vector<int> where(np, -1);
+        for (int k = 0; k < n_idx; k++) where[idx[k]] = k;
+        int start = 0;
+        for (size_t s = 0; s < P.ncol.size(); s++) {
+            const int n = P.ncol[s];
+            const double lam = std::exp(par[L.off_lambda + s]);
+            const double* b = par + L.off_re + start;
+            const int wl = where[L.off_lambda + (int)s];
+            double quad = 0.0;
+            std::vector<double> Sb(n, 0.0);                 // (S + S') b / 2
+            for (int a = 0; a < n; a++) {
+                double sx = 0.0, stx = 0.0;
+                for (int c = 0; c < n; c++) { sx += P.S[s][a + (size_t)c * n] * b[c]; stx += P.S[s][c + (size_t)a * n] * b[c]; }
+                quad += b[a] * sx;
+                Sb[a] = 0.5 * (sx + stx);
+            }
+            if (wl >= 0) H[wl + (size_t)wl * n_idx] += 0.5 * lam * quad;
+            for (int a = 0; a < n; a++) {
+                const int wa = where[L.off_re + start + a];
+                if (wa < 0) continue;
+                if (wl >= 0) { H[wa + (size_t)wl * n_idx] += lam * Sb[a]; H[wl + (size_t)wa * n_idx] += lam * Sb[a]; }
+                for (int c = 0; c < n; c++) {
+                    const int wc = where[L.off_re + start + c];
+                    if (wc >= 0) H[wa + (size_t)wc * n_idx] += 0.5 * lam * (P.S[s][a + (size_t)c * n] + P.S[s][c + (size_t)a * n]);
+                }
+            }
+            start += n;
+        }
+    }
+    return SSDE_OK;
+}
+
+}  // namespace ssde_engine
+
+extern "C" int ssde_hess(ssde_handle* h, const double* par, int32_t n_par_full, const int32_t* idx, int32_t n_idx, double* hess) {
+    if (!h || !par || !idx || !hess || n_idx < 1) return SSDE_ERR_ARG;
+    if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
+    return ssde_engine::hess_exact(h, par, idx, n_idx, hess);
+}

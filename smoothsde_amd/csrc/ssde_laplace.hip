@@ -69,6 +69,7 @@ struct Laplace {
     std::vector<int> ir;               // coeff_re entries that are not fixed
     double hess_step, fd_step, newton_tol;
     int max_newton;
+    bool exact = false;                // exact second derivatives available (ssde_engine::hess_exact_available)
     std::vector<double> work, grad;
 
     int joint(const std::vector<double>& par, double* v, std::vector<double>* g) {
@@ -128,6 +129,10 @@ struct Laplace {
     // H_uu at (par): central differences of the gradient, symmetrised
     int hess_uu(const std::vector<double>& par, std::vector<double>& H) {
         H.assign((size_t)nu * nu, 0.0);
+        if (exact) {                                 // direct families BM / OU: X' D X + lambda S, nothing differenced (ssde_hess.hip)
+            std::vector<int32_t> ix(ir.begin(), ir.end());
+            return ssde_engine::hess_exact(h, par.data(), ix.data(), nu, H.data());
+        }
         std::vector<std::vector<double>> P;
         std::vector<double> steps((size_t)nu);
         for (int k = 0; k < nu; k++) {
@@ -192,7 +197,7 @@ struct Laplace {
             double smax = 0.0, umax = 0.0;
             for (int i = 0; i < nu; i++) { smax = std::max(smax, std::fabs(t * step[i])); umax = std::max(umax, std::fabs(p_new[ir[i]])); }
             par = p_new; *val = v_new; g = g_new;
-            h_current = smax <= 1e-3 * hess_step * std::max(1.0, umax);   // H moved by less than its own differencing error
+            h_current = smax <= (exact ? 1e-12 : 1e-3 * hess_step) * std::max(1.0, umax);   // H moved by less than its own (differencing) error
             if (smax <= newton_tol * std::max(1.0, umax)) break;
         }
         if (!h_current && std::isfinite(*val)) {
@@ -212,9 +217,11 @@ extern "C" int ssde_laplace_eval(ssde_handle* h, double* par, int32_t n_par_full
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     Laplace lp;
     lp.h = h; lp.np = n_par_full;
+    lp.exact = ssde_engine::hess_exact_available(h);
     lp.hess_step = (opts && opts->hess_step > 0) ? opts->hess_step : 1e-4;
-    lp.fd_step = (opts && opts->fd_step > 0) ? opts->fd_step : 1e-4;
-    lp.newton_tol = (opts && opts->newton_tol > 0) ? opts->newton_tol : 1e-8;
+    // the log-determinant term differences H_uu: with exact Hessians a shorter step is affordable (truncation e^2, rounding 1e-16 / e)
+    lp.fd_step = (opts && opts->fd_step > 0) ? opts->fd_step : (lp.exact ? 1e-5 : 1e-4);
+    lp.newton_tol = (opts && opts->newton_tol > 0) ? opts->newton_tol : (lp.exact ? 1e-10 : 1e-8);   // (exact Hessians: Newton converges quadratically)
     lp.max_newton = (opts && opts->max_newton > 0) ? opts->max_newton : 30;
     for (int k = 0; k < h->L.n_re; k++)
         if (!h->fixed[h->L.off_re + k]) lp.ir.push_back(h->L.off_re + k);
@@ -242,18 +249,35 @@ extern "C" int ssde_laplace_eval(ssde_handle* h, double* par, int32_t n_par_full
     std::vector<uint8_t> is_u(np, 0);
     for (int i = 0; i < nu; i++) is_u[lp.ir[i]] = 1;
     std::vector<double> pp, gp, gm, Hk, du(nu);
-    for (int k = 0; k < np; k++) {
-        if (h->fixed[k] || is_u[k]) continue;
+    // H_u,theta for every outer parameter at once where second derivatives are exact
+    std::vector<int> outer;
+    for (int k = 0; k < np; k++) if (!h->fixed[k] && !is_u[k]) outer.push_back(k);
+    std::vector<double> Hfull;
+    const int no = (int)outer.size(), nf = nu + no;
+    if (lp.exact && no > 0) {
+        std::vector<int32_t> ix;
+        for (int i = 0; i < nu; i++) ix.push_back(lp.ir[i]);
+        for (int k : outer) ix.push_back(k);
+        Hfull.assign((size_t)nf * nf, 0.0);
+        st = ssde_engine::hess_exact(h, p.data(), ix.data(), nf, Hfull.data());
+        if (st) return st;
+    }
+    for (int ko = 0; ko < no; ko++) {
+        const int k = outer[ko];
         const double e = lp.fd_step * std::max(1.0, std::fabs(p[k]));
         // H_u,theta_k and the tangent of u^(theta)
-        double v;
-        pp = p; pp[k] = p[k] + e;
-        st = lp.joint(pp, &v, &gp);
-        if (st) return st;
-        pp[k] = p[k] - e;
-        st = lp.joint(pp, &v, &gm);
-        if (st) return st;
-        for (int i = 0; i < nu; i++) du[i] = (gp[lp.ir[i]] - gm[lp.ir[i]]) / (2.0 * e);
+        if (lp.exact) {
+            for (int i = 0; i < nu; i++) du[i] = Hfull[i + (size_t)(nu + ko) * nf];
+        } else {
+            double v;
+            pp = p; pp[k] = p[k] + e;
+            st = lp.joint(pp, &v, &gp);
+            if (st) return st;
+            pp[k] = p[k] - e;
+            st = lp.joint(pp, &v, &gm);
+            if (st) return st;
+            for (int i = 0; i < nu; i++) du[i] = (gp[lp.ir[i]] - gm[lp.ir[i]]) / (2.0 * e);
+        }
         chol_solve(Lm, nu, du);                                       // du = H^-1 H_u,theta_k;  du^/dtheta_k = -du
         double half_ld[2] = {0.0, 0.0};
         bool okk = true;

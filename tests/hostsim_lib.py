@@ -14,8 +14,10 @@ _lp = C.POINTER(C.c_int64)
 def load():
     global _LIB
     if _LIB is None:
-        subprocess.run(["make", "-s", "-C", _DIR], check=True)
-        lib = C.CDLL(os.path.join(_DIR, "libhostsim.so"))
+        alt = os.environ.get("SSDE_ORACLE_LIBDIR")           # tools/sanitize_cpu.sh: the sanitizer build
+        if not alt:
+            subprocess.run(["make", "-s", "-C", _DIR], check=True)
+        lib = C.CDLL(os.path.join(alt or _DIR, "libhostsim.so"))
         lib.hostsim_kalman_iso.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp,
                                            _dp, _dp, _dp, _dp, _dp]
         lib.hostsim_kalman_iso.restype = C.c_int

@@ -14,7 +14,8 @@ import numpy as np
 from smoothsde_amd.capi import Problem, SsdeDesc
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+# SSDE_ORACLE_LIBDIR: load the checker's libraries from another directory (tools/sanitize_cpu.sh: ASan / UBSan builds)
+_ORACLE_DIR = os.environ.get("SSDE_ORACLE_LIBDIR") or os.path.join(_ROOT, "oracle")
 _LIB = None
 _dp = C.POINTER(C.c_double)
 

@@ -3,9 +3,11 @@
 device gradient, against EXACT references that share nothing with the engine: the dense joint-Gaussian / Normal-density
 restatements of tests/refimpl.py under torch autograd (exact Hessians, tight inner solves).
 
-Tolerances: marginal value 1e-6 relative (the engine's H_uu is a central difference of the device gradient), u_hat 1e-5,
-marginal gradient 1e-4 of its largest entry (its log-determinant term is a difference of differenced Hessians),
-Hessian blocks 1e-5 relative."""
+Tolerances, Kalman families: marginal value 1e-6 relative (the engine's H_uu is a central difference of the device gradient),
+u_hat 1e-5, marginal gradient 1e-4 of its largest entry (its log-determinant term is a difference of differenced
+Hessians), Hessian blocks 1e-5 relative.  Direct families BM / OU (exact second derivatives, ssde_hess): Hessians 1e-10,
+marginal value 1e-10, u_hat 1e-8, marginal gradient 1e-7 against the EXACT Laplace gradient (implicit-function
+differentiation of the dense restatement under torch autograd)."""
 import numpy as np
 import pytest
 import torch
@@ -112,4 +114,94 @@ def test_sdreport_quantities_on_the_device_gradient_match_autograd_hessians(name
     H = torch.autograd.functional.hessian(obj, torch.tensor(par[io])).numpy()
     assert np.allclose(rep.hessian_fixed, H, rtol=1e-5, atol=1e-6 * np.max(np.abs(H)))
     assert np.allclose(rep.cov_fixed, np.linalg.inv(H), rtol=1e-4, atol=1e-6 * np.max(np.abs(np.linalg.inv(H))))
+    eng.close()
+
+
+# ---- exact second derivatives (ssde_hess: direct families BM / OU) -----------------------------------------------------
+def _joint_fn(pb, p0, idx):
+    def f(x):
+        p = p0.clone()
+        p[list(idx)] = x
+        return (kalman_dense_nllk(pb, p) if pb.kalman else direct_nllk(pb, p)) + penalty(pb, p)
+    return f
+
+
+@pytest.mark.parametrize("name", ["OU_d1_tv", "OU_d2_tv", "BM_d1_tv", "BM_d2_tv", "OU_d1_tv2", "OU_d1_const", "BM_d2_const"])
+def test_exact_hessian_matches_autograd(name):
+    """tmb_obj_joint$he(x) (R/sde.R:1363): every coefficient and log_lambda entry, missing rows included."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not (pb.off_decay <= k < pb.off_decay + pb.n_decay)]
+    eng = capi.Engine(pb)
+    H = eng.hess(par, idx)
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
+    assert np.allclose(H, H.T, rtol=0, atol=1e-12 * np.max(np.abs(H)))
+    assert np.max(np.abs(H - H_exact)) <= 1e-10 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
+    # a subset in another order is the same numbers
+    sub = idx[::-2]
+    Hs = eng.hess(par, sub)
+    pos = [idx.index(k) for k in sub]
+    assert np.array_equal(Hs, H[np.ix_(pos, pos)])
+    # shards of whole tracks sum to the batch's Hessian
+    em = capi.Engine(pb, devices=[0, 0])
+    Hm = em.hess(par, idx)
+    assert np.max(np.abs(Hm - H)) <= 1e-12 * np.max(np.abs(H))
+    eng.close(); em.close()
+
+
+def test_exact_hessian_is_refused_where_it_does_not_exist():
+    for name in ("CTCRW_d1_tv", "BM_t_d1_tv", "OU_d1_decay"):
+        rec = GOLD[name]
+        pb = problem_from_spec(rec)
+        eng = capi.Engine(pb)
+        with pytest.raises(capi.EngineError, match="exact second derivatives"):
+            eng.hess(rec["par"], [pb.off_fe])
+        eng.close()
+
+
+def _exact_marginal_gradient(pb, p_hat, io, ir):
+    """df/dtheta of the Laplace marginal at (theta, u_hat): partial derivative of g + 1/2 log det H_uu at fixed u, plus the
+    dependence of log det H_uu on u_hat(theta) through du_hat/dtheta = -H_uu^-1 H_u,theta (dg/du = 0 at u_hat)."""
+    p0 = torch.tensor(p_hat)
+    nt = len(io)
+
+    def joint(theta, u):
+        p = p0.clone()
+        p[list(io)] = theta
+        p[list(ir)] = u
+        return (kalman_dense_nllk(pb, p) if pb.kalman else direct_nllk(pb, p)) + penalty(pb, p)
+
+    theta = torch.tensor(p_hat[io], requires_grad=True)
+    u = torch.tensor(p_hat[ir], requires_grad=True)
+    g_theta, = torch.autograd.grad(joint(theta, u), theta)
+    H = torch.autograd.functional.hessian(lambda uu: joint(theta, uu), u, create_graph=True)
+    hl = 0.5 * torch.logdet(H)
+    hl_theta, hl_u = torch.autograd.grad(hl, (theta, u))
+    full = torch.autograd.functional.hessian(lambda x: joint(x[:nt], x[nt:]), torch.cat([theta.detach(), u.detach()]))
+    du = -torch.linalg.solve(full[nt:, nt:], full[nt:, :nt])
+    return (g_theta + hl_theta + du.T @ hl_u).numpy()
+
+
+@pytest.mark.parametrize("name", ["OU_d1_tv", "BM_d2_tv", "OU_d1_tv2"])
+def test_laplace_gradient_with_exact_hessians_reaches_1e_7(name):
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    io, ir = _split(pb)
+    eng = capi.Engine(pb)
+    n0 = eng.info()["n_evals"]
+    f, g, p_hat, H = eng.laplace_eval(par, order=1, want_hessian=True)
+    n_joint = eng.info()["n_evals"] - n0
+    f_exact, u_exact = _exact_laplace(pb, par, ir)
+    assert abs(f - f_exact) <= 1e-10 * max(1.0, abs(f_exact)), (f, f_exact)
+    assert np.max(np.abs(p_hat[ir] - u_exact)) <= 1e-8
+    pe = par.copy()
+    pe[ir] = u_exact
+    g_exact = _exact_marginal_gradient(pb, pe, io, ir)
+    assert np.max(np.abs(g[io] - g_exact)) <= 1e-7 * max(1.0, np.max(np.abs(g_exact))), (g[io], g_exact)
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(pe), ir), torch.tensor(u_exact)).numpy()
+    assert np.max(np.abs(H - H_exact)) <= 1e-8 * np.max(np.abs(H_exact))
+    # no differenced Hessian: a handful of joint evaluations (Newton + line search), not 2 n_u per Hessian
+    assert n_joint <= 40, n_joint
     eng.close()
