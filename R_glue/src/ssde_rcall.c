@@ -212,6 +212,20 @@ SEXP ssdeR_report(SEXP ptr, SEXP par) {
     return out;
 }
 
+/* he(x): exact second derivatives of the joint penalised nllk over the 0-based full-parameter indices `idx` (ssde_hess:
+ * direct families BM / OU).  Returns NULL where the engine has no exact Hessian: the R side then differences gr(). */
+SEXP ssdeR_hess(SEXP ptr, SEXP par, SEXP idx) {
+    ssde_handle *h = (ssde_handle *)R_ExternalPtrAddr(ptr);
+    if (!h) Rf_error("engine handle was destroyed (call $setup() again)");
+    int n = (int)Rf_xlength(idx);
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+    int st = ssde_hess(h, REAL(par), (int)Rf_xlength(par), INTEGER(idx), n, REAL(out));
+    UNPROTECT(1);
+    if (st == SSDE_ERR_MODEL) return R_NilValue;
+    if (st != SSDE_OK) Rf_error("ssde_hess failed (%d): %s", st, ssde_last_error(h));
+    return out;
+}
+
 SEXP ssdeR_info(SEXP ptr) {
     ssde_handle *h = (ssde_handle *)R_ExternalPtrAddr(ptr);
     if (!h) Rf_error("engine handle was destroyed");
@@ -233,6 +247,7 @@ static const R_CallMethodDef ssde_calldefs[] = {
     {"ssdeR_eval", (DL_FUNC)&ssdeR_eval, 3},
     {"ssdeR_laplace", (DL_FUNC)&ssdeR_laplace, 3},
     {"ssdeR_report", (DL_FUNC)&ssdeR_report, 2},
+    {"ssdeR_hess", (DL_FUNC)&ssdeR_hess, 3},
     {"ssdeR_info", (DL_FUNC)&ssdeR_info, 1},
     {NULL, NULL, 0}};
 

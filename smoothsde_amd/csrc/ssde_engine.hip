@@ -237,7 +237,6 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
     if (const char* e = getenv("SSDE_W0_RATIO")) h->env_w0_ratio = atof(e);     // 0 = equal windows on the general kernel
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
-    if (const char* e = getenv("SSDE_SHARED_DEEP")) h->env_shared_deep = atoi(e) != 0;
     h->env_own_stream = getenv("SSDE_SYNC_OWN_STREAM") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
     h->sdim = state_dim(d->model, d->n_dim);
@@ -1198,9 +1197,6 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
             IsoArgs b = a;
             b.group_mode = 2;
-            // two response columns: the deeper prefetch rotation when the windows are short (k_iso_shared.inc: run_segment) --
-            // a wave's rate is bytes in flight over latency, and only ~1000 waves with > 1000 rows each reach the read ceiling without it
-            b.deep_prefetch = h->env_shared_deep >= 0 ? h->env_shared_deep : (h->glen_max / std::max(1, a.n_chunks - (a.t0 > 0 ? 1 : 0)) <= 800 ? 1 : 0);
             if (any_dirty) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, s));
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));

@@ -129,7 +129,6 @@ struct ssde_handle {
     // testing / tuning knobs, read once at create: nothing calls getenv per evaluation
     int env_window = 0, env_tv_waves = 0, env_tv_minlen = 0;
     bool env_no_derive = false, env_no_graph = false;
-    int env_shared_deep = -1;      // SSDE_SHARED_DEEP=0|1: force the prefetch depth of the shared-covariance kernel (d = 2); -1 = by window length
     double env_t0_cost = 3.0;
     double env_w0_ratio = 1.2;     // (measured: 0 .. 1.45 swept, 3 % on CTCRW at 1.2, nothing on the scalar models) cost of a row of window 0 (every direction) over a row of a later window (one derived)
     // recovery from a widened plan (ssde_eval): after `cooldown` evaluations accepted at the first try the boost is

@@ -114,12 +114,14 @@ def _block_name(pb, k: int) -> str:
 
 def sdreport(problem, joint_eval: Callable[[np.ndarray], tuple], par_full: np.ndarray, idx_fixed, idx_random,
              marginal_fn: Optional[Callable[[np.ndarray], float]] = None, rel_step: float = 1e-4,
-             marginal_step: float = 1e-2) -> SdReport:
+             marginal_step: float = 1e-2, joint_hess: Optional[Callable] = None) -> SdReport:
     """problem       capi.Problem (parameter layout / block names)
     joint_eval    par_full -> (value, grad_full): the joint penalised nllk (Engine.eval)
     par_full      full parameter vector at the optimum (theta_hat, u_hat)
     idx_fixed     indices of the free non-random parameters, idx_random of the free coeff_re entries
-    marginal_fn   theta -> Laplace marginal (LaplaceObjective.fn); None when there are no random effects"""
+    marginal_fn   theta -> Laplace marginal (LaplaceObjective.fn); None when there are no random effects
+    joint_hess    (par_full, idx) -> exact Hessian of the joint nllk over idx, or None where the engine has none
+                  (Engine.hess = ssde_hess: direct families BM / OU); replaces the differenced gradient"""
     par_full = np.asarray(par_full, dtype=np.float64)
     io = np.asarray(idx_fixed, dtype=int)
     ir = np.asarray(idx_random, dtype=int)
@@ -132,7 +134,11 @@ def sdreport(problem, joint_eval: Callable[[np.ndarray], tuple], par_full: np.nd
 
     names_f = [_block_name(problem, k) for k in io]
     names_r = [_block_name(problem, k) for k in ir]
-    H = fd_hessian(gr_free, par_full[free], rel_step)
+    H = None
+    if joint_hess is not None:
+        H = joint_hess(par_full, free)
+    if H is None:
+        H = fd_hessian(gr_free, par_full[free], rel_step)
     nf = len(io)
     if len(ir) == 0:
         cov = np.linalg.inv(H)

@@ -387,6 +387,13 @@ class SDE:
             self.rho_ = np.exp(full[pb.off_decay:pb.off_decay + pb.n_decay])             # R/sde.R:715-718
         return self.out_
 
+    def _exact_hess(self, par_full, idx):
+        """tmb_obj_joint$he counterpart where the engine has exact second derivatives (ssde_hess: BM / OU); None elsewhere."""
+        try:
+            return self.engine_.hess(par_full, idx)
+        except capi.EngineError:
+            return None
+
     def report(self):
         """sdreport counterpart (R/sde.R:702-704): estimates, cov.fixed and the joint precision of
         (fixed, random) built from finite differences of the GPU gradient (smoothsde_amd/report.py)."""
@@ -400,13 +407,13 @@ class SDE:
             def marg(theta):
                 lap.u_hat = u_keep.copy()
                 return lap.fn(theta, update_warm_start=False)
-            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, lap.io, lap.ir, marginal_fn=marg)
+            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, lap.io, lap.ir, marginal_fn=marg, joint_hess=self._exact_hess)
             lap.u_hat = u_keep
         else:
             free = pb.free_index()
             ir = np.array([k for k in free if pb.off_re <= k < pb.off_re + pb.n_re], dtype=int)
             io = np.array([k for k in free if k not in set(ir.tolist())], dtype=int)
-            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, io, ir, marginal_fn=None)
+            rep = sdreport(pb, lambda p: self.engine_.eval(p, order=1), full, io, ir, marginal_fn=None, joint_hess=self._exact_hess)
         self.tmb_rep_ = rep
         return rep
 

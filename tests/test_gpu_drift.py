@@ -92,7 +92,7 @@ def _batch(model, d, M, T, ks, seed, fe_slope=False, ragged=False, dt=1.0):
 
 
 @pytest.mark.parametrize("model,d,ks,fe", [("OU_SSM", 1, (9,), False), ("CTCRW", 2, (9, 9), False), ("CTCRW", 1, (5,), True),
-                                            ("BM_SSM", 2, (0, 6), False), ("OU_SSM", 2, (12, 11), True), ("CTCRW", 2, (4, 0), False)])
+                                            ("BM_SSM", 2, (0, 6), False), ("OU_SSM", 2, (12, 10), True), ("CTCRW", 2, (4, 0), False)])
 def test_long_tracks_with_time_windows_vs_oracle(model, d, ks, fe):
     pb, par = _batch(model, d, 96, 1500, ks, seed=11, fe_slope=fe)
     eng = capi.Engine(pb)
