@@ -414,8 +414,6 @@ def main():
                 h0.eng._check(st)
             if host_reduce:
                 last["val"], last["grad"] = reduce_on_host(val_c.value, grad)
-            else:
-                last["val"], last["grad"] = val_c.value, grad
     else:
         def step(k):                                      # the three handles side by side, each on its own stream
             for h in handles:
@@ -456,6 +454,8 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if not concurrent and not host_reduce:
+        last["val"], last["grad"] = val_c.value, grad                        # (the C ABI wrote them in place)
     val, grad_last = last["val"], np.array(last["grad"])
     infos = [h.eng.info() for h in handles]
     check_max = max([i["window_check_max"] for i in infos] + [last.get("check", 0.0)])   # over EVERY evaluation since create
@@ -535,7 +535,11 @@ def main():
     dom = int(np.argmax([h.kernel_ms for h in handles]))
     roofline = dict(roofs[dom])
     if concurrent:
-        roofline["handles"] = roofs
+        roofline["handles"] = roofs          # (each kernel's own duration WHILE the others share the chip with it)
+        tot_req = sum(i["required_bytes_per_row"] * i["main_kernel_rows"] for i in infos)
+        roofline["concurrent"] = {"required_bytes_all_handles": tot_req, "ms_per_step": 1e3 * elapsed / args.steps,
+                                  "achieved": tot_req / (elapsed / args.steps) / 1e9, "frac": tot_req / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "the three handles' bytes over the wall time of one step: what the concurrently running kernels move together"}
     profiled = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc) and args.config == "c2p":

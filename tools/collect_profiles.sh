@@ -26,6 +26,21 @@ python3 tools/bench_configs.py > "$OUT/other_configs.txt" 2> "$OUT/other_configs
 echo "[collect] other configs done"
 python3 tools/bench_tv.py > "$OUT/tv_configs.txt" 2> "$OUT/tv_configs.err"
 echo "[collect] tv configs done"
+# round 3: the strong-scaling shares of the metric's batch (predicted curve), the drift kernel, BASELINE configs 4 and 5
+python3 tools/bench_strong.py > "$OUT/strong_shares.txt" 2> "$OUT/strong_shares.err"
+python3 tools/bench_strong.py --comm > "$OUT/strong_shares_comm.txt" 2>> "$OUT/strong_shares.err"
+echo "[collect] strong-scaling shares done"
+python3 tools/bench_drift.py 10000 10000 9 > "$OUT/drift.txt" 2> "$OUT/drift.err"
+python3 tools/bench_drift.py 10000 1000 18 CTCRW 2 >> "$OUT/drift.txt" 2>> "$OUT/drift.err"
+echo "[collect] drift kernel done"
+python3 bench.py --config c4 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config c5 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
+echo "[collect] c4 / c5 lines done"
+bash tools/pmc_kernel.sh "iso_shared" ${TAG}_share8 -- python3 $ROOT/tools/bench_strong.py --ranks 8 --evals 20 > /dev/null 2>&1 || true
+bash tools/pmc_kernel.sh "iso_drift" ${TAG}_drift -- python3 $ROOT/tools/bench_drift.py 10000 10000 9 > /dev/null 2>&1 || true
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_drift" -d "$OUT/pmc_drift_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_drift.py 10000 10000 9 > "$OUT/pmc_drift_fetch.log" 2>&1 ) || true
+cp gpurun_out/pmc_${TAG}_share8.txt gpurun_out/pmc_${TAG}_drift.txt "$OUT/" 2>/dev/null || true
+echo "[collect] SQ counters done"
 find "$OUT" -name "*.csv" -size +8M -delete
 du -sh "$OUT"
 ls -R "$OUT" | head -50

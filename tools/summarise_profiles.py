@@ -70,4 +70,19 @@ line["roofline"]["traffic_profiled"] = {"main_kernel_bytes": main_bytes, "evalua
 json.dump(line, open(pre + "bench_line.json", "w"))
 shutil.copy(os.path.join(src, "other_configs.txt"), pre + "other_configs.txt")
 shutil.copy(os.path.join(src, "tv_configs.txt"), pre + "tv_configs.txt")
+# round 3: strong-scaling shares, the drift kernel, BASELINE configs 4 / 5, SQ counters
+for name in ("strong_shares.txt", "strong_shares_comm.txt", "drift.txt", "bench_c4.json", "bench_c5.json",
+             f"pmc_{tag}_share8.txt", f"pmc_{tag}_drift.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
+try:   # FETCH_SIZE of the drift kernel (same x2 calibration)
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_drift_fetch", "fetch_counter_collection.csv")))
+            if "iso_drift" in r["Kernel_Name"]]
+    if vals:
+        with open(pre + "pmc_drift_fetch.txt", "w") as f:
+            f.write(f"iso_drift_kernel: {len(vals)} dispatches, FETCH_SIZE avg {sum(vals) / len(vals):.1f} KiB -> {2 * 1024 * sum(vals) / len(vals) / 1e9:.3f} GB per launch "
+                    f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_drift.py 10000 10000 9 (OU_SSM d = 1, 9 streamed drift columns: 80 B/row required = 8.0 GB)\n")
+except Exception as e:  # noqa: BLE001
+    print("no drift PMC:", e)
 print("wrote", pre + "*", "and profiles/pmc_latest.json; main kernel", main, f"{main_bytes / 1e9:.3f} GB per launch")
