@@ -22,6 +22,8 @@
 // state, the covariance directions, the intercept direction and the column sensitivities (IsoArgs.bnd_stride wide).
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "ssde_device.hpp"
 
 namespace ssde {
@@ -287,6 +289,231 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_drift_kernel(const Iso
     int g, part, chunk;
     if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
     run_lane_drift<MODEL, D, NG>(A, g, chunk);
+}
+
+// =====================================================================================================================
+// The same drift model where the covariance half is NOT shared: missing rows and / or an irregular time grid.  Lane = track
+// with the lane's own covariance and covariance sensitivities -- the fused general step of ssde_math.hpp (ctcrw_step /
+// scal_cov_step + scal_mean_step, what k_iso.hip runs for constant coefficients) fed THIS ROW's mu -- plus the column
+// recursions with the lane's own gains: k1 = (p11 + t12 p12) / F, k2 = e p12 / F (CTCRW), c = t h / F (OU / BM), all zero /
+// one on a row that is not scored (nllk_ctcrw.hpp:214-217, 226-228).  Bound by fp64 issue like the general kernel it extends
+// (~180 + 8 K instructions per row), one wave per SIMD; still an order of magnitude above the lane = direction path at
+// batch scale, which is where a batch with ANY missing row used to land.
+template <int MODEL, int D, int KP>
+struct DriftGenLane {
+    typedef DriftModel<MODEL> DM;
+    static constexpr bool CT = DM::CT, HAS_P2 = DM::HAS_P2;
+    static constexpr int SD = CT ? 2 * D : D;
+    typedef typename std::conditional<CT, CtcrwLane<D, DRIFT_MASK>, ScalLane<D, DRIFT_MASK>>::type Lane;
+    static constexpr int NBASE = Lane::NSTATE;
+    static constexpr int NSTATE = NBASE + KP * (CT ? 2 : 1);
+    Lane L;
+    double cx[KP], cv[CT ? KP : 1], gk[KP];
+
+    __device__ __forceinline__ void init(const double* a0, const IsoArgs& A) {
+        if constexpr (CT) L.init(a0, A.p0[0], A.p0[1], A.p0[2]); else L.init(a0, A.p0[0]);
+#pragma unroll
+        for (int k = 0; k < KP; k++) { cx[k] = 0.0; gk[k] = 0.0; if (CT) cv[k] = 0.0; }
+    }
+    __device__ __forceinline__ void reset_acc() {
+        L.reset_acc();
+#pragma unroll
+        for (int k = 0; k < KP; k++) gk[k] = 0.0;
+    }
+    __device__ __forceinline__ void step(const IsoArgs& A, const typename DM::Trans& tr, const double* y, const double* X) {
+        const bool na = is_na(y[0], A.any_nan);
+        const double h = A.h;
+        double mu[D];
+#pragma unroll
+        for (int a = 0; a < D; a++) mu[a] = A.mu[a];
+#pragma unroll
+        for (int k = 0; k < KP; k++) {
+            mu[0] = fma(A.coefA[k], X[k], mu[0]);
+            if (D > 1) mu[D - 1] = fma(A.coefB[k], X[k], mu[D - 1]);
+        }
+        if constexpr (CT) {
+            // the lane's gains, exactly as ctcrw_step forms them (the compiler merges the two)
+            const double F = L.C.p11 + h;
+            const double detF = (D == 1) ? F : F * F;
+            const bool upd = !na && !(detF <= 0.0);
+            const double updf = upd ? 1.0 : 0.0;
+            const double iF = rcp(upd ? F : 1.0) * updf;
+            const double bm = (na || upd) ? 1.0 : 0.0;
+            const double kf1 = L.C.p11 * iF, kf2 = L.C.p12 * iF;
+            const double k1 = fma(tr.t12, kf2, kf1), k2 = tr.e * kf2, c1 = 1.0 - k1;
+            const double b1 = bm * tr.b1, b2 = bm * tr.b2;
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const double yk = (D > 1 && ((A.drift_dim1 >> k) & 1u)) ? y[D - 1] : y[0];
+                const double xk = (D > 1 && ((A.drift_dim1 >> k) & 1u)) ? L.M.x[D - 1] : L.M.x[0];
+                const double uk = upd ? yk - xk : 0.0;
+                const double mx = cx[k], mv = cv[k];
+                gk[k] = fma(-iF * mx, uk, gk[k]);
+                cx[k] = fma(b1, X[k], fma(tr.t12, mv, c1 * mx));
+                cv[k] = fma(b2, X[k], fma(tr.e, mv, -k2 * mx));
+            }
+            ctcrw_step<D, DRIFT_MASK>(L, tr, h, mu, y, na);
+        } else {
+            ScalGain G;
+            const double x0 = L.M.x[0], x1 = L.M.x[D - 1];
+            scal_cov_step<D, DRIFT_MASK, HAS_P2>(L.C, tr, h, na, G);
+            const bool scored = G.iF != 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const bool d1 = D > 1 && ((A.drift_dim1 >> k) & 1u);
+                const double uk = scored ? (d1 ? y[D - 1] - x1 : y[0] - x0) : 0.0;
+                const double mx = cx[k];
+                gk[k] = fma(-G.iF * mx, uk, gk[k]);
+                cx[k] = fma(tr.b, X[k], G.c * mx);
+            }
+            scal_mean_step<D, DRIFT_MASK, HAS_P2>(L.M, tr, G, mu, y, scored);
+        }
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {      // o[k * WAVE]
+        double st[NBASE];
+        L.dump(st);
+#pragma unroll
+        for (int k = 0; k < NBASE; k++) o[k * WAVE] = st[k];
+        int n = NBASE;
+#pragma unroll
+        for (int k = 0; k < KP; k++) { o[(n++) * WAVE] = cx[k]; if constexpr (CT) o[(n++) * WAVE] = cv[k]; }
+    }
+};
+
+int drift_general_nstate(int model, int d, int k) {
+    const int kp = (k + 3) / 4 * 4;
+    return iso_nstate(model, d) + kp * (model == M_CTCRW ? 2 : 1);
+}
+
+template <int MODEL, int D, int NG, bool UNI>
+__device__ __forceinline__ void run_lane_drift_general(const IsoArgs& A, int g, int chunk) {
+    constexpr int KP = 4 * NG;
+    constexpr int U = (NG <= 3) ? 4 : 2;
+    typedef DriftGenLane<MODEL, D, KP> Lane;
+    typedef DriftModel<MODEL> DM;
+    constexpr int SD = Lane::SD;
+    constexpr int W = 1 + D + KP;                              // register block row: [dt | y | columns]
+    const int lane = threadIdx.x & 63;
+    const TileView& tv = A.tv;
+    const int C = tv.C, c_obs = tv.c_obs, K = A.drift_k, c_col = A.c_col;
+    const int nacc = 4 + D + K;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, 0, chunk, s_begin, s_acc, s_end, 0);
+    int chan[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) chan[k] = c_col + (k < K ? k : 0);
+
+    double bufA[U][W], bufB[U][W];
+    auto load = [&](double (&dst)[U][W], int s0) {
+        const double* p = base + (int64_t)s0 * C * WAVE;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dst[u][0] = 0.0;
+            if (!UNI) dst[u][0] = p[(u * C) * WAVE];           // the dt channel exists whenever the grid is not regular
+#pragma unroll
+            for (int a = 0; a < D; a++) dst[u][1 + a] = p[(u * C + c_obs + a) * WAVE];
+#pragma unroll
+            for (int k = 0; k < KP; k++) dst[u][1 + D + k] = p[(u * C + chan[k]) * WAVE];
+        }
+    };
+    load(bufA, s_begin);
+    Lane S;
+    {
+        double a0[SD];
+        if (s_begin == 0) {
+#pragma unroll
+            for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        } else {
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double y0 = bufA[0][1 + a];
+                if constexpr (DM::CT) { a0[2 * a] = (y0 == y0) ? y0 : 0.0; a0[2 * a + 1] = 0.0; }
+                else a0[a] = (y0 == y0) ? y0 : 0.0;
+            }
+        }
+        S.init(a0, A);
+    }
+    typename DM::Trans tr_uni;
+    if constexpr (DM::CT) tr_uni = A.ctr; else tr_uni = A.str;
+    auto block = [&](const double (&blk)[U][W], int s0) {
+        if (s0 == s_acc && s_acc > s_begin) {
+            S.dump_to(A.bnd + (((int64_t)chunk * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane);
+            S.reset_acc();
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s0 + u < ns) {
+                if constexpr (UNI) S.step(A, tr_uni, &blk[u][1], &blk[u][1 + D]);
+                else {
+                    typename DM::Trans tr;
+                    if constexpr (DM::CT) ctcrw_trans(blk[u][0], A.tau, A.beta, A.sigma, tr);
+                    else if constexpr (MODEL == M_OU_SSM) ou_trans(blk[u][0], A.tau, A.sigma, tr);
+                    else bm_trans(blk[u][0], A.sigma, tr);
+                    S.step(A, tr, &blk[u][1], &blk[u][1 + D]);
+                }
+            }
+    };
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+        load(bufB, s0 + U);
+        block(bufA, s0);
+        load(bufA, s0 + 2 * U);
+        if (s0 + U < s_end) block(bufB, s0 + U);
+    }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks)
+        S.dump_to(A.bnd + (((int64_t)chunk * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane);
+    double out[4 + D];
+    if constexpr (DM::CT) ctcrw_finish<D, DRIFT_MASK>(S.L, out); else scal_finish<D, DRIFT_MASK>(S.L, out);
+    const bool empty = s_acc >= s_end;
+#pragma unroll
+    for (int k = 0; k < 4 + D; k++) {
+        const double t = wave_sum(empty ? 0.0 : out[k]);
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + k) * tv.n_groups + g] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const double t = wave_sum(empty ? 0.0 : S.gk[k]);
+        if (lane == 0 && k < K) A.partials[((int64_t)chunk * nacc + 4 + D + k) * tv.n_groups + g] = t;
+    }
+}
+
+template <int MODEL, int D, int NG, bool UNI>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_drift_general_kernel(const IsoArgs A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
+    int g, part, chunk;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+    run_lane_drift_general<MODEL, D, NG, UNI>(A, g, chunk);
+}
+
+template <int MODEL, int D>
+static hipError_t launch_ng_general(const IsoArgs& a, dim3 grid, hipStream_t s) {
+    dim3 block(WG_WAVES * WAVE);
+    const int ng = (a.drift_k + 3) / 4;
+    const bool uni = a.uniform_dt != 0;
+    switch (ng) {
+#define SSDE_CASE(N) case N: if (uni) hipLaunchKernelGGL((iso_drift_general_kernel<MODEL, D, N, true>), grid, block, 0, s, a); \
+                             else hipLaunchKernelGGL((iso_drift_general_kernel<MODEL, D, N, false>), grid, block, 0, s, a); break;
+        SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6)
+#undef SSDE_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_iso_drift_general(int model, int d, const IsoArgs& a, hipStream_t s) {
+    if (a.n_parts != 1 || a.drift_k < 1 || a.drift_k > DRIFT_KMAX) return hipErrorInvalidValue;
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES);
+    if (grid.x == 0) return hipSuccess;
+    if (model == M_CTCRW && d == 1) return launch_ng_general<M_CTCRW, 1>(a, grid, s);
+    if (model == M_CTCRW && d == 2) return launch_ng_general<M_CTCRW, 2>(a, grid, s);
+    if (model == M_OU_SSM && d == 1) return launch_ng_general<M_OU_SSM, 1>(a, grid, s);
+    if (model == M_OU_SSM && d == 2) return launch_ng_general<M_OU_SSM, 2>(a, grid, s);
+    if (model == M_BM_SSM && d == 1) return launch_ng_general<M_BM_SSM, 1>(a, grid, s);
+    if (model == M_BM_SSM && d == 2) return launch_ng_general<M_BM_SSM, 2>(a, grid, s);
+    return hipErrorInvalidValue;
 }
 
 template <int MODEL, int D>

@@ -131,6 +131,9 @@ hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, 
 // shared-covariance lanes with a streamed row-varying drift (k_iso_drift.hip); partials [n_chunks][4 + d + drift_k][n_groups]
 hipError_t launch_iso_drift(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 int drift_nstate(int model, int d, int k);
+// the same model with the lane's own covariance (missing rows / irregular grid): general step + column recursions
+hipError_t launch_iso_drift_general(int model, int d, const IsoArgs& a, hipStream_t s);
+int drift_general_nstate(int model, int d, int k);
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
 struct ReduceArgs;
 // the hand-over checks and the final sums of an isotropic evaluation in ONE launch (the checks raise out[n_out])

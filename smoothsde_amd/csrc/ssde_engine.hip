@@ -514,18 +514,18 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
                             !(d->flags & SSDE_FLAG_FORCE_DENSE);
         h->path = iso_ok ? PATH_ISO : PATH_DENSE;
         // Row-varying DRIFT only (design columns in the rows of mu_1 .. mu_d, everything else constant), many tracks: the
-        // covariance half is as data-independent as with constant coefficients -- the shared-covariance lanes with the
-        // design columns streamed next to the observations (k_iso_drift.hip).  Needs a regular grid and complete tracks,
-        // which the tiling pass below finds out (SSDE_RETRY_WITHOUT_DRIFT otherwise).  Few tracks (C1: one animal) stay on
-        // the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
-        if (!iso_ok && allow_drift && !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) && !(d->flags & (SSDE_FLAG_FORCE_DENSE | SSDE_FLAG_NO_UNIFORM_DT)) &&
-            !getenv("SSDE_NO_DRIFT") && !getenv("SSDE_NO_SHARED") && h->n_stream_cols <= DRIFT_KMAX) {
+        // register path with the design columns streamed next to the observations (k_iso_drift.hip) -- on a regular grid with
+        // complete tracks (which the tiling pass below finds out) the covariance half is as data-independent as with constant
+        // coefficients and the shared-covariance lanes run; otherwise the lanes carry their own covariance.  Few tracks (C1:
+        // one animal) stay on the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
+        if (!iso_ok && allow_drift && !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
+            !getenv("SSDE_NO_DRIFT") && h->n_stream_cols <= DRIFT_KMAX) {
             bool mu_only = true;
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;
             int min_tracks = 32;
             if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
-            if (mu_only && h->n_seg >= min_tracks) { h->drift = true; h->path = PATH_ISO; }
+            if (mu_only && h->n_seg >= min_tracks) { h->drift = 1; h->path = PATH_ISO; }
         }
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
         // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic
@@ -706,10 +706,14 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         h->hbm_bytes = h->tile_doubles * 8;
 
         if (h->drift) {
+            // regular grid and every track complete: the shared-covariance lanes; otherwise the lanes carry their own covariance
+            // (SSDE_NO_DRIFT_GENERAL: back to the lane = direction path instead, for A/B)
             bool all_clean = h->uniform_dt;
             for (int g = 0; g < G; g++) all_clean = all_clean && gflags[g] != 0;
-            if (!all_clean) return SSDE_RETRY_WITHOUT_DRIFT;
-            h->drift_nstate = drift_nstate(h->model, h->d, h->n_stream_cols);
+            if (!all_clean && getenv("SSDE_NO_DRIFT_GENERAL")) return SSDE_RETRY_WITHOUT_DRIFT;
+            if (getenv("SSDE_NO_SHARED")) all_clean = false;                  // (testing: the general lanes on a batch the shared ones would take)
+            h->drift = all_clean ? 1 : 2;
+            h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
         }
         if (h->path == PATH_ISO) {
             if (h->drift) { h->iso_parts = 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
@@ -737,6 +741,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             for (size_t ns = 1; ns < cnt.size(); ns++)
                 if (cnt[ns]) h->clean_ns_hist.push_back({(int)ns, cnt[ns]});
             h->use_shared = h->uniform_dt && h->n_clean_groups > 0 && h->iso_parts == 1 && !getenv("SSDE_NO_SHARED");
+            if (h->drift) h->use_shared = h->drift == 1;
             // (two concurrent launches, a fork / join and a longer finalize cost ~40 us: with fewer than a quarter of the groups on
             //  the shared kernel that is more than it wins -- measured 0.82 against 0.78 ms at one tenth -- and everything stays general)
             if (h->use_shared && h->n_clean_groups < G && 4 * h->n_clean_groups < G && !getenv("SSDE_SHARED_ALWAYS")) h->use_shared = false;
@@ -753,7 +758,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             // (a mixed batch whose general launch gets a plan of its own, below, keeps the shared kernel's plan here whatever the
             //  share of its groups)
             const bool own_plans = h->use_shared && h->n_clean_groups < G && !getenv("SSDE_CHUNKS") && !getenv("SSDE_ONE_PLAN");
-            if (!(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || (2 * h->n_clean_groups < G && !own_plans)) && !getenv("SSDE_NO_LIGHT2"))
+            if (!h->drift && !(h->model == SSDE_MODEL_CTCRW && !h->uniform_dt) && (!h->uniform_dt || (2 * h->n_clean_groups < G && !own_plans)) && !getenv("SSDE_NO_LIGHT2"))
                 // measured (tools/bench_na.py, SSDE_CHUNKS sweep 12 .. 32): the scalar-covariance models run best with
                 // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
                 // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
@@ -767,7 +772,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             // sets the evaluation's time (0.75-0.9 ms with 1-30 % of the tracks affected).  The general launch gets a plan of
             // its own: enough windows to fill its two waves per SIMD (plan_windows keeps them at least two warm-ups long).
             int buf_chunks = h->max_chunks;
-            if (h->use_shared && h->n_clean_groups < G && !h->chunks_forced && !getenv("SSDE_ONE_PLAN")) {
+            if (h->use_shared && !h->drift && h->n_clean_groups < G && !h->chunks_forced && !getenv("SSDE_ONE_PLAN")) {
                 const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
                 const int want_d = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / gd8);
                 // (the hand-over dumps are sized for every group x the longer plan: keep them under ~0.5 GB)
@@ -1112,8 +1117,8 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.bnd = h->bnd.p; a.chk = h->chk.p;
         a.bnd_stride = h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX;
         a.chk_out = out_dev + (1 + L.n_full);
-        a.derive = h->env_no_derive ? 0 : 1;
-        a.all_clean = (h->use_shared && h->n_clean_groups == h->n_groups) ? 1 : 0;
+        a.derive = (h->env_no_derive || h->drift) ? 0 : 1;
+        a.all_clean = ((h->use_shared && h->n_clean_groups == h->n_groups) || h->drift) ? 1 : 0;      // (drift: one dump layout for every group)
         a.nstate_clean = h->drift ? h->drift_nstate
                        : h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
         h->last_chunks = a.n_chunks; h->last_window = a.window;
@@ -1156,7 +1161,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             const double cost = h->env_t0_cost;
             a.t0_delta = (int)(cost * a.t0 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         }
-        if (!h->use_shared && a.n_chunks > 1 && h->env_w0_ratio > 0.0) {
+        if (!h->use_shared && !h->drift && a.n_chunks > 1 && h->env_w0_ratio > 0.0) {
             // General kernel, every window on its own wave: window 0 carries EVERY direction (windows >= 1 derive one,
             // k_iso.hip) but has no warm-up rows.  With equal windows its waves are the last to finish and the whole
             // launch waits for them (CTCRW: 212 against 163 instructions per row).  Balance: window 0 = [0, L0) with
@@ -1210,7 +1215,8 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
         } else {
             if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
-            HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+            if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
+            else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
             if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
             h->ev_k_valid = h->stamps;
             h->last_s_stat = -1;

@@ -143,7 +143,8 @@ struct ssde_handle {
     int n_dirty_groups = 0;
     int n_clean_groups = 0;
     bool use_shared = false;
-    bool drift = false;            // row-varying drift on the shared-covariance path (k_iso_drift.hip)
+    int drift = 0;                 // row-varying drift on the register path (k_iso_drift.hip): 1 = shared-covariance lanes (regular grid, complete
+                                   // tracks), 2 = lanes with their own covariance (missing rows / irregular grid)
     int drift_nstate = 0;          // components of its hand-over dumps
     // one-row tracks never reach a kernel; REPORT(aest_all) still shows their a0 (nllk_ctcrw.hpp:196-200, 246)
     std::vector<int64_t> single_rows;

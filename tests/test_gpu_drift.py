@@ -126,29 +126,60 @@ def test_ragged_tracks_fixed_parameters_and_a_short_step():
     eng.close()
 
 
-def test_missing_rows_or_an_irregular_grid_fall_back_to_the_lane_direction_path():
-    pb, par = _batch("OU_SSM", 1, 64, 300, (6,), seed=7)
-    o = pb.obs.copy()
-    o[1234] = np.nan
-    pbn = capi.Problem("OU_SSM", pb.id, pb.times, o, X_re=pb.X_re, S_list=pb.S_list)
-    eng = capi.Engine(pbn)
-    assert eng.info()["path"] == PATH_TV
+@pytest.mark.parametrize("model,d,ks", [("OU_SSM", 1, (6,)), ("CTCRW", 2, (5, 4)), ("BM_SSM", 2, (0, 7)), ("CTCRW", 1, (9,))])
+@pytest.mark.parametrize("what", ["missing", "irregular", "both"])
+def test_missing_rows_and_irregular_grids_keep_the_register_path(model, d, ks, what):
+    """The lanes then carry their own covariance (nllk_ctcrw.hpp:214-217: a row whose first column is NA is a prediction step):
+    general step + column recursions with the lane's gains, against the oracle."""
+    pb, par = _batch(model, d, 96, 700, ks, seed=21)
+    o, t = pb.obs.copy(), pb.times.copy()
+    rng = np.random.default_rng(4)
+    if what in ("missing", "both"):
+        na = rng.random(len(t)) < 0.05
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan                                       # column 0 decides (the other column may hold a number)
+        o[na & (rng.random(len(t)) < 0.5)] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    pb2 = capi.Problem(model, pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list)
+    eng = capi.Engine(pb2)
+    assert _is_drift(eng) and eng.info()["uniform_dt"] == (0 if what != "missing" else 1)
     val, grad = eng.eval(par)
-    _close(val, grad, *_oracle(pbn, par))
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb2, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
     eng.close()
-    t = pb.times.copy()
-    t[5000:] += 0.25
-    t[5001:] += 0.5                                                              # one odd interval inside a track
-    pbi = capi.Problem("OU_SSM", pb.id, t, pb.obs, X_re=pb.X_re, S_list=pb.S_list)
-    eng = capi.Engine(pbi)
-    assert eng.info()["path"] == PATH_TV
-    val, grad = eng.eval(par)
-    _close(val, grad, *_oracle(pbi, par))
-    eng.close()
-    # few tracks (one animal): the lane = direction path by design
+
+
+def test_general_and_shared_lanes_agree_on_a_complete_regular_batch(monkeypatch):
+    pb, par = _batch("CTCRW", 2, 128, 600, (6, 6), seed=23)
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    monkeypatch.setenv("SSDE_NO_SHARED", "1")
+    e2 = capi.Engine(pb)
+    assert _is_drift(e2)
+    v2, g2 = e2.eval(par)
+    assert abs(v1 - v2) <= 1e-11 * abs(v1) and np.max(np.abs(g1 - g2)) <= 1e-9 * np.max(np.abs(g1))
+    e1.close(); e2.close()
+
+
+def test_few_tracks_stay_on_the_lane_direction_path(monkeypatch):
     pb1, par1 = _batch("CTCRW", 2, 3, 600, (5, 5), seed=9)
     eng = capi.Engine(pb1)
     assert eng.info()["path"] == PATH_TV
+    eng.close()
+    # ... and SSDE_NO_DRIFT_GENERAL sends an incomplete batch back there too
+    pb, par = _batch("OU_SSM", 1, 64, 300, (6,), seed=7)
+    o = pb.obs.copy()
+    o[1234] = np.nan
+    monkeypatch.setenv("SSDE_NO_DRIFT_GENERAL", "1")
+    eng = capi.Engine(capi.Problem("OU_SSM", pb.id, pb.times, o, X_re=pb.X_re, S_list=pb.S_list))
+    assert eng.info()["path"] == PATH_TV
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(capi.Problem("OU_SSM", pb.id, pb.times, o, X_re=pb.X_re, S_list=pb.S_list), par))
     eng.close()
 
 
