@@ -388,7 +388,7 @@ int drift_general_nstate(int model, int d, int k) {
 template <int MODEL, int D, int NG, bool UNI>
 __device__ __forceinline__ void run_lane_drift_general(const IsoArgs& A, int g, int chunk) {
     constexpr int KP = 4 * NG;
-    constexpr int U = (NG <= 3) ? 4 : 2;
+    constexpr int U = (NG <= 1) ? 4 : 2;            // fp64-issue-bound: a short look-ahead is enough, and registers are what this kernel lacks
     typedef DriftGenLane<MODEL, D, KP> Lane;
     typedef DriftModel<MODEL> DM;
     constexpr int SD = Lane::SD;

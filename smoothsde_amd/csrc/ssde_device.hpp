@@ -108,6 +108,7 @@ struct IsoArgs {
     int all_clean;               // every group dumps the compact layout (no group on the general kernel): the hand-over check need not read group_flags
     int derive;                  // windows >= 1 of the general kernel derive one variance direction from log sigma_obs (k_iso.hip)
     double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
+    double* wave_clock;          // debugging (SSDE_WAVE_CLOCK=file at create): [work item][4] = start, end (wall_clock64, 100 MHz), HW_ID, rows
     int deep_prefetch;           // shared-covariance kernel, d = 2: three-block rotation (two blocks in flight) instead of the ping-pong pair
     int bnd_stride;              // components per hand-over dump in `bnd` (NSTATE_MAX, or more with drift columns)
     // Row-varying DRIFT on the shared-covariance path (k_iso_drift.hip): mu_a(i) = mu[a] + sum_k coef_k X_k(i) over the

@@ -27,6 +27,19 @@ namespace ssde_engine {
 
 // everything the handle holds on the device and in pinned memory (the handle itself stays)
 static void release_device(ssde_handle* h) {
+    if (!h->wave_clock_file.empty() && h->wave_clock.p && h->wave_clock_items > 0) {
+        std::vector<double> w((size_t)4 * h->wave_clock_items);
+        if (hipSetDevice(h->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(w.data(), h->wave_clock.p, w.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(h->wave_clock_file.c_str(), "w")) {
+                fprintf(f, "# work item, start, end (100 MHz ticks), HW_ID; windows %d, warm-up %d, t0 %d\n", h->last_chunks, h->last_window, h->last_t0);
+                for (int i = 0; i < h->wave_clock_items; i++)
+                    if (w[4 * (size_t)i + 3] != 0.0) fprintf(f, "%d %.0f %.0f %.0f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2]);
+                fclose(f);
+            }
+        }
+    }
+    h->wave_clock.release();
     if (h->trace && h->trace_n > 0)
         fprintf(stderr, "[ssde trace] %lld isotropic evaluations, host us per evaluation: plan %.1f | gain table %.1f | main launch %.1f | "
                         "finalize launch %.1f | read-back (blocks until the GPU is done) %.1f\n", (long long)h->trace_n,
@@ -239,6 +252,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
     h->env_own_stream = getenv("SSDE_SYNC_OWN_STREAM") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
+    if (const char* e = getenv("SSDE_WAVE_CLOCK")) h->wave_clock_file = e;
     h->sdim = state_dim(d->model, d->n_dim);
     h->na_any = d->na_mode == SSDE_NA_ANY_NAN;
     h->has_h = is_kalman(d->model) && d->h_array != nullptr;
@@ -1202,6 +1216,12 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             }
             IsoArgs b = a;
             b.group_mode = 2;
+            if (!h->wave_clock_file.empty()) {
+                const int items = ((h->n_groups + 7) / 8 * 8) * a.n_chunks + 8;
+                if ((int)h->wave_clock.n < 4 * items) { h->wave_clock.release(); HIPCHK(h, h->wave_clock.alloc((size_t)4 * items)); }
+                HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
+                b.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
+            }
             if (any_dirty) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, s));
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));

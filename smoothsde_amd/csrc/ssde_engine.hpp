@@ -218,6 +218,9 @@ struct ssde_handle {
     unsigned long long pub_seq = 0;
     DevBuf<unsigned int> pub_count;
     bool pub_ok = false;                      // buffers exist and SSDE_NO_PUBLISH is not set
+    DevBuf<double> wave_clock;                // SSDE_WAVE_CLOCK=file: per-wave stamps of the last shared-covariance launch, written at destroy
+    std::string wave_clock_file;
+    int wave_clock_items = 0;
     bool pub_request = false;                 // run_once asks the next eval_device to publish
     std::vector<double> gain_cum[4];          // build_gain_table's running sums
     bool pub_armed = false;                   // the evaluation just enqueued will publish (set by eval_device, consumed by run_once)

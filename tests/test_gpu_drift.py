@@ -217,3 +217,18 @@ def test_forced_short_warm_up_is_caught_and_repaired(monkeypatch):
     assert inf["window_retries"] >= 1 and inf["window_check"] <= 1e-11
     _close(val, grad, *_oracle(pb, par))
     eng.close()
+
+
+def test_a_response_wider_than_two_columns_runs_the_drift_kernels_as_column_pairs():
+    """n_dim = 3: the parts (columns 0-1, column 2) each take the register path with their own mu columns."""
+    ID, t, o = simulate("CTCRW", 70, 300, 3, tau=1.5, nu=0.8, sigma_obs=0.1, seed=31)
+    n = len(ID)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 41), 0, 1)
+    X_re = [bspline_basis(x, 5), None, bspline_basis(x ** 2, 4), None, None]
+    pb = capi.Problem("CTCRW", ID, t, o, X_re=X_re, S_list=[second_difference_penalty(5), second_difference_penalty(4)])
+    rng = np.random.default_rng(2)
+    par = np.r_[np.log(0.12), 0.05, -0.03, 0.02, np.log(1.5), np.log(0.8), 0.3, -0.2, 0.2 * rng.standard_normal(9)]
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pb, par))
+    eng.close()
