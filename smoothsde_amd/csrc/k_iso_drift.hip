@@ -516,6 +516,149 @@ hipError_t launch_iso_drift_general(int model, int d, const IsoArgs& a, hipStrea
     return hipErrorInvalidValue;
 }
 
+// =====================================================================================================================
+// EXACT Hessian of the data term over the drift coefficients (shared-covariance case).  The innovation is LINEAR in them --
+// u_a(i) = y_a(i) - x_a(i), d x_a / d beta_k = mx_k(i), no second derivative -- and the covariance half does not see them, so
+//     d2 nllk / d beta_k d beta_l = sum_i F_i^-1 mx_k(i) mx_l(i)        (k, l feeding the same dimension; 0 otherwise)
+// exactly: the Gauss-Newton form IS the Hessian, and it does not even depend on the observations.  This is the H_uu block of
+// the Laplace approximation for a smooth drift (random = "coeff_re", R/sde.R:510-525), which TMB gets from second-order AD.
+// One pass over the design columns: the coefficient pairs are cut into HESS_T x HESS_T tiles (blockIdx.y), a wave carries the
+// column recursions of its tile's two groups and HESS_T^2 accumulators through its time window (same windows, same warm-up,
+// same gains as the evaluation: the plan was verified by the evaluation at these parameters that precedes the call).
+// A slot is a streamed column (chan >= 0) or the intercept of a dimension (chan < 0: a column of ones).
+template <int MODEL>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_drift_hess_kernel(const IsoArgs A, const DriftHessArgs H) {
+    typedef DriftModel<MODEL> DM;
+    constexpr bool CT = DM::CT;
+    constexpr int U = 4;
+    int g, part, chunk;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+    const int tile = blockIdx.y, ti = H.tile_i[tile], tj = H.tile_j[tile];
+    const int lane = threadIdx.x & 63;
+    const TileView& tv = A.tv;
+    const int C = tv.C;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end, A.t0_delta);
+    int s_stat = (A.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+    if (A.gain_stat[0] == 0.0) s_stat = INT32_MAX;
+    __shared__ double gain_slab[WG_WAVES][DRIFT_SLAB_ROWS * GAIN_ROW];
+    double* slab = gain_slab[threadIdx.x >> 6];
+    int slab_row0 = -1;
+    // the tile's slots: 2 x HESS_T (group ti, group tj); a slot beyond the list repeats slot 0 and is dropped by the host
+    int chan[2 * HESS_T];
+#pragma unroll
+    for (int k = 0; k < 2 * HESS_T; k++) {
+        const int idx = (k < HESS_T ? ti : tj) * HESS_T + (k % HESS_T);
+        chan[k] = H.chan[idx < H.n ? idx : 0];
+    }
+    typename DM::Trans tr;
+    if constexpr (CT) tr = A.ctr; else tr = A.str;
+    const typename DM::Gain Gs = gain_from_row<typename DM::Gain>(A.gain_stat);
+    double cx[2 * HESS_T], cv[CT ? 2 * HESS_T : 1], acc[HESS_T][HESS_T];
+#pragma unroll
+    for (int k = 0; k < 2 * HESS_T; k++) { cx[k] = 0.0; if (CT) cv[k] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) acc[a][b] = 0.0;
+    double bufA[U][2 * HESS_T], bufB[U][2 * HESS_T];
+    auto load = [&](double (&dst)[U][2 * HESS_T], int s0) {
+        const double* p = base + (int64_t)s0 * C * WAVE;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < 2 * HESS_T; k++) dst[u][k] = chan[k] >= 0 ? p[(u * C + chan[k]) * WAVE] : 1.0;      // (uniform select)
+    };
+    auto row = [&](const typename DM::Gain& G, const double* X, bool score) {
+        const double w = score ? G.iF : 0.0;
+#pragma unroll
+        for (int a = 0; a < HESS_T; a++) {
+            const double wa = w * cx[a];
+#pragma unroll
+            for (int b = 0; b < HESS_T; b++) acc[a][b] = fma(wa, cx[HESS_T + b], acc[a][b]);
+        }
+        const bool scored = G.iF != 0.0;
+#pragma unroll
+        for (int k = 0; k < 2 * HESS_T; k++) {
+            const double mx = cx[k];
+            if constexpr (CT) {
+                const double mv = cv[k], du = scored ? -mx : 0.0;
+                cx[k] = fma(G.bm * tr.b1, X[k], fma(G.k1, du, fma(tr.t12, mv, mx)));
+                cv[k] = fma(G.bm * tr.b2, X[k], fma(G.k2, du, tr.e * mv));
+            } else {
+                cx[k] = fma(tr.b, X[k], G.c * mx);
+            }
+        }
+    };
+    auto block = [&](const double (&blk)[U][2 * HESS_T], int s0) {
+        if (s0 < s_stat) {
+            if (slab_row0 < 0 || s0 >= slab_row0 + DRIFT_SLAB_ROWS) {
+                slab_row0 = s0;
+                const int glast = A.gain_last;
+                const double* __restrict__ gain = A.gain;
+#pragma unroll 4
+                for (int r = 0; r < DRIFT_SLAB_ROWS; r += WAVE / GAIN_ROW) {
+                    const int rr = r + lane / GAIN_ROW;
+                    slab[rr * GAIN_ROW + (lane % GAIN_ROW)] = gain[(int64_t)min(s0 + rr, glast) * GAIN_ROW + (lane % GAIN_ROW)];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (s0 + u < ns) row(gain_from_row<typename DM::Gain>(slab + (s0 + u - slab_row0) * GAIN_ROW), &blk[u][0], s0 + u >= s_acc);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (s0 + u < ns) row(Gs, &blk[u][0], s0 + u >= s_acc);
+        }
+    };
+    load(bufA, s_begin);
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+        load(bufB, s0 + U);
+        block(bufA, s0);
+        load(bufA, s0 + 2 * U);
+        if (s0 + U < s_end) block(bufB, s0 + U);
+    }
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) {
+            const double t = wave_sum(acc[a][b]);
+            if (lane == 0) H.partials[(((int64_t)tile * HESS_T * HESS_T + a * HESS_T + b) * A.n_chunks + chunk) * tv.n_groups + g] = t;
+        }
+}
+
+// H[k + l n] (and its mirror) = the tile's partials summed over windows and groups in a fixed order
+__global__ __launch_bounds__(64) void iso_drift_hess_reduce_kernel(const DriftHessArgs H, int n_items) {
+    const int tile = blockIdx.x, e = blockIdx.y, a = e / HESS_T, b = e % HESS_T;
+    const int k = H.tile_i[tile] * HESS_T + a, l = H.tile_j[tile] * HESS_T + b;
+    if (k >= H.n || l >= H.n) return;
+    const double* p = H.partials + ((int64_t)tile * HESS_T * HESS_T + e) * n_items;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_items; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) { H.hess[k + (int64_t)l * H.n] = s; H.hess[l + (int64_t)k * H.n] = s; }
+}
+
+hipError_t launch_iso_drift_hess(int model, const IsoArgs& a, const DriftHessArgs& hx, int n_tiles, hipStream_t s) {
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES, n_tiles), block(WG_WAVES * WAVE);
+    if (grid.x == 0) return hipSuccess;
+    if (model == M_CTCRW) hipLaunchKernelGGL((iso_drift_hess_kernel<M_CTCRW>), grid, block, 0, s, a, hx);
+    else if (model == M_OU_SSM) hipLaunchKernelGGL((iso_drift_hess_kernel<M_OU_SSM>), grid, block, 0, s, a, hx);
+    else if (model == M_BM_SSM) hipLaunchKernelGGL((iso_drift_hess_kernel<M_BM_SSM>), grid, block, 0, s, a, hx);
+    else return hipErrorInvalidValue;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(iso_drift_hess_reduce_kernel, dim3(n_tiles, HESS_T * HESS_T), dim3(64), 0, s, hx, a.n_chunks * a.tv.n_groups);
+    return hipGetLastError();
+}
+
 template <int MODEL, int D>
 static hipError_t launch_ng(const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     dim3 block(WG_WAVES * WAVE);

@@ -42,6 +42,7 @@ constexpr int MAX_PARTS = 4;     // direction split: at most one part per direct
 constexpr int MAX_PAR = 320;     // parameters passed by value in the kernel argument block
 constexpr int MAX_COLS = 96;     // streamed design columns (dense / direct kernels)
 constexpr int MAX_Q = 4;         // SDE parameters per row (d + 2, d <= 2)
+constexpr int HESS_T = 8;         // exact Hessians: coefficient pairs are cut into HESS_T x HESS_T tiles
 constexpr int DRIFT_KMAX = 24;   // streamed drift columns of the shared-covariance kernel with a row-varying drift (k_iso_drift.hip)
 
 struct TileView {
@@ -135,6 +136,17 @@ int drift_nstate(int model, int d, int k);
 // the same model with the lane's own covariance (missing rows / irregular grid): general step + column recursions
 hipError_t launch_iso_drift_general(int model, int d, const IsoArgs& a, hipStream_t s);
 int drift_general_nstate(int model, int d, int k);
+// exact Hessian over the drift coefficients, shared-covariance case (k_iso_drift.hip: iso_drift_hess_kernel)
+constexpr int DRIFT_HESS_MAXN = DRIFT_KMAX + 2;     // streamed columns + one intercept per dimension
+struct DriftHessArgs {
+    int n;                         // slots
+    const int16_t* chan;           // device [n]: tile channel of the slot's column, or -1: an intercept (a column of ones)
+    const int16_t* tile_i;         // device [n_tiles]
+    const int16_t* tile_j;
+    double* partials;              // [n_tiles][HESS_T^2][n_chunks][n_groups]
+    double* hess;                  // [n x n] column-major
+};
+hipError_t launch_iso_drift_hess(int model, const IsoArgs& a, const DriftHessArgs& hx, int n_tiles, hipStream_t s);
 hipError_t launch_window_check(int model, int d, const IsoArgs& a, hipStream_t s);
 struct ReduceArgs;
 // the hand-over checks and the final sums of an isotropic evaluation in ONE launch (the checks raise out[n_out])
@@ -286,7 +298,6 @@ struct DirectFastArgs {
 };
 hipError_t launch_direct_fast(const DirectFastArgs& a, hipStream_t s);
 // exact Hessian of the data term over coefficients of the linear predictor, BM / OU (k_direct_hess.hip)
-constexpr int HESS_T = 8;         // coefficient pairs are cut into HESS_T x HESS_T tiles
 struct DirectHessArgs {
     const double* times;
     const double* obs;

@@ -250,6 +250,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
     if (const char* e = getenv("SSDE_W0_RATIO")) h->env_w0_ratio = atof(e);     // 0 = equal windows on the general kernel
     h->env_no_derive = getenv("SSDE_NO_DERIVE") != nullptr;
     h->env_no_graph = getenv("SSDE_NO_GRAPH") != nullptr;
+    h->env_no_exact_hess = getenv("SSDE_NO_EXACT_HESS") != nullptr;
     h->env_own_stream = getenv("SSDE_SYNC_OWN_STREAM") != nullptr;
     h->trace = getenv("SSDE_TRACE") != nullptr;
     if (const char* e = getenv("SSDE_WAVE_CLOCK")) h->wave_clock_file = e;
@@ -1227,6 +1228,13 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
                 HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
                 HIPCHK(h, launch_iso(h->model, h->d, ad, true, h->aux[1]));
                 HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
+            }
+            if (h->drift && h->hess_req) {
+                // ssde_hess on a drift handle: the same plan, the same gains, the Hessian kernels instead of the evaluation
+                h->hess_req = false;
+                DriftHessArgs hx = h->hess_args;
+                HIPCHK(h, launch_iso_drift_hess(h->model, b, hx, h->hess_tiles, s));
+                return SSDE_OK;
             }
             if (h->drift) HIPCHK(h, launch_iso_drift(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
             else HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));

@@ -128,7 +128,7 @@ struct ssde_handle {
     int n_retries = 0;
     // testing / tuning knobs, read once at create: nothing calls getenv per evaluation
     int env_window = 0, env_tv_waves = 0, env_tv_minlen = 0;
-    bool env_no_derive = false, env_no_graph = false;
+    bool env_no_derive = false, env_no_graph = false, env_no_exact_hess = false;   // (SSDE_NO_EXACT_HESS: difference the gradient even where ssde_hess is exact)
     double env_t0_cost = 3.0;
     double env_w0_ratio = 1.2;     // (measured: 0 .. 1.45 swept, 3 % on CTCRW at 1.2, nothing on the scalar models) cost of a row of window 0 (every direction) over a row of a later window (one derived)
     // recovery from a widened plan (ssde_eval): after `cooldown` evaluations accepted at the first try the boost is
@@ -146,6 +146,10 @@ struct ssde_handle {
     int drift = 0;                 // row-varying drift on the register path (k_iso_drift.hip): 1 = shared-covariance lanes (regular grid, complete
                                    // tracks), 2 = lanes with their own covariance (missing rows / irregular grid)
     int drift_nstate = 0;          // components of its hand-over dumps
+    // exact Hessian over the drift coefficients (ssde_hess.hip): eval_device launches the Hessian kernels instead of an evaluation
+    bool hess_req = false;
+    DriftHessArgs hess_args;
+    int hess_tiles = 0;
     // one-row tracks never reach a kernel; REPORT(aest_all) still shows their a0 (nllk_ctcrw.hpp:196-200, 246)
     std::vector<int64_t> single_rows;
     std::vector<double> single_a0;       // [single_rows.size()][sdim]
@@ -302,7 +306,10 @@ void destroy_dist(ssde_handle* h);
 hipError_t launch_sum_into(double* dst, const double* src, int n, hipStream_t s);   // k_reduce.hip
 
 // ---- exact second derivatives, direct families BM / OU (ssde_hess.hip) -------------------------------------------------
-bool hess_exact_available(const ssde_handle* h);
+// 0: no exact second derivatives; 1: over the drift coefficients of a shared-covariance drift handle (and log_lambda);
+// 2: over every coefficient and log_lambda (direct families BM / OU)
+int hess_exact_scope(const ssde_handle* h);
+inline bool hess_exact_available(const ssde_handle* h) { return hess_exact_scope(h) == 2; }
 int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H);
 
 // copy a caller array (host or device) into a fresh device buffer

@@ -4,8 +4,10 @@
 //
 // EXACT for the Gaussian direct families BM and OU: their SDE parameters are linear in the coefficients, so the Hessian
 // of the data term is X' D X with the closed-form per-row D of k_direct_hess.hip, and the smoothing penalty is a
-// quadratic form in coeff_re times exp(log_lambda) (nllk_sde.hpp:91-124): nothing is differenced.  Every other model
-// returns SSDE_ERR_MODEL: the documented route there is central differences of ssde_eval's gradient (what
+// quadratic form in coeff_re times exp(log_lambda) (nllk_sde.hpp:91-124): nothing is differenced.  EXACT as well over the
+// drift coefficients of a state-space batch on the shared-covariance lanes (a smooth mu, everything else constant, regular
+// grid, complete tracks: k_iso_drift.hip): the innovations are linear in them, so the Hessian is sum_i F_i^-1 mx_k mx_l of
+// the column recursions the evaluation already runs.  Every other model / entry returns SSDE_ERR_MODEL / SSDE_ERR_ARG: the documented route there is central differences of ssde_eval's gradient (what
 // ssde_laplace_eval, smoothsde_amd/report.py and R_glue's he() do).
 #include <cmath>
 #include <cstring>
@@ -16,17 +18,68 @@
 
 namespace ssde_engine {
 
-bool hess_exact_available(const ssde_handle* h) {
+int hess_exact_scope(const ssde_handle* h) {
     const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
-    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return false;
-    for (const ssde_handle* s : h->shards) if (s->path != PATH_DIRECT) return false;
+    if (h->n_dim_parts > 1 || e->env_no_exact_hess) return 0;
+    if (e->path == PATH_ISO) {
+        // a smooth drift on the shared-covariance lanes: the data term is QUADRATIC in the drift coefficients (k_iso_drift.hip)
+        if (e->drift != 1) return 0;
+        for (const ssde_handle* s : h->shards) if (s->path != PATH_ISO || s->drift != 1) return 0;
+        return 1;
+    }
+    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
+    for (const ssde_handle* s : h->shards) if (s->path != PATH_DIRECT) return 0;
     auto resident = [](const ssde_handle* g) {
         for (auto& sl : g->slots) if (sl.col == -2) return false;          // a block evaluated from its basis table has no columns to read
         return true;
     };
-    if (h->shards.empty()) return resident(h);
-    for (const ssde_handle* s : h->shards) if (!resident(s)) return false;
-    return h->n_dim_parts <= 1;
+    if (h->shards.empty()) return resident(h) ? 2 : 0;
+    for (const ssde_handle* s : h->shards) if (!resident(s)) return 0;
+    return 2;
+}
+
+// drift handle: Hessian of the data term over the mu coefficients idx[] (streamed columns and intercepts), device buffer
+static int hess_drift_device(ssde_handle* h, const double* par, const std::vector<int>& idx, DevBuf<double>& hess_dev, hipStream_t s,
+                             std::vector<int>& dim_of) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int n = (int)idx.size();
+    std::vector<int16_t> chan(n, 0);
+    dim_of.assign(n, 0);
+    for (int k = 0; k < n; k++) {
+        const Slot* sl = nullptr;
+        for (auto& t : h->slots) if (t.pidx == idx[k]) sl = &t;
+        if (!sl || sl->par_j >= h->d) { h->err = "ssde_hess: on a state-space model only the drift coefficients (and log_lambda) have exact second derivatives"; return SSDE_ERR_ARG; }
+        chan[k] = sl->col >= 0 ? (int16_t)(h->c_obs + h->d + sl->col) : (int16_t)-1;
+        dim_of[k] = sl->par_j;
+    }
+    // the window plan is the evaluation's: evaluate once at these parameters first (answered from the memo after an
+    // ssde_eval at the same point), so that a hand-over failure widens the plan before the Hessian pass uses it
+    {
+        double v;
+        std::vector<double> g((size_t)h->L.n_full);
+        int st = ssde_eval(h, par, h->L.n_full, 1, &v, g.data());
+        if (st) return st;
+    }
+    const int nt = (n + HESS_T - 1) / HESS_T;
+    std::vector<int16_t> ti, tj;
+    for (int a = 0; a < nt; a++) for (int b = a; b < nt; b++) { ti.push_back((int16_t)a); tj.push_back((int16_t)b); }
+    const int n_tiles = (int)ti.size();
+    DevBuf<int16_t> d_ch, d_ti, d_tj;
+    DevBuf<double> partials;
+    HIPCHK(h, d_ch.upload(chan)); HIPCHK(h, d_ti.upload(ti)); HIPCHK(h, d_tj.upload(tj));
+    HIPCHK(h, partials.alloc((size_t)n_tiles * HESS_T * HESS_T * (size_t)(h->max_chunks + 1) * h->n_groups));
+    HIPCHK(h, hess_dev.alloc((size_t)n * n));
+    h->hess_args.n = n; h->hess_args.chan = d_ch.p; h->hess_args.tile_i = d_ti.p; h->hess_args.tile_j = d_tj.p;
+    h->hess_args.partials = partials.p; h->hess_args.hess = hess_dev.p;
+    h->hess_tiles = n_tiles;
+    h->hess_req = true;
+    if (h->async_pending) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_async, 0)); h->async_pending = false; }
+    int st = eval_device(h, par, 1, h->out.p, s);
+    h->hess_req = false;
+    if (st) return st;
+    HIPCHK(h, hipStreamSynchronize(s));
+    d_ch.release(); d_ti.release(); d_tj.release(); partials.release();
+    return SSDE_OK;
 }
 
 // data-term Hessian of ONE engine over the coefficients with full-parameter indices idx[] (slots only), left in the
@@ -67,7 +120,8 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
 
 // H (n_idx x n_idx, column-major, host) of the joint penalised nllk over the full-parameter indices idx[]
 int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H) {
-    if (!hess_exact_available(h)) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU with resident design columns and no decaying terms"; return SSDE_ERR_MODEL; }
+    const int scope = hess_exact_scope(h);
+    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms) and for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows"; return SSDE_ERR_MODEL; }
     const ParLayout& L = h->L;
     const int np = L.n_full;
     for (int k = 0; k < n_idx; k++)
@@ -86,7 +140,8 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
         auto one = [&](ssde_handle* e, bool all_reduce) -> int {
             DevBuf<double> hd;
             hipStream_t s = e->own_stream ? e->own_stream : 0;
-            int st = hess_data_device(e, par, cidx, hd, s);
+            std::vector<int> dim_of;
+            int st = scope == 2 ? hess_data_device(e, par, cidx, hd, s) : hess_drift_device(e, par, cidx, hd, s, dim_of);
             if (st) { h->err = e->err; hd.release(); return st; }
             if (all_reduce) {
                 // ranks of a communicator: the batch's Hessian is the sum of the ranks' (tracks are independent)
@@ -97,6 +152,9 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
             hipError_t ce = hipMemcpy(tmp.data(), hd.p, (size_t)nu * nu * 8, hipMemcpyDeviceToHost);
             hd.release();
             if (ce != hipSuccess) { h->err = "ssde_hess: read-back failed"; return SSDE_ERR_HIP; }
+            if (scope == 1)                                 // columns that feed different dimensions do not meet in the likelihood
+                for (int a = 0; a < nu; a++)
+                    for (int b = 0; b < nu; b++) if (dim_of[a] != dim_of[b]) tmp[a + (size_t)b * nu] = 0.0;
             for (size_t k = 0; k < tmp.size(); k++) Hd[k] += tmp[k];
             return SSDE_OK;
         };
@@ -117,7 +175,7 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
     }
     // ---- smoothing penalty (nllk_sde.hpp:91-124): sum_s [ -Sn/2 log_lambda_s + exp(log_lambda_s)/2 b_s' S_s b_s ] -----
     const Penalty& P = h->pen;
-    if (!P.ncol.empty() && P.include_penalty) {
+    if (!P.ncol.empty() && (P.include_penalty || is_kalman(h->model))) {       // (the Kalman templates ignore include_penalty: Q7)
         std::vector<int> where(np, -1);
         for (int k = 0; k < n_idx; k++) where[idx[k]] = k;
         int start = 0;

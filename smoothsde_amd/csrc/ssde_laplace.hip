@@ -69,7 +69,8 @@ struct Laplace {
     std::vector<int> ir;               // coeff_re entries that are not fixed
     double hess_step, fd_step, newton_tol;
     int max_newton;
-    bool exact = false;                // exact second derivatives available (ssde_engine::hess_exact_available)
+    bool exact = false;                // exact second derivatives over EVERY parameter (ssde_engine::hess_exact_scope == 2)
+    bool exact_uu = false;             // ... over the random-effect coefficients at least (scope >= 1)
     std::vector<double> work, grad;
 
     int joint(const std::vector<double>& par, double* v, std::vector<double>* g) {
@@ -129,9 +130,12 @@ struct Laplace {
     // H_uu at (par): central differences of the gradient, symmetrised
     int hess_uu(const std::vector<double>& par, std::vector<double>& H) {
         H.assign((size_t)nu * nu, 0.0);
-        if (exact) {                                 // direct families BM / OU: X' D X + lambda S, nothing differenced (ssde_hess.hip)
+        if (exact_uu) {                              // direct families BM / OU, smooth-drift state-space batches: nothing differenced (ssde_hess.hip)
             std::vector<int32_t> ix(ir.begin(), ir.end());
-            return ssde_engine::hess_exact(h, par.data(), ix.data(), nu, H.data());
+            const int st = ssde_engine::hess_exact(h, par.data(), ix.data(), nu, H.data());
+            if (st != SSDE_ERR_ARG && st != SSDE_ERR_MODEL) return st;
+            exact_uu = false;                        // (an entry without exact second derivatives after all: difference the gradient)
+            H.assign((size_t)nu * nu, 0.0);
         }
         std::vector<std::vector<double>> P;
         std::vector<double> steps((size_t)nu);
@@ -197,7 +201,7 @@ struct Laplace {
             double smax = 0.0, umax = 0.0;
             for (int i = 0; i < nu; i++) { smax = std::max(smax, std::fabs(t * step[i])); umax = std::max(umax, std::fabs(p_new[ir[i]])); }
             par = p_new; *val = v_new; g = g_new;
-            h_current = smax <= (exact ? 1e-12 : 1e-3 * hess_step) * std::max(1.0, umax);   // H moved by less than its own (differencing) error
+            h_current = smax <= (exact_uu ? 1e-12 : 1e-3 * hess_step) * std::max(1.0, umax);   // H moved by less than its own (differencing) error
             if (smax <= newton_tol * std::max(1.0, umax)) break;
         }
         if (!h_current && std::isfinite(*val)) {
@@ -217,11 +221,12 @@ extern "C" int ssde_laplace_eval(ssde_handle* h, double* par, int32_t n_par_full
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     Laplace lp;
     lp.h = h; lp.np = n_par_full;
-    lp.exact = ssde_engine::hess_exact_available(h);
+    lp.exact = ssde_engine::hess_exact_scope(h) == 2;
+    lp.exact_uu = ssde_engine::hess_exact_scope(h) >= 1;
     lp.hess_step = (opts && opts->hess_step > 0) ? opts->hess_step : 1e-4;
     // the log-determinant term differences H_uu: with exact Hessians a shorter step is affordable (truncation e^2, rounding 1e-16 / e)
-    lp.fd_step = (opts && opts->fd_step > 0) ? opts->fd_step : (lp.exact ? 1e-5 : 1e-4);
-    lp.newton_tol = (opts && opts->newton_tol > 0) ? opts->newton_tol : (lp.exact ? 1e-10 : 1e-8);   // (exact Hessians: Newton converges quadratically)
+    lp.fd_step = (opts && opts->fd_step > 0) ? opts->fd_step : (lp.exact_uu ? 1e-5 : 1e-4);
+    lp.newton_tol = (opts && opts->newton_tol > 0) ? opts->newton_tol : (lp.exact_uu ? 1e-10 : 1e-8);   // (exact Hessians: Newton converges quadratically)
     lp.max_newton = (opts && opts->max_newton > 0) ? opts->max_newton : 30;
     for (int k = 0; k < h->L.n_re; k++)
         if (!h->fixed[h->L.off_re + k]) lp.ir.push_back(h->L.off_re + k);

@@ -209,3 +209,75 @@ def test_laplace_gradient_with_exact_hessians_reaches_1e_7(name):
     # no differenced Hessian: a handful of joint evaluations (Newton + line search), not 2 n_u per Hessian
     assert n_joint <= 40, n_joint
     eng.close()
+
+
+# ---- exact second derivatives over the drift coefficients of a state-space batch (k_iso_drift.hip) ---------------------
+DRIFT = ["CTCRW_d2_drift", "BM_SSM_d2_drift_fixsig", "CTCRW_d1_drift_fe", "OU_SSM_d1_drift"]
+
+
+def _mu_entries(pb):
+    """full-parameter indices of every coefficient of mu_1 .. mu_d (fixed and random), and of log_lambda"""
+    idx = []
+    for j in range(pb.n_dim):
+        idx += [pb.off_fe + pb.fe_off[j] + c for c in range(pb.ncol_fe[j])]
+        idx += [pb.off_re + pb.re_off[j] + c for c in range(pb.ncol_re[j])]
+    return sorted(idx) + [pb.off_lambda + s for s in range(pb.n_smooth)]
+
+
+@pytest.mark.parametrize("name", DRIFT)
+def test_exact_hessian_of_the_drift_coefficients_matches_autograd(name):
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = _mu_entries(pb)
+    eng = capi.Engine(pb)
+    H = eng.hess(par, idx)
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
+    assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
+    with pytest.raises(capi.EngineError, match="only the drift coefficients"):
+        eng.hess(par, [pb.off_fe + pb.fe_off[pb.n_dim]])            # tau / sigma: no exact second derivative here
+    eng.close()
+
+
+def test_drift_hessian_on_long_tracks_with_time_windows_matches_the_differenced_gradient():
+    from test_gpu_drift import _batch
+    pb, par = _batch("CTCRW", 2, 96, 1500, (9, 5), seed=11)
+    eng = capi.Engine(pb)
+    idx = [k for k in range(pb.off_re, pb.off_re + pb.n_re)] + [pb.off_fe, pb.off_fe + 1]
+    H = eng.hess(par, idx)
+    assert eng.info()["lanes_per_track"] > 1
+    Hfd = np.zeros_like(H)
+    for j, k in enumerate(idx):
+        e = 1e-4
+        pp, pm = par.copy(), par.copy()
+        pp[k] += e; pm[k] -= e
+        Hfd[:, j] = (eng.eval(pp)[1][idx] - eng.eval(pm)[1][idx]) / (2 * e)
+    # the data term is quadratic in these coefficients: central differences are exact up to rounding
+    assert np.max(np.abs(H - Hfd)) <= 1e-7 * np.max(np.abs(H)), np.max(np.abs(H - Hfd)) / np.max(np.abs(H))
+    em = capi.Engine(pb, devices=[0, 0])
+    assert np.max(np.abs(em.hess(par, idx) - H)) <= 1e-11 * np.max(np.abs(H))
+    eng.close(); em.close()
+
+
+@pytest.mark.parametrize("name", ["CTCRW_d2_drift", "BM_SSM_d2_drift_fixsig"])
+def test_laplace_on_a_smooth_drift_uses_the_exact_hessian(name):
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    io, ir = _split(pb)
+    eng = capi.Engine(pb)
+    f_exact, u_exact = _exact_laplace(pb, par, ir)
+    par[ir] = u_exact + 1e-3 * np.cos(np.arange(len(ir)))
+    n0 = eng.info()["n_evals"]
+    f, g, p_hat, H = eng.laplace_eval(par, order=1, want_hessian=True)
+    n_joint = eng.info()["n_evals"] - n0
+    assert abs(f - f_exact) <= 1e-9 * max(1.0, abs(f_exact)), (f, f_exact)
+    assert np.max(np.abs(p_hat[ir] - u_exact)) <= 1e-7
+    pe = par.copy()
+    pe[ir] = u_exact
+    g_exact = _exact_marginal_gradient(pb, pe, io, ir)
+    # H_uu exact, H_u,theta a central difference of the device gradient: 1e-6 (1e-4 with a differenced H_uu)
+    assert np.max(np.abs(g[io] - g_exact)) <= 1e-6 * max(1.0, np.max(np.abs(g_exact))), (g[io], g_exact)
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(pe), ir), torch.tensor(u_exact)).numpy()
+    assert np.max(np.abs(H - H_exact)) <= 1e-8 * np.max(np.abs(H_exact))
+    eng.close()
