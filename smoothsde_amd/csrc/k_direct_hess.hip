@@ -89,6 +89,17 @@ __global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A
         ca[a] = T->col[sa] >= 0 ? A.cols[T->col[sa]] : nullptr;
         cb[a] = T->col[sb] >= 0 ? A.cols[T->col[sb]] : nullptr;
     }
+    // the slot table once per workgroup, in LDS: column pointer (NULL = intercept), coefficient, SDE parameter
+    __shared__ const double* s_col[MAX_COLS];
+    __shared__ double s_coef[MAX_COLS];
+    __shared__ int s_pj[MAX_COLS];
+    for (int k = threadIdx.x; k < ns; k += 256) {
+        const int c = T->col[k];
+        s_col[k] = c >= 0 ? A.cols[c] : nullptr;
+        s_coef[k] = A.par[T->pidx[k]];
+        s_pj[k] = T->par_j[k];
+    }
+    __syncthreads();
     const int64_t per_block = ((A.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
     const int64_t row_lo = (int64_t)blockIdx.x * per_block;
     const int64_t row_hi = row_lo + per_block < A.n ? row_lo + per_block : A.n;
@@ -97,9 +108,9 @@ __global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A
         const double dt = A.times[i] - A.times[i - 1];                             // dtimes(i-1), nllk_sde.hpp:37, 80
         double par[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
         for (int k = 0; k < ns; k++) {                                             // the linear predictor of row i-1 (Q6)
-            const int c = T->col[k], j = T->par_j[k];
-            const double x = c >= 0 ? A.cols[c][i - 1] : 1.0;
-            const double t = x * A.par[T->pidx[k]];
+            const double* cp = s_col[k];
+            const int j = s_pj[k];
+            const double t = (cp ? cp[i - 1] : 1.0) * s_coef[k];
             par[0] += j == 0 ? t : 0.0; par[1] += j == 1 ? t : 0.0; par[2] += j == 2 ? t : 0.0; par[3] += j == 3 ? t : 0.0;
         }
         double Dm[MAX_Q][MAX_Q];
@@ -118,21 +129,19 @@ __global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A
             for (int b = 0; b < HESS_T; b++) acc[a][b] = fma(pick4(row, jb[b]), xb[b], acc[a][b]);
         }
     }
-    // workgroup sums in a fixed order: [tile][a * HESS_T + b][block]
-    __shared__ double sh[256];
+    // workgroup sums in a fixed order (wave shuffles, then the four waves): [tile][a * HESS_T + b][block]
+    __shared__ double sh[HESS_T * HESS_T][4];
 #pragma unroll
     for (int a = 0; a < HESS_T; a++)
 #pragma unroll
         for (int b = 0; b < HESS_T; b++) {
-            sh[threadIdx.x] = acc[a][b];
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) A.partials[((int64_t)tile * HESS_T * HESS_T + a * HESS_T + b) * gridDim.x + blockIdx.x] = sh[0];
-            __syncthreads();
+            const double t = wave_sum(acc[a][b]);
+            if ((threadIdx.x & 63) == 0) sh[a * HESS_T + b][threadIdx.x >> 6] = t;
         }
+    __syncthreads();
+    if (threadIdx.x < HESS_T * HESS_T)
+        A.partials[((int64_t)tile * HESS_T * HESS_T + threadIdx.x) * gridDim.x + blockIdx.x] =
+            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
 // H[k + l nu] (and its mirror) = sum over blocks of the tile's partials, in block order

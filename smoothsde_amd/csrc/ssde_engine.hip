@@ -40,6 +40,7 @@ static void release_device(ssde_handle* h) {
         }
     }
     h->wave_clock.release();
+    h->hs_partials.release(); h->hs_hess.release(); h->hs_i16.release();
     if (h->trace && h->trace_n > 0)
         fprintf(stderr, "[ssde trace] %lld isotropic evaluations, host us per evaluation: plan %.1f | gain table %.1f | main launch %.1f | "
                         "finalize launch %.1f | read-back (blocks until the GPU is done) %.1f\n", (long long)h->trace_n,

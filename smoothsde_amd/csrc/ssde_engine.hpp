@@ -147,6 +147,8 @@ struct ssde_handle {
                                    // tracks), 2 = lanes with their own covariance (missing rows / irregular grid)
     int drift_nstate = 0;          // components of its hand-over dumps
     // exact Hessian over the drift coefficients (ssde_hess.hip): eval_device launches the Hessian kernels instead of an evaluation
+    DevBuf<double> hs_partials, hs_hess;      // scratch of the Hessian passes, kept between calls (allocation costs more than the pass)
+    DevBuf<int16_t> hs_i16;
     bool hess_req = false;
     DriftHessArgs hess_args;
     int hess_tiles = 0;

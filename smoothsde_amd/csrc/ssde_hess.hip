@@ -38,8 +38,22 @@ int hess_exact_scope(const ssde_handle* h) {
     return 2;
 }
 
+// scratch of a Hessian pass, kept in the handle between calls: three small index arrays (one upload), partials, the result
+static int hess_scratch(ssde_handle* h, const std::vector<int16_t>& a, const std::vector<int16_t>& ti, const std::vector<int16_t>& tj,
+                        size_t n_partials, size_t n_hess, const int16_t** pa, const int16_t** pti, const int16_t** ptj) {
+    std::vector<int16_t> pack(a);
+    pack.insert(pack.end(), ti.begin(), ti.end());
+    pack.insert(pack.end(), tj.begin(), tj.end());
+    if (h->hs_i16.n < pack.size()) { h->hs_i16.release(); HIPCHK(h, h->hs_i16.alloc(std::max<size_t>(pack.size(), 512))); }
+    HIPCHK(h, hipMemcpy(h->hs_i16.p, pack.data(), pack.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (h->hs_partials.n < n_partials) { h->hs_partials.release(); HIPCHK(h, h->hs_partials.alloc(n_partials)); }
+    if (h->hs_hess.n < n_hess) { h->hs_hess.release(); HIPCHK(h, h->hs_hess.alloc(std::max<size_t>(n_hess, 1024))); }
+    *pa = h->hs_i16.p; *pti = h->hs_i16.p + a.size(); *ptj = h->hs_i16.p + a.size() + ti.size();
+    return SSDE_OK;
+}
+
 // drift handle: Hessian of the data term over the mu coefficients idx[] (streamed columns and intercepts), device buffer
-static int hess_drift_device(ssde_handle* h, const double* par, const std::vector<int>& idx, DevBuf<double>& hess_dev, hipStream_t s,
+static int hess_drift_device(ssde_handle* h, const double* par, const std::vector<int>& idx, const double** hess_dev, hipStream_t s,
                              std::vector<int>& dim_of) {
     HIPCHK(h, hipSetDevice(h->device));
     const int n = (int)idx.size();
@@ -64,13 +78,12 @@ static int hess_drift_device(ssde_handle* h, const double* par, const std::vecto
     std::vector<int16_t> ti, tj;
     for (int a = 0; a < nt; a++) for (int b = a; b < nt; b++) { ti.push_back((int16_t)a); tj.push_back((int16_t)b); }
     const int n_tiles = (int)ti.size();
-    DevBuf<int16_t> d_ch, d_ti, d_tj;
-    DevBuf<double> partials;
-    HIPCHK(h, d_ch.upload(chan)); HIPCHK(h, d_ti.upload(ti)); HIPCHK(h, d_tj.upload(tj));
-    HIPCHK(h, partials.alloc((size_t)n_tiles * HESS_T * HESS_T * (size_t)(h->max_chunks + 1) * h->n_groups));
-    HIPCHK(h, hess_dev.alloc((size_t)n * n));
-    h->hess_args.n = n; h->hess_args.chan = d_ch.p; h->hess_args.tile_i = d_ti.p; h->hess_args.tile_j = d_tj.p;
-    h->hess_args.partials = partials.p; h->hess_args.hess = hess_dev.p;
+    const int16_t *p_ch, *p_ti, *p_tj;
+    int sst = hess_scratch(h, chan, ti, tj, (size_t)n_tiles * HESS_T * HESS_T * (size_t)(h->max_chunks + 1) * h->n_groups, (size_t)n * n, &p_ch, &p_ti, &p_tj);
+    if (sst) return sst;
+    h->hess_args.n = n; h->hess_args.chan = p_ch; h->hess_args.tile_i = p_ti; h->hess_args.tile_j = p_tj;
+    h->hess_args.partials = h->hs_partials.p; h->hess_args.hess = h->hs_hess.p;
+    *hess_dev = h->hs_hess.p;
     h->hess_tiles = n_tiles;
     h->hess_req = true;
     if (h->async_pending) { HIPCHK(h, hipStreamWaitEvent(s, h->ev_async, 0)); h->async_pending = false; }
@@ -78,13 +91,12 @@ static int hess_drift_device(ssde_handle* h, const double* par, const std::vecto
     h->hess_req = false;
     if (st) return st;
     HIPCHK(h, hipStreamSynchronize(s));
-    d_ch.release(); d_ti.release(); d_tj.release(); partials.release();
     return SSDE_OK;
 }
 
 // data-term Hessian of ONE engine over the coefficients with full-parameter indices idx[] (slots only), left in the
 // device buffer `hess_dev` (nu x nu, column-major) on stream s
-static int hess_data_device(ssde_handle* h, const double* par, const std::vector<int>& idx, DevBuf<double>& hess_dev, hipStream_t s) {
+static int hess_data_device(ssde_handle* h, const double* par, const std::vector<int>& idx, const double** hess_dev, hipStream_t s) {
     HIPCHK(h, hipSetDevice(h->device));
     const int nu = (int)idx.size();
     std::vector<int16_t> uslot(nu, 0);
@@ -99,11 +111,10 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     for (int a = 0; a < nt; a++) for (int b = a; b < nt; b++) { ti.push_back((int16_t)a); tj.push_back((int16_t)b); }
     const int n_tiles = (int)ti.size();
     const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->n + 2047) / 2048));
-    DevBuf<int16_t> d_us, d_ti, d_tj;
-    DevBuf<double> partials;
-    HIPCHK(h, d_us.upload(uslot)); HIPCHK(h, d_ti.upload(ti)); HIPCHK(h, d_tj.upload(tj));
-    HIPCHK(h, partials.alloc((size_t)n_tiles * HESS_T * HESS_T * n_blocks));
-    HIPCHK(h, hess_dev.alloc((size_t)nu * nu));
+    const int16_t *p_us, *p_ti, *p_tj;
+    int sst = hess_scratch(h, uslot, ti, tj, (size_t)n_tiles * HESS_T * HESS_T * n_blocks, (size_t)nu * nu, &p_us, &p_ti, &p_tj);
+    if (sst) return sst;
+    *hess_dev = h->hs_hess.p;
     const double* pdev = nullptr;
     int st = push_par(h, par, s, &pdev);
     if (st) return st;
@@ -111,10 +122,9 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     memset(&a, 0, sizeof(a));
     a.times = h->times.p; a.obs = h->obs.p; a.cols = h->colptr.p; a.scored = h->scored.p; a.n = h->n;
     a.d = h->d; a.model = h->model; a.any_nan = h->na_any; a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
-    a.nu = nu; a.uslot = d_us.p; a.tile_i = d_ti.p; a.tile_j = d_tj.p; a.partials = partials.p; a.hess = hess_dev.p;
+    a.nu = nu; a.uslot = p_us; a.tile_i = p_ti; a.tile_j = p_tj; a.partials = h->hs_partials.p; a.hess = h->hs_hess.p;
     HIPCHK(h, launch_direct_hess(a, n_tiles, n_blocks, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    d_us.release(); d_ti.release(); d_tj.release(); partials.release();
     return SSDE_OK;
 }
 
@@ -138,19 +148,18 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
     if (nu > 0) {
         std::vector<double> Hd((size_t)nu * nu, 0.0), tmp((size_t)nu * nu);
         auto one = [&](ssde_handle* e, bool all_reduce) -> int {
-            DevBuf<double> hd;
+            const double* hd = nullptr;
             hipStream_t s = e->own_stream ? e->own_stream : 0;
             std::vector<int> dim_of;
-            int st = scope == 2 ? hess_data_device(e, par, cidx, hd, s) : hess_drift_device(e, par, cidx, hd, s, dim_of);
-            if (st) { h->err = e->err; hd.release(); return st; }
+            int st = scope == 2 ? hess_data_device(e, par, cidx, &hd, s) : hess_drift_device(e, par, cidx, &hd, s, dim_of);
+            if (st) { h->err = e->err; return st; }
             if (all_reduce) {
                 // ranks of a communicator: the batch's Hessian is the sum of the ranks' (tracks are independent)
-                ncclResult_t r = rccl().AllReduce(hd.p, hd.p, (size_t)nu * nu, ncclDouble, ncclSum, (ncclComm_t)h->comms[0], s);
-                if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + rccl().GetErrorString(r); hd.release(); return SSDE_ERR_HIP; }
-                if (hipStreamSynchronize(s) != hipSuccess) { h->err = "ssde_hess: stream synchronisation failed"; hd.release(); return SSDE_ERR_HIP; }
+                ncclResult_t r = rccl().AllReduce(hd, (void*)hd, (size_t)nu * nu, ncclDouble, ncclSum, (ncclComm_t)h->comms[0], s);
+                if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + rccl().GetErrorString(r); return SSDE_ERR_HIP; }
+                if (hipStreamSynchronize(s) != hipSuccess) { h->err = "ssde_hess: stream synchronisation failed"; return SSDE_ERR_HIP; }
             }
-            hipError_t ce = hipMemcpy(tmp.data(), hd.p, (size_t)nu * nu * 8, hipMemcpyDeviceToHost);
-            hd.release();
+            hipError_t ce = hipMemcpy(tmp.data(), hd, (size_t)nu * nu * 8, hipMemcpyDeviceToHost);
             if (ce != hipSuccess) { h->err = "ssde_hess: read-back failed"; return SSDE_ERR_HIP; }
             if (scope == 1)                                 // columns that feed different dimensions do not meet in the likelihood
                 for (int a = 0; a < nu; a++)

@@ -212,7 +212,16 @@ def test_laplace_gradient_with_exact_hessians_reaches_1e_7(name):
 
 
 # ---- exact second derivatives over the drift coefficients of a state-space batch (k_iso_drift.hip) ---------------------
-DRIFT = ["CTCRW_d2_drift", "BM_SSM_d2_drift_fixsig", "CTCRW_d1_drift_fe", "OU_SSM_d1_drift"]
+def _small_drift_specs():
+    """the golden drift cases' shapes with 8 tracks (the torch references cost minutes on 34): SSDE_DRIFT_MIN_TRACKS=4 lets them in"""
+    from cases import drift_spec
+    return [drift_spec("CTCRW_d2_drift_small", "CTCRW", 2, seed=352, n_tracks=8, smooth_dims=(0, 1)),
+            drift_spec("BM_SSM_d2_drift_fixsig_small", "BM_SSM", 2, seed=353, n_tracks=8, smooth_dims=(1,), fix=(0,)),
+            drift_spec("CTCRW_d1_drift_fe_small", "CTCRW", 1, seed=354, n_tracks=8, fe_slope=True, smooth_dims=()),
+            drift_spec("OU_SSM_d1_drift_small", "OU_SSM", 1, seed=351, n_tracks=8)]
+
+
+DRIFT = _small_drift_specs()
 
 
 def _mu_entries(pb):
@@ -224,13 +233,14 @@ def _mu_entries(pb):
     return sorted(idx) + [pb.off_lambda + s for s in range(pb.n_smooth)]
 
 
-@pytest.mark.parametrize("name", DRIFT)
-def test_exact_hessian_of_the_drift_coefficients_matches_autograd(name):
-    rec = GOLD[name]
+@pytest.mark.parametrize("rec", DRIFT + [GOLD["OU_SSM_d1_drift"]], ids=lambda r: r["name"])
+def test_exact_hessian_of_the_drift_coefficients_matches_autograd(rec, monkeypatch):
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "4")
     pb = problem_from_spec(rec)
     par = rec["par"].copy()
     idx = _mu_entries(pb)
     eng = capi.Engine(pb)
+    assert eng.info()["path"] == 1 and eng.info()["const_coeff"] == 0
     H = eng.hess(par, idx)
     H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
     assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
@@ -259,9 +269,9 @@ def test_drift_hessian_on_long_tracks_with_time_windows_matches_the_differenced_
     eng.close(); em.close()
 
 
-@pytest.mark.parametrize("name", ["CTCRW_d2_drift", "BM_SSM_d2_drift_fixsig"])
-def test_laplace_on_a_smooth_drift_uses_the_exact_hessian(name):
-    rec = GOLD[name]
+@pytest.mark.parametrize("rec", DRIFT[:2], ids=lambda r: r["name"])
+def test_laplace_on_a_smooth_drift_uses_the_exact_hessian(rec, monkeypatch):
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "4")
     pb = problem_from_spec(rec)
     par = rec["par"].copy()
     io, ir = _split(pb)
