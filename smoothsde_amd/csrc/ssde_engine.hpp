@@ -292,9 +292,11 @@ namespace ssde_engine {
 
 int fail(ssde_handle* h, int code, const std::string& msg);
 
-// ssde_engine.hip
+// ssde_engine_build.hip
 int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout = nullptr);
 void destroy(ssde_handle* h);
+void release_device(ssde_handle* h);          // everything the handle holds on the device / in pinned memory (the handle stays)
+int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s, ReduceArgs& ra);   // ssde_engine_iso.hip
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s);
 
 // ---- distributed evaluation (ssde_engine_dist.hip) --------------------------------------------------------------------

@@ -1,0 +1,403 @@
+// ssde_engine_iso.hip -- one evaluation on the register Kalman path (constant coefficients, or a row-varying drift): the
+// window plan, the gain table of the shared-covariance kernels, the launches (shared / general / drift / mixed batch) and
+// the finalising launch (hand-over checks + fixed-order sums).  Called from eval_device (ssde_engine.hip).
+#include "ssde_engine.hpp"
+
+#include <chrono>
+
+using namespace ssde_engine;
+
+namespace {
+
+// Warm-up length of a time window: iterate the (data-independent) covariance recursion on the
+// host at the smallest interval of the batch until it is stationary, take the spectral radius
+// rho of the closed-loop matrix T - K Z there, and ask for rho^W <= 1e-18 (plus slack for the
+// t * rho^t growth of the sensitivity recursions).  The device-side hand-over check decides
+// whether the estimate was good enough; it never has to be trusted.
+void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) {
+    *n_chunks = 1;
+    *window = 0;
+    h->plan_warmup = 0;
+    if (h->max_chunks <= 1) return;
+    const double dt = h->uniform_dt ? h->dt_uniform : h->dt_min;
+    double rho = 1.0;
+    if (dt > 0.0 && std::isfinite(dt)) {
+        if (h->model == SSDE_MODEL_CTCRW) {
+            CtcrwTrans tr;
+            ctcrw_trans(dt, a.tau, a.beta, a.sigma, tr);
+            double p11 = a.p0[0], p12 = a.p0[1], p22 = a.p0[2], k1 = 0, k2 = 0;
+            for (int it = 0; it < 20000; it++) {
+                const double F = p11 + a.h, iF = 1.0 / F;
+                const double tp11 = p11 + tr.t12 * p12, tp12 = p12 + tr.t12 * p22, tp21 = tr.e * p12, tp22 = tr.e * p22;
+                k1 = tp11 * iF; k2 = tp21 * iF;
+                const double n11 = tp11 * (1.0 - k1) + tp12 * tr.t12 + tr.q11, n12 = -tp11 * k2 + tp12 * tr.e + tr.q12,
+                             n22 = -tp21 * k2 + tp22 * tr.e + tr.q22;
+                const double ch = std::fabs(n11 - p11) + std::fabs(n12 - p12) + std::fabs(n22 - p22);
+                p11 = n11; p12 = n12; p22 = n22;
+                if (ch <= 1e-15 * (std::fabs(p11) + std::fabs(p22))) break;
+            }
+            // L = [[1 - k1, t12], [-k2, e]]
+            const double trc = (1.0 - k1) + tr.e, det = (1.0 - k1) * tr.e + k2 * tr.t12;
+            const double disc = trc * trc - 4.0 * det;
+            rho = disc >= 0.0 ? std::max(std::fabs(0.5 * (trc + std::sqrt(disc))), std::fabs(0.5 * (trc - std::sqrt(disc))))
+                              : std::sqrt(std::fabs(det));
+        } else {
+            ScalTrans tr;
+            if (h->model == SSDE_MODEL_OU_SSM) ou_trans(dt, a.tau, a.sigma, tr);
+            else bm_trans(dt, a.sigma, tr);
+            double p = a.p0[0], k = 0;
+            for (int it = 0; it < 20000; it++) {
+                const double F = p + a.h, tp = tr.t * p;
+                k = tp / F;
+                const double np_ = tp * (tr.t - k) + tr.q;
+                const double ch = std::fabs(np_ - p);
+                p = np_;
+                if (ch <= 1e-15 * std::fabs(p)) break;
+            }
+            rho = std::fabs(tr.t - k);
+        }
+    }
+    int W = 0;
+    if (!(rho < 0.9995) || !std::isfinite(rho)) return;  // no usable forgetting: sequential filter
+    // The stationary CTCRW lanes run the filter as 1/D(q)^2 recursions (k_iso_shared.hip): with closed-loop poles
+    // close to 1 their intermediate signals grow like 1/(1-rho)^2 and cancel in the innovation -- below rho = 0.97
+    // that costs < 1e-12 relative; above, the evaluation stays on the sequential direction-form filter
+    if (h->use_shared && !h->drift && h->model == SSDE_MODEL_CTCRW && rho > 0.97) return;
+    W = (int)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
+    W = std::max(W, 16);
+    if (h->env_window > 0) W = h->env_window;                             // testing: deliberately short overlaps
+    if ((int64_t)W * h->window_boost > (int64_t)h->glen_max) return;     // longer than a track: sequential filter
+    W *= h->window_boost;
+    W = (W + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+    // a window must be long enough to amortise its warm-up
+    int glmax = 0;
+    {
+        // group lengths are sorted descending: the first group is the longest
+        glmax = h->glen_max;
+    }
+    int nc = h->want_chunks;
+    while (nc > 1 && (glmax / nc) < 2 * W) nc--;
+    *n_chunks = nc;
+    *window = nc > 1 ? W : 0;
+    h->plan_warmup = W;                                  // usable warm-up length even when one window is planned
+}
+
+// Shared-covariance path: run the covariance half of the filter (ssde_math.hpp) ONCE on the host
+// for the regular grid -- it does not depend on the observations -- until it is bitwise
+// stationary, upload the gains, and return the data-independent likelihood terms
+// (D/2 sum log F and its derivatives, weighted by how many tracks reach each row).
+template <int D>
+int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double add[4]) {
+    const int slot = h->par_next;
+    h->par_next = (h->par_next + 1) % PAR_RING;
+    // the ring protects the pinned slot of an ASYNCHRONOUS caller's earlier evaluation (ssde_eval_device); a
+    // synchronous ssde_eval has read its result back before the next call: no event traffic on that path
+    if (!h->sync_call || h->par_ev_pending[slot]) { HIPCHK(h, hipEventSynchronize(h->par_ev[slot])); h->par_ev_pending[slot] = false; }
+    double* host = h->gain_pinned + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
+    double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
+    const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
+    // running sums of log F and of its derivatives, row by row (member buffers: no allocation per evaluation)
+    std::vector<double>& cum_ld = h->gain_cum[0];
+    std::vector<double>* cum_g = &h->gain_cum[1];
+    for (int j = 0; j < 1 + NDIRP; j++) { if ((int)h->gain_cum[j].capacity() < tmax) h->gain_cum[j].reserve(tmax); h->gain_cum[j].clear(); }
+    int last = 0, stable = 0;
+    (void)mask;
+    // Stationarity test.  In floating point the recursion ends in a last-bit limit cycle rather than a
+    // bitwise fixed point, so "stationary" = every component moved by less than 2e-15 relative for 4 rows
+    // in a row; the row reached then is used for all later rows (a 1e-15 relative perturbation of gains
+    // that themselves carry rounding errors of that size).
+    auto close = [](double a, double b) { return std::fabs(a - b) <= 2e-15 * (std::fabs(a) + std::fabs(b)) + 1e-300; };
+    if (h->model == SSDE_MODEL_CTCRW) {
+        CtcrwCov<15> C;
+        C.init(a.p0[0], a.p0[1], a.p0[2]);
+        double ld = 0.0;
+        for (int t = 0; t < tmax; t++) {
+            const CtcrwCov<15> prev = C;
+            CtcrwGain G;
+            const double F = C.p11 + a.h;
+            ctcrw_cov_step<D, 15>(C, a.ctr, a.h, false, G);
+            double* r = host + (size_t)t * GAIN_ROW;
+            r[0] = G.iF; r[1] = G.k1; r[2] = G.k2; r[3] = G.bm;
+            for (int j = 0; j < NDIRP; j++) { r[4 + j] = G.diF[j]; r[7 + j] = G.dk1[j]; r[10 + j] = G.dk2[j]; }
+            r[13] = r[14] = r[15] = 0.0;
+            ld += (G.iF != 0.0) ? std::log(std::fabs(F)) : 0.0;
+            cum_ld.push_back(ld);
+            for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
+            last = t;
+            bool same = close(C.p11, prev.p11) && close(C.p12, prev.p12) && close(C.p22, prev.p22);
+            for (int j = 0; j < NDIRP && same; j++)
+                same = close(C.d11[j], prev.d11[j]) && close(C.d12[j], prev.d12[j]) && close(C.d22[j], prev.d22[j]);
+            stable = same ? stable + 1 : 0;
+            if (stable >= 4) break;
+        }
+    } else {
+        ScalCov<15> C;
+        C.init(a.p0[0]);
+        double ld = 0.0;
+        for (int t = 0; t < tmax; t++) {
+            const ScalCov<15> prev = C;
+            ScalGain G;
+            const double F = C.p + a.h;
+            if (h->model == SSDE_MODEL_OU_SSM) scal_cov_step<D, 15, true>(C, a.str, a.h, false, G);
+            else scal_cov_step<D, 15, false>(C, a.str, a.h, false, G);
+            double* r = host + (size_t)t * GAIN_ROW;
+            for (int k = 0; k < GAIN_ROW; k++) r[k] = 0.0;
+            r[0] = G.iF; r[1] = G.k; r[2] = G.c;
+            for (int j = 0; j < NDIRP; j++) { r[4 + j] = G.diF[j]; r[7 + j] = G.dk[j]; }
+            ld += (G.iF != 0.0) ? std::log(std::fabs(F)) : 0.0;
+            cum_ld.push_back(ld);
+            for (int j = 0; j < NDIRP; j++) cum_g[j].push_back(C.gld[j]);
+            last = t;
+            bool same = close(C.p, prev.p);
+            for (int j = 0; j < NDIRP && same; j++) same = close(C.dp[j], prev.dp[j]);
+            stable = same ? stable + 1 : 0;
+            if (stable >= 4) break;
+        }
+    }
+    const int rows = last + 1;
+    h->last_gain_rows = rows;
+    HIPCHK(h, hipMemcpyAsync(dev, host, (size_t)rows * GAIN_ROW * 8, hipMemcpyHostToDevice, s));
+    if (!h->sync_call) { HIPCHK(h, hipEventRecord(h->par_ev[slot], s)); h->par_ev_pending[slot] = true; }
+    a.gain = dev;
+    a.gain_last = last;
+    for (int k = 0; k < GAIN_ROW; k++) a.gain_stat[k] = host[(size_t)last * GAIN_ROW + k];
+    fill_stat_consts(h->model, h->d, a);
+    // data-independent terms: a track with ns scored rows contributes cum(ns - 1); past the
+    // stationary row every further row adds the same increment
+    auto cum_at = [&](const std::vector<double>& c, int idx) {
+        if (idx <= last) return c[idx];
+        const double inc = last > 0 ? c[last] - c[last - 1] : c[last];
+        return c[last] + inc * (double)(idx - last);
+    };
+    double s_ld = 0.0, s_g[NDIRP] = {0, 0, 0};
+    for (auto& e : h->clean_ns_hist) {
+        s_ld += (double)e.second * cum_at(cum_ld, e.first - 1);
+        for (int j = 0; j < NDIRP; j++) s_g[j] += (double)e.second * cum_at(cum_g[j], e.first - 1);
+    }
+    add[0] = 0.5 * D * s_ld;
+    for (int j = 0; j < NDIRP; j++) add[1 + j] = 0.5 * D * s_g[j];
+    return SSDE_OK;
+}
+
+}  // namespace
+
+namespace ssde_engine {
+
+int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s, ReduceArgs& ra) {
+    const ParLayout& L = h->L;
+    IsoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tv.tiles = h->tiles.p; a.tv.group_off = h->group_off.p; a.tv.group_len = h->group_len.p;
+    a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
+    a.partials = h->partials.p;
+    if (order >= 1) {
+        a.n_parts = h->iso_parts;
+        for (int p = 0; p < MAX_PARTS; p++) a.part_mask[p] = h->iso_masks[p];
+    } else {
+        a.n_parts = 1;
+    }
+    a.any_nan = h->na_any;
+    a.uniform_dt = h->uniform_dt ? 1 : 0;
+    const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
+    a.h = sig * sig;                                    // makeH: sigma_obs * sigma_obs
+    for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + L.fe_off[i]];
+    for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+    if (h->drift) {
+        // mu_a(i) = intercept + sum_k coef_k X_k(i) (nllk_ctcrw.hpp:143-149): the intercept slot (if any) goes where the
+        // constant-drift kernels keep mu, the streamed columns get their coefficients by the dimension they feed
+        for (int i = 0; i < h->d; i++) a.mu[i] = 0.0;
+        for (auto& sl : h->slots) {
+            if (sl.col < 0) { if (sl.par_j < h->d) a.mu[sl.par_j] = par[sl.pidx]; continue; }
+            if (sl.par_j == 0) a.coefA[sl.col] = par[sl.pidx];
+            else { a.coefB[sl.col] = par[sl.pidx]; a.drift_dim1 |= 1u << sl.col; }
+        }
+        a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+    }
+    const double p1 = par[L.off_fe + L.fe_off[h->d]];
+    const double p2 = (h->q > h->d + 1) ? par[L.off_fe + L.fe_off[h->d + 1]] : 0.0;
+    if (h->model == SSDE_MODEL_CTCRW) {
+        a.tau = exp(p1);                                // :153
+        const double nu = exp(p2);                      // :154
+        a.beta = 1.0 / a.tau;                           // :155
+        a.sigma = 2.0 * nu / sqrt(M_PI * a.tau);        // :156
+        if (h->uniform_dt) ctcrw_trans(h->dt_uniform, a.tau, a.beta, a.sigma, a.ctr);
+    } else if (h->model == SSDE_MODEL_OU_SSM) {
+        a.tau = exp(p1);
+        a.sigma = exp(p2);                              // kappa
+        if (h->uniform_dt) ou_trans(h->dt_uniform, a.tau, a.sigma, a.str);
+    } else {
+        a.sigma = exp(p1);
+        if (h->uniform_dt) bm_trans(h->dt_uniform, a.sigma, a.str);
+    }
+    auto tick = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tk0 = h->trace ? tick() : 0.0;
+    plan_windows(h, a, &a.n_chunks, &a.window);
+    if (h->trace) { const double t = tick(); h->trace_us[0] += t - tk0; tk0 = t; }
+    a.bnd = h->bnd.p; a.chk = h->chk.p;
+    a.bnd_stride = h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX;
+    a.chk_out = out_dev + (1 + L.n_full);
+    a.derive = (h->env_no_derive || h->drift) ? 0 : 1;
+    a.all_clean = ((h->use_shared && h->n_clean_groups == h->n_groups) || h->drift) ? 1 : 0;      // (drift: one dump layout for every group)
+    a.nstate_clean = h->drift ? h->drift_nstate
+                   : h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
+    h->last_chunks = a.n_chunks; h->last_window = a.window;
+    a.group_flags = h->group_flags.p;
+    a.group_mode = 0;
+    double add[4] = {0, 0, 0, 0};
+    if (h->use_shared) {
+        int st = (h->d == 1) ? build_gain_table<1>(h, a, h->iso_free_mask, s, add)
+                             : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
+        if (st) return st;
+        if (h->trace) { const double t = tick(); h->trace_us[1] += t - tk0; tk0 = t; }
+        a.group_mode = 3;
+        // the covariance transient gets its own short window [0, t0): every other window (warm-up
+        // included) then lies in the stationary regime and runs the lean kernel
+        // A batch with more track groups than SIMDs needs no time windows to fill the chip, but the lean
+        // stationary kernel only exists for windows past the covariance transient: split every track into
+        // the transient window and ONE stationary window (same wave, so no extra work items)
+        if (h->drift) {
+            // every row costs the same here (HBM-bound; the table rows and the stationary rows run the same step): plain equal windows
+            a.t0 = 0;
+        } else
+        if (a.n_chunks == 1 && h->plan_warmup > 0 && h->max_chunks >= 2 && !h->chunks_forced) {
+            a.n_chunks = 1; a.window = h->plan_warmup;
+            const int s_stat0 = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+            const int t0c = (s_stat0 + a.window + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+            if (t0c + 2 * a.window < h->glen_max) { a.t0 = t0c; a.n_chunks = 2; h->last_window = a.window; }
+            else a.window = 0;
+        } else
+        if (a.n_chunks > 1) {
+            const int s_stat = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+            a.t0 = (s_stat + a.window + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+            if (a.t0 + 2 * a.window >= h->glen_max) { a.t0 = 0; }            // tracks too short to bother
+            else if (a.n_chunks < h->max_chunks) a.n_chunks += 1;           // window 0 + the planned ones
+        }
+        h->last_chunks = a.n_chunks;
+    }
+    // the transient window (gain table, direction form) runs on the wave that owns window 1: that window is
+    // shortened by what the transient rows cost, in stationary rows (SSDE_T0_COST x t0)
+    {
+        const double cost = h->env_t0_cost;
+        a.t0_delta = (int)(cost * a.t0 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+    }
+    if (!h->use_shared && !h->drift && a.n_chunks > 1 && h->env_w0_ratio > 0.0) {
+        // General kernel, every window on its own wave: window 0 carries EVERY direction (windows >= 1 derive one,
+        // k_iso.hip) but has no warm-up rows.  With equal windows its waves are the last to finish and the whole
+        // launch waits for them (CTCRW: 212 against 163 instructions per row).  Balance: window 0 = [0, L0) with
+        // r L0 = L1 + W, the others split [L0, L) equally -- the geometry window_bounds already has for a transient
+        // window (t0 = L0), with nothing to subtract from window 1 (t0_delta = 0: it has a wave of its own).
+        const bool can_derive = order >= 1 && a.derive && (a.part_mask[0] & DIR_SIG) &&
+                                (a.part_mask[0] & (h->model == SSDE_MODEL_BM_SSM ? DIR_P1 : DIR_P2));
+        const double r = can_derive ? h->env_w0_ratio : 1.0;
+        const int nc = a.n_chunks;
+        const double L0 = ((double)h->glen_max / (nc - 1) + a.window) / (r + 1.0 / (nc - 1));
+        const int t0 = (int)(L0 / WIN_ALIGN) * WIN_ALIGN;
+        if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) { a.t0 = t0; a.t0_delta = 0; }
+    }
+    h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
+    if (h->use_shared) {
+        // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
+        // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check
+        const bool any_dirty = h->n_clean_groups < h->n_groups;
+        IsoArgs ad = a;                      // the general launch: this plan, or -- mixed batch -- one of its own
+        if (any_dirty && h->want_chunks_d > 0 && a.n_chunks > 1 && h->max_chunks > 1 && !h->gave_up) {
+            int nc = h->want_chunks_d;
+            while (nc > 1 && (h->glen_max / nc) < 2 * a.window) nc--;
+            if (nc > 1) {
+                ad.n_chunks = nc; ad.t0 = 0; ad.t0_delta = 0;
+                // window 0 carries every direction and has no warm-up: the balance of the all-general case (below)
+                const bool can_derive = order >= 1 && a.derive && (a.part_mask[0] & DIR_SIG) &&
+                                        (a.part_mask[0] & (h->model == SSDE_MODEL_BM_SSM ? DIR_P1 : DIR_P2));
+                const double r = (can_derive && h->env_w0_ratio > 0.0) ? h->env_w0_ratio : 1.0;
+                const double L0 = ((double)h->glen_max / (nc - 1) + a.window) / (r + 1.0 / (nc - 1));
+                const int t0 = (int)(L0 / WIN_ALIGN) * WIN_ALIGN;
+                if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) ad.t0 = t0;
+                a.dual = 1; a.n_chunks_d = ad.n_chunks; a.window_d = ad.window; a.t0_d = ad.t0; a.t0_delta_d = ad.t0_delta;
+                a.dirty_groups = h->dirty_groups.p; a.n_dirty_groups = h->n_dirty_groups;
+                ad.dirty_groups = h->dirty_groups.p; ad.n_dirty_groups = h->n_dirty_groups; ad.use_group_list = 1;
+                // the final sums run over the longer of the two plans: the slots the shorter one does not write must be zero
+                HIPCHK(h, hipMemsetAsync(h->partials.p, 0, (size_t)std::max(a.n_chunks, ad.n_chunks) * (4 + h->d) * h->n_groups * 8, s));
+            }
+        }
+        IsoArgs b = a;
+        b.group_mode = 2;
+        if (!h->wave_clock_file.empty()) {
+            const int items = ((h->n_groups + 7) / 8 * 8) * a.n_chunks + 8;
+            if ((int)h->wave_clock.n < 4 * items) { h->wave_clock.release(); HIPCHK(h, h->wave_clock.alloc((size_t)4 * items)); }
+            HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
+            b.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
+        }
+        if (any_dirty) {
+            HIPCHK(h, hipEventRecord(h->ev_fork, s));
+            HIPCHK(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
+            HIPCHK(h, launch_iso(h->model, h->d, ad, true, h->aux[1]));
+            HIPCHK(h, hipEventRecord(h->ev_join[1], h->aux[1]));
+        }
+        if (h->drift && h->hess_req) {
+            // ssde_hess on a drift handle: the same plan, the same gains, the Hessian kernels instead of the evaluation
+            h->hess_req = false;
+            DriftHessArgs hx = h->hess_args;
+            HIPCHK(h, launch_iso_drift_hess(h->model, b, hx, h->hess_tiles, s));
+            return SSDE_OK;
+        }
+        if (h->drift) HIPCHK(h, launch_iso_drift(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+        else HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+        h->ev_k_valid = h->stamps;
+        h->last_s_stat = h->drift ? -1 : (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
+        if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
+    } else {
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
+        if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
+        else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+        if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
+        h->ev_k_valid = h->stamps;
+        h->last_s_stat = -1;
+    }
+    if (h->trace) { const double t = tick(); h->trace_us[2] += t - tk0; tk0 = t; }
+    for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
+    if (h->use_shared) {
+        ra.add_slot[0] = 0;
+        if (order >= 1) {
+            const int pj[NDIRP] = {0, L.off_fe + L.fe_off[h->d], h->q > h->d + 1 ? L.off_fe + L.fe_off[h->d + 1] : 0};
+            for (int j = 0; j < NDIRP; j++)
+                if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
+        }
+    }
+    const int nacc = 4 + h->d + (h->drift ? h->n_stream_cols : 0);
+    const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
+    ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+    ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
+    ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
+    if (order >= 1 && h->drift) {
+        // accumulators of k_iso_drift.hip: [value | sigma_obs | mu intercepts | par d | par d+1 | streamed columns]
+        if (!h->fixed[0]) ra.map[0] = 1;
+        for (auto& sl : h->slots) {
+            if (h->fixed[sl.pidx]) continue;
+            const int k = sl.col >= 0 ? 4 + h->d + sl.col : (sl.par_j < h->d ? 2 + sl.par_j : sl.par_j == h->d ? 2 + h->d : 3 + h->d);
+            ra.map[k - 1] = (int16_t)(1 + sl.pidx);
+        }
+    } else
+    if (order >= 1) {
+        for (int p = 0; p < a.n_parts; p++)
+            for (int k = 1; k < nacc; k++) {
+                // accumulators are ordered like the constant-coefficient parameter vector: sigma_obs, one per SDE parameter
+                const int j = k - 2;     // SDE parameter of accumulator k (k == 1: log_sigma_obs)
+                if (j >= h->q) continue;
+                const int pidx = j < 0 ? 0 : L.off_fe + L.fe_off[j];
+                if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
+            }
+    }
+    // the hand-over checks and the final sums in one launch
+    HIPCHK(h, launch_iso_finalize(h->model, h->d, a, ra, s));
+    if (h->trace) {
+        const double t = tick(); h->trace_us[3] += t - tk0; h->trace_n++;
+        if (h->trace_skip < 8) {                        // the first calls load code objects: not what is being measured
+            h->trace_skip++;
+            for (double& v : h->trace_us) v = 0.0;
+            h->trace_n = 0;
+        }
+    }
+    return SSDE_OK;
+}
+
+}  // namespace ssde_engine
