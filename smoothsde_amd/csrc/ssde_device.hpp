@@ -120,7 +120,24 @@ struct IsoArgs {
     double coefA[DRIFT_KMAX];    // coefficient of column k if it feeds dimension 0, else 0
     double coefB[DRIFT_KMAX];    // ... dimension 1
     unsigned drift_dim1;         // bit k: column k feeds dimension 1
+    // Row-varying tau / nu (kappa, sigma) on lane = track lanes (k_iso_colvar.hip): the linear predictors are
+    // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
+    double cv_eta0[2];
 };
+// One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients the part's waves carry, sorted by
+// what the column feeds (device table, one entry per part)
+constexpr int CV_KC = 8;         // columns per part (register budget of a wave); the parts are the WG_WAVES waves of a workgroup
+struct CvPart {
+    int32_t n_col;               // columns of this part
+    int32_t n0, n01;             // slots [0, n0): log sigma_obs; [n0, n01): par[d] (log tau / log sigma); [n01, n_col): par[d+1] (log nu / log kappa)
+    int32_t with_mu;             // the part also carries the drift-intercept direction
+    int32_t chan[CV_KC];         // tile channel of the slot's design column, -1 = a column of ones (an intercept)
+};
+// partials [n_parts * n_chunks][1 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d; a.n_parts == WG_WAVES;
+// a.part_mask[0] == 0: the value only (no tangents)
+hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s);
+int colvar_nstate(int model, int d, int kc);
+hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance
 // direction, one block for mu
 __host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool has_p2) {

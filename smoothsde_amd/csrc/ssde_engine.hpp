@@ -120,6 +120,7 @@ struct ssde_handle {
     int want_chunks_d = 0;         // mixed batch: windows of the general launch's own plan (0 = one plan for everything)
     int glen_max = 0;              // steps of the longest track group
     double dt_min = 0.0;           // smallest interval used inside a track
+    double dt_max = 0.0;           // ... and the largest
     bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
     int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
     int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
@@ -146,6 +147,11 @@ struct ssde_handle {
     int drift = 0;                 // row-varying drift on the register path (k_iso_drift.hip): 1 = shared-covariance lanes (regular grid, complete
                                    // tracks), 2 = lanes with their own covariance (missing rows / irregular grid)
     int drift_nstate = 0;          // components of its hand-over dumps
+    DevBuf<ssde::CvPart> cv_parts;  // drift == 3 (row-varying tau / nu on lane = track lanes, k_iso_colvar.hip): the columns of the four parts
+    std::vector<int> cv_pidx;      // [WG_WAVES][CV_KC] full-parameter index of a part's column, -1 = unused slot
+    int cv_mu_part = -1;           // the part that carries the drift-intercept direction
+    std::vector<double> cv_col_lo, cv_col_hi;   // range of every streamed column over the batch (found at create)
+    double cv_eta_lo[2] = {0, 0}, cv_eta_hi[2] = {0, 0};   // range the linear predictors of par[d], par[d + 1] can reach at the last parameters
     // exact Hessian over the drift coefficients (ssde_hess.hip): eval_device launches the Hessian kernels instead of an evaluation
     DevBuf<double> hs_partials, hs_hess;      // scratch of the Hessian passes, kept between calls (allocation costs more than the pass)
     DevBuf<int16_t> hs_i16;
@@ -297,6 +303,8 @@ int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout = nul
 void destroy(ssde_handle* h);
 void release_device(ssde_handle* h);          // everything the handle holds on the device / in pinned memory (the handle stays)
 int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s, ReduceArgs& ra);   // ssde_engine_iso.hip
+// spectral radius of the stationary closed-loop matrix T - K Z at constant parameters p1, p2 (ssde_engine_tv.hip); p0 = {p11, p12, p22} or {p}
+double closed_loop_rho(int model, double dt, double p1, double p2, double hobs, const double* p0);
 int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s);
 
 // ---- distributed evaluation (ssde_engine_dist.hip) --------------------------------------------------------------------

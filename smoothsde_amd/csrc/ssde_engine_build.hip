@@ -133,6 +133,61 @@ constexpr int SSDE_RETRY_WITHOUT_DRIFT = -77;     // internal: the drift layout 
 // time windows, and the buffers of the hand-over check.  gflags[g] != 0: group g has no missing row; glen: padded steps per group ----
 static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>& gflags, const std::vector<int32_t>& lane_ns,
                               const std::vector<int32_t>& glen) {
+    if (h->drift == 3) {
+        // row-varying tau / nu: deal the columns whose coefficients are free to the four waves of a workgroup (k_iso_colvar.hip),
+        // sorted by what they feed -- log sigma_obs (a column of ones), par[d], par[d + 1] -- so that a wave's unrolled column
+        // loop takes uniform branches; round robin keeps the order and evens the counts out
+        struct Col { int type, chan, pidx; };
+        std::vector<Col> cols;
+        const int c_col = h->c_obs + h->d;
+        if (!h->fixed[0]) cols.push_back({0, -1, 0});
+        for (int type = 1; type <= 2; type++)
+            for (auto& sl : h->slots)
+                if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
+        if ((int)cols.size() > WG_WAVES * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;
+        std::vector<CvPart> parts(WG_WAVES);
+        memset(parts.data(), 0, sizeof(CvPart) * WG_WAVES);
+        h->cv_pidx.assign((size_t)WG_WAVES * CV_KC, -1);
+        for (size_t i = 0; i < cols.size(); i++) {
+            CvPart& P = parts[i % WG_WAVES];
+            const int k = P.n_col++;
+            P.chan[k] = cols[i].chan;
+            if (cols[i].type == 0) { P.n0++; P.n01++; }
+            if (cols[i].type == 1) P.n01++;
+            h->cv_pidx[(i % WG_WAVES) * CV_KC + k] = cols[i].pidx;
+        }
+        bool mu_free = false;
+        for (auto& sl : h->slots)
+            if (sl.par_j < h->d && !h->fixed[sl.pidx]) mu_free = true;
+        if (mu_free) {
+            int best = WG_WAVES - 1;
+            for (int p = WG_WAVES - 1; p >= 0; p--)
+                if (parts[p].n_col < parts[best].n_col) best = p;
+            parts[best].with_mu = 1;
+            h->cv_mu_part = best;
+        }
+        HIPCHK(h, h->cv_parts.upload(parts));
+        {
+            // the range of every streamed column over the batch
+            const int K = h->n_stream_cols;
+            DevBuf<double> rg;
+            HIPCHK(h, rg.alloc((size_t)G * K * 2));
+            TileView tv;
+            memset(&tv, 0, sizeof(tv));
+            tv.tiles = h->tiles.p; tv.group_off = h->group_off.p; tv.group_len = h->group_len.p; tv.lane_nsteps = h->lane_nsteps.p;
+            tv.n_groups = G; tv.C = h->C; tv.c_obs = h->c_obs;
+            HIPCHK(h, launch_colvar_ranges(tv, c_col, K, rg.p, 0));
+            std::vector<double> rh((size_t)G * K * 2);
+            HIPCHK(h, hipMemcpy(rh.data(), rg.p, rh.size() * 8, hipMemcpyDeviceToHost));
+            h->cv_col_lo.assign(K, INFINITY); h->cv_col_hi.assign(K, -INFINITY);
+            for (int g = 0; g < G; g++)
+                for (int k = 0; k < K; k++) {
+                    h->cv_col_lo[k] = std::min(h->cv_col_lo[k], rh[((size_t)g * K + k) * 2]);
+                    h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
+                }
+        }
+        h->drift_nstate = (colvar_nstate(h->model, h->d, CV_KC) + 3) / 4 * 4;
+    } else
     if (h->drift) {
         // regular grid and every track complete: the shared-covariance lanes; otherwise the lanes carry their own covariance
         // (SSDE_NO_DRIFT_GENERAL: back to the lane = direction path instead, for A/B)
@@ -143,7 +198,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->drift = all_clean ? 1 : 2;
         h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
     }
-    if (h->drift) { h->iso_parts = 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+    if (h->drift) { h->iso_parts = h->drift == 3 ? WG_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
     else choose_iso_split(h);
     // shared-covariance path: regular grid + groups without missing rows
     HIPCHK(h, h->group_flags.upload(gflags));
@@ -190,6 +245,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // 1.5 work items per wave slot (shorter items even out the tail; their hand-over dumps are small), CTCRW
         // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
         want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
+    // row-varying tau / nu: a WORKGROUP per (group, window), one per CU -- up to eight rounds' worth; plan_windows picks the count
+    if (h->drift == 3) want = std::max(1, (8 * 256 + G - 1) / G);
     if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
     h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
     h->want_chunks = std::max(1, std::min(want, h->max_chunks));
@@ -215,7 +272,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     }
     HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
-    h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * NACC_MAX * G;
+    h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * std::max(NACC_MAX, 1 + CV_KC + 2) * G;
     h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
     return SSDE_OK;
 }
@@ -584,6 +641,14 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             int min_tracks = 32;
             if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
             if (mu_only && h->n_seg >= min_tracks) { h->drift = 1; h->path = PATH_ISO; }
+            // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
+            // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
+            // whatever the batch.  Columns evaluated from a basis table (ssde_ppbasis) and mixed designs (columns in the drift
+            // AND in tau / nu) stay on that path.
+            bool par_only = !mu_only && !getenv("SSDE_NO_COLVAR");
+            for (auto& sl : h->slots)
+                if (sl.col >= 0 && (sl.par_j < h->d || sl.basis_c >= 0)) par_only = false;
+            if (par_only && h->n_seg >= min_tracks && h->d <= 2) { h->drift = 3; h->path = PATH_ISO; }
         }
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
         // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic
@@ -758,6 +823,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         }
         h->dt_uniform = h->uniform_dt ? dmin : 0.0;
         h->dt_min = std::isfinite(dmin) ? dmin : 0.0;
+        h->dt_max = std::isfinite(dmax) ? dmax : 0.0;
         mm.release(); s_times.release(); s_obs.release(); s_h.release(); s_a0.release(); s_cols.release();
         s_colptr.release(); s_lane_seg.release();
         pad_times.release(); pad_obs.release();

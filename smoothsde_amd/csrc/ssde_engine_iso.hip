@@ -57,6 +57,17 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
             rho = std::fabs(tr.t - k);
         }
     }
+    if (h->drift == 3 && dt > 0.0 && std::isfinite(dt)) {
+        // row-varying tau / nu: the slowest-forgetting corner of the ranges the linear predictors can reach on this design
+        // (the hand-over check decides whether that was enough, as everywhere)
+        rho = 0.0;
+        const double dts[2] = {dt, h->uniform_dt ? dt : h->dt_max};
+        for (int c = 0; c < 8; c++) {
+            const double r = closed_loop_rho(h->model, dts[c & 1], (c & 2) ? h->cv_eta_hi[0] : h->cv_eta_lo[0],
+                                             (c & 4) ? h->cv_eta_hi[1] : h->cv_eta_lo[1], a.h, a.p0);
+            rho = std::max(rho, std::isfinite(r) ? r : 1.0);
+        }
+    }
     int W = 0;
     if (!(rho < 0.9995) || !std::isfinite(rho)) return;  // no usable forgetting: sequential filter
     // The stationary CTCRW lanes run the filter as 1/D(q)^2 recursions (k_iso_shared.hip): with closed-loop poles
@@ -77,6 +88,16 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     }
     int nc = h->want_chunks;
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
+    if (h->drift == 3 && !h->chunks_forced) {
+        // one workgroup per (group, window) and per CU: rounds x (rows of a window + its warm-up) is what the launch takes
+        int best = 1;
+        double best_cost = (double)((h->n_groups + 255) / 256) * glmax;
+        for (int c = 2; c <= nc; c++) {
+            const double cost = (double)(((int64_t)h->n_groups * c + 255) / 256) * ((double)glmax / c + W);
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+        nc = best;
+    }
     *n_chunks = nc;
     *window = nc > 1 ? W : 0;
     h->plan_warmup = W;                                  // usable warm-up length even when one window is planned
@@ -196,12 +217,29 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     } else {
         a.n_parts = 1;
     }
+    if (h->drift == 3) { a.n_parts = WG_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
     a.any_nan = h->na_any;
     a.uniform_dt = h->uniform_dt ? 1 : 0;
     const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
     a.h = sig * sig;                                    // makeH: sigma_obs * sigma_obs
     for (int i = 0; i < h->d; i++) a.mu[i] = par[L.off_fe + L.fe_off[i]];
     for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+    if (h->drift == 3) {
+        // p_j(i) = intercept_j + sum_k coef_k X_k(i) for the rows of par[d] and par[d + 1] (nllk_ctcrw.hpp:143-156); and the range
+        // each can reach on this design (column ranges found at create), for the window plan
+        for (int j = 0; j < 2; j++) h->cv_eta_lo[j] = h->cv_eta_hi[j] = 0.0;
+        for (auto& sl : h->slots) {
+            const int j = sl.par_j - h->d;
+            if (j < 0) continue;
+            const double b = par[sl.pidx];
+            if (sl.col < 0) { a.cv_eta0[j] = b; h->cv_eta_lo[j] += b; h->cv_eta_hi[j] += b; continue; }
+            (j == 0 ? a.coefA : a.coefB)[sl.col] = b;
+            const double lo = h->cv_col_lo[sl.col], hi = h->cv_col_hi[sl.col];
+            h->cv_eta_lo[j] += std::min(b * lo, b * hi);
+            h->cv_eta_hi[j] += std::max(b * lo, b * hi);
+        }
+        a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+    } else
     if (h->drift) {
         // mu_a(i) = intercept + sum_k coef_k X_k(i) (nllk_ctcrw.hpp:143-149): the intercept slot (if any) goes where the
         // constant-drift kernels keep mu, the streamed columns get their coefficients by the dimension they feed
@@ -347,7 +385,8 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
     } else {
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
-        if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
+        if (h->drift == 3) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_colvar(h->model, h->d, a, h->cv_parts.p, s)); }
+        else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
         else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
         h->ev_k_valid = h->stamps;
@@ -363,11 +402,23 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
         }
     }
-    const int nacc = 4 + h->d + (h->drift ? h->n_stream_cols : 0);
+    const int nacc = h->drift == 3 ? 1 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
     const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
     ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
     ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
     ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
+    if (order >= 1 && h->drift == 3) {
+        // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d]
+        for (int p = 0; p < WG_WAVES; p++) {
+            for (int k = 0; k < CV_KC; k++) {
+                const int pidx = h->cv_pidx[(size_t)p * CV_KC + k];
+                if (pidx >= 0) ra.map[p * (nacc - 1) + k] = (int16_t)(1 + pidx);
+            }
+            if (p == h->cv_mu_part)
+                for (auto& sl : h->slots)
+                    if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) ra.map[p * (nacc - 1) + CV_KC + sl.par_j] = (int16_t)(1 + sl.pidx);
+        }
+    } else
     if (order >= 1 && h->drift) {
         // accumulators of k_iso_drift.hip: [value | sigma_obs | mu intercepts | par d | par d+1 | streamed columns]
         if (!h->fixed[0]) ra.map[0] = 1;

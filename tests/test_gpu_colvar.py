@@ -1,0 +1,195 @@
+"""GPU suite: lane = track Kalman lanes with ROW-VARYING tau / nu (kappa, sigma) -- one filter tangent per design column, the
+columns dealt to the four waves of a workgroup, rows staged once through LDS (csrc/k_iso_colvar.hip) -- against the oracle, the
+golden vectors and the lane = direction path (k_tv.hip) on the same problems.
+Reference: nllk_ctcrw.hpp:143-156, 206-241; nllk_ou_ssm.hpp:113-124, 174-207; nllk_bm_ssm.hpp:98-108, 138-169.
+
+Tolerances (fp64): value 1e-10 * max(1,|v|); gradient 1e-8 * max|g| + 1e-10 (north-star bar: 1e-8)."""
+import numpy as np
+import pytest
+
+from cases import problem_from_spec
+from golden_io import load_golden
+from smoothsde_amd import capi
+from smoothsde_amd.synth import bspline_basis, second_difference_penalty, simulate
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden()
+PATH_ISO, PATH_TV = 1, 3
+
+
+def _oracle(pb, par, **kw):
+    from oracle_lib import oracle_eval
+    return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=8, **kw)
+
+
+def _close(val, grad, oval, ograd):
+    assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (val, oval)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd, np.abs(grad - ograd))
+
+
+def _is_colvar(eng):
+    inf = eng.info()
+    return inf["path"] == PATH_ISO and inf["const_coeff"] == 0
+
+
+# golden cases whose design columns sit in the rows of tau / nu (kappa) only: X_fe = [1, x] on par[d], a spline on par[d + 1]
+CV_GOLD = [r for r in GOLD if r["name"] in ("CTCRW_d1_tv", "CTCRW_d2_tv", "OU_SSM_d1_tv", "OU_SSM_d2_tv")]
+
+
+@pytest.mark.parametrize("rec", CV_GOLD, ids=[r["name"] for r in CV_GOLD])
+def test_golden_row_varying_cases_on_the_lane_track_path(rec, monkeypatch):
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    assert abs(eng.eval(rec["par"], order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    aest = eng.report(rec["par"])
+    assert np.allclose(aest, rec["expected"]["aest_all"], rtol=1e-10, atol=1e-10)
+    eng.close()
+
+
+def _batch(model, d, M, T, k1, k2, seed, fe_slope=False, ragged=False, dt=1.0, same_basis=False):
+    """M tracks x T rows; par[d] (log tau / log sigma) gets a k1-column spline of a per-row covariate, par[d + 1] (log nu /
+    log kappa) a k2-column one (0: constant); fe_slope adds a fixed-effect slope to par[d]."""
+    kw = dict(CTCRW=dict(tau=1.5, nu=0.8), OU_SSM=dict(mu=2.0, tau=2.0, kappa=1.0, z0=2.0), BM_SSM=dict(sigma=0.7))[model]
+    ID, t, o = simulate(model, M, T, d, sigma_obs=0.1, dt=dt, seed=seed, **kw)
+    if ragged:
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(T // 3, T + 1, size=M)
+        keep = np.concatenate([np.arange(T) < L for L in lens])
+        ID, o = ID[keep], o[keep]
+        t = dt * np.arange(1.0, len(ID) + 1)
+    n = len(ID)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 37) + 0.05 * np.random.default_rng(seed + 1).standard_normal(n), 0, 1)
+    q = capi.n_sde_par(model, d)
+    X_fe, X_re, S = [None] * q, [None] * q, []
+    if fe_slope:
+        X_fe[d] = np.column_stack([np.ones(n), x])
+    if k1:
+        X_re[d] = bspline_basis(x, k1)
+        S.append(second_difference_penalty(k1))
+    if k2 and q > d + 1:
+        X_re[d + 1] = bspline_basis(x if same_basis else np.clip(x ** 2, 0, 1), k2)
+        S.append(second_difference_penalty(k2))
+    pb = capi.Problem(model, ID, t, o, X_fe=X_fe, X_re=X_re, S_list=S)
+    rng = np.random.default_rng(seed + 2)
+    par = []
+    for nm in pb.par_names():
+        if nm == "log_sigma_obs":
+            par.append(np.log(0.12))
+        elif nm.startswith("log_lambda"):
+            par.append(0.3)
+        elif nm.startswith("coeff_re"):
+            par.append(0.15 * rng.standard_normal())
+        else:
+            par.append(0.1 * rng.standard_normal() + (2.0 if model == "OU_SSM" and nm.startswith("coeff_fe[0]") else 0.0))
+    par = np.array(par)
+    par[pb.off_fe + pb.fe_off[d]] = np.log(2.0 if model != "BM_SSM" else 0.7)
+    return pb, par
+
+
+@pytest.mark.parametrize("model,d,k1,k2,fe", [("CTCRW", 2, 9, 9, False), ("CTCRW", 1, 5, 0, True), ("CTCRW", 2, 0, 7, False),
+                                               ("OU_SSM", 1, 9, 6, False), ("OU_SSM", 2, 4, 12, True), ("BM_SSM", 2, 8, 0, False),
+                                               ("BM_SSM", 1, 5, 0, True), ("CTCRW", 2, 11, 11, True)])
+def test_long_tracks_with_time_windows_vs_oracle(model, d, k1, k2, fe):
+    pb, par = _batch(model, d, 96, 1500, k1, k2, seed=11, fe_slope=fe)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["window"] > 0 and inf["window_check"] <= 1e-11      # several verified windows
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    # bitwise repeatable, and the value-only call agrees
+    eng.forget()
+    v2, g2 = eng.eval(par)
+    assert v2 == val and np.array_equal(g2, grad)
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    eng.close()
+
+
+def test_ragged_tracks_fixed_parameters_and_a_short_step():
+    pb, par = _batch("CTCRW", 2, 150, 400, 7, 5, seed=5, ragged=True, dt=0.25)
+    fixed = np.zeros(pb.n_par_full, dtype=np.uint8)
+    fixed[[0, pb.off_fe + pb.fe_off[0], pb.off_fe + pb.fe_off[3], pb.off_re + 3]] = 1     # sigma_obs, mu_1, the nu intercept and one spline coefficient held
+    pb = capi.Problem("CTCRW", pb.id, pb.times, pb.obs, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, par_fixed=fixed)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    oval, ograd = _oracle(pb, par)
+    _close(val, grad, oval, ograd)
+    assert grad[0] == 0.0 and grad[pb.off_re + 3] == 0.0 and grad[pb.off_fe + pb.fe_off[0]] == 0.0
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb, par, report=True)
+    assert np.max(np.abs(aest - oaest)) <= 1e-9 * max(1.0, np.max(np.abs(oaest)))
+    eng.close()
+
+
+@pytest.mark.parametrize("model,d,k1,k2", [("OU_SSM", 1, 6, 4), ("CTCRW", 2, 5, 4), ("BM_SSM", 2, 7, 0), ("CTCRW", 1, 9, 0)])
+@pytest.mark.parametrize("what", ["missing", "irregular", "both"])
+def test_missing_rows_and_irregular_grids(model, d, k1, k2, what):
+    """nllk_ctcrw.hpp:214-217: a row whose first column is NA is a prediction step; the interval is the row's own."""
+    pb, par = _batch(model, d, 96, 700, k1, k2, seed=21)
+    o, t = pb.obs.copy(), pb.times.copy()
+    rng = np.random.default_rng(4)
+    if what in ("missing", "both"):
+        na = rng.random(len(t)) < 0.05
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan                                       # column 0 decides (the other column may hold a number)
+        o[na & (rng.random(len(t)) < 0.5)] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    pb2 = capi.Problem(model, pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list)
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb2, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    eng.close()
+
+
+def test_lane_track_and_lane_direction_paths_agree(monkeypatch):
+    pb, par = _batch("CTCRW", 2, 128, 600, 6, 6, seed=23, same_basis=True)
+    e1 = capi.Engine(pb)
+    assert _is_colvar(e1)
+    v1, g1 = e1.eval(par)
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb)
+    assert e2.info()["path"] == PATH_TV
+    v2, g2 = e2.eval(par)
+    assert abs(v1 - v2) <= 1e-10 * abs(v1) and np.max(np.abs(g1 - g2)) <= 1e-8 * np.max(np.abs(g1))
+    e1.close(); e2.close()
+
+
+def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path():
+    pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
+    eng = capi.Engine(pb1)
+    assert eng.info()["path"] == PATH_TV
+    eng.close()
+    # a smooth in the drift AND in tau
+    pb, _ = _batch("CTCRW", 1, 64, 200, 5, 0, seed=3)
+    B = bspline_basis(np.clip(np.linspace(0, 1, pb.n), 0, 1), 4)
+    pb2 = capi.Problem("CTCRW", pb.id, pb.times, pb.obs, X_re=[B, pb.X_re[1], None],
+                       S_list=[second_difference_penalty(4), second_difference_penalty(5)])
+    eng = capi.Engine(pb2)
+    assert eng.info()["path"] == PATH_TV
+    eng.close()
+
+
+def test_sharded_handle_and_one_rank_communicator():
+    pb, par = _batch("OU_SSM", 1, 130, 500, 9, 5, seed=13)
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    e2 = capi.Engine(pb, devices=[0, 0])
+    v2, g2 = e2.eval(par)
+    assert abs(v1 - v2) <= 1e-11 * abs(v1) and np.max(np.abs(g1 - g2)) <= 1e-9 * np.max(np.abs(g1))
+    e1.comm_init(1, 0, capi.comm_unique_id())
+    v3, g3 = e1.eval(par)
+    assert abs(v1 - v3) <= 1e-12 * abs(v1) and np.max(np.abs(g1 - g3)) <= 1e-10 * np.max(np.abs(g1))
+    e1.close(); e2.close()

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""tools/bench_colvar.py [--tracks M --rows T --k1 K --k2 K] -- nllk + gradient of a CTCRW batch with ROW-VARYING tau and nu
+(splines of a covariate: the batch-scale form of BASELINE's C1) on ONE MI355X: the lane = track kernel with one filter
+tangent per design column (k_iso_colvar.hip) against the lane = direction path (k_tv.hip, SSDE_NO_COLVAR=1) on the same
+problem and parameters.  One JSON object per line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from smoothsde_amd import capi  # noqa: E402
+from smoothsde_amd.synth import second_difference_penalty, bspline_basis  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tracks", type=int, default=10_000)
+ap.add_argument("--rows", type=int, default=1_000)
+ap.add_argument("--k1", type=int, default=9)
+ap.add_argument("--k2", type=int, default=9)
+ap.add_argument("--evals", type=int, default=20)
+ap.add_argument("--only", default="")
+args = ap.parse_args()
+
+M, T = args.tracks, args.rows
+dev = torch.device("cuda:0")
+ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=342, device=dev)
+ID, times, obs = ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy()
+n = M * T
+temp = 30 + 10 * np.sin(np.arange(n) * 2 * np.pi / 24) + np.random.default_rng(342).normal(0, 2, n)
+u = (temp - temp.min()) / (temp.max() - temp.min())
+X_re, S = [None, None, None, None], []
+if args.k1:
+    X_re[2] = bspline_basis(u, args.k1); S.append(second_difference_penalty(args.k1))
+if args.k2:
+    X_re[3] = bspline_basis(u, args.k2); S.append(second_difference_penalty(args.k2))
+nre = args.k1 + args.k2
+fixed = np.r_[0, 1, 1, 0, 0, np.ones(len(S)), np.zeros(nre)].astype(np.uint8)
+pb = capi.Problem("CTCRW", ID, times, obs, X_re=X_re, S_list=S, par_fixed=fixed)
+par = np.r_[np.log(0.05), 0, 0, 0, 0, np.zeros(len(S)), 0.05 * np.sin(np.arange(nre))]
+bytes_row = 8.0 * (2 + nre)
+for label, env in (("lane=track", None), ("lane=direction", "1")):
+    if args.only and args.only != label:
+        continue
+    if env:
+        os.environ["SSDE_NO_COLVAR"] = env
+    else:
+        os.environ.pop("SSDE_NO_COLVAR", None)
+    t0 = time.perf_counter()
+    eng = capi.Engine(pb)
+    t_create = time.perf_counter() - t0
+    reps = args.evals if not env else max(3, args.evals // 4)
+    v0, g0 = eng.eval(par)
+    eng.eval(par + 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        eng.eval(par + 1e-3 * np.sin(k + np.arange(len(par))))
+    wall = (time.perf_counter() - t0) / reps
+    inf = eng.info()
+    print(json.dumps(dict(kernel=label, path=capi.PATH_NAMES[inf["path"]], tracks=M, rows=T, columns=nre, ms_per_eval=1e3 * wall,
+                          rows_per_s=n / wall, main_kernel_ms=inf["main_kernel_ms"], windows=inf["lanes_per_track"], warm_up=inf["window"],
+                          window_check=inf["window_check"], retries=inf["window_retries"], create_s=t_create,
+                          frac_of_8TBps_required=bytes_row * n / wall / 8e12, value=v0, grad_norm=float(np.linalg.norm(g0)))), flush=True)
+    eng.close()
+os.environ.pop("SSDE_NO_COLVAR", None)
