@@ -9,13 +9,15 @@
 // TANGENT of the filter in that direction: the linearised step is the same for every column, only the seed differs --
 //     (dP, da)_k  <-  Lin_i (dP, da)_k  +  X_k(i) * seed_type(k)(i)
 // where Lin_i is the Jacobian of row i's update + prediction with respect to (P, a) and seed_t the derivative of
-// (T, Q, B, H) with respect to log tau (t = 1), log nu / kappa (t = 2) or log sigma_obs (t = 0, a column of ones) at THIS
-// row's parameters.  3 + 2 d doubles of state and ~40 fp64 instructions per column and row (CTCRW, d = 2).
+// (T, Q, B, H) with respect to log tau (t = 1), log nu / kappa (t = 2) or log sigma_obs (t = 0) at THIS row's parameters.
+// 3 + 2 d doubles of state and ~45 fp64 instructions per column and row (CTCRW, d = 2).
 //
 // Work split: the columns are dealt to the four waves of a workgroup (PARTS of at most CV_KC columns: a wave's register
-// budget); every part recomputes the primal filter (the exp's of the row's tau / nu, T, Q, the gains) and carries its own
-// columns, sorted by type so that the unrolled column loop takes uniform branches.  One workgroup per (64-track group,
-// time window); windows, warm-up and the verified hand-over as in k_iso.hip.
+// budget); the waves that carry columns recompute the primal filter (the gains: ~140 instructions) next to them.  The
+// column loop is straight-line code: what a column feeds is a pair of 0/1 factors on its value, not a branch (measured: a
+// uniform branch per column and type cost 2100 of 4600 cycles per row -- every column a basic block of its own, nothing to
+// overlap).  The log sigma_obs direction and the drift-intercept direction are single slots behind one uniform branch each.
+// One workgroup per (64-track group, time window); windows, warm-up and the verified hand-over as in k_iso.hip.
 // Layout: the tiles of ssde_device.hpp with the design columns as further channels (as k_iso_drift.hip).
 #include <type_traits>
 
@@ -28,13 +30,12 @@ template <int D, int KC>
 struct CvCtcrw {
     static constexpr int SD = 2 * D;
     static constexpr int NCOL = 3 + 2 * D;
-    static constexpr int NBASE = SD + 3 + 2;
-    static constexpr int NSTATE = NBASE + KC * NCOL;
+    static constexpr int NSTATE = SD + 3 + 2 + (KC + 1) * NCOL;
     double x[D], v[D], p11, p12, p22;
     LogAcc ld;
     double accq;
     double mx, mv, gmu[D];
-    double d11[KC], d12[KC], d22[KC], tx[KC][D], tv[KC][D], g[KC];
+    double d11[KC + 1], d12[KC + 1], d22[KC + 1], tx[KC + 1][D], tv[KC + 1][D], g[KC + 1];      // slot KC: log sigma_obs
 
     __device__ __forceinline__ void init(const double* a0, const double* p0) {
 #pragma unroll
@@ -42,7 +43,7 @@ struct CvCtcrw {
         p11 = p0[0]; p12 = p0[1]; p22 = p0[2];
         ld.init(); accq = 0.0; mx = mv = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
+        for (int k = 0; k <= KC; k++) {
             d11[k] = d12[k] = d22[k] = g[k] = 0.0;
 #pragma unroll
             for (int a = 0; a < D; a++) tx[k][a] = tv[k][a] = 0.0;
@@ -53,12 +54,13 @@ struct CvCtcrw {
 #pragma unroll
         for (int a = 0; a < D; a++) gmu[a] = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) g[k] = 0.0;
+        for (int k = 0; k <= KC; k++) g[k] = 0.0;
     }
     // One row: score y (unless NA), the column tangents, then the prediction over the row's interval (ctcrw_step's
-    // arrangement: filtered-form covariance update, Joseph-form sensitivities; ssde_math.hpp)
-    __device__ __forceinline__ void step(const CvPart& P, const CtcrwTrans& tr, double h, const double* mu, const double* y,
-                                         bool na, const double* X) {
+    // arrangement: filtered-form covariance update, Joseph-form sensitivities; ssde_math.hpp).
+    // X1[k] / X2[k]: the column's value if it feeds log tau / log nu, else 0.
+    __device__ __forceinline__ void step(const CtcrwTrans& tr, double h, const double* mu, const double* y, bool na,
+                                         const double* X1, const double* X2, bool with_sig, bool with_mu) {
         const double F = p11 + h;
         const double detF = (D == 1) ? F : F * F;                  // nllk_ctcrw.hpp:16-19, 223
         const bool upd = !na && !(detF <= 0.0);                    // :214, 226
@@ -73,7 +75,7 @@ struct CvCtcrw {
         const double f11 = p11 * a, f12 = p12 * a, f22 = fma(-p12, kf2, p22);
         const double m = fma(t12, f22, f12);
         const double k1 = fma(t12, kf2, kf1), k2 = e * kf2, c1 = 1.0 - k1;
-        double u[D], mue[D], wv[D];
+        double u[D], mue[D];
         double su2 = 0.0;
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) {
@@ -81,39 +83,24 @@ struct CvCtcrw {
             u[a_] = ys - x[a_];
             su2 = fma(u[a_], u[a_], su2);
             mue[a_] = bm * mu[a_];
-            wv[a_] = v[a_] - mue[a_];
         }
         accq = fma(iF, su2, accq);
         const double gF = fma(-0.5 * iF * iF, su2, 0.5 * (double)D * iF);     // d nllk / d F of this row
         // ---- seeds ------------------------------------------------------------------------------------------------
-        // type 0, log sigma_obs: dh = 2 h enters F, the filtered covariance (k k' dh) and the gain (-k dh / F)
-        const double h2 = 2.0 * h;
-        double s0_11, s0_12, s0_22, s0_k1, s0_k2;
-        {
-            const double q1 = kf1 * h2, q2 = kf2 * h2;
-            const double g11 = kf1 * q1, g12 = kf2 * q1, g22 = kf2 * q2;
-            const double dkf1 = -q1 * iF, dkf2 = -q2 * iF;
-            const double dm = fma(t12, g22, g12);
-            s0_11 = fma(t12, g12 + dm, g11); s0_12 = e * dm; s0_22 = e2 * g22;
-            s0_k1 = fma(t12, dkf2, dkf1); s0_k2 = e * dkf2;
-        }
-        // type 1, log tau: T, B and Q move
+        // log tau: T, B and Q move
         const double s1_11 = fma(tr.dt12x2, m, tr.dq11), s1_12 = fma(tr.dt12e, f22, fma(tr.de, m, tr.dq12)),
                      s1_22 = fma(tr.edex2, f22, tr.dq22);
         double s1_x[D], s1_v[D];
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) {
-            const double w = fma(kf2, u[a_], wv[a_]);              // d k u + d(T a + B mu): (dt12, de) (kf2 u + v - mu)
+            const double w = fma(kf2, u[a_], v[a_] - mue[a_]);     // d k u + d(T a + B mu): (dt12, de) (kf2 u + v - mu)
             s1_x[a_] = tr.dt12 * w; s1_v[a_] = tr.de * w;
         }
-        // type 2, log nu: Q only (dQ = 2 Q)
+        // log nu: Q only (dQ = 2 Q)
         const double s2_11 = 2.0 * tr.q11, s2_12 = 2.0 * tr.q12, s2_22 = 2.0 * tr.q22;
-        // ---- columns ----------------------------------------------------------------------------------------------
-        auto col = [&](int k, auto type) {
-            constexpr int T = decltype(type)::value;
-            const double Xk = X[k];
+        // the part of a tangent's step that does not depend on what it is a tangent of: returns the gain tangent
+        auto lin = [&](int k, double dF, double& n11, double& n12, double& n22, double& dk1, double& dk2) {
             const double c11 = d11[k], c12 = d12[k], c22 = d22[k];
-            const double dF = (T == 0) ? fma(Xk, h2, c11) : c11;
             double sud = 0.0;
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k][a_], sud);
@@ -122,31 +109,44 @@ struct CvCtcrw {
             const double g11 = a2 * c11, g12 = a * w, g22 = fma(-kf2, c12 + w, c22);
             const double dkf1 = c11 * aiF, dkf2 = w * iF;
             const double dm = fma(t12, g22, g12);
-            double n11 = fma(t12, g12 + dm, g11), n12 = e * dm, n22 = e2 * g22;
-            double dk1 = fma(t12, dkf2, dkf1), dk2 = e * dkf2;
-            if (T == 0) { n11 = fma(Xk, s0_11, n11); n12 = fma(Xk, s0_12, n12); n22 = fma(Xk, s0_22, n22);
-                          dk1 = fma(Xk, s0_k1, dk1); dk2 = fma(Xk, s0_k2, dk2); }
-            if (T == 1) { n11 = fma(Xk, s1_11, n11); n12 = fma(Xk, s1_12, n12); n22 = fma(Xk, s1_22, n22); }
-            if (T == 2) { n11 = fma(Xk, s2_11, n11); n12 = fma(Xk, s2_12, n12); n22 = fma(Xk, s2_22, n22); }
-            d11[k] = n11; d12[k] = n12; d22[k] = n22;
+            n11 = fma(t12, g12 + dm, g11); n12 = e * dm; n22 = e2 * g22;
+            dk1 = fma(t12, dkf2, dkf1); dk2 = e * dkf2;
+        };
+        // ---- columns (straight-line: the two seed sets are weighted by the column's 0/1 factors) -----------------------
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            double n11, n12, n22, dk1, dk2;
+            lin(k, d11[k], n11, n12, n22, dk1, dk2);
+            const double x1 = X1[k], x2 = X2[k];
+            d11[k] = fma(x2, s2_11, fma(x1, s1_11, n11));
+            d12[k] = fma(x2, s2_12, fma(x1, s1_12, n12));
+            d22[k] = fma(x2, s2_22, fma(x1, s1_22, n22));
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
                 const double txk = tx[k][a_], tvk = tv[k][a_];
-                double nx = fma(dk1, u[a_], fma(t12, tvk, c1 * txk));
-                double nv = fma(dk2, u[a_], fma(e, tvk, -k2 * txk));
-                if (T == 1) { nx = fma(Xk, s1_x[a_], nx); nv = fma(Xk, s1_v[a_], nv); }
-                tx[k][a_] = nx; tv[k][a_] = nv;
-            }
-        };
-#pragma unroll
-        for (int k = 0; k < KC; k++) {
-            if (k < P.n_col) {                                     // (wave-uniform branches: the part's columns are sorted by type)
-                if (k < P.n0) col(k, std::integral_constant<int, 0>());
-                else if (k < P.n01) col(k, std::integral_constant<int, 1>());
-                else col(k, std::integral_constant<int, 2>());
+                tx[k][a_] = fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk)));
+                tv[k][a_] = fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk)));
             }
         }
-        if (P.with_mu) {                                           // d / d mu_a: one data-independent chain for every dimension
+        if (with_sig) {
+            // log sigma_obs: dh = 2 h enters F, the filtered covariance (k k' dh) and the gain (-k dh / F)
+            const double h2 = 2.0 * h;
+            double n11, n12, n22, dk1, dk2;
+            lin(KC, d11[KC] + h2, n11, n12, n22, dk1, dk2);
+            const double q1 = kf1 * h2, q2 = kf2 * h2;
+            const double g11 = kf1 * q1, g12 = kf2 * q1, g22 = kf2 * q2;
+            const double dkf1 = -q1 * iF, dkf2 = -q2 * iF;
+            const double dm = fma(t12, g22, g12);
+            d11[KC] = n11 + fma(t12, g12 + dm, g11); d12[KC] = fma(e, dm, n12); d22[KC] = fma(e2, g22, n22);
+            dk1 += fma(t12, dkf2, dkf1); dk2 = fma(e, dkf2, dk2);
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) {
+                const double txk = tx[KC][a_], tvk = tv[KC][a_];
+                tx[KC][a_] = fma(dk1, u[a_], fma(t12, tvk, c1 * txk));
+                tv[KC][a_] = fma(dk2, u[a_], fma(e, tvk, -k2 * txk));
+            }
+        }
+        if (with_mu) {                                             // d / d mu_a: one data-independent chain for every dimension
             const double imx = iF * mx;
             const double nx = fma(bm, tr.b1, fma(t12, mv, c1 * mx)), nv = fma(bm, tr.b2, fma(e, mv, -k2 * mx));
 #pragma unroll
@@ -171,7 +171,7 @@ struct CvCtcrw {
         o[(n++) * WAVE] = p11; o[(n++) * WAVE] = p12; o[(n++) * WAVE] = p22;
         o[(n++) * WAVE] = mx; o[(n++) * WAVE] = mv;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
+        for (int k = 0; k <= KC; k++) {
             o[(n++) * WAVE] = d11[k]; o[(n++) * WAVE] = d12[k]; o[(n++) * WAVE] = d22[k];
 #pragma unroll
             for (int a = 0; a < D; a++) { o[(n++) * WAVE] = tx[k][a]; o[(n++) * WAVE] = tv[k][a]; }
@@ -191,13 +191,12 @@ template <int D, int KC, bool HAS_P2>
 struct CvScal {
     static constexpr int SD = D;
     static constexpr int NCOL = 1 + D;
-    static constexpr int NBASE = SD + 1 + 1;
-    static constexpr int NSTATE = NBASE + KC * NCOL;
+    static constexpr int NSTATE = SD + 1 + 1 + (KC + 1) * NCOL;
     double x[D], p;
     LogAcc ld;
     double accq;
     double mx, gmu[D];
-    double dp[KC], tx[KC][D], g[KC];
+    double dp[KC + 1], tx[KC + 1][D], g[KC + 1];               // slot KC: log sigma_obs
 
     __device__ __forceinline__ void init(const double* a0, const double* p0) {
 #pragma unroll
@@ -205,7 +204,7 @@ struct CvScal {
         p = p0[0];
         ld.init(); accq = 0.0; mx = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
+        for (int k = 0; k <= KC; k++) {
             dp[k] = g[k] = 0.0;
 #pragma unroll
             for (int a = 0; a < D; a++) tx[k][a] = 0.0;
@@ -216,11 +215,11 @@ struct CvScal {
 #pragma unroll
         for (int a = 0; a < D; a++) gmu[a] = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) g[k] = 0.0;
+        for (int k = 0; k <= KC; k++) g[k] = 0.0;
     }
     // scal_cov_step + scal_mean_step (ssde_math.hpp) with the direction loops replaced by the column loop
-    __device__ __forceinline__ void step(const CvPart& P, const ScalTrans& tr, double h, const double* mu, const double* y,
-                                         bool na, const double* X) {
+    __device__ __forceinline__ void step(const ScalTrans& tr, double h, const double* mu, const double* y, bool na,
+                                         const double* X1, const double* X2, bool with_sig, bool with_mu) {
         const double F = p + h;
         const bool upd = !na && !(fabs(F) <= 0.0);                 // nllk_ou_ssm.hpp:190-195, nllk_bm_ssm.hpp:152-157
         const double updf = upd ? 1.0 : 0.0;
@@ -241,44 +240,41 @@ struct CvScal {
         }
         accq = fma(iF, su2, accq);
         const double gF = fma(-0.5 * iF * iF, su2, 0.5 * (double)D * iF);
-        const double h2 = 2.0 * h, bh = b * h2;
-        const double s0_k = -tiF * bh, s0_p = k * t * bh;           // type 0: d sigma_obs
-        const double s1_k = HAS_P2 ? dt_ * b : 0.0;                 // type 1: log tau (OU) / log sigma (BM)
+        const double s1_k = HAS_P2 ? dt_ * b : 0.0;                 // log tau (OU) / log sigma (BM)
         const double s1_p = HAS_P2 ? fma(2.0 * dt_, cp, tr.dq) : tr.dq;
         double s1_x[D];
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) s1_x[a_] = HAS_P2 ? fma(s1_k, u[a_], fma(tr.dt_, x[a_], tr.db * mu[a_])) : 0.0;
-        const double s2_p = tr.q;                                   // type 2: log kappa (OU)
-        auto col = [&](int k_, auto type) {
-            constexpr int T = decltype(type)::value;
-            const double Xk = X[k_];
-            const double cdp = dp[k_];
-            const double dF = (T == 0) ? fma(Xk, h2, cdp) : cdp;
+        const double s2_p = tr.q;                                   // log kappa (OU)
+        auto lin = [&](int k_, double dF, double& np_, double& dk) {
             double sud = 0.0;
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k_][a_], sud);
             g[k_] = fma(gF, dF, fma(-iF, sud, g[k_]));
-            double dk = ca * cdp, np_ = tca * cdp;
-            if (T == 0) { dk = fma(Xk, s0_k, dk); np_ = fma(Xk, s0_p, np_); }
-            if (T == 1) np_ = fma(Xk, s1_p, np_);
-            if (T == 2) np_ = fma(Xk, s2_p, np_);
-            dp[k_] = np_;
-#pragma unroll
-            for (int a_ = 0; a_ < D; a_++) {
-                double nx = fma(dk, u[a_], c * tx[k_][a_]);
-                if (T == 1 && HAS_P2) nx = fma(Xk, s1_x[a_], nx);
-                tx[k_][a_] = nx;
-            }
+            dk = ca * dp[k_]; np_ = tca * dp[k_];
         };
 #pragma unroll
         for (int k_ = 0; k_ < KC; k_++) {
-            if (k_ < P.n_col) {
-                if (k_ < P.n0) col(k_, std::integral_constant<int, 0>());
-                else if (k_ < P.n01) col(k_, std::integral_constant<int, 1>());
-                else col(k_, std::integral_constant<int, 2>());
+            double np_, dk;
+            lin(k_, dp[k_], np_, dk);
+            const double x1 = X1[k_], x2 = X2[k_];
+            dp[k_] = HAS_P2 ? fma(x2, s2_p, fma(x1, s1_p, np_)) : fma(x1, s1_p, np_);
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) {
+                const double nx = fma(dk, u[a_], c * tx[k_][a_]);
+                tx[k_][a_] = HAS_P2 ? fma(x1, s1_x[a_], nx) : nx;
             }
         }
-        if (P.with_mu) {
+        if (with_sig) {
+            const double h2 = 2.0 * h, bh = b * h2;
+            double np_, dk;
+            lin(KC, dp[KC] + h2, np_, dk);
+            dk = fma(-tiF, bh, dk);
+            dp[KC] = fma(k * t, bh, np_);
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) tx[KC][a_] = fma(dk, u[a_], c * tx[KC][a_]);
+        }
+        if (with_mu) {
             const double imx = iF * mx;
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) gmu[a_] = fma(-imx, u[a_], gmu[a_]);
@@ -295,7 +291,7 @@ struct CvScal {
         o[(n++) * WAVE] = p;
         o[(n++) * WAVE] = mx;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
+        for (int k = 0; k <= KC; k++) {
             o[(n++) * WAVE] = dp[k];
 #pragma unroll
             for (int a = 0; a < D; a++) o[(n++) * WAVE] = tx[k][a];
@@ -317,50 +313,105 @@ struct CvModel<M_OU_SSM, D, KC> { typedef CvScal<D, KC, true> Lane; typedef Scal
 template <int D, int KC>
 struct CvModel<M_BM_SSM, D, KC> { typedef CvScal<D, KC, false> Lane; typedef ScalTrans Trans; };
 
+// components of a part's hand-over dump with kc column slots
 int colvar_nstate(int model, int d, int kc) {
-    return model == M_CTCRW ? 2 * d + 5 + kc * (3 + 2 * d) : d + 2 + kc * (1 + d);
+    return model == M_CTCRW ? 2 * d + 5 + (kc + 1) * (3 + 2 * d) : d + 2 + (kc + 1) * (1 + d);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
-// One WORKGROUP per (64-track group, time window); its four waves are the four PARTS (the columns dealt to them); the rows
-// are staged ONCE through LDS for all four: wave w loads the channels c = w, w + 4, ... of the row two ahead into registers,
-// stores them to the ring slot the row after next will be read from, and one barrier per row keeps the four in step.  HBM is
-// read once per row (8 (1 + d + K) bytes), a wave holds a quarter of the row in flight instead of all of it, and the linear
-// predictors come from a run-time loop over LDS (no register array as wide as the design matrix).
-// accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d]
-constexpr int CV_CMAX = 1 + 2 + DRIFT_KMAX;                   // channels of a staged row: dt, y, the streamed columns
-constexpr int CV_LD = (CV_CMAX + WG_WAVES - 1) / WG_WAVES;   // channels a wave loads per row
+// One WORKGROUP per (64-track group, time window); its four waves are the four PARTS (the columns dealt to them), in step row
+// by row (one barrier per row), and they share three things through LDS:
+//   * the rows, staged ONCE for all four: wave w loads the channels c = w, w + 4, ... of a row into registers two rows ahead
+//     and stores them to the ring slot the next row is read from -- HBM is read once per row (8 (1 + d + K) bytes), and a
+//     wave holds a quarter of a row in flight instead of all of it;
+//   * the linear predictors p1 = log tau_i, p2 = log nu_i: every wave sums ITS channels' terms while they are still in
+//     registers (coefficients in scalar registers) and stores two partial sums per row;
+//   * the row's transition: the LAST wave adds the partial sums of the NEXT row, takes the exp's and builds T, Q, B and
+//     their log tau derivatives once (makeT/Q/B_ctcrw: nllk_ctcrw.hpp:45-91 through ctcrw_trans) into a two-slot ring; the
+//     engine deals that wave fewer columns.
+// accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]
+constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + WG_WAVES - 1) / WG_WAVES;   // channels a wave loads per row (dt, y, the streamed columns)
+constexpr int CV_CMAX = CV_LD * WG_WAVES;                               // channels of a staged row
+constexpr int CV_PRODUCER = WG_WAVES - 1;                               // the wave that builds the transitions
 
-template <int MODEL, int D>
+__device__ __forceinline__ double uniform_double(double x) {   // a wave-uniform value into scalar registers
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+template <int MODEL> struct CvTransIO;
+template <> struct CvTransIO<M_CTCRW> {
+    static constexpr int N = 12;
+    static __device__ __forceinline__ void put(double* o, const CtcrwTrans& t) {      // o[j * WAVE]
+        o[0 * WAVE] = t.e; o[1 * WAVE] = t.t12; o[2 * WAVE] = t.b1; o[3 * WAVE] = t.b2; o[4 * WAVE] = t.q11; o[5 * WAVE] = t.q12;
+        o[6 * WAVE] = t.q22; o[7 * WAVE] = t.de; o[8 * WAVE] = t.dt12; o[9 * WAVE] = t.dq11; o[10 * WAVE] = t.dq12; o[11 * WAVE] = t.dq22;
+    }
+    static __device__ __forceinline__ void get(const double* o, CtcrwTrans& t) {
+        t.e = o[0 * WAVE]; t.t12 = o[1 * WAVE]; t.b1 = o[2 * WAVE]; t.b2 = o[3 * WAVE]; t.q11 = o[4 * WAVE]; t.q12 = o[5 * WAVE];
+        t.q22 = o[6 * WAVE]; t.de = o[7 * WAVE]; t.dt12 = o[8 * WAVE]; t.dq11 = o[9 * WAVE]; t.dq12 = o[10 * WAVE]; t.dq22 = o[11 * WAVE];
+        t.e2 = t.e * t.e; t.dt12x2 = 2.0 * t.dt12; t.dt12e = t.dt12 * t.e; t.edex2 = 2.0 * t.e * t.de;      // as ctcrw_trans forms them
+    }
+};
+template <int MODEL> struct CvTransIO {                       // OU_SSM, BM_SSM
+    static constexpr int N = 6;
+    static __device__ __forceinline__ void put(double* o, const ScalTrans& t) {
+        o[0 * WAVE] = t.t; o[1 * WAVE] = t.b; o[2 * WAVE] = t.q; o[3 * WAVE] = t.dt_; o[4 * WAVE] = t.db; o[5 * WAVE] = t.dq;
+    }
+    static __device__ __forceinline__ void get(const double* o, ScalTrans& t) {
+        t.t = o[0 * WAVE]; t.b = o[1 * WAVE]; t.q = o[2 * WAVE]; t.dt_ = o[3 * WAVE]; t.db = o[4 * WAVE]; t.dq = o[5 * WAVE];
+    }
+};
+
+// KC: column slots per wave (the widest part's count, rounded up to even; the engine picks the instantiation)
+template <int MODEL, int D, int KC>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
-    constexpr int KC = CV_KC;
     typedef typename CvModel<MODEL, D, KC>::Lane Lane;
     typedef typename CvModel<MODEL, D, KC>::Trans Trans;
+    typedef CvTransIO<MODEL> TIO;
     constexpr int SD = Lane::SD;
-    __shared__ double raw[2][CV_CMAX * WAVE];
+    __shared__ double raw[2][CV_CMAX * WAVE];                  // the staged rows
+    __shared__ double eta[2][(2 * WG_WAVES + 1) * WAVE];       // per row: the four waves' partial sums of p1, p2, and the interval
+    __shared__ double trs[2][TIO::N * WAVE];                   // per row: the transition
     __shared__ double coef[DRIFT_KMAX][2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: the part tables are read with scalar loads)
     const TileView& tv = A.tv;
     const int G = tv.n_groups;
     const int g = blockIdx.x % G, chunk = blockIdx.x / G;      // (groups are sorted longest first: the long ones start first)
     const int C = tv.C, c_obs = tv.c_obs, K = A.drift_k, c_col = A.c_col;
-    constexpr int nacc = 1 + CV_KC + D;
+    constexpr int nacc = 2 + CV_KC + D;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < DRIFT_KMAX; k++) { coef[k][0] = A.coefA[k]; coef[k][1] = A.coefB[k]; }
     }
-    CvPart P;                                                  // (wave-uniform: scalar loads)
-    P.n_col = parts[part].n_col; P.n0 = parts[part].n0; P.n01 = parts[part].n01; P.with_mu = parts[part].with_mu;
-    if (!A.part_mask[0]) { P.n_col = 0; P.n0 = 0; P.n01 = 0; P.with_mu = 0; }      // value only: part 0 runs the primal filter alone
-    const bool active = part == 0 || P.n_col > 0 || P.with_mu; // (a part without work still stages its share of the rows)
+    __syncthreads();
+    // the channels this wave stages (past the last one: a design column again, with coefficient 0) and their coefficients
+    int lch[CV_LD];
+    unsigned col_bits = 0;                                     // bit i: the wave's i-th channel is a design column
+    double cA[CV_LD], cB[CV_LD];
+#pragma unroll
+    for (int i = 0; i < CV_LD; i++) {
+        const int c = part + WG_WAVES * i, k = c - c_col;
+        const bool on = k >= 0 && k < K;
+        if (on) col_bits |= 1u << i;
+        lch[i] = c < C ? c : c_col;
+        cA[i] = uniform_double(on ? coef[on ? k : 0][0] : 0.0);
+        cB[i] = uniform_double(on ? coef[on ? k : 0][1] : 0.0);
+    }
+    const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- part 0 runs the primal filter alone)
+    const int n_col = grad ? parts[part].n_col : 0;
+    const bool with_mu = grad && parts[part].with_mu, with_sig = grad && parts[part].with_sig;
+    const bool active = part == 0 || n_col > 0 || with_mu || with_sig;     // (a part without work still stages its share of the rows)
     int chan[KC];
-    bool ones[KC];
+    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0;           // per slot: a column of ones / feeds par[d] / feeds par[d + 1]
 #pragma unroll
     for (int k = 0; k < KC; k++) {
-        const int ch = parts[part].chan[k];
-        ones[k] = !(k < P.n_col && ch >= 0);
-        chan[k] = ones[k] ? c_col : ch;
+        const bool on = k < n_col;
+        const int ch = on ? parts[part].chan[k] : -2, ty = on ? parts[part].type[k] : 0;
+        chan[k] = ch >= 0 ? ch : c_col;                        // (an unused slot reads a design column and weighs it with 0)
+        if (ch == -1) ones_bits |= 1u << k;
+        if (ty == 1) t1_bits |= 1u << k;
+        if (ty == 2) t2_bits |= 1u << k;
     }
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -369,25 +420,42 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     window_bounds(L, A.n_chunks, A.window, 0, chunk, s_begin, s_acc, s_end, 0);
     const int pc = part * A.n_chunks + chunk;
 
-    double set0[CV_LD], set1[CV_LD];
+    double setA[CV_LD], setB[CV_LD];
     auto ld = [&](double (&dst)[CV_LD], int s) {               // this wave's channels of row s: HBM -> registers
         const double* p = base + (int64_t)s * C * WAVE;
 #pragma unroll
-        for (int i = 0; i < CV_LD; i++) {
-            const int c = part + WG_WAVES * i;
-            dst[i] = 0.0;
-            if (c < C) dst[i] = p[c * WAVE];
-        }
+        for (int i = 0; i < CV_LD; i++) dst[i] = p[lch[i] * WAVE];
     };
-    auto st = [&](const double (&src)[CV_LD], int slot) {      // registers -> the ring
+    auto st_raw = [&](const double (&src)[CV_LD], int slot) {  // registers -> the ring of rows (a channel past the last: written, never read)
+#pragma unroll
+        for (int i = 0; i < CV_LD; i++) raw[slot][(part + WG_WAVES * i) * WAVE + lane] = src[i];
+    };
+    auto st_eta = [&](const double (&src)[CV_LD], int slot) {  // this wave's terms of the row's linear predictors
+        double pa = 0.0, pb = 0.0;
 #pragma unroll
         for (int i = 0; i < CV_LD; i++) {
-            const int c = part + WG_WAVES * i;
-            if (c < C) raw[slot][c * WAVE + lane] = src[i];
+            const double xs = ((col_bits >> i) & 1u) ? src[i] : 0.0;      // (an observation may be NaN: 0 * NaN is not 0)
+            pa = fma(cA[i], xs, pa);
+            if (MODEL != M_BM_SSM) pb = fma(cB[i], xs, pb);
         }
+        eta[slot][(2 * part) * WAVE + lane] = pa;
+        eta[slot][(2 * part + 1) * WAVE + lane] = pb;
+        if (part == 0) eta[slot][(2 * WG_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
-    ld(set0, s_begin);
-    ld(set1, s_begin + 1);
+    auto produce = [&](int slot) {                             // the last wave: the transition of the row whose sums sit in eta[slot]
+        if (part != CV_PRODUCER) return;
+        const double* e_ = &eta[slot][lane];
+        double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
+#pragma unroll
+        for (int w = 0; w < WG_WAVES; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
+        const double dtc = e_[(2 * WG_WAVES) * WAVE];
+        const double dt = c_obs ? dtc : tv.dt_all;
+        Trans tr;
+        Lane::trans(dt, p1, p2, tr);
+        TIO::put(&trs[slot][lane], tr);
+    };
+    ld(setA, s_begin);
+    ld(setB, s_begin + 1);
     Lane S;
     {
         double a0[SD];
@@ -416,39 +484,66 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         }
         if (s < ns) {
             const double* r = &raw[slot][lane];
-            double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
-#pragma unroll 4
-            for (int k = 0; k < K; k++) {
-                const double xk = r[(c_col + k) * WAVE];
-                p1 = fma(coef[k][0], xk, p1);
-                if (MODEL != M_BM_SSM) p2 = fma(coef[k][1], xk, p2);
-            }
-            double dt = tv.dt_all;
-            if (c_obs) dt = r[0];
             double y[D];
 #pragma unroll
             for (int a = 0; a < D; a++) y[a] = r[(c_obs + a) * WAVE];
             Trans tr;
-            Lane::trans(dt, p1, p2, tr);
-            double X[KC];
+            TIO::get(&trs[slot][lane], tr);
+            double X1[KC], X2[KC];
 #pragma unroll
-            for (int k = 0; k < KC; k++) { const double xl = r[chan[k] * WAVE]; X[k] = ones[k] ? 1.0 : xl; }
-            S.step(P, tr, h, mu, y, is_na(y[0], A.any_nan), X);
+            for (int k = 0; k < KC; k++) {
+                const double xl = r[chan[k] * WAVE];
+                const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
+                X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+            }
+            S.step(tr, h, mu, y, is_na(y[0], A.any_nan), X1, X2, with_sig, with_mu);
         }
     };
-    st(set0, 0);                                               // (window bounds are multiples of WIN_ALIGN: row s lives in slot s & 1)
-    ld(set0, s_begin + 2);
+#ifdef SSDE_CV_CLOCK
+    // (tuning build: where a wave's cycles go -- staging, the transition, the row, the barrier)
+    long long ck[4] = {0, 0, 0, 0};
+    long long t_ = __builtin_amdgcn_s_memtime();
+#define SSDE_CK(i) { const long long n_ = __builtin_amdgcn_s_memtime(); ck[i] += n_ - t_; t_ = n_; }
+#else
+#define SSDE_CK(i)
+#endif
+    // (window bounds are multiples of WIN_ALIGN: row s lives in slot s & 1 of every ring)
+    st_eta(setA, 0);                                           // row s_begin
+    __syncthreads();
+    st_raw(setA, 0);
+    st_eta(setB, 1);                                           // row s_begin + 1
+    ld(setA, s_begin + 2);
+    produce(0);
     __syncthreads();
     for (int s = s_begin; s < s_end; s += 2) {
-        st(set1, 1);                                           // row s + 1 (slot 1 was last read for row s - 1, before the barrier)
-        ld(set1, s + 3);
+        // setB holds row s + 1, setA row s + 2
+        st_raw(setB, 1);                                       // (slot 1 was last read for row s - 1, before the barrier)
+        st_eta(setA, 0);                                       // row s + 2 (slot 0 was last read by the producer for row s, before the barrier)
+        ld(setB, s + 3);                                       // (issued AFTER the stores: they wait for loads one and two rows old, not for these)
+        SSDE_CK(0)
+        produce(1);                                            // row s + 1
+        SSDE_CK(1)
         row(0, s);
+        SSDE_CK(2)
         __syncthreads();
-        st(set0, 0);                                           // row s + 2
-        ld(set0, s + 4);
+        SSDE_CK(3)
+        st_raw(setA, 0);                                       // row s + 2
+        st_eta(setB, 1);                                       // row s + 3
+        ld(setA, s + 4);
+        SSDE_CK(0)
+        produce(0);                                            // row s + 2
+        SSDE_CK(1)
         row(1, s + 1);
+        SSDE_CK(2)
         __syncthreads();
+        SSDE_CK(3)
     }
+#ifdef SSDE_CV_CLOCK
+    if (A.wave_clock && lane == 0) {
+        double* o = A.wave_clock + 4 * ((int64_t)blockIdx.x * WG_WAVES + part);
+        for (int i = 0; i < 4; i++) o[i] = (double)ck[i] / (double)(s_end - s_begin);
+    }
+#endif
     if (active && A.n_chunks > 1 && chunk + 1 < A.n_chunks)
         S.dump_to(A.bnd + (((int64_t)pc * G + g) * 2 + 1) * A.bnd_stride * WAVE + lane);
     const bool empty = s_acc >= s_end || !active;
@@ -458,13 +553,17 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     }
 #pragma unroll
     for (int k = 0; k < CV_KC; k++) {
-        const double t = wave_sum(empty ? 0.0 : S.g[k]);
+        const double t = wave_sum((empty || k >= KC) ? 0.0 : S.g[k < KC ? k : 0]);
         if (lane == 0) A.partials[((int64_t)pc * nacc + 1 + k) * G + g] = t;
     }
 #pragma unroll
     for (int a = 0; a < D; a++) {
         const double t = wave_sum(empty ? 0.0 : S.gmu[a]);
         if (lane == 0) A.partials[((int64_t)pc * nacc + 1 + CV_KC + a) * G + g] = t;
+    }
+    {
+        const double t = wave_sum(empty ? 0.0 : S.g[KC]);
+        if (lane == 0) A.partials[((int64_t)pc * nacc + 1 + CV_KC + D) * G + g] = t;
     }
 }
 
@@ -498,12 +597,21 @@ hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* ou
     return hipGetLastError();
 }
 
-// a.n_parts == WG_WAVES parts (one per wave of a workgroup), a.drift_k streamed columns (1 .. DRIFT_KMAX)
-hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s) {
-    if (a.n_parts != WG_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX) return hipErrorInvalidValue;
+// a.n_parts == WG_WAVES parts (one per wave of a workgroup), a.drift_k streamed columns (1 .. DRIFT_KMAX), kc: the widest
+// part's column count
+template <int MODEL, int D>
+static hipError_t launch_cv(const IsoArgs& a, const CvPart* parts, int kc, dim3 grid, dim3 block, hipStream_t s) {
+    if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2>), grid, block, 0, s, a, parts);
+    else if (kc <= 4) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4>), grid, block, 0, s, a, parts);
+    else if (kc <= 6) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 6>), grid, block, 0, s, a, parts);
+    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 8>), grid, block, 0, s, a, parts);
+    return hipGetLastError();
+}
+hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s) {
+    if (a.n_parts != WG_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
     dim3 grid(a.tv.n_groups * a.n_chunks), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
-#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) { hipLaunchKernelGGL((iso_colvar_kernel<M_, D_>), grid, block, 0, s, a, parts); return hipGetLastError(); }
+#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) return launch_cv<M_, D_>(a, parts, kc, grid, block, s);
     SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)
 #undef SSDE_CASE
     return hipErrorInvalidValue;

@@ -124,18 +124,19 @@ struct IsoArgs {
     // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
     double cv_eta0[2];
 };
-// One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients the part's waves carry, sorted by
-// what the column feeds (device table, one entry per part)
-constexpr int CV_KC = 8;         // columns per part (register budget of a wave); the parts are the WG_WAVES waves of a workgroup
+// One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients one wave of the workgroups carries
+// (device table, WG_WAVES entries)
+constexpr int CV_KC = 8;         // columns per part (register budget of a wave)
 struct CvPart {
     int32_t n_col;               // columns of this part
-    int32_t n0, n01;             // slots [0, n0): log sigma_obs; [n0, n01): par[d] (log tau / log sigma); [n01, n_col): par[d+1] (log nu / log kappa)
     int32_t with_mu;             // the part also carries the drift-intercept direction
+    int32_t with_sig;            // ... the log sigma_obs direction
     int32_t chan[CV_KC];         // tile channel of the slot's design column, -1 = a column of ones (an intercept)
+    int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa)
 };
-// partials [n_parts * n_chunks][1 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d; a.n_parts == WG_WAVES;
-// a.part_mask[0] == 0: the value only (no tangents)
-hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s);
+// partials [n_parts * n_chunks][2 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d | log sigma_obs;
+// a.n_parts == WG_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count
+hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
 int colvar_nstate(int model, int d, int kc);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance

@@ -34,7 +34,8 @@ void release_device(ssde_handle* h) {
             if (FILE* f = fopen(h->wave_clock_file.c_str(), "w")) {
                 fprintf(f, "# work item, start, end (100 MHz ticks), HW_ID; windows %d, warm-up %d, t0 %d\n", h->last_chunks, h->last_window, h->last_t0);
                 for (int i = 0; i < h->wave_clock_items; i++)
-                    if (w[4 * (size_t)i + 3] != 0.0) fprintf(f, "%d %.0f %.0f %.0f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2]);
+                    if (h->drift == 3) fprintf(f, "%d %.1f %.1f %.1f %.1f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2], w[4 * (size_t)i + 3]);
+                    else if (w[4 * (size_t)i + 3] != 0.0) fprintf(f, "%d %.0f %.0f %.0f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2]);
                 fclose(f);
             }
         }

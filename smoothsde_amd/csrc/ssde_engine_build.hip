@@ -134,13 +134,11 @@ constexpr int SSDE_RETRY_WITHOUT_DRIFT = -77;     // internal: the drift layout 
 static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>& gflags, const std::vector<int32_t>& lane_ns,
                               const std::vector<int32_t>& glen) {
     if (h->drift == 3) {
-        // row-varying tau / nu: deal the columns whose coefficients are free to the four waves of a workgroup (k_iso_colvar.hip),
-        // sorted by what they feed -- log sigma_obs (a column of ones), par[d], par[d + 1] -- so that a wave's unrolled column
-        // loop takes uniform branches; round robin keeps the order and evens the counts out
+        // row-varying tau / nu: deal the design columns whose coefficients are free (an intercept is a column of ones) to the four
+        // waves of a workgroup (k_iso_colvar.hip)
         struct Col { int type, chan, pidx; };
         std::vector<Col> cols;
         const int c_col = h->c_obs + h->d;
-        if (!h->fixed[0]) cols.push_back({0, -1, 0});
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
@@ -148,24 +146,37 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         std::vector<CvPart> parts(WG_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * WG_WAVES);
         h->cv_pidx.assign((size_t)WG_WAVES * CV_KC, -1);
+        // A wave's row costs, in fp64 instructions (counted: profiles/r03_colvar_*): the primal filter if it carries anything, so
+        // much per column, and -- the last wave -- the exp's and the transition it builds for all four.  Every column goes to
+        // the wave that is cheapest with it.
+        const bool ct = h->model == SSDE_MODEL_CTCRW;
+        const double c_primal = ct ? 140.0 : 50.0, c_col_ = ct ? (h->d == 2 ? 48.0 : 34.0) : 12.0 + 3.0 * h->d, c_trans = ct ? 330.0 : 120.0;
+        double cost[WG_WAVES];
+        for (int p = 0; p < WG_WAVES; p++) cost[p] = (p == 0 ? c_primal : 0.0) + (p == WG_WAVES - 1 ? c_trans : 0.0);
+        auto idle = [&](int p) { return p != 0 && parts[p].n_col == 0 && !parts[p].with_mu && !parts[p].with_sig; };
+        auto cost_with = [&](int p) { return cost[p] + c_col_ + (idle(p) ? c_primal : 0.0); };
+        auto cheapest = [&](bool need_slot) {
+            int best = -1;
+            for (int p = 0; p < WG_WAVES; p++)
+                if ((!need_slot || parts[p].n_col < CV_KC) && (best < 0 || cost_with(p) < cost_with(best))) best = p;
+            return best;
+        };
         for (size_t i = 0; i < cols.size(); i++) {
-            CvPart& P = parts[i % WG_WAVES];
+            const int best = cheapest(true);
+            CvPart& P = parts[best];
+            cost[best] = cost_with(best);
             const int k = P.n_col++;
-            P.chan[k] = cols[i].chan;
-            if (cols[i].type == 0) { P.n0++; P.n01++; }
-            if (cols[i].type == 1) P.n01++;
-            h->cv_pidx[(i % WG_WAVES) * CV_KC + k] = cols[i].pidx;
+            P.chan[k] = cols[i].chan; P.type[k] = cols[i].type;
+            h->cv_pidx[(size_t)best * CV_KC + k] = cols[i].pidx;
         }
+        h->cv_sig_part = h->cv_mu_part = -1;
+        if (!h->fixed[0]) { const int p = cheapest(false); cost[p] = cost_with(p); parts[p].with_sig = 1; h->cv_sig_part = p; }
         bool mu_free = false;
         for (auto& sl : h->slots)
             if (sl.par_j < h->d && !h->fixed[sl.pidx]) mu_free = true;
-        if (mu_free) {
-            int best = WG_WAVES - 1;
-            for (int p = WG_WAVES - 1; p >= 0; p--)
-                if (parts[p].n_col < parts[best].n_col) best = p;
-            parts[best].with_mu = 1;
-            h->cv_mu_part = best;
-        }
+        if (mu_free) { const int p = cheapest(false); parts[p].with_mu = 1; h->cv_mu_part = p; }
+        h->cv_kc = 0;
+        for (int p = 0; p < WG_WAVES; p++) h->cv_kc = std::max(h->cv_kc, (int)parts[p].n_col);
         HIPCHK(h, h->cv_parts.upload(parts));
         {
             // the range of every streamed column over the batch
@@ -186,7 +197,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = (colvar_nstate(h->model, h->d, CV_KC) + 3) / 4 * 4;
+        h->drift_nstate = colvar_nstate(h->model, h->d, (std::max(h->cv_kc, 1) + 1) / 2 * 2);      // (the kernel is instantiated for 2, 4, 6, 8 slots)
     } else
     if (h->drift) {
         // regular grid and every track complete: the shared-covariance lanes; otherwise the lanes carry their own covariance
@@ -272,7 +283,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     }
     HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
-    h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * std::max(NACC_MAX, 1 + CV_KC + 2) * G;
+    h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
     h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
     return SSDE_OK;
 }

@@ -385,7 +385,16 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
     } else {
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
-        if (h->drift == 3) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_colvar(h->model, h->d, a, h->cv_parts.p, s)); }
+        if (h->drift == 3) {
+            a.t0 = 0; a.t0_delta = 0;
+            if (!h->wave_clock_file.empty()) {                  // (a build with -DSSDE_CV_CLOCK fills it: cycles per row and phase of every wave)
+                const int items = h->n_groups * a.n_chunks * WG_WAVES;
+                if ((int)h->wave_clock.n < 4 * items) { h->wave_clock.release(); HIPCHK(h, h->wave_clock.alloc((size_t)4 * items)); }
+                HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
+                a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
+            }
+            HIPCHK(h, launch_iso_colvar(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
+        }
         else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
         else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
@@ -402,13 +411,13 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
         }
     }
-    const int nacc = h->drift == 3 ? 1 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
+    const int nacc = h->drift == 3 ? 2 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
     const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
     ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
     ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
     ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
     if (order >= 1 && h->drift == 3) {
-        // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d]
+        // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d | log sigma_obs]
         for (int p = 0; p < WG_WAVES; p++) {
             for (int k = 0; k < CV_KC; k++) {
                 const int pidx = h->cv_pidx[(size_t)p * CV_KC + k];
@@ -417,6 +426,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             if (p == h->cv_mu_part)
                 for (auto& sl : h->slots)
                     if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) ra.map[p * (nacc - 1) + CV_KC + sl.par_j] = (int16_t)(1 + sl.pidx);
+            if (p == h->cv_sig_part) ra.map[p * (nacc - 1) + CV_KC + h->d] = 1;
         }
     } else
     if (order >= 1 && h->drift) {
