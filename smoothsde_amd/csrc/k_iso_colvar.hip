@@ -12,55 +12,60 @@
 // (T, Q, B, H) with respect to log tau (t = 1), log nu / kappa (t = 2) or log sigma_obs (t = 0) at THIS row's parameters.
 // 3 + 2 d doubles of state and ~45 fp64 instructions per column and row (CTCRW, d = 2).
 //
-// Work split: the columns are dealt to the four waves of a workgroup (PARTS of at most CV_KC columns: a wave's register
-// budget); the waves that carry columns recompute the primal filter (the gains: ~140 instructions) next to them.  The
-// column loop is straight-line code: what a column feeds is a pair of 0/1 factors on its value, not a branch (measured: a
-// uniform branch per column and type cost 2100 of 4600 cycles per row -- every column a basic block of its own, nothing to
-// overlap).  The log sigma_obs direction and the drift-intercept direction are single slots behind one uniform branch each.
-// One workgroup per (64-track group, time window); windows, warm-up and the verified hand-over as in k_iso.hip.
-// Layout: the tiles of ssde_device.hpp with the design columns as further channels (as k_iso_drift.hip).
+// One WORKGROUP per (64-track group, time window).  Its four waves form a three-stage pipeline over the rows, one barrier per
+// row, everything between the stages in LDS rings:
+//   stage 0, every wave:  loads a quarter of the channels of the row four ahead (HBM is read ONCE per row: 8 (1 + d + K)
+//                         bytes), stores the row two ahead to the ring of rows, and adds ITS channels' terms of the linear
+//                         predictors p1 = log tau_i, p2 = log nu_i of the row three ahead (two partial sums per wave and row);
+//   stage 1, the last wave:  for the row two ahead, sums the partial predictors, takes the exp's and builds T, Q, B and their
+//                         log tau derivatives (makeT/Q/B_ctcrw: nllk_ctcrw.hpp:45-91 through ctcrw_trans);
+//   stage 2, wave 0:      the primal filter of the NEXT row (gains, residuals, state, covariance, likelihood terms; the
+//                         log sigma_obs and drift-intercept directions), and the row's LINEARISATION: the nine numbers of
+//                         Lin_i, the residuals and the seed vectors -- 15 + 3 d doubles per lane;
+//   stage 3, every wave:  the column tangents of the current row from the linearisation -- straight-line code, what a column
+//                         feeds is a pair of 0/1 factors on its value, not a branch -- for the columns dealt to the wave.
+// The engine deals the columns by cost: the waves that also run a stage get fewer.  A wave's registers hold its columns'
+// state and little else: the transition lives in the last wave, the filter in wave 0.
+// (Measured on the way here, 1e4 tracks x 1e3 rows, 18 columns: every wave running the primal filter + a uniform branch per
+// column and type 2.06 ms; straight-line columns + a transition wave 1.54 ms -- more than half of its VALU instructions were
+// register-file overflow traffic, v_accvgpr / v_readlane moves.)
+// Windows, warm-up and the verified hand-over as in k_iso.hip.  Layout: the tiles of ssde_device.hpp with the design
+// columns as further channels (as k_iso_drift.hip).
 #include <type_traits>
 
 #include "ssde_device.hpp"
 
 namespace ssde {
 
-// ---- the per-row linearisation and the column recursion, CTCRW ------------------------------------------------------
-template <int D, int KC>
-struct CvCtcrw {
+// ---- CTCRW: the primal filter and the linearisation it hands to the column waves ----------------------------------------------
+template <int D>
+struct CvPrimalCtcrw {
     static constexpr int SD = 2 * D;
-    static constexpr int NCOL = 3 + 2 * D;
-    static constexpr int NSTATE = SD + 3 + 2 + (KC + 1) * NCOL;
+    static constexpr int NLIN = 15 + 3 * D;
+    static constexpr int NCOL = 3 + 2 * D;                     // doubles of a tangent
+    static constexpr int NDUMP = SD + 3 + 2 + NCOL;
+    typedef CtcrwTrans Trans;
     double x[D], v[D], p11, p12, p22;
     LogAcc ld;
     double accq;
     double mx, mv, gmu[D];
-    double d11[KC + 1], d12[KC + 1], d22[KC + 1], tx[KC + 1][D], tv[KC + 1][D], g[KC + 1];      // slot KC: log sigma_obs
+    double s11, s12, s22, stx[D], stv[D], sg;                  // the log sigma_obs tangent
 
     __device__ __forceinline__ void init(const double* a0, const double* p0) {
 #pragma unroll
-        for (int a = 0; a < D; a++) { x[a] = a0[2 * a]; v[a] = a0[2 * a + 1]; gmu[a] = 0.0; }
+        for (int a = 0; a < D; a++) { x[a] = a0[2 * a]; v[a] = a0[2 * a + 1]; gmu[a] = 0.0; stx[a] = stv[a] = 0.0; }
         p11 = p0[0]; p12 = p0[1]; p22 = p0[2];
-        ld.init(); accq = 0.0; mx = mv = 0.0;
-#pragma unroll
-        for (int k = 0; k <= KC; k++) {
-            d11[k] = d12[k] = d22[k] = g[k] = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) tx[k][a] = tv[k][a] = 0.0;
-        }
+        ld.init(); accq = 0.0; mx = mv = 0.0; s11 = s12 = s22 = sg = 0.0;
     }
     __device__ __forceinline__ void reset_acc() {
-        ld.init(); accq = 0.0;
+        ld.init(); accq = 0.0; sg = 0.0;
 #pragma unroll
         for (int a = 0; a < D; a++) gmu[a] = 0.0;
-#pragma unroll
-        for (int k = 0; k <= KC; k++) g[k] = 0.0;
     }
-    // One row: score y (unless NA), the column tangents, then the prediction over the row's interval (ctcrw_step's
-    // arrangement: filtered-form covariance update, Joseph-form sensitivities; ssde_math.hpp).
-    // X1[k] / X2[k]: the column's value if it feeds log tau / log nu, else 0.
-    __device__ __forceinline__ void step(const CtcrwTrans& tr, double h, const double* mu, const double* y, bool na,
-                                         const double* X1, const double* X2, bool with_sig, bool with_mu) {
+    // One row: score y (unless NA), then the prediction over the row's interval (ctcrw_step's arrangement: filtered-form
+    // covariance update, Joseph-form sensitivities; ssde_math.hpp).  lin[j * WAVE]: the row's linearisation (LDS).
+    __device__ __forceinline__ void step(const CtcrwTrans& tr, double h, const double* mu, const double* y, bool na, bool with_sig,
+                                         bool with_mu, double* lin) {
         const double F = p11 + h;
         const double detF = (D == 1) ? F : F * F;                  // nllk_ctcrw.hpp:16-19, 223
         const bool upd = !na && !(detF <= 0.0);                    // :214, 226
@@ -70,7 +75,7 @@ struct CvCtcrw {
         ld.mul(Fe);
         const double bm = (na || upd) ? 1.0 : 0.0;                 // Q3 (:226-228)
         const double e = tr.e, t12 = tr.t12, e2 = tr.e2;
-        const double a = fma(h, iF, 1.0 - updf), a2 = a * a, aiF = a * iF;
+        const double a = fma(h, iF, 1.0 - updf), aiF = a * iF;
         const double kf1 = p11 * iF, kf2 = p12 * iF;
         const double f11 = p11 * a, f12 = p12 * a, f22 = fma(-p12, kf2, p22);
         const double m = fma(t12, f22, f12);
@@ -86,64 +91,41 @@ struct CvCtcrw {
         }
         accq = fma(iF, su2, accq);
         const double gF = fma(-0.5 * iF * iF, su2, 0.5 * (double)D * iF);     // d nllk / d F of this row
-        // ---- seeds ------------------------------------------------------------------------------------------------
-        // log tau: T, B and Q move
-        const double s1_11 = fma(tr.dt12x2, m, tr.dq11), s1_12 = fma(tr.dt12e, f22, fma(tr.de, m, tr.dq12)),
-                     s1_22 = fma(tr.edex2, f22, tr.dq22);
-        double s1_x[D], s1_v[D];
+        int n = 0;
+        lin[(n++) * WAVE] = iF; lin[(n++) * WAVE] = a; lin[(n++) * WAVE] = aiF; lin[(n++) * WAVE] = kf2; lin[(n++) * WAVE] = t12;
+        lin[(n++) * WAVE] = e; lin[(n++) * WAVE] = c1; lin[(n++) * WAVE] = k2; lin[(n++) * WAVE] = gF;
+#pragma unroll
+        for (int a_ = 0; a_ < D; a_++) lin[(n++) * WAVE] = u[a_];
+        // seeds: log tau moves T, B and Q ...
+        lin[(n++) * WAVE] = fma(tr.dt12x2, m, tr.dq11);
+        lin[(n++) * WAVE] = fma(tr.dt12e, f22, fma(tr.de, m, tr.dq12));
+        lin[(n++) * WAVE] = fma(tr.edex2, f22, tr.dq22);
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) {
             const double w = fma(kf2, u[a_], v[a_] - mue[a_]);     // d k u + d(T a + B mu): (dt12, de) (kf2 u + v - mu)
-            s1_x[a_] = tr.dt12 * w; s1_v[a_] = tr.de * w;
+            lin[(n++) * WAVE] = tr.dt12 * w; lin[(n++) * WAVE] = tr.de * w;
         }
-        // log nu: Q only (dQ = 2 Q)
-        const double s2_11 = 2.0 * tr.q11, s2_12 = 2.0 * tr.q12, s2_22 = 2.0 * tr.q22;
-        // the part of a tangent's step that does not depend on what it is a tangent of: returns the gain tangent
-        auto lin = [&](int k, double dF, double& n11, double& n12, double& n22, double& dk1, double& dk2) {
-            const double c11 = d11[k], c12 = d12[k], c22 = d22[k];
-            double sud = 0.0;
-#pragma unroll
-            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k][a_], sud);
-            g[k] = fma(gF, dF, fma(-iF, sud, g[k]));
-            const double w = fma(-kf2, c11, c12);
-            const double g11 = a2 * c11, g12 = a * w, g22 = fma(-kf2, c12 + w, c22);
-            const double dkf1 = c11 * aiF, dkf2 = w * iF;
-            const double dm = fma(t12, g22, g12);
-            n11 = fma(t12, g12 + dm, g11); n12 = e * dm; n22 = e2 * g22;
-            dk1 = fma(t12, dkf2, dkf1); dk2 = e * dkf2;
-        };
-        // ---- columns (straight-line: the two seed sets are weighted by the column's 0/1 factors) -----------------------
-#pragma unroll
-        for (int k = 0; k < KC; k++) {
-            double n11, n12, n22, dk1, dk2;
-            lin(k, d11[k], n11, n12, n22, dk1, dk2);
-            const double x1 = X1[k], x2 = X2[k];
-            d11[k] = fma(x2, s2_11, fma(x1, s1_11, n11));
-            d12[k] = fma(x2, s2_12, fma(x1, s1_12, n12));
-            d22[k] = fma(x2, s2_22, fma(x1, s1_22, n22));
-#pragma unroll
-            for (int a_ = 0; a_ < D; a_++) {
-                const double txk = tx[k][a_], tvk = tv[k][a_];
-                tx[k][a_] = fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk)));
-                tv[k][a_] = fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk)));
-            }
-        }
+        // ... log nu Q only (dQ = 2 Q)
+        lin[(n++) * WAVE] = 2.0 * tr.q11; lin[(n++) * WAVE] = 2.0 * tr.q12; lin[(n++) * WAVE] = 2.0 * tr.q22;
         if (with_sig) {
             // log sigma_obs: dh = 2 h enters F, the filtered covariance (k k' dh) and the gain (-k dh / F)
-            const double h2 = 2.0 * h;
-            double n11, n12, n22, dk1, dk2;
-            lin(KC, d11[KC] + h2, n11, n12, n22, dk1, dk2);
+            const double h2 = 2.0 * h, dF = s11 + h2;
+            double sud = 0.0;
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], stx[a_], sud);
+            sg = fma(gF, dF, fma(-iF, sud, sg));
+            const double w = fma(-kf2, s11, s12);
             const double q1 = kf1 * h2, q2 = kf2 * h2;
-            const double g11 = kf1 * q1, g12 = kf2 * q1, g22 = kf2 * q2;
-            const double dkf1 = -q1 * iF, dkf2 = -q2 * iF;
+            const double g11 = fma(kf1, q1, a * a * s11), g12 = fma(kf2, q1, a * w), g22 = fma(kf2, q2, fma(-kf2, s12 + w, s22));
+            const double dkf1 = fma(-q1, iF, s11 * aiF), dkf2 = fma(-q2, iF, w * iF);
             const double dm = fma(t12, g22, g12);
-            d11[KC] = n11 + fma(t12, g12 + dm, g11); d12[KC] = fma(e, dm, n12); d22[KC] = fma(e2, g22, n22);
-            dk1 += fma(t12, dkf2, dkf1); dk2 = fma(e, dkf2, dk2);
+            s11 = fma(t12, g12 + dm, g11); s12 = e * dm; s22 = e2 * g22;
+            const double dk1 = fma(t12, dkf2, dkf1), dk2 = e * dkf2;
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
-                const double txk = tx[KC][a_], tvk = tv[KC][a_];
-                tx[KC][a_] = fma(dk1, u[a_], fma(t12, tvk, c1 * txk));
-                tv[KC][a_] = fma(dk2, u[a_], fma(e, tvk, -k2 * txk));
+                const double txk = stx[a_], tvk = stv[a_];
+                stx[a_] = fma(dk1, u[a_], fma(t12, tvk, c1 * txk));
+                stv[a_] = fma(dk2, u[a_], fma(e, tvk, -k2 * txk));
             }
         }
         if (with_mu) {                                             // d / d mu_a: one data-independent chain for every dimension
@@ -153,7 +135,6 @@ struct CvCtcrw {
             for (int a_ = 0; a_ < D; a_++) gmu[a_] = fma(-imx, u[a_], gmu[a_]);
             mx = nx; mv = nv;
         }
-        // ---- primal -------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) {                           // a = T a + K u + B mu (:238)
             const double nx = fma(tr.b1, mue[a_], fma(k1, u[a_], fma(t12, v[a_], x[a_])));
@@ -170,12 +151,9 @@ struct CvCtcrw {
         for (int a = 0; a < D; a++) { o[(n++) * WAVE] = x[a]; o[(n++) * WAVE] = v[a]; }
         o[(n++) * WAVE] = p11; o[(n++) * WAVE] = p12; o[(n++) * WAVE] = p22;
         o[(n++) * WAVE] = mx; o[(n++) * WAVE] = mv;
+        o[(n++) * WAVE] = s11; o[(n++) * WAVE] = s12; o[(n++) * WAVE] = s22;
 #pragma unroll
-        for (int k = 0; k <= KC; k++) {
-            o[(n++) * WAVE] = d11[k]; o[(n++) * WAVE] = d12[k]; o[(n++) * WAVE] = d22[k];
-#pragma unroll
-            for (int a = 0; a < D; a++) { o[(n++) * WAVE] = tx[k][a]; o[(n++) * WAVE] = tv[k][a]; }
-        }
+        for (int a = 0; a < D; a++) { o[(n++) * WAVE] = stx[a]; o[(n++) * WAVE] = stv[a]; }
     }
     __device__ __forceinline__ double value() const { return 0.5 * ((double)D * ld.value() + accq); }
     // this row's transition from the linear predictors p1 = log tau, p2 = log nu (nllk_ctcrw.hpp:152-156)
@@ -184,42 +162,119 @@ struct CvCtcrw {
         const double beta = rcp(tau);
         ctcrw_trans(dt, tau, beta, 2.0 * nu / sqrt(M_PI * tau), tr);
     }
+    static constexpr int NTR = 12;
+    static __device__ __forceinline__ void put_trans(double* o, const CtcrwTrans& t) {      // o[j * WAVE]
+        o[0 * WAVE] = t.e; o[1 * WAVE] = t.t12; o[2 * WAVE] = t.b1; o[3 * WAVE] = t.b2; o[4 * WAVE] = t.q11; o[5 * WAVE] = t.q12;
+        o[6 * WAVE] = t.q22; o[7 * WAVE] = t.de; o[8 * WAVE] = t.dt12; o[9 * WAVE] = t.dq11; o[10 * WAVE] = t.dq12; o[11 * WAVE] = t.dq22;
+    }
+    static __device__ __forceinline__ void get_trans(const double* o, CtcrwTrans& t) {
+        t.e = o[0 * WAVE]; t.t12 = o[1 * WAVE]; t.b1 = o[2 * WAVE]; t.b2 = o[3 * WAVE]; t.q11 = o[4 * WAVE]; t.q12 = o[5 * WAVE];
+        t.q22 = o[6 * WAVE]; t.de = o[7 * WAVE]; t.dt12 = o[8 * WAVE]; t.dq11 = o[9 * WAVE]; t.dq12 = o[10 * WAVE]; t.dq22 = o[11 * WAVE];
+        t.e2 = t.e * t.e; t.dt12x2 = 2.0 * t.dt12; t.dt12e = t.dt12 * t.e; t.edex2 = 2.0 * t.e * t.de;      // as ctcrw_trans forms them
+    }
+};
+
+// the column tangents of a wave, CTCRW
+template <int D, int KC>
+struct CvColsCtcrw {
+    static constexpr int NCOL = 3 + 2 * D;
+    double d11[KC], d12[KC], d22[KC], tx[KC][D], tv[KC][D], g[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            d11[k] = d12[k] = d22[k] = g[k] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) tx[k][a] = tv[k][a] = 0.0;
+        }
+    }
+    __device__ __forceinline__ void reset_acc() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) g[k] = 0.0;
+    }
+    struct Lin {                                               // a row's linearisation, read from LDS once per row
+        double iF, a, aiF, kf2, t12, e, c1, k2, gF, u[D], s1_11, s1_12, s1_22, s1_x[D], s1_v[D], s2_11, s2_12, s2_22;
+        __device__ __forceinline__ void read(const double* lin) {
+            int n = 0;
+            iF = lin[(n++) * WAVE]; a = lin[(n++) * WAVE]; aiF = lin[(n++) * WAVE]; kf2 = lin[(n++) * WAVE]; t12 = lin[(n++) * WAVE];
+            e = lin[(n++) * WAVE]; c1 = lin[(n++) * WAVE]; k2 = lin[(n++) * WAVE]; gF = lin[(n++) * WAVE];
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) u[a_] = lin[(n++) * WAVE];
+            s1_11 = lin[(n++) * WAVE]; s1_12 = lin[(n++) * WAVE]; s1_22 = lin[(n++) * WAVE];
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) { s1_x[a_] = lin[(n++) * WAVE]; s1_v[a_] = lin[(n++) * WAVE]; }
+            s2_11 = lin[(n++) * WAVE]; s2_12 = lin[(n++) * WAVE]; s2_22 = lin[(n++) * WAVE];
+        }
+    };
+    // slots [K0, K1): X1[k] / X2[k] = the column's value if it feeds log tau / log nu, else 0
+    template <int K0, int K1>
+    __device__ __forceinline__ void step(const Lin& L, const double* X1, const double* X2) {
+        const double iF = L.iF, a = L.a, aiF = L.aiF, kf2 = L.kf2, t12 = L.t12, e = L.e, c1 = L.c1, k2 = L.k2, gF = L.gF;
+        const double* u = L.u; const double* s1_x = L.s1_x; const double* s1_v = L.s1_v;
+        const double s1_11 = L.s1_11, s1_12 = L.s1_12, s1_22 = L.s1_22, s2_11 = L.s2_11, s2_12 = L.s2_12, s2_22 = L.s2_22;
+        const double a2 = a * a, e2 = e * e;
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            const double c11 = d11[k], c12 = d12[k], c22 = d22[k];
+            double sud = 0.0;
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k][a_], sud);
+            g[k] = fma(gF, c11, fma(-iF, sud, g[k]));
+            const double w = fma(-kf2, c11, c12);
+            const double g11 = a2 * c11, g12 = a * w, g22 = fma(-kf2, c12 + w, c22);
+            const double dkf1 = c11 * aiF, dkf2 = w * iF;
+            const double dm = fma(t12, g22, g12);
+            const double dk1 = fma(t12, dkf2, dkf1), dk2 = e * dkf2;
+            const double x1 = X1[k], x2 = X2[k];
+            d11[k] = fma(x2, s2_11, fma(x1, s1_11, fma(t12, g12 + dm, g11)));
+            d12[k] = fma(x2, s2_12, fma(x1, s1_12, e * dm));
+            d22[k] = fma(x2, s2_22, fma(x1, s1_22, e2 * g22));
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) {
+                const double txk = tx[k][a_], tvk = tv[k][a_];
+                tx[k][a_] = fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk)));
+                tv[k][a_] = fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk)));
+            }
+        }
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            o[(n++) * WAVE] = d11[k]; o[(n++) * WAVE] = d12[k]; o[(n++) * WAVE] = d22[k];
+#pragma unroll
+            for (int a = 0; a < D; a++) { o[(n++) * WAVE] = tx[k][a]; o[(n++) * WAVE] = tv[k][a]; }
+        }
+    }
 };
 
 // ---- OU_SSM / BM_SSM: scalar covariance --------------------------------------------------------------------------------
-template <int D, int KC, bool HAS_P2>
-struct CvScal {
+template <int D, bool HAS_P2>
+struct CvPrimalScal {
     static constexpr int SD = D;
+    static constexpr int NLIN = 7 + 2 * D;
     static constexpr int NCOL = 1 + D;
-    static constexpr int NSTATE = SD + 1 + 1 + (KC + 1) * NCOL;
+    static constexpr int NDUMP = SD + 1 + 1 + NCOL;
+    typedef ScalTrans Trans;
     double x[D], p;
     LogAcc ld;
     double accq;
     double mx, gmu[D];
-    double dp[KC + 1], tx[KC + 1][D], g[KC + 1];               // slot KC: log sigma_obs
+    double sp, stx[D], sg;                                     // the log sigma_obs tangent
 
     __device__ __forceinline__ void init(const double* a0, const double* p0) {
 #pragma unroll
-        for (int a = 0; a < D; a++) { x[a] = a0[a]; gmu[a] = 0.0; }
+        for (int a = 0; a < D; a++) { x[a] = a0[a]; gmu[a] = 0.0; stx[a] = 0.0; }
         p = p0[0];
-        ld.init(); accq = 0.0; mx = 0.0;
-#pragma unroll
-        for (int k = 0; k <= KC; k++) {
-            dp[k] = g[k] = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) tx[k][a] = 0.0;
-        }
+        ld.init(); accq = 0.0; mx = 0.0; sp = sg = 0.0;
     }
     __device__ __forceinline__ void reset_acc() {
-        ld.init(); accq = 0.0;
+        ld.init(); accq = 0.0; sg = 0.0;
 #pragma unroll
         for (int a = 0; a < D; a++) gmu[a] = 0.0;
-#pragma unroll
-        for (int k = 0; k <= KC; k++) g[k] = 0.0;
     }
-    // scal_cov_step + scal_mean_step (ssde_math.hpp) with the direction loops replaced by the column loop
-    __device__ __forceinline__ void step(const ScalTrans& tr, double h, const double* mu, const double* y, bool na,
-                                         const double* X1, const double* X2, bool with_sig, bool with_mu) {
+    // scal_cov_step + scal_mean_step (ssde_math.hpp)
+    __device__ __forceinline__ void step(const ScalTrans& tr, double h, const double* mu, const double* y, bool na, bool with_sig,
+                                         bool with_mu, double* lin) {
         const double F = p + h;
         const bool upd = !na && !(fabs(F) <= 0.0);                 // nllk_ou_ssm.hpp:190-195, nllk_bm_ssm.hpp:152-157
         const double updf = upd ? 1.0 : 0.0;
@@ -241,38 +296,24 @@ struct CvScal {
         accq = fma(iF, su2, accq);
         const double gF = fma(-0.5 * iF * iF, su2, 0.5 * (double)D * iF);
         const double s1_k = HAS_P2 ? dt_ * b : 0.0;                 // log tau (OU) / log sigma (BM)
-        const double s1_p = HAS_P2 ? fma(2.0 * dt_, cp, tr.dq) : tr.dq;
-        double s1_x[D];
+        int n = 0;
+        lin[(n++) * WAVE] = iF; lin[(n++) * WAVE] = ca; lin[(n++) * WAVE] = tca; lin[(n++) * WAVE] = c; lin[(n++) * WAVE] = gF;
 #pragma unroll
-        for (int a_ = 0; a_ < D; a_++) s1_x[a_] = HAS_P2 ? fma(s1_k, u[a_], fma(tr.dt_, x[a_], tr.db * mu[a_])) : 0.0;
-        const double s2_p = tr.q;                                   // log kappa (OU)
-        auto lin = [&](int k_, double dF, double& np_, double& dk) {
+        for (int a_ = 0; a_ < D; a_++) lin[(n++) * WAVE] = u[a_];
+        lin[(n++) * WAVE] = HAS_P2 ? fma(2.0 * dt_, cp, tr.dq) : tr.dq;
+#pragma unroll
+        for (int a_ = 0; a_ < D; a_++) lin[(n++) * WAVE] = HAS_P2 ? fma(s1_k, u[a_], fma(tr.dt_, x[a_], tr.db * mu[a_])) : 0.0;
+        lin[(n++) * WAVE] = tr.q;                                   // log kappa (OU)
+        if (with_sig) {
+            const double h2 = 2.0 * h, bh = b * h2, dF = sp + h2;
             double sud = 0.0;
 #pragma unroll
-            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k_][a_], sud);
-            g[k_] = fma(gF, dF, fma(-iF, sud, g[k_]));
-            dk = ca * dp[k_]; np_ = tca * dp[k_];
-        };
+            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], stx[a_], sud);
+            sg = fma(gF, dF, fma(-iF, sud, sg));
+            const double dk = fma(-tiF, bh, ca * sp);
+            sp = fma(k * t, bh, tca * sp);
 #pragma unroll
-        for (int k_ = 0; k_ < KC; k_++) {
-            double np_, dk;
-            lin(k_, dp[k_], np_, dk);
-            const double x1 = X1[k_], x2 = X2[k_];
-            dp[k_] = HAS_P2 ? fma(x2, s2_p, fma(x1, s1_p, np_)) : fma(x1, s1_p, np_);
-#pragma unroll
-            for (int a_ = 0; a_ < D; a_++) {
-                const double nx = fma(dk, u[a_], c * tx[k_][a_]);
-                tx[k_][a_] = HAS_P2 ? fma(x1, s1_x[a_], nx) : nx;
-            }
-        }
-        if (with_sig) {
-            const double h2 = 2.0 * h, bh = b * h2;
-            double np_, dk;
-            lin(KC, dp[KC] + h2, np_, dk);
-            dk = fma(-tiF, bh, dk);
-            dp[KC] = fma(k * t, bh, np_);
-#pragma unroll
-            for (int a_ = 0; a_ < D; a_++) tx[KC][a_] = fma(dk, u[a_], c * tx[KC][a_]);
+            for (int a_ = 0; a_ < D; a_++) stx[a_] = fma(dk, u[a_], c * stx[a_]);
         }
         if (with_mu) {
             const double imx = iF * mx;
@@ -290,89 +331,119 @@ struct CvScal {
         for (int a = 0; a < D; a++) o[(n++) * WAVE] = x[a];
         o[(n++) * WAVE] = p;
         o[(n++) * WAVE] = mx;
+        o[(n++) * WAVE] = sp;
 #pragma unroll
-        for (int k = 0; k <= KC; k++) {
-            o[(n++) * WAVE] = dp[k];
-#pragma unroll
-            for (int a = 0; a < D; a++) o[(n++) * WAVE] = tx[k][a];
-        }
+        for (int a = 0; a < D; a++) o[(n++) * WAVE] = stx[a];
     }
     __device__ __forceinline__ double value() const { return 0.5 * ((double)D * ld.value() + accq); }
     static __device__ __forceinline__ void trans(double dt, double p1, double p2, ScalTrans& tr) {
         if constexpr (HAS_P2) ou_trans(dt, exp(p1), exp(p2), tr);     // nllk_ou_ssm.hpp:121-124
         else bm_trans(dt, exp(p1), tr);                               // nllk_bm_ssm.hpp:106-108
     }
+    static constexpr int NTR = 6;
+    static __device__ __forceinline__ void put_trans(double* o, const ScalTrans& t) {
+        o[0 * WAVE] = t.t; o[1 * WAVE] = t.b; o[2 * WAVE] = t.q; o[3 * WAVE] = t.dt_; o[4 * WAVE] = t.db; o[5 * WAVE] = t.dq;
+    }
+    static __device__ __forceinline__ void get_trans(const double* o, ScalTrans& t) {
+        t.t = o[0 * WAVE]; t.b = o[1 * WAVE]; t.q = o[2 * WAVE]; t.dt_ = o[3 * WAVE]; t.db = o[4 * WAVE]; t.dq = o[5 * WAVE];
+    }
+};
+
+template <int D, int KC, bool HAS_P2>
+struct CvColsScal {
+    static constexpr int NCOL = 1 + D;
+    double dp[KC], tx[KC][D], g[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            dp[k] = g[k] = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) tx[k][a] = 0.0;
+        }
+    }
+    __device__ __forceinline__ void reset_acc() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) g[k] = 0.0;
+    }
+    struct Lin {
+        double iF, ca, tca, c, gF, u[D], s1_p, s1_x[D], s2_p;
+        __device__ __forceinline__ void read(const double* lin) {
+            int n = 0;
+            iF = lin[(n++) * WAVE]; ca = lin[(n++) * WAVE]; tca = lin[(n++) * WAVE]; c = lin[(n++) * WAVE]; gF = lin[(n++) * WAVE];
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) u[a_] = lin[(n++) * WAVE];
+            s1_p = lin[(n++) * WAVE];
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) s1_x[a_] = lin[(n++) * WAVE];
+            s2_p = lin[(n++) * WAVE];
+        }
+    };
+    template <int K0, int K1>
+    __device__ __forceinline__ void step(const Lin& L, const double* X1, const double* X2) {
+        const double iF = L.iF, ca = L.ca, tca = L.tca, c = L.c, gF = L.gF, s1_p = L.s1_p, s2_p = L.s2_p;
+        const double* u = L.u; const double* s1_x = L.s1_x;
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            const double cdp = dp[k];
+            double sud = 0.0;
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k][a_], sud);
+            g[k] = fma(gF, cdp, fma(-iF, sud, g[k]));
+            const double dk = ca * cdp;
+            const double x1 = X1[k], x2 = X2[k];
+            dp[k] = HAS_P2 ? fma(x2, s2_p, fma(x1, s1_p, tca * cdp)) : fma(x1, s1_p, tca * cdp);
+#pragma unroll
+            for (int a_ = 0; a_ < D; a_++) {
+                const double nx = fma(dk, u[a_], c * tx[k][a_]);
+                tx[k][a_] = HAS_P2 ? fma(x1, s1_x[a_], nx) : nx;
+            }
+        }
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            o[(n++) * WAVE] = dp[k];
+#pragma unroll
+            for (int a = 0; a < D; a++) o[(n++) * WAVE] = tx[k][a];
+        }
+    }
 };
 
 template <int MODEL, int D, int KC>
 struct CvModel;
 template <int D, int KC>
-struct CvModel<M_CTCRW, D, KC> { typedef CvCtcrw<D, KC> Lane; typedef CtcrwTrans Trans; };
+struct CvModel<M_CTCRW, D, KC> { typedef CvPrimalCtcrw<D> Primal; typedef CvColsCtcrw<D, KC> Cols; };
 template <int D, int KC>
-struct CvModel<M_OU_SSM, D, KC> { typedef CvScal<D, KC, true> Lane; typedef ScalTrans Trans; };
+struct CvModel<M_OU_SSM, D, KC> { typedef CvPrimalScal<D, true> Primal; typedef CvColsScal<D, KC, true> Cols; };
 template <int D, int KC>
-struct CvModel<M_BM_SSM, D, KC> { typedef CvScal<D, KC, false> Lane; typedef ScalTrans Trans; };
+struct CvModel<M_BM_SSM, D, KC> { typedef CvPrimalScal<D, false> Primal; typedef CvColsScal<D, KC, false> Cols; };
 
-// components of a part's hand-over dump with kc column slots
+// components of a part's hand-over dump with kc column slots: the filter's block (written by part 0), then the columns
 int colvar_nstate(int model, int d, int kc) {
-    return model == M_CTCRW ? 2 * d + 5 + (kc + 1) * (3 + 2 * d) : d + 2 + (kc + 1) * (1 + d);
+    return model == M_CTCRW ? 2 * d + 5 + (3 + 2 * d) + kc * (3 + 2 * d) : d + 2 + (1 + d) + kc * (1 + d);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
-// One WORKGROUP per (64-track group, time window); its four waves are the four PARTS (the columns dealt to them), in step row
-// by row (one barrier per row), and they share three things through LDS:
-//   * the rows, staged ONCE for all four: wave w loads the channels c = w, w + 4, ... of a row into registers two rows ahead
-//     and stores them to the ring slot the next row is read from -- HBM is read once per row (8 (1 + d + K) bytes), and a
-//     wave holds a quarter of a row in flight instead of all of it;
-//   * the linear predictors p1 = log tau_i, p2 = log nu_i: every wave sums ITS channels' terms while they are still in
-//     registers (coefficients in scalar registers) and stores two partial sums per row;
-//   * the row's transition: the LAST wave adds the partial sums of the NEXT row, takes the exp's and builds T, Q, B and
-//     their log tau derivatives once (makeT/Q/B_ctcrw: nllk_ctcrw.hpp:45-91 through ctcrw_trans) into a two-slot ring; the
-//     engine deals that wave fewer columns.
-// accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]
+// accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]   (value, mu, sigma_obs: part 0)
 constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + WG_WAVES - 1) / WG_WAVES;   // channels a wave loads per row (dt, y, the streamed columns)
 constexpr int CV_CMAX = CV_LD * WG_WAVES;                               // channels of a staged row
 constexpr int CV_PRODUCER = WG_WAVES - 1;                               // the wave that builds the transitions
+constexpr int CV_FILTER = 0;                                            // the wave that runs the primal filter
 
-__device__ __forceinline__ double uniform_double(double x) {   // a wave-uniform value into scalar registers
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-
-template <int MODEL> struct CvTransIO;
-template <> struct CvTransIO<M_CTCRW> {
-    static constexpr int N = 12;
-    static __device__ __forceinline__ void put(double* o, const CtcrwTrans& t) {      // o[j * WAVE]
-        o[0 * WAVE] = t.e; o[1 * WAVE] = t.t12; o[2 * WAVE] = t.b1; o[3 * WAVE] = t.b2; o[4 * WAVE] = t.q11; o[5 * WAVE] = t.q12;
-        o[6 * WAVE] = t.q22; o[7 * WAVE] = t.de; o[8 * WAVE] = t.dt12; o[9 * WAVE] = t.dq11; o[10 * WAVE] = t.dq12; o[11 * WAVE] = t.dq22;
-    }
-    static __device__ __forceinline__ void get(const double* o, CtcrwTrans& t) {
-        t.e = o[0 * WAVE]; t.t12 = o[1 * WAVE]; t.b1 = o[2 * WAVE]; t.b2 = o[3 * WAVE]; t.q11 = o[4 * WAVE]; t.q12 = o[5 * WAVE];
-        t.q22 = o[6 * WAVE]; t.de = o[7 * WAVE]; t.dt12 = o[8 * WAVE]; t.dq11 = o[9 * WAVE]; t.dq12 = o[10 * WAVE]; t.dq22 = o[11 * WAVE];
-        t.e2 = t.e * t.e; t.dt12x2 = 2.0 * t.dt12; t.dt12e = t.dt12 * t.e; t.edex2 = 2.0 * t.e * t.de;      // as ctcrw_trans forms them
-    }
-};
-template <int MODEL> struct CvTransIO {                       // OU_SSM, BM_SSM
-    static constexpr int N = 6;
-    static __device__ __forceinline__ void put(double* o, const ScalTrans& t) {
-        o[0 * WAVE] = t.t; o[1 * WAVE] = t.b; o[2 * WAVE] = t.q; o[3 * WAVE] = t.dt_; o[4 * WAVE] = t.db; o[5 * WAVE] = t.dq;
-    }
-    static __device__ __forceinline__ void get(const double* o, ScalTrans& t) {
-        t.t = o[0 * WAVE]; t.b = o[1 * WAVE]; t.q = o[2 * WAVE]; t.dt_ = o[3 * WAVE]; t.db = o[4 * WAVE]; t.dq = o[5 * WAVE];
-    }
-};
-
-// KC: column slots per wave (the widest part's count, rounded up to even; the engine picks the instantiation)
+// KC: column slots per wave (even; the engine picks the instantiation from the widest part)
 template <int MODEL, int D, int KC>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
-    typedef typename CvModel<MODEL, D, KC>::Lane Lane;
-    typedef typename CvModel<MODEL, D, KC>::Trans Trans;
-    typedef CvTransIO<MODEL> TIO;
-    constexpr int SD = Lane::SD;
-    __shared__ double raw[2][CV_CMAX * WAVE];                  // the staged rows
+    typedef typename CvModel<MODEL, D, KC>::Primal Primal;
+    typedef typename CvModel<MODEL, D, KC>::Cols Cols;
+    typedef typename Primal::Trans Trans;
+    constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
+    __shared__ double raw[3][CV_CMAX * WAVE];                  // the staged rows
     __shared__ double eta[2][(2 * WG_WAVES + 1) * WAVE];       // per row: the four waves' partial sums of p1, p2, and the interval
-    __shared__ double trs[2][TIO::N * WAVE];                   // per row: the transition
+    __shared__ double trs[2][NTR * WAVE];                      // per row: the transition
+    __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
     __shared__ double coef[DRIFT_KMAX][2];
+    __shared__ double wcoef[WG_WAVES][CV_LD][2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: the part tables are read with scalar loads)
     const TileView& tv = A.tv;
@@ -385,33 +456,34 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         for (int k = 0; k < DRIFT_KMAX; k++) { coef[k][0] = A.coefA[k]; coef[k][1] = A.coefB[k]; }
     }
     __syncthreads();
-    // the channels this wave stages (past the last one: a design column again, with coefficient 0) and their coefficients
-    int lch[CV_LD];
+    // the channels this wave stages are c = part + 4 i; those that are design columns enter the linear predictors with their
+    // coefficients, re-packed per wave so that the staging code reads them with one broadcast LDS load per channel
     unsigned col_bits = 0;                                     // bit i: the wave's i-th channel is a design column
-    double cA[CV_LD], cB[CV_LD];
 #pragma unroll
     for (int i = 0; i < CV_LD; i++) {
-        const int c = part + WG_WAVES * i, k = c - c_col;
+        const int k = part + WG_WAVES * i - c_col;
         const bool on = k >= 0 && k < K;
         if (on) col_bits |= 1u << i;
-        lch[i] = c < C ? c : c_col;
-        cA[i] = uniform_double(on ? coef[on ? k : 0][0] : 0.0);
-        cB[i] = uniform_double(on ? coef[on ? k : 0][1] : 0.0);
+        if (lane == 0) { wcoef[part][i][0] = on ? coef[on ? k : 0][0] : 0.0; wcoef[part][i][1] = on ? coef[on ? k : 0][1] : 0.0; }
     }
-    const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- part 0 runs the primal filter alone)
+    const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- no tangents)
     const int n_col = grad ? parts[part].n_col : 0;
-    const bool with_mu = grad && parts[part].with_mu, with_sig = grad && parts[part].with_sig;
-    const bool active = part == 0 || n_col > 0 || with_mu || with_sig;     // (a part without work still stages its share of the rows)
+    const bool with_mu = grad && parts[CV_FILTER].with_mu, with_sig = grad && parts[CV_FILTER].with_sig;
+    // per slot: the channel to read and the factors that turn the value read into X1 = f1 x + o1 (the column's value if it feeds
+    // par[d], else 0) and X2 = f2 x + o2 (... par[d + 1]): (1, 0) a streamed column of that kind, (0, 1) a column of ones of that
+    // kind, (0, 0) otherwise -- wave-uniform numbers the column code reads from LDS (broadcast) instead of holding them in
+    // scalar registers, of which this kernel has none to spare
+    __shared__ double xfac[WG_WAVES][KC][4];
     int chan[KC];
-    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0;           // per slot: a column of ones / feeds par[d] / feeds par[d + 1]
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const bool on = k < n_col;
         const int ch = on ? parts[part].chan[k] : -2, ty = on ? parts[part].type[k] : 0;
         chan[k] = ch >= 0 ? ch : c_col;                        // (an unused slot reads a design column and weighs it with 0)
-        if (ch == -1) ones_bits |= 1u << k;
-        if (ty == 1) t1_bits |= 1u << k;
-        if (ty == 2) t2_bits |= 1u << k;
+        if (lane == 0) {
+            xfac[part][k][0] = (ty == 1 && ch >= 0) ? 1.0 : 0.0; xfac[part][k][1] = (ty == 1 && ch == -1) ? 1.0 : 0.0;
+            xfac[part][k][2] = (ty == 2 && ch >= 0) ? 1.0 : 0.0; xfac[part][k][3] = (ty == 2 && ch == -1) ? 1.0 : 0.0;
+        }
     }
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -419,14 +491,17 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     int s_begin, s_acc, s_end;
     window_bounds(L, A.n_chunks, A.window, 0, chunk, s_begin, s_acc, s_end, 0);
     const int pc = part * A.n_chunks + chunk;
+    double* const dump0 = A.bnd + (((int64_t)pc * G + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
+    double* const dump1 = A.bnd + (((int64_t)pc * G + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+    const bool last_chunk = !(A.n_chunks > 1 && chunk + 1 < A.n_chunks);
 
     double setA[CV_LD], setB[CV_LD];
     auto ld = [&](double (&dst)[CV_LD], int s) {               // this wave's channels of row s: HBM -> registers
         const double* p = base + (int64_t)s * C * WAVE;
 #pragma unroll
-        for (int i = 0; i < CV_LD; i++) dst[i] = p[lch[i] * WAVE];
+        for (int i = 0; i < CV_LD; i++) dst[i] = p[(part + WG_WAVES * i) * WAVE];     // (past the last channel: the next row's first ones -- staged, never used)
     };
-    auto st_raw = [&](const double (&src)[CV_LD], int slot) {  // registers -> the ring of rows (a channel past the last: written, never read)
+    auto st_raw = [&](const double (&src)[CV_LD], int slot) {  // registers -> the ring of rows
 #pragma unroll
         for (int i = 0; i < CV_LD; i++) raw[slot][(part + WG_WAVES * i) * WAVE + lane] = src[i];
     };
@@ -435,15 +510,14 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
 #pragma unroll
         for (int i = 0; i < CV_LD; i++) {
             const double xs = ((col_bits >> i) & 1u) ? src[i] : 0.0;      // (an observation may be NaN: 0 * NaN is not 0)
-            pa = fma(cA[i], xs, pa);
-            if (MODEL != M_BM_SSM) pb = fma(cB[i], xs, pb);
+            pa = fma(wcoef[part][i][0], xs, pa);
+            if (MODEL != M_BM_SSM) pb = fma(wcoef[part][i][1], xs, pb);
         }
         eta[slot][(2 * part) * WAVE + lane] = pa;
         eta[slot][(2 * part + 1) * WAVE + lane] = pb;
         if (part == 0) eta[slot][(2 * WG_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
-    auto produce = [&](int slot) {                             // the last wave: the transition of the row whose sums sit in eta[slot]
-        if (part != CV_PRODUCER) return;
+    auto produce = [&](int slot) {                             // stage 1: the transition of the row whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
@@ -451,13 +525,13 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         const double dtc = e_[(2 * WG_WAVES) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
-        Lane::trans(dt, p1, p2, tr);
-        TIO::put(&trs[slot][lane], tr);
+        Primal::trans(dt, p1, p2, tr);
+        Primal::put_trans(&trs[slot][lane], tr);
     };
-    ld(setA, s_begin);
-    ld(setB, s_begin + 1);
-    Lane S;
-    {
+    Primal F;                                                  // (wave 0 only)
+    Cols S;
+    S.init();
+    if (part == CV_FILTER) {
         double a0[SD];
         if (s_begin == 0) {
 #pragma unroll
@@ -470,73 +544,81 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
                 else a0[a] = (y0 == y0) ? y0 : 0.0;
             }
         }
-        S.init(a0, A.p0);
+        F.init(a0, A.p0);
     }
     double mu[D];
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
     const double h = A.h;
-    auto row = [&](int slot, int s) {
-        if (!active) return;
-        if (s == s_acc && s_acc > s_begin) {
-            S.dump_to(A.bnd + (((int64_t)pc * G + g) * 2 + 0) * A.bnd_stride * WAVE + lane);
-            S.reset_acc();
-        }
+    auto filter = [&](int s, int slot3, int slot2) {           // stage 2 (wave 0): row s -- its y in raw[slot3], its transition in trs[slot2]
+        if (s == s_acc && s_acc > s_begin) { F.dump_to(dump0); F.reset_acc(); }
+        double* lo = &lin[slot2][lane];
         if (s < ns) {
-            const double* r = &raw[slot][lane];
+            const double* r = &raw[slot3][lane];
             double y[D];
 #pragma unroll
             for (int a = 0; a < D; a++) y[a] = r[(c_obs + a) * WAVE];
             Trans tr;
-            TIO::get(&trs[slot][lane], tr);
-            double X1[KC], X2[KC];
+            Primal::get_trans(&trs[slot2][lane], tr);
+            F.step(tr, h, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
+        }
+        if (s == s_end - 1 && !last_chunk) F.dump_to(dump1);
+    };
+    auto columns = [&](int s, int slot3, int slot2) {          // stage 3: the tangents of row s
+        if (s == s_acc && s_acc > s_begin) { S.dump_to(dump0 + NPD * WAVE); S.reset_acc(); }
+        if (s < ns) {
+            const double* r = &raw[slot3][lane];
+            typename Cols::Lin li;
+            li.read(&lin[slot2][lane]);
+            auto quarter = [&](auto k0) {                          // (a wave that also runs a stage is dealt fewer slots: whole quarters are skipped)
+                constexpr int K0 = decltype(k0)::value, K1 = K0 + (KC + 3) / 4 < KC ? K0 + (KC + 3) / 4 : KC;
+                double X1[KC], X2[KC];
 #pragma unroll
-            for (int k = 0; k < KC; k++) {
-                const double xl = r[chan[k] * WAVE];
-                const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
-                X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
-            }
-            S.step(tr, h, mu, y, is_na(y[0], A.any_nan), X1, X2, with_sig, with_mu);
+                for (int k = K0; k < K1; k++) {
+                    const double xl = r[chan[k] * WAVE];
+                    X1[k] = fma(xfac[part][k][0], xl, xfac[part][k][1]);
+                    X2[k] = fma(xfac[part][k][2], xl, xfac[part][k][3]);
+                }
+                S.template step<K0, K1>(li, X1, X2);
+            };
+            constexpr int Q = (KC + 3) / 4;
+            if (n_col > 0) quarter(std::integral_constant<int, 0>());
+            if (Q < KC && n_col > Q) quarter(std::integral_constant<int, (Q < KC ? Q : 0)>());
+            if (2 * Q < KC && n_col > 2 * Q) quarter(std::integral_constant<int, (2 * Q < KC ? 2 * Q : 0)>());
+            if (3 * Q < KC && n_col > 3 * Q) quarter(std::integral_constant<int, (3 * Q < KC ? 3 * Q : 0)>());
         }
     };
 #ifdef SSDE_CV_CLOCK
-    // (tuning build: where a wave's cycles go -- staging, the transition, the row, the barrier)
+    // (tuning build: where a wave's cycles go -- staging, the transition / the filter, the columns, the barrier)
     long long ck[4] = {0, 0, 0, 0};
     long long t_ = __builtin_amdgcn_s_memtime();
 #define SSDE_CK(i) { const long long n_ = __builtin_amdgcn_s_memtime(); ck[i] += n_ - t_; t_ = n_; }
 #else
 #define SSDE_CK(i)
 #endif
-    // (window bounds are multiples of WIN_ALIGN: row s lives in slot s & 1 of every ring)
-    st_eta(setA, 0);                                           // row s_begin
-    __syncthreads();
-    st_raw(setA, 0);
-    st_eta(setB, 1);                                           // row s_begin + 1
-    ld(setA, s_begin + 2);
-    produce(0);
-    __syncthreads();
-    for (int s = s_begin; s < s_end; s += 2) {
-        // setB holds row s + 1, setA row s + 2
-        st_raw(setB, 1);                                       // (slot 1 was last read for row s - 1, before the barrier)
-        st_eta(setA, 0);                                       // row s + 2 (slot 0 was last read by the producer for row s, before the barrier)
-        ld(setB, s + 3);                                       // (issued AFTER the stores: they wait for loads one and two rows old, not for these)
+    // Iteration t: rows t + 2 (-> ring of rows) and t + 3 (-> partial predictors) leave the registers, row t + 4 is requested;
+    // the transition of row t + 2, the filter on row t + 1, the columns of row t.  X holds row t + 2, Y row t + 3.
+    int r3 = 0;                                                // (t + 3 - s_begin) mod 3 == the ring slot of row t
+    auto iter = [&](int t, double (&X)[CV_LD], double (&Y)[CV_LD]) {
+        const int sl_t = r3, sl_t1 = r3 == 2 ? 0 : r3 + 1, sl_t2 = r3 == 0 ? 2 : r3 - 1;   // slots of rows t, t + 1, t + 2 (t + 2 == t - 1 mod 3)
+        if (t + 2 >= s_begin) st_raw(X, sl_t2);
+        st_eta(Y, (t + 3) & 1);
+        ld(X, t + 4);
         SSDE_CK(0)
-        produce(1);                                            // row s + 1
+        if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1);
+        if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
         SSDE_CK(1)
-        row(0, s);
+        if (t >= s_begin) columns(t, sl_t, t & 1);
         SSDE_CK(2)
         __syncthreads();
         SSDE_CK(3)
-        st_raw(setA, 0);                                       // row s + 2
-        st_eta(setB, 1);                                       // row s + 3
-        ld(setA, s + 4);
-        SSDE_CK(0)
-        produce(0);                                            // row s + 2
-        SSDE_CK(1)
-        row(1, s + 1);
-        SSDE_CK(2)
-        __syncthreads();
-        SSDE_CK(3)
+        r3 = r3 == 2 ? 0 : r3 + 1;
+    };
+    ld(setB, s_begin);                                         // Y of the first iteration (t = s_begin - 3): row s_begin
+    iter(s_begin - 3, setA, setB);
+    for (int t = s_begin - 2; t < s_end; t += 2) {             // (s_end - s_begin is a multiple of WIN_ALIGN: an even count)
+        iter(t, setB, setA);
+        iter(t + 1, setA, setB);
     }
 #ifdef SSDE_CV_CLOCK
     if (A.wave_clock && lane == 0) {
@@ -544,11 +626,11 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         for (int i = 0; i < 4; i++) o[i] = (double)ck[i] / (double)(s_end - s_begin);
     }
 #endif
-    if (active && A.n_chunks > 1 && chunk + 1 < A.n_chunks)
-        S.dump_to(A.bnd + (((int64_t)pc * G + g) * 2 + 1) * A.bnd_stride * WAVE + lane);
-    const bool empty = s_acc >= s_end || !active;
+    if (!last_chunk) S.dump_to(dump1 + NPD * WAVE);
+    const bool empty = s_acc >= s_end;
+    const bool filt = part == CV_FILTER;
     {
-        const double t = wave_sum(empty ? 0.0 : S.value());
+        const double t = wave_sum((empty || !filt) ? 0.0 : F.value());
         if (lane == 0) A.partials[((int64_t)pc * nacc + 0) * G + g] = t;
     }
 #pragma unroll
@@ -558,11 +640,11 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     }
 #pragma unroll
     for (int a = 0; a < D; a++) {
-        const double t = wave_sum(empty ? 0.0 : S.gmu[a]);
+        const double t = wave_sum((empty || !filt) ? 0.0 : F.gmu[a]);
         if (lane == 0) A.partials[((int64_t)pc * nacc + 1 + CV_KC + a) * G + g] = t;
     }
     {
-        const double t = wave_sum(empty ? 0.0 : S.g[KC]);
+        const double t = wave_sum((empty || !filt) ? 0.0 : F.sg);
         if (lane == 0) A.partials[((int64_t)pc * nacc + 1 + CV_KC + D) * G + g] = t;
     }
 }

@@ -146,37 +146,49 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         std::vector<CvPart> parts(WG_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * WG_WAVES);
         h->cv_pidx.assign((size_t)WG_WAVES * CV_KC, -1);
-        // A wave's row costs, in fp64 instructions (counted: profiles/r03_colvar_*): the primal filter if it carries anything, so
-        // much per column, and -- the last wave -- the exp's and the transition it builds for all four.  Every column goes to
-        // the wave that is cheapest with it.
+        // What a wave's row costs, in fp64 instructions: so much per column SLOT it computes -- the column loop is straight-line
+        // code in four blocks of slots, a block runs if the wave has a column in it --, the filter and the directions it
+        // carries on wave 0, the exp's and the transition on the last wave.  Pick the slot count kc (2, 4, 6, 8: the kernel's
+        // instantiations) and the columns per wave that make the slowest wave fastest.
         const bool ct = h->model == SSDE_MODEL_CTCRW;
-        const double c_primal = ct ? 140.0 : 50.0, c_col_ = ct ? (h->d == 2 ? 48.0 : 34.0) : 12.0 + 3.0 * h->d, c_trans = ct ? 330.0 : 120.0;
-        double cost[WG_WAVES];
-        for (int p = 0; p < WG_WAVES; p++) cost[p] = (p == 0 ? c_primal : 0.0) + (p == WG_WAVES - 1 ? c_trans : 0.0);
-        auto idle = [&](int p) { return p != 0 && parts[p].n_col == 0 && !parts[p].with_mu && !parts[p].with_sig; };
-        auto cost_with = [&](int p) { return cost[p] + c_col_ + (idle(p) ? c_primal : 0.0); };
-        auto cheapest = [&](bool need_slot) {
-            int best = -1;
-            for (int p = 0; p < WG_WAVES; p++)
-                if ((!need_slot || parts[p].n_col < CV_KC) && (best < 0 || cost_with(p) < cost_with(best))) best = p;
-            return best;
-        };
-        for (size_t i = 0; i < cols.size(); i++) {
-            const int best = cheapest(true);
-            CvPart& P = parts[best];
-            cost[best] = cost_with(best);
-            const int k = P.n_col++;
-            P.chan[k] = cols[i].chan; P.type[k] = cols[i].type;
-            h->cv_pidx[(size_t)best * CV_KC + k] = cols[i].pidx;
+        const double c_slot = ct ? (h->d == 2 ? 48.0 : 34.0) : 10.0 + 4.0 * h->d, c_filter = ct ? 300.0 : 120.0, c_trans = ct ? 360.0 : 150.0;
+        const int N = (int)cols.size();
+        int best_n[WG_WAVES] = {0, 0, 0, 0}, best_kc = 2;
+        double best_cost = INFINITY;
+        for (int kc = 2; kc <= CV_KC; kc += 2) {
+            const int q = (kc + 3) / 4;
+            auto slots = [&](int n) { return std::min(kc, (n + q - 1) / q * q); };
+            for (int n0 = 0; n0 <= kc; n0++)
+                for (int n3 = 0; n3 <= kc; n3++) {
+                    const int rest = N - n0 - n3;
+                    if (rest < 0 || rest > 2 * kc) continue;
+                    const int n1 = (rest + 1) / 2, n2 = rest / 2;
+                    const double c = std::max(std::max(c_filter + c_slot * slots(n0), c_slot * slots(n1)), std::max(c_slot * slots(n2), c_trans + c_slot * slots(n3)));
+                    if (c < best_cost - 1e-9) { best_cost = c; best_kc = kc; best_n[0] = n0; best_n[1] = n1; best_n[2] = n2; best_n[3] = n3; }
+                }
         }
+        if (const char* e = getenv("SSDE_CV_DEAL")) {              // testing: "n0,n1,n2,n3"
+            int v[4];
+            if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] + v[1] + v[2] + v[3] == N) {
+                best_kc = 2;
+                for (int p = 0; p < 4; p++) { best_n[p] = std::min(std::max(v[p], 0), CV_KC); best_kc = std::max(best_kc, (best_n[p] + 1) / 2 * 2); }
+            }
+        }
+        {
+            size_t i = 0;
+            for (int p = 0; p < WG_WAVES; p++)
+                for (int k = 0; k < best_n[p] && i < cols.size(); k++, i++) {
+                    parts[p].chan[k] = cols[i].chan; parts[p].type[k] = cols[i].type; parts[p].n_col = k + 1;
+                    h->cv_pidx[(size_t)p * CV_KC + k] = cols[i].pidx;
+                }
+            if (i != cols.size()) return fail(h, SSDE_ERR_ARG, "internal: the design columns were not all dealt");
+        }
+        // the log sigma_obs and drift-intercept directions ride on the wave that runs the filter
         h->cv_sig_part = h->cv_mu_part = -1;
-        if (!h->fixed[0]) { const int p = cheapest(false); cost[p] = cost_with(p); parts[p].with_sig = 1; h->cv_sig_part = p; }
-        bool mu_free = false;
+        if (!h->fixed[0]) { parts[0].with_sig = 1; h->cv_sig_part = 0; }
         for (auto& sl : h->slots)
-            if (sl.par_j < h->d && !h->fixed[sl.pidx]) mu_free = true;
-        if (mu_free) { const int p = cheapest(false); parts[p].with_mu = 1; h->cv_mu_part = p; }
-        h->cv_kc = 0;
-        for (int p = 0; p < WG_WAVES; p++) h->cv_kc = std::max(h->cv_kc, (int)parts[p].n_col);
+            if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
+        h->cv_kc = best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
         {
             // the range of every streamed column over the batch
@@ -197,7 +209,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = colvar_nstate(h->model, h->d, (std::max(h->cv_kc, 1) + 1) / 2 * 2);      // (the kernel is instantiated for 2, 4, 6, 8 slots)
+        h->drift_nstate = colvar_nstate(h->model, h->d, h->cv_kc);
     } else
     if (h->drift) {
         // regular grid and every track complete: the shared-covariance lanes; otherwise the lanes carry their own covariance
@@ -283,6 +295,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     }
     HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
+    if (h->drift == 3) HIPCHK(h, hipMemset(h->bnd.p, 0, h->bnd.n * 8));      // (a part dumps its own block of a hand-over record; the check reads all of it)
     h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
     h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
     return SSDE_OK;
