@@ -335,6 +335,51 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
             "rows_tiled": inf["n_rows_tiled"], "groups": inf["n_groups"], "clean_groups": inf["n_clean_groups"]}
 
 
+def row_varying_workload(M, T, dev, steps, k_cols=9):
+    """1e4 CTCRW tracks with tau AND nu smooth in a covariate (2 x 9 design columns streamed next to the observations): the
+    batch-scale form of BASELINE's config 1 (nllk_ctcrw.hpp:143-156), on the lane = track kernel with one filter tangent per
+    design column (k_iso_colvar.hip).  Hat-function basis of a per-row covariate, built on the device."""
+    import torch
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import second_difference_penalty
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=342, device=dev)
+    n = M * T
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    i = torch.arange(n, device=dev, dtype=torch.float64)
+    u = (0.5 + 0.4 * torch.sin(i * (2 * np.pi / 24)) + 0.03 * torch.randn(n, device=dev, dtype=torch.float64, generator=gen)).clamp_(0.0, 1.0)
+    knots = torch.arange(k_cols, device=dev, dtype=torch.float64)
+    B = (1.0 - (u[:, None] * (k_cols - 1) - knots[None, :]).abs()).clamp_(min=0.0)       # (n, k): a partition of unity
+    del i, u
+    S = second_difference_penalty(k_cols)
+    fixed = np.r_[0, 1, 1, 0, 0, 1, 1, np.zeros(2 * k_cols)].astype(np.uint8)            # mu and the smoothing parameters held
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), X_re=[None, None, B, B], S_list=[S, S], par_fixed=fixed))
+    del ID, times, obs, B
+    npar = 7 + 2 * k_cols
+    def theta(k):
+        return np.ascontiguousarray(np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(2 * k_cols))] + 1e-3 * np.sin(k + np.arange(npar)))
+    for k in range(2):
+        eng.eval(theta(-1 - k))
+    ssde_eval = eng.bound_eval(order=1)
+    ths = [theta(k) for k in range(steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kms = []
+    for k in range(steps):
+        ssde_eval(ths[k])
+        kms.append(eng.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    inf = eng.info()
+    eng.close()
+    kern = float(np.mean(kms))
+    return {"workload": f"{M} CTCRW x {T}, tau and nu smooth in a covariate ({2 * k_cols} design columns streamed), regular grid",
+            "value": inf["n_rows"] * steps / el, "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]], "required_bytes_per_row": inf["required_bytes_per_row"],
+            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,6 +673,7 @@ def main():
             sec.append(secondary_workload(f"{M} CTCRW x {T} slots of a regular schedule, 5 % of the fixes absent from the data "
                                           f"(intervals of 1-4 steps; laid out on the lattice at create)", "CTCRW", M, T, dev,
                                           max(3, args.steps // 2), absent))
+            sec.append(row_varying_workload(M, max(16, T // 10), dev, max(3, args.steps // 2)))
         except Exception as e:  # the secondary numbers must never take the bench line down
             sec.append({"workload": "failed", "error": str(e)})
         line["secondary"] = sec

@@ -12,23 +12,27 @@
 // (T, Q, B, H) with respect to log tau (t = 1), log nu / kappa (t = 2) or log sigma_obs (t = 0) at THIS row's parameters.
 // 3 + 2 d doubles of state and ~45 fp64 instructions per column and row (CTCRW, d = 2).
 //
-// One WORKGROUP per (64-track group, time window).  Its four waves form a three-stage pipeline over the rows, one barrier per
-// row, everything between the stages in LDS rings:
-//   stage 0, every wave:  loads a quarter of the channels of the row four ahead (HBM is read ONCE per row: 8 (1 + d + K)
+// One WORKGROUP of EIGHT waves (two per SIMD) per (64-track group, time window).  The waves form a pipeline over the rows, one
+// barrier per row, everything between the stages in LDS rings:
+//   stage 0, every wave:  loads an eighth of the channels of the row four ahead (HBM is read ONCE per row: 8 (1 + d + K)
 //                         bytes), stores the row two ahead to the ring of rows, and adds ITS channels' terms of the linear
 //                         predictors p1 = log tau_i, p2 = log nu_i of the row three ahead (two partial sums per wave and row);
 //   stage 1, the last wave:  for the row two ahead, sums the partial predictors, takes the exp's and builds T, Q, B and their
 //                         log tau derivatives (makeT/Q/B_ctcrw: nllk_ctcrw.hpp:45-91 through ctcrw_trans);
 //   stage 2, wave 0:      the primal filter of the NEXT row (gains, residuals, state, covariance, likelihood terms; the
 //                         log sigma_obs and drift-intercept directions), and the row's LINEARISATION: the nine numbers of
-//                         Lin_i, the residuals and the seed vectors -- 15 + 3 d doubles per lane;
+//                         Lin_i, the residuals and the seed vectors -- 15 + 3 d doubles per lane.  Its state lives in LDS
+//                         between rows: held in registers it would take ~45 of EVERY wave's 256 (a kernel's allocation is the
+//                         union of its waves' roles);
 //   stage 3, every wave:  the column tangents of the current row from the linearisation -- straight-line code, what a column
-//                         feeds is a pair of 0/1 factors on its value, not a branch -- for the columns dealt to the wave.
-// The engine deals the columns by cost: the waves that also run a stage get fewer.  A wave's registers hold its columns'
-// state and little else: the transition lives in the last wave, the filter in wave 0.
-// (Measured on the way here, 1e4 tracks x 1e3 rows, 18 columns: every wave running the primal filter + a uniform branch per
-// column and type 2.06 ms; straight-line columns + a transition wave 1.54 ms -- more than half of its VALU instructions were
-// register-file overflow traffic, v_accvgpr / v_readlane moves.)
+//                         feeds is a pair of 0/1 factors on its value, not a branch -- for the up to CV_KC columns dealt to it.
+// The engine deals the columns by cost: waves w and w + 4 share a SIMD, the SIMDs of the two stage waves get fewer.  A wave's
+// registers hold its columns' state and little else, so two waves fit a SIMD and cover each other's LDS / barrier waits.
+// Measured on the way here (1e4 tracks x 1e3 rows, 18 columns; lane = direction path 3.70 ms):
+//   four waves, each running the primal filter, a uniform branch per column and type             2.06 ms  (the branches: 2100 of 4600 cycles per row)
+//   ... straight-line columns, a transition wave                                                 1.54 ms  (> half of the VALU instructions v_accvgpr / v_readlane moves)
+//   ... + a filter wave handing the linearisation on, columns in four blocks                      1.36 ms
+//   eight waves (two per SIMD, 256 registers each), filter state parked in LDS                    1.26 ms
 // Windows, warm-up and the verified hand-over as in k_iso.hip.  Layout: the tiles of ssde_device.hpp with the design
 // columns as further channels (as k_iso_drift.hip).
 #include <type_traits>
@@ -154,6 +158,23 @@ struct CvPrimalCtcrw {
         o[(n++) * WAVE] = s11; o[(n++) * WAVE] = s12; o[(n++) * WAVE] = s22;
 #pragma unroll
         for (int a = 0; a < D; a++) { o[(n++) * WAVE] = stx[a]; o[(n++) * WAVE] = stv[a]; }
+    }
+    static constexpr int NSAVE = SD + 3 + 2 + 1 + 2 + D + NCOL + 1;
+    __device__ __forceinline__ void save(double* o) const {          // o[k * WAVE]: everything, accumulators included
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[(n++) * WAVE] = x[a]; o[(n++) * WAVE] = v[a]; o[(n++) * WAVE] = gmu[a]; o[(n++) * WAVE] = stx[a]; o[(n++) * WAVE] = stv[a]; }
+        o[(n++) * WAVE] = p11; o[(n++) * WAVE] = p12; o[(n++) * WAVE] = p22; o[(n++) * WAVE] = mx; o[(n++) * WAVE] = mv;
+        o[(n++) * WAVE] = accq; o[(n++) * WAVE] = ld.m; o[(n++) * WAVE] = (double)ld.e;
+        o[(n++) * WAVE] = s11; o[(n++) * WAVE] = s12; o[(n++) * WAVE] = s22; o[(n++) * WAVE] = sg;
+    }
+    __device__ __forceinline__ void restore(const double* o) {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { x[a] = o[(n++) * WAVE]; v[a] = o[(n++) * WAVE]; gmu[a] = o[(n++) * WAVE]; stx[a] = o[(n++) * WAVE]; stv[a] = o[(n++) * WAVE]; }
+        p11 = o[(n++) * WAVE]; p12 = o[(n++) * WAVE]; p22 = o[(n++) * WAVE]; mx = o[(n++) * WAVE]; mv = o[(n++) * WAVE];
+        accq = o[(n++) * WAVE]; ld.m = o[(n++) * WAVE]; ld.e = (int)o[(n++) * WAVE];
+        s11 = o[(n++) * WAVE]; s12 = o[(n++) * WAVE]; s22 = o[(n++) * WAVE]; sg = o[(n++) * WAVE];
     }
     __device__ __forceinline__ double value() const { return 0.5 * ((double)D * ld.value() + accq); }
     // this row's transition from the linear predictors p1 = log tau, p2 = log nu (nllk_ctcrw.hpp:152-156)
@@ -335,6 +356,21 @@ struct CvPrimalScal {
 #pragma unroll
         for (int a = 0; a < D; a++) o[(n++) * WAVE] = stx[a];
     }
+    static constexpr int NSAVE = 3 * D + 1 + 1 + 1 + 2 + 2;
+    __device__ __forceinline__ void save(double* o) const {          // o[k * WAVE]: everything, accumulators included
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { o[(n++) * WAVE] = x[a]; o[(n++) * WAVE] = gmu[a]; o[(n++) * WAVE] = stx[a]; }
+        o[(n++) * WAVE] = p; o[(n++) * WAVE] = mx; o[(n++) * WAVE] = accq; o[(n++) * WAVE] = ld.m; o[(n++) * WAVE] = (double)ld.e;
+        o[(n++) * WAVE] = sp; o[(n++) * WAVE] = sg;
+    }
+    __device__ __forceinline__ void restore(const double* o) {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { x[a] = o[(n++) * WAVE]; gmu[a] = o[(n++) * WAVE]; stx[a] = o[(n++) * WAVE]; }
+        p = o[(n++) * WAVE]; mx = o[(n++) * WAVE]; accq = o[(n++) * WAVE]; ld.m = o[(n++) * WAVE]; ld.e = (int)o[(n++) * WAVE];
+        sp = o[(n++) * WAVE]; sg = o[(n++) * WAVE];
+    }
     __device__ __forceinline__ double value() const { return 0.5 * ((double)D * ld.value() + accq); }
     static __device__ __forceinline__ void trans(double dt, double p1, double p2, ScalTrans& tr) {
         if constexpr (HAS_P2) ou_trans(dt, exp(p1), exp(p2), tr);     // nllk_ou_ssm.hpp:121-124
@@ -426,24 +462,25 @@ int colvar_nstate(int model, int d, int kc) {
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
 // accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]   (value, mu, sigma_obs: part 0)
-constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + WG_WAVES - 1) / WG_WAVES;   // channels a wave loads per row (dt, y, the streamed columns)
-constexpr int CV_CMAX = CV_LD * WG_WAVES;                               // channels of a staged row
-constexpr int CV_PRODUCER = WG_WAVES - 1;                               // the wave that builds the transitions
+constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + CV_WAVES - 1) / CV_WAVES;   // channels a wave loads per row (dt, y, the streamed columns)
+constexpr int CV_CMAX = CV_LD * CV_WAVES;                               // channels of a staged row
+constexpr int CV_PRODUCER = CV_WAVES - 1;                               // the wave that builds the transitions
 constexpr int CV_FILTER = 0;                                            // the wave that runs the primal filter
 
 // KC: column slots per wave (even; the engine picks the instantiation from the widest part)
 template <int MODEL, int D, int KC>
-__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
+__global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
     typedef typename CvModel<MODEL, D, KC>::Primal Primal;
     typedef typename CvModel<MODEL, D, KC>::Cols Cols;
     typedef typename Primal::Trans Trans;
     constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
     __shared__ double raw[3][CV_CMAX * WAVE];                  // the staged rows
-    __shared__ double eta[2][(2 * WG_WAVES + 1) * WAVE];       // per row: the four waves' partial sums of p1, p2, and the interval
+    __shared__ double eta[2][(2 * CV_WAVES + 1) * WAVE];       // per row: the four waves' partial sums of p1, p2, and the interval
     __shared__ double trs[2][NTR * WAVE];                      // per row: the transition
     __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
+    __shared__ double fst[Primal::NSAVE * WAVE];               // the filter's state between rows (wave 0; see below)
     __shared__ double coef[DRIFT_KMAX][2];
-    __shared__ double wcoef[WG_WAVES][CV_LD][2];
+    __shared__ double wcoef[CV_WAVES][CV_LD][2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: the part tables are read with scalar loads)
     const TileView& tv = A.tv;
@@ -461,7 +498,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     unsigned col_bits = 0;                                     // bit i: the wave's i-th channel is a design column
 #pragma unroll
     for (int i = 0; i < CV_LD; i++) {
-        const int k = part + WG_WAVES * i - c_col;
+        const int k = part + CV_WAVES * i - c_col;
         const bool on = k >= 0 && k < K;
         if (on) col_bits |= 1u << i;
         if (lane == 0) { wcoef[part][i][0] = on ? coef[on ? k : 0][0] : 0.0; wcoef[part][i][1] = on ? coef[on ? k : 0][1] : 0.0; }
@@ -473,7 +510,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     // par[d], else 0) and X2 = f2 x + o2 (... par[d + 1]): (1, 0) a streamed column of that kind, (0, 1) a column of ones of that
     // kind, (0, 0) otherwise -- wave-uniform numbers the column code reads from LDS (broadcast) instead of holding them in
     // scalar registers, of which this kernel has none to spare
-    __shared__ double xfac[WG_WAVES][KC][4];
+    __shared__ double xfac[CV_WAVES][KC][4];
     int chan[KC];
 #pragma unroll
     for (int k = 0; k < KC; k++) {
@@ -496,14 +533,19 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     const bool last_chunk = !(A.n_chunks > 1 && chunk + 1 < A.n_chunks);
 
     double setA[CV_LD], setB[CV_LD];
-    auto ld = [&](double (&dst)[CV_LD], int s) {               // this wave's channels of row s: HBM -> registers
-        const double* p = base + (int64_t)s * C * WAVE;
+    // (a uniform row pointer + a 32-bit lane offset per channel: scalar-base addressing, the row advance is scalar arithmetic)
+    const double* const gbase = tv.tiles + tv.group_off[g];
+    unsigned voff[CV_LD];
 #pragma unroll
-        for (int i = 0; i < CV_LD; i++) dst[i] = p[(part + WG_WAVES * i) * WAVE];     // (past the last channel: the next row's first ones -- staged, never used)
+    for (int i = 0; i < CV_LD; i++) voff[i] = (unsigned)((part + CV_WAVES * i) * WAVE + lane);
+    auto ld = [&](double (&dst)[CV_LD], int s) {               // this wave's channels of row s: HBM -> registers
+        const double* rowp = gbase + (int64_t)s * C * WAVE;
+#pragma unroll
+        for (int i = 0; i < CV_LD; i++) dst[i] = rowp[voff[i]];       // (past the last channel: the next row's first ones -- staged, never used)
     };
     auto st_raw = [&](const double (&src)[CV_LD], int slot) {  // registers -> the ring of rows
 #pragma unroll
-        for (int i = 0; i < CV_LD; i++) raw[slot][(part + WG_WAVES * i) * WAVE + lane] = src[i];
+        for (int i = 0; i < CV_LD; i++) raw[slot][(part + CV_WAVES * i) * WAVE + lane] = src[i];
     };
     auto st_eta = [&](const double (&src)[CV_LD], int slot) {  // this wave's terms of the row's linear predictors
         double pa = 0.0, pb = 0.0;
@@ -515,23 +557,25 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         }
         eta[slot][(2 * part) * WAVE + lane] = pa;
         eta[slot][(2 * part + 1) * WAVE + lane] = pb;
-        if (part == 0) eta[slot][(2 * WG_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
+        if (part == 0) eta[slot][(2 * CV_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
     auto produce = [&](int slot) {                             // stage 1: the transition of the row whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
-        for (int w = 0; w < WG_WAVES; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
-        const double dtc = e_[(2 * WG_WAVES) * WAVE];
+        for (int w = 0; w < CV_WAVES; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
+        const double dtc = e_[(2 * CV_WAVES) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
         Primal::trans(dt, p1, p2, tr);
         Primal::put_trans(&trs[slot][lane], tr);
     };
-    Primal F;                                                  // (wave 0 only)
+    // The filter's state lives in LDS between rows: only wave 0 ever touches it, and held in registers across the row loop it
+    // would take ~45 of every wave's 256 (a kernel's allocation is the union of its waves' roles)
     Cols S;
     S.init();
     if (part == CV_FILTER) {
+        Primal F;
         double a0[SD];
         if (s_begin == 0) {
 #pragma unroll
@@ -545,12 +589,15 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
             }
         }
         F.init(a0, A.p0);
+        F.save(&fst[lane]);
     }
     double mu[D];
 #pragma unroll
     for (int a = 0; a < D; a++) mu[a] = A.mu[a];
     const double h = A.h;
     auto filter = [&](int s, int slot3, int slot2) {           // stage 2 (wave 0): row s -- its y in raw[slot3], its transition in trs[slot2]
+        Primal F;
+        F.restore(&fst[lane]);
         if (s == s_acc && s_acc > s_begin) { F.dump_to(dump0); F.reset_acc(); }
         double* lo = &lin[slot2][lane];
         if (s < ns) {
@@ -563,6 +610,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
             F.step(tr, h, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
         }
         if (s == s_end - 1 && !last_chunk) F.dump_to(dump1);
+        F.save(&fst[lane]);
     };
     auto columns = [&](int s, int slot3, int slot2) {          // stage 3: the tangents of row s
         if (s == s_acc && s_acc > s_begin) { S.dump_to(dump0 + NPD * WAVE); S.reset_acc(); }
@@ -605,6 +653,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
         st_eta(Y, (t + 3) & 1);
         ld(X, t + 4);
         SSDE_CK(0)
+        // (raising the two stage waves' priority over the column waves they share a SIMD with, s_setprio, changed nothing: 1.264 / 1.260 ms)
         if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1);
         if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
         SSDE_CK(1)
@@ -622,13 +671,15 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_colvar_kernel(const Is
     }
 #ifdef SSDE_CV_CLOCK
     if (A.wave_clock && lane == 0) {
-        double* o = A.wave_clock + 4 * ((int64_t)blockIdx.x * WG_WAVES + part);
+        double* o = A.wave_clock + 4 * ((int64_t)blockIdx.x * CV_WAVES + part);
         for (int i = 0; i < 4; i++) o[i] = (double)ck[i] / (double)(s_end - s_begin);
     }
 #endif
     if (!last_chunk) S.dump_to(dump1 + NPD * WAVE);
     const bool empty = s_acc >= s_end;
     const bool filt = part == CV_FILTER;
+    Primal F;
+    F.restore(&fst[lane]);                                     // (wave 0's; the other waves read it for nothing and discard it)
     {
         const double t = wave_sum((empty || !filt) ? 0.0 : F.value());
         if (lane == 0) A.partials[((int64_t)pc * nacc + 0) * G + g] = t;
@@ -679,19 +730,31 @@ hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* ou
     return hipGetLastError();
 }
 
-// a.n_parts == WG_WAVES parts (one per wave of a workgroup), a.drift_k streamed columns (1 .. DRIFT_KMAX), kc: the widest
+// are two design columns (device arrays of n doubles) the same numbers?  *differ is raised if not (create time)
+__global__ __launch_bounds__(256) void cols_differ_kernel(const double* a, const double* b, int64_t n, int* differ) {
+    bool d = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long x = __double_as_longlong(a[i]), y = __double_as_longlong(b[i]);
+        d = d || x != y;
+    }
+    if (__any(d) && (threadIdx.x & 63) == 0) atomicOr(differ, 1);
+}
+hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* differ, hipStream_t s) {
+    hipLaunchKernelGGL(cols_differ_kernel, dim3(1024), dim3(256), 0, s, a, b, n, differ);
+    return hipGetLastError();
+}
+
+// a.n_parts == CV_WAVES parts (one per wave of a workgroup), a.drift_k streamed columns (1 .. DRIFT_KMAX), kc: the widest
 // part's column count
 template <int MODEL, int D>
 static hipError_t launch_cv(const IsoArgs& a, const CvPart* parts, int kc, dim3 grid, dim3 block, hipStream_t s) {
     if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2>), grid, block, 0, s, a, parts);
-    else if (kc <= 4) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4>), grid, block, 0, s, a, parts);
-    else if (kc <= 6) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 6>), grid, block, 0, s, a, parts);
-    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 8>), grid, block, 0, s, a, parts);
+    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4>), grid, block, 0, s, a, parts);
     return hipGetLastError();
 }
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s) {
-    if (a.n_parts != WG_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
-    dim3 grid(a.tv.n_groups * a.n_chunks), block(WG_WAVES * WAVE);
+    if (a.n_parts != CV_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
+    dim3 grid(a.tv.n_groups * a.n_chunks), block(CV_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
 #define SSDE_CASE(M_, D_) if (model == M_ && d == D_) return launch_cv<M_, D_>(a, parts, kc, grid, block, s);
     SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)

@@ -125,8 +125,9 @@ struct IsoArgs {
     double cv_eta0[2];
 };
 // One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients one wave of the workgroups carries
-// (device table, WG_WAVES entries)
-constexpr int CV_KC = 8;         // columns per part (register budget of a wave)
+// (device table, CV_WAVES entries)
+constexpr int CV_WAVES = 8;      // waves of a workgroup = parts: two per SIMD
+constexpr int CV_KC = 4;         // columns per part (register budget of a wave at two per SIMD)
 struct CvPart {
     int32_t n_col;               // columns of this part
     int32_t with_mu;             // the part also carries the drift-intercept direction
@@ -135,9 +136,10 @@ struct CvPart {
     int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa)
 };
 // partials [n_parts * n_chunks][2 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d | log sigma_obs;
-// a.n_parts == WG_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count
+// a.n_parts == CV_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
 int colvar_nstate(int model, int d, int kc);
+hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* differ /* device, zeroed */, hipStream_t s);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance
 // direction, one block for mu

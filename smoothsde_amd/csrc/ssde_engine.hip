@@ -760,6 +760,8 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         if (h->df_ja >= 0 && h->pp_fast[h->df_ja]) info->required_bytes_per_row -= 8.0 * ((double)h->df_pidxA.size() - 1.0);
         if (h->df_jb >= 0 && h->pp_fast[h->df_jb]) info->required_bytes_per_row -= 8.0 * ((double)h->df_pidxB.size() - 1.0);
     }
+    // row-varying tau / nu: a design column both parameters use is resident (and read) once
+    if (h->drift == 3) info->required_bytes_per_row -= 8.0 * (double)(h->n_stream_cols_algo - h->n_stream_cols);
     if (h->n_pad > 0) info->required_bytes_per_row *= (double)h->n_pad / (double)h->n;
     if (h->path == PATH_ISO || h->path == PATH_DENSE) {
         info->n_rows_tiled = h->n_pad > 0 ? h->n_pad : h->n;

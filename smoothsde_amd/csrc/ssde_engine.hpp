@@ -148,7 +148,7 @@ struct ssde_handle {
                                    // tracks), 2 = lanes with their own covariance (missing rows / irregular grid)
     int drift_nstate = 0;          // components of its hand-over dumps
     DevBuf<ssde::CvPart> cv_parts;  // drift == 3 (row-varying tau / nu on lane = track lanes, k_iso_colvar.hip): the columns of the four parts
-    std::vector<int> cv_pidx;      // [WG_WAVES][CV_KC] full-parameter index of a part's column, -1 = unused slot
+    std::vector<int> cv_pidx;      // [CV_WAVES][CV_KC] full-parameter index of a part's column, -1 = unused slot
     int cv_mu_part = -1, cv_sig_part = -1;   // the parts that carry the drift-intercept / log sigma_obs direction
     int cv_kc = 0;                 // the widest part's column count
     std::vector<double> cv_col_lo, cv_col_hi;   // range of every streamed column over the batch (found at create)

@@ -142,45 +142,51 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
-        if ((int)cols.size() > WG_WAVES * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;
-        std::vector<CvPart> parts(WG_WAVES);
-        memset(parts.data(), 0, sizeof(CvPart) * WG_WAVES);
-        h->cv_pidx.assign((size_t)WG_WAVES * CV_KC, -1);
-        // What a wave's row costs, in fp64 instructions: so much per column SLOT it computes -- the column loop is straight-line
-        // code in four blocks of slots, a block runs if the wave has a column in it --, the filter and the directions it
-        // carries on wave 0, the exp's and the transition on the last wave.  Pick the slot count kc (2, 4, 6, 8: the kernel's
-        // instantiations) and the columns per wave that make the slowest wave fastest.
+        if ((int)cols.size() > CV_WAVES * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;
+        std::vector<CvPart> parts(CV_WAVES);
+        memset(parts.data(), 0, sizeof(CvPart) * CV_WAVES);
+        h->cv_pidx.assign((size_t)CV_WAVES * CV_KC, -1);
+        // What a wave's row costs, in fp64 instructions: so much per column it carries, the filter and the directions that ride
+        // on it on wave 0, the exp's and the transition on the last wave.  Waves w and w + 4 share a SIMD, and what the row
+        // takes is what the busiest SIMD has to issue: every column goes to the SIMD with the least work, there to the wave
+        // with fewer columns (the one without a stage first).
         const bool ct = h->model == SSDE_MODEL_CTCRW;
-        const double c_slot = ct ? (h->d == 2 ? 48.0 : 34.0) : 10.0 + 4.0 * h->d, c_filter = ct ? 300.0 : 120.0, c_trans = ct ? 360.0 : 150.0;
+        const double c_slot = ct ? (h->d == 2 ? 60.0 : 44.0) : 14.0 + 5.0 * h->d, c_filter = ct ? 390.0 : 150.0, c_trans = ct ? 390.0 : 170.0;
         const int N = (int)cols.size();
-        int best_n[WG_WAVES] = {0, 0, 0, 0}, best_kc = 2;
-        double best_cost = INFINITY;
-        for (int kc = 2; kc <= CV_KC; kc += 2) {
-            const int q = (kc + 3) / 4;
-            auto slots = [&](int n) { return std::min(kc, (n + q - 1) / q * q); };
-            for (int n0 = 0; n0 <= kc; n0++)
-                for (int n3 = 0; n3 <= kc; n3++) {
-                    const int rest = N - n0 - n3;
-                    if (rest < 0 || rest > 2 * kc) continue;
-                    const int n1 = (rest + 1) / 2, n2 = rest / 2;
-                    const double c = std::max(std::max(c_filter + c_slot * slots(n0), c_slot * slots(n1)), std::max(c_slot * slots(n2), c_trans + c_slot * slots(n3)));
-                    if (c < best_cost - 1e-9) { best_cost = c; best_kc = kc; best_n[0] = n0; best_n[1] = n1; best_n[2] = n2; best_n[3] = n3; }
-                }
-        }
-        if (const char* e = getenv("SSDE_CV_DEAL")) {              // testing: "n0,n1,n2,n3"
-            int v[4];
-            if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] + v[1] + v[2] + v[3] == N) {
-                best_kc = 2;
-                for (int p = 0; p < 4; p++) { best_n[p] = std::min(std::max(v[p], 0), CV_KC); best_kc = std::max(best_kc, (best_n[p] + 1) / 2 * 2); }
+        int n_w[CV_WAVES];
+        for (int p = 0; p < CV_WAVES; p++) n_w[p] = 0;
+        if (const char* e = getenv("SSDE_CV_DEAL")) {              // testing: "n0,n1,...,n7"
+            int v[8], tot = 0;
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) == 8) {
+                for (int p = 0; p < 8; p++) { v[p] = std::min(std::max(v[p], 0), CV_KC); tot += v[p]; }
+                if (tot == N) for (int p = 0; p < 8; p++) n_w[p] = v[p];
             }
         }
         {
+            int dealt = 0;
+            for (int p = 0; p < CV_WAVES; p++) dealt += n_w[p];
+            double simd[4] = {c_filter, 0.0, 0.0, c_trans};        // wave 0 (filter) sits on SIMD 0, wave 7 (transition) on SIMD 3
+            for (int p = 0; p < CV_WAVES; p++) simd[p & 3] += c_slot * n_w[p];
+            for (; dealt < N; dealt++) {
+                int bs = -1;
+                for (int q = 0; q < 4; q++)
+                    if ((n_w[q] < CV_KC || n_w[q + 4] < CV_KC) && (bs < 0 || simd[q] < simd[bs])) bs = q;
+                // within the SIMD: the wave without a stage, unless it is full or already two ahead
+                int w = (bs == 0) ? 4 : (bs == 3) ? 3 : (n_w[bs] <= n_w[bs + 4] ? bs : bs + 4), other = (w == bs) ? bs + 4 : bs;
+                if (n_w[w] >= CV_KC || ((bs == 0 || bs == 3) && n_w[w] >= n_w[other] + 3 && n_w[other] < CV_KC)) w = other;
+                n_w[w]++; simd[bs] += c_slot;
+            }
+        }
+        int best_kc = 2;
+        {
             size_t i = 0;
-            for (int p = 0; p < WG_WAVES; p++)
-                for (int k = 0; k < best_n[p] && i < cols.size(); k++, i++) {
+            for (int p = 0; p < CV_WAVES; p++) {
+                best_kc = std::max(best_kc, (n_w[p] + 1) / 2 * 2);
+                for (int k = 0; k < n_w[p] && i < cols.size(); k++, i++) {
                     parts[p].chan[k] = cols[i].chan; parts[p].type[k] = cols[i].type; parts[p].n_col = k + 1;
                     h->cv_pidx[(size_t)p * CV_KC + k] = cols[i].pidx;
                 }
+            }
             if (i != cols.size()) return fail(h, SSDE_ERR_ARG, "internal: the design columns were not all dealt");
         }
         // the log sigma_obs and drift-intercept directions ride on the wave that runs the filter
@@ -221,7 +227,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->drift = all_clean ? 1 : 2;
         h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
     }
-    if (h->drift) { h->iso_parts = h->drift == 3 ? WG_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+    if (h->drift) { h->iso_parts = h->drift == 3 ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
     else choose_iso_split(h);
     // shared-covariance path: regular grid + groups without missing rows
     HIPCHK(h, h->group_flags.upload(gflags));
@@ -296,7 +302,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
     if (h->drift == 3) HIPCHK(h, hipMemset(h->bnd.p, 0, h->bnd.n * 8));      // (a part dumps its own block of a hand-over record; the check reads all of it)
-    h->partial_doubles = (size_t)MAX_PARTS * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
+    h->partial_doubles = (size_t)std::max(MAX_PARTS, CV_WAVES) * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
     h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
     return SSDE_OK;
 }
@@ -612,6 +618,50 @@ static int build_direct(const ssde_desc* d, ssde_handle* h, bool on_dev, int64_t
     return SSDE_OK;
 }
 
+// Row-varying tau / nu: a design column of par[d + 1] that holds the same numbers as one of par[d] (the same smooth of the same
+// covariate in both formulas -- the usual case) is streamed ONCE: the two coefficients share the tile channel.  Returns the
+// number of distinct columns; `col` of the slots is renumbered.
+static int share_equal_columns(const ssde_desc* d, ssde_handle* h, bool on_dev, int64_t n, int* n_distinct) {
+    DevBuf<int> flag;
+    if (on_dev) HIPCHK(h, flag.alloc(1));
+    auto equal = [&](const double* a, const double* b, bool* eq) -> int {
+        *eq = false;
+        if (a == b) { *eq = true; return SSDE_OK; }
+        if (!a || !b) return SSDE_OK;
+        if (on_dev) {
+            HIPCHK(h, hipMemset(flag.p, 0, sizeof(int)));
+            HIPCHK(h, launch_cols_differ(a, b, n, flag.p, 0));
+            int f = 1;
+            HIPCHK(h, hipMemcpy(&f, flag.p, sizeof(int), hipMemcpyDeviceToHost));
+            *eq = f == 0;
+            return SSDE_OK;
+        }
+        for (int k = 0; k < 64; k++) {                             // a sample first: most pairs differ at once
+            const int64_t i = (int64_t)((double)k / 63.0 * (double)(n - 1));
+            if (memcmp(a + i, b + i, 8) != 0) return SSDE_OK;
+        }
+        *eq = memcmp(a, b, (size_t)n * 8) == 0;
+        return SSDE_OK;
+    };
+    for (auto& b : h->slots) {
+        if (b.col < 0 || b.par_j != h->d + 1 || b.basis_c >= 0) continue;
+        for (auto& a : h->slots) {
+            if (a.col < 0 || a.par_j != h->d || a.basis_c >= 0) continue;
+            bool eq;
+            int st = equal(a.src, b.src, &eq);
+            if (st) return st;
+            if (eq) { b.col = a.col; break; }
+        }
+    }
+    std::vector<int> remap(h->n_stream_cols, -1);
+    int nd = 0;
+    for (auto& sl : h->slots)
+        if (sl.col >= 0) { if (remap[sl.col] < 0) remap[sl.col] = nd++; sl.col = remap[sl.col]; }
+    *n_distinct = nd;
+    (void)d;
+    return SSDE_OK;
+}
+
 static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout, bool allow_drift) {
     { int st = check_descriptor(d, h, part_layout); if (st) return st; }
 
@@ -658,13 +708,13 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // coefficients and the shared-covariance lanes run; otherwise the lanes carry their own covariance.  Few tracks (C1:
         // one animal) stay on the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
         if (!iso_ok && allow_drift && !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
-            !getenv("SSDE_NO_DRIFT") && h->n_stream_cols <= DRIFT_KMAX) {
+            !getenv("SSDE_NO_DRIFT")) {
             bool mu_only = true;
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;
             int min_tracks = 32;
             if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
-            if (mu_only && h->n_seg >= min_tracks) { h->drift = 1; h->path = PATH_ISO; }
+            if (mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.  Columns evaluated from a basis table (ssde_ppbasis) and mixed designs (columns in the drift
@@ -672,7 +722,12 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             bool par_only = !mu_only && !getenv("SSDE_NO_COLVAR");
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && (sl.par_j < h->d || sl.basis_c >= 0)) par_only = false;
-            if (par_only && h->n_seg >= min_tracks && h->d <= 2) { h->drift = 3; h->path = PATH_ISO; }
+            if (par_only && h->n_seg >= min_tracks && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
+                int nd = h->n_stream_cols;
+                if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
+                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; }
+                else return SSDE_RETRY_WITHOUT_DRIFT;              // (the slots were renumbered: start over)
+            }
         }
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
         // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic

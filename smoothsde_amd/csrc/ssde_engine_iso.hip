@@ -217,7 +217,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     } else {
         a.n_parts = 1;
     }
-    if (h->drift == 3) { a.n_parts = WG_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
+    if (h->drift == 3) { a.n_parts = CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
     a.any_nan = h->na_any;
     a.uniform_dt = h->uniform_dt ? 1 : 0;
     const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
@@ -388,7 +388,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         if (h->drift == 3) {
             a.t0 = 0; a.t0_delta = 0;
             if (!h->wave_clock_file.empty()) {                  // (a build with -DSSDE_CV_CLOCK fills it: cycles per row and phase of every wave)
-                const int items = h->n_groups * a.n_chunks * WG_WAVES;
+                const int items = h->n_groups * a.n_chunks * CV_WAVES;
                 if ((int)h->wave_clock.n < 4 * items) { h->wave_clock.release(); HIPCHK(h, h->wave_clock.alloc((size_t)4 * items)); }
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
@@ -418,7 +418,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
     if (order >= 1 && h->drift == 3) {
         // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d | log sigma_obs]
-        for (int p = 0; p < WG_WAVES; p++) {
+        for (int p = 0; p < CV_WAVES; p++) {
             for (int k = 0; k < CV_KC; k++) {
                 const int pidx = h->cv_pidx[(size_t)p * CV_KC + k];
                 if (pidx >= 0) ra.map[p * (nacc - 1) + k] = (int16_t)(1 + pidx);

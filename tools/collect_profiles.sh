@@ -40,6 +40,14 @@ bash tools/pmc_kernel.sh "iso_shared" ${TAG}_share8 -- python3 $ROOT/tools/bench
 bash tools/pmc_kernel.sh "iso_drift" ${TAG}_drift -- python3 $ROOT/tools/bench_drift.py 10000 10000 9 > /dev/null 2>&1 || true
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_drift" -d "$OUT/pmc_drift_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_drift.py 10000 10000 9 > "$OUT/pmc_drift_fetch.log" 2>&1 ) || true
 cp gpurun_out/pmc_${TAG}_share8.txt gpurun_out/pmc_${TAG}_drift.txt "$OUT/" 2>/dev/null || true
+# round 3, second half: row-varying tau / nu on lane = track lanes (k_iso_colvar.hip) against the lane = direction path
+python3 tools/bench_colvar.py > "$OUT/colvar.txt" 2> "$OUT/colvar.err"
+( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/colvar_stats" -o stats --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track > "$OUT/colvar_under_rocprof.log" 2>&1 ) || true
+find "$OUT/colvar_stats" -name "*kernel_trace*" -delete 2>/dev/null || true
+bash tools/pmc_kernel.sh "iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > /dev/null 2>&1 || true
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_colvar" -d "$OUT/pmc_colvar_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > "$OUT/pmc_colvar_fetch.log" 2>&1 ) || true
+cp gpurun_out/pmc_${TAG}_colvar.txt "$OUT/" 2>/dev/null || true
+echo "[collect] colvar kernel done"
 echo "[collect] SQ counters done"
 find "$OUT" -name "*.csv" -size +8M -delete
 du -sh "$OUT"

@@ -4,7 +4,7 @@
 import sys
 import numpy as np
 d = np.loadtxt(sys.argv[1], comments="#")
-for p in range(4):
-    r = d[d[:, 0].astype(int) % 4 == p][:, 1:]
+for p in range(8):
+    r = d[d[:, 0].astype(int) % 8 == p][:, 1:]
     r = r[r.sum(axis=1) > 0]
     print(f"part {p}: {len(r)} waves; cycles per row: staging {r[:,0].mean():.0f}, transition {r[:,1].mean():.0f}, row {r[:,2].mean():.0f}, barrier {r[:,3].mean():.0f}, total {r.sum(axis=1).mean():.0f}")

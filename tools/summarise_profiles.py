@@ -4,6 +4,7 @@ into the small files kept under profiles/: kernel statistics of this engine's ke
 pmc_latest.json (quoted by bench.py as `roofline.traffic_profiled`, with its tag), the bench line and the other configurations' timings."""
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
@@ -85,4 +86,25 @@ try:   # FETCH_SIZE of the drift kernel (same x2 calibration)
                     f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_drift.py 10000 10000 9 (OU_SSM d = 1, 9 streamed drift columns: 80 B/row required = 8.0 GB)\n")
 except Exception as e:  # noqa: BLE001
     print("no drift PMC:", e)
+# round 3, second half: the row-varying tau / nu kernel (k_iso_colvar.hip)
+for name in ("colvar.txt", f"pmc_{tag}_colvar.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
+try:
+    f = glob.glob(os.path.join(src, "colvar_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if f:
+        rows = [r for r in csv.DictReader(open(f[0])) if "ssde" in r["Name"]]
+        with open(pre + "colvar_kernel_stats.csv", "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+            w.writeheader(); w.writerows(rows)
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_colvar_fetch", "fetch_counter_collection.csv")))
+            if "iso_colvar" in r["Kernel_Name"]]
+    if vals:
+        with open(pre + "pmc_colvar_fetch.txt", "w") as fh:
+            fh.write(f"iso_colvar_kernel: {len(vals)} dispatches, FETCH_SIZE avg {sum(vals) / len(vals):.1f} KiB -> {2 * 1024 * sum(vals) / len(vals) / 1e9:.3f} GB per launch "
+                     f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_colvar.py (1e4 CTCRW x 1e3, 18 streamed columns: 160 B/row required = 1.6 GB, "
+                     f"plus the warm-up rows of the time windows)\n")
+except Exception as e:  # noqa: BLE001
+    print("no colvar profile:", e)
 print("wrote", pre + "*", "and profiles/pmc_latest.json; main kernel", main, f"{main_bytes / 1e9:.3f} GB per launch")
