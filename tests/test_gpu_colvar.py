@@ -167,6 +167,36 @@ def test_lane_track_and_lane_direction_paths_agree(monkeypatch):
     e1.close(); e2.close()
 
 
+def test_a_smooth_shared_by_tau_and_nu_is_streamed_once(monkeypatch):
+    """The same design block in both formulas (tau ~ s(x), nu ~ s(x)): the engine finds the equal columns at create (host arrays
+    and device-resident ones) and keeps one tile channel per distinct column."""
+    import torch
+    pb, par = _batch("CTCRW", 2, 96, 700, 7, 7, seed=29, same_basis=True)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    inf = eng.info()
+    assert inf["algo_bytes_per_row"] == 8.0 * (3 + 14) and inf["required_bytes_per_row"] == 8.0 * (2 + 7)      # regular grid: no dt channel
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pb, par))
+    # device-resident columns (distinct tensors holding the same numbers), and 14 + 14 columns that only fit because they are shared
+    dev = torch.device("cuda:0")
+    B = torch.as_tensor(pb.X_re[2], device=dev)
+    pbd = capi.Problem.from_torch("CTCRW", torch.as_tensor(pb.id, device=dev), torch.as_tensor(pb.times, device=dev),
+                                  torch.as_tensor(pb.obs, device=dev), X_re=[None, None, B, B.clone()], S_list=pb.S_list)
+    engd = capi.Engine(pbd)
+    assert _is_colvar(engd) and engd.info()["required_bytes_per_row"] == 8.0 * (2 + 7)
+    vd, gd = engd.eval(par)
+    assert abs(vd - val) <= 1e-12 * abs(val) and np.max(np.abs(gd - grad)) <= 1e-10 * np.max(np.abs(grad))
+    pb14, par14 = _batch("CTCRW", 2, 64, 300, 14, 14, seed=31, same_basis=True)
+    e14 = capi.Engine(pb14)
+    assert _is_colvar(e14)
+    _close(*e14.eval(par14), *_oracle(pb14, par14))
+    monkeypatch.setenv("SSDE_CV_NO_SHARE", "1")
+    e14b = capi.Engine(pb14)
+    assert e14b.info()["path"] == PATH_TV                       # 28 distinct channels do not fit
+    eng.close(); engd.close(); e14.close(); e14b.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path():
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
