@@ -559,11 +559,13 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         eta[slot][(2 * part + 1) * WAVE + lane] = pb;
         if (part == 0) eta[slot][(2 * CV_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
-    auto produce = [&](int slot) {                             // stage 1: the transition of the row whose sums sit in eta[slot]
+    double p1_lo = INFINITY, p1_hi = -INFINITY, p2_lo = INFINITY, p2_hi = -INFINITY;      // (the transition wave: what the predictors reached)
+    auto produce = [&](int slot, int s) {                      // stage 1: the transition of row s, whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
         for (int w = 0; w < CV_WAVES; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
+        if (s < ns) { p1_lo = fmin(p1_lo, p1); p1_hi = fmax(p1_hi, p1); p2_lo = fmin(p2_lo, p2); p2_hi = fmax(p2_hi, p2); }
         const double dtc = e_[(2 * CV_WAVES) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         ld(X, t + 4);
         SSDE_CK(0)
         // (raising the two stage waves' priority over the column waves they share a SIMD with, s_setprio, changed nothing: 1.264 / 1.260 ms)
-        if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1);
+        if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1, t + 2);
         if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
         SSDE_CK(1)
         if (t >= s_begin) columns(t, sl_t, t & 1);
@@ -676,6 +678,14 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     }
 #endif
     if (!last_chunk) S.dump_to(dump1 + NPD * WAVE);
+    if (part == CV_PRODUCER && A.cv_ranges) {                  // per workgroup: the range of p1 and p2 over its rows (the next evaluation's window plan)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            p1_lo = fmin(p1_lo, __shfl_xor(p1_lo, o, 64)); p1_hi = fmax(p1_hi, __shfl_xor(p1_hi, o, 64));
+            p2_lo = fmin(p2_lo, __shfl_xor(p2_lo, o, 64)); p2_hi = fmax(p2_hi, __shfl_xor(p2_hi, o, 64));
+        }
+        if (lane == 0) { double* o_ = A.cv_ranges + 4 * (int64_t)blockIdx.x; o_[0] = p1_lo; o_[1] = p1_hi; o_[2] = p2_lo; o_[3] = p2_hi; }
+    }
     const bool empty = s_acc >= s_end;
     const bool filt = part == CV_FILTER;
     Primal F;
@@ -727,6 +737,30 @@ __global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_ranges_kernel(TileView
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out, hipStream_t s) {
     if (tv.n_groups == 0 || K == 0) return hipSuccess;
     hipLaunchKernelGGL(colvar_ranges_kernel, dim3(tv.n_groups), dim3(WG_WAVES * WAVE), 0, s, tv, c_col, K, out);
+    return hipGetLastError();
+}
+
+// the ranges of the linear predictors over the whole launch -> four doubles in host-visible memory (read by the next window plan)
+__global__ __launch_bounds__(256) void colvar_range_reduce_kernel(const double* wg, int n_wg, double* out) {
+    __shared__ double sh[4][4];
+    double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n_wg; i += 256)
+        for (int k = 0; k < 4; k++) v[k] = (k & 1) ? fmax(v[k], wg[4 * (int64_t)i + k]) : fmin(v[k], wg[4 * (int64_t)i + k]);
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v[k], o, 64); v[k] = (k & 1) ? fmax(v[k], t) : fmin(v[k], t); }
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        double t = sh[0][k];
+        for (int w = 1; w < 4; w++) t = (k & 1) ? fmax(t, sh[w][k]) : fmin(t, sh[w][k]);
+        out[k] = t;
+    }
+}
+hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pinned, hipStream_t s) {
+    hipLaunchKernelGGL(colvar_range_reduce_kernel, dim3(1), dim3(256), 0, s, wg, n_wg, out_pinned);
     return hipGetLastError();
 }
 

@@ -123,6 +123,7 @@ struct IsoArgs {
     // Row-varying tau / nu (kappa, sigma) on lane = track lanes (k_iso_colvar.hip): the linear predictors are
     // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
     double cv_eta0[2];
+    double* cv_ranges;           // [workgroup][4]: min / max of p1, min / max of p2 over the workgroup's rows, or NULL
 };
 // One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients one wave of the workgroups carries
 // (device table, CV_WAVES entries)
@@ -139,6 +140,7 @@ struct CvPart {
 // a.n_parts == CV_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
 int colvar_nstate(int model, int d, int kc);
+hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pinned /* 4 doubles, host-visible */, hipStream_t s);
 hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* differ /* device, zeroed */, hipStream_t s);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance

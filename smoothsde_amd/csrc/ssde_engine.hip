@@ -41,6 +41,8 @@ void release_device(ssde_handle* h) {
         }
     }
     h->wave_clock.release();
+    h->cv_ranges.release(); h->cv_parts.release();
+    if (h->cv_ranges_pinned) { (void)hipHostFree(h->cv_ranges_pinned); h->cv_ranges_pinned = nullptr; }
     h->hs_partials.release(); h->hs_hess.release(); h->hs_i16.release();
     if (h->trace && h->trace_n > 0)
         fprintf(stderr, "[ssde trace] %lld isotropic evaluations, host us per evaluation: plan %.1f | gain table %.1f | main launch %.1f | "
@@ -472,7 +474,8 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
         // the row-varying path plans from the parameter ranges its pre-pass saw in the PREVIOUS evaluation: after a
         // jump in the parameters the first retry needs no boost, just this evaluation's own ranges
         const int path0 = h->shards.empty() ? h->path : h->shards[0]->path;
-        if (path0 == PATH_TV && attempt == 0) continue;
+        const int drift0 = h->shards.empty() ? h->drift : h->shards[0]->drift;
+        if ((path0 == PATH_TV || drift0 == 3) && attempt == 0) continue;       // (k_iso_colvar.hip plans the same way)
         if (attempt >= 3) {                                            // give up on windows: sequential filter
             each_engine(h, [](ssde_handle* e) {
                 if (!e->gave_up) { e->saved_max_chunks = e->max_chunks; e->saved_want_chunks = e->want_chunks; e->gave_up = true; }

@@ -152,6 +152,8 @@ struct ssde_handle {
     int cv_mu_part = -1, cv_sig_part = -1;   // the parts that carry the drift-intercept / log sigma_obs direction
     int cv_kc = 0;                 // the widest part's column count
     std::vector<double> cv_col_lo, cv_col_hi;   // range of every streamed column over the batch (found at create)
+    DevBuf<double> cv_ranges;      // [workgroup][4] ranges of the linear predictors seen by the last launch
+    double* cv_ranges_pinned = nullptr;   // ... reduced over the launch: min / max of p1, min / max of p2 (host-visible; +inf / -inf before the first launch)
     double cv_eta_lo[2] = {0, 0}, cv_eta_hi[2] = {0, 0};   // range the linear predictors of par[d], par[d + 1] can reach at the last parameters
     // exact Hessian over the drift coefficients (ssde_hess.hip): eval_device launches the Hessian kernels instead of an evaluation
     DevBuf<double> hs_partials, hs_hess;      // scratch of the Hessian passes, kept between calls (allocation costs more than the pass)

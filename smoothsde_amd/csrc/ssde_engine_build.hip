@@ -196,6 +196,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
         h->cv_kc = best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
+        HIPCHK(h, hipHostMalloc((void**)&h->cv_ranges_pinned, 4 * sizeof(double), hipHostMallocDefault));
+        h->cv_ranges_pinned[0] = h->cv_ranges_pinned[2] = INFINITY; h->cv_ranges_pinned[1] = h->cv_ranges_pinned[3] = -INFINITY;
         {
             // the range of every streamed column over the batch
             const int K = h->n_stream_cols;

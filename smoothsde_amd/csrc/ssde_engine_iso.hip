@@ -239,6 +239,18 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             h->cv_eta_hi[j] += std::max(b * lo, b * hi);
         }
         a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+        // ... which is loose (a partition-of-unity basis reaches max |coef|, the bound says sum |coef|): once a launch has run,
+        // the range it actually saw, widened by a quarter of its width (+ 0.05), bounds the plan; a parameter jump that leaves
+        // it fails the hand-over check and the retry plans from that evaluation's own range
+        if (h->cv_ranges_pinned && !getenv("SSDE_CV_DESIGN_BOUND"))
+            for (int j = 0; j < 2; j++) {
+                const double lo = h->cv_ranges_pinned[2 * j], hi = h->cv_ranges_pinned[2 * j + 1];
+                if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) continue;
+                const double m = 0.25 * (hi - lo) + 0.05;
+                h->cv_eta_lo[j] = std::max(h->cv_eta_lo[j], lo - m);
+                h->cv_eta_hi[j] = std::min(h->cv_eta_hi[j], hi + m);
+                if (h->cv_eta_lo[j] > h->cv_eta_hi[j]) { h->cv_eta_lo[j] = lo - m; h->cv_eta_hi[j] = hi + m; }
+            }
     } else
     if (h->drift) {
         // mu_a(i) = intercept + sum_k coef_k X_k(i) (nllk_ctcrw.hpp:143-149): the intercept slot (if any) goes where the
@@ -393,7 +405,11 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
+            const int n_wg = h->n_groups * a.n_chunks;
+            if ((int)h->cv_ranges.n < 4 * n_wg) { h->cv_ranges.release(); HIPCHK(h, h->cv_ranges.alloc((size_t)4 * n_wg)); }
+            a.cv_ranges = h->cv_ranges.p;
             HIPCHK(h, launch_iso_colvar(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
+            HIPCHK(h, launch_colvar_range_reduce(h->cv_ranges.p, n_wg, h->cv_ranges_pinned, s));
         }
         else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
         else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));

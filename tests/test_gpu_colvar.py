@@ -197,6 +197,33 @@ def test_a_smooth_shared_by_tau_and_nu_is_streamed_once(monkeypatch):
     eng.close(); engd.close(); e14.close(); e14b.close()
 
 
+def test_window_plan_follows_the_range_the_predictors_actually_reach():
+    """The design-based bound on log tau_i, log nu_i (sum of |coefficient| x column range) is loose for a partition-of-unity
+    basis; from the second evaluation on the plan uses the range the previous launch saw.  A parameter jump that leaves it is
+    caught by the hand-over check and repaired by the retry."""
+    pb, par = _batch("CTCRW", 2, 96, 1500, 9, 9, seed=41)
+    big = par.copy()
+    big[pb.off_re:] = 1.2 * np.sin(np.arange(pb.n_par_full - pb.off_re))          # sum |coef| ~ 7 per block, max |coef| 1.2
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    v1, g1 = eng.eval(big)
+    w_first = eng.info()["window"]
+    v2, g2 = eng.eval(big + 1e-6)
+    inf = eng.info()
+    assert inf["window"] > 0 and inf["lanes_per_track"] > 8 and inf["window_check"] <= 1e-11
+    assert w_first == 0 or inf["window"] <= w_first                # the measured range never asks for a longer warm-up than the bound
+    _close(v1, g1, *_oracle(pb, big))
+    _close(v2, g2, *_oracle(pb, big + 1e-6))
+    # a jump to slow-forgetting parameters (small tau x large nu corner moves): still right, whatever the plan had to become
+    jump = big.copy()
+    jump[pb.off_fe + pb.fe_off[2]] += 2.5
+    jump[0] += 1.5
+    v3, g3 = eng.eval(jump)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(v3, g3, *_oracle(pb, jump))
+    eng.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path():
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
