@@ -14,7 +14,7 @@
 //
 // One WORKGROUP of EIGHT waves (two per SIMD) per (64-track group, time window).  The waves form a pipeline over the rows, one
 // barrier per row, everything between the stages in LDS rings:
-//   stage 0, every wave:  loads an eighth of the channels of the row four ahead (HBM is read ONCE per row: 8 (1 + d + K)
+//   stage 0, waves 1-6:   each loads a sixth of the channels of the row four ahead (HBM is read ONCE per row: 8 (1 + d + K)
 //                         bytes), stores the row two ahead to the ring of rows, and adds ITS channels' terms of the linear
 //                         predictors p1 = log tau_i, p2 = log nu_i of the row three ahead (two partial sums per wave and row);
 //   stage 1, the last wave:  for the row two ahead, sums the partial predictors, takes the exp's and builds T, Q, B and their
@@ -26,13 +26,17 @@
 //                         union of its waves' roles);
 //   stage 3, every wave:  the column tangents of the current row from the linearisation -- straight-line code, what a column
 //                         feeds is a pair of 0/1 factors on its value, not a branch -- for the up to CV_KC columns dealt to it.
-// The engine deals the columns by cost: waves w and w + 4 share a SIMD, the SIMDs of the two stage waves get fewer.  A wave's
+// The two stage waves are long dependent chains -- the row's critical path: they stage nothing, go first on the SIMD they share
+// (s_setprio) and get columns only when the six waves between them are full (the engine deals round robin).  A wave's
 // registers hold its columns' state and little else, so two waves fit a SIMD and cover each other's LDS / barrier waits.
 // Measured on the way here (1e4 tracks x 1e3 rows, 18 columns; lane = direction path 3.70 ms):
 //   four waves, each running the primal filter, a uniform branch per column and type             2.06 ms  (the branches: 2100 of 4600 cycles per row)
 //   ... straight-line columns, a transition wave                                                 1.54 ms  (> half of the VALU instructions v_accvgpr / v_readlane moves)
 //   ... + a filter wave handing the linearisation on, columns in four blocks                      1.36 ms
 //   eight waves (two per SIMD, 256 registers each), filter state parked in LDS                    1.26 ms
+//   ... a design column both parameters use streamed once (this bench: 9 instead of 18)           1.13-1.16 ms
+//   (stage waves freed of staging and columns, 0/1 factors as bit selects instead of an LDS table: 1.13 ms, no change --
+//    SQ counters: 22 % of the wave cycles issue VALU, 39 % wait on s_waitcnt, 25 % issue-stalled; ~400 LDS instructions per row)
 // Windows, warm-up and the verified hand-over as in k_iso.hip.  Layout: the tiles of ssde_device.hpp with the design
 // columns as further channels (as k_iso_drift.hip).
 #include <type_traits>
@@ -462,9 +466,10 @@ int colvar_nstate(int model, int d, int kc) {
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------
 // accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]   (value, mu, sigma_obs: part 0)
-constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + CV_WAVES - 1) / CV_WAVES;   // channels a wave loads per row (dt, y, the streamed columns)
-constexpr int CV_CMAX = CV_LD * CV_WAVES;                               // channels of a staged row
 constexpr int CV_PRODUCER = CV_WAVES - 1;                               // the wave that builds the transitions
+constexpr int CV_LOADERS = CV_WAVES - 2;                                // the waves between the two stage waves stage the rows
+constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + CV_LOADERS - 1) / CV_LOADERS;   // channels a loading wave handles per row (dt, y, the streamed columns)
+constexpr int CV_CMAX = CV_LD * CV_LOADERS;                             // channels of a staged row
 constexpr int CV_FILTER = 0;                                            // the wave that runs the primal filter
 
 // KC: column slots per wave (even; the engine picks the instantiation from the widest part)
@@ -475,14 +480,19 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     typedef typename Primal::Trans Trans;
     constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
     __shared__ double raw[3][CV_CMAX * WAVE];                  // the staged rows
-    __shared__ double eta[2][(2 * CV_WAVES + 1) * WAVE];       // per row: the four waves' partial sums of p1, p2, and the interval
+    __shared__ double eta[2][(2 * CV_LOADERS + 1) * WAVE];     // per row: the loading waves' partial sums of p1, p2, and the interval
     __shared__ double trs[2][NTR * WAVE];                      // per row: the transition
     __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
     __shared__ double fst[Primal::NSAVE * WAVE];               // the filter's state between rows (wave 0; see below)
     __shared__ double coef[DRIFT_KMAX][2];
-    __shared__ double wcoef[CV_WAVES][CV_LD][2];
+    __shared__ double wcoef[CV_LOADERS][CV_LD][2];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: the part tables are read with scalar loads)
+    // the two stage waves are the row's critical path (each a long dependent chain): they neither stage rows nor, unless the
+    // other six are full, carry columns
+    const bool loader = part != CV_FILTER && part != CV_PRODUCER;
+    if (!loader) __builtin_amdgcn_s_setprio(3);                 // (... and they go first on the SIMD they share with a column wave)
+    const int ldr = loader ? part - 1 : 0;                      // (waves 1 .. 6: loaders 0 .. 5)
     const TileView& tv = A.tv;
     const int G = tv.n_groups;
     const int g = blockIdx.x % G, chunk = blockIdx.x / G;      // (groups are sorted longest first: the long ones start first)
@@ -493,34 +503,32 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         for (int k = 0; k < DRIFT_KMAX; k++) { coef[k][0] = A.coefA[k]; coef[k][1] = A.coefB[k]; }
     }
     __syncthreads();
-    // the channels this wave stages are c = part + 4 i; those that are design columns enter the linear predictors with their
+    // the channels a loading wave stages are c = loader + 6 i; those that are design columns enter the linear predictors with their
     // coefficients, re-packed per wave so that the staging code reads them with one broadcast LDS load per channel
     unsigned col_bits = 0;                                     // bit i: the wave's i-th channel is a design column
 #pragma unroll
     for (int i = 0; i < CV_LD; i++) {
-        const int k = part + CV_WAVES * i - c_col;
+        const int k = ldr + CV_LOADERS * i - c_col;
         const bool on = k >= 0 && k < K;
         if (on) col_bits |= 1u << i;
-        if (lane == 0) { wcoef[part][i][0] = on ? coef[on ? k : 0][0] : 0.0; wcoef[part][i][1] = on ? coef[on ? k : 0][1] : 0.0; }
+        if (lane == 0 && loader) { wcoef[ldr][i][0] = on ? coef[on ? k : 0][0] : 0.0; wcoef[ldr][i][1] = on ? coef[on ? k : 0][1] : 0.0; }
     }
     const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- no tangents)
     const int n_col = grad ? parts[part].n_col : 0;
     const bool with_mu = grad && parts[CV_FILTER].with_mu, with_sig = grad && parts[CV_FILTER].with_sig;
-    // per slot: the channel to read and the factors that turn the value read into X1 = f1 x + o1 (the column's value if it feeds
-    // par[d], else 0) and X2 = f2 x + o2 (... par[d + 1]): (1, 0) a streamed column of that kind, (0, 1) a column of ones of that
-    // kind, (0, 0) otherwise -- wave-uniform numbers the column code reads from LDS (broadcast) instead of holding them in
-    // scalar registers, of which this kernel has none to spare
-    __shared__ double xfac[CV_WAVES][KC][4];
+    // per slot: the channel to read, and what the value read is -- a column of ones / a column that feeds par[d] / par[d + 1]
+    // (bit masks: the selects are VALU work, of which this kernel has plenty to spare; an LDS table of 0/1 factors cost
+    // 16 more LDS reads per wave and row on the LDS pipe, which it has not)
     int chan[KC];
+    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0;
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const bool on = k < n_col;
         const int ch = on ? parts[part].chan[k] : -2, ty = on ? parts[part].type[k] : 0;
-        chan[k] = ch >= 0 ? ch : c_col;                        // (an unused slot reads a design column and weighs it with 0)
-        if (lane == 0) {
-            xfac[part][k][0] = (ty == 1 && ch >= 0) ? 1.0 : 0.0; xfac[part][k][1] = (ty == 1 && ch == -1) ? 1.0 : 0.0;
-            xfac[part][k][2] = (ty == 2 && ch >= 0) ? 1.0 : 0.0; xfac[part][k][3] = (ty == 2 && ch == -1) ? 1.0 : 0.0;
-        }
+        chan[k] = ch >= 0 ? ch : c_col;                        // (an unused slot reads a design column and discards it)
+        if (ch == -1) ones_bits |= 1u << k;
+        if (ty == 1) t1_bits |= 1u << k;
+        if (ty == 2) t2_bits |= 1u << k;
     }
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     const double* const gbase = tv.tiles + tv.group_off[g];
     unsigned voff[CV_LD];
 #pragma unroll
-    for (int i = 0; i < CV_LD; i++) voff[i] = (unsigned)((part + CV_WAVES * i) * WAVE + lane);
+    for (int i = 0; i < CV_LD; i++) voff[i] = (unsigned)((ldr + CV_LOADERS * i) * WAVE + lane);
     auto ld = [&](double (&dst)[CV_LD], int s) {               // this wave's channels of row s: HBM -> registers
         const double* rowp = gbase + (int64_t)s * C * WAVE;
 #pragma unroll
@@ -545,28 +553,28 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     };
     auto st_raw = [&](const double (&src)[CV_LD], int slot) {  // registers -> the ring of rows
 #pragma unroll
-        for (int i = 0; i < CV_LD; i++) raw[slot][(part + CV_WAVES * i) * WAVE + lane] = src[i];
+        for (int i = 0; i < CV_LD; i++) raw[slot][(ldr + CV_LOADERS * i) * WAVE + lane] = src[i];
     };
     auto st_eta = [&](const double (&src)[CV_LD], int slot) {  // this wave's terms of the row's linear predictors
         double pa = 0.0, pb = 0.0;
 #pragma unroll
         for (int i = 0; i < CV_LD; i++) {
             const double xs = ((col_bits >> i) & 1u) ? src[i] : 0.0;      // (an observation may be NaN: 0 * NaN is not 0)
-            pa = fma(wcoef[part][i][0], xs, pa);
-            if (MODEL != M_BM_SSM) pb = fma(wcoef[part][i][1], xs, pb);
+            pa = fma(wcoef[ldr][i][0], xs, pa);
+            if (MODEL != M_BM_SSM) pb = fma(wcoef[ldr][i][1], xs, pb);
         }
-        eta[slot][(2 * part) * WAVE + lane] = pa;
-        eta[slot][(2 * part + 1) * WAVE + lane] = pb;
-        if (part == 0) eta[slot][(2 * CV_WAVES) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
+        eta[slot][(2 * ldr) * WAVE + lane] = pa;
+        eta[slot][(2 * ldr + 1) * WAVE + lane] = pb;
+        if (ldr == 0) eta[slot][(2 * CV_LOADERS) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
     double p1_lo = INFINITY, p1_hi = -INFINITY, p2_lo = INFINITY, p2_hi = -INFINITY;      // (the transition wave: what the predictors reached)
     auto produce = [&](int slot, int s) {                      // stage 1: the transition of row s, whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
-        for (int w = 0; w < CV_WAVES; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
+        for (int w = 0; w < CV_LOADERS; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
         if (s < ns) { p1_lo = fmin(p1_lo, p1); p1_hi = fmax(p1_hi, p1); p2_lo = fmin(p2_lo, p2); p2_hi = fmax(p2_hi, p2); }
-        const double dtc = e_[(2 * CV_WAVES) * WAVE];
+        const double dtc = e_[(2 * CV_LOADERS) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
         Primal::trans(dt, p1, p2, tr);
@@ -614,9 +622,9 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         if (s == s_end - 1 && !last_chunk) F.dump_to(dump1);
         F.save(&fst[lane]);
     };
-    auto columns = [&](int s, int slot3, int slot2) {          // stage 3: the tangents of row s
-        if (s == s_acc && s_acc > s_begin) { S.dump_to(dump0 + NPD * WAVE); S.reset_acc(); }
-        if (s < ns) {
+    auto columns = [&](int s, int slot3, int slot2) {          // stage 3: the tangents of row s (waves that carry columns)
+        if (s == s_acc && s_acc > s_begin) { S.dump_to(dump0 + NPD * WAVE); S.reset_acc(); }      // (a wave without columns too: the check reads the whole record)
+        if (s < ns && n_col > 0) {
             const double* r = &raw[slot3][lane];
             typename Cols::Lin li;
             li.read(&lin[slot2][lane]);
@@ -626,8 +634,8 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
 #pragma unroll
                 for (int k = K0; k < K1; k++) {
                     const double xl = r[chan[k] * WAVE];
-                    X1[k] = fma(xfac[part][k][0], xl, xfac[part][k][1]);
-                    X2[k] = fma(xfac[part][k][2], xl, xfac[part][k][3]);
+                    const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
+                    X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
                 }
                 S.template step<K0, K1>(li, X1, X2);
             };
@@ -651,11 +659,12 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     int r3 = 0;                                                // (t + 3 - s_begin) mod 3 == the ring slot of row t
     auto iter = [&](int t, double (&X)[CV_LD], double (&Y)[CV_LD]) {
         const int sl_t = r3, sl_t1 = r3 == 2 ? 0 : r3 + 1, sl_t2 = r3 == 0 ? 2 : r3 - 1;   // slots of rows t, t + 1, t + 2 (t + 2 == t - 1 mod 3)
-        if (t + 2 >= s_begin) st_raw(X, sl_t2);
-        st_eta(Y, (t + 3) & 1);
-        ld(X, t + 4);
+        if (loader) {
+            if (t + 2 >= s_begin) st_raw(X, sl_t2);
+            st_eta(Y, (t + 3) & 1);
+            ld(X, t + 4);
+        }
         SSDE_CK(0)
-        // (raising the two stage waves' priority over the column waves they share a SIMD with, s_setprio, changed nothing: 1.264 / 1.260 ms)
         if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1, t + 2);
         if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
         SSDE_CK(1)
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         SSDE_CK(3)
         r3 = r3 == 2 ? 0 : r3 + 1;
     };
-    ld(setB, s_begin);                                         // Y of the first iteration (t = s_begin - 3): row s_begin
+    if (loader) ld(setB, s_begin);                             // Y of the first iteration (t = s_begin - 3): row s_begin
     iter(s_begin - 3, setA, setB);
     for (int t = s_begin - 2; t < s_end; t += 2) {             // (s_end - s_begin is a multiple of WIN_ALIGN: an even count)
         iter(t, setB, setA);

@@ -146,36 +146,26 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         std::vector<CvPart> parts(CV_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * CV_WAVES);
         h->cv_pidx.assign((size_t)CV_WAVES * CV_KC, -1);
-        // What a wave's row costs, in fp64 instructions: so much per column it carries, the filter and the directions that ride
-        // on it on wave 0, the exp's and the transition on the last wave.  Waves w and w + 4 share a SIMD, and what the row
-        // takes is what the busiest SIMD has to issue: every column goes to the SIMD with the least work, there to the wave
-        // with fewer columns (the one without a stage first).
-        const bool ct = h->model == SSDE_MODEL_CTCRW;
-        const double c_slot = ct ? (h->d == 2 ? 60.0 : 44.0) : 14.0 + 5.0 * h->d, c_filter = ct ? 390.0 : 150.0, c_trans = ct ? 390.0 : 170.0;
+        // The two stage waves (wave 0: filter, wave 7: transition) are the row's critical path -- long dependent chains -- and
+        // get columns only when the six waves between them are full; those take the columns round robin.
         const int N = (int)cols.size();
         int n_w[CV_WAVES];
         for (int p = 0; p < CV_WAVES; p++) n_w[p] = 0;
+        bool dealt_by_env = false;
         if (const char* e = getenv("SSDE_CV_DEAL")) {              // testing: "n0,n1,...,n7"
             int v[8], tot = 0;
             if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) == 8) {
                 for (int p = 0; p < 8; p++) { v[p] = std::min(std::max(v[p], 0), CV_KC); tot += v[p]; }
-                if (tot == N) for (int p = 0; p < 8; p++) n_w[p] = v[p];
+                if (tot == N) { for (int p = 0; p < 8; p++) n_w[p] = v[p]; dealt_by_env = true; }
             }
         }
-        {
-            int dealt = 0;
-            for (int p = 0; p < CV_WAVES; p++) dealt += n_w[p];
-            double simd[4] = {c_filter, 0.0, 0.0, c_trans};        // wave 0 (filter) sits on SIMD 0, wave 7 (transition) on SIMD 3
-            for (int p = 0; p < CV_WAVES; p++) simd[p & 3] += c_slot * n_w[p];
-            for (; dealt < N; dealt++) {
-                int bs = -1;
-                for (int q = 0; q < 4; q++)
-                    if ((n_w[q] < CV_KC || n_w[q + 4] < CV_KC) && (bs < 0 || simd[q] < simd[bs])) bs = q;
-                // within the SIMD: the wave without a stage, unless it is full or already two ahead
-                int w = (bs == 0) ? 4 : (bs == 3) ? 3 : (n_w[bs] <= n_w[bs + 4] ? bs : bs + 4), other = (w == bs) ? bs + 4 : bs;
-                if (n_w[w] >= CV_KC || ((bs == 0 || bs == 3) && n_w[w] >= n_w[other] + 3 && n_w[other] < CV_KC)) w = other;
-                n_w[w]++; simd[bs] += c_slot;
-            }
+        if (!dealt_by_env) {
+            int left = N;
+            for (int k = 0; k < CV_KC && left > 0; k++)
+                for (int p = 1; p < CV_WAVES - 1 && left > 0; p++) { n_w[p]++; left--; }
+            for (int k = 0; k < CV_KC && left > 0; k++)
+                for (int p : {CV_WAVES - 1, 0})
+                    if (left > 0) { n_w[p]++; left--; }
         }
         int best_kc = 2;
         {
