@@ -636,7 +636,7 @@ static int share_equal_columns(const ssde_desc* d, ssde_handle* h, bool on_dev, 
         return SSDE_OK;
     };
     for (auto& b : h->slots) {
-        if (b.col < 0 || b.par_j != h->d + 1 || b.basis_c >= 0) continue;
+        if (b.col < 0 || b.par_j != h->d + 1 || b.basis_c >= 0) continue;      // (materialised basis blocks live on the device whatever the caller's arrays: left alone)
         for (auto& a : h->slots) {
             if (a.col < 0 || a.par_j != h->d || a.basis_c >= 0) continue;
             bool eq;
@@ -709,11 +709,10 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
-            // whatever the batch.  Columns evaluated from a basis table (ssde_ppbasis) and mixed designs (columns in the drift
-            // AND in tau / nu) stay on that path.
+            // whatever the batch.  Mixed designs (columns in the drift AND in tau / nu) stay on that path.
             bool par_only = !mu_only && !getenv("SSDE_NO_COLVAR");
             for (auto& sl : h->slots)
-                if (sl.col >= 0 && (sl.par_j < h->d || sl.basis_c >= 0)) par_only = false;
+                if (sl.col >= 0 && (sl.par_j < h->d || (sl.basis_c >= 0 && !sl.src))) par_only = false;      // (a basis block materialised at create is a block of columns)
             if (par_only && h->n_seg >= min_tracks && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }

@@ -224,6 +224,58 @@ def test_window_plan_follows_the_range_the_predictors_actually_reach():
     eng.close()
 
 
+def test_a_block_given_as_a_basis_function_is_materialised_and_streamed():
+    """ssde_ppbasis (include/ssde.h): the design block of tau as a piecewise-cubic function of a covariate; the Kalman families
+    materialise it at create, and the lane = track path takes the columns like any others."""
+    from smoothsde_amd.synth import bspline_ppbasis
+    pb0, _ = _batch("CTCRW", 2, 80, 500, 0, 6, seed=51)
+    x = np.clip(0.5 + 0.45 * np.sin(np.arange(pb0.n) * 0.013), 0, 1)
+    basis = [None, None, bspline_ppbasis(x, 7), None]
+    S = [second_difference_penalty(7), second_difference_penalty(6)]
+    pb = capi.Problem("CTCRW", pb0.id, pb0.times, pb0.obs, X_re=[None, None, None, pb0.X_re[3]], S_list=S, basis_re=basis)
+    dense = capi.Problem("CTCRW", pb0.id, pb0.times, pb0.obs, X_re=[None, None, basis[2].dense(), pb0.X_re[3]], S_list=S)
+    rng = np.random.default_rng(2)
+    par = np.r_[np.log(0.12), 0.05, -0.03, np.log(2.0), np.log(0.8), 0.3, 0.2, 0.15 * rng.standard_normal(13)]
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(dense, par))
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_against_the_oracle(seed):
+    """Random model / dimension / block sizes / grid / missing rows / fixed parameters / track lengths."""
+    rng = np.random.default_rng(1000 + seed)
+    model = ["CTCRW", "OU_SSM", "BM_SSM"][rng.integers(3)]
+    d = int(rng.integers(1, 3))
+    k1 = int(rng.choice([0, 3, 4, 6, 9, 12]))
+    k2 = int(rng.choice([0, 3, 5, 8, 11])) if model != "BM_SSM" else 0
+    if k1 == 0 and k2 == 0:
+        k1 = 3
+    fe = bool(rng.integers(2)) and k1 + k2 < 22
+    pb, par = _batch(model, d, int(rng.integers(33, 140)), int(rng.integers(60, 900)), k1, k2, seed=2000 + seed, fe_slope=fe,
+                     ragged=bool(rng.integers(2)), dt=float(rng.choice([0.25, 1.0, 3.0])), same_basis=bool(rng.integers(2)))
+    o, t = pb.obs.copy(), pb.times.copy()
+    if rng.integers(2):
+        na = rng.random(len(t)) < 0.03
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan
+    if rng.integers(2):
+        t = np.cumsum(rng.uniform(0.5, 1.5, len(t)))
+    fixed = (rng.random(pb.n_par_full) < 0.15).astype(np.uint8)
+    fixed[pb.off_fe:pb.off_fe + d] |= np.uint8(rng.integers(2))   # mu held or free
+    pb2 = capi.Problem(model, pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, par_fixed=fixed)
+    par = par + 0.1 * rng.standard_normal(len(par))
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    assert np.all(grad[fixed.astype(bool)] == 0.0)
+    eng.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path():
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
