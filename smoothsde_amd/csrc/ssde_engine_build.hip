@@ -270,6 +270,9 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     if (h->drift == 3) want = std::max(1, (8 * 256 + G - 1) / G);
     if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
     h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
+    // (row-varying tau / nu with few groups: windows down to two alignment units, shorter than their warm-up -- with CUs idle
+    //  the redundant warm-up rows run in parallel, only a workgroup's own chain of rows matters; ssde_engine_iso.hip picks)
+    if (h->drift == 3 && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
     h->want_chunks = std::max(1, std::min(want, h->max_chunks));
     // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows on
     // the general kernel.  With ONE plan -- the shared kernel's few long windows -- the general launch is a handful of
@@ -713,7 +716,10 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             bool par_only = !mu_only && !getenv("SSDE_NO_COLVAR");
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && (sl.par_j < h->d || (sl.basis_c >= 0 && !sl.src))) par_only = false;      // (a basis block materialised at create is a block of columns)
-            if (par_only && h->n_seg >= min_tracks && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
+            // (measured, tools/bench_colvar.py --tracks M --rows 1000, 18 columns: 0.18 / 0.19 / 0.20 / 0.22 / 0.24 ms at M = 32 / 128 /
+            //  256 / 512 / 1024 against 0.11 / 0.18 / 0.22 / 0.32 / 0.50 on the lane = direction path: the crossover is near 128 tracks)
+            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : 160;
+            if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
                 if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; }

@@ -87,6 +87,8 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
         glmax = h->glen_max;
     }
     int nc = h->want_chunks;
+    if (h->drift == 3 && !h->chunks_forced) { while (nc > 1 && (glmax / nc) < 2 * WIN_ALIGN) nc--; }     // (the cost below decides, not a rule)
+    else
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
     if (h->drift == 3 && !h->chunks_forced) {
         // one workgroup per (group, window) and per CU: rounds x (rows of a window + its warm-up) is what the launch takes

@@ -17,6 +17,13 @@ GOLD = load_golden()
 PATH_ISO, PATH_TV = 1, 3
 
 
+@pytest.fixture(autouse=True)
+def _take_the_lane_track_path_from_32_tracks(monkeypatch):
+    """The engine sends row-varying tau / nu batches to this kernel from 160 tracks on (the measured crossover against the
+    lane = direction path); the cases below are smaller so that the oracle stays quick."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
+
+
 def _oracle(pb, par, **kw):
     from oracle_lib import oracle_eval
     return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=8, **kw)
@@ -276,11 +283,18 @@ def test_fuzz_against_the_oracle(seed):
     eng.close()
 
 
-def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path():
+def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatch):
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
     assert eng.info()["path"] == PATH_TV
     eng.close()
+    monkeypatch.delenv("SSDE_DRIFT_MIN_TRACKS")                 # the engine's own threshold: 160 tracks
+    for M, want in ((100, PATH_TV), (200, PATH_ISO)):
+        pbm, _ = _batch("CTCRW", 1, M, 100, 4, 0, seed=9)
+        eng = capi.Engine(pbm)
+        assert eng.info()["path"] == want
+        eng.close()
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
     # a smooth in the drift AND in tau
     pb, _ = _batch("CTCRW", 1, 64, 200, 5, 0, seed=3)
     B = bspline_basis(np.clip(np.linspace(0, 1, pb.n), 0, 1), 4)
