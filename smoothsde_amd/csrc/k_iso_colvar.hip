@@ -272,6 +272,226 @@ struct CvColsCtcrw {
     }
 };
 
+// ---- CTCRW, d = 2, FULL 4 x 4 covariance: a per-row measurement covariance H_i (H_array, nllk_ctcrw.hpp:203-205) couples the two
+// dimensions (and P0 may be anything).  State s = (x0, v0, x1, v1), Z picks components 0 and 2, P symmetric (10 numbers).  With
+// M = T P Z', K = M F^-1, L = T - K Z (nllk_ctcrw.hpp:236-241: P' = T P L' + Q) the tangent of a row is
+//     da' = L (da + dP Z' w) + X seed_a          dP' = L dP L' + X seed_P          d nllk = <C, Z dP Z'> - w' Z da
+// with w = F^-1 u, C = (F^-1 - w w') / 2, seed_P = dT P L' + L P dT' + dQ, seed_a = dT (a + P Z' w) + dB mu.  No log sigma_obs
+// direction (H_i holds no parameter); the drift intercepts are columns of ones of their own kinds (seed_a = B e_a, seed_P = 0).
+struct CvPrimalCtcrwFull {
+    static constexpr int D = 2, SD = 4, NLIN = 34, NCOL = 14, NDUMP = 14, NTR = 12, NSAVE = 14 + 3;
+    typedef CtcrwTrans Trans;
+    double a[4], p[10];                                        // p: 00 01 02 03 11 12 13 22 23 33
+    LogAcc ld;
+    double accq;
+    double gmu[2], sg;                                         // (unused here: the kernel's epilogue reads them)
+    __device__ __forceinline__ void init(const double* a0, const double* p0f) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = a0[i];
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = i; j < 4; j++) p[n++] = p0f[i + 4 * j];
+        ld.init(); accq = 0.0; gmu[0] = gmu[1] = sg = 0.0;
+    }
+    __device__ __forceinline__ void reset_acc() { ld.init(); accq = 0.0; }
+    // y[2], H = (H00, H01, H11) of this row; lin[j * WAVE]: the row's linearisation
+    __device__ __forceinline__ void step(const CtcrwTrans& tr, const double* H, const double* mu, const double* y, bool na, double* lin) {
+        const double p00 = p[0], p01 = p[1], p02 = p[2], p03 = p[3], p11 = p[4], p12 = p[5], p13 = p[6], p22 = p[7], p23 = p[8], p33 = p[9];
+        const double F11 = p00 + H[0], F12 = p02 + H[1], F22 = p22 + H[2];
+        const double detF = fma(F11, F22, -F12 * F12);             // det(): nllk_ctcrw.hpp:16-19
+        const bool upd = !na && !(detF <= 0.0);                    // :214, 226
+        const double updf = upd ? 1.0 : 0.0;
+        const double dete = upd ? detF : 1.0;
+        const double idet = rcp(dete) * updf;
+        ld.mul(dete);                                              // (log detF itself: value() counts it once)
+        const double bm = (na || upd) ? 1.0 : 0.0;                 // Q3 (:226-228)
+        const double i11 = F22 * idet, i12 = -F12 * idet, i22 = F11 * idet;
+        const double e = tr.e, t = tr.t12;
+        const double u0 = upd ? y[0] - a[0] : 0.0, u1 = upd ? y[1] - a[2] : 0.0;
+        const double w0 = fma(i11, u0, i12 * u1), w1 = fma(i12, u0, i22 * u1);
+        accq = fma(u0, w0, fma(u1, w1, accq));
+        // M = T P Z' (4 x 2), K = M F^-1
+        const double m00 = fma(t, p01, p00), m10 = e * p01, m20 = fma(t, p03, p02), m30 = e * p03;
+        const double m01 = fma(t, p12, p02), m11 = e * p12, m21 = fma(t, p23, p22), m31 = e * p23;
+        const double k00 = fma(m00, i11, m01 * i12), k01 = fma(m00, i12, m01 * i22);
+        const double k10 = fma(m10, i11, m11 * i12), k11 = fma(m10, i12, m11 * i22);
+        const double k20 = fma(m20, i11, m21 * i12), k21 = fma(m20, i12, m21 * i22);
+        const double k30 = fma(m30, i11, m31 * i12), k31 = fma(m30, i12, m31 * i22);
+        // L = T - K Z: rows (l00, t, l02, 0), (l10, e, l12, 0), (l20, 0, l22, t), (l30, 0, l32, e)
+        const double l00 = 1.0 - k00, l02 = -k01, l10 = -k10, l12 = -k11, l20 = -k20, l22 = 1.0 - k21, l30 = -k30, l32 = -k31;
+        const double mue0 = bm * mu[0], mue1 = bm * mu[1];
+        int n = 0;
+        lin[(n++) * WAVE] = l00; lin[(n++) * WAVE] = l02; lin[(n++) * WAVE] = l10; lin[(n++) * WAVE] = l12;
+        lin[(n++) * WAVE] = l20; lin[(n++) * WAVE] = l22; lin[(n++) * WAVE] = l30; lin[(n++) * WAVE] = l32;
+        lin[(n++) * WAVE] = t; lin[(n++) * WAVE] = e; lin[(n++) * WAVE] = w0; lin[(n++) * WAVE] = w1;
+        lin[(n++) * WAVE] = 0.5 * fma(-w0, w0, i11); lin[(n++) * WAVE] = fma(-w0, w1, i12); lin[(n++) * WAVE] = 0.5 * fma(-w1, w1, i22);
+        // seed_P of log tau: N = dT P (rows dt12 P1, de P1, dt12 P3, de P3), S[i][j] = N_i . L_j + N_j . L_i + dQ[i][j]
+        {
+            const double P1[4] = {p01, p11, p12, p13}, P3[4] = {p03, p13, p23, p33};
+            const double a1[4] = {fma(l00, P1[0], fma(t, P1[1], l02 * P1[2])), fma(l10, P1[0], fma(e, P1[1], l12 * P1[2])),
+                                  fma(l20, P1[0], fma(l22, P1[2], t * P1[3])), fma(l30, P1[0], fma(l32, P1[2], e * P1[3]))};      // P1 . L_j
+            const double a3[4] = {fma(l00, P3[0], fma(t, P3[1], l02 * P3[2])), fma(l10, P3[0], fma(e, P3[1], l12 * P3[2])),
+                                  fma(l20, P3[0], fma(l22, P3[2], t * P3[3])), fma(l30, P3[0], fma(l32, P3[2], e * P3[3]))};      // P3 . L_j
+            const double dt12 = tr.dt12, de = tr.de;
+            // N_i . L_j: i = 0: dt12 a1[j]; 1: de a1[j]; 2: dt12 a3[j]; 3: de a3[j]
+            lin[(n++) * WAVE] = fma(2.0 * dt12, a1[0], tr.dq11);                        // (0,0)
+            lin[(n++) * WAVE] = fma(dt12, a1[1], fma(de, a1[0], tr.dq12));              // (0,1)
+            lin[(n++) * WAVE] = fma(dt12, a1[2], dt12 * a3[0]);                         // (0,2)
+            lin[(n++) * WAVE] = fma(dt12, a1[3], de * a3[0]);                           // (0,3)
+            lin[(n++) * WAVE] = fma(2.0 * de, a1[1], tr.dq22);                          // (1,1)
+            lin[(n++) * WAVE] = fma(de, a1[2], dt12 * a3[1]);                           // (1,2)
+            lin[(n++) * WAVE] = fma(de, a1[3], de * a3[1]);                             // (1,3)
+            lin[(n++) * WAVE] = fma(2.0 * dt12, a3[2], tr.dq11);                        // (2,2)
+            lin[(n++) * WAVE] = fma(dt12, a3[3], fma(de, a3[2], tr.dq12));              // (2,3)
+            lin[(n++) * WAVE] = fma(2.0 * de, a3[3], tr.dq22);                          // (3,3)
+            // seed_a of log tau: dT (a + P Z' w) + dB mu
+            const double s0 = a[1] - mue0 + fma(p01, w0, p12 * w1), s1 = a[3] - mue1 + fma(p03, w0, p23 * w1);
+            lin[(n++) * WAVE] = dt12 * s0; lin[(n++) * WAVE] = de * s0; lin[(n++) * WAVE] = dt12 * s1; lin[(n++) * WAVE] = de * s1;
+        }
+        lin[(n++) * WAVE] = 2.0 * tr.q11; lin[(n++) * WAVE] = 2.0 * tr.q12; lin[(n++) * WAVE] = 2.0 * tr.q22;       // seed_P of log nu
+        lin[(n++) * WAVE] = bm * tr.b1; lin[(n++) * WAVE] = bm * tr.b2;                                            // seed_a of mu_a
+        // a' = T a + K u + B mu (:238)
+        const double n0 = fma(tr.b1, mue0, fma(k00, u0, fma(k01, u1, fma(t, a[1], a[0]))));
+        const double n1 = fma(tr.b2, mue0, fma(k10, u0, fma(k11, u1, e * a[1])));
+        const double n2 = fma(tr.b1, mue1, fma(k20, u0, fma(k21, u1, fma(t, a[3], a[2]))));
+        const double n3 = fma(tr.b2, mue1, fma(k30, u0, fma(k31, u1, e * a[3])));
+        a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
+        // P' = T P T' - M K' + Q (:240-241, symmetric F): A = T P, then A T'
+        const double A00 = fma(t, p01, p00), A01 = fma(t, p11, p01), A02 = fma(t, p12, p02), A03 = fma(t, p13, p03);
+        const double A11 = e * p11, A12 = e * p12, A13 = e * p13;
+        const double A22 = fma(t, p23, p22), A23 = fma(t, p33, p23);
+        const double A33 = e * p33;
+        p[0] = fma(t, A01, A00) - fma(m00, k00, m01 * k01) + tr.q11;
+        p[1] = e * A01 - fma(m00, k10, m01 * k11) + tr.q12;
+        p[2] = fma(t, A03, A02) - fma(m00, k20, m01 * k21);
+        p[3] = e * A03 - fma(m00, k30, m01 * k31);
+        p[4] = e * A11 - fma(m10, k10, m11 * k11) + tr.q22;
+        p[5] = fma(t, A13, A12) - fma(m10, k20, m11 * k21);
+        p[6] = e * A13 - fma(m10, k30, m11 * k31);
+        p[7] = fma(t, A23, A22) - fma(m20, k20, m21 * k21) + tr.q11;
+        p[8] = e * A23 - fma(m20, k30, m21 * k31) + tr.q12;
+        p[9] = e * A33 - fma(m30, k30, m31 * k31) + tr.q22;
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i * WAVE] = a[i];
+#pragma unroll
+        for (int i = 0; i < 10; i++) o[(4 + i) * WAVE] = p[i];
+    }
+    __device__ __forceinline__ void save(double* o) const {
+        dump_to(o);
+        o[14 * WAVE] = accq; o[15 * WAVE] = ld.m; o[16 * WAVE] = (double)ld.e;
+    }
+    __device__ __forceinline__ void restore(const double* o) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = o[i * WAVE];
+#pragma unroll
+        for (int i = 0; i < 10; i++) p[i] = o[(4 + i) * WAVE];
+        accq = o[14 * WAVE]; ld.m = o[15 * WAVE]; ld.e = (int)o[16 * WAVE];
+        gmu[0] = gmu[1] = sg = 0.0;
+    }
+    __device__ __forceinline__ double value() const { return 0.5 * (ld.value() + accq); }      // (ld holds log det F of both dimensions)
+    static __device__ __forceinline__ void trans(double dt, double p1, double p2, CtcrwTrans& tr) { CvPrimalCtcrw<2>::trans(dt, p1, p2, tr); }
+    static __device__ __forceinline__ void put_trans(double* o, const CtcrwTrans& t) { CvPrimalCtcrw<2>::put_trans(o, t); }
+    static __device__ __forceinline__ void get_trans(const double* o, CtcrwTrans& t) { CvPrimalCtcrw<2>::get_trans(o, t); }
+};
+
+// the column tangents of a wave, CTCRW d = 2, full covariance: dP (10) and da (4) per column.  X[k][j]: the column's value if it is
+// of kind j (0: feeds log tau, 1: log nu, 2: mu_1, 3: mu_2), else 0
+template <int KC>
+struct CvColsCtcrwFull {
+    static constexpr int NCOL = 14;
+    double dp[KC][10], da[KC][4], g[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            g[k] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) dp[k][i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) da[k][i] = 0.0;
+        }
+    }
+    __device__ __forceinline__ void reset_acc() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) g[k] = 0.0;
+    }
+    struct Lin {
+        double l00, l02, l10, l12, l20, l22, l30, l32, t, e, w0, w1, c00, c02, c22, s1[10], sa[4], s2[3], sb[2];
+        __device__ __forceinline__ void read(const double* lin) {
+            int n = 0;
+            l00 = lin[(n++) * WAVE]; l02 = lin[(n++) * WAVE]; l10 = lin[(n++) * WAVE]; l12 = lin[(n++) * WAVE];
+            l20 = lin[(n++) * WAVE]; l22 = lin[(n++) * WAVE]; l30 = lin[(n++) * WAVE]; l32 = lin[(n++) * WAVE];
+            t = lin[(n++) * WAVE]; e = lin[(n++) * WAVE]; w0 = lin[(n++) * WAVE]; w1 = lin[(n++) * WAVE];
+            c00 = lin[(n++) * WAVE]; c02 = lin[(n++) * WAVE]; c22 = lin[(n++) * WAVE];
+#pragma unroll
+            for (int i = 0; i < 10; i++) s1[i] = lin[(n++) * WAVE];
+#pragma unroll
+            for (int i = 0; i < 4; i++) sa[i] = lin[(n++) * WAVE];
+#pragma unroll
+            for (int i = 0; i < 3; i++) s2[i] = lin[(n++) * WAVE];
+#pragma unroll
+            for (int i = 0; i < 2; i++) sb[i] = lin[(n++) * WAVE];
+        }
+    };
+    template <int K0, int K1>
+    __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            const double* d = dp[k];                               // 00 01 02 03 11 12 13 22 23 33
+            const double x1 = X[k][0], x2 = X[k][1], x3 = X[k][2], x4 = X[k][3];
+            g[k] = fma(L.c00, d[0], fma(L.c02, d[2], fma(L.c22, d[7], fma(-L.w0, da[k][0], fma(-L.w1, da[k][2], g[k])))));
+            // z = da + dP Z' w
+            const double z0 = fma(d[0], L.w0, fma(d[2], L.w1, da[k][0])), z1 = fma(d[1], L.w0, fma(d[5], L.w1, da[k][1]));
+            const double z2 = fma(d[2], L.w0, fma(d[7], L.w1, da[k][2])), z3 = fma(d[3], L.w0, fma(d[8], L.w1, da[k][3]));
+            da[k][0] = fma(x3, L.sb[0], fma(x1, L.sa[0], fma(L.l00, z0, fma(L.t, z1, L.l02 * z2))));
+            da[k][1] = fma(x3, L.sb[1], fma(x1, L.sa[1], fma(L.l10, z0, fma(L.e, z1, L.l12 * z2))));
+            da[k][2] = fma(x4, L.sb[0], fma(x1, L.sa[2], fma(L.l20, z0, fma(L.l22, z2, L.t * z3))));
+            da[k][3] = fma(x4, L.sb[1], fma(x1, L.sa[3], fma(L.l30, z0, fma(L.l32, z2, L.e * z3))));
+            // R = L dP L' (symmetric), row by row: G_i = L_i dP (a 4-vector), R[i][j] = G_i . L_j for j >= i
+            const double q0 = d[0], q1 = d[1], q2 = d[2], q3 = d[3], q4 = d[4], q5 = d[5], q6 = d[6], q7 = d[7], q8 = d[8], q9 = d[9];
+            {
+                const double G0 = fma(L.l00, q0, fma(L.t, q1, L.l02 * q2)), G1 = fma(L.l00, q1, fma(L.t, q4, L.l02 * q5));
+                const double G2 = fma(L.l00, q2, fma(L.t, q5, L.l02 * q7)), G3 = fma(L.l00, q3, fma(L.t, q6, L.l02 * q8));
+                dp[k][0] = fma(x2, L.s2[0], fma(x1, L.s1[0], fma(L.l00, G0, fma(L.t, G1, L.l02 * G2))));
+                dp[k][1] = fma(x2, L.s2[1], fma(x1, L.s1[1], fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
+                dp[k][2] = fma(x1, L.s1[2], fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
+                dp[k][3] = fma(x1, L.s1[3], fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
+            }
+            {
+                const double G0 = fma(L.l10, q0, fma(L.e, q1, L.l12 * q2)), G1 = fma(L.l10, q1, fma(L.e, q4, L.l12 * q5));
+                const double G2 = fma(L.l10, q2, fma(L.e, q5, L.l12 * q7)), G3 = fma(L.l10, q3, fma(L.e, q6, L.l12 * q8));
+                dp[k][4] = fma(x2, L.s2[2], fma(x1, L.s1[4], fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
+                dp[k][5] = fma(x1, L.s1[5], fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
+                dp[k][6] = fma(x1, L.s1[6], fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
+            }
+            {
+                const double G0 = fma(L.l20, q0, fma(L.l22, q2, L.t * q3)), G2 = fma(L.l20, q2, fma(L.l22, q7, L.t * q8));
+                const double G3 = fma(L.l20, q3, fma(L.l22, q8, L.t * q9));
+                dp[k][7] = fma(x2, L.s2[0], fma(x1, L.s1[7], fma(L.l20, G0, fma(L.l22, G2, L.t * G3))));
+                dp[k][8] = fma(x2, L.s2[1], fma(x1, L.s1[8], fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
+            }
+            {
+                const double G0 = fma(L.l30, q0, fma(L.l32, q2, L.e * q3)), G2 = fma(L.l30, q2, fma(L.l32, q7, L.e * q8));
+                const double G3 = fma(L.l30, q3, fma(L.l32, q8, L.e * q9));
+                dp[k][9] = fma(x2, L.s2[2], fma(x1, L.s1[9], fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
+            }
+        }
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) o[(n++) * WAVE] = dp[k][i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[(n++) * WAVE] = da[k][i];
+        }
+    }
+};
+
 // ---- OU_SSM / BM_SSM: scalar covariance --------------------------------------------------------------------------------
 template <int D, bool HAS_P2>
 struct CvPrimalScal {
@@ -450,17 +670,20 @@ struct CvColsScal {
     }
 };
 
-template <int MODEL, int D, int KC>
+template <int MODEL, int D, int KC, bool FULL>
 struct CvModel;
 template <int D, int KC>
-struct CvModel<M_CTCRW, D, KC> { typedef CvPrimalCtcrw<D> Primal; typedef CvColsCtcrw<D, KC> Cols; };
+struct CvModel<M_CTCRW, D, KC, false> { typedef CvPrimalCtcrw<D> Primal; typedef CvColsCtcrw<D, KC> Cols; };
 template <int D, int KC>
-struct CvModel<M_OU_SSM, D, KC> { typedef CvPrimalScal<D, true> Primal; typedef CvColsScal<D, KC, true> Cols; };
+struct CvModel<M_OU_SSM, D, KC, false> { typedef CvPrimalScal<D, true> Primal; typedef CvColsScal<D, KC, true> Cols; };
 template <int D, int KC>
-struct CvModel<M_BM_SSM, D, KC> { typedef CvPrimalScal<D, false> Primal; typedef CvColsScal<D, KC, false> Cols; };
+struct CvModel<M_BM_SSM, D, KC, false> { typedef CvPrimalScal<D, false> Primal; typedef CvColsScal<D, KC, false> Cols; };
+template <int KC>
+struct CvModel<M_CTCRW, 2, KC, true> { typedef CvPrimalCtcrwFull Primal; typedef CvColsCtcrwFull<KC> Cols; };
 
 // components of a part's hand-over dump with kc column slots: the filter's block (written by part 0), then the columns
-int colvar_nstate(int model, int d, int kc) {
+int colvar_nstate(int model, int d, int kc, bool full) {
+    if (full) return 14 + kc * 14;                            // CTCRW, d = 2, 4 x 4 covariance
     return model == M_CTCRW ? 2 * d + 5 + (3 + 2 * d) + kc * (3 + 2 * d) : d + 2 + (1 + d) + kc * (1 + d);
 }
 
@@ -468,18 +691,18 @@ int colvar_nstate(int model, int d, int kc) {
 // accumulators of a part: [value | column 0 .. CV_KC-1 | mu_1 .. mu_d | log sigma_obs]   (value, mu, sigma_obs: part 0)
 constexpr int CV_PRODUCER = CV_WAVES - 1;                               // the wave that builds the transitions
 constexpr int CV_LOADERS = CV_WAVES - 2;                                // the waves between the two stage waves stage the rows
-constexpr int CV_LD = (1 + 2 + DRIFT_KMAX + CV_LOADERS - 1) / CV_LOADERS;   // channels a loading wave handles per row (dt, y, the streamed columns)
-constexpr int CV_CMAX = CV_LD * CV_LOADERS;                             // channels of a staged row
+constexpr int CV_LD = (CV_CMAX + CV_LOADERS - 1) / CV_LOADERS;          // channels a loading wave handles per row (dt, y, H_array entries, the streamed columns)
+static_assert(CV_LD * CV_LOADERS >= CV_CMAX && CV_CMAX >= 1 + 2 + 4 + DRIFT_KMAX, "ring of rows too narrow");
 constexpr int CV_FILTER = 0;                                            // the wave that runs the primal filter
 
 // KC: column slots per wave (even; the engine picks the instantiation from the widest part)
-template <int MODEL, int D, int KC>
+template <int MODEL, int D, int KC, bool FULL>
 __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
-    typedef typename CvModel<MODEL, D, KC>::Primal Primal;
-    typedef typename CvModel<MODEL, D, KC>::Cols Cols;
+    typedef typename CvModel<MODEL, D, KC, FULL>::Primal Primal;
+    typedef typename CvModel<MODEL, D, KC, FULL>::Cols Cols;
     typedef typename Primal::Trans Trans;
     constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
-    __shared__ double raw[3][CV_CMAX * WAVE];                  // the staged rows
+    __shared__ double raw[3][CV_LD * CV_LOADERS * WAVE];       // the staged rows
     __shared__ double eta[2][(2 * CV_LOADERS + 1) * WAVE];     // per row: the loading waves' partial sums of p1, p2, and the interval
     __shared__ double trs[2][NTR * WAVE];                      // per row: the transition
     __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
@@ -520,7 +743,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     // (bit masks: the selects are VALU work, of which this kernel has plenty to spare; an LDS table of 0/1 factors cost
     // 16 more LDS reads per wave and row on the LDS pipe, which it has not)
     int chan[KC];
-    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0;
+    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0, t3_bits = 0, t4_bits = 0;      // (kinds 3, 4: the drift of dimension 1, 2 -- full-covariance lanes)
 #pragma unroll
     for (int k = 0; k < KC; k++) {
         const bool on = k < n_col;
@@ -529,6 +752,8 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         if (ch == -1) ones_bits |= 1u << k;
         if (ty == 1) t1_bits |= 1u << k;
         if (ty == 2) t2_bits |= 1u << k;
+        if (ty == 3) t3_bits |= 1u << k;
+        if (ty == 4) t4_bits |= 1u << k;
     }
     const double* base = tv.tiles + tv.group_off[g] + lane;
     const int L = tv.group_len[g];
@@ -598,7 +823,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
                 else a0[a] = (y0 == y0) ? y0 : 0.0;
             }
         }
-        F.init(a0, A.p0);
+        if constexpr (FULL) F.init(a0, A.cv_p0); else F.init(a0, A.p0);
         F.save(&fst[lane]);
     }
     double mu[D];
@@ -617,7 +842,11 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             for (int a = 0; a < D; a++) y[a] = r[(c_obs + a) * WAVE];
             Trans tr;
             Primal::get_trans(&trs[slot2][lane], tr);
-            F.step(tr, h, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
+            if constexpr (FULL) {
+                double H[3] = {h, 0.0, h};                          // H_array[,,i] (symmetric, checked at create)
+                if (A.cv_has_h) { H[0] = r[(c_obs + D) * WAVE]; H[1] = r[(c_obs + D + 2) * WAVE]; H[2] = r[(c_obs + D + 3) * WAVE]; }
+                F.step(tr, H, mu, y, is_na(y[0], A.any_nan), lo);
+            } else F.step(tr, h, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
         }
         if (s == s_end - 1 && !last_chunk) F.dump_to(dump1);
         F.save(&fst[lane]);
@@ -630,14 +859,26 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             li.read(&lin[slot2][lane]);
             auto quarter = [&](auto k0) {                          // (a wave that also runs a stage is dealt fewer slots: whole quarters are skipped)
                 constexpr int K0 = decltype(k0)::value, K1 = K0 + (KC + 3) / 4 < KC ? K0 + (KC + 3) / 4 : KC;
-                double X1[KC], X2[KC];
+                if constexpr (FULL) {
+                    double X[KC][4];
 #pragma unroll
-                for (int k = K0; k < K1; k++) {
-                    const double xl = r[chan[k] * WAVE];
-                    const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
-                    X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+                    for (int k = K0; k < K1; k++) {
+                        const double xl = r[chan[k] * WAVE];
+                        const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
+                        X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+                        X[k][2] = ((t3_bits >> k) & 1u) ? xk : 0.0; X[k][3] = ((t4_bits >> k) & 1u) ? xk : 0.0;
+                    }
+                    S.template step<K0, K1>(li, X);
+                } else {
+                    double X1[KC], X2[KC];
+#pragma unroll
+                    for (int k = K0; k < K1; k++) {
+                        const double xl = r[chan[k] * WAVE];
+                        const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
+                        X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+                    }
+                    S.template step<K0, K1>(li, X1, X2);
                 }
-                S.template step<K0, K1>(li, X1, X2);
             };
             constexpr int Q = (KC + 3) / 4;
             if (n_col > 0) quarter(std::integral_constant<int, 0>());
@@ -773,6 +1014,36 @@ hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pi
     return hipGetLastError();
 }
 
+// per group: the largest diagonal entry of H_array[,,i] over its rows, and the largest |H01 - H10| (create time: the window
+// planner's observation variance; the full-covariance lanes take a symmetric H)
+__global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileView tv, int c_h, double* out /* [n_groups][2] */) {
+    __shared__ double sh[WG_WAVES][2];
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    double hmax = 0.0, asym = 0.0;
+    for (int s = wv; s < ns; s += WG_WAVES) {
+        const double* p = base + ((int64_t)s * tv.C + c_h) * WAVE;
+        const double h00 = p[0], h10 = p[WAVE], h01 = p[2 * WAVE], h11 = p[3 * WAVE];
+        hmax = fmax(hmax, fmax(h00, h11));
+        asym = fmax(asym, fabs(h01 - h10));
+        if (!(h00 == h00) || !(h11 == h11) || !(h01 == h01) || !(h10 == h10)) asym = INFINITY;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { hmax = fmax(hmax, __shfl_xor(hmax, o, 64)); asym = fmax(asym, __shfl_xor(asym, o, 64)); }
+    if (lane == 0) { sh[wv][0] = hmax; sh[wv][1] = asym; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < WG_WAVES; w++) { hmax = fmax(hmax, sh[w][0]); asym = fmax(asym, sh[w][1]); }
+        out[2 * g] = hmax; out[2 * g + 1] = asym;
+    }
+}
+hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, double* out, hipStream_t s) {
+    if (tv.n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(colvar_h_stats_kernel, dim3(tv.n_groups), dim3(WG_WAVES * WAVE), 0, s, tv, c_h, out);
+    return hipGetLastError();
+}
+
 // are two design columns (device arrays of n doubles) the same numbers?  *differ is raised if not (create time)
 __global__ __launch_bounds__(256) void cols_differ_kernel(const double* a, const double* b, int64_t n, int* differ) {
     bool d = false;
@@ -791,14 +1062,21 @@ hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* 
 // part's column count
 template <int MODEL, int D>
 static hipError_t launch_cv(const IsoArgs& a, const CvPart* parts, int kc, dim3 grid, dim3 block, hipStream_t s) {
-    if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2>), grid, block, 0, s, a, parts);
-    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4>), grid, block, 0, s, a, parts);
+    if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2, false>), grid, block, 0, s, a, parts);
+    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4, false>), grid, block, 0, s, a, parts);
     return hipGetLastError();
 }
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s) {
     if (a.n_parts != CV_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
     dim3 grid(a.tv.n_groups * a.n_chunks), block(CV_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
+    if (a.cv_full) {                                           // 4 x 4 covariance lanes: CTCRW, d = 2
+        if (model != M_CTCRW || d != 2) return hipErrorInvalidValue;
+        if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 2, true>), grid, block, 0, s, a, parts);
+        else if (kc <= 3) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 3, true>), grid, block, 0, s, a, parts);
+        else hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 4, true>), grid, block, 0, s, a, parts);
+        return hipGetLastError();
+    }
 #define SSDE_CASE(M_, D_) if (model == M_ && d == D_) return launch_cv<M_, D_>(a, parts, kc, grid, block, s);
     SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)
 #undef SSDE_CASE

@@ -124,9 +124,13 @@ struct IsoArgs {
     // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
     double cv_eta0[2];
     double* cv_ranges;           // [workgroup][4]: min / max of p1, min / max of p2 over the workgroup's rows, or NULL
+    int cv_full;                 // 4 x 4 covariance lanes (CTCRW, d = 2): per-row H_array and / or a P0 that is not block-identical
+    int cv_has_h;                // ... the tiles hold H_array[,,i] in the d^2 channels after the observations
+    double cv_p0[16];            // ... P0, column-major
 };
 // One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients one wave of the workgroups carries
 // (device table, CV_WAVES entries)
+constexpr int CV_CMAX = 32;      // channels of a row the kernel can stage: dt, y, H_array entries (d = 2), DRIFT_KMAX columns
 constexpr int CV_WAVES = 8;      // waves of a workgroup = parts: two per SIMD
 constexpr int CV_KC = 4;         // columns per part (register budget of a wave at two per SIMD)
 struct CvPart {
@@ -134,14 +138,15 @@ struct CvPart {
     int32_t with_mu;             // the part also carries the drift-intercept direction
     int32_t with_sig;            // ... the log sigma_obs direction
     int32_t chan[CV_KC];         // tile channel of the slot's design column, -1 = a column of ones (an intercept)
-    int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa)
+    int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa); full-covariance lanes: 3, 4 = mu_1, mu_2
 };
 // partials [n_parts * n_chunks][2 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d | log sigma_obs;
 // a.n_parts == CV_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
-int colvar_nstate(int model, int d, int kc);
+int colvar_nstate(int model, int d, int kc, bool full);
 hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pinned /* 4 doubles, host-visible */, hipStream_t s);
 hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* differ /* device, zeroed */, hipStream_t s);
+hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, double* out /* [n_groups][2]: max diag(H), max |H01 - H10| */, hipStream_t s);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance
 // direction, one block for mu

@@ -138,7 +138,11 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // waves of a workgroup (k_iso_colvar.hip)
         struct Col { int type, chan, pidx; };
         std::vector<Col> cols;
-        const int c_col = h->c_obs + h->d;
+        const int c_col = h->c_obs + h->d + (h->has_h ? h->d * h->d : 0);
+        if (h->C > CV_CMAX) return SSDE_RETRY_WITHOUT_DRIFT;
+        if (h->cv_full)                                            // the drift intercepts are columns of ones of kinds 3, 4 on those lanes
+            for (auto& sl : h->slots)
+                if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) cols.push_back({3 + sl.par_j, -1, sl.pidx});
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
@@ -181,9 +185,11 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         }
         // the log sigma_obs and drift-intercept directions ride on the wave that runs the filter
         h->cv_sig_part = h->cv_mu_part = -1;
-        if (!h->fixed[0]) { parts[0].with_sig = 1; h->cv_sig_part = 0; }
-        for (auto& sl : h->slots)
-            if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
+        if (!h->cv_full) {
+            if (!h->fixed[0]) { parts[0].with_sig = 1; h->cv_sig_part = 0; }
+            for (auto& sl : h->slots)
+                if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
+        }
         h->cv_kc = best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
         HIPCHK(h, hipHostMalloc((void**)&h->cv_ranges_pinned, 4 * sizeof(double), hipHostMallocDefault));
@@ -207,7 +213,22 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = colvar_nstate(h->model, h->d, h->cv_kc);
+        h->drift_nstate = colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
+        if (h->has_h) {
+            DevBuf<double> hs;
+            HIPCHK(h, hs.alloc((size_t)G * 2));
+            TileView tv;
+            memset(&tv, 0, sizeof(tv));
+            tv.tiles = h->tiles.p; tv.group_off = h->group_off.p; tv.group_len = h->group_len.p; tv.lane_nsteps = h->lane_nsteps.p;
+            tv.n_groups = G; tv.C = h->C; tv.c_obs = h->c_obs;
+            HIPCHK(h, launch_colvar_h_stats(tv, h->c_obs + h->d, hs.p, 0));
+            std::vector<double> hh((size_t)G * 2);
+            HIPCHK(h, hipMemcpy(hh.data(), hs.p, hh.size() * 8, hipMemcpyDeviceToHost));
+            double asym = 0.0;
+            h->cv_hmax = 0.0;
+            for (int g = 0; g < G; g++) { h->cv_hmax = std::max(h->cv_hmax, hh[2 * (size_t)g]); asym = std::max(asym, hh[2 * (size_t)g + 1]); }
+            if (!(asym == 0.0) || !(h->cv_hmax > 0.0) || !std::isfinite(h->cv_hmax)) return SSDE_RETRY_WITHOUT_DRIFT;     // (not a covariance: the literal path)
+        }
     } else
     if (h->drift) {
         // regular grid and every track complete: the shared-covariance lanes; otherwise the lanes carry their own covariance
@@ -702,14 +723,17 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // complete tracks (which the tiling pass below finds out) the covariance half is as data-independent as with constant
         // coefficients and the shared-covariance lanes run; otherwise the lanes carry their own covariance.  Few tracks (C1:
         // one animal) stay on the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
-        if (!iso_ok && allow_drift && !h->has_h && !h->const_coeff && p0_is_isotropic(d, h->p0_iso) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
+        // (a per-row H_array couples the dimensions: CTCRW with d = 2 has 4 x 4 covariance lanes in k_iso_colvar.hip, any P0)
+        const bool iso_cfg = !h->has_h && p0_is_isotropic(d, h->p0_iso);
+        const bool full_cfg = h->has_h && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_NO_COLVAR_FULL");
+        if (!iso_ok && allow_drift && (iso_cfg || full_cfg) && !h->const_coeff && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
             !getenv("SSDE_NO_DRIFT")) {
             bool mu_only = true;
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;
             int min_tracks = 32;
             if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
-            if (mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
+            if (iso_cfg && mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.  Mixed designs (columns in the drift AND in tau / nu) stay on that path.
@@ -722,7 +746,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
-                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; }
+                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = !iso_cfg; }
                 else return SSDE_RETRY_WITHOUT_DRIFT;              // (the slots were renumbered: start over)
             }
         }

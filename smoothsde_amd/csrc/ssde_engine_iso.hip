@@ -240,7 +240,10 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             h->cv_eta_lo[j] += std::min(b * lo, b * hi);
             h->cv_eta_hi[j] += std::max(b * lo, b * hi);
         }
-        a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+        a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d + (h->has_h ? h->d * h->d : 0);
+        a.cv_full = h->cv_full ? 1 : 0; a.cv_has_h = h->has_h ? 1 : 0;
+        for (int i = 0; i < 16; i++) a.cv_p0[i] = h->p0_full[i];
+        if (h->has_h) a.h = h->cv_hmax;                         // (the window planner's observation variance; the lanes read H_array[,,i])
         // ... which is loose (a partition-of-unity basis reaches max |coef|, the bound says sum |coef|): once a launch has run,
         // the range it actually saw, widened by a quarter of its width (+ 0.05), bounds the plan; a parameter jump that leaves
         // it fails the hand-over check and the retry plans from that evaluation's own range

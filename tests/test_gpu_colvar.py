@@ -283,6 +283,67 @@ def test_fuzz_against_the_oracle(seed):
     eng.close()
 
 
+def _with_h(pb, seed, scale=0.1, floor=0.01):
+    """per-row 2 x 2 error ellipses (Argos-like): H_array[,,i] = A_i A_i' + floor I.  (Of the size of the simulated measurement
+    noise: with H two orders of magnitude below the state covariance the reference's literal update P' = T P L' + Q is itself
+    unstable over hundreds of rows -- the oracle, the lane = direction lanes and these lanes then each give a different number.)"""
+    n = pb.n
+    A = np.random.default_rng(seed).standard_normal((n, 2, 2)) * scale
+    return np.einsum("nij,nkj->ikn", A, A) + floor * np.eye(2)[:, :, None]
+
+
+H_GOLD = [r for r in GOLD if r["name"] == "CTCRW_d2_tv_H_P0"]
+
+
+@pytest.mark.parametrize("rec", H_GOLD, ids=[r["name"] for r in H_GOLD])
+def test_golden_case_with_h_array_and_a_general_p0_on_the_full_covariance_lanes(rec, monkeypatch):
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    aest = eng.report(rec["par"])
+    assert np.allclose(aest, rec["expected"]["aest_all"], rtol=1e-10, atol=1e-10)
+    eng.close()
+
+
+@pytest.mark.parametrize("k1,k2,what", [(9, 9, "plain"), (5, 0, "missing"), (0, 7, "irregular"), (6, 6, "both")])
+def test_per_row_measurement_covariance_vs_oracle(k1, k2, what, monkeypatch):
+    """H_array (nllk_ctcrw.hpp:203-205): 4 x 4 covariance lanes, one tangent of 14 doubles per design column; drift intercepts free."""
+    pb, par = _batch("CTCRW", 2, 96, 900, k1, k2, seed=61, same_basis=(what == "plain"))
+    o, t = pb.obs.copy(), pb.times.copy()
+    rng = np.random.default_rng(6)
+    if what in ("missing", "both"):
+        na = rng.random(len(t)) < 0.05
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    P0 = None
+    if what == "both":
+        A = rng.standard_normal((4, 4))
+        P0 = A @ A.T + np.eye(4)
+    pb2 = capi.Problem("CTCRW", pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, H=_with_h(pb, 7), P0=P0)
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    assert grad[0] == 0.0                                       # log sigma_obs is not in the model when H_array is given
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb2, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    # the lane = direction full-covariance lanes on the same problem
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb2)
+    assert e2.info()["path"] == PATH_TV
+    v2, g2 = e2.eval(par)
+    assert abs(val - v2) <= 1e-10 * abs(val) and np.max(np.abs(grad - g2)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e2.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatch):
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
