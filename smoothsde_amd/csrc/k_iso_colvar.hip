@@ -418,23 +418,23 @@ struct CvColsCtcrwFull {
 #pragma unroll
         for (int k = 0; k < KC; k++) g[k] = 0.0;
     }
+    // (the nine numbers of L, w and C stay in registers for the row; the seed vectors -- 19 doubles -- are read from LDS where a
+    //  column needs them: with them resident a wave of four columns spilled 800 bytes per lane to scratch)
     struct Lin {
-        double l00, l02, l10, l12, l20, l22, l30, l32, t, e, w0, w1, c00, c02, c22, s1[10], sa[4], s2[3], sb[2];
+        double l00, l02, l10, l12, l20, l22, l30, l32, t, e, w0, w1, c00, c02, c22;
+        const double* seeds;                                   // s1[10] | sa[4] | s2[3] | sb[2], each [j * WAVE]
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             l00 = lin[(n++) * WAVE]; l02 = lin[(n++) * WAVE]; l10 = lin[(n++) * WAVE]; l12 = lin[(n++) * WAVE];
             l20 = lin[(n++) * WAVE]; l22 = lin[(n++) * WAVE]; l30 = lin[(n++) * WAVE]; l32 = lin[(n++) * WAVE];
             t = lin[(n++) * WAVE]; e = lin[(n++) * WAVE]; w0 = lin[(n++) * WAVE]; w1 = lin[(n++) * WAVE];
             c00 = lin[(n++) * WAVE]; c02 = lin[(n++) * WAVE]; c22 = lin[(n++) * WAVE];
-#pragma unroll
-            for (int i = 0; i < 10; i++) s1[i] = lin[(n++) * WAVE];
-#pragma unroll
-            for (int i = 0; i < 4; i++) sa[i] = lin[(n++) * WAVE];
-#pragma unroll
-            for (int i = 0; i < 3; i++) s2[i] = lin[(n++) * WAVE];
-#pragma unroll
-            for (int i = 0; i < 2; i++) sb[i] = lin[(n++) * WAVE];
+            seeds = lin + n * WAVE;
         }
+        __device__ __forceinline__ double s1(int i) const { return seeds[i * WAVE]; }
+        __device__ __forceinline__ double sa(int i) const { return seeds[(10 + i) * WAVE]; }
+        __device__ __forceinline__ double s2(int i) const { return seeds[(14 + i) * WAVE]; }
+        __device__ __forceinline__ double sb(int i) const { return seeds[(17 + i) * WAVE]; }
     };
     template <int K0, int K1>
     __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
@@ -446,37 +446,37 @@ struct CvColsCtcrwFull {
             // z = da + dP Z' w
             const double z0 = fma(d[0], L.w0, fma(d[2], L.w1, da[k][0])), z1 = fma(d[1], L.w0, fma(d[5], L.w1, da[k][1]));
             const double z2 = fma(d[2], L.w0, fma(d[7], L.w1, da[k][2])), z3 = fma(d[3], L.w0, fma(d[8], L.w1, da[k][3]));
-            da[k][0] = fma(x3, L.sb[0], fma(x1, L.sa[0], fma(L.l00, z0, fma(L.t, z1, L.l02 * z2))));
-            da[k][1] = fma(x3, L.sb[1], fma(x1, L.sa[1], fma(L.l10, z0, fma(L.e, z1, L.l12 * z2))));
-            da[k][2] = fma(x4, L.sb[0], fma(x1, L.sa[2], fma(L.l20, z0, fma(L.l22, z2, L.t * z3))));
-            da[k][3] = fma(x4, L.sb[1], fma(x1, L.sa[3], fma(L.l30, z0, fma(L.l32, z2, L.e * z3))));
+            da[k][0] = fma(x3, L.sb(0), fma(x1, L.sa(0), fma(L.l00, z0, fma(L.t, z1, L.l02 * z2))));
+            da[k][1] = fma(x3, L.sb(1), fma(x1, L.sa(1), fma(L.l10, z0, fma(L.e, z1, L.l12 * z2))));
+            da[k][2] = fma(x4, L.sb(0), fma(x1, L.sa(2), fma(L.l20, z0, fma(L.l22, z2, L.t * z3))));
+            da[k][3] = fma(x4, L.sb(1), fma(x1, L.sa(3), fma(L.l30, z0, fma(L.l32, z2, L.e * z3))));
             // R = L dP L' (symmetric), row by row: G_i = L_i dP (a 4-vector), R[i][j] = G_i . L_j for j >= i
             const double q0 = d[0], q1 = d[1], q2 = d[2], q3 = d[3], q4 = d[4], q5 = d[5], q6 = d[6], q7 = d[7], q8 = d[8], q9 = d[9];
             {
                 const double G0 = fma(L.l00, q0, fma(L.t, q1, L.l02 * q2)), G1 = fma(L.l00, q1, fma(L.t, q4, L.l02 * q5));
                 const double G2 = fma(L.l00, q2, fma(L.t, q5, L.l02 * q7)), G3 = fma(L.l00, q3, fma(L.t, q6, L.l02 * q8));
-                dp[k][0] = fma(x2, L.s2[0], fma(x1, L.s1[0], fma(L.l00, G0, fma(L.t, G1, L.l02 * G2))));
-                dp[k][1] = fma(x2, L.s2[1], fma(x1, L.s1[1], fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
-                dp[k][2] = fma(x1, L.s1[2], fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
-                dp[k][3] = fma(x1, L.s1[3], fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
+                dp[k][0] = fma(x2, L.s2(0), fma(x1, L.s1(0), fma(L.l00, G0, fma(L.t, G1, L.l02 * G2))));
+                dp[k][1] = fma(x2, L.s2(1), fma(x1, L.s1(1), fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
+                dp[k][2] = fma(x1, L.s1(2), fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
+                dp[k][3] = fma(x1, L.s1(3), fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
             }
             {
                 const double G0 = fma(L.l10, q0, fma(L.e, q1, L.l12 * q2)), G1 = fma(L.l10, q1, fma(L.e, q4, L.l12 * q5));
                 const double G2 = fma(L.l10, q2, fma(L.e, q5, L.l12 * q7)), G3 = fma(L.l10, q3, fma(L.e, q6, L.l12 * q8));
-                dp[k][4] = fma(x2, L.s2[2], fma(x1, L.s1[4], fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
-                dp[k][5] = fma(x1, L.s1[5], fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
-                dp[k][6] = fma(x1, L.s1[6], fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
+                dp[k][4] = fma(x2, L.s2(2), fma(x1, L.s1(4), fma(L.l10, G0, fma(L.e, G1, L.l12 * G2))));
+                dp[k][5] = fma(x1, L.s1(5), fma(L.l20, G0, fma(L.l22, G2, L.t * G3)));
+                dp[k][6] = fma(x1, L.s1(6), fma(L.l30, G0, fma(L.l32, G2, L.e * G3)));
             }
             {
                 const double G0 = fma(L.l20, q0, fma(L.l22, q2, L.t * q3)), G2 = fma(L.l20, q2, fma(L.l22, q7, L.t * q8));
                 const double G3 = fma(L.l20, q3, fma(L.l22, q8, L.t * q9));
-                dp[k][7] = fma(x2, L.s2[0], fma(x1, L.s1[7], fma(L.l20, G0, fma(L.l22, G2, L.t * G3))));
-                dp[k][8] = fma(x2, L.s2[1], fma(x1, L.s1[8], fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
+                dp[k][7] = fma(x2, L.s2(0), fma(x1, L.s1(7), fma(L.l20, G0, fma(L.l22, G2, L.t * G3))));
+                dp[k][8] = fma(x2, L.s2(1), fma(x1, L.s1(8), fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
             }
             {
                 const double G0 = fma(L.l30, q0, fma(L.l32, q2, L.e * q3)), G2 = fma(L.l30, q2, fma(L.l32, q7, L.e * q8));
                 const double G3 = fma(L.l30, q3, fma(L.l32, q8, L.e * q9));
-                dp[k][9] = fma(x2, L.s2[2], fma(x1, L.s1[9], fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
+                dp[k][9] = fma(x2, L.s2(2), fma(x1, L.s1(9), fma(L.l30, G0, fma(L.l32, G2, L.e * G3))));
             }
         }
     }
@@ -906,8 +906,10 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             ld(X, t + 4);
         }
         SSDE_CK(0)
-        if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1, t + 2);
-        if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
+        if constexpr (!FULL) {                                 // (full-covariance lanes: the stage waves run loops of their own, below)
+            if (part == CV_PRODUCER && t + 2 >= s_begin) produce((t + 2) & 1, t + 2);
+            if (part == CV_FILTER && t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
+        }
         SSDE_CK(1)
         if (t >= s_begin) columns(t, sl_t, t & 1);
         SSDE_CK(2)
@@ -915,11 +917,35 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         SSDE_CK(3)
         r3 = r3 == 2 ? 0 : r3 + 1;
     };
-    if (loader) ld(setB, s_begin);                             // Y of the first iteration (t = s_begin - 3): row s_begin
-    iter(s_begin - 3, setA, setB);
-    for (int t = s_begin - 2; t < s_end; t += 2) {             // (s_end - s_begin is a multiple of WIN_ALIGN: an even count)
-        iter(t, setB, setA);
-        iter(t + 1, setA, setB);
+    // Full-covariance lanes: the filter needs ~120 registers of its own and the column state another 120; in ONE loop the
+    // allocator keeps both live and spills around the filter in every wave (measured: 800 bytes per lane of scratch, column
+    // waves at 12 000 cycles per row).  The two stage waves -- which carry no columns there (the engine sees to it) -- run loops
+    // of their own with the same barriers, so that neither allocation contains the other's state.
+    if (FULL && part == CV_FILTER) {
+        for (int t = s_begin - 3; t < s_end; t++) {
+            const int sl_t1 = r3 == 2 ? 0 : r3 + 1;
+            SSDE_CK(0)
+            if (t + 1 >= s_begin && t + 1 < s_end) filter(t + 1, sl_t1, (t + 1) & 1);
+            SSDE_CK(1)
+            __syncthreads();
+            SSDE_CK(3)
+            r3 = r3 == 2 ? 0 : r3 + 1;
+        }
+    } else if (FULL && part == CV_PRODUCER) {
+        for (int t = s_begin - 3; t < s_end; t++) {
+            SSDE_CK(0)
+            if (t + 2 >= s_begin) produce((t + 2) & 1, t + 2);
+            SSDE_CK(1)
+            __syncthreads();
+            SSDE_CK(3)
+        }
+    } else {
+        if (loader) ld(setB, s_begin);                         // Y of the first iteration (t = s_begin - 3): row s_begin
+        iter(s_begin - 3, setA, setB);
+        for (int t = s_begin - 2; t < s_end; t += 2) {         // (s_end - s_begin is a multiple of WIN_ALIGN: an even count)
+            iter(t, setB, setA);
+            iter(t + 1, setA, setB);
+        }
     }
 #ifdef SSDE_CV_CLOCK
     if (A.wave_clock && lane == 0) {

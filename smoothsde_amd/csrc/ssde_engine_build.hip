@@ -146,7 +146,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
-        if ((int)cols.size() > CV_WAVES * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;
+        if ((int)cols.size() > (h->cv_full ? CV_WAVES - 2 : CV_WAVES) * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;     // (full-covariance lanes: the two stage waves carry no columns)
         std::vector<CvPart> parts(CV_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * CV_WAVES);
         h->cv_pidx.assign((size_t)CV_WAVES * CV_KC, -1);
