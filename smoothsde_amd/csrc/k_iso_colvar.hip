@@ -1093,7 +1093,7 @@ static hipError_t launch_cv(const IsoArgs& a, const CvPart* parts, int kc, dim3 
     return hipGetLastError();
 }
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s) {
-    if (a.n_parts != CV_WAVES || a.drift_k < 1 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
+    if (a.n_parts != CV_WAVES || a.drift_k < 0 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
     dim3 grid(a.tv.n_groups * a.n_chunks), block(CV_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
     if (a.cv_full) {                                           // 4 x 4 covariance lanes: CTCRW, d = 2

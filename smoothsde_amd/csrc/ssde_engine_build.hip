@@ -726,7 +726,8 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // (a per-row H_array couples the dimensions: CTCRW with d = 2 has 4 x 4 covariance lanes in k_iso_colvar.hip, any P0)
         const bool iso_cfg = !h->has_h && p0_is_isotropic(d, h->p0_iso);
         const bool full_cfg = h->has_h && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_NO_COLVAR_FULL");
-        if (!iso_ok && allow_drift && (iso_cfg || full_cfg) && !h->const_coeff && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
+        // (... also with CONSTANT coefficients: tracks with error ellipses and one tau, one nu -- the intercepts are columns of ones)
+        if (!iso_ok && allow_drift && (iso_cfg || full_cfg) && (!h->const_coeff || full_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
             !getenv("SSDE_NO_DRIFT")) {
             bool mu_only = true;
             for (auto& sl : h->slots)
@@ -737,7 +738,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.  Mixed designs (columns in the drift AND in tau / nu) stay on that path.
-            bool par_only = !mu_only && !getenv("SSDE_NO_COLVAR");
+            bool par_only = (!mu_only || (full_cfg && h->const_coeff)) && !getenv("SSDE_NO_COLVAR");
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && (sl.par_j < h->d || (sl.basis_c >= 0 && !sl.src))) par_only = false;      // (a basis block materialised at create is a block of columns)
             // (measured, tools/bench_colvar.py --tracks M --rows 1000, 18 columns: 0.18 / 0.19 / 0.20 / 0.22 / 0.24 ms at M = 32 / 128 /

@@ -344,6 +344,32 @@ def test_per_row_measurement_covariance_vs_oracle(k1, k2, what, monkeypatch):
     eng.close(); e2.close()
 
 
+def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lanes(monkeypatch):
+    """Tracks with per-row measurement covariances and ONE tau, ONE nu (the usual Argos model): no design column at all, the
+    intercepts are columns of ones."""
+    ID, t, o = simulate("CTCRW", 80, 700, 2, tau=1.5, nu=0.8, sigma_obs=0.1, seed=71)
+    o = o.copy()
+    rng = np.random.default_rng(8)
+    na = rng.random(len(t)) < 0.03
+    na[::700] = False
+    o[na, 0] = np.nan
+    pb0 = capi.Problem("CTCRW", ID, t, o)
+    pb = capi.Problem("CTCRW", ID, t, o, H=_with_h(pb0, 9))
+    par = np.array([0.0, 0.05, -0.03, np.log(1.7), np.log(0.7)])
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["path"] == PATH_ISO and inf["const_coeff"] == 1
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb, par))
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb)
+    assert e2.info()["path"] == PATH_TV
+    v2, g2 = e2.eval(par)
+    assert abs(val - v2) <= 1e-10 * abs(val) and np.max(np.abs(grad - g2)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e2.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatch):
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)

@@ -46,7 +46,7 @@ if args.with_h:   # error ellipses of the size of the simulated measurement nois
     A = np.random.default_rng(343).standard_normal((n, 2, 2)) * 0.05
     H = np.einsum("nij,nkj->ikn", A, A) + 0.0025 * np.eye(2)[:, :, None]
     del A
-pb = capi.Problem("CTCRW", ID, times, obs, X_re=X_re, S_list=S, par_fixed=fixed, H=H)
+pb = capi.Problem("CTCRW", ID, times, obs, X_re=X_re if S else None, S_list=S or None, par_fixed=fixed, H=H)
 par = np.r_[np.log(0.05), 0, 0, 0, 0, np.zeros(len(S)), 0.05 * np.sin(np.arange(nre))]
 bytes_row = 8.0 * (2 + nre + (4 if args.with_h else 0))
 for label, env in (("lane=track", None), ("lane=direction", "1")):
