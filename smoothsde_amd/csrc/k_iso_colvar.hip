@@ -1040,6 +1040,129 @@ hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pi
     return hipGetLastError();
 }
 
+// ---- constant tau / nu with per-row H_array (CTCRW, d = 2): one wave per (64-track group, time window) ------------------------------
+// The Argos model: error ellipses on every fix, one tau, one nu.  No design column to stage and at most four tangents (log tau, log nu
+// and the two drift intercepts: columns of ones), so the eight-wave pipeline above is overkill -- its row takes the filter wave's
+// whole dependent chain whatever the other waves do.  Here a wave runs the filter and its four tangents itself, four independent
+// waves per workgroup like k_iso.hip, with the same structs: the filter writes the row's linearisation to the wave's own LDS slab
+// and the tangents read it back (no barrier: one wave).  Rows are prefetched two ahead in ping-pong registers.
+template <bool UNI>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoArgs A, const CvPart* parts) {
+    typedef CvPrimalCtcrwFull Primal;
+    typedef CvColsCtcrwFull<2> Cols;                            // slots 0, 1 of parts[0]: log tau, log nu (dP and da)
+    constexpr int D = 2, SD = 4, U = 2, W = 1 + D + 4;         // register block row: [dt | y | H00 H10 H01 H11]
+    __shared__ double lin[WG_WAVES][Primal::NLIN * WAVE];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
+    int g, part, chunk;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TileView& tv = A.tv;
+    const int C = tv.C, c_obs = tv.c_obs, G = tv.n_groups;
+    constexpr int nacc = 2 + CV_KC + D;
+    const bool grad = A.part_mask[0] != 0;
+    const int n_col = grad ? parts[0].n_col : 0;
+    // (the engine puts log tau / log nu into slots 0, 1 and the drift intercepts into slots 2, 3; type 0: not wanted)
+    const int ty0 = n_col > 0 ? parts[0].type[0] : 0, ty1 = n_col > 1 ? parts[0].type[1] : 0;
+    const bool mu0 = n_col > 2 && parts[0].type[2] == 3, mu1 = n_col > 3 && parts[0].type[3] == 4;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, 0, chunk, s_begin, s_acc, s_end, 0);
+    double* const dump0 = A.bnd + (((int64_t)chunk * G + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
+    double* const dump1 = A.bnd + (((int64_t)chunk * G + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+    double bufA[U][W], bufB[U][W];
+    auto load = [&](double (&dst)[U][W], int s0) {
+        const double* p = base + (int64_t)s0 * C * WAVE;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dst[u][0] = 0.0;
+            if (!UNI) dst[u][0] = p[(u * C) * WAVE];
+#pragma unroll
+            for (int a = 0; a < D + 4; a++) dst[u][1 + a] = p[(u * C + c_obs + a) * WAVE];
+        }
+    };
+    load(bufA, s_begin);
+    Primal F;
+    Cols S;
+    S.init();
+    // the drift-intercept tangents: dP stays zero (B mu does not enter the covariance), so only da' = L da + B e_a is carried
+    double ma[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, mg[2] = {0, 0};
+    {
+        double a0[SD];
+        if (s_begin == 0) {
+#pragma unroll
+            for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        } else {
+#pragma unroll
+            for (int a = 0; a < D; a++) { const double y0 = bufA[0][1 + a]; a0[2 * a] = (y0 == y0) ? y0 : 0.0; a0[2 * a + 1] = 0.0; }
+        }
+        F.init(a0, A.cv_p0);
+    }
+    double mu[D] = {A.mu[0], A.mu[1]};
+    double* lo = &lin[wv][lane];
+    auto dump = [&](double* o) {
+        F.dump_to(o); S.dump_to(o + Primal::NDUMP * WAVE);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[(Primal::NDUMP + 2 * 14 + 4 * j + i) * WAVE] = ma[j][i];
+    };
+    auto block = [&](const double (&blk)[U][W], int s0) {
+        if (s0 == s_acc && s_acc > s_begin) { dump(dump0); F.reset_acc(); S.reset_acc(); mg[0] = mg[1] = 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s0 + u < ns) {
+                CtcrwTrans tr;
+                if constexpr (UNI) tr = A.ctr; else ctcrw_trans(blk[u][0], A.tau, A.beta, A.sigma, tr);
+                const double H[3] = {blk[u][1 + D], blk[u][1 + D + 2], blk[u][1 + D + 3]};
+                F.step(tr, H, mu, &blk[u][1], is_na(blk[u][1], A.any_nan), lo);
+                if (n_col > 0) {
+                    typename Cols::Lin li;
+                    li.read(lo);
+                    const double X[2][4] = {{ty0 == 1 ? 1.0 : 0.0, ty0 == 2 ? 1.0 : 0.0, 0.0, 0.0}, {ty1 == 1 ? 1.0 : 0.0, ty1 == 2 ? 1.0 : 0.0, 0.0, 0.0}};
+                    S.template step<0, 2>(li, X);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const double on = (j == 0 ? mu0 : mu1) ? 1.0 : 0.0;
+                        const double z0 = ma[j][0], z1 = ma[j][1], z2 = ma[j][2], z3 = ma[j][3];
+                        mg[j] = fma(-li.w0, z0, fma(-li.w1, z2, mg[j]));
+                        const double b1 = on * li.sb(0), b2 = on * li.sb(1);
+                        ma[j][0] = fma(li.l00, z0, fma(li.t, z1, li.l02 * z2)) + (j == 0 ? b1 : 0.0);
+                        ma[j][1] = fma(li.l10, z0, fma(li.e, z1, li.l12 * z2)) + (j == 0 ? b2 : 0.0);
+                        ma[j][2] = fma(li.l20, z0, fma(li.l22, z2, li.t * z3)) + (j == 1 ? b1 : 0.0);
+                        ma[j][3] = fma(li.l30, z0, fma(li.l32, z2, li.e * z3)) + (j == 1 ? b2 : 0.0);
+                    }
+                }
+            }
+    };
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+        load(bufB, s0 + U);
+        block(bufA, s0);
+        load(bufA, s0 + 2 * U);
+        if (s0 + U < s_end) block(bufB, s0 + U);
+    }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) dump(dump1);
+    const bool empty = s_acc >= s_end;
+    const double out[nacc] = {F.value(), S.g[0], S.g[1], mg[0], mg[1], 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < nacc; k++) {
+        const double t = wave_sum(empty ? 0.0 : out[k]);
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + k) * G + g] = t;
+    }
+}
+// a.n_parts == 1; parts[0]: slots 0, 1 = log tau, log nu, slots 2, 3 = the drift intercepts (type 0: not wanted); hand-over record:
+// filter 14 | two tangents 2 x 14 | two drift tangents 2 x 4
+hipError_t launch_iso_full(const IsoArgs& a, const CvPart* parts, hipStream_t s) {
+    if (a.n_parts != 1 || !a.cv_has_h) return hipErrorInvalidValue;
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
+    if (grid.x == 0) return hipSuccess;
+    if (a.uniform_dt) hipLaunchKernelGGL((iso_full_kernel<true>), grid, block, 0, s, a, parts);
+    else hipLaunchKernelGGL((iso_full_kernel<false>), grid, block, 0, s, a, parts);
+    return hipGetLastError();
+}
+
 // per group: the largest diagonal entry of H_array[,,i] over its rows, and the largest |H01 - H10| (create time: the window
 // planner's observation variance; the full-covariance lanes take a symmetric H)
 __global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileView tv, int c_h, double* out /* [n_groups][2] */) {

@@ -163,6 +163,19 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                 if (tot == N) { for (int p = 0; p < 8; p++) n_w[p] = v[p]; dealt_by_env = true; }
             }
         }
+        if (h->cv_single) {
+            // one wave does it all (iso_full_kernel): slots 0, 1 = the log tau, log nu intercepts, slots 2, 3 = the drift intercepts
+            static_assert(CV_KC >= 4, "four slots");
+            parts[0].n_col = 4;
+            for (int k = 0; k < 4; k++) { parts[0].chan[k] = -1; parts[0].type[k] = 0; }
+            for (auto& c : cols) {
+                if (c.chan >= 0 || c.type < 1 || c.type > 4) return SSDE_RETRY_WITHOUT_DRIFT;
+                const int k = c.type <= 2 ? c.type - 1 : c.type - 1;       // kinds 1, 2, 3, 4 -> slots 0, 1, 2, 3
+                parts[0].type[k] = c.type;
+                h->cv_pidx[k] = c.pidx;
+            }
+            cols.clear();                                          // (dealt)
+        } else
         if (!dealt_by_env) {
             int left = N;
             for (int k = 0; k < CV_KC && left > 0; k++)
@@ -190,7 +203,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             for (auto& sl : h->slots)
                 if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
         }
-        h->cv_kc = best_kc;
+        h->cv_kc = h->cv_single ? CV_KC : best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
         HIPCHK(h, hipHostMalloc((void**)&h->cv_ranges_pinned, 4 * sizeof(double), hipHostMallocDefault));
         h->cv_ranges_pinned[0] = h->cv_ranges_pinned[2] = INFINITY; h->cv_ranges_pinned[1] = h->cv_ranges_pinned[3] = -INFINITY;
@@ -213,7 +226,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
+        h->drift_nstate = h->cv_single ? 14 + 2 * 14 + 2 * 4 : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
         if (h->has_h) {
             DevBuf<double> hs;
             HIPCHK(h, hs.alloc((size_t)G * 2));
@@ -240,7 +253,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->drift = all_clean ? 1 : 2;
         h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
     }
-    if (h->drift) { h->iso_parts = h->drift == 3 ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+    if (h->drift) { h->iso_parts = (h->drift == 3 && !h->cv_single) ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
     else choose_iso_split(h);
     // shared-covariance path: regular grid + groups without missing rows
     HIPCHK(h, h->group_flags.upload(gflags));
@@ -288,12 +301,12 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
         want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
     // row-varying tau / nu: a WORKGROUP per (group, window), one per CU -- up to eight rounds' worth; plan_windows picks the count
-    if (h->drift == 3) want = std::max(1, (8 * 256 + G - 1) / G);
+    if (h->drift == 3 && !h->cv_single) want = std::max(1, (8 * 256 + G - 1) / G);
     if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
     h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
     // (row-varying tau / nu with few groups: windows down to two alignment units, shorter than their warm-up -- with CUs idle
     //  the redundant warm-up rows run in parallel, only a workgroup's own chain of rows matters; ssde_engine_iso.hip picks)
-    if (h->drift == 3 && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
+    if (h->drift == 3 && !h->cv_single && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
     h->want_chunks = std::max(1, std::min(want, h->max_chunks));
     // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows on
     // the general kernel.  With ONE plan -- the shared kernel's few long windows -- the general launch is a handful of
@@ -747,7 +760,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
-                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = !iso_cfg; }
+                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = !iso_cfg; h->cv_single = h->cv_full && nd == 0 && !getenv("SSDE_CV_NO_SINGLE"); }
                 else return SSDE_RETRY_WITHOUT_DRIFT;              // (the slots were renumbered: start over)
             }
         }

@@ -87,10 +87,10 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
         glmax = h->glen_max;
     }
     int nc = h->want_chunks;
-    if (h->drift == 3 && !h->chunks_forced) { while (nc > 1 && (glmax / nc) < 2 * WIN_ALIGN) nc--; }     // (the cost below decides, not a rule)
+    if (h->drift == 3 && !h->cv_single && !h->chunks_forced) { while (nc > 1 && (glmax / nc) < 2 * WIN_ALIGN) nc--; }     // (the cost below decides, not a rule)
     else
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
-    if (h->drift == 3 && !h->chunks_forced) {
+    if (h->drift == 3 && !h->cv_single && !h->chunks_forced) {
         // one workgroup per (group, window) and per CU: rounds x (rows of a window + its warm-up) is what the launch takes
         int best = 1;
         double best_cost = (double)((h->n_groups + 255) / 256) * glmax;
@@ -219,7 +219,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     } else {
         a.n_parts = 1;
     }
-    if (h->drift == 3) { a.n_parts = CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
+    if (h->drift == 3) { a.n_parts = h->cv_single ? 1 : CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
     a.any_nan = h->na_any;
     a.uniform_dt = h->uniform_dt ? 1 : 0;
     const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
@@ -410,11 +410,14 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
+            if (h->cv_single) HIPCHK(h, launch_iso_full(a, h->cv_parts.p, s));
+            else {
             const int n_wg = h->n_groups * a.n_chunks;
             if ((int)h->cv_ranges.n < 4 * n_wg) { h->cv_ranges.release(); HIPCHK(h, h->cv_ranges.alloc((size_t)4 * n_wg)); }
             a.cv_ranges = h->cv_ranges.p;
             HIPCHK(h, launch_iso_colvar(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
             HIPCHK(h, launch_colvar_range_reduce(h->cv_ranges.p, n_wg, h->cv_ranges_pinned, s));
+            }
         }
         else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
         else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));

@@ -344,24 +344,36 @@ def test_per_row_measurement_covariance_vs_oracle(k1, k2, what, monkeypatch):
     eng.close(); e2.close()
 
 
-def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lanes(monkeypatch):
-    """Tracks with per-row measurement covariances and ONE tau, ONE nu (the usual Argos model): no design column at all, the
-    intercepts are columns of ones."""
+@pytest.mark.parametrize("irregular,fix", [(False, ()), (True, ()), (True, (1, 2)), (False, (3,)), (True, (2, 4))])
+def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lanes(irregular, fix, monkeypatch):
+    """Tracks with per-row measurement covariances and ONE tau, ONE nu (the usual Argos model): no design column at all; one
+    wave per (group, window) runs the 4 x 4 filter and its (at most) four tangents (iso_full_kernel)."""
     ID, t, o = simulate("CTCRW", 80, 700, 2, tau=1.5, nu=0.8, sigma_obs=0.1, seed=71)
     o = o.copy()
     rng = np.random.default_rng(8)
     na = rng.random(len(t)) < 0.03
     na[::700] = False
     o[na, 0] = np.nan
+    if irregular:
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    fixed = np.zeros(5, dtype=np.uint8)
+    fixed[list(fix)] = 1
     pb0 = capi.Problem("CTCRW", ID, t, o)
-    pb = capi.Problem("CTCRW", ID, t, o, H=_with_h(pb0, 9))
+    A = rng.standard_normal((4, 4))
+    pb = capi.Problem("CTCRW", ID, t, o, H=_with_h(pb0, 9), par_fixed=fixed, P0=(A @ A.T + np.eye(4)) if irregular else None)
     par = np.array([0.0, 0.05, -0.03, np.log(1.7), np.log(0.7)])
     eng = capi.Engine(pb)
     inf = eng.info()
-    assert inf["path"] == PATH_ISO and inf["const_coeff"] == 1
+    assert inf["path"] == PATH_ISO and inf["const_coeff"] == 1 and inf["uniform_dt"] == (0 if irregular else 1)
     val, grad = eng.eval(par)
-    assert eng.info()["window_check"] <= 1e-11
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["window_check"] <= 1e-11
     _close(val, grad, *_oracle(pb, par))
+    assert np.all(grad[fixed.astype(bool)] == 0.0) and grad[0] == 0.0
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
     monkeypatch.setenv("SSDE_NO_COLVAR", "1")
     e2 = capi.Engine(pb)
     assert e2.info()["path"] == PATH_TV
