@@ -43,6 +43,7 @@ cp gpurun_out/pmc_${TAG}_share8.txt gpurun_out/pmc_${TAG}_drift.txt "$OUT/" 2>/d
 # round 3, second half: row-varying tau / nu on lane = track lanes (k_iso_colvar.hip) against the lane = direction path
 python3 tools/bench_colvar.py > "$OUT/colvar.txt" 2> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
+python3 tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 6 >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/colvar_stats" -o stats --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track > "$OUT/colvar_under_rocprof.log" 2>&1 ) || true
 find "$OUT/colvar_stats" -name "*kernel_trace*" -delete 2>/dev/null || true
 bash tools/pmc_kernel.sh "iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > /dev/null 2>&1 || true
