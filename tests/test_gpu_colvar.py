@@ -415,3 +415,17 @@ def test_sharded_handle_and_one_rank_communicator():
     v3, g3 = e1.eval(par)
     assert abs(v1 - v3) <= 1e-12 * abs(v1) and np.max(np.abs(g1 - g3)) <= 1e-10 * np.max(np.abs(g1))
     e1.close(); e2.close()
+    # ... and with error ellipses: the full-covariance lanes, row-varying and constant coefficients
+    for k1 in (5, 0):
+        pbh, parh = _batch("CTCRW", 2, 130, 400, k1, 0, seed=15)
+        if k1 == 0:
+            pbh = capi.Problem("CTCRW", pbh.id, pbh.times, pbh.obs, H=_with_h(pbh, 3))
+            parh = np.array([0.0, 0.05, -0.03, np.log(1.7), np.log(0.7)])
+        else:
+            pbh = capi.Problem("CTCRW", pbh.id, pbh.times, pbh.obs, X_re=pbh.X_re, S_list=pbh.S_list, H=_with_h(pbh, 3))
+        ea, eb = capi.Engine(pbh), capi.Engine(pbh, devices=[0, 0, 0])
+        assert ea.info()["path"] == PATH_ISO
+        va, ga = ea.eval(parh)
+        vb, gb = eb.eval(parh)
+        assert abs(va - vb) <= 1e-11 * abs(va) and np.max(np.abs(ga - gb)) <= 1e-9 * np.max(np.abs(ga))
+        ea.close(); eb.close()
