@@ -382,6 +382,23 @@ def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lane
     eng.close(); e2.close()
 
 
+def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
+    """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
+    shared tau / nu coefficients are summed over the parts."""
+    ID, t, o = simulate("CTCRW", 70, 300, 3, tau=1.5, nu=0.8, sigma_obs=0.1, seed=31)
+    n = len(ID)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 41), 0, 1)
+    B = bspline_basis(x, 5)
+    pb = capi.Problem("CTCRW", ID, t, o, X_re=[None, None, None, B, bspline_basis(x ** 2, 4)],
+                      S_list=[second_difference_penalty(5), second_difference_penalty(4)])
+    rng = np.random.default_rng(2)
+    par = np.r_[np.log(0.12), 0.05, -0.03, 0.02, np.log(1.5), np.log(0.8), 0.3, -0.2, 0.2 * rng.standard_normal(9)]
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pb, par))
+    eng.close()
+
+
 def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatch):
     pb1, _ = _batch("CTCRW", 2, 3, 600, 5, 5, seed=9)
     eng = capi.Engine(pb1)
