@@ -846,7 +846,11 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
                 double H[3] = {h, 0.0, h};                          // H_array[,,i] (symmetric, checked at create)
                 if (A.cv_has_h) { H[0] = r[(c_obs + D) * WAVE]; H[1] = r[(c_obs + D + 2) * WAVE]; H[2] = r[(c_obs + D + 3) * WAVE]; }
                 F.step(tr, H, mu, y, is_na(y[0], A.any_nan), lo);
-            } else F.step(tr, h, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
+            } else {
+                // (d = 1 with H_array: the measurement variance of THIS row; no log sigma_obs direction then)
+                const double hr = (D == 1 && A.cv_has_h) ? r[(c_obs + D) * WAVE] : h;
+                F.step(tr, hr, mu, y, is_na(y[0], A.any_nan), with_sig, with_mu, lo);
+            }
         }
         if (s == s_end - 1 && !last_chunk) F.dump_to(dump1);
         F.save(&fst[lane]);
@@ -1165,7 +1169,7 @@ hipError_t launch_iso_full(const IsoArgs& a, const CvPart* parts, hipStream_t s)
 
 // per group: the largest diagonal entry of H_array[,,i] over its rows, and the largest |H01 - H10| (create time: the window
 // planner's observation variance; the full-covariance lanes take a symmetric H)
-__global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileView tv, int c_h, double* out /* [n_groups][2] */) {
+__global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileView tv, int c_h, int d, double* out /* [n_groups][2] */) {
     __shared__ double sh[WG_WAVES][2];
     const int g = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const double* base = tv.tiles + tv.group_off[g] + lane;
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileVie
     double hmax = 0.0, asym = 0.0;
     for (int s = wv; s < ns; s += WG_WAVES) {
         const double* p = base + ((int64_t)s * tv.C + c_h) * WAVE;
-        const double h00 = p[0], h10 = p[WAVE], h01 = p[2 * WAVE], h11 = p[3 * WAVE];
+        const double h00 = p[0], h10 = d == 2 ? p[WAVE] : 0.0, h01 = d == 2 ? p[2 * WAVE] : 0.0, h11 = d == 2 ? p[3 * WAVE] : p[0];
         hmax = fmax(hmax, fmax(h00, h11));
         asym = fmax(asym, fabs(h01 - h10));
         if (!(h00 == h00) || !(h11 == h11) || !(h01 == h01) || !(h10 == h10)) asym = INFINITY;
@@ -1187,9 +1191,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE) void colvar_h_stats_kernel(TileVie
         out[2 * g] = hmax; out[2 * g + 1] = asym;
     }
 }
-hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, double* out, hipStream_t s) {
+hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, int d, double* out, hipStream_t s) {
     if (tv.n_groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(colvar_h_stats_kernel, dim3(tv.n_groups), dim3(WG_WAVES * WAVE), 0, s, tv, c_h, out);
+    hipLaunchKernelGGL(colvar_h_stats_kernel, dim3(tv.n_groups), dim3(WG_WAVES * WAVE), 0, s, tv, c_h, d, out);
     return hipGetLastError();
 }
 

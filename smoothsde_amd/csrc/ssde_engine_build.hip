@@ -199,7 +199,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // the log sigma_obs and drift-intercept directions ride on the wave that runs the filter
         h->cv_sig_part = h->cv_mu_part = -1;
         if (!h->cv_full) {
-            if (!h->fixed[0]) { parts[0].with_sig = 1; h->cv_sig_part = 0; }
+            if (!h->fixed[0] && !h->has_h) { parts[0].with_sig = 1; h->cv_sig_part = 0; }     // (H_array: log sigma_obs is not in the model)
             for (auto& sl : h->slots)
                 if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
         }
@@ -234,7 +234,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             memset(&tv, 0, sizeof(tv));
             tv.tiles = h->tiles.p; tv.group_off = h->group_off.p; tv.group_len = h->group_len.p; tv.lane_nsteps = h->lane_nsteps.p;
             tv.n_groups = G; tv.C = h->C; tv.c_obs = h->c_obs;
-            HIPCHK(h, launch_colvar_h_stats(tv, h->c_obs + h->d, hs.p, 0));
+            HIPCHK(h, launch_colvar_h_stats(tv, h->c_obs + h->d, h->d, hs.p, 0));
             std::vector<double> hh((size_t)G * 2);
             HIPCHK(h, hipMemcpy(hh.data(), hs.p, hh.size() * 8, hipMemcpyDeviceToHost));
             double asym = 0.0;
@@ -739,8 +739,10 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // (a per-row H_array couples the dimensions: CTCRW with d = 2 has 4 x 4 covariance lanes in k_iso_colvar.hip, any P0)
         const bool iso_cfg = !h->has_h && p0_is_isotropic(d, h->p0_iso);
         const bool full_cfg = h->has_h && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_NO_COLVAR_FULL");
+        // (one response column: H_array[,,i] is the row's measurement variance -- the isotropic lanes of k_iso_colvar.hip with h = H_i)
+        const bool h1_cfg = h->has_h && h->d == 1 && p0_is_isotropic(d, h->p0_iso) && !getenv("SSDE_NO_COLVAR_FULL");
         // (... also with CONSTANT coefficients: tracks with error ellipses and one tau, one nu -- the intercepts are columns of ones)
-        if (!iso_ok && allow_drift && (iso_cfg || full_cfg) && (!h->const_coeff || full_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
+        if (!iso_ok && allow_drift && (iso_cfg || full_cfg || h1_cfg) && (!h->const_coeff || full_cfg || h1_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
             !getenv("SSDE_NO_DRIFT")) {
             bool mu_only = true;
             for (auto& sl : h->slots)
@@ -751,7 +753,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.  Mixed designs (columns in the drift AND in tau / nu) stay on that path.
-            bool par_only = (!mu_only || (full_cfg && h->const_coeff)) && !getenv("SSDE_NO_COLVAR");
+            bool par_only = (!mu_only || ((full_cfg || h1_cfg) && h->const_coeff)) && !getenv("SSDE_NO_COLVAR");
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && (sl.par_j < h->d || (sl.basis_c >= 0 && !sl.src))) par_only = false;      // (a basis block materialised at create is a block of columns)
             // (measured, tools/bench_colvar.py --tracks M --rows 1000, 18 columns: 0.18 / 0.19 / 0.20 / 0.22 / 0.24 ms at M = 32 / 128 /
@@ -760,7 +762,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
-                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = !iso_cfg; h->cv_single = h->cv_full && nd == 0 && !getenv("SSDE_CV_NO_SINGLE"); }
+                if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = full_cfg; h->cv_single = h->cv_full && nd == 0 && !getenv("SSDE_CV_NO_SINGLE"); }
                 else return SSDE_RETRY_WITHOUT_DRIFT;              // (the slots were renumbered: start over)
             }
         }

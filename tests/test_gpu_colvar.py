@@ -382,6 +382,44 @@ def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lane
     eng.close(); e2.close()
 
 
+H1_GOLD = [r for r in GOLD if r["name"] in ("CTCRW_d1_H", "OU_SSM_d1_H", "BM_SSM_d1_H")]
+
+
+@pytest.mark.parametrize("rec", H1_GOLD, ids=[r["name"] for r in H1_GOLD])
+def test_golden_one_column_cases_with_h_array(rec, monkeypatch):
+    """One response column: H_array[,,i] is the row's measurement variance; the isotropic lanes run with h = H_i."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == PATH_ISO
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    eng.close()
+
+
+@pytest.mark.parametrize("model,k1,k2", [("CTCRW", 6, 5), ("OU_SSM", 0, 7), ("BM_SSM", 5, 0), ("CTCRW", 0, 0), ("OU_SSM", 0, 0)])
+def test_one_column_with_per_row_measurement_variance_vs_oracle(model, k1, k2):
+    pb, par = _batch(model, 1, 96, 700, k1 or 3, k2, seed=81)
+    rng = np.random.default_rng(5)
+    o = pb.obs.copy()
+    na = rng.random(pb.n) < 0.03
+    na[pb.seg_start] = False
+    o[na, 0] = np.nan
+    H = (0.01 + 0.02 * rng.random(pb.n)).reshape(1, 1, -1)
+    if k1 == 0 and k2 == 0:                                      # constant coefficients
+        pb2 = capi.Problem(model, pb.id, pb.times, o, H=H)
+        par = par[:pb2.n_par_full].copy()
+    else:
+        pb2 = capi.Problem(model, pb.id, pb.times, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, H=H)
+    eng = capi.Engine(pb2)
+    assert eng.info()["path"] == PATH_ISO
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    assert grad[0] == 0.0
+    eng.close()
+
+
 def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
     """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
     shared tau / nu coefficients are summed over the parts."""

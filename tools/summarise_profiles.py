@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-rnd, letter = tag[:3], tag[3:] or "x"
+rnd, letter = tag[:3], tag[3:].lstrip("_") or "x"
 pre = os.path.join(dst, f"{rnd}_{letter}_")
 
 # --- kernel statistics: this engine's kernels only (the synthetic-data generator launches 10^5 torch kernels) ----
