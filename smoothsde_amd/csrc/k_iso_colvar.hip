@@ -480,6 +480,17 @@ struct CvColsCtcrwFull {
             }
         }
     }
+    // a drift-intercept tangent (dimension `dim`): dP stays zero (B mu does not enter the covariance), da' = L da + B e_dim
+    static constexpr int NMEAN = 4;
+    static __device__ __forceinline__ void mean_step(const Lin& L, double* m, double& mg, int dim, bool on) {
+        const double z0 = m[0], z1 = m[1], z2 = m[2], z3 = m[3];
+        mg = fma(-L.w0, z0, fma(-L.w1, z2, mg));
+        const double b1 = on ? L.sb(0) : 0.0, b2 = on ? L.sb(1) : 0.0;
+        m[0] = fma(L.l00, z0, fma(L.t, z1, L.l02 * z2)) + (dim == 0 ? b1 : 0.0);
+        m[1] = fma(L.l10, z0, fma(L.e, z1, L.l12 * z2)) + (dim == 0 ? b2 : 0.0);
+        m[2] = fma(L.l20, z0, fma(L.l22, z2, L.t * z3)) + (dim == 1 ? b1 : 0.0);
+        m[3] = fma(L.l30, z0, fma(L.l32, z2, L.e * z3)) + (dim == 1 ? b2 : 0.0);
+    }
     __device__ __forceinline__ void dump_to(double* o) const {
         int n = 0;
 #pragma unroll
@@ -670,6 +681,133 @@ struct CvColsScal {
     }
 };
 
+// ---- OU_SSM / BM_SSM, d = 2, FULL 2 x 2 covariance (per-row H_array, nllk_ou_ssm.hpp:171-172, nllk_bm_ssm.hpp:135-136): T = t I,
+// B = b I, Q = q I, Z = I, so M = t P, K = t P F^-1, L = t I - K; the tangent formulas are those of the CTCRW lanes above.
+template <bool HAS_P2>
+struct CvPrimalScalFull {
+    static constexpr int D = 2, SD = 2, NLIN = 16, NCOL = 5, NDUMP = 5, NTR = 6, NSAVE = 5 + 3;
+    typedef ScalTrans Trans;
+    double a[2], p[3];                                         // p: 00 01 11
+    LogAcc ld;
+    double accq;
+    double gmu[2], sg;                                         // (unused here: the pipeline kernel's epilogue reads them)
+    __device__ __forceinline__ void init(const double* a0, const double* p0f) {
+        a[0] = a0[0]; a[1] = a0[1];
+        p[0] = p0f[0]; p[1] = p0f[2]; p[2] = p0f[3];               // (column-major 2 x 2)
+        ld.init(); accq = 0.0; gmu[0] = gmu[1] = sg = 0.0;
+    }
+    __device__ __forceinline__ void reset_acc() { ld.init(); accq = 0.0; }
+    __device__ __forceinline__ void step(const ScalTrans& tr, const double* H, const double* mu, const double* y, bool na, double* lin) {
+        const double p00 = p[0], p01 = p[1], p11 = p[2];
+        const double F11 = p00 + H[0], F12 = p01 + H[1], F22 = p11 + H[2];
+        const double detF = fma(F11, F22, -F12 * F12);
+        const bool upd = !na && !(fabs(detF) <= 0.0);              // nllk_ou_ssm.hpp:190-195, nllk_bm_ssm.hpp:152-157 (the drift stays in every branch)
+        const double updf = upd ? 1.0 : 0.0;
+        const double dete = upd ? detF : 1.0;
+        const double idet = rcp(dete) * updf;
+        ld.mul(dete);
+        const double i11 = F22 * idet, i12 = -F12 * idet, i22 = F11 * idet;
+        const double t = HAS_P2 ? tr.t : 1.0;
+        const double u0 = upd ? y[0] - a[0] : 0.0, u1 = upd ? y[1] - a[1] : 0.0;
+        const double w0 = fma(i11, u0, i12 * u1), w1 = fma(i12, u0, i22 * u1);
+        accq = fma(u0, w0, fma(u1, w1, accq));
+        // K = t P F^-1, L = t I - K
+        const double k00 = t * fma(p00, i11, p01 * i12), k01 = t * fma(p00, i12, p01 * i22);
+        const double k10 = t * fma(p01, i11, p11 * i12), k11 = t * fma(p01, i12, p11 * i22);
+        const double l00 = t - k00, l01 = -k01, l10 = -k10, l11 = t - k11;
+        int n = 0;
+        lin[(n++) * WAVE] = l00; lin[(n++) * WAVE] = l01; lin[(n++) * WAVE] = l10; lin[(n++) * WAVE] = l11;
+        lin[(n++) * WAVE] = w0; lin[(n++) * WAVE] = w1;
+        lin[(n++) * WAVE] = 0.5 * fma(-w0, w0, i11); lin[(n++) * WAVE] = fma(-w0, w1, i12); lin[(n++) * WAVE] = 0.5 * fma(-w1, w1, i22);
+        // seed_P of par[d] (log tau: dT = dt_ I, dQ = dq I; BM_SSM log sigma: dQ only): dt_ (P L' + L P) + dq I
+        const double dt_ = HAS_P2 ? tr.dt_ : 0.0;
+        lin[(n++) * WAVE] = fma(2.0 * dt_, fma(l00, p00, l01 * p01), tr.dq);
+        lin[(n++) * WAVE] = dt_ * (fma(l10, p00, l11 * p01) + fma(l00, p01, l01 * p11));
+        lin[(n++) * WAVE] = fma(2.0 * dt_, fma(l10, p01, l11 * p11), tr.dq);
+        // seed_a of par[d]: dT (a + P w) + dB mu
+        lin[(n++) * WAVE] = HAS_P2 ? fma(dt_, a[0] + fma(p00, w0, p01 * w1), tr.db * mu[0]) : 0.0;
+        lin[(n++) * WAVE] = HAS_P2 ? fma(dt_, a[1] + fma(p01, w0, p11 * w1), tr.db * mu[1]) : 0.0;
+        lin[(n++) * WAVE] = tr.q;                                  // seed_P of log kappa: q I
+        lin[(n++) * WAVE] = tr.b;                                  // seed_a of mu_a: b e_a
+        // a' = T a + K u + B mu; P' = T P T' - M K' + Q with M = t P
+        const double n0 = fma(tr.b, mu[0], fma(k00, u0, fma(k01, u1, t * a[0]))), n1 = fma(tr.b, mu[1], fma(k10, u0, fma(k11, u1, t * a[1])));
+        a[0] = n0; a[1] = n1;
+        const double tt = t * t;
+        p[0] = fma(tt, p00, -t * fma(p00, k00, p01 * k01)) + tr.q;
+        p[1] = fma(tt, p01, -t * fma(p00, k10, p01 * k11));
+        p[2] = fma(tt, p11, -t * fma(p01, k10, p11 * k11)) + tr.q;
+    }
+    __device__ __forceinline__ void dump_to(double* o) const { o[0] = a[0]; o[WAVE] = a[1]; o[2 * WAVE] = p[0]; o[3 * WAVE] = p[1]; o[4 * WAVE] = p[2]; }
+    __device__ __forceinline__ void save(double* o) const { dump_to(o); o[5 * WAVE] = accq; o[6 * WAVE] = ld.m; o[7 * WAVE] = (double)ld.e; }
+    __device__ __forceinline__ void restore(const double* o) {
+        a[0] = o[0]; a[1] = o[WAVE]; p[0] = o[2 * WAVE]; p[1] = o[3 * WAVE]; p[2] = o[4 * WAVE];
+        accq = o[5 * WAVE]; ld.m = o[6 * WAVE]; ld.e = (int)o[7 * WAVE];
+        gmu[0] = gmu[1] = sg = 0.0;
+    }
+    __device__ __forceinline__ double value() const { return 0.5 * (ld.value() + accq); }
+    static __device__ __forceinline__ void trans(double dt, double p1, double p2, ScalTrans& tr) { CvPrimalScal<2, HAS_P2>::trans(dt, p1, p2, tr); }
+    static __device__ __forceinline__ void put_trans(double* o, const ScalTrans& t) { CvPrimalScal<2, HAS_P2>::put_trans(o, t); }
+    static __device__ __forceinline__ void get_trans(const double* o, ScalTrans& t) { CvPrimalScal<2, HAS_P2>::get_trans(o, t); }
+};
+
+template <int KC, bool HAS_P2>
+struct CvColsScalFull {
+    static constexpr int NCOL = 5;
+    double dp[KC][3], da[KC][2], g[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) { g[k] = 0.0; dp[k][0] = dp[k][1] = dp[k][2] = 0.0; da[k][0] = da[k][1] = 0.0; }
+    }
+    __device__ __forceinline__ void reset_acc() {
+#pragma unroll
+        for (int k = 0; k < KC; k++) g[k] = 0.0;
+    }
+    struct Lin {
+        double l00, l01, l10, l11, w0, w1, c00, c01, c11, s1[3], sa[2], s2, b;
+        __device__ __forceinline__ void read(const double* lin) {
+            int n = 0;
+            l00 = lin[(n++) * WAVE]; l01 = lin[(n++) * WAVE]; l10 = lin[(n++) * WAVE]; l11 = lin[(n++) * WAVE];
+            w0 = lin[(n++) * WAVE]; w1 = lin[(n++) * WAVE]; c00 = lin[(n++) * WAVE]; c01 = lin[(n++) * WAVE]; c11 = lin[(n++) * WAVE];
+            s1[0] = lin[(n++) * WAVE]; s1[1] = lin[(n++) * WAVE]; s1[2] = lin[(n++) * WAVE];
+            sa[0] = lin[(n++) * WAVE]; sa[1] = lin[(n++) * WAVE]; s2 = lin[(n++) * WAVE]; b = lin[(n++) * WAVE];
+        }
+    };
+    template <int K0, int K1>
+    __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            const double q0 = dp[k][0], q1 = dp[k][1], q2 = dp[k][2];
+            const double x1 = X[k][0], x2 = X[k][1], x3 = X[k][2], x4 = X[k][3];
+            g[k] = fma(L.c00, q0, fma(L.c01, q1, fma(L.c11, q2, fma(-L.w0, da[k][0], fma(-L.w1, da[k][1], g[k])))));
+            const double z0 = fma(q0, L.w0, fma(q1, L.w1, da[k][0])), z1 = fma(q1, L.w0, fma(q2, L.w1, da[k][1]));
+            da[k][0] = fma(x3, L.b, fma(x1, L.sa[0], fma(L.l00, z0, L.l01 * z1)));
+            da[k][1] = fma(x4, L.b, fma(x1, L.sa[1], fma(L.l10, z0, L.l11 * z1)));
+            // L dP L'
+            const double G00 = fma(L.l00, q0, L.l01 * q1), G01 = fma(L.l00, q1, L.l01 * q2);
+            const double G10 = fma(L.l10, q0, L.l11 * q1), G11 = fma(L.l10, q1, L.l11 * q2);
+            dp[k][0] = fma(x2, L.s2, fma(x1, L.s1[0], fma(G00, L.l00, G01 * L.l01)));
+            dp[k][1] = fma(x1, L.s1[1], fma(G00, L.l10, G01 * L.l11));
+            dp[k][2] = fma(x2, L.s2, fma(x1, L.s1[2], fma(G10, L.l10, G11 * L.l11)));
+        }
+    }
+    static constexpr int NMEAN = 2;
+    static __device__ __forceinline__ void mean_step(const Lin& L, double* m, double& mg, int dim, bool on) {
+        const double z0 = m[0], z1 = m[1];
+        mg = fma(-L.w0, z0, fma(-L.w1, z1, mg));
+        const double b = on ? L.b : 0.0;
+        m[0] = fma(L.l00, z0, L.l01 * z1) + (dim == 0 ? b : 0.0);
+        m[1] = fma(L.l10, z0, L.l11 * z1) + (dim == 1 ? b : 0.0);
+    }
+    __device__ __forceinline__ void dump_to(double* o) const {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            o[(n++) * WAVE] = dp[k][0]; o[(n++) * WAVE] = dp[k][1]; o[(n++) * WAVE] = dp[k][2];
+            o[(n++) * WAVE] = da[k][0]; o[(n++) * WAVE] = da[k][1];
+        }
+    }
+};
+
 template <int MODEL, int D, int KC, bool FULL>
 struct CvModel;
 template <int D, int KC>
@@ -680,10 +818,14 @@ template <int D, int KC>
 struct CvModel<M_BM_SSM, D, KC, false> { typedef CvPrimalScal<D, false> Primal; typedef CvColsScal<D, KC, false> Cols; };
 template <int KC>
 struct CvModel<M_CTCRW, 2, KC, true> { typedef CvPrimalCtcrwFull Primal; typedef CvColsCtcrwFull<KC> Cols; };
+template <int KC>
+struct CvModel<M_OU_SSM, 2, KC, true> { typedef CvPrimalScalFull<true> Primal; typedef CvColsScalFull<KC, true> Cols; };
+template <int KC>
+struct CvModel<M_BM_SSM, 2, KC, true> { typedef CvPrimalScalFull<false> Primal; typedef CvColsScalFull<KC, false> Cols; };
 
 // components of a part's hand-over dump with kc column slots: the filter's block (written by part 0), then the columns
 int colvar_nstate(int model, int d, int kc, bool full) {
-    if (full) return 14 + kc * 14;                            // CTCRW, d = 2, 4 x 4 covariance
+    if (full) return model == M_CTCRW ? 14 + kc * 14 : 5 + kc * 5;     // d = 2: 4 x 4 covariance (CTCRW), 2 x 2 (OU_SSM, BM_SSM)
     return model == M_CTCRW ? 2 * d + 5 + (3 + 2 * d) + kc * (3 + 2 * d) : d + 2 + (1 + d) + kc * (1 + d);
 }
 
@@ -1050,11 +1192,12 @@ hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pi
 // whole dependent chain whatever the other waves do.  Here a wave runs the filter and its four tangents itself, four independent
 // waves per workgroup like k_iso.hip, with the same structs: the filter writes the row's linearisation to the wave's own LDS slab
 // and the tangents read it back (no barrier: one wave).  Rows are prefetched two ahead in ping-pong registers.
-template <bool UNI>
+template <int MODEL, bool UNI>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoArgs A, const CvPart* parts) {
-    typedef CvPrimalCtcrwFull Primal;
-    typedef CvColsCtcrwFull<2> Cols;                            // slots 0, 1 of parts[0]: log tau, log nu (dP and da)
-    constexpr int D = 2, SD = 4, U = 2, W = 1 + D + 4;         // register block row: [dt | y | H00 H10 H01 H11]
+    typedef typename CvModel<MODEL, 2, 2, true>::Primal Primal;
+    typedef typename CvModel<MODEL, 2, 2, true>::Cols Cols;    // slots 0, 1 of parts[0]: par[d], par[d + 1] (dP and da)
+    typedef typename Primal::Trans Trans;
+    constexpr int D = 2, SD = Primal::SD, NM = Cols::NMEAN, U = 2, W = 1 + D + 4;      // register block row: [dt | y | H00 H10 H01 H11]
     __shared__ double lin[WG_WAVES][Primal::NLIN * WAVE];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     int g, part, chunk;
@@ -1091,7 +1234,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
     Cols S;
     S.init();
     // the drift-intercept tangents: dP stays zero (B mu does not enter the covariance), so only da' = L da + B e_a is carried
-    double ma[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, mg[2] = {0, 0};
+    double ma[2][NM], mg[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < NM; i++) ma[0][i] = ma[1][i] = 0.0;
     {
         double a0[SD];
         if (s_begin == 0) {
@@ -1099,7 +1244,11 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
             for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
         } else {
 #pragma unroll
-            for (int a = 0; a < D; a++) { const double y0 = bufA[0][1 + a]; a0[2 * a] = (y0 == y0) ? y0 : 0.0; a0[2 * a + 1] = 0.0; }
+            for (int a = 0; a < D; a++) {
+                const double y0 = bufA[0][1 + a];
+                if constexpr (MODEL == M_CTCRW) { a0[2 * a] = (y0 == y0) ? y0 : 0.0; a0[2 * a + 1] = 0.0; }
+                else a0[a] = (y0 == y0) ? y0 : 0.0;
+            }
         }
         F.init(a0, A.cv_p0);
     }
@@ -1110,15 +1259,17 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) o[(Primal::NDUMP + 2 * 14 + 4 * j + i) * WAVE] = ma[j][i];
+            for (int i = 0; i < NM; i++) o[(Primal::NDUMP + 2 * Cols::NCOL + NM * j + i) * WAVE] = ma[j][i];
     };
     auto block = [&](const double (&blk)[U][W], int s0) {
         if (s0 == s_acc && s_acc > s_begin) { dump(dump0); F.reset_acc(); S.reset_acc(); mg[0] = mg[1] = 0.0; }
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (s0 + u < ns) {
-                CtcrwTrans tr;
-                if constexpr (UNI) tr = A.ctr; else ctcrw_trans(blk[u][0], A.tau, A.beta, A.sigma, tr);
+                Trans tr;
+                if constexpr (MODEL == M_CTCRW) { if constexpr (UNI) tr = A.ctr; else ctcrw_trans(blk[u][0], A.tau, A.beta, A.sigma, tr); }
+                else if constexpr (MODEL == M_OU_SSM) { if constexpr (UNI) tr = A.str; else ou_trans(blk[u][0], A.tau, A.sigma, tr); }
+                else { if constexpr (UNI) tr = A.str; else bm_trans(blk[u][0], A.sigma, tr); }
                 const double H[3] = {blk[u][1 + D], blk[u][1 + D + 2], blk[u][1 + D + 3]};
                 F.step(tr, H, mu, &blk[u][1], is_na(blk[u][1], A.any_nan), lo);
                 if (n_col > 0) {
@@ -1126,17 +1277,8 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
                     li.read(lo);
                     const double X[2][4] = {{ty0 == 1 ? 1.0 : 0.0, ty0 == 2 ? 1.0 : 0.0, 0.0, 0.0}, {ty1 == 1 ? 1.0 : 0.0, ty1 == 2 ? 1.0 : 0.0, 0.0, 0.0}};
                     S.template step<0, 2>(li, X);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const double on = (j == 0 ? mu0 : mu1) ? 1.0 : 0.0;
-                        const double z0 = ma[j][0], z1 = ma[j][1], z2 = ma[j][2], z3 = ma[j][3];
-                        mg[j] = fma(-li.w0, z0, fma(-li.w1, z2, mg[j]));
-                        const double b1 = on * li.sb(0), b2 = on * li.sb(1);
-                        ma[j][0] = fma(li.l00, z0, fma(li.t, z1, li.l02 * z2)) + (j == 0 ? b1 : 0.0);
-                        ma[j][1] = fma(li.l10, z0, fma(li.e, z1, li.l12 * z2)) + (j == 0 ? b2 : 0.0);
-                        ma[j][2] = fma(li.l20, z0, fma(li.l22, z2, li.t * z3)) + (j == 1 ? b1 : 0.0);
-                        ma[j][3] = fma(li.l30, z0, fma(li.l32, z2, li.e * z3)) + (j == 1 ? b2 : 0.0);
-                    }
+                    Cols::mean_step(li, ma[0], mg[0], 0, mu0);
+                    Cols::mean_step(li, ma[1], mg[1], 1, mu1);
                 }
             }
     };
@@ -1157,14 +1299,16 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
 }
 // a.n_parts == 1; parts[0]: slots 0, 1 = log tau, log nu, slots 2, 3 = the drift intercepts (type 0: not wanted); hand-over record:
 // filter 14 | two tangents 2 x 14 | two drift tangents 2 x 4
-hipError_t launch_iso_full(const IsoArgs& a, const CvPart* parts, hipStream_t s) {
+hipError_t launch_iso_full(int model, const IsoArgs& a, const CvPart* parts, hipStream_t s) {
     if (a.n_parts != 1 || !a.cv_has_h) return hipErrorInvalidValue;
     const int g8 = (a.tv.n_groups + 7) / 8;
     dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
-    if (a.uniform_dt) hipLaunchKernelGGL((iso_full_kernel<true>), grid, block, 0, s, a, parts);
-    else hipLaunchKernelGGL((iso_full_kernel<false>), grid, block, 0, s, a, parts);
-    return hipGetLastError();
+#define SSDE_CASE(M_) if (model == M_) { if (a.uniform_dt) hipLaunchKernelGGL((iso_full_kernel<M_, true>), grid, block, 0, s, a, parts); \
+                                         else hipLaunchKernelGGL((iso_full_kernel<M_, false>), grid, block, 0, s, a, parts); return hipGetLastError(); }
+    SSDE_CASE(M_CTCRW) SSDE_CASE(M_OU_SSM) SSDE_CASE(M_BM_SSM)
+#undef SSDE_CASE
+    return hipErrorInvalidValue;
 }
 
 // per group: the largest diagonal entry of H_array[,,i] over its rows, and the largest |H01 - H10| (create time: the window
@@ -1223,11 +1367,15 @@ hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* p
     if (a.n_parts != CV_WAVES || a.drift_k < 0 || a.drift_k > DRIFT_KMAX || a.tv.C > CV_CMAX || kc < 0 || kc > CV_KC) return hipErrorInvalidValue;
     dim3 grid(a.tv.n_groups * a.n_chunks), block(CV_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
-    if (a.cv_full) {                                           // 4 x 4 covariance lanes: CTCRW, d = 2
-        if (model != M_CTCRW || d != 2) return hipErrorInvalidValue;
-        if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 2, true>), grid, block, 0, s, a, parts);
-        else if (kc <= 3) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 3, true>), grid, block, 0, s, a, parts);
-        else hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 4, true>), grid, block, 0, s, a, parts);
+    if (a.cv_full) {                                           // full-covariance lanes, d = 2: 4 x 4 (CTCRW), 2 x 2 (OU_SSM, BM_SSM)
+        if (d != 2) return hipErrorInvalidValue;
+        if (model == M_CTCRW) {
+            if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 2, true>), grid, block, 0, s, a, parts);
+            else if (kc <= 3) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 3, true>), grid, block, 0, s, a, parts);
+            else hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 4, true>), grid, block, 0, s, a, parts);
+        } else if (model == M_OU_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_OU_SSM, 2, 4, true>), grid, block, 0, s, a, parts);
+        else if (model == M_BM_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_BM_SSM, 2, 4, true>), grid, block, 0, s, a, parts);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
 #define SSDE_CASE(M_, D_) if (model == M_ && d == D_) return launch_cv<M_, D_>(a, parts, kc, grid, block, s);

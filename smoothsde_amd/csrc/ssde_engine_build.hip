@@ -226,7 +226,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = h->cv_single ? 14 + 2 * 14 + 2 * 4 : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
+        h->drift_nstate = h->cv_single ? (h->model == SSDE_MODEL_CTCRW ? 14 + 2 * 14 + 2 * 4 : 5 + 2 * 5 + 2 * 2) : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
         if (h->has_h) {
             DevBuf<double> hs;
             HIPCHK(h, hs.alloc((size_t)G * 2));
@@ -738,7 +738,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // one animal) stay on the lane = direction path, whose windows cut ONE track into a hundred concurrent pieces.
         // (a per-row H_array couples the dimensions: CTCRW with d = 2 has 4 x 4 covariance lanes in k_iso_colvar.hip, any P0)
         const bool iso_cfg = !h->has_h && p0_is_isotropic(d, h->p0_iso);
-        const bool full_cfg = h->has_h && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_NO_COLVAR_FULL");
+        const bool full_cfg = h->has_h && h->d == 2 && !getenv("SSDE_NO_COLVAR_FULL");
         // (one response column: H_array[,,i] is the row's measurement variance -- the isotropic lanes of k_iso_colvar.hip with h = H_i)
         const bool h1_cfg = h->has_h && h->d == 1 && p0_is_isotropic(d, h->p0_iso) && !getenv("SSDE_NO_COLVAR_FULL");
         // (... also with CONSTANT coefficients: tracks with error ellipses and one tau, one nu -- the intercepts are columns of ones)

@@ -410,7 +410,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
-            if (h->cv_single) HIPCHK(h, launch_iso_full(a, h->cv_parts.p, s));
+            if (h->cv_single) HIPCHK(h, launch_iso_full(h->model, a, h->cv_parts.p, s));
             else {
             const int n_wg = h->n_groups * a.n_chunks;
             if ((int)h->cv_ranges.n < 4 * n_wg) { h->cv_ranges.release(); HIPCHK(h, h->cv_ranges.alloc((size_t)4 * n_wg)); }

@@ -382,6 +382,62 @@ def test_constant_coefficients_with_error_ellipses_take_the_full_covariance_lane
     eng.close(); e2.close()
 
 
+H2_GOLD = [r for r in GOLD if r["name"] in ("CTCRW_d2_H", "OU_SSM_d2_H", "BM_SSM_d2_H")]
+
+
+@pytest.mark.parametrize("rec", H2_GOLD, ids=[r["name"] for r in H2_GOLD])
+def test_golden_two_column_cases_with_h_array(rec, monkeypatch):
+    """Constant coefficients with per-row 2 x 2 measurement covariances: one wave per (group, window) runs the full-covariance
+    filter and its tangents (iso_full_kernel: 4 x 4 for CTCRW, 2 x 2 for OU_SSM / BM_SSM)."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == PATH_ISO
+    val, grad = eng.eval(rec["par"], order=1)
+    _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
+    aest = eng.report(rec["par"])
+    assert np.allclose(aest, rec["expected"]["aest_all"], rtol=1e-10, atol=1e-10)
+    eng.close()
+
+
+@pytest.mark.parametrize("model,k1,k2,irregular", [("OU_SSM", 6, 5, False), ("OU_SSM", 0, 0, True), ("BM_SSM", 7, 0, True), ("BM_SSM", 0, 0, False),
+                                                   ("OU_SSM", 0, 8, True)])
+def test_scalar_models_with_error_ellipses_vs_oracle(model, k1, k2, irregular, monkeypatch):
+    """OU_SSM / BM_SSM, d = 2, H_array (nllk_ou_ssm.hpp:171-172, nllk_bm_ssm.hpp:135-136): full 2 x 2 covariance lanes, through
+    the pipeline (row-varying coefficients) or one wave per (group, window) (constant coefficients)."""
+    const = k1 == 0 and k2 == 0
+    pb, par = _batch(model, 2, 96, 700, k1 or (0 if k2 else 3), k2, seed=91)
+    rng = np.random.default_rng(5)
+    o, t = pb.obs.copy(), pb.times.copy()
+    na = rng.random(pb.n) < 0.03
+    na[pb.seg_start] = False
+    o[na, 0] = np.nan
+    if irregular:
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    H = _with_h(pb, 11)
+    if const:
+        pb2 = capi.Problem(model, pb.id, t, o, H=H)
+        par = par[:pb2.n_par_full].copy()
+    else:
+        pb2 = capi.Problem(model, pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, H=H)
+    eng = capi.Engine(pb2)
+    inf = eng.info()
+    assert inf["path"] == PATH_ISO and inf["const_coeff"] == (1 if const else 0)
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    assert grad[0] == 0.0
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb2, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb2)
+    assert e2.info()["path"] == PATH_TV
+    v2, g2 = e2.eval(par)
+    assert abs(val - v2) <= 1e-10 * max(1.0, abs(val)) and np.max(np.abs(grad - g2)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e2.close()
+
+
 H1_GOLD = [r for r in GOLD if r["name"] in ("CTCRW_d1_H", "OU_SSM_d1_H", "BM_SSM_d1_H")]
 
 
