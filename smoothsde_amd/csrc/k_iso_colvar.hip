@@ -49,7 +49,7 @@ namespace ssde {
 template <int D>
 struct CvPrimalCtcrw {
     static constexpr int SD = 2 * D;
-    static constexpr int NLIN = 15 + 3 * D;
+    static constexpr int NLIN = 17 + 3 * D;
     static constexpr int NCOL = 3 + 2 * D;                     // doubles of a tangent
     static constexpr int NDUMP = SD + 3 + 2 + NCOL;
     typedef CtcrwTrans Trans;
@@ -113,8 +113,9 @@ struct CvPrimalCtcrw {
             const double w = fma(kf2, u[a_], v[a_] - mue[a_]);     // d k u + d(T a + B mu): (dt12, de) (kf2 u + v - mu)
             lin[(n++) * WAVE] = tr.dt12 * w; lin[(n++) * WAVE] = tr.de * w;
         }
-        // ... log nu Q only (dQ = 2 Q)
+        // ... log nu Q only (dQ = 2 Q), a drift column B e_a only
         lin[(n++) * WAVE] = 2.0 * tr.q11; lin[(n++) * WAVE] = 2.0 * tr.q12; lin[(n++) * WAVE] = 2.0 * tr.q22;
+        lin[(n++) * WAVE] = bm * tr.b1; lin[(n++) * WAVE] = bm * tr.b2;
         if (with_sig) {
             // log sigma_obs: dh = 2 h enters F, the filtered covariance (k k' dh) and the gain (-k dh / F)
             const double h2 = 2.0 * h, dF = s11 + h2;
@@ -217,7 +218,7 @@ struct CvColsCtcrw {
         for (int k = 0; k < KC; k++) g[k] = 0.0;
     }
     struct Lin {                                               // a row's linearisation, read from LDS once per row
-        double iF, a, aiF, kf2, t12, e, c1, k2, gF, u[D], s1_11, s1_12, s1_22, s1_x[D], s1_v[D], s2_11, s2_12, s2_22;
+        double iF, a, aiF, kf2, t12, e, c1, k2, gF, u[D], s1_11, s1_12, s1_22, s1_x[D], s1_v[D], s2_11, s2_12, s2_22, sb1, sb2;
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             iF = lin[(n++) * WAVE]; a = lin[(n++) * WAVE]; aiF = lin[(n++) * WAVE]; kf2 = lin[(n++) * WAVE]; t12 = lin[(n++) * WAVE];
@@ -228,11 +229,12 @@ struct CvColsCtcrw {
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) { s1_x[a_] = lin[(n++) * WAVE]; s1_v[a_] = lin[(n++) * WAVE]; }
             s2_11 = lin[(n++) * WAVE]; s2_12 = lin[(n++) * WAVE]; s2_22 = lin[(n++) * WAVE];
+            sb1 = lin[(n++) * WAVE]; sb2 = lin[(n++) * WAVE];
         }
     };
-    // slots [K0, K1): X1[k] / X2[k] = the column's value if it feeds log tau / log nu, else 0
+    // slots [K0, K1): X[k][j] = the column's value if it is of kind j (0: feeds log tau, 1: log nu, 2: mu_1, 3: mu_2), else 0
     template <int K0, int K1>
-    __device__ __forceinline__ void step(const Lin& L, const double* X1, const double* X2) {
+    __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
         const double iF = L.iF, a = L.a, aiF = L.aiF, kf2 = L.kf2, t12 = L.t12, e = L.e, c1 = L.c1, k2 = L.k2, gF = L.gF;
         const double* u = L.u; const double* s1_x = L.s1_x; const double* s1_v = L.s1_v;
         const double s1_11 = L.s1_11, s1_12 = L.s1_12, s1_22 = L.s1_22, s2_11 = L.s2_11, s2_12 = L.s2_12, s2_22 = L.s2_22;
@@ -249,15 +251,15 @@ struct CvColsCtcrw {
             const double dkf1 = c11 * aiF, dkf2 = w * iF;
             const double dm = fma(t12, g22, g12);
             const double dk1 = fma(t12, dkf2, dkf1), dk2 = e * dkf2;
-            const double x1 = X1[k], x2 = X2[k];
+            const double x1 = X[k][0], x2 = X[k][1];
             d11[k] = fma(x2, s2_11, fma(x1, s1_11, fma(t12, g12 + dm, g11)));
             d12[k] = fma(x2, s2_12, fma(x1, s1_12, e * dm));
             d22[k] = fma(x2, s2_22, fma(x1, s1_22, e2 * g22));
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
-                const double txk = tx[k][a_], tvk = tv[k][a_];
-                tx[k][a_] = fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk)));
-                tv[k][a_] = fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk)));
+                const double txk = tx[k][a_], tvk = tv[k][a_], xm = X[k][2 + a_];      // (a drift column of dimension a_: B e_a)
+                tx[k][a_] = fma(xm, L.sb1, fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk))));
+                tv[k][a_] = fma(xm, L.sb2, fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk))));
             }
         }
     }
@@ -507,7 +509,7 @@ struct CvColsCtcrwFull {
 template <int D, bool HAS_P2>
 struct CvPrimalScal {
     static constexpr int SD = D;
-    static constexpr int NLIN = 7 + 2 * D;
+    static constexpr int NLIN = 8 + 2 * D;
     static constexpr int NCOL = 1 + D;
     static constexpr int NDUMP = SD + 1 + 1 + NCOL;
     typedef ScalTrans Trans;
@@ -560,6 +562,7 @@ struct CvPrimalScal {
 #pragma unroll
         for (int a_ = 0; a_ < D; a_++) lin[(n++) * WAVE] = HAS_P2 ? fma(s1_k, u[a_], fma(tr.dt_, x[a_], tr.db * mu[a_])) : 0.0;
         lin[(n++) * WAVE] = tr.q;                                   // log kappa (OU)
+        lin[(n++) * WAVE] = tr.b;                                   // a drift column: b e_a
         if (with_sig) {
             const double h2 = 2.0 * h, bh = b * h2, dF = sp + h2;
             double sud = 0.0;
@@ -637,7 +640,7 @@ struct CvColsScal {
         for (int k = 0; k < KC; k++) g[k] = 0.0;
     }
     struct Lin {
-        double iF, ca, tca, c, gF, u[D], s1_p, s1_x[D], s2_p;
+        double iF, ca, tca, c, gF, u[D], s1_p, s1_x[D], s2_p, sb;
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             iF = lin[(n++) * WAVE]; ca = lin[(n++) * WAVE]; tca = lin[(n++) * WAVE]; c = lin[(n++) * WAVE]; gF = lin[(n++) * WAVE];
@@ -646,11 +649,11 @@ struct CvColsScal {
             s1_p = lin[(n++) * WAVE];
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) s1_x[a_] = lin[(n++) * WAVE];
-            s2_p = lin[(n++) * WAVE];
+            s2_p = lin[(n++) * WAVE]; sb = lin[(n++) * WAVE];
         }
     };
     template <int K0, int K1>
-    __device__ __forceinline__ void step(const Lin& L, const double* X1, const double* X2) {
+    __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
         const double iF = L.iF, ca = L.ca, tca = L.tca, c = L.c, gF = L.gF, s1_p = L.s1_p, s2_p = L.s2_p;
         const double* u = L.u; const double* s1_x = L.s1_x;
 #pragma unroll
@@ -661,11 +664,11 @@ struct CvColsScal {
             for (int a_ = 0; a_ < D; a_++) sud = fma(u[a_], tx[k][a_], sud);
             g[k] = fma(gF, cdp, fma(-iF, sud, g[k]));
             const double dk = ca * cdp;
-            const double x1 = X1[k], x2 = X2[k];
+            const double x1 = X[k][0], x2 = X[k][1];
             dp[k] = HAS_P2 ? fma(x2, s2_p, fma(x1, s1_p, tca * cdp)) : fma(x1, s1_p, tca * cdp);
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
-                const double nx = fma(dk, u[a_], c * tx[k][a_]);
+                const double nx = fma(X[k][2 + a_], L.sb, fma(dk, u[a_], c * tx[k][a_]));
                 tx[k][a_] = HAS_P2 ? fma(x1, s1_x[a_], nx) : nx;
             }
         }
@@ -845,12 +848,12 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     typedef typename Primal::Trans Trans;
     constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
     __shared__ double raw[3][CV_LD * CV_LOADERS * WAVE];       // the staged rows
-    __shared__ double eta[2][(2 * CV_LOADERS + 1) * WAVE];     // per row: the loading waves' partial sums of p1, p2, and the interval
-    __shared__ double trs[2][NTR * WAVE];                      // per row: the transition
+    __shared__ double eta[2][(4 * CV_LOADERS + 1) * WAVE];     // per row: the loading waves' partial sums of p1, p2 (and mu_1, mu_2), and the interval
+    __shared__ double trs[2][(NTR + 2) * WAVE];                // per row: the transition (and the row's drift, when it has design columns)
     __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
     __shared__ double fst[Primal::NSAVE * WAVE];               // the filter's state between rows (wave 0; see below)
-    __shared__ double coef[DRIFT_KMAX][2];
-    __shared__ double wcoef[CV_LOADERS][CV_LD][2];
+    __shared__ double coef[DRIFT_KMAX][4];                     // per streamed column: its coefficient in p1, p2, mu_1, mu_2 (0: not in that predictor)
+    __shared__ double wcoef[CV_LOADERS][CV_LD][4];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     const int lane = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: the part tables are read with scalar loads)
     // the two stage waves are the row's critical path (each a long dependent chain): they neither stage rows nor, unless the
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
     constexpr int nacc = 2 + CV_KC + D;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < DRIFT_KMAX; k++) { coef[k][0] = A.coefA[k]; coef[k][1] = A.coefB[k]; }
+        for (int k = 0; k < DRIFT_KMAX; k++) { coef[k][0] = A.coefA[k]; coef[k][1] = A.coefB[k]; coef[k][2] = A.coefC[k]; coef[k][3] = A.coefD[k]; }
     }
     __syncthreads();
     // the channels a loading wave stages are c = loader + 6 i; those that are design columns enter the linear predictors with their
@@ -876,9 +879,10 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         const int k = ldr + CV_LOADERS * i - c_col;
         const bool on = k >= 0 && k < K;
         if (on) col_bits |= 1u << i;
-        if (lane == 0 && loader) { wcoef[ldr][i][0] = on ? coef[on ? k : 0][0] : 0.0; wcoef[ldr][i][1] = on ? coef[on ? k : 0][1] : 0.0; }
+        if (lane < 4 && loader) wcoef[ldr][i][lane] = on ? coef[on ? k : 0][lane] : 0.0;
     }
     const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- no tangents)
+    const bool mu_cols = A.cv_mu_cols != 0;                    // the drift has design columns too
     const int n_col = grad ? parts[part].n_col : 0;
     const bool with_mu = grad && parts[CV_FILTER].with_mu, with_sig = grad && parts[CV_FILTER].with_sig;
     // per slot: the channel to read, and what the value read is -- a column of ones / a column that feeds par[d] / par[d + 1]
@@ -923,29 +927,37 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         for (int i = 0; i < CV_LD; i++) raw[slot][(ldr + CV_LOADERS * i) * WAVE + lane] = src[i];
     };
     auto st_eta = [&](const double (&src)[CV_LD], int slot) {  // this wave's terms of the row's linear predictors
-        double pa = 0.0, pb = 0.0;
+        double pa = 0.0, pb = 0.0, pm0 = 0.0, pm1 = 0.0;
 #pragma unroll
         for (int i = 0; i < CV_LD; i++) {
             const double xs = ((col_bits >> i) & 1u) ? src[i] : 0.0;      // (an observation may be NaN: 0 * NaN is not 0)
             pa = fma(wcoef[ldr][i][0], xs, pa);
             if (MODEL != M_BM_SSM) pb = fma(wcoef[ldr][i][1], xs, pb);
+            if (mu_cols) { pm0 = fma(wcoef[ldr][i][2], xs, pm0); if (D > 1) pm1 = fma(wcoef[ldr][i][3], xs, pm1); }
         }
-        eta[slot][(2 * ldr) * WAVE + lane] = pa;
-        eta[slot][(2 * ldr + 1) * WAVE + lane] = pb;
-        if (ldr == 0) eta[slot][(2 * CV_LOADERS) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
+        eta[slot][(4 * ldr) * WAVE + lane] = pa;
+        eta[slot][(4 * ldr + 1) * WAVE + lane] = pb;
+        if (mu_cols) { eta[slot][(4 * ldr + 2) * WAVE + lane] = pm0; eta[slot][(4 * ldr + 3) * WAVE + lane] = pm1; }
+        if (ldr == 0) eta[slot][(4 * CV_LOADERS) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
     double p1_lo = INFINITY, p1_hi = -INFINITY, p2_lo = INFINITY, p2_hi = -INFINITY;      // (the transition wave: what the predictors reached)
     auto produce = [&](int slot, int s) {                      // stage 1: the transition of row s, whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
-        for (int w = 0; w < CV_LOADERS; w++) { p1 += e_[(2 * w) * WAVE]; p2 += e_[(2 * w + 1) * WAVE]; }
+        for (int w = 0; w < CV_LOADERS; w++) { p1 += e_[(4 * w) * WAVE]; p2 += e_[(4 * w + 1) * WAVE]; }
         if (s < ns) { p1_lo = fmin(p1_lo, p1); p1_hi = fmax(p1_hi, p1); p2_lo = fmin(p2_lo, p2); p2_hi = fmax(p2_hi, p2); }
-        const double dtc = e_[(2 * CV_LOADERS) * WAVE];
+        const double dtc = e_[(4 * CV_LOADERS) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
         Primal::trans(dt, p1, p2, tr);
         Primal::put_trans(&trs[slot][lane], tr);
+        if (mu_cols) {                                         // a row-varying drift: mu_a(i) = intercept + its columns' terms, handed to the filter with the transition
+            double m0 = A.mu[0], m1 = A.mu[D - 1];
+#pragma unroll
+            for (int w = 0; w < CV_LOADERS; w++) { m0 += e_[(4 * w + 2) * WAVE]; m1 += e_[(4 * w + 3) * WAVE]; }
+            trs[slot][NTR * WAVE + lane] = m0; trs[slot][(NTR + 1) * WAVE + lane] = m1;
+        }
     };
     // The filter's state lives in LDS between rows: only wave 0 ever touches it, and held in registers across the row loop it
     // would take ~45 of every wave's 256 (a kernel's allocation is the union of its waves' roles)
@@ -968,9 +980,9 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         if constexpr (FULL) F.init(a0, A.cv_p0); else F.init(a0, A.p0);
         F.save(&fst[lane]);
     }
-    double mu[D];
+    double mu_c[D];
 #pragma unroll
-    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
+    for (int a = 0; a < D; a++) mu_c[a] = A.mu[a];
     const double h = A.h;
     auto filter = [&](int s, int slot3, int slot2) {           // stage 2 (wave 0): row s -- its y in raw[slot3], its transition in trs[slot2]
         Primal F;
@@ -984,6 +996,9 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             for (int a = 0; a < D; a++) y[a] = r[(c_obs + a) * WAVE];
             Trans tr;
             Primal::get_trans(&trs[slot2][lane], tr);
+            double mu[D];
+#pragma unroll
+            for (int a = 0; a < D; a++) mu[a] = mu_cols ? trs[slot2][(NTR + a) * WAVE + lane] : mu_c[a];
             if constexpr (FULL) {
                 double H[3] = {h, 0.0, h};                          // H_array[,,i] (symmetric, checked at create)
                 if (A.cv_has_h) { H[0] = r[(c_obs + D) * WAVE]; H[1] = r[(c_obs + D + 2) * WAVE]; H[2] = r[(c_obs + D + 3) * WAVE]; }
@@ -1005,26 +1020,15 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             li.read(&lin[slot2][lane]);
             auto quarter = [&](auto k0) {                          // (a wave that also runs a stage is dealt fewer slots: whole quarters are skipped)
                 constexpr int K0 = decltype(k0)::value, K1 = K0 + (KC + 3) / 4 < KC ? K0 + (KC + 3) / 4 : KC;
-                if constexpr (FULL) {
-                    double X[KC][4];
+                double X[KC][4];
 #pragma unroll
-                    for (int k = K0; k < K1; k++) {
-                        const double xl = r[chan[k] * WAVE];
-                        const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
-                        X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
-                        X[k][2] = ((t3_bits >> k) & 1u) ? xk : 0.0; X[k][3] = ((t4_bits >> k) & 1u) ? xk : 0.0;
-                    }
-                    S.template step<K0, K1>(li, X);
-                } else {
-                    double X1[KC], X2[KC];
-#pragma unroll
-                    for (int k = K0; k < K1; k++) {
-                        const double xl = r[chan[k] * WAVE];
-                        const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
-                        X1[k] = ((t1_bits >> k) & 1u) ? xk : 0.0; X2[k] = ((t2_bits >> k) & 1u) ? xk : 0.0;
-                    }
-                    S.template step<K0, K1>(li, X1, X2);
+                for (int k = K0; k < K1; k++) {
+                    const double xl = r[chan[k] * WAVE];
+                    const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
+                    X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+                    X[k][2] = ((t3_bits >> k) & 1u) ? xk : 0.0; X[k][3] = ((t4_bits >> k) & 1u) ? xk : 0.0;
                 }
+                S.template step<K0, K1>(li, X);
             };
             constexpr int Q = (KC + 3) / 4;
             if (n_col > 0) quarter(std::integral_constant<int, 0>());

@@ -123,6 +123,9 @@ struct IsoArgs {
     // Row-varying tau / nu (kappa, sigma) on lane = track lanes (k_iso_colvar.hip): the linear predictors are
     // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
     double cv_eta0[2];
+    double coefC[DRIFT_KMAX];    // ... and a row-varying drift next to them: column k's coefficient in mu_1, mu_2 (cv_mu_cols != 0)
+    double coefD[DRIFT_KMAX];
+    int cv_mu_cols;
     double* cv_ranges;           // [workgroup][4]: min / max of p1, min / max of p2 over the workgroup's rows, or NULL
     int cv_full;                 // 4 x 4 covariance lanes (CTCRW, d = 2): per-row H_array and / or a P0 that is not block-identical
     int cv_has_h;                // ... the tiles hold H_array[,,i] in the d^2 channels after the observations
@@ -138,7 +141,7 @@ struct CvPart {
     int32_t with_mu;             // the part also carries the drift-intercept direction
     int32_t with_sig;            // ... the log sigma_obs direction
     int32_t chan[CV_KC];         // tile channel of the slot's design column, -1 = a column of ones (an intercept)
-    int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa); full-covariance lanes: 3, 4 = mu_1, mu_2
+    int32_t type[CV_KC];         // 1: the column feeds par[d] (log tau / log sigma), 2: par[d + 1] (log nu / log kappa), 3, 4: mu_1, mu_2
 };
 // partials [n_parts * n_chunks][2 + CV_KC + d][n_groups]: value | the part's columns | mu_1 .. mu_d | log sigma_obs;
 // a.n_parts == CV_WAVES; a.part_mask[0] == 0: the value only (no tangents); kc: the widest part's column count

@@ -143,6 +143,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         if (h->cv_full)                                            // the drift intercepts are columns of ones of kinds 3, 4 on those lanes
             for (auto& sl : h->slots)
                 if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) cols.push_back({3 + sl.par_j, -1, sl.pidx});
+        for (auto& sl : h->slots)                                  // the drift's design columns (a mixed design, or a smooth drift with H_array)
+            if (sl.par_j < h->d && sl.col >= 0 && !h->fixed[sl.pidx]) cols.push_back({3 + sl.par_j, c_col + sl.col, sl.pidx});
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
@@ -752,10 +754,16 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (iso_cfg && mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
-            // whatever the batch.  Mixed designs (columns in the drift AND in tau / nu) stay on that path.
-            bool par_only = (!mu_only || ((full_cfg || h1_cfg) && h->const_coeff)) && !getenv("SSDE_NO_COLVAR");
+            // whatever the batch.
+            // (a smooth drift alone, H = sigma_obs^2 I, took the drift kernels above; with H_array, or next to columns of tau / nu, the
+            //  drift's design columns are columns of kinds of their own here)
+            bool par_only = (!(mu_only && iso_cfg) || h->const_coeff) && !getenv("SSDE_NO_COLVAR");
+            if (h->const_coeff && !(full_cfg || h1_cfg)) par_only = false;
             for (auto& sl : h->slots)
-                if (sl.col >= 0 && (sl.par_j < h->d || (sl.basis_c >= 0 && !sl.src))) par_only = false;      // (a basis block materialised at create is a block of columns)
+                if (sl.col >= 0 && sl.basis_c >= 0 && !sl.src) par_only = false;      // (a basis block materialised at create is a block of columns)
+            if (getenv("SSDE_CV_NO_MU_COLS"))
+                for (auto& sl : h->slots)
+                    if (sl.col >= 0 && sl.par_j < h->d) par_only = false;
             // (measured, tools/bench_colvar.py --tracks M --rows 1000, 18 columns: 0.18 / 0.19 / 0.20 / 0.22 / 0.24 ms at M = 32 / 128 /
             //  256 / 512 / 1024 against 0.11 / 0.18 / 0.22 / 0.32 / 0.50 on the lane = direction path: the crossover is near 128 tracks)
             const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : 160;

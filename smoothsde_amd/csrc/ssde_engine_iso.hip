@@ -232,7 +232,10 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         for (int j = 0; j < 2; j++) h->cv_eta_lo[j] = h->cv_eta_hi[j] = 0.0;
         for (auto& sl : h->slots) {
             const int j = sl.par_j - h->d;
-            if (j < 0) continue;
+            if (j < 0) {                                        // a design column of the drift: mu_a(i) = intercept + sum_k coef_k X_k(i)
+                if (sl.col >= 0) { (sl.par_j == 0 ? a.coefC : a.coefD)[sl.col] = par[sl.pidx]; a.cv_mu_cols = 1; }
+                continue;
+            }
             const double b = par[sl.pidx];
             if (sl.col < 0) { a.cv_eta0[j] = b; h->cv_eta_lo[j] += b; h->cv_eta_hi[j] += b; continue; }
             (j == 0 ? a.coefA : a.coefB)[sl.col] = b;

@@ -476,6 +476,59 @@ def test_one_column_with_per_row_measurement_variance_vs_oracle(model, k1, k2):
     eng.close()
 
 
+@pytest.mark.parametrize("model,d,kmu,k1,k2,with_h", [("CTCRW", 2, (5, 4), 6, 0, False), ("CTCRW", 1, (6,), 0, 5, False), ("OU_SSM", 2, (0, 7), 5, 4, False),
+                                                     ("BM_SSM", 2, (4, 3), 6, 0, False), ("OU_SSM", 1, (5,), 4, 0, False), ("CTCRW", 2, (4, 0), 5, 5, True),
+                                                     ("OU_SSM", 2, (5, 5), 0, 0, True), ("CTCRW", 2, (0, 6), 0, 0, True)])
+def test_mixed_designs_drift_columns_next_to_tau_nu_columns(model, d, kmu, k1, k2, with_h, monkeypatch):
+    """mu_a smooth in a covariate AND tau / nu (kappa, sigma) smooth: the drift's design columns are columns of kinds of their
+    own, mu_a(i) reaches the filter wave with the row's transition.  With H_array also when only the drift is smooth."""
+    pb, par0 = _batch(model, d, 96, 700, k1, k2, seed=101)
+    n = pb.n
+    rng = np.random.default_rng(12)
+    xm = np.clip(0.5 + 0.4 * np.cos(np.arange(n) * 2 * np.pi / 53), 0, 1)
+    q = capi.n_sde_par(model, d)
+    X_re = list(pb.X_re) if pb.X_re is not None else [None] * q
+    S = []
+    for a in range(d):
+        if kmu[a]:
+            X_re[a] = bspline_basis(np.clip(xm ** (1 + a), 0, 1), kmu[a])
+    for j in range(q):
+        if X_re[j] is not None:
+            S.append(second_difference_penalty(X_re[j].shape[1]))
+    o = pb.obs.copy()
+    na = rng.random(n) < 0.03
+    na[pb.seg_start] = False
+    o[na, 0] = np.nan
+    H = _with_h(pb, 13) if with_h else None
+    pb2 = capi.Problem(model, pb.id, pb.times, o, X_re=X_re, S_list=S, H=H)
+    par = []
+    for nm in pb2.par_names():
+        if nm == "log_sigma_obs":
+            par.append(np.log(0.12))
+        elif nm.startswith("log_lambda"):
+            par.append(0.3)
+        elif nm.startswith("coeff_re"):
+            par.append(0.15 * rng.standard_normal())
+        else:
+            par.append(0.1 * rng.standard_normal() + (2.0 if model == "OU_SSM" and nm.startswith("coeff_fe[0]") else 0.0))
+    par = np.array(par)
+    par[pb2.off_fe + pb2.fe_off[d]] = np.log(2.0 if model != "BM_SSM" else 0.7)
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb2, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb2)
+    assert e2.info()["path"] == PATH_TV
+    v2, g2 = e2.eval(par)
+    assert abs(val - v2) <= 1e-10 * max(1.0, abs(val)) and np.max(np.abs(grad - g2)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e2.close()
+
+
 def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
     """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
     shared tau / nu coefficients are summed over the parts."""
@@ -505,14 +558,16 @@ def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatc
         assert eng.info()["path"] == want
         eng.close()
     monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
-    # a smooth in the drift AND in tau
+    # a smooth in the drift AND in tau with SSDE_CV_NO_MU_COLS: back to the lane = direction path
     pb, _ = _batch("CTCRW", 1, 64, 200, 5, 0, seed=3)
     B = bspline_basis(np.clip(np.linspace(0, 1, pb.n), 0, 1), 4)
     pb2 = capi.Problem("CTCRW", pb.id, pb.times, pb.obs, X_re=[B, pb.X_re[1], None],
                        S_list=[second_difference_penalty(4), second_difference_penalty(5)])
+    monkeypatch.setenv("SSDE_CV_NO_MU_COLS", "1")
     eng = capi.Engine(pb2)
     assert eng.info()["path"] == PATH_TV
     eng.close()
+    monkeypatch.delenv("SSDE_CV_NO_MU_COLS")
 
 
 def test_sharded_handle_and_one_rank_communicator():
