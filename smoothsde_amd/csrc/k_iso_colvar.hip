@@ -219,6 +219,7 @@ struct CvColsCtcrw {
     }
     struct Lin {                                               // a row's linearisation, read from LDS once per row
         double iF, a, aiF, kf2, t12, e, c1, k2, gF, u[D], s1_11, s1_12, s1_22, s1_x[D], s1_v[D], s2_11, s2_12, s2_22, sb1, sb2;
+        template <bool MU>
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             iF = lin[(n++) * WAVE]; a = lin[(n++) * WAVE]; aiF = lin[(n++) * WAVE]; kf2 = lin[(n++) * WAVE]; t12 = lin[(n++) * WAVE];
@@ -229,11 +230,13 @@ struct CvColsCtcrw {
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) { s1_x[a_] = lin[(n++) * WAVE]; s1_v[a_] = lin[(n++) * WAVE]; }
             s2_11 = lin[(n++) * WAVE]; s2_12 = lin[(n++) * WAVE]; s2_22 = lin[(n++) * WAVE];
-            sb1 = lin[(n++) * WAVE]; sb2 = lin[(n++) * WAVE];
+            sb1 = sb2 = 0.0;
+            if constexpr (MU) { sb1 = lin[(n++) * WAVE]; sb2 = lin[(n++) * WAVE]; }
         }
     };
-    // slots [K0, K1): X[k][j] = the column's value if it is of kind j (0: feeds log tau, 1: log nu, 2: mu_1, 3: mu_2), else 0
-    template <int K0, int K1>
+    // slots [K0, K1): X[k][j] = the column's value if it is of kind j (0: feeds log tau, 1: log nu, 2: mu_1, 3: mu_2), else 0;
+    // MU: drift columns may be among them
+    template <int K0, int K1, bool MU>
     __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
         const double iF = L.iF, a = L.a, aiF = L.aiF, kf2 = L.kf2, t12 = L.t12, e = L.e, c1 = L.c1, k2 = L.k2, gF = L.gF;
         const double* u = L.u; const double* s1_x = L.s1_x; const double* s1_v = L.s1_v;
@@ -257,9 +260,11 @@ struct CvColsCtcrw {
             d22[k] = fma(x2, s2_22, fma(x1, s1_22, e2 * g22));
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
-                const double txk = tx[k][a_], tvk = tv[k][a_], xm = X[k][2 + a_];      // (a drift column of dimension a_: B e_a)
-                tx[k][a_] = fma(xm, L.sb1, fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk))));
-                tv[k][a_] = fma(xm, L.sb2, fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk))));
+                const double txk = tx[k][a_], tvk = tv[k][a_];
+                double nx = fma(x1, s1_x[a_], fma(dk1, u[a_], fma(t12, tvk, c1 * txk)));
+                double nv = fma(x1, s1_v[a_], fma(dk2, u[a_], fma(e, tvk, -k2 * txk)));
+                if constexpr (MU) { nx = fma(X[k][2 + a_], L.sb1, nx); nv = fma(X[k][2 + a_], L.sb2, nv); }      // (a drift column of dimension a_: B e_a)
+                tx[k][a_] = nx; tv[k][a_] = nv;
             }
         }
     }
@@ -425,6 +430,7 @@ struct CvColsCtcrwFull {
     struct Lin {
         double l00, l02, l10, l12, l20, l22, l30, l32, t, e, w0, w1, c00, c02, c22;
         const double* seeds;                                   // s1[10] | sa[4] | s2[3] | sb[2], each [j * WAVE]
+        template <bool MU>
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             l00 = lin[(n++) * WAVE]; l02 = lin[(n++) * WAVE]; l10 = lin[(n++) * WAVE]; l12 = lin[(n++) * WAVE];
@@ -438,7 +444,7 @@ struct CvColsCtcrwFull {
         __device__ __forceinline__ double s2(int i) const { return seeds[(14 + i) * WAVE]; }
         __device__ __forceinline__ double sb(int i) const { return seeds[(17 + i) * WAVE]; }
     };
-    template <int K0, int K1>
+    template <int K0, int K1, bool MU>
     __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
 #pragma unroll
         for (int k = K0; k < K1; k++) {
@@ -641,6 +647,7 @@ struct CvColsScal {
     }
     struct Lin {
         double iF, ca, tca, c, gF, u[D], s1_p, s1_x[D], s2_p, sb;
+        template <bool MU>
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             iF = lin[(n++) * WAVE]; ca = lin[(n++) * WAVE]; tca = lin[(n++) * WAVE]; c = lin[(n++) * WAVE]; gF = lin[(n++) * WAVE];
@@ -649,10 +656,11 @@ struct CvColsScal {
             s1_p = lin[(n++) * WAVE];
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) s1_x[a_] = lin[(n++) * WAVE];
-            s2_p = lin[(n++) * WAVE]; sb = lin[(n++) * WAVE];
+            s2_p = lin[(n++) * WAVE]; sb = 0.0;
+            if constexpr (MU) sb = lin[(n++) * WAVE];
         }
     };
-    template <int K0, int K1>
+    template <int K0, int K1, bool MU>
     __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
         const double iF = L.iF, ca = L.ca, tca = L.tca, c = L.c, gF = L.gF, s1_p = L.s1_p, s2_p = L.s2_p;
         const double* u = L.u; const double* s1_x = L.s1_x;
@@ -668,7 +676,8 @@ struct CvColsScal {
             dp[k] = HAS_P2 ? fma(x2, s2_p, fma(x1, s1_p, tca * cdp)) : fma(x1, s1_p, tca * cdp);
 #pragma unroll
             for (int a_ = 0; a_ < D; a_++) {
-                const double nx = fma(X[k][2 + a_], L.sb, fma(dk, u[a_], c * tx[k][a_]));
+                double nx = fma(dk, u[a_], c * tx[k][a_]);
+                if constexpr (MU) nx = fma(X[k][2 + a_], L.sb, nx);
                 tx[k][a_] = HAS_P2 ? fma(x1, s1_x[a_], nx) : nx;
             }
         }
@@ -767,6 +776,7 @@ struct CvColsScalFull {
     }
     struct Lin {
         double l00, l01, l10, l11, w0, w1, c00, c01, c11, s1[3], sa[2], s2, b;
+        template <bool MU>
         __device__ __forceinline__ void read(const double* lin) {
             int n = 0;
             l00 = lin[(n++) * WAVE]; l01 = lin[(n++) * WAVE]; l10 = lin[(n++) * WAVE]; l11 = lin[(n++) * WAVE];
@@ -775,7 +785,7 @@ struct CvColsScalFull {
             sa[0] = lin[(n++) * WAVE]; sa[1] = lin[(n++) * WAVE]; s2 = lin[(n++) * WAVE]; b = lin[(n++) * WAVE];
         }
     };
-    template <int K0, int K1>
+    template <int K0, int K1, bool MU>
     __device__ __forceinline__ void step(const Lin& L, const double (*X)[4]) {
 #pragma unroll
         for (int k = K0; k < K1; k++) {
@@ -841,15 +851,17 @@ static_assert(CV_LD * CV_LOADERS >= CV_CMAX && CV_CMAX >= 1 + 2 + 4 + DRIFT_KMAX
 constexpr int CV_FILTER = 0;                                            // the wave that runs the primal filter
 
 // KC: column slots per wave (even; the engine picks the instantiation from the widest part)
-template <int MODEL, int D, int KC, bool FULL>
+// MU: drift design columns may be among the columns (always on the full-covariance lanes, whose drift intercepts are such columns)
+template <int MODEL, int D, int KC, bool FULL, bool MU>
 __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoArgs A, const CvPart* parts) {
     typedef typename CvModel<MODEL, D, KC, FULL>::Primal Primal;
     typedef typename CvModel<MODEL, D, KC, FULL>::Cols Cols;
     typedef typename Primal::Trans Trans;
     constexpr int SD = Primal::SD, NLIN = Primal::NLIN, NTR = Primal::NTR, NPD = Primal::NDUMP;
     __shared__ double raw[3][CV_LD * CV_LOADERS * WAVE];       // the staged rows
-    __shared__ double eta[2][(4 * CV_LOADERS + 1) * WAVE];     // per row: the loading waves' partial sums of p1, p2 (and mu_1, mu_2), and the interval
-    __shared__ double trs[2][(NTR + 2) * WAVE];                // per row: the transition (and the row's drift, when it has design columns)
+    constexpr int NE = MU ? 4 : 2;                             // partial sums per loading wave and row: p1, p2 (and mu_1, mu_2)
+    __shared__ double eta[2][(NE * CV_LOADERS + 1) * WAVE];    // ... of every loading wave, and the interval
+    __shared__ double trs[2][(NTR + (MU ? 2 : 0)) * WAVE];     // per row: the transition (and the row's drift, when it has design columns)
     __shared__ double lin[2][NLIN * WAVE];                     // per row: the linearisation
     __shared__ double fst[Primal::NSAVE * WAVE];               // the filter's state between rows (wave 0; see below)
     __shared__ double coef[DRIFT_KMAX][4];                     // per streamed column: its coefficient in p1, p2, mu_1, mu_2 (0: not in that predictor)
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         if (lane < 4 && loader) wcoef[ldr][i][lane] = on ? coef[on ? k : 0][lane] : 0.0;
     }
     const bool grad = A.part_mask[0] != 0;                     // (0: the value only -- no tangents)
-    const bool mu_cols = A.cv_mu_cols != 0;                    // the drift has design columns too
+    const bool mu_cols = MU && A.cv_mu_cols != 0;              // the drift has design columns too
     const int n_col = grad ? parts[part].n_col : 0;
     const bool with_mu = grad && parts[CV_FILTER].with_mu, with_sig = grad && parts[CV_FILTER].with_sig;
     // per slot: the channel to read, and what the value read is -- a column of ones / a column that feeds par[d] / par[d + 1]
@@ -935,27 +947,27 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             if (MODEL != M_BM_SSM) pb = fma(wcoef[ldr][i][1], xs, pb);
             if (mu_cols) { pm0 = fma(wcoef[ldr][i][2], xs, pm0); if (D > 1) pm1 = fma(wcoef[ldr][i][3], xs, pm1); }
         }
-        eta[slot][(4 * ldr) * WAVE + lane] = pa;
-        eta[slot][(4 * ldr + 1) * WAVE + lane] = pb;
-        if (mu_cols) { eta[slot][(4 * ldr + 2) * WAVE + lane] = pm0; eta[slot][(4 * ldr + 3) * WAVE + lane] = pm1; }
-        if (ldr == 0) eta[slot][(4 * CV_LOADERS) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
+        eta[slot][(NE * ldr) * WAVE + lane] = pa;
+        eta[slot][(NE * ldr + 1) * WAVE + lane] = pb;
+        if constexpr (MU) { if (mu_cols) { eta[slot][(NE * ldr + 2) * WAVE + lane] = pm0; eta[slot][(NE * ldr + 3) * WAVE + lane] = pm1; } }
+        if (ldr == 0) eta[slot][(NE * CV_LOADERS) * WAVE + lane] = src[0];      // channel 0: the interval after the row (if the tiles hold it)
     };
     double p1_lo = INFINITY, p1_hi = -INFINITY, p2_lo = INFINITY, p2_hi = -INFINITY;      // (the transition wave: what the predictors reached)
     auto produce = [&](int slot, int s) {                      // stage 1: the transition of row s, whose sums sit in eta[slot]
         const double* e_ = &eta[slot][lane];
         double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
-        for (int w = 0; w < CV_LOADERS; w++) { p1 += e_[(4 * w) * WAVE]; p2 += e_[(4 * w + 1) * WAVE]; }
+        for (int w = 0; w < CV_LOADERS; w++) { p1 += e_[(NE * w) * WAVE]; p2 += e_[(NE * w + 1) * WAVE]; }
         if (s < ns) { p1_lo = fmin(p1_lo, p1); p1_hi = fmax(p1_hi, p1); p2_lo = fmin(p2_lo, p2); p2_hi = fmax(p2_hi, p2); }
-        const double dtc = e_[(4 * CV_LOADERS) * WAVE];
+        const double dtc = e_[(NE * CV_LOADERS) * WAVE];
         const double dt = c_obs ? dtc : tv.dt_all;
         Trans tr;
         Primal::trans(dt, p1, p2, tr);
         Primal::put_trans(&trs[slot][lane], tr);
-        if (mu_cols) {                                         // a row-varying drift: mu_a(i) = intercept + its columns' terms, handed to the filter with the transition
+        if constexpr (MU) if (mu_cols) {                       // a row-varying drift: mu_a(i) = intercept + its columns' terms, handed to the filter with the transition
             double m0 = A.mu[0], m1 = A.mu[D - 1];
 #pragma unroll
-            for (int w = 0; w < CV_LOADERS; w++) { m0 += e_[(4 * w + 2) * WAVE]; m1 += e_[(4 * w + 3) * WAVE]; }
+            for (int w = 0; w < CV_LOADERS; w++) { m0 += e_[(NE * w + 2) * WAVE]; m1 += e_[(NE * w + 3) * WAVE]; }
             trs[slot][NTR * WAVE + lane] = m0; trs[slot][(NTR + 1) * WAVE + lane] = m1;
         }
     };
@@ -998,7 +1010,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
             Primal::get_trans(&trs[slot2][lane], tr);
             double mu[D];
 #pragma unroll
-            for (int a = 0; a < D; a++) mu[a] = mu_cols ? trs[slot2][(NTR + a) * WAVE + lane] : mu_c[a];
+            for (int a = 0; a < D; a++) { mu[a] = mu_c[a]; if constexpr (MU) { if (mu_cols) mu[a] = trs[slot2][(NTR + a) * WAVE + lane]; } }
             if constexpr (FULL) {
                 double H[3] = {h, 0.0, h};                          // H_array[,,i] (symmetric, checked at create)
                 if (A.cv_has_h) { H[0] = r[(c_obs + D) * WAVE]; H[1] = r[(c_obs + D + 2) * WAVE]; H[2] = r[(c_obs + D + 3) * WAVE]; }
@@ -1017,7 +1029,7 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
         if (s < ns && n_col > 0) {
             const double* r = &raw[slot3][lane];
             typename Cols::Lin li;
-            li.read(&lin[slot2][lane]);
+            li.template read<MU>(&lin[slot2][lane]);
             auto quarter = [&](auto k0) {                          // (a wave that also runs a stage is dealt fewer slots: whole quarters are skipped)
                 constexpr int K0 = decltype(k0)::value, K1 = K0 + (KC + 3) / 4 < KC ? K0 + (KC + 3) / 4 : KC;
                 double X[KC][4];
@@ -1026,9 +1038,10 @@ __global__ __launch_bounds__(CV_WAVES * WAVE) void iso_colvar_kernel(const IsoAr
                     const double xl = r[chan[k] * WAVE];
                     const double xk = ((ones_bits >> k) & 1u) ? 1.0 : xl;
                     X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
-                    X[k][2] = ((t3_bits >> k) & 1u) ? xk : 0.0; X[k][3] = ((t4_bits >> k) & 1u) ? xk : 0.0;
+                    X[k][2] = X[k][3] = 0.0;
+                    if constexpr (MU) { X[k][2] = ((t3_bits >> k) & 1u) ? xk : 0.0; X[k][3] = ((t4_bits >> k) & 1u) ? xk : 0.0; }
                 }
-                S.template step<K0, K1>(li, X);
+                S.template step<K0, K1, MU>(li, X);
             };
             constexpr int Q = (KC + 3) / 4;
             if (n_col > 0) quarter(std::integral_constant<int, 0>());
@@ -1278,9 +1291,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
                 F.step(tr, H, mu, &blk[u][1], is_na(blk[u][1], A.any_nan), lo);
                 if (n_col > 0) {
                     typename Cols::Lin li;
-                    li.read(lo);
+                    li.template read<true>(lo);
                     const double X[2][4] = {{ty0 == 1 ? 1.0 : 0.0, ty0 == 2 ? 1.0 : 0.0, 0.0, 0.0}, {ty1 == 1 ? 1.0 : 0.0, ty1 == 2 ? 1.0 : 0.0, 0.0, 0.0}};
-                    S.template step<0, 2>(li, X);
+                    S.template step<0, 2, true>(li, X);
                     Cols::mean_step(li, ma[0], mg[0], 0, mu0);
                     Cols::mean_step(li, ma[1], mg[1], 1, mu1);
                 }
@@ -1363,8 +1376,13 @@ hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* 
 // part's column count
 template <int MODEL, int D>
 static hipError_t launch_cv(const IsoArgs& a, const CvPart* parts, int kc, dim3 grid, dim3 block, hipStream_t s) {
-    if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2, false>), grid, block, 0, s, a, parts);
-    else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4, false>), grid, block, 0, s, a, parts);
+    if (a.cv_mu_cols) {
+        if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2, false, true>), grid, block, 0, s, a, parts);
+        else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4, false, true>), grid, block, 0, s, a, parts);
+    } else {
+        if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 2, false, false>), grid, block, 0, s, a, parts);
+        else hipLaunchKernelGGL((iso_colvar_kernel<MODEL, D, 4, false, false>), grid, block, 0, s, a, parts);
+    }
     return hipGetLastError();
 }
 hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s) {
@@ -1374,11 +1392,11 @@ hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* p
     if (a.cv_full) {                                           // full-covariance lanes, d = 2: 4 x 4 (CTCRW), 2 x 2 (OU_SSM, BM_SSM)
         if (d != 2) return hipErrorInvalidValue;
         if (model == M_CTCRW) {
-            if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 2, true>), grid, block, 0, s, a, parts);
-            else if (kc <= 3) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 3, true>), grid, block, 0, s, a, parts);
-            else hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 4, true>), grid, block, 0, s, a, parts);
-        } else if (model == M_OU_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_OU_SSM, 2, 4, true>), grid, block, 0, s, a, parts);
-        else if (model == M_BM_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_BM_SSM, 2, 4, true>), grid, block, 0, s, a, parts);
+            if (kc <= 2) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 2, true, true>), grid, block, 0, s, a, parts);
+            else if (kc <= 3) hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 3, true, true>), grid, block, 0, s, a, parts);
+            else hipLaunchKernelGGL((iso_colvar_kernel<M_CTCRW, 2, 4, true, true>), grid, block, 0, s, a, parts);
+        } else if (model == M_OU_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_OU_SSM, 2, 4, true, true>), grid, block, 0, s, a, parts);
+        else if (model == M_BM_SSM) hipLaunchKernelGGL((iso_colvar_kernel<M_BM_SSM, 2, 4, true, true>), grid, block, 0, s, a, parts);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
