@@ -380,6 +380,49 @@ def row_varying_workload(M, T, dev, steps, k_cols=9):
             "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
 
 
+def argos_workload(M, T, dev, steps):
+    """The Argos model at the metric's size: CTCRW tracks with a 2 x 2 error ellipse on every fix (H_array, nllk_ctcrw.hpp:203-205)
+    and one tau, one nu -- 4 x 4 covariance lanes, one wave per (64-track group, time window) (iso_full_kernel)."""
+    import torch
+    from smoothsde_amd import capi
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13, device=dev)
+    n = M * T
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(17)
+    A = 0.05 * torch.randn(n, 2, 2, device=dev, dtype=torch.float64, generator=gen)
+    Hn = A @ A.transpose(1, 2)
+    Hn[:, 0, 0] += 0.0025
+    Hn[:, 1, 1] += 0.0025
+    H = Hn.permute(1, 2, 0)                                   # (d, d, n)
+    del A
+    fixed = np.array([1, 1, 1, 0, 0], dtype=np.uint8)         # (log_sigma_obs is not in the model; the drift held at zero)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), par_fixed=fixed, H=H))
+    del ID, times, obs, H, Hn
+
+    def theta(k):
+        return np.ascontiguousarray(np.array([0.0, 0.0, 0.0, np.log(2.0), 0.0]) + 1e-3 * np.sin(k + np.arange(5)))
+    for k in range(2):
+        eng.eval(theta(-1 - k))
+    ssde_eval = eng.bound_eval(order=1)
+    ths = [theta(k) for k in range(steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kms = []
+    for k in range(steps):
+        ssde_eval(ths[k])
+        kms.append(eng.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    inf = eng.info()
+    eng.close()
+    kern = float(np.mean(kms))
+    return {"workload": f"{M} CTCRW x {T} with a per-row 2 x 2 measurement covariance (H_array) and constant tau, nu", "value": inf["n_rows"] * steps / el,
+            "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]],
+            "required_bytes_per_row": inf["required_bytes_per_row"],
+            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -674,6 +717,7 @@ def main():
                                           f"(intervals of 1-4 steps; laid out on the lattice at create)", "CTCRW", M, T, dev,
                                           max(3, args.steps // 2), absent))
             sec.append(row_varying_workload(M, max(16, T // 10), dev, max(3, args.steps // 2)))
+            sec.append(argos_workload(M, T, dev, max(3, args.steps // 2)))
         except Exception as e:  # the secondary numbers must never take the bench line down
             sec.append({"workload": "failed", "error": str(e)})
         line["secondary"] = sec

@@ -268,11 +268,12 @@ class Problem:
 
     @classmethod
     def from_torch(cls, model: str, ID, times, obs, par_fixed=None, na_mode: int = NA_ANY_NAN, flags: int = 0,
-                   X_re=None, S_list=None, basis_re=None):
+                   X_re=None, S_list=None, basis_re=None, H=None):
         """Problem whose data already live in HBM (torch CUDA tensors, fp64): the engine re-tiles /
         copies them on the device instead of uploading (SSDE_FLAG_DEVICE_DATA).  Fixed effects are
         intercept-only; `X_re[j]` may be an (n, k) CUDA tensor of streamed design columns for SDE
-        parameter j, with the penalty blocks in `S_list` (numpy)."""
+        parameter j, with the penalty blocks in `S_list` (numpy); `H`: per-row measurement covariances as a (d, d, n)
+        CUDA tensor (H_array, Kalman families)."""
         import torch
         assert ID.is_cuda and times.is_cuda and obs.is_cuda
         self = cls.__new__(cls)
@@ -342,6 +343,12 @@ class Problem:
         fixed = np.zeros(self.n_par_full, dtype=np.uint8)
         if par_fixed is not None:
             fixed[:] = np.asarray(par_fixed, dtype=np.uint8)
+        self._t_h = None
+        if H is not None:
+            if not self.kalman or tuple(H.shape) != (self.n_dim, self.n_dim, self.n):
+                raise ValueError("H must be a (d, d, n) tensor, Kalman families only")
+            self._t_h = H.to(torch.float64).permute(2, 1, 0).contiguous()     # memory order of the column-major d x d x n array
+            fixed[0] = 1                                                       # log_sigma_obs is not in the model then (R/sde.R:565, 595)
         self.par_fixed = fixed
         self.na_mode, self.device = int(na_mode), int(ID.device.index or 0)
         self.flags = int(flags) | FLAG_DEVICE_DATA
@@ -396,6 +403,8 @@ class Problem:
         d.include_penalty = self.include_penalty
         d.n_seg = self.n_seg
         d.a0, d.p0, d.h_array = ptr(self.a0), ptr(self.P0), ptr(self.H)
+        if getattr(self, "_t_h", None) is not None:
+            d.h_array = self._t_h.data_ptr()
         d.par_fixed = ptr(self.par_fixed)
         d.na_mode, d.device, d.flags = self.na_mode, self.device, self.flags
         d.other_data = ptr(getattr(self, "other_data", None))

@@ -43,7 +43,8 @@ def test_bench_line_has_what_the_driver_reads():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
-    assert len(d["secondary"]) == 4 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
+    assert len(d["secondary"]) == 5 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
+    assert "H_array" in d["secondary"][4]["workload"] and d["secondary"][4]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
     assert "tau and nu smooth" in d["secondary"][3]["workload"] and d["secondary"][3]["path"] == "isotropic-register"   # the lane = track kernel
 
 

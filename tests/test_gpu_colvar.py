@@ -438,6 +438,24 @@ def test_scalar_models_with_error_ellipses_vs_oracle(model, k1, k2, irregular, m
     eng.close(); e2.close()
 
 
+def test_device_resident_h_array_gives_the_same_numbers_as_the_host_array():
+    import torch
+    ID, t, o = simulate("CTCRW", 70, 300, 2, tau=1.5, nu=0.8, sigma_obs=0.1, seed=77)
+    pb0 = capi.Problem("CTCRW", ID, t, o)
+    H = _with_h(pb0, 19)
+    pbh = capi.Problem("CTCRW", ID, t, o, H=H)
+    dev = torch.device("cuda:0")
+    pbd = capi.Problem.from_torch("CTCRW", torch.as_tensor(ID, device=dev), torch.as_tensor(t, device=dev), torch.as_tensor(o, device=dev),
+                                  H=torch.as_tensor(H, device=dev))
+    assert pbd.par_fixed[0] == 1
+    par = np.array([0.0, 0.05, -0.03, np.log(1.7), np.log(0.7)])
+    eh, ed = capi.Engine(pbh), capi.Engine(pbd)
+    vh, gh = eh.eval(par)
+    vd, gd = ed.eval(par)
+    assert vh == vd and np.array_equal(gh, gd)
+    eh.close(); ed.close()
+
+
 H1_GOLD = [r for r in GOLD if r["name"] in ("CTCRW_d1_H", "OU_SSM_d1_H", "BM_SSM_d1_H")]
 
 
