@@ -24,6 +24,7 @@ ap.add_argument("--k1", type=int, default=9)
 ap.add_argument("--k2", type=int, default=9)
 ap.add_argument("--evals", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--irregular", action="store_true", help="irregular time grid (dt ~ U[0.5, 1.5] per row)")
 ap.add_argument("--with-h", action="store_true", help="per-row 2 x 2 measurement covariances (H_array): the full-covariance lanes")
 args = ap.parse_args()
 
@@ -31,6 +32,8 @@ M, T = args.tracks, args.rows
 dev = torch.device("cuda:0")
 ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=342, device=dev)
 ID, times, obs = ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy()
+if args.irregular:
+    times = np.cumsum(np.random.default_rng(5).uniform(0.5, 1.5, len(times)))
 n = M * T
 temp = 30 + 10 * np.sin(np.arange(n) * 2 * np.pi / 24) + np.random.default_rng(342).normal(0, 2, n)
 u = (temp - temp.min()) / (temp.max() - temp.min())

@@ -44,6 +44,9 @@ cp gpurun_out/pmc_${TAG}_share8.txt gpurun_out/pmc_${TAG}_drift.txt "$OUT/" 2>/d
 python3 tools/bench_colvar.py > "$OUT/colvar.txt" 2> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 6 >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
+python3 tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 6 --irregular --only lane=track >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
+bash tools/pmc_kernel.sh "iso_full" ${TAG}_isofull -- python3 $ROOT/tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 4 --only lane=track > /dev/null 2>&1 || true
+cp gpurun_out/pmc_${TAG}_isofull.txt "$OUT/" 2>/dev/null || true
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/colvar_stats" -o stats --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track > "$OUT/colvar_under_rocprof.log" 2>&1 ) || true
 find "$OUT/colvar_stats" -name "*kernel_trace*" -delete 2>/dev/null || true
 bash tools/pmc_kernel.sh "iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > /dev/null 2>&1 || true

@@ -87,7 +87,7 @@ try:   # FETCH_SIZE of the drift kernel (same x2 calibration)
 except Exception as e:  # noqa: BLE001
     print("no drift PMC:", e)
 # round 3, second half: the row-varying tau / nu kernel (k_iso_colvar.hip)
-for name in ("colvar.txt", f"pmc_{tag}_colvar.txt"):
+for name in ("colvar.txt", f"pmc_{tag}_colvar.txt", f"pmc_{tag}_isofull.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
