@@ -547,6 +547,50 @@ def test_mixed_designs_drift_columns_next_to_tau_nu_columns(model, d, kmu, k1, k
     eng.close(); e2.close()
 
 
+def test_bench_size_properties(monkeypatch):
+    """At the size tools/bench_colvar.py and bench.py time (10^4 tracks x 10^3 rows, 18 design columns), where the oracle is out of
+    reach: the windowed evaluation agrees with the sequential one (one window per track) and with the lane = direction path, the
+    value-only call with the gradient call, a repeat is bitwise the same, and the gradient is the derivative of the value along a
+    random direction (central difference)."""
+    import torch
+    dev = torch.device("cuda:0")
+    M, T, k = 10_000, 1_000, 9
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=342, device=dev)
+    n = M * T
+    i = torch.arange(n, device=dev, dtype=torch.float64)
+    u = (0.5 + 0.4 * torch.sin(i * (2 * np.pi / 24))).clamp_(0.0, 1.0)
+    B = (1.0 - (u[:, None] * (k - 1) - torch.arange(k, device=dev, dtype=torch.float64)[None, :]).abs()).clamp_(min=0.0)
+    B2 = (1.0 - ((u ** 2)[:, None] * (k - 1) - torch.arange(k, device=dev, dtype=torch.float64)[None, :]).abs()).clamp_(min=0.0)
+    S = second_difference_penalty(k)
+    pb = capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), X_re=[None, None, B, B2], S_list=[S, S])
+    rng = np.random.default_rng(3)
+    par = np.r_[np.log(0.05), 0.01, -0.02, 0.1, -0.1, 0.2, 0.3, 0.1 * rng.standard_normal(2 * k)]
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 8 and inf["window_check"] <= 1e-11
+    v2, g2 = eng.eval(par + 0.0)
+    assert v2 == val and np.array_equal(g2, grad)
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * abs(val)
+    dvec = rng.standard_normal(len(par))
+    eps = 1e-6
+    fd = (eng.eval(par + eps * dvec, order=0) - eng.eval(par - eps * dvec, order=0)) / (2 * eps)
+    assert abs(fd - grad @ dvec) <= 1e-6 * abs(grad @ dvec) + 1e-3
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    assert e1.info()["lanes_per_track"] == 8                                # one window per track (x eight waves)
+    assert abs(v1 - val) <= 1e-11 * abs(val) and np.max(np.abs(g1 - grad)) <= 1e-9 * np.max(np.abs(grad))
+    monkeypatch.delenv("SSDE_CHUNKS")
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb)
+    assert e2.info()["path"] == PATH_TV
+    vt, gt = e2.eval(par)
+    assert abs(vt - val) <= 1e-10 * abs(val) and np.max(np.abs(gt - grad)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e1.close(); e2.close()
+
+
 def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
     """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
     shared tau / nu coefficients are summed over the parts."""
