@@ -591,6 +591,49 @@ def test_bench_size_properties(monkeypatch):
     eng.close(); e1.close(); e2.close()
 
 
+def test_argos_batch_size_properties(monkeypatch):
+    """10^4 tracks x 2000 rows with error ellipses and constant tau / nu (iso_full_kernel), out of the oracle's reach: windows vs one
+    window per track, vs the lane = direction full-covariance lanes, value-only, repeat, directional derivative."""
+    import torch
+    dev = torch.device("cuda:0")
+    M, T = 10_000, 2_000
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(17)
+    A = 0.1 * torch.randn(M * T, 2, 2, device=dev, dtype=torch.float64, generator=gen)
+    Hn = A @ A.transpose(1, 2)
+    Hn[:, 0, 0] += 0.01
+    Hn[:, 1, 1] += 0.01
+    pb = capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), H=Hn.permute(1, 2, 0))
+    del A
+    par = np.array([0.0, 0.02, -0.01, np.log(2.2), np.log(0.9)])
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["path"] == PATH_ISO and inf["const_coeff"] == 1
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["window_check"] <= 1e-11
+    v2, g2 = eng.eval(par + 0.0)
+    assert v2 == val and np.array_equal(g2, grad) and grad[0] == 0.0
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * abs(val)
+    dvec = np.array([0.0, 0.3, -0.5, 0.7, 0.4])
+    eps = 1e-6
+    fd = (eng.eval(par + eps * dvec, order=0) - eng.eval(par - eps * dvec, order=0)) / (2 * eps)
+    assert abs(fd - grad @ dvec) <= 1e-6 * abs(grad @ dvec) + 1e-2
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par)
+    assert e1.info()["lanes_per_track"] == 1
+    assert abs(v1 - val) <= 1e-11 * abs(val) and np.max(np.abs(g1 - grad)) <= 1e-9 * np.max(np.abs(grad))
+    monkeypatch.delenv("SSDE_CHUNKS")
+    monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    e2 = capi.Engine(pb)
+    assert e2.info()["path"] == PATH_TV
+    vt, gt = e2.eval(par)
+    assert abs(vt - val) <= 1e-10 * abs(val) and np.max(np.abs(gt - grad)) <= 1e-8 * np.max(np.abs(grad))
+    eng.close(); e1.close(); e2.close()
+
+
 def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
     """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
     shared tau / nu coefficients are summed over the parts."""
