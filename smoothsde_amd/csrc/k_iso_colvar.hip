@@ -39,6 +39,15 @@
 //    SQ counters: 22 % of the wave cycles issue VALU, 39 % wait on s_waitcnt, 25 % issue-stalled; ~400 LDS instructions per row)
 // Windows, warm-up and the verified hand-over as in k_iso.hip.  Layout: the tiles of ssde_device.hpp with the design
 // columns as further channels (as k_iso_drift.hip).
+//
+// What else is in this file, with the same pipeline and the same interfaces (Primal: the filter + the linearisation it writes; Cols:
+// the tangents that read it):
+//   * drift design columns next to those of tau / nu (kinds 3, 4; the MU variants of the kernels): mixed designs;
+//   * per-row measurement covariances, H_array: full 4 x 4 covariance lanes for CTCRW with two response columns
+//     (CvPrimalCtcrwFull / CvColsCtcrwFull), full 2 x 2 lanes for OU_SSM / BM_SSM (Cv...ScalFull), h = H_i on the isotropic lanes
+//     for one response column;
+//   * iso_full_kernel: H_array with CONSTANT coefficients (the Argos model) -- one wave per (group, window) runs filter and tangents;
+//   * create-time helpers: column ranges, H statistics, equal-column detection, the reduction of the predictors' ranges.
 #include <type_traits>
 
 #include "ssde_device.hpp"
