@@ -1323,6 +1323,154 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
         if (lane == 0) A.partials[((int64_t)chunk * nacc + k) * G + g] = t;
     }
 }
+// ---- row-varying tau / nu with FEW columns (H = sigma_obs^2 I): one wave per (64-track group, time window) ------------------------
+// A linear covariate effect or two -- tau ~ 1 + x -- is the common case next to splines: at most CV_FEW_K streamed columns and
+// CV_KC tangents besides the log sigma_obs and drift-intercept directions the filter carries itself.  The eight-wave pipeline
+// spends its ~3500 cycles per row whatever the number of columns; here a wave computes its rows' predictors, exp's and transition,
+// runs the filter and the tangents itself (same structs, the linearisation through the wave's own LDS slab), and four such waves
+// share a CU.
+template <int MODEL, int D>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoArgs A, const CvPart* parts) {
+    constexpr int KC = CV_KC;
+    typedef typename CvModel<MODEL, D, KC, false>::Primal Primal;
+    typedef typename CvModel<MODEL, D, KC, false>::Cols Cols;
+    typedef typename Primal::Trans Trans;
+    constexpr int SD = Primal::SD, U = 2, W = 1 + D + CV_FEW_K;        // register block row: [dt | y | the streamed columns]
+    __shared__ double lin[WG_WAVES][Primal::NLIN * WAVE];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
+    int g, part, chunk;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TileView& tv = A.tv;
+    const int C = tv.C, c_obs = tv.c_obs, G = tv.n_groups, K = A.drift_k, c_col = A.c_col;
+    constexpr int nacc = 2 + CV_KC + D;
+    const bool grad = A.part_mask[0] != 0;
+    const int n_col = grad ? parts[0].n_col : 0;
+    const bool with_mu = grad && parts[0].with_mu, with_sig = grad && parts[0].with_sig;
+    int xsel[KC];                                              // per slot: which streamed column it reads (-1: a column of ones)
+    unsigned t1_bits = 0, t2_bits = 0;
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        const bool on = k < n_col;
+        const int ch = on ? parts[0].chan[k] : -2, ty = on ? parts[0].type[k] : 0;
+        xsel[k] = ch >= 0 ? ch - c_col : -1;
+        if (ty == 1) t1_bits |= 1u << k;
+        if (ty == 2) t2_bits |= 1u << k;
+    }
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, 0, chunk, s_begin, s_acc, s_end, 0);
+    double* const dump0 = A.bnd + (((int64_t)chunk * G + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
+    double* const dump1 = A.bnd + (((int64_t)chunk * G + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+    double bufA[U][W], bufB[U][W];
+    auto load = [&](double (&dst)[U][W], int s0) {
+        const double* p = base + (int64_t)s0 * C * WAVE;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            dst[u][0] = tv.dt_all;
+            if (c_obs) dst[u][0] = p[(u * C) * WAVE];
+#pragma unroll
+            for (int a = 0; a < D; a++) dst[u][1 + a] = p[(u * C + c_obs + a) * WAVE];
+#pragma unroll
+            for (int k = 0; k < CV_FEW_K; k++) dst[u][1 + D + k] = p[(u * C + c_col + (k < K ? k : 0)) * WAVE];
+        }
+    };
+    load(bufA, s_begin);
+    Primal F;
+    Cols S;
+    S.init();
+    {
+        double a0[SD];
+        if (s_begin == 0) {
+#pragma unroll
+            for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        } else {
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double y0 = bufA[0][1 + a];
+                if constexpr (MODEL == M_CTCRW) { a0[2 * a] = (y0 == y0) ? y0 : 0.0; a0[2 * a + 1] = 0.0; }
+                else a0[a] = (y0 == y0) ? y0 : 0.0;
+            }
+        }
+        F.init(a0, A.p0);
+    }
+    double mu[D];
+#pragma unroll
+    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
+    const double h = A.h;
+    double* lo = &lin[wv][lane];
+    auto dump = [&](double* o) { F.dump_to(o); S.dump_to(o + Primal::NDUMP * WAVE); };
+    auto block = [&](const double (&blk)[U][W], int s0) {
+        if (s0 == s_acc && s_acc > s_begin) { dump(dump0); F.reset_acc(); S.reset_acc(); }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (s0 + u < ns) {
+                double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
+#pragma unroll
+                for (int k = 0; k < CV_FEW_K; k++) {               // (coefficients past the last column are zero)
+                    p1 = fma(A.coefA[k], blk[u][1 + D + k], p1);
+                    if (MODEL != M_BM_SSM) p2 = fma(A.coefB[k], blk[u][1 + D + k], p2);
+                }
+                Trans tr;
+                Primal::trans(blk[u][0], p1, p2, tr);
+                F.step(tr, h, mu, &blk[u][1], is_na(blk[u][1], A.any_nan), with_sig, with_mu, lo);
+                if (n_col > 0) {
+                    typename Cols::Lin li;
+                    li.template read<false>(lo);
+                    double X[KC][4];
+#pragma unroll
+                    for (int k = 0; k < KC; k++) {
+                        double xk = 1.0;
+#pragma unroll
+                        for (int j = 0; j < CV_FEW_K; j++) xk = xsel[k] == j ? blk[u][1 + D + j] : xk;
+                        X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
+                        X[k][2] = X[k][3] = 0.0;
+                    }
+                    S.template step<0, KC, false>(li, X);
+                }
+            }
+    };
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
+        load(bufB, s0 + U);
+        block(bufA, s0);
+        load(bufA, s0 + 2 * U);
+        if (s0 + U < s_end) block(bufB, s0 + U);
+    }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) dump(dump1);
+    const bool empty = s_acc >= s_end;
+    {
+        const double t = wave_sum(empty ? 0.0 : F.value());
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + 0) * G + g] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < CV_KC; k++) {
+        const double t = wave_sum(empty ? 0.0 : S.g[k]);
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + k) * G + g] = t;
+    }
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+        const double t = wave_sum(empty ? 0.0 : F.gmu[a]);
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + CV_KC + a) * G + g] = t;
+    }
+    {
+        const double t = wave_sum(empty ? 0.0 : F.sg);
+        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + CV_KC + D) * G + g] = t;
+    }
+}
+// a.n_parts == 1; parts[0]: at most CV_KC tangents over at most CV_FEW_K streamed columns (+ the directions the filter carries)
+hipError_t launch_iso_few(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s) {
+    if (a.n_parts != 1 || a.cv_full || a.cv_has_h || a.cv_mu_cols || a.drift_k < 1 || a.drift_k > CV_FEW_K) return hipErrorInvalidValue;
+    const int g8 = (a.tv.n_groups + 7) / 8;
+    dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
+    if (grid.x == 0) return hipSuccess;
+#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) { hipLaunchKernelGGL((iso_few_kernel<M_, D_>), grid, block, 0, s, a, parts); return hipGetLastError(); }
+    SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)
+#undef SSDE_CASE
+    return hipErrorInvalidValue;
+}
+
 // a.n_parts == 1; parts[0]: slots 0, 1 = log tau, log nu, slots 2, 3 = the drift intercepts (type 0: not wanted); hand-over record:
 // filter 14 | two tangents 2 x 14 | two drift tangents 2 x 4
 hipError_t launch_iso_full(int model, const IsoArgs& a, const CvPart* parts, hipStream_t s) {

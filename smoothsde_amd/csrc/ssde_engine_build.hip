@@ -148,6 +148,13 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         for (int type = 1; type <= 2; type++)
             for (auto& sl : h->slots)
                 if (sl.par_j == h->d + type - 1 && !h->fixed[sl.pidx]) cols.push_back({type, sl.col >= 0 ? c_col + sl.col : -1, sl.pidx});
+        {
+            // few columns and few tangents besides the directions the filter carries: one wave per (group, window) does it all
+            bool mu_streamed = false;
+            for (auto& c : cols) mu_streamed = mu_streamed || c.type >= 3;
+            h->cv_few = !h->cv_full && !h->has_h && !mu_streamed && h->n_stream_cols >= 1 && h->n_stream_cols <= CV_FEW_K &&
+                        (int)cols.size() <= CV_KC && !getenv("SSDE_CV_NO_FEW");
+        }
         if ((int)cols.size() > (h->cv_full ? CV_WAVES - 2 : CV_WAVES) * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;     // (full-covariance lanes: the two stage waves carry no columns)
         std::vector<CvPart> parts(CV_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * CV_WAVES);
@@ -165,6 +172,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                 if (tot == N) { for (int p = 0; p < 8; p++) n_w[p] = v[p]; dealt_by_env = true; }
             }
         }
+        if (h->cv_few) n_w[0] = N;                                 // (iso_few_kernel: every column on the one wave)
+        else
         if (h->cv_single) {
             // one wave does it all (iso_full_kernel): slots 0, 1 = the log tau, log nu intercepts, slots 2, 3 = the drift intercepts
             static_assert(CV_KC >= 4, "four slots");
@@ -205,7 +214,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             for (auto& sl : h->slots)
                 if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
         }
-        h->cv_kc = h->cv_single ? CV_KC : best_kc;
+        h->cv_kc = h->cv_one_wave() ? CV_KC : best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
         HIPCHK(h, hipHostMalloc((void**)&h->cv_ranges_pinned, 4 * sizeof(double), hipHostMallocDefault));
         h->cv_ranges_pinned[0] = h->cv_ranges_pinned[2] = INFINITY; h->cv_ranges_pinned[1] = h->cv_ranges_pinned[3] = -INFINITY;
@@ -255,7 +264,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->drift = all_clean ? 1 : 2;
         h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
     }
-    if (h->drift) { h->iso_parts = (h->drift == 3 && !h->cv_single) ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+    if (h->drift) { h->iso_parts = (h->drift == 3 && !h->cv_one_wave()) ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
     else choose_iso_split(h);
     // shared-covariance path: regular grid + groups without missing rows
     HIPCHK(h, h->group_flags.upload(gflags));
@@ -303,12 +312,12 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // with one (its 32-component dumps make every further boundary cost what the shorter tail gains)
         want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
     // row-varying tau / nu: a WORKGROUP per (group, window), one per CU -- up to eight rounds' worth; plan_windows picks the count
-    if (h->drift == 3 && !h->cv_single) want = std::max(1, (8 * 256 + G - 1) / G);
+    if (h->drift == 3 && !h->cv_one_wave()) want = std::max(1, (8 * 256 + G - 1) / G);
     if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
     h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
     // (row-varying tau / nu with few groups: windows down to two alignment units, shorter than their warm-up -- with CUs idle
     //  the redundant warm-up rows run in parallel, only a workgroup's own chain of rows matters; ssde_engine_iso.hip picks)
-    if (h->drift == 3 && !h->cv_single && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
+    if (h->drift == 3 && !h->cv_one_wave() && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
     h->want_chunks = std::max(1, std::min(want, h->max_chunks));
     // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows on
     // the general kernel.  With ONE plan -- the shared kernel's few long windows -- the general launch is a handful of

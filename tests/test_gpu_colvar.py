@@ -634,6 +634,55 @@ def test_argos_batch_size_properties(monkeypatch):
     eng.close(); e1.close(); e2.close()
 
 
+@pytest.mark.parametrize("model,d,which,what", [("CTCRW", 2, "p1", "plain"), ("CTCRW", 1, "p2", "missing"), ("OU_SSM", 2, "both", "irregular"),
+                                                ("BM_SSM", 2, "p1", "both"), ("OU_SSM", 1, "p2", "plain"), ("CTCRW", 2, "both", "both")])
+def test_linear_covariate_effects_run_on_one_wave_per_window(model, d, which, what, monkeypatch):
+    """tau ~ 1 + x and / or nu ~ 1 + x (fixed-effect slopes, no smooth): at most four streamed columns and four tangents besides
+    the directions the filter carries -- iso_few_kernel; against the oracle and, A/B, the eight-wave pipeline."""
+    ID, t, o = simulate(model, 96, 900, d, sigma_obs=0.1, seed=111,
+                        **dict(CTCRW=dict(tau=1.5, nu=0.8), OU_SSM=dict(mu=2.0, tau=2.0, kappa=1.0, z0=2.0), BM_SSM=dict(sigma=0.7))[model])
+    n = len(ID)
+    rng = np.random.default_rng(14)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 37) + 0.05 * rng.standard_normal(n), 0, 1)
+    q = capi.n_sde_par(model, d)
+    X_fe = [None] * q
+    if which in ("p1", "both"):
+        X_fe[d] = np.column_stack([np.ones(n), x])
+    if which in ("p2", "both") and q > d + 1:
+        X_fe[d + 1] = np.column_stack([np.ones(n), x ** 2])
+    if all(v is None for v in X_fe):
+        X_fe[d] = np.column_stack([np.ones(n), x])
+    o = o.copy()
+    if what in ("missing", "both"):
+        na = rng.random(n) < 0.04
+        na[::900] = False
+        o[na, 0] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, n))
+    pb = capi.Problem(model, ID, t, o, X_fe=X_fe)
+    par = 0.1 * rng.standard_normal(pb.n_par_full)
+    par[0] = np.log(0.12)
+    if model == "OU_SSM":
+        par[pb.off_fe:pb.off_fe + d] += 2.0
+    par[pb.off_fe + pb.fe_off[d]] = np.log(2.0 if model != "BM_SSM" else 0.7)
+    eng = capi.Engine(pb)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["lanes_per_track"] > 1 and inf["lanes_per_track"] < 8 and inf["window_check"] <= 1e-11      # (windows x ONE wave)
+    _close(val, grad, *_oracle(pb, par))
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("SSDE_CV_NO_FEW", "1")
+    e2 = capi.Engine(pb)
+    v2, g2 = e2.eval(par)
+    assert e2.info()["lanes_per_track"] % 8 == 0                                # the pipeline: eight waves per window
+    assert abs(val - v2) <= 1e-11 * max(1.0, abs(val)) and np.max(np.abs(grad - g2)) <= 1e-9 * np.max(np.abs(grad))
+    eng.close(); e2.close()
+
+
 def test_a_response_wider_than_two_columns_runs_this_kernel_as_column_pairs():
     """n_dim = 3: the parts (columns 0-1, column 2) each take the lane = track kernel; the gradient entries of the
     shared tau / nu coefficients are summed over the parts."""

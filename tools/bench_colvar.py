@@ -24,6 +24,7 @@ ap.add_argument("--k1", type=int, default=9)
 ap.add_argument("--k2", type=int, default=9)
 ap.add_argument("--evals", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--linear", action="store_true", help="tau ~ 1 + x as a fixed-effect slope instead of the splines (two streamed columns: iso_few_kernel)")
 ap.add_argument("--irregular", action="store_true", help="irregular time grid (dt ~ U[0.5, 1.5] per row)")
 ap.add_argument("--with-h", action="store_true", help="per-row 2 x 2 measurement covariances (H_array): the full-covariance lanes")
 args = ap.parse_args()
@@ -38,19 +39,27 @@ n = M * T
 temp = 30 + 10 * np.sin(np.arange(n) * 2 * np.pi / 24) + np.random.default_rng(342).normal(0, 2, n)
 u = (temp - temp.min()) / (temp.max() - temp.min())
 X_re, S = [None, None, None, None], []
+X_fe = None
+if args.linear:
+    args.k1 = args.k2 = 0
+    X_fe = [None, None, np.column_stack([np.ones(n), u]), None]
 if args.k1:
     X_re[2] = bspline_basis(u, args.k1); S.append(second_difference_penalty(args.k1))
 if args.k2:
     X_re[3] = bspline_basis(u, args.k2); S.append(second_difference_penalty(args.k2))
 nre = args.k1 + args.k2
 fixed = np.r_[0, 1, 1, 0, 0, np.ones(len(S)), np.zeros(nre)].astype(np.uint8)
+if args.linear:
+    fixed = np.array([0, 1, 1, 0, 0, 0], dtype=np.uint8)
 H = None
 if args.with_h:   # error ellipses of the size of the simulated measurement noise
     A = np.random.default_rng(343).standard_normal((n, 2, 2)) * 0.05
     H = np.einsum("nij,nkj->ikn", A, A) + 0.0025 * np.eye(2)[:, :, None]
     del A
-pb = capi.Problem("CTCRW", ID, times, obs, X_re=X_re if S else None, S_list=S or None, par_fixed=fixed, H=H)
+pb = capi.Problem("CTCRW", ID, times, obs, X_fe=X_fe, X_re=X_re if S else None, S_list=S or None, par_fixed=fixed, H=H)
 par = np.r_[np.log(0.05), 0, 0, 0, 0, np.zeros(len(S)), 0.05 * np.sin(np.arange(nre))]
+if args.linear:
+    par = np.array([np.log(0.05), 0, 0, 0.0, 0.3, 0.0])
 bytes_row = 8.0 * (2 + nre + (4 if args.with_h else 0))
 for label, env in (("lane=track", None), ("lane=direction", "1")):
     if args.only and args.only != label:
