@@ -46,6 +46,7 @@
 //   * per-row measurement covariances, H_array: full 4 x 4 covariance lanes for CTCRW with two response columns
 //     (CvPrimalCtcrwFull / CvColsCtcrwFull), full 2 x 2 lanes for OU_SSM / BM_SSM (Cv...ScalFull), h = H_i on the isotropic lanes
 //     for one response column;
+//   * iso_few_kernel: few design columns (tau ~ 1 + x) -- one wave per (group, window) runs the whole row;
 //   * iso_full_kernel: H_array with CONSTANT coefficients (the Argos model) -- one wave per (group, window) runs filter and tangents;
 //   * create-time helpers: column ranges, H statistics, equal-column detection, the reduction of the predictors' ranges.
 #include <type_traits>

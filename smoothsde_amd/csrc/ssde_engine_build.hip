@@ -775,7 +775,15 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
                     if (sl.col >= 0 && sl.par_j < h->d) par_only = false;
             // (measured, tools/bench_colvar.py --tracks M --rows 1000, 18 columns: 0.18 / 0.19 / 0.20 / 0.22 / 0.24 ms at M = 32 / 128 /
             //  256 / 512 / 1024 against 0.11 / 0.18 / 0.22 / 0.32 / 0.50 on the lane = direction path: the crossover is near 128 tracks)
-            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : 160;
+            //  The lane = direction path costs in proportion to tracks x directions, this one does not depend on the directions: the
+            //  crossover moves with their number -- 3 directions (tau ~ 1 + x): 0.094 / 0.106 / 0.119 / 0.25 ms at 32 / 128 / 256 / 1024
+            //  tracks there, 0.26-0.28 ms on the one-wave kernel for few columns (iso_few_kernel), which wins from ~1200 tracks on.
+            int n_dirs = h->fixed[0] ? 0 : 1, n_tan = 0, n_mu_cols = 0;
+            for (auto& sl : h->slots)
+                if (!h->fixed[sl.pidx]) { n_dirs++; if (sl.par_j >= h->d) n_tan++; else if (sl.col >= 0) n_mu_cols++; }
+            const bool few_shape = iso_cfg && n_mu_cols == 0 && n_tan <= CV_KC && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
+                                   !getenv("SSDE_CV_NO_FEW");                   // (columns may still be shared below: checked again at the plan)
+            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : few_shape ? 1200 : std::max(160, 3400 / std::max(n_dirs, 1));
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }

@@ -42,6 +42,7 @@ bash tools/pmc_kernel.sh "iso_drift" ${TAG}_drift -- python3 $ROOT/tools/bench_d
 cp gpurun_out/pmc_${TAG}_share8.txt gpurun_out/pmc_${TAG}_drift.txt "$OUT/" 2>/dev/null || true
 # round 3, second half: row-varying tau / nu on lane = track lanes (k_iso_colvar.hip) against the lane = direction path
 python3 tools/bench_colvar.py > "$OUT/colvar.txt" 2> "$OUT/colvar.err"
+python3 tools/bench_colvar.py --linear >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 6 >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
 python3 tools/bench_colvar.py --with-h --k1 0 --k2 0 --rows 10000 --evals 6 --irregular --only lane=track >> "$OUT/colvar.txt" 2>> "$OUT/colvar.err"
