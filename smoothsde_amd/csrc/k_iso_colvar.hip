@@ -1330,13 +1330,13 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_full_kernel(const IsoA
 // spends its ~3500 cycles per row whatever the number of columns; here a wave computes its rows' predictors, exp's and transition,
 // runs the filter and the tangents itself (same structs, the linearisation through the wave's own LDS slab), and four such waves
 // share a CU.
-template <int MODEL, int D>
+// KC: tangent slots (4 or 8: slot k is slot k % CV_KC of parts[k / CV_KC], its accumulators are those of that part); KS: streamed columns
+template <int MODEL, int D, int KC, int KS>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoArgs A, const CvPart* parts) {
-    constexpr int KC = CV_KC;
     typedef typename CvModel<MODEL, D, KC, false>::Primal Primal;
     typedef typename CvModel<MODEL, D, KC, false>::Cols Cols;
     typedef typename Primal::Trans Trans;
-    constexpr int SD = Primal::SD, U = 2, W = 1 + D + CV_FEW_K;        // register block row: [dt | y | the streamed columns]
+    constexpr int SD = Primal::SD, U = KC > CV_KC ? 1 : 2, W = 1 + D + KS + KC;     // register block row: [dt | y | the streamed columns | the slots' columns]
     __shared__ double lin[WG_WAVES][Primal::NLIN * WAVE];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
     int g, part, chunk;
@@ -1344,17 +1344,19 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoAr
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const TileView& tv = A.tv;
     const int C = tv.C, c_obs = tv.c_obs, G = tv.n_groups, K = A.drift_k, c_col = A.c_col;
-    constexpr int nacc = 2 + CV_KC + D;
+    constexpr int nacc = 2 + CV_KC + D, NP = KC / CV_KC;
     const bool grad = A.part_mask[0] != 0;
-    const int n_col = grad ? parts[0].n_col : 0;
     const bool with_mu = grad && parts[0].with_mu, with_sig = grad && parts[0].with_sig;
-    int xsel[KC];                                              // per slot: which streamed column it reads (-1: a column of ones)
-    unsigned t1_bits = 0, t2_bits = 0;
+    int chan[KC], n_col = 0;                                   // per slot: the channel it reads (an unused slot or a column of ones: any column)
+    unsigned ones_bits = 0, t1_bits = 0, t2_bits = 0;
 #pragma unroll
     for (int k = 0; k < KC; k++) {
-        const bool on = k < n_col;
-        const int ch = on ? parts[0].chan[k] : -2, ty = on ? parts[0].type[k] : 0;
-        xsel[k] = ch >= 0 ? ch - c_col : -1;
+        const int p = k / CV_KC, kk = k % CV_KC;
+        const bool on = grad && kk < parts[p].n_col;
+        const int ch = on ? parts[p].chan[kk] : -2, ty = on ? parts[p].type[kk] : 0;
+        chan[k] = ch >= 0 ? ch : c_col;
+        if (on) n_col = k + 1;
+        if (ch == -1) ones_bits |= 1u << k;
         if (ty == 1) t1_bits |= 1u << k;
         if (ty == 2) t2_bits |= 1u << k;
     }
@@ -1375,7 +1377,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoAr
 #pragma unroll
             for (int a = 0; a < D; a++) dst[u][1 + a] = p[(u * C + c_obs + a) * WAVE];
 #pragma unroll
-            for (int k = 0; k < CV_FEW_K; k++) dst[u][1 + D + k] = p[(u * C + c_col + (k < K ? k : 0)) * WAVE];
+            for (int k = 0; k < KS; k++) dst[u][1 + D + k] = p[(u * C + c_col + (k < K ? k : 0)) * WAVE];
+#pragma unroll
+            for (int k = 0; k < KC; k++) dst[u][1 + D + KS + k] = p[(u * C + chan[k]) * WAVE];       // (the same lines again: cache hits, no selects)
         }
     };
     load(bufA, s_begin);
@@ -1410,7 +1414,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoAr
             if (s0 + u < ns) {
                 double p1 = A.cv_eta0[0], p2 = A.cv_eta0[1];
 #pragma unroll
-                for (int k = 0; k < CV_FEW_K; k++) {               // (coefficients past the last column are zero)
+                for (int k = 0; k < KS; k++) {                     // (coefficients past the last column are zero)
                     p1 = fma(A.coefA[k], blk[u][1 + D + k], p1);
                     if (MODEL != M_BM_SSM) p2 = fma(A.coefB[k], blk[u][1 + D + k], p2);
                 }
@@ -1423,13 +1427,12 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoAr
                     double X[KC][4];
 #pragma unroll
                     for (int k = 0; k < KC; k++) {
-                        double xk = 1.0;
-#pragma unroll
-                        for (int j = 0; j < CV_FEW_K; j++) xk = xsel[k] == j ? blk[u][1 + D + j] : xk;
+                        const double xk = ((ones_bits >> k) & 1u) ? 1.0 : blk[u][1 + D + KS + k];
                         X[k][0] = ((t1_bits >> k) & 1u) ? xk : 0.0; X[k][1] = ((t2_bits >> k) & 1u) ? xk : 0.0;
                         X[k][2] = X[k][3] = 0.0;
                     }
-                    S.template step<0, KC, false>(li, X);
+                    S.template step<0, (KC < 4 ? KC : 4), false>(li, X);
+                    if constexpr (KC > 4) { if (n_col > 4) S.template step<4, KC, false>(li, X); }
                 }
             }
     };
@@ -1441,32 +1444,43 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_few_kernel(const IsoAr
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) dump(dump1);
     const bool empty = s_acc >= s_end;
-    {
-        const double t = wave_sum(empty ? 0.0 : F.value());
-        if (lane == 0) A.partials[((int64_t)chunk * nacc + 0) * G + g] = t;
-    }
 #pragma unroll
-    for (int k = 0; k < CV_KC; k++) {
-        const double t = wave_sum(empty ? 0.0 : S.g[k]);
-        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + k) * G + g] = t;
-    }
+    for (int p = 0; p < NP; p++) {
+        const int64_t pc = (int64_t)p * A.n_chunks + chunk;
+        {
+            const double t = wave_sum((empty || p > 0) ? 0.0 : F.value());
+            if (lane == 0) A.partials[(pc * nacc + 0) * G + g] = t;
+        }
 #pragma unroll
-    for (int a = 0; a < D; a++) {
-        const double t = wave_sum(empty ? 0.0 : F.gmu[a]);
-        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + CV_KC + a) * G + g] = t;
-    }
-    {
-        const double t = wave_sum(empty ? 0.0 : F.sg);
-        if (lane == 0) A.partials[((int64_t)chunk * nacc + 1 + CV_KC + D) * G + g] = t;
+        for (int k = 0; k < CV_KC; k++) {
+            const double t = wave_sum(empty ? 0.0 : S.g[p * CV_KC + k]);
+            if (lane == 0) A.partials[(pc * nacc + 1 + k) * G + g] = t;
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double t = wave_sum((empty || p > 0) ? 0.0 : F.gmu[a]);
+            if (lane == 0) A.partials[(pc * nacc + 1 + CV_KC + a) * G + g] = t;
+        }
+        {
+            const double t = wave_sum((empty || p > 0) ? 0.0 : F.sg);
+            if (lane == 0) A.partials[(pc * nacc + 1 + CV_KC + D) * G + g] = t;
+        }
     }
 }
-// a.n_parts == 1; parts[0]: at most CV_KC tangents over at most CV_FEW_K streamed columns (+ the directions the filter carries)
-hipError_t launch_iso_few(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s) {
-    if (a.n_parts != 1 || a.cv_full || a.cv_has_h || a.cv_mu_cols || a.drift_k < 1 || a.drift_k > CV_FEW_K) return hipErrorInvalidValue;
+// one wave per (group, window); kc = 4 or 8 tangent slots (parts[0], parts[1]), a.drift_k <= 8 streamed columns; a.n_parts is the number of
+// parts the partials / the hand-over records are laid out for (1 or 2), the grid enumerates ONE work item per (group, window)
+hipError_t launch_iso_few(int model, int d, const IsoArgs& a0, const CvPart* parts, int kc, hipStream_t s) {
+    if (a0.cv_full || a0.cv_has_h || a0.cv_mu_cols || a0.drift_k < 1 || a0.drift_k > 2 * CV_FEW_K || (kc != CV_KC && kc != 2 * CV_KC)) return hipErrorInvalidValue;
+    IsoArgs a = a0;
+    a.n_parts = 1;
     const int g8 = (a.tv.n_groups + 7) / 8;
     dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
-#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) { hipLaunchKernelGGL((iso_few_kernel<M_, D_>), grid, block, 0, s, a, parts); return hipGetLastError(); }
+    const bool wide = kc > CV_KC || a.drift_k > CV_FEW_K;
+#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) { \
+        if (wide) hipLaunchKernelGGL((iso_few_kernel<M_, D_, 2 * CV_KC, 2 * CV_FEW_K>), grid, block, 0, s, a, parts); \
+        else hipLaunchKernelGGL((iso_few_kernel<M_, D_, CV_KC, CV_FEW_K>), grid, block, 0, s, a, parts); \
+        return hipGetLastError(); }
     SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)
 #undef SSDE_CASE
     return hipErrorInvalidValue;

@@ -149,9 +149,10 @@ hipError_t launch_iso_colvar(int model, int d, const IsoArgs& a, const CvPart* p
 int colvar_nstate(int model, int d, int kc, bool full);
 hipError_t launch_colvar_range_reduce(const double* wg, int n_wg, double* out_pinned /* 4 doubles, host-visible */, hipStream_t s);
 hipError_t launch_cols_differ(const double* a, const double* b, int64_t n, int* differ /* device, zeroed */, hipStream_t s);
-// row-varying tau / nu with at most CV_FEW_K streamed columns and CV_KC tangents: one wave per (group, window) (iso_few_kernel)
+// row-varying tau / nu with at most 2 CV_FEW_K streamed columns and 2 CV_KC tangents: one wave per (group, window) (iso_few_kernel);
+// kc = CV_KC or 2 CV_KC tangent slots (parts[0], parts[1])
 constexpr int CV_FEW_K = 4;
-hipError_t launch_iso_few(int model, int d, const IsoArgs& a, const CvPart* parts, hipStream_t s);
+hipError_t launch_iso_few(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
 // constant tau / nu with per-row H_array (CTCRW, d = 2): one wave per (group, window), the tangents of parts[0] (columns of ones)
 hipError_t launch_iso_full(int model, const IsoArgs& a, const CvPart* parts, hipStream_t s);
 hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, int d, double* out /* [n_groups][2]: max diag(H), max |H01 - H10| */, hipStream_t s);

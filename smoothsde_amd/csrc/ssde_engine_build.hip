@@ -152,8 +152,11 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             // few columns and few tangents besides the directions the filter carries: one wave per (group, window) does it all
             bool mu_streamed = false;
             for (auto& c : cols) mu_streamed = mu_streamed || c.type >= 3;
-            h->cv_few = !h->cv_full && !h->has_h && !mu_streamed && h->n_stream_cols >= 1 && h->n_stream_cols <= CV_FEW_K &&
-                        (int)cols.size() <= CV_KC && !getenv("SSDE_CV_NO_FEW");
+            h->cv_few = !h->cv_full && !h->has_h && !mu_streamed && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
+                        (int)cols.size() <= 2 * CV_KC && !getenv("SSDE_CV_NO_FEW");
+            // (the wide instantiation -- more than four columns or tangents -- of CTCRW with two response columns spills: the pipeline)
+            const bool wide = h->n_stream_cols > CV_FEW_K || (int)cols.size() > CV_KC;
+            if (wide && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_CV_FEW_WIDE")) h->cv_few = false;
         }
         if ((int)cols.size() > (h->cv_full ? CV_WAVES - 2 : CV_WAVES) * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;     // (full-covariance lanes: the two stage waves carry no columns)
         std::vector<CvPart> parts(CV_WAVES);
@@ -172,7 +175,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                 if (tot == N) { for (int p = 0; p < 8; p++) n_w[p] = v[p]; dealt_by_env = true; }
             }
         }
-        if (h->cv_few) n_w[0] = N;                                 // (iso_few_kernel: every column on the one wave)
+        if (h->cv_few) { n_w[0] = std::min(N, CV_KC); n_w[1] = N - n_w[0]; }     // (iso_few_kernel: every column on the one wave; slots 0-3 / 4-7 = parts 0 / 1)
         else
         if (h->cv_single) {
             // one wave does it all (iso_full_kernel): slots 0, 1 = the log tau, log nu intercepts, slots 2, 3 = the drift intercepts
@@ -214,7 +217,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             for (auto& sl : h->slots)
                 if (sl.par_j < h->d && !h->fixed[sl.pidx]) { parts[0].with_mu = 1; h->cv_mu_part = 0; }
         }
-        h->cv_kc = h->cv_one_wave() ? CV_KC : best_kc;
+        h->cv_kc = h->cv_few ? ((N > CV_KC || h->n_stream_cols > CV_FEW_K) ? 2 * CV_KC : CV_KC) : h->cv_single ? CV_KC : best_kc;
         HIPCHK(h, h->cv_parts.upload(parts));
         HIPCHK(h, hipHostMalloc((void**)&h->cv_ranges_pinned, 4 * sizeof(double), hipHostMallocDefault));
         h->cv_ranges_pinned[0] = h->cv_ranges_pinned[2] = INFINITY; h->cv_ranges_pinned[1] = h->cv_ranges_pinned[3] = -INFINITY;
@@ -264,7 +267,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->drift = all_clean ? 1 : 2;
         h->drift_nstate = all_clean ? drift_nstate(h->model, h->d, h->n_stream_cols) : drift_general_nstate(h->model, h->d, h->n_stream_cols);
     }
-    if (h->drift) { h->iso_parts = (h->drift == 3 && !h->cv_one_wave()) ? CV_WAVES : 1; h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
+    if (h->drift) { h->iso_parts = (h->drift == 3 && !h->cv_one_wave()) ? CV_WAVES : (h->cv_few ? h->cv_kc / CV_KC : 1); h->iso_masks[0] = DIR_SIG | DIR_MU | DIR_P1 | DIR_P2; h->iso_free_mask = h->iso_masks[0]; }
     else choose_iso_split(h);
     // shared-covariance path: regular grid + groups without missing rows
     HIPCHK(h, h->group_flags.upload(gflags));
@@ -781,7 +784,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             int n_dirs = h->fixed[0] ? 0 : 1, n_tan = 0, n_mu_cols = 0;
             for (auto& sl : h->slots)
                 if (!h->fixed[sl.pidx]) { n_dirs++; if (sl.par_j >= h->d) n_tan++; else if (sl.col >= 0) n_mu_cols++; }
-            const bool few_shape = iso_cfg && n_mu_cols == 0 && n_tan <= CV_KC && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
+            const bool few_shape = iso_cfg && n_mu_cols == 0 && n_tan <= CV_KC * ((h->model == SSDE_MODEL_CTCRW && h->d == 2) ? 1 : 2) && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
                                    !getenv("SSDE_CV_NO_FEW");                   // (columns may still be shared below: checked again at the plan)
             const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : few_shape ? 1200 : std::max(160, 3400 / std::max(n_dirs, 1));
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {

@@ -219,7 +219,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     } else {
         a.n_parts = 1;
     }
-    if (h->drift == 3) { a.n_parts = h->cv_one_wave() ? 1 : CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
+    if (h->drift == 3) { a.n_parts = h->cv_few ? h->cv_kc / CV_KC : h->cv_single ? 1 : CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
     a.any_nan = h->na_any;
     a.uniform_dt = h->uniform_dt ? 1 : 0;
     const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
@@ -414,7 +414,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
             if (h->cv_single) HIPCHK(h, launch_iso_full(h->model, a, h->cv_parts.p, s));
-            else if (h->cv_few) HIPCHK(h, launch_iso_few(h->model, h->d, a, h->cv_parts.p, s));
+            else if (h->cv_few) HIPCHK(h, launch_iso_few(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
             else {
             const int n_wg = h->n_groups * a.n_chunks;
             if ((int)h->cv_ranges.n < 4 * n_wg) { h->cv_ranges.release(); HIPCHK(h, h->cv_ranges.alloc((size_t)4 * n_wg)); }

@@ -635,7 +635,8 @@ def test_argos_batch_size_properties(monkeypatch):
 
 
 @pytest.mark.parametrize("model,d,which,what", [("CTCRW", 2, "p1", "plain"), ("CTCRW", 1, "p2", "missing"), ("OU_SSM", 2, "both", "irregular"),
-                                                ("BM_SSM", 2, "p1", "both"), ("OU_SSM", 1, "p2", "plain"), ("CTCRW", 2, "both", "both")])
+                                                ("BM_SSM", 2, "p1", "both"), ("OU_SSM", 1, "p2", "plain"), ("CTCRW", 2, "both", "both"),
+                                                ("OU_SSM", 2, "wide", "both"), ("CTCRW", 1, "wide", "missing"), ("BM_SSM", 1, "wide", "plain")])
 def test_linear_covariate_effects_run_on_one_wave_per_window(model, d, which, what, monkeypatch):
     """tau ~ 1 + x and / or nu ~ 1 + x (fixed-effect slopes, no smooth): at most four streamed columns and four tangents besides
     the directions the filter carries -- iso_few_kernel; against the oracle and, A/B, the eight-wave pipeline."""
@@ -650,6 +651,10 @@ def test_linear_covariate_effects_run_on_one_wave_per_window(model, d, which, wh
         X_fe[d] = np.column_stack([np.ones(n), x])
     if which in ("p2", "both") and q > d + 1:
         X_fe[d + 1] = np.column_stack([np.ones(n), x ** 2])
+    if which == "wide":                                          # five to seven streamed columns and tangents: the wide instantiation
+        X_fe[d] = np.column_stack([np.ones(n), x, x ** 2, np.sin(3 * x)])
+        if q > d + 1:
+            X_fe[d + 1] = np.column_stack([np.ones(n), x ** 2, np.cos(2 * x)])
     if all(v is None for v in X_fe):
         X_fe[d] = np.column_stack([np.ones(n), x])
     o = o.copy()
