@@ -419,7 +419,7 @@ def argos_workload(M, T, dev, steps):
     return {"workload": f"{M} CTCRW x {T} with a per-row 2 x 2 measurement covariance (H_array) and constant tau, nu", "value": inf["n_rows"] * steps / el,
             "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]],
             "required_bytes_per_row": inf["required_bytes_per_row"],
-            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac": (inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern > 0 else None,
             "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
 
 

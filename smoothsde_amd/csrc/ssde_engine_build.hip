@@ -786,7 +786,9 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
                 if (!h->fixed[sl.pidx]) { n_dirs++; if (sl.par_j >= h->d) n_tan++; else if (sl.col >= 0) n_mu_cols++; }
             const bool few_shape = iso_cfg && n_mu_cols == 0 && n_tan <= CV_KC * ((h->model == SSDE_MODEL_CTCRW && h->d == 2) ? 1 : 2) && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
                                    !getenv("SSDE_CV_NO_FEW");                   // (columns may still be shared below: checked again at the plan)
-            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : few_shape ? 1200 : std::max(160, 3400 / std::max(n_dirs, 1));
+            //  (With H_array the lane = direction lanes carry a full covariance and cost three times as much: 64 / 640 / 1280 tracks x 10^3 rows,
+            //   constant tau / nu: 0.245 / 0.30 / 0.53 ms there against 0.23-0.24 on iso_full_kernel; row-varying, 160 tracks: 0.60 against 0.36.)
+            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : h->has_h ? 64 : few_shape ? 1200 : std::max(160, 3400 / std::max(n_dirs, 1));
             if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
