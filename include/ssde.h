@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 8
+#define SSDE_ABI_VERSION 9
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -236,6 +236,11 @@ typedef struct ssde_info_t {
                                on its lattice */
     int32_t n_groups;       /* 64-track wavefront groups */
     int32_t n_clean_groups; /* ... of which every track has every row: the shared-covariance kernel's share on a regular grid */
+    int32_t quiet_window;   /* > 0: the general kernel of the last evaluation ran rows that lie this many rows past the last missing
+                               observation of their wavefront with the stationary gains; 0: no such rows */
+    int32_t reserved_;
+    double  quiet_share;    /* share of the blocks of wavefronts with missing rows that qualify, at a nominal 128-row memory
+                               (found at ssde_create; 0 when the layout has no such wavefront or the grid is irregular) */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the

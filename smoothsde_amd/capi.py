@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -86,6 +86,7 @@ class SsdeInfo(C.Structure):
         ("required_bytes_per_row", C.c_double), ("n_evals", C.c_int64), ("n_memo_hits", C.c_int64),
         ("n_devices", C.c_int32), ("comm_ranks", C.c_int32), ("window_check_max", C.c_double),
         ("n_rows_tiled", C.c_int64), ("n_groups", C.c_int32), ("n_clean_groups", C.c_int32),
+        ("quiet_window", C.c_int32), ("reserved_", C.c_int32), ("quiet_share", C.c_double),
     ]
 
     def as_dict(self):

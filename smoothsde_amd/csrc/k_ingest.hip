@@ -147,7 +147,7 @@ __global__ void seg_nan_kernel(const double* obs, int64_t n, int d, const int64_
     if (!bad) return;
     int64_t lo = 0, hi = n_seg;                     // the segment with starts[lo] <= i < starts[lo + 1]
     while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
-    flags[lo] = 1;
+    atomicMax(&flags[lo], (int)min((long long)(i - starts[lo]), (long long)(INT32_MAX - 1)) + 1);   // != 0: the track misses a row; 1 + its last such row
 }
 hipError_t launch_seg_nan(const double* obs, int64_t n, int d, const int64_t* starts, int64_t n_seg, int* flags, hipStream_t s) {
     if (n == 0) return hipSuccess;

@@ -42,12 +42,15 @@ constexpr int ISO_U = SSDE_ISO_U;
 #define SSDE_ISO_WAVES_SCAL 2   // ... the scalar-covariance models (OU_SSM, BM_SSM)
 #endif
 static_assert(ISO_U % TILE_U == 0 && WIN_ALIGN % (2 * ISO_U) == 0 && 3 * ISO_U <= TILE_SPARE, "prefetch block");
+// ... of the kernels with quiet rows (below): those rows cost a third of a general row, so the loads lead by twice as many
+constexpr int QUIET_U = 8;
+static_assert(QUIET_U % TILE_U == 0 && WIN_ALIGN % (2 * QUIET_U) == 0 && 3 * QUIET_U <= TILE_SPARE, "prefetch block");
 
 // register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
-template <int C>
-__device__ __forceinline__ void load_block(double (&dst)[ISO_U][C], const double* p, int Cr, int c_obs) {
+template <int C, int U>
+__device__ __forceinline__ void load_block(double (&dst)[U][C], const double* p, int Cr, int c_obs) {
 #pragma unroll
-    for (int u = 0; u < ISO_U; u++) {
+    for (int u = 0; u < U; u++) {
         dst[u][0] = 0.0;
         if (c_obs) dst[u][0] = p[(u * Cr) * WAVE];
 #pragma unroll
@@ -116,6 +119,132 @@ struct LaneOps {  // OU_SSM / BM_SSM
 };
 
 
+// ---- quiet rows (regular grid) ---------------------------------------------------------------------------------------
+// A lane whose covariance is at its stationary value needs the mean half of the step only, with the gains and their
+// sensitivities as constants (IsoArgs.statc -- the numbers the shared-covariance kernels use, k_iso_shared.inc).  The engine
+// marks the blocks of QUIET_U rows in which some lane of the group misses an observation (IsoArgs.nan_bits); a block is QUIET
+// when neither it nor the quiet_w blocks before it hold such a row and the transient of P0 is over: the lanes drop their
+// covariance there and take it up again, from the stationary values, at the next marked block.  The accumulators are the
+// general step's (sum u'F^-1 u and its derivatives); the data-independent terms (log F, dF / F) are counted per lane (nq).
+template <int MODEL, int D, int MASK>
+struct QuietOps;
+
+template <int D, int MASK>
+struct QuietOps<M_CTCRW, D, MASK> {
+    typedef CtcrwLane<D, MASK> State;
+    double k1, k2, c1, t12, e, iF, hd[NDIRP], dk1[NDIRP], dk2[NDIRP], dt12, de, cb1, cb2, cx[D], cv[D], bmu[D];
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        const double* c = A.statc;
+        iF = c[0]; k1 = c[1]; k2 = c[2]; c1 = c[3]; t12 = c[4]; e = c[5]; dt12 = c[6]; de = c[7]; cb1 = c[8]; cb2 = c[9];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
+#pragma unroll
+        for (int a = 0; a < D; a++) { cx[a] = c[19 + a]; cv[a] = c[21 + a]; bmu[a] = c[23 + a]; }
+    }
+    // nllk_ctcrw.hpp:221, 231-234, 238 with K, F^-1 and their derivatives at the stationary covariance
+    __device__ __forceinline__ void step(State& S, const double* y) const {
+        CtcrwMean<D, MASK>& M = S.M;
+        double u[D], su2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { u[a] = y[a] - M.x[a]; su2 = fma(u[a], u[a], su2); }
+        M.accq = fma(iF, su2, M.accq);
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j))) continue;
+            double sud = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double tx = M.tx[j][a], tv = M.tv[j][a];
+                sud = fma(u[a], tx, sud);
+                double nx = dk1[j] * u[a], nv = dk2[j] * u[a];
+                if (j == 1) {
+                    const double w = M.v[a] - bmu[a];
+                    nx = fma(dt12, w, nx);
+                    nv = fma(de, w, nv);
+                }
+                M.tx[j][a] = fma(c1, tx, fma(t12, tv, nx));
+                M.tv[j][a] = fma(e, tv, fma(-k2, tx, nv));
+            }
+            M.gq[j] = fma(hd[j], su2, fma(-iF, sud, M.gq[j]));
+        }
+        if (MASK & DIR_MU) {
+            const double mx = M.mx[0], mv = M.mv[0], imx = iF * mx;
+            const double nx = fma(c1, mx, fma(t12, mv, cb1)), nv = fma(e, mv, fma(-k2, mx, cb2));
+#pragma unroll
+            for (int a = 0; a < D; a++) { M.gmu[a] = fma(-imx, u[a], M.gmu[a]); M.mx[a] = nx; M.mv[a] = nv; }
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double x = M.x[a], v = M.v[a];
+            M.x[a] = fma(k1, u[a], fma(t12, v, x)) + cx[a];
+            M.v[a] = fma(k2, u[a], fma(e, v, cv[a]));
+        }
+        S.C.nupd += 1.0;
+    }
+    // the lane's covariance and its sensitivities at their stationary values
+    __device__ static __forceinline__ void stationary(State& S, const IsoArgs& A) {
+        S.C.p11 = A.quiet_p[0]; S.C.p12 = A.quiet_p[1]; S.C.p22 = A.quiet_p[2];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j))) continue;
+            S.C.d11[j] = A.quiet_p[3 + 3 * j]; S.C.d12[j] = A.quiet_p[4 + 3 * j]; S.C.d22[j] = A.quiet_p[5 + 3 * j];
+        }
+    }
+};
+
+template <int MODEL, int D, int MASK>
+struct QuietOps {   // OU_SSM / BM_SSM
+    typedef ScalLane<D, MASK> State;
+    static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    double k, c, t, b, iF, hd[NDIRP], dk[NDIRP], dt_, cmu[D], dbmu[D];
+    __device__ __forceinline__ void setup(const IsoArgs& A) {
+        const double* cc = A.statc;
+        iF = cc[0]; k = cc[1]; c = cc[2]; t = cc[3]; b = cc[4]; dt_ = cc[5];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) { hd[j] = cc[10 + j]; dk[j] = cc[13 + j]; }
+#pragma unroll
+        for (int a = 0; a < D; a++) { cmu[a] = cc[19 + a]; dbmu[a] = cc[21 + a]; }
+    }
+    // x' = t x + k u + b mu;  tx' = (t - k) tx + dk u [+ dt_ x + db mu]   (nllk_ou_ssm.hpp:204, nllk_bm_ssm.hpp:166)
+    __device__ __forceinline__ void step(State& S, const double* y) const {
+        ScalMean<D, MASK>& M = S.M;
+        double u[D], su2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { u[a] = y[a] - M.x[a]; su2 = fma(u[a], u[a], su2); }
+        M.accq = fma(iF, su2, M.accq);
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+            double sud = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) {
+                const double tx = M.tx[j][a];
+                sud = fma(u[a], tx, sud);
+                double nx = dk[j] * u[a];
+                if (j == 1 && HAS_P2) nx = fma(dt_, M.x[a], nx) + dbmu[a];
+                M.tx[j][a] = fma(c, tx, nx);
+            }
+            M.gq[j] = fma(hd[j], su2, fma(-iF, sud, M.gq[j]));
+        }
+        if (MASK & DIR_MU) {
+            const double mx = M.mx[0], imx = iF * mx, nx = fma(c, mx, b);
+#pragma unroll
+            for (int a = 0; a < D; a++) { M.gmu[a] = fma(-imx, u[a], M.gmu[a]); M.mx[a] = nx; }
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) M.x[a] = fma(k, u[a], fma(t, M.x[a], cmu[a]));
+        S.C.nupd += 1.0;
+    }
+    __device__ static __forceinline__ void stationary(State& S, const IsoArgs& A) {
+        S.C.p = A.quiet_p[0];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+            S.C.dp[j] = A.quiet_p[3 + 3 * j];
+        }
+    }
+};
+
 // DER >= 0: the covariance direction DER (1 = par[d] for BM_SSM, 2 = par[d+1] for CTCRW / OU_SSM) is NOT carried
 // through the recursion but derived from the log sigma_obs direction.  The filter is homogeneous in the variances:
 // scaling (sigma_obs^2, process variance, P0) by c scales P and F by c and leaves the mean and the gains alone, so
@@ -145,10 +274,12 @@ struct DeriveOps {
     }
 };
 
-template <int MODEL, int D, int MASK, bool UNI, int DER = -1>
+template <int MODEL, int D, int MASK, bool UNI, int DER = -1, bool QUIET = false>
 __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
     typedef LaneOps<MODEL, D, MASK> Ops;
+    typedef QuietOps<MODEL, D, MASK> QOps;
     constexpr int C = 1 + D;
+    constexpr int U = QUIET ? QUIET_U : ISO_U;     // rows per prefetch block
     constexpr int NACC = 4 + D;
     constexpr int SD = Ops::SD;
     const int lane = threadIdx.x & 63;
@@ -174,8 +305,8 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     ns_min = __builtin_amdgcn_readfirstlane(ns_min);
 
     // two register blocks in ping-pong: while one is consumed the other is in flight (no copies)
-    double bufA[ISO_U][C], bufB[ISO_U][C];
-    load_block<C>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
+    double bufA[U][C], bufB[U][C];
+    load_block<C, U>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
@@ -185,13 +316,65 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         Ops::warm_init(S, &bufA[0][1], A);
     }
 
-    auto run_block = [&](const double (&blk)[ISO_U][C], int s0) {
-        if (s0 + ISO_U <= ns_min) {          // every lane's track covers the block: no per-row predication
+    // quiet rows (QUIET): q_last = the latest block with a missing observation (a window that does not start quiet counts its
+    // own start as one: its covariance is a guess there), q_word = the 64 block flags around the current block
+    QOps Q;
+    int q_last = 0, q_wi = -1;
+    unsigned long long q_word = 0ull;
+    bool q_mode = false;
+    double nq = 0.0;                         // rows this lane scored in quiet mode
+    const unsigned long long* qbits = nullptr;
+    if (QUIET) {
+        Q.setup(A);
+        qbits = A.nan_bits + (int64_t)g * A.nan_words;
+        const int b0 = s_begin / U;
+        q_last = -A.quiet_w - 1;
+        if (b0 > 0) {
+            const int lo = max(0, b0 - A.quiet_w);
+            bool any = false;
+            for (int wi = lo >> 6; wi <= (b0 - 1) >> 6; wi++) {
+                const int blo = max(lo, wi * 64) - wi * 64, bhi = min(b0, wi * 64 + 64) - wi * 64;   // bits [blo, bhi) of this word
+                const unsigned long long m = (bhi - blo >= 64) ? ~0ull : (((1ull << (bhi - blo)) - 1ull) << blo);
+                any = any || ((qbits[wi] & m) != 0ull);
+            }
+            q_last = any ? b0 - 1 : b0 - A.quiet_w - 1;
+        }
+    }
+    auto quiet_block = [&](int s0) -> bool {
+        const int b = s0 / U;
+        if ((b >> 6) != q_wi) {
+            q_wi = b >> 6;
+            const unsigned long long w = qbits[q_wi];
+            q_word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0xffffffffull));
+        }
+        if ((q_word >> (b & 63)) & 1ull) q_last = b;
+        return (b - q_last > A.quiet_w) && (b >= A.quiet_b0);
+    };
+    auto run_block = [&](const double (&blk)[U][C], int s0) {
+        if (QUIET) {
+            const bool q = quiet_block(s0);
+            if (q_mode && !q) QOps::stationary(S, A);     // a missing row ahead: the lane's own covariance again
+            q_mode = q;
+            if (q) {
+                if (s0 + U <= ns_min) {
 #pragma unroll
-            for (int u = 0; u < ISO_U; u++) Ops::template step<UNI>(S, A, mu, blk[u]);
+                    for (int u = 0; u < U; u++) Q.step(S, &blk[u][1]);
+                    nq += (double)U;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        if (s0 + u < ns) { Q.step(S, &blk[u][1]); nq += 1.0; }
+                }
+                return;
+            }
+        }
+        if (s0 + U <= ns_min) {          // every lane's track covers the block: no per-row predication
+#pragma unroll
+            for (int u = 0; u < U; u++) Ops::template step<UNI>(S, A, mu, blk[u]);
         } else {
 #pragma unroll
-            for (int u = 0; u < ISO_U; u++)
+            for (int u = 0; u < U; u++)
                 if (s0 + u < ns) Ops::template step<UNI>(S, A, mu, blk[u]);
         }
     };
@@ -199,28 +382,31 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         if (s0 == s_acc && s_acc > s_begin) {
             // end of warm-up: publish the state for the hand-over check, start scoring from zero
             double st[Ops::State::NSTATE];
+            if (QUIET && q_mode) QOps::stationary(S, A);
             S.dump(st);
             if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
             double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
 #pragma unroll
             for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
             S.reset_acc();
+            nq = 0.0;
         }
     };
-    for (int s0 = s_begin; s0 < s_end; s0 += 2 * ISO_U) {
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
         // TILE_SPARE keeps the look-ahead loads inside the allocation
-        load_block<C>(bufB, base + (int64_t)(s0 + ISO_U) * Cr * WAVE, Cr, c_obs);
+        load_block<C, U>(bufB, base + (int64_t)(s0 + U) * Cr * WAVE, Cr, c_obs);
         handover(s0);
         run_block(bufA, s0);
-        load_block<C>(bufA, base + (int64_t)(s0 + 2 * ISO_U) * Cr * WAVE, Cr, c_obs);
-        if (s0 + ISO_U < s_end) {
-            handover(s0 + ISO_U);
-            run_block(bufB, s0 + ISO_U);
+        load_block<C, U>(bufA, base + (int64_t)(s0 + 2 * U) * Cr * WAVE, Cr, c_obs);
+        if (s0 + U < s_end) {
+            handover(s0 + U);
+            run_block(bufB, s0 + U);
         }
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
         // state on arrival at the next window's first scored row
         double st[Ops::State::NSTATE];
+        if (QUIET && q_mode) QOps::stationary(S, A);
         S.dump(st);
         if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
         double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
@@ -229,6 +415,13 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     }
     double out[NACC];
     Ops::finish(S, out);
+    if (QUIET) {                             // the data-independent terms of the rows scored in quiet mode
+        const double hn = 0.5 * (double)D * nq;
+        out[0] = fma(hn, A.quiet_ld, out[0]);
+        if (MASK & DIR_SIG) out[1] = fma(hn, A.quiet_gld[0], out[1]);
+        if (MASK & DIR_P1) out[2 + D] = fma(hn, A.quiet_gld[1], out[2 + D]);
+        if (MASK & DIR_P2) out[3 + D] = fma(hn, A.quiet_gld[2], out[3 + D]);
+    }
     if (DER >= 0) {   // gradient of the derived direction: slots [value, sig, mu.., par[d], par[d+1]]
         constexpr double CB = DeriveOps<MODEL, DER>::CB;
         out[1 + D + DER] = CB * ((double)D * S.C.nupd - S.M.accq - out[1]);
@@ -246,7 +439,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 
 // One kernel per (direction mask, regular / irregular grid) when the whole launch uses a single mask (n_parts == 1, the
 // default): a kernel's register allocation is the worst case over everything it contains.
-template <int MODEL, int D, int MASK, bool UNI>
+template <int MODEL, int D, int MASK, bool UNI, bool QUIET = false>
 __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
@@ -254,8 +447,8 @@ __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (!group_selected(A, g)) return;
     constexpr int DERJ = (MODEL == M_BM_SSM) ? 1 : 2;
     constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
-    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), UNI, DERJ>(A, g, part, chunk);
-    else run_lane<MODEL, D, MASK, UNI>(A, g, part, chunk);
+    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), UNI, DERJ, QUIET>(A, g, part, chunk);
+    else run_lane<MODEL, D, MASK, UNI, -1, QUIET>(A, g, part, chunk);
 }
 
 // Two waves per SIMD (256 registers each): a lone wave leaves the fp64 pipe idle behind its dependent instructions
@@ -268,6 +461,12 @@ __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
 template <int MODEL, int D, int MASK, bool UNI>
 __global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_ISO_WAVES : 1) : SSDE_ISO_WAVES_SCAL) void iso_mask_kernel(const IsoArgs A) {
     iso_mask_body<MODEL, D, MASK, UNI>(A);
+}
+// ... the same lanes with quiet rows (regular grid, a.quiet_w > 0): a kernel of its own, so that batches without quiet rows run
+// the code (and the register allocation) they always ran
+template <int MODEL, int D, int MASK>
+__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? SSDE_ISO_WAVES : SSDE_ISO_WAVES_SCAL) void iso_quiet_kernel(const IsoArgs A) {
+    iso_mask_body<MODEL, D, MASK, true, true>(A);
 }
 
 // Direction-split launches (several parts with different masks; a testing path) keep the masks in one kernel.
@@ -296,7 +495,8 @@ static void launch_one_mask(const IsoArgs& a, dim3 grid, hipStream_t s) {
     switch (a.part_mask[0]) {
 #define SSDE_CASE(M)                                                                                          \
     case M:                                                                                                   \
-        if (uni) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M, true>), grid, block, 0, s, a);              \
+        if (uni && a.quiet_w > 0 && a.nan_bits) hipLaunchKernelGGL((iso_quiet_kernel<MODEL, D, M>), grid, block, 0, s, a); \
+        else if (uni) hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M, true>), grid, block, 0, s, a);         \
         else hipLaunchKernelGGL((iso_mask_kernel<MODEL, D, M, false>), grid, block, 0, s, a);                 \
         break;
         SSDE_CASE(0) SSDE_CASE(1) SSDE_CASE(2) SSDE_CASE(3) SSDE_CASE(4) SSDE_CASE(5) SSDE_CASE(6) SSDE_CASE(7)
@@ -443,6 +643,35 @@ hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceA
     ReduceArgs rr = r;
     rr.pub_blocks = n_check + r.n_out;
     hipLaunchKernelGGL(iso_finalize_kernel, dim3(n_check + r.n_out), dim3(256), 0, s, a, rr, iso_nstate(model, d), n_check);
+    return hipGetLastError();
+}
+
+// ---- which blocks of QUIET_U rows hold a missing observation (ssde_create, once; IsoArgs.nan_bits) ------------------------
+// One wave per (group, 64 blocks): lane = track, bit b of the word = some lane's row in block b is not a number in some
+// response column (rows past a lane's last step are padding and do not count).
+__global__ __launch_bounds__(WAVE) void nan_blocks_kernel(const TileView tv, int d, unsigned long long* bits, int nwords) {
+    const int g = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    const int L = tv.group_len[g];
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    unsigned long long word = 0ull;
+    for (int bb = 0; bb < 64; bb++) {
+        const int s0 = (w * 64 + bb) * QUIET_U;
+        if (s0 >= L) break;                                   // (workgroup-uniform)
+        bool bad = false;
+        for (int u = 0; u < QUIET_U; u++) {
+            const int s = s0 + u;
+            if (s < ns && s < L)
+                for (int a = 0; a < d; a++) { const double v = base[((int64_t)s * tv.C + tv.c_obs + a) * WAVE]; bad = bad || (v != v); }
+        }
+        if (__ballot(bad) != 0ull) word |= 1ull << bb;
+    }
+    if (lane == 0) bits[(int64_t)g * nwords + w] = word;
+}
+int iso_block_rows() { return QUIET_U; }
+hipError_t launch_nan_blocks(const TileView& tv, int d, unsigned long long* bits, int nwords, hipStream_t s) {
+    if (tv.n_groups == 0 || nwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(nan_blocks_kernel, dim3(tv.n_groups, nwords), dim3(WAVE), 0, s, tv, d, bits, nwords);
     return hipGetLastError();
 }
 

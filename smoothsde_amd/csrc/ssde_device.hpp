@@ -130,6 +130,17 @@ struct IsoArgs {
     int cv_full;                 // 4 x 4 covariance lanes (CTCRW, d = 2): per-row H_array and / or a P0 that is not block-identical
     int cv_has_h;                // ... the tiles hold H_array[,,i] in the d^2 channels after the observations
     double cv_p0[16];            // ... P0, column-major
+    // Quiet rows of the general kernel (regular grid; k_iso.hip): a block of ISO_U rows with no missing observation in it or in
+    // the quiet_w blocks before it (any lane), past the covariance transient, has the STATIONARY covariance on every lane --
+    // the lanes run the mean half with the stationary gains (statc) there and take up their own covariance again, from the
+    // stationary values, at the next missing row.
+    const unsigned long long* nan_bits;   // [n_groups][nan_words] bit b: a lane of the group misses an observation in rows [ISO_U b, ISO_U (b + 1)), or NULL
+    int nan_words;
+    int quiet_w;                 // blocks a lane's covariance takes to forget a missing row (0: no quiet rows in this launch)
+    int quiet_b0;                // first block past the covariance transient of the initial P0
+    double quiet_p[3 + 3 * 3];   // stationary P (CTCRW: p11, p12, p22; OU / BM: p) | its sensitivities, direction-major
+    double quiet_ld;             // log F at the stationary covariance
+    double quiet_gld[3];         // ... dF / F per covariance direction
 };
 // One part of a k_iso_colvar.hip launch: the design columns whose coefficient gradients one wave of the workgroups carries
 // (device table, CV_WAVES entries)
@@ -164,6 +175,9 @@ __host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool ha
             ((mask & DIR_MU) ? 1 : 0)) * sd;
 }
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
+// blocks of iso_block_rows() rows in which some lane of a group misses an observation: bits [n_groups][nwords] (k_iso.hip)
+int iso_block_rows();
+hipError_t launch_nan_blocks(const TileView& tv, int d, unsigned long long* bits, int nwords, hipStream_t s);
 // ev0 / ev1 (may be NULL): stamped with the kernel's own begin / end
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // shared-covariance lanes with a streamed row-varying drift (k_iso_drift.hip); partials [n_chunks][4 + d + drift_k][n_groups]

@@ -50,7 +50,7 @@ void release_device(ssde_handle* h) {
                 h->trace_us[0] / h->trace_n, h->trace_us[1] / h->trace_n, h->trace_us[2] / h->trace_n, h->trace_us[3] / h->trace_n,
                 h->trace_us[4] / h->trace_n);
     destroy_dist(h);
-    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release(); h->dirty_groups.release(); h->lap_out.release();
+    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release(); h->dirty_groups.release(); h->lap_out.release(); h->nan_bits.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -719,6 +719,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
                 if (first_part) { info->n_tracks += si.n_tracks; info->n_rows += si.n_rows; info->n_steps += si.n_steps; info->main_kernel_rows += si.main_kernel_rows; }
                 info->hbm_bytes += si.hbm_bytes;
                 info->n_rows_tiled += si.n_rows_tiled; info->n_groups += si.n_groups; info->n_clean_groups += si.n_clean_groups;
+                info->quiet_window = std::max(info->quiet_window, si.quiet_window); info->quiet_share = std::max(info->quiet_share, si.quiet_share);
                 info->n_kernel_blocks += si.n_kernel_blocks;   // (n_evals: shard 0's count -- every shard runs every evaluation)
                 info->uniform_dt = info->uniform_dt && si.uniform_dt;
                 info->const_coeff = info->const_coeff && si.const_coeff;
@@ -769,6 +770,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     if (h->path == PATH_ISO || h->path == PATH_DENSE) {
         info->n_rows_tiled = h->n_pad > 0 ? h->n_pad : h->n;
         info->n_groups = h->n_groups; info->n_clean_groups = h->path == PATH_ISO ? h->n_clean_groups : 0;
+        info->quiet_window = h->last_quiet_window; info->quiet_share = h->quiet_share;
     }
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;

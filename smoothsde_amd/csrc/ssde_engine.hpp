@@ -122,6 +122,14 @@ struct ssde_handle {
     double dt_min = 0.0;           // smallest interval used inside a track
     double dt_max = 0.0;           // ... and the largest
     bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
+    // quiet rows of the general kernel (k_iso.hip): blocks that hold a missing observation, per group; 0 words = not in use
+    DevBuf<unsigned long long> nan_bits;
+    int nan_words = 0;
+    bool quiet_ok = false;
+    double quiet_share = 0.0;      // share of the dirty groups' blocks that qualify (nominal 128-row memory)
+    int last_quiet_window = 0;     // rows of memory the last launch used (0: no quiet rows)
+    bool gain_stationary = false;  // the last gain recursion reached its stationary row
+    double stat_p[12] = {0}, stat_ld = 0.0, stat_gld[3] = {0, 0, 0};   // ... the covariance, log F and dF / F there
     int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
     int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
     int last_chunks = 1, last_window = 0;

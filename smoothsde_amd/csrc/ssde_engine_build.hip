@@ -336,7 +336,38 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         h->want_chunks_d = std::max(1, std::min(std::min(std::min(want_d, 64), by_mem), std::max(1, glmax / (4 * WIN_ALIGN))));
         buf_chunks = std::max(buf_chunks, h->want_chunks_d + 1);
     }
-    if (h->use_shared) {
+    // Quiet rows: a regular-grid batch whose groups hold missing rows here and there (no complete group to keep on the shared
+    // kernel, or some) -- the general lanes drop their covariance wherever it is stationary on all 64 lanes (k_iso.hip).  Worth it
+    // when a fair share of the blocks qualifies (with missing rows in every block of every group the flags cost a little and win nothing).
+    if (h->uniform_dt && !h->drift && h->iso_parts == 1 && h->n_clean_groups < G && glmax >= 8 * WIN_ALIGN && !getenv("SSDE_NO_QUIET")) {
+        const int U = iso_block_rows();
+        h->nan_words = (glmax / U + 63) / 64 + 1;
+        HIPCHK(h, h->nan_bits.alloc((size_t)G * h->nan_words));
+        HIPCHK(h, hipMemset(h->nan_bits.p, 0, (size_t)G * h->nan_words * 8));
+        TileView tv;
+        tv.tiles = h->tiles.p; tv.group_off = h->group_off.p; tv.group_len = h->group_len.p; tv.lane_nsteps = h->lane_nsteps.p;
+        tv.a0 = h->a0.p; tv.n_groups = G; tv.C = h->C; tv.c_obs = h->c_obs; tv.dt_all = h->dt_all;
+        HIPCHK(h, launch_nan_blocks(tv, h->d, h->nan_bits.p, h->nan_words, 0));
+        std::vector<unsigned long long> bits((size_t)G * h->nan_words);
+        HIPCHK(h, hipMemcpy(bits.data(), h->nan_bits.p, bits.size() * 8, hipMemcpyDeviceToHost));
+        // share of the dirty groups' blocks that would be quiet with a nominal 128-row memory
+        const int wq = 128 / U;
+        int64_t n_blocks = 0, n_quiet = 0;
+        for (int g = 0; g < G; g++) {
+            if (gflags[g]) continue;
+            const int nb = glen[g] / U;
+            int last = -wq - 1;
+            for (int b = 0; b < nb; b++) {
+                if ((bits[(size_t)g * h->nan_words + (b >> 6)] >> (b & 63)) & 1ull) last = b;
+                n_quiet += (b - last > wq) ? 1 : 0;
+            }
+            n_blocks += nb;
+        }
+        h->quiet_share = n_blocks > 0 ? (double)n_quiet / (double)n_blocks : 0.0;
+        h->quiet_ok = n_blocks > 0 && (double)n_quiet >= (getenv("SSDE_QUIET_ALWAYS") ? 0.0 : 0.2) * (double)n_blocks;
+        if (!h->quiet_ok) { h->nan_bits.release(); h->nan_words = 0; }
+    }
+    if (h->use_shared || h->quiet_ok) {
         h->gain_rows_cap = (size_t)glmax + 1;
         HIPCHK(h, h->gain_ring.alloc((size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW));
         HIPCHK(h, hipHostMalloc((void**)&h->gain_pinned, (size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW * 8,
@@ -838,6 +869,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         const double* p_obs = t_obs;
         if (!t_on_dev) { HIPCHK(h, stage(t_obs, (size_t)tn * d->n_dim, false, s_obs)); p_obs = s_obs.p; }
         std::vector<uint8_t> seg_dirty((size_t)M, 0);
+        std::vector<int> seg_napos;
         if (h->path == PATH_ISO && !h->drift && !getenv("SSDE_NO_REGROUP")) {
             DevBuf<int64_t> sd;
             DevBuf<int> fl;
@@ -849,12 +881,18 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             HIPCHK(h, hipMemcpy(flh.data(), fl.p, (size_t)M * sizeof(int), hipMemcpyDeviceToHost));
             for (int64_t k = 0; k < M; k++) seg_dirty[k] = flh[k] != 0;
             sd.release(); fl.release();
+            if (!getenv("SSDE_NO_NA_SORT")) seg_napos = flh;    // 1 + the track's last row with a missing observation
         }
         std::vector<int64_t> order(M);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
             if (seg_dirty[a] != seg_dirty[b]) return seg_dirty[a] < seg_dirty[b];
-            return (tstarts[a + 1] - tstarts[a]) > (tstarts[b + 1] - tstarts[b]);
+            const int64_t la = tstarts[a + 1] - tstarts[a], lb = tstarts[b + 1] - tstarts[b];
+            if (la != lb) return la > lb;
+            // tracks of one length with missing rows: neighbours by WHERE they miss them share a wavefront, so that its lanes
+            // leave the stationary regime together (quiet rows of the general kernel, k_iso.hip)
+            if (!seg_napos.empty() && seg_dirty[a]) return seg_napos[a] < seg_napos[b];
+            return false;
         });
         h->n_groups = (int)((M + WAVE - 1) / WAVE);
         const int G = h->n_groups;

@@ -115,7 +115,7 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
     h->par_next = (h->par_next + 1) % PAR_RING;
     // the ring protects the pinned slot of an ASYNCHRONOUS caller's earlier evaluation (ssde_eval_device); a
     // synchronous ssde_eval has read its result back before the next call: no event traffic on that path
-    if (!h->sync_call || h->par_ev_pending[slot]) { HIPCHK(h, hipEventSynchronize(h->par_ev[slot])); h->par_ev_pending[slot] = false; }
+    if (h->use_shared && (!h->sync_call || h->par_ev_pending[slot])) { HIPCHK(h, hipEventSynchronize(h->par_ev[slot])); h->par_ev_pending[slot] = false; }
     double* host = h->gain_pinned + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     double* dev = h->gain_ring.p + (size_t)slot * h->gain_rows_cap * GAIN_ROW;
     const int tmax = h->glen_max;                 // rows 0 .. tmax-1 can be asked for
@@ -153,6 +153,8 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
             stable = same ? stable + 1 : 0;
             if (stable >= 4) break;
         }
+        h->stat_p[0] = C.p11; h->stat_p[1] = C.p12; h->stat_p[2] = C.p22;
+        for (int j = 0; j < NDIRP; j++) { h->stat_p[3 + 3 * j] = C.d11[j]; h->stat_p[4 + 3 * j] = C.d12[j]; h->stat_p[5 + 3 * j] = C.d22[j]; }
     } else {
         ScalCov<15> C;
         C.init(a.p0[0]);
@@ -176,11 +178,22 @@ int build_gain_table(ssde_handle* h, IsoArgs& a, int mask, hipStream_t s, double
             stable = same ? stable + 1 : 0;
             if (stable >= 4) break;
         }
+        for (int i = 0; i < 12; i++) h->stat_p[i] = 0.0;
+        h->stat_p[0] = C.p;
+        for (int j = 0; j < NDIRP; j++) h->stat_p[3 + 3 * j] = C.dp[j];
     }
     const int rows = last + 1;
     h->last_gain_rows = rows;
-    HIPCHK(h, hipMemcpyAsync(dev, host, (size_t)rows * GAIN_ROW * 8, hipMemcpyHostToDevice, s));
-    if (!h->sync_call) { HIPCHK(h, hipEventRecord(h->par_ev[slot], s)); h->par_ev_pending[slot] = true; }
+    // (quiet rows of the general kernel: the covariance after the last row, and what a further row adds to sum log F / sum dF / F)
+    h->gain_stationary = stable >= 4 && last >= 1;
+    if (last >= 1) {
+        h->stat_ld = cum_ld[last] - cum_ld[last - 1];
+        for (int j = 0; j < NDIRP; j++) h->stat_gld[j] = cum_g[j][last] - cum_g[j][last - 1];
+    }
+    if (h->use_shared) {                                    // (otherwise only the stationary constants are wanted)
+        HIPCHK(h, hipMemcpyAsync(dev, host, (size_t)rows * GAIN_ROW * 8, hipMemcpyHostToDevice, s));
+        if (!h->sync_call) { HIPCHK(h, hipEventRecord(h->par_ev[slot], s)); h->par_ev_pending[slot] = true; }
+    }
     a.gain = dev;
     a.gain_last = last;
     for (int k = 0; k < GAIN_ROW; k++) a.gain_stat[k] = host[(size_t)last * GAIN_ROW + k];
@@ -302,6 +315,12 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     a.group_flags = h->group_flags.p;
     a.group_mode = 0;
     double add[4] = {0, 0, 0, 0};
+    if (!h->use_shared && h->quiet_ok) {
+        int st = (h->d == 1) ? build_gain_table<1>(h, a, h->iso_free_mask, s, add) : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
+        if (st) return st;
+        a.gain = nullptr;
+        for (double& v : add) v = 0.0;
+    }
     if (h->use_shared) {
         int st = (h->d == 1) ? build_gain_table<1>(h, a, h->iso_free_mask, s, add)
                              : build_gain_table<2>(h, a, h->iso_free_mask, s, add);
@@ -353,6 +372,17 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         if (t0 >= 2 * WIN_ALIGN && t0 + 2 * a.window < h->glen_max) { a.t0 = t0; a.t0_delta = 0; }
     }
     h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
+    h->last_quiet_window = 0;
+    if (h->quiet_ok && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1) {
+        const int U = iso_block_rows();
+        h->last_quiet_window = h->plan_warmup;
+        a.nan_bits = h->nan_bits.p; a.nan_words = h->nan_words;
+        a.quiet_w = (h->plan_warmup + U - 1) / U;
+        a.quiet_b0 = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U / U + 1;
+        for (int i = 0; i < 12; i++) a.quiet_p[i] = h->stat_p[i];
+        a.quiet_ld = h->stat_ld;
+        for (int j = 0; j < NDIRP; j++) a.quiet_gld[j] = h->stat_gld[j];
+    }
     if (h->use_shared) {
         // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
         // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check

@@ -1,0 +1,176 @@
+"""GPU suite (-m gpu): QUIET ROWS of the general kernel (csrc/k_iso.hip).
+
+A regular-grid batch in which every wavefront holds a few missing rows has no group for the shared-covariance kernel.  The
+general lanes drop their covariance wherever it is stationary on all 64 lanes of the wavefront -- no missing observation in the
+block or in the `quiet_window` rows before it, past the transient of P0 -- and run the mean half with the stationary gains there
+(nllk_ctcrw.hpp:214-241: a row without an observation is a prediction step; every other row sees the same K and F once P has
+forgotten the last such step).  Tracks are dealt to wavefronts by WHERE they miss rows, so that the lanes of a wavefront leave the
+stationary regime together.  Checked against the oracle and against the same engine with SSDE_NO_QUIET=1 (every row on the
+lane's own covariance)."""
+import numpy as np
+import pytest
+
+from oracle_lib import oracle_eval
+from smoothsde_amd import capi
+from smoothsde_amd.capi import na_real
+from smoothsde_amd.synth import simulate
+
+pytestmark = pytest.mark.gpu
+
+
+def _par(model, d, rng):
+    q = capi.n_sde_par(model, d)
+    p = [rng.uniform(-1.5, -0.3)] + list(rng.uniform(-0.3, 0.3, size=d) + (3.0 if model == "OU_SSM" else 0.0))
+    return np.array(p + list(rng.uniform(-0.2, 0.6, size=q - d)))
+
+
+def _close(val, grad, eval_, egrad):
+    assert abs(val - eval_) <= 1e-10 * max(1.0, abs(eval_)), (val, eval_)
+    assert np.max(np.abs(grad - egrad)) <= 1e-8 * np.max(np.abs(egrad)) + 1e-10, (grad, egrad)
+
+
+def _batch(model, M, T, d, seed, n_na=1, col0_only=False, first_rows=False):
+    """every track misses n_na rows (uniform positions; `first_rows`: the track's second row and its last one as well)"""
+    ID, times, obs = simulate(model, M, T, d, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    for k in range(M):
+        rows = list(rng.integers(1, T, size=n_na))
+        if first_rows and k % 7 == 0:
+            rows += [1, T - 1]
+        for r in rows:
+            if col0_only:
+                obs[k * T + r, 0] = na_real()
+            else:
+                obs[k * T + r, :] = np.nan
+    return ID, times, obs
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM", "BM_SSM"])
+@pytest.mark.parametrize("d", [1, 2])
+def test_one_missing_row_per_track_against_the_oracle(model, d, monkeypatch):
+    M, T = 256, 900
+    ID, times, obs = _batch(model, M, T, d, seed=3 + d, first_rows=True)
+    pb = capi.Problem(model, ID, times, obs)
+    rng = np.random.default_rng(5)
+    par = _par(model, d, rng)
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["n_clean_groups"] == 0 and inf["quiet_share"] > 0.3, inf
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    assert inf["quiet_window"] > 0 and inf["window_retries"] == 0, inf
+    v0 = eng.eval(par, order=0)
+    v0 = v0[0] if isinstance(v0, tuple) else v0
+    assert abs(v0 - val) <= 1e-12 * abs(val)
+    eng.close()
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+    monkeypatch.setenv("SSDE_NO_QUIET", "1")
+    e2 = capi.Engine(pb)
+    v2, g2 = e2.eval(par, order=1)
+    assert e2.info()["quiet_window"] == 0
+    e2.close()
+    assert abs(v2 - val) <= 1e-11 * abs(val) and np.max(np.abs(g2 - grad)) <= 1e-9 * max(1.0, np.max(np.abs(grad)))
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_windows_and_one_window_agree(model, monkeypatch):
+    """the same batch as one sequential window per track (SSDE_CHUNKS=1) and with the planned windows: the hand-over check
+    passes (quiet lanes dump the stationary covariance) and the sums agree"""
+    M, T, d = 192, 2400, 2
+    ID, times, obs = _batch(model, M, T, d, seed=11, n_na=2)
+    pb = capi.Problem(model, ID, times, obs)
+    par = _par(model, d, np.random.default_rng(8))
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    assert inf["quiet_window"] > 0 and inf["lanes_per_track"] > 1 and inf["window_retries"] == 0 and inf["window_check"] < 1e-11, inf
+    eng.close()
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    e1 = capi.Engine(pb)
+    v1, g1 = e1.eval(par, order=1)
+    assert e1.info()["lanes_per_track"] == 1
+    e1.close()
+    assert abs(v1 - val) <= 1e-11 * abs(val) and np.max(np.abs(g1 - grad)) <= 1e-9 * max(1.0, np.max(np.abs(grad)))
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+
+
+def test_missing_first_column_only_and_fixed_parameters():
+    """NA_real_ in the first response column only is a missing row (nllk_ctcrw.hpp:214); fixed parameters change the direction
+    mask of the kernel"""
+    M, T, d = 128, 800, 2
+    ID, times, obs = _batch("CTCRW", M, T, d, seed=21, col0_only=True)
+    for fixed in ([], [0], [3], [0, 4]):
+        pf = np.zeros(1 + d + 2, dtype=np.uint8)
+        pf[fixed] = 1
+        pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=pf)
+        par = _par("CTCRW", d, np.random.default_rng(2))
+        eng = capi.Engine(pb)
+        val, grad = eng.eval(par, order=1)
+        assert eng.info()["quiet_window"] > 0
+        eng.close()
+        oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+        _close(val, grad, oval, ograd)
+
+
+def test_mixed_batch_keeps_its_complete_groups_on_the_shared_kernel():
+    """half of the tracks complete (shared-covariance kernel, plan of its own), the others with one missing row each"""
+    M, T, d = 512, 1600, 2
+    ID, times, obs = simulate("CTCRW", M, T, d, seed=4)
+    rng = np.random.default_rng(9)
+    for k in range(0, M, 2):
+        obs[k * T + rng.integers(1, T), :] = np.nan
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    par = _par("CTCRW", d, rng)
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["n_clean_groups"] == 4 and inf["n_groups"] == 8
+    val, grad = eng.eval(par, order=1)
+    assert eng.info()["quiet_window"] > 0 and eng.info()["window_retries"] == 0
+    eng.close()
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+
+
+def test_dense_missing_rows_stay_on_the_lanes_own_covariance():
+    """5 % of the rows missing: no block of a wavefront qualifies, the handle does not carry the flags"""
+    M, T, d = 128, 600, 2
+    ID, times, obs = simulate("CTCRW", M, T, d, seed=6)
+    rng = np.random.default_rng(3)
+    first = np.r_[True, ID[1:] != ID[:-1]]
+    obs[(rng.random(len(ID)) < 0.05) & ~first, :] = np.nan
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    eng = capi.Engine(pb)
+    par = _par("CTCRW", d, rng)
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    assert inf["quiet_share"] < 0.2 and inf["quiet_window"] == 0
+    eng.close()
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+
+
+def test_ragged_tracks_and_parameter_moves(monkeypatch):
+    """ragged lengths (padding rows of the shorter lanes are not missing rows; tracks are dealt by length first, so few blocks
+    qualify: SSDE_QUIET_ALWAYS keeps the flags all the same) and a sequence of parameter vectors on one handle (the memory of
+    the covariance follows the plan's warm-up)"""
+    monkeypatch.setenv("SSDE_QUIET_ALWAYS", "1")
+    rng = np.random.default_rng(17)
+    M, d = 200, 2
+    lens = rng.integers(500, 1000, size=M)
+    ID = np.repeat(np.arange(float(M)), lens)
+    times = np.arange(len(ID), dtype=float)
+    obs = np.cumsum(rng.standard_normal((len(ID), d)), axis=0)
+    starts = np.r_[0, np.cumsum(lens)[:-1]]
+    for k in range(M):
+        obs[starts[k] + rng.integers(1, lens[k]), :] = np.nan
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    eng = capi.Engine(pb)
+    for i in range(4):
+        par = _par("CTCRW", d, rng) + np.r_[0.0, 0.0, 0.0, 0.4 * i, -0.3 * i]
+        val, grad = eng.eval(par, order=1)
+        oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+        _close(val, grad, oval, ograd)
+    assert eng.info()["quiet_window"] > 0
+    eng.close()
