@@ -26,6 +26,7 @@
 // Reference arithmetic: ssde_math.hpp (nllk_ctcrw.hpp:195-247, nllk_ou_ssm.hpp:163-213,
 // nllk_bm_ssm.hpp:127-175).
 #include "ssde_device.hpp"
+#include "ssde_tf.hpp"
 
 namespace ssde {
 
@@ -121,127 +122,86 @@ struct LaneOps {  // OU_SSM / BM_SSM
 
 // ---- quiet rows (regular grid) ---------------------------------------------------------------------------------------
 // A lane whose covariance is at its stationary value needs the mean half of the step only, with the gains and their
-// sensitivities as constants (IsoArgs.statc -- the numbers the shared-covariance kernels use, k_iso_shared.inc).  The engine
-// marks the blocks of QUIET_U rows in which some lane of the group misses an observation (IsoArgs.nan_bits); a block is QUIET
-// when neither it nor the quiet_w blocks before it hold such a row and the transient of P0 is over: the lanes drop their
-// covariance there and take it up again, from the stationary values, at the next marked block.  The accumulators are the
-// general step's (sum u'F^-1 u and its derivatives); the data-independent terms (log F, dF / F) are counted per lane (nq).
+// sensitivities as constants (IsoArgs.statc): the stationary-only lanes of the shared-covariance kernels (ssde_tf.hpp: the
+// transfer-function form for CTCRW, the basis form for OU_SSM / BM_SSM -- 11 and 10 fp64 instructions per row and dimension
+// against ~80 of the general step's mean half).  The engine marks the blocks of QUIET_U rows in which some lane of the group
+// misses an observation (IsoArgs.nan_bits).  After such a block the lanes run the general step for quiet_w + 2 blocks (their
+// covariance forgets the prediction step) with the stationary lanes WARMING UP beside it -- a fixed linear filter of the
+// observations that forgets its start at the same rate --, then the stationary lanes alone score the rows, until the next marked
+// block: there their state goes back to the direction form (their hand-over dump is that conversion), the covariance and its
+// sensitivities restart from the stationary values, and the general step takes over.  A window that starts past the transient
+// of P0 warms up on the stationary lanes alone, like a window of the shared-covariance kernels.  The sums of a quiet stretch are
+// folded into the general accumulators; the data-independent terms (log F, dF / F) are counted per lane (nq).
 template <int MODEL, int D, int MASK>
-struct QuietOps;
+struct QuietOps {   // OU_SSM / BM_SSM
+    typedef ScalLane<D, MASK> State;
+    typedef BasisScal<MODEL, D, MASK> Stat;
+    static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
+    // start beside a running general lane: its state as it stands (the sensitivity bases warm up)
+    __device__ static __forceinline__ void start(Stat& F, const State& S, const double*, int64_t) { F.init(S.M.x); }
+    // start a window: the first observation (what the general lanes' warm_init takes)
+    __device__ static __forceinline__ void start_window(Stat& F, const double* y, const double*, int64_t) {
+        double a0[D];
+        Stat::warm_a0(y, a0);
+        F.init(a0);
+    }
+    // back to the direction form, covariance at its stationary value
+    __device__ static __forceinline__ void leave(const Stat& F, State& S, const IsoArgs& A) {
+        double o[Stat::NSTATE];
+        F.dump(o);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) S.M.x[a] = o[k++];
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+#pragma unroll
+            for (int a = 0; a < D; a++) S.M.tx[j][a] = o[k++];
+            S.C.dp[j] = A.quiet_p[3 + 3 * j];
+        }
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) S.M.mx[a] = o[k++];
+        }
+        S.C.p = A.quiet_p[0];
+    }
+};
 
 template <int D, int MASK>
 struct QuietOps<M_CTCRW, D, MASK> {
     typedef CtcrwLane<D, MASK> State;
-    double k1, k2, c1, t12, e, iF, hd[NDIRP], dk1[NDIRP], dk2[NDIRP], dt12, de, cb1, cb2, cx[D], cv[D], bmu[D];
-    __device__ __forceinline__ void setup(const IsoArgs& A) {
-        const double* c = A.statc;
-        iF = c[0]; k1 = c[1]; k2 = c[2]; c1 = c[3]; t12 = c[4]; e = c[5]; dt12 = c[6]; de = c[7]; cb1 = c[8]; cb2 = c[9];
+    typedef TfCtcrw<D, MASK> Stat;
+    // the transfer-function lanes start from the observation of the row before (a block without a missing row)
+    __device__ static __forceinline__ void start(Stat& F, const State&, const double* obs_prev, int64_t stride) {
+        double yp[D];
 #pragma unroll
-        for (int j = 0; j < NDIRP; j++) { hd[j] = c[10 + j]; dk1[j] = c[13 + j]; dk2[j] = c[16 + j]; }
-#pragma unroll
-        for (int a = 0; a < D; a++) { cx[a] = c[19 + a]; cv[a] = c[21 + a]; bmu[a] = c[23 + a]; }
+        for (int a = 0; a < D; a++) yp[a] = obs_prev[a * stride];
+        F.init(yp);
     }
-    // nllk_ctcrw.hpp:221, 231-234, 238 with K, F^-1 and their derivatives at the stationary covariance
-    __device__ __forceinline__ void step(State& S, const double* y) const {
-        CtcrwMean<D, MASK>& M = S.M;
-        double u[D], su2 = 0.0;
+    __device__ static __forceinline__ void start_window(Stat& F, const double*, const double* obs_prev, int64_t stride) {
+        double yp[D];
 #pragma unroll
-        for (int a = 0; a < D; a++) { u[a] = y[a] - M.x[a]; su2 = fma(u[a], u[a], su2); }
-        M.accq = fma(iF, su2, M.accq);
+        for (int a = 0; a < D; a++) yp[a] = obs_prev[a * stride];
+        F.init(yp);
+    }
+    __device__ static __forceinline__ void leave(const Stat& F, State& S, const IsoArgs& A) {
+        double o[Stat::NSTATE];
+        F.dump(o);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < D; a++) { S.M.x[a] = o[k++]; S.M.v[a] = o[k++]; }
 #pragma unroll
         for (int j = 0; j < NDIRP; j++) {
             if (!(MASK & dir_bit(j))) continue;
-            double sud = 0.0;
 #pragma unroll
-            for (int a = 0; a < D; a++) {
-                const double tx = M.tx[j][a], tv = M.tv[j][a];
-                sud = fma(u[a], tx, sud);
-                double nx = dk1[j] * u[a], nv = dk2[j] * u[a];
-                if (j == 1) {
-                    const double w = M.v[a] - bmu[a];
-                    nx = fma(dt12, w, nx);
-                    nv = fma(de, w, nv);
-                }
-                M.tx[j][a] = fma(c1, tx, fma(t12, tv, nx));
-                M.tv[j][a] = fma(e, tv, fma(-k2, tx, nv));
-            }
-            M.gq[j] = fma(hd[j], su2, fma(-iF, sud, M.gq[j]));
-        }
-        if (MASK & DIR_MU) {
-            const double mx = M.mx[0], mv = M.mv[0], imx = iF * mx;
-            const double nx = fma(c1, mx, fma(t12, mv, cb1)), nv = fma(e, mv, fma(-k2, mx, cb2));
-#pragma unroll
-            for (int a = 0; a < D; a++) { M.gmu[a] = fma(-imx, u[a], M.gmu[a]); M.mx[a] = nx; M.mv[a] = nv; }
-        }
-#pragma unroll
-        for (int a = 0; a < D; a++) {
-            const double x = M.x[a], v = M.v[a];
-            M.x[a] = fma(k1, u[a], fma(t12, v, x)) + cx[a];
-            M.v[a] = fma(k2, u[a], fma(e, v, cv[a]));
-        }
-        S.C.nupd += 1.0;
-    }
-    // the lane's covariance and its sensitivities at their stationary values
-    __device__ static __forceinline__ void stationary(State& S, const IsoArgs& A) {
-        S.C.p11 = A.quiet_p[0]; S.C.p12 = A.quiet_p[1]; S.C.p22 = A.quiet_p[2];
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) {
-            if (!(MASK & dir_bit(j))) continue;
+            for (int a = 0; a < D; a++) { S.M.tx[j][a] = o[k++]; S.M.tv[j][a] = o[k++]; }
             S.C.d11[j] = A.quiet_p[3 + 3 * j]; S.C.d12[j] = A.quiet_p[4 + 3 * j]; S.C.d22[j] = A.quiet_p[5 + 3 * j];
         }
-    }
-};
-
-template <int MODEL, int D, int MASK>
-struct QuietOps {   // OU_SSM / BM_SSM
-    typedef ScalLane<D, MASK> State;
-    static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
-    double k, c, t, b, iF, hd[NDIRP], dk[NDIRP], dt_, cmu[D], dbmu[D];
-    __device__ __forceinline__ void setup(const IsoArgs& A) {
-        const double* cc = A.statc;
-        iF = cc[0]; k = cc[1]; c = cc[2]; t = cc[3]; b = cc[4]; dt_ = cc[5];
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) { hd[j] = cc[10 + j]; dk[j] = cc[13 + j]; }
-#pragma unroll
-        for (int a = 0; a < D; a++) { cmu[a] = cc[19 + a]; dbmu[a] = cc[21 + a]; }
-    }
-    // x' = t x + k u + b mu;  tx' = (t - k) tx + dk u [+ dt_ x + db mu]   (nllk_ou_ssm.hpp:204, nllk_bm_ssm.hpp:166)
-    __device__ __forceinline__ void step(State& S, const double* y) const {
-        ScalMean<D, MASK>& M = S.M;
-        double u[D], su2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < D; a++) { u[a] = y[a] - M.x[a]; su2 = fma(u[a], u[a], su2); }
-        M.accq = fma(iF, su2, M.accq);
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) {
-            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
-            double sud = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; a++) {
-                const double tx = M.tx[j][a];
-                sud = fma(u[a], tx, sud);
-                double nx = dk[j] * u[a];
-                if (j == 1 && HAS_P2) nx = fma(dt_, M.x[a], nx) + dbmu[a];
-                M.tx[j][a] = fma(c, tx, nx);
-            }
-            M.gq[j] = fma(hd[j], su2, fma(-iF, sud, M.gq[j]));
-        }
         if (MASK & DIR_MU) {
-            const double mx = M.mx[0], imx = iF * mx, nx = fma(c, mx, b);
 #pragma unroll
-            for (int a = 0; a < D; a++) { M.gmu[a] = fma(-imx, u[a], M.gmu[a]); M.mx[a] = nx; }
+            for (int a = 0; a < D; a++) { S.M.mx[a] = o[k++]; S.M.mv[a] = o[k++]; }
         }
-#pragma unroll
-        for (int a = 0; a < D; a++) M.x[a] = fma(k, u[a], fma(t, M.x[a], cmu[a]));
-        S.C.nupd += 1.0;
-    }
-    __device__ static __forceinline__ void stationary(State& S, const IsoArgs& A) {
-        S.C.p = A.quiet_p[0];
-#pragma unroll
-        for (int j = 0; j < NDIRP; j++) {
-            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
-            S.C.dp[j] = A.quiet_p[3 + 3 * j];
-        }
+        S.C.p11 = A.quiet_p[0]; S.C.p12 = A.quiet_p[1]; S.C.p22 = A.quiet_p[2];
     }
 };
 
@@ -316,55 +276,82 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         Ops::warm_init(S, &bufA[0][1], A);
     }
 
-    // quiet rows (QUIET): q_last = the latest block with a missing observation (a window that does not start quiet counts its
-    // own start as one: its covariance is a guess there), q_word = the 64 block flags around the current block
-    QOps Q;
-    int q_last = 0, q_wi = -1;
+    // quiet rows (QUIET): q_last = the latest block with a missing observation, q_word = the 64 block flags around the current
+    // block; tf_live: the stationary lanes F are running (since block tf_since), q_mode: they alone score the rows
+    typename QOps::Stat F;
+    int q_last = 0, q_wi = -1, tf_since = 0;
     unsigned long long q_word = 0ull;
-    bool q_mode = false;
+    bool q_mode = false, tf_live = false;
     double nq = 0.0;                         // rows this lane scored in quiet mode
     const unsigned long long* qbits = nullptr;
+    auto load_word = [&](int wi) -> unsigned long long {
+        const unsigned long long w = qbits[wi];
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0xffffffffull));
+    };
     if (QUIET) {
-        Q.setup(A);
+        F.setup(A);
         qbits = A.nan_bits + (int64_t)g * A.nan_words;
         const int b0 = s_begin / U;
-        q_last = -A.quiet_w - 1;
+        q_last = -A.quiet_w - 2;
         if (b0 > 0) {
-            const int lo = max(0, b0 - A.quiet_w);
-            bool any = false;
-            for (int wi = lo >> 6; wi <= (b0 - 1) >> 6; wi++) {
-                const int blo = max(lo, wi * 64) - wi * 64, bhi = min(b0, wi * 64 + 64) - wi * 64;   // bits [blo, bhi) of this word
-                const unsigned long long m = (bhi - blo >= 64) ? ~0ull : (((1ull << (bhi - blo)) - 1ull) << blo);
-                any = any || ((qbits[wi] & m) != 0ull);
+            // the row before the window is in a block without a missing row, and the transient of P0 is over: the stationary
+            // lanes alone from the first row on (the window's warm-up rows are theirs, as in k_iso_shared.inc)
+            const bool prev_nan = (load_word((b0 - 1) >> 6) >> ((b0 - 1) & 63)) & 1ull;
+            if (!prev_nan && b0 >= A.quiet_b0) {
+                QOps::start_window(F, &bufA[0][1], base + ((int64_t)(s_begin - 1) * Cr + c_obs) * WAVE, WAVE);
+                q_mode = tf_live = true;
+                tf_since = b0 - A.quiet_w;
+                q_last = b0 - A.quiet_w - 2;
+            } else {
+                q_last = b0 - 1;             // (the lane's covariance is a guess at the window's start: like a missing row)
             }
-            q_last = any ? b0 - 1 : b0 - A.quiet_w - 1;
         }
     }
-    auto quiet_block = [&](int s0) -> bool {
-        const int b = s0 / U;
-        if ((b >> 6) != q_wi) {
-            q_wi = b >> 6;
-            const unsigned long long w = qbits[q_wi];
-            q_word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
-                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0xffffffffull));
+    // fold the sums of a quiet stretch into the general accumulators (ctcrw_finish_parts / scal_finish_parts add them up)
+    auto fold = [&]() {
+        double fo[NACC];
+        F.finish(fo);
+        S.M.accq += 2.0 * fo[0];
+        if (MASK & DIR_SIG) S.M.gq[0] += fo[1];
+        if (MASK & DIR_MU) {
+#pragma unroll
+            for (int a = 0; a < D; a++) S.M.gmu[a] += fo[2 + a];
         }
-        if ((q_word >> (b & 63)) & 1ull) q_last = b;
-        return (b - q_last > A.quiet_w) && (b >= A.quiet_b0);
+        if (MASK & DIR_P1) S.M.gq[1] += fo[2 + D];
+        if (MASK & DIR_P2) S.M.gq[2] += fo[3 + D];
+        F.reset_acc();
     };
     auto run_block = [&](const double (&blk)[U][C], int s0) {
+        bool both = false;                    // general step with the stationary lanes warming up beside it
         if (QUIET) {
-            const bool q = quiet_block(s0);
-            if (q_mode && !q) QOps::stationary(S, A);     // a missing row ahead: the lane's own covariance again
-            q_mode = q;
-            if (q) {
+            const int b = s0 / U;
+            if ((b >> 6) != q_wi) { q_wi = b >> 6; q_word = load_word(q_wi); }
+            if ((q_word >> (b & 63)) & 1ull) {
+                q_last = b;
+                if (q_mode) { fold(); QOps::leave(F, S, A); }      // a missing row ahead: the lane's own covariance again
+                q_mode = tf_live = false;
+            } else if (!q_mode) {
+                const int age = b - q_last;
+                if (!tf_live && age >= 2 && s0 > 0) {
+                    QOps::start(F, S, base + ((int64_t)(s0 - 1) * Cr + c_obs) * WAVE, WAVE);
+                    tf_live = true; tf_since = b;
+                }
+                if (tf_live && b - tf_since >= A.quiet_w && age >= A.quiet_w + 2 && b >= A.quiet_b0 + A.quiet_w) {
+                    F.reset_acc();
+                    q_mode = true;
+                }
+                both = tf_live && !q_mode;
+            }
+            if (q_mode) {
                 if (s0 + U <= ns_min) {
 #pragma unroll
-                    for (int u = 0; u < U; u++) Q.step(S, &blk[u][1]);
+                    for (int u = 0; u < U; u++) F.step_stat(&blk[u][1]);
                     nq += (double)U;
                 } else {
 #pragma unroll
                     for (int u = 0; u < U; u++)
-                        if (s0 + u < ns) { Q.step(S, &blk[u][1]); nq += 1.0; }
+                        if (s0 + u < ns) { F.step_stat(&blk[u][1]); nq += 1.0; }
                 }
                 return;
             }
@@ -377,12 +364,17 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
             for (int u = 0; u < U; u++)
                 if (s0 + u < ns) Ops::template step<UNI>(S, A, mu, blk[u]);
         }
+        if (QUIET && both) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (s0 + u < ns) F.step_stat(&blk[u][1]);
+        }
     };
     auto handover = [&](int s0) {
         if (s0 == s_acc && s_acc > s_begin) {
             // end of warm-up: publish the state for the hand-over check, start scoring from zero
             double st[Ops::State::NSTATE];
-            if (QUIET && q_mode) QOps::stationary(S, A);
+            if (QUIET && q_mode) { QOps::leave(F, S, A); F.reset_acc(); }
             S.dump(st);
             if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
             double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
@@ -406,7 +398,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
         // state on arrival at the next window's first scored row
         double st[Ops::State::NSTATE];
-        if (QUIET && q_mode) QOps::stationary(S, A);
+        if (QUIET && q_mode) QOps::leave(F, S, A);
         S.dump(st);
         if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
         double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
@@ -414,6 +406,10 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
     }
     double out[NACC];
+    if (QUIET) {
+        if (q_mode) fold();
+        S.C.nupd += nq;
+    }
     Ops::finish(S, out);
     if (QUIET) {                             // the data-independent terms of the rows scored in quiet mode
         const double hn = 0.5 * (double)D * nq;
@@ -465,7 +461,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_I
 // ... the same lanes with quiet rows (regular grid, a.quiet_w > 0): a kernel of its own, so that batches without quiet rows run
 // the code (and the register allocation) they always ran
 template <int MODEL, int D, int MASK>
-__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? SSDE_ISO_WAVES : SSDE_ISO_WAVES_SCAL) void iso_quiet_kernel(const IsoArgs A) {
+// (CTCRW carries the general lane, the transfer-function lane and two 8-row blocks: one wave per SIMD with the whole register
+//  file, like the shared-covariance kernels whose rows most of its rows are; the engine plans half as many windows for it)
+__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? 1 : SSDE_ISO_WAVES_SCAL) void iso_quiet_kernel(const IsoArgs A) {
     iso_mask_body<MODEL, D, MASK, true, true>(A);
 }
 

@@ -130,6 +130,7 @@ struct ssde_handle {
     int last_quiet_window = 0;     // rows of memory the last launch used (0: no quiet rows)
     bool gain_stationary = false;  // the last gain recursion reached its stationary row
     double stat_p[12] = {0}, stat_ld = 0.0, stat_gld[3] = {0, 0, 0};   // ... the covariance, log F and dF / F there
+    double plan_rho = 1.0;         // spectral radius of the closed-loop matrix the last plan_windows call found
     int plan_warmup = 0;           // warm-up rows the last plan_windows call found sufficient (0: no usable forgetting)
     int window_boost = 1;          // multiplies the estimated warm-up after a failed hand-over check
     int last_chunks = 1, last_window = 0;

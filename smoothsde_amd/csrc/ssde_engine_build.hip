@@ -364,8 +364,22 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             n_blocks += nb;
         }
         h->quiet_share = n_blocks > 0 ? (double)n_quiet / (double)n_blocks : 0.0;
-        h->quiet_ok = n_blocks > 0 && (double)n_quiet >= (getenv("SSDE_QUIET_ALWAYS") ? 0.0 : 0.2) * (double)n_blocks;
+        // (CTCRW's kernel with quiet rows runs one wave per SIMD: its general rows cost more than the plain general kernel's, so
+        //  it needs most blocks quiet -- three missing rows per track, share 0.32: 0.87 against 0.84 ms; one, share 0.98: 0.42)
+        const double need = getenv("SSDE_QUIET_ALWAYS") ? 0.0 : h->model == SSDE_MODEL_CTCRW ? 0.5 : 0.2;
+        h->quiet_ok = n_blocks > 0 && (double)n_quiet >= need * (double)n_blocks;
         if (!h->quiet_ok) { h->nan_bits.release(); h->nan_words = 0; }
+        if (h->quiet_ok && !h->chunks_forced) {
+            // most rows cost what a row of the shared-covariance kernels costs: one work item per wave slot -- CTCRW's kernel
+            // with quiet rows runs one wave per SIMD (k_iso.hip), the scalar models' two
+            const int slots = h->model == SSDE_MODEL_CTCRW ? 1024 : 2048;
+            if (h->use_shared && h->want_chunks_d > 0) {
+                const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
+                h->want_chunks_d = std::max(1, std::min(h->want_chunks_d, slots / gd8));
+            } else if (!h->use_shared) {
+                h->want_chunks = std::max(1, std::min(h->want_chunks, slots / ((G + 7) / 8 * 8)));
+            }
+        }
     }
     if (h->use_shared || h->quiet_ok) {
         h->gain_rows_cap = (size_t)glmax + 1;

@@ -69,6 +69,7 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
         }
     }
     int W = 0;
+    h->plan_rho = rho;
     if (!(rho < 0.9995) || !std::isfinite(rho)) return;  // no usable forgetting: sequential filter
     // The stationary CTCRW lanes run the filter as 1/D(q)^2 recursions (k_iso_shared.hip): with closed-loop poles
     // close to 1 their intermediate signals grow like 1/(1-rho)^2 and cancel in the innovation -- below rho = 0.97
@@ -373,7 +374,9 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     }
     h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
     h->last_quiet_window = 0;
-    if (h->quiet_ok && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1) {
+    // (CTCRW: the transfer-function lanes lose digits when the closed-loop poles approach 1 -- the limit plan_windows has for them)
+    if (h->quiet_ok && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1 &&
+        !(h->model == SSDE_MODEL_CTCRW && h->plan_rho > 0.97)) {
         const int U = iso_block_rows();
         h->last_quiet_window = h->plan_warmup;
         a.nan_bits = h->nan_bits.p; a.nan_words = h->nan_words;

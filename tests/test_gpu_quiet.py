@@ -18,6 +18,13 @@ from smoothsde_amd.synth import simulate
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _flags_whatever_the_share(monkeypatch):
+    """the batches here are small (a few wavefronts, whose missing rows spread over much of the track): keep the block flags
+    whatever share of the blocks qualifies; the tests of the decision itself remove the variable"""
+    monkeypatch.setenv("SSDE_QUIET_ALWAYS", "1")
+
+
 def _par(model, d, rng):
     q = capi.n_sde_par(model, d)
     p = [rng.uniform(-1.5, -0.3)] + list(rng.uniform(-0.3, 0.3, size=d) + (3.0 if model == "OU_SSM" else 0.0))
@@ -133,8 +140,30 @@ def test_mixed_batch_keeps_its_complete_groups_on_the_shared_kernel():
     _close(val, grad, oval, ograd)
 
 
-def test_dense_missing_rows_stay_on_the_lanes_own_covariance():
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_the_share_of_quiet_blocks_decides(model, monkeypatch):
+    """one missing row per track of 2000 rows, four wavefronts: two thirds of the blocks qualify -- quiet rows for every model;
+    three per track: few do -- CTCRW's kernel with quiet rows (one wave per SIMD) wants half of them, the scalar models' (two
+    waves per SIMD either way) a fifth"""
+    monkeypatch.delenv("SSDE_QUIET_ALWAYS")
+    rng = np.random.default_rng(4)
+    for n_na in (1, 3):
+        ID, times, obs = _batch(model, 256, 2000, 2, seed=31, n_na=n_na)
+        pb = capi.Problem(model, ID, times, obs)
+        par = _par(model, 2, rng)
+        eng = capi.Engine(pb)
+        val, grad = eng.eval(par, order=1)
+        inf = eng.info()
+        eng.close()
+        want = inf["quiet_share"] >= (0.5 if model == "CTCRW" else 0.2)
+        assert (inf["quiet_window"] > 0) == want and (want or n_na == 3), (n_na, inf["quiet_share"], inf["quiet_window"])
+        oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+        _close(val, grad, oval, ograd)
+
+
+def test_dense_missing_rows_stay_on_the_lanes_own_covariance(monkeypatch):
     """5 % of the rows missing: no block of a wavefront qualifies, the handle does not carry the flags"""
+    monkeypatch.delenv("SSDE_QUIET_ALWAYS")
     M, T, d = 128, 600, 2
     ID, times, obs = simulate("CTCRW", M, T, d, seed=6)
     rng = np.random.default_rng(3)
@@ -151,11 +180,9 @@ def test_dense_missing_rows_stay_on_the_lanes_own_covariance():
     _close(val, grad, oval, ograd)
 
 
-def test_ragged_tracks_and_parameter_moves(monkeypatch):
+def test_ragged_tracks_and_parameter_moves():
     """ragged lengths (padding rows of the shorter lanes are not missing rows; tracks are dealt by length first, so few blocks
-    qualify: SSDE_QUIET_ALWAYS keeps the flags all the same) and a sequence of parameter vectors on one handle (the memory of
-    the covariance follows the plan's warm-up)"""
-    monkeypatch.setenv("SSDE_QUIET_ALWAYS", "1")
+    qualify) and a sequence of parameter vectors on one handle (the memory of the covariance follows the plan's warm-up)"""
     rng = np.random.default_rng(17)
     M, d = 200, 2
     lens = rng.integers(500, 1000, size=M)
