@@ -54,6 +54,15 @@ bash tools/pmc_kernel.sh "iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_colvar" -d "$OUT/pmc_colvar_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > "$OUT/pmc_colvar_fetch.log" 2>&1 ) || true
 cp gpurun_out/pmc_${TAG}_colvar.txt "$OUT/" 2>/dev/null || true
 echo "[collect] colvar kernel done"
+# round 3, last part: one missing row in every track -- quiet rows of the general kernel, against SSDE_NO_QUIET=1
+python3 tools/bench_na.py --per-track 1 CTCRW OU_SSM BM_SSM > "$OUT/quiet.txt" 2> "$OUT/quiet.err"
+SSDE_NO_QUIET=1 python3 tools/bench_na.py --per-track 1 CTCRW OU_SSM BM_SSM >> "$OUT/quiet.txt" 2>> "$OUT/quiet.err"
+python3 tools/bench_na.py --per-track 2 CTCRW >> "$OUT/quiet.txt" 2>> "$OUT/quiet.err"
+python3 tools/bench_na.py CTCRW >> "$OUT/quiet.txt" 2>> "$OUT/quiet.err"
+bash tools/pmc_kernel.sh "iso_quiet" ${TAG}_quiet -- python3 $ROOT/tools/bench_na.py --per-track 1 CTCRW > /dev/null 2>&1 || true
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_quiet" -d "$OUT/pmc_quiet_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_na.py --per-track 1 CTCRW > "$OUT/pmc_quiet_fetch.log" 2>&1 ) || true
+cp gpurun_out/pmc_${TAG}_quiet.txt "$OUT/" 2>/dev/null || true
+echo "[collect] quiet rows done"
 echo "[collect] SQ counters done"
 find "$OUT" -name "*.csv" -size +8M -delete
 du -sh "$OUT"

@@ -87,7 +87,7 @@ try:   # FETCH_SIZE of the drift kernel (same x2 calibration)
 except Exception as e:  # noqa: BLE001
     print("no drift PMC:", e)
 # round 3, second half: the row-varying tau / nu kernel (k_iso_colvar.hip)
-for name in ("colvar.txt", f"pmc_{tag}_colvar.txt", f"pmc_{tag}_isofull.txt"):
+for name in ("colvar.txt", f"pmc_{tag}_colvar.txt", f"pmc_{tag}_isofull.txt", "quiet.txt", f"pmc_{tag}_quiet.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
@@ -107,4 +107,14 @@ try:
                      f"plus the warm-up rows of the time windows)\n")
 except Exception as e:  # noqa: BLE001
     print("no colvar profile:", e)
+try:
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_quiet_fetch", "fetch_counter_collection.csv")))
+            if "iso_quiet" in r["Kernel_Name"]]
+    if vals:
+        with open(pre + "pmc_quiet_fetch.txt", "w") as fh:
+            fh.write(f"iso_quiet_kernel: {len(vals)} dispatches, FETCH_SIZE avg {sum(vals) / len(vals):.1f} KiB -> {2 * 1024 * sum(vals) / len(vals) / 1e9:.3f} GB per launch "
+                     f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_na.py --per-track 1 CTCRW (1e4 x 1e4 rows, 16 B/row required = 1.6 GB, "
+                     f"plus the warm-up rows of the time windows)\n")
+except Exception as e:  # noqa: BLE001
+    print("no quiet-rows PMC:", e)
 print("wrote", pre + "*", "and profiles/pmc_latest.json; main kernel", main, f"{main_bytes / 1e9:.3f} GB per launch")
