@@ -332,7 +332,8 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
             "required_bytes_per_row": inf["required_bytes_per_row"],
             "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "window_check_max": chk, "window_retries": inf["window_retries"],
-            "rows_tiled": inf["n_rows_tiled"], "groups": inf["n_groups"], "clean_groups": inf["n_clean_groups"]}
+            "rows_tiled": inf["n_rows_tiled"], "groups": inf["n_groups"], "clean_groups": inf["n_clean_groups"],
+            "quiet_window": inf["quiet_window"], "quiet_share": inf["quiet_share"]}
 
 
 def row_varying_workload(M, T, dev, steps, k_cols=9):
@@ -702,6 +703,13 @@ def main():
                 obs[na] = float("nan")
                 return ID, times, obs
 
+            def missing_one(ID, times, obs):           # every track misses ONE row (quiet rows of the general kernel)
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(8)
+                rows = torch.randint(1, T, (M,), device=dev, generator=gen) + T * torch.arange(M, device=dev)
+                obs[rows] = float("nan")
+                return ID, times, obs
+
             def absent(ID, times, obs):                # the same schedule, but the missing fixes are simply not in the data
                 gen = torch.Generator(device=dev)
                 gen.manual_seed(9)
@@ -713,6 +721,8 @@ def main():
                                           dev, max(3, args.steps // 2), irregular))
             sec.append(secondary_workload(f"{M} CTCRW x {T}, regular grid, 5 % missing rows", "CTCRW", M, T, dev,
                                           max(3, args.steps // 2), missing))
+            sec.append(secondary_workload(f"{M} CTCRW x {T}, regular grid, one missing row in every track", "CTCRW", M, T, dev,
+                                          max(3, args.steps // 2), missing_one))
             sec.append(secondary_workload(f"{M} CTCRW x {T} slots of a regular schedule, 5 % of the fixes absent from the data "
                                           f"(intervals of 1-4 steps; laid out on the lattice at create)", "CTCRW", M, T, dev,
                                           max(3, args.steps // 2), absent))

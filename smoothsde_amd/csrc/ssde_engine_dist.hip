@@ -58,7 +58,7 @@ struct PartArrays {
     std::vector<int32_t> ncol_fe, ncol_re;
     std::vector<const double*> fe_ptr, re_ptr;
     std::vector<const ssde_ppbasis*> pp_ptr;
-    std::vector<double> p0, obs_host, t_decay_host;
+    std::vector<double> p0, obs_host, t_decay_host, h_block;
     DevBuf<double> obs_dev, t_decay_dev;
     DevBuf<int> poison_dev;
 };
@@ -95,9 +95,22 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     if (P > 1) {
         if (is_eseal(d->model)) return fail(parent, SSDE_ERR_MODEL, "ESEAL_SSM takes one response variable");
         if (d->model == SSDE_MODEL_BM_T) return fail(parent, SSDE_ERR_MODEL, "BM_t takes one response variable");
-        if (is_kalman(d->model) && d->h_array)
-            return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: a per-row measurement covariance may couple the dimensions, "
-                                                "which this engine evaluates in pairs (n_dim <= 2 takes H_array)");
+        if (is_kalman(d->model) && d->h_array) {
+            // a per-row measurement covariance that is block-diagonal in the column pairs (independent axis errors, one error
+            // ellipse per pair) keeps F block-diagonal: log det F and u' F^-1 u stay sums over the pairs, and every part gets
+            // its own block of every row.  Anything else couples the parts.
+            if (on_dev)
+                return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with a device-resident H_array: the per-pair blocks are cut on the host "
+                                                    "(pass host arrays, or n_dim <= 2)");
+            for (int64_t r = 0; r < d->n; r++) {
+                const double* Hr = d->h_array + (size_t)r * D * D;
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++)
+                        if (i / 2 != j / 2 && Hr[i + (size_t)j * D] != 0.0)       // (a NaN entry counts as coupling)
+                            return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: H_array[,, i] must not couple response columns of "
+                                                                "different pairs (2k, 2k+1), which this engine evaluates side by side");
+            }
+        }
         if (is_kalman(d->model) && d->p0)
             for (int i = 0; i < sdim; i++)
                 for (int j = 0; j < sdim; j++)
@@ -260,6 +273,14 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                     for (int i = 0; i < sc; i++)
                         for (int j = 0; j < sc; j++) B.p0[i + (size_t)j * sc] = d->p0[(s0c + i) + (size_t)(s0c + j) * sdim];
                     cd.p0 = B.p0.data();
+                }
+                if (is_kalman(d->model) && sd.h_array) {                           // the part's cnt x cnt block of every row
+                    B.h_block.resize((size_t)cnt * cnt * ns);
+                    for (int64_t r = 0; r < ns; r++)
+                        for (int jj = 0; jj < cnt; jj++)
+                            for (int ii = 0; ii < cnt; ii++)
+                                B.h_block[(size_t)r * cnt * cnt + ii + (size_t)jj * cnt] = sd.h_array[(size_t)r * D * D + (dlo + ii) + (size_t)(dlo + jj) * D];
+                    cd.h_array = B.h_block.data();
                 }
                 HIPCHK(parent, hipSetDevice(sd.device));
                 if (d->n_decay > 0 && sd.t_decay) {                               // [q x n] -> the part's [qc x n]

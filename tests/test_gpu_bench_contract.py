@@ -43,9 +43,10 @@ def test_bench_line_has_what_the_driver_reads():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
-    assert len(d["secondary"]) == 5 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
-    assert "H_array" in d["secondary"][4]["workload"] and d["secondary"][4]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
-    assert "tau and nu smooth" in d["secondary"][3]["workload"] and d["secondary"][3]["path"] == "isotropic-register"   # the lane = track kernel
+    assert len(d["secondary"]) == 6 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
+    assert "H_array" in d["secondary"][5]["workload"] and d["secondary"][5]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
+    assert "tau and nu smooth" in d["secondary"][4]["workload"] and d["secondary"][4]["path"] == "isotropic-register"   # the lane = track kernel
+    assert "one missing row" in d["secondary"][2]["workload"] and d["secondary"][2]["quiet_window"] > 0             # quiet rows of the general kernel
 
 
 def test_one_rank_communicator_rehearsal_prints_one_line_too():

@@ -108,9 +108,32 @@ def test_what_couples_the_pairs_is_refused_with_a_reason():
     P0 = np.eye(6); P0[0, 4] = P0[4, 0] = 0.1
     with pytest.raises(capi.EngineError, match="P0 must not couple"):
         capi.Engine(problem_from_spec(dict(spec, P0=P0)))
-    spec = make_spec("wide_bad", "OU_SSM", 3, seed=5, lengths=[20, 20], with_H=True)
-    with pytest.raises(capi.EngineError, match="H_array"):
+    spec = make_spec("wide_bad", "OU_SSM", 3, seed=5, lengths=[20, 20], with_H=True)        # full 3 x 3 matrices: column 2 coupled with 0, 1
+    with pytest.raises(capi.EngineError, match="H_array.*must not couple"):
         capi.Engine(problem_from_spec(spec))
+
+
+@pytest.mark.parametrize("model,d", [("CTCRW", 3), ("CTCRW", 4), ("OU_SSM", 4), ("BM_SSM", 5)])
+def test_wide_response_with_a_block_diagonal_H_array(model, d):
+    """per-row measurement covariances that couple the columns of a pair only (an error ellipse per pair, independent axis
+    errors): F stays block-diagonal (nllk_ctcrw.hpp:223-234 with logdet, :20-22), every column pair runs with its block of
+    every row; value, gradient and filtered states against the oracle, which takes the d x d matrices as they are"""
+    spec = make_spec("wide_h", model, d, seed=17, lengths=[40, 23, 57], with_H=True)
+    H = np.array(spec["H"], dtype=float)                                                   # (d, d, n)
+    for i in range(d):
+        for j in range(d):
+            if i // 2 != j // 2:
+                H[i, j, :] = 0.0
+    spec["H"] = H
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(spec["par"], order=1)
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    _close(val, grad, oval, ograd)
+    aest = eng.report(spec["par"])
+    _, _, oaest = oracle_eval(pb, spec["par"], order=1, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
+    eng.close()
 
 
 @pytest.mark.parametrize("model,d", [("CTCRW", 3), ("OU", 4), ("OU_SSM", 5)])
