@@ -201,3 +201,53 @@ def test_ragged_tracks_and_parameter_moves():
         _close(val, grad, oval, ograd)
     assert eng.info()["quiet_window"] > 0
     eng.close()
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_a_schedule_with_one_fix_absent_per_track(model):
+    """the missing fixes are simply not in the data (an interval of two steps): laid out on the lattice at create, the absent
+    fix becomes a row without an observation -- and everything W rows past it a quiet row"""
+    rng = np.random.default_rng(23)
+    M, T, d = 128, 900, 2
+    ID, times, obs = simulate(model, M, T, d, seed=13)
+    keep = np.ones(len(ID), dtype=bool)
+    for k in range(M):
+        keep[k * T + rng.integers(2, T - 2)] = False
+    ID, times, obs = ID[keep], times[keep], obs[keep]
+    pb = capi.Problem(model, ID, times, obs)
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["uniform_dt"] == 1 and inf["n_rows_tiled"] == M * T and inf["quiet_share"] > 0.2, inf
+    par = _par(model, d, rng)
+    val, grad = eng.eval(par, order=1)
+    assert eng.info()["quiet_window"] > 0
+    aest = eng.report(par)
+    eng.close()
+    oval, ograd, oaest = oracle_eval(pb, par, order=1, threads=8, report=True)
+    _close(val, grad, oval, ograd)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
+
+
+def test_asynchronous_evaluations_and_a_one_rank_communicator():
+    """ssde_eval_device on a caller's stream (no gain table is uploaded for a handle without complete wavefronts: nothing of
+    the previous evaluation is in flight when the next one plans), then the same handle behind a rank communicator"""
+    import torch
+    M, T, d = 192, 1000, 2
+    ID, times, obs = _batch("CTCRW", M, T, d, seed=41)
+    pb = capi.Problem("CTCRW", ID, times, obs)
+    eng = capi.Engine(pb)
+    rng = np.random.default_rng(6)
+    pars = [_par("CTCRW", d, rng) for _ in range(4)]
+    outs = [torch.zeros(2 + pb.n_par_full, dtype=torch.float64, device="cuda:0") for _ in pars]
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for p, o in zip(pars, outs):
+            eng.eval_device(p, o.data_ptr(), order=1, stream=st.cuda_stream)
+    st.synchronize()
+    assert eng.info()["quiet_window"] > 0
+    for p, o in zip(pars, outs):
+        v, g = eng.eval(p, order=1)
+        pen = eng.penalty(p)[0]
+        assert abs(o[0].item() + pen - v) <= 1e-12 * abs(v) and np.max(np.abs(o[1:-1].cpu().numpy() - g)) <= 1e-10 * max(1.0, np.max(np.abs(g)))
+        assert o[-1].item() < 1e-11
+    eng.close()
