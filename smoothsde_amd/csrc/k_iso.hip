@@ -44,8 +44,11 @@ constexpr int ISO_U = SSDE_ISO_U;
 #endif
 static_assert(ISO_U % TILE_U == 0 && WIN_ALIGN % (2 * ISO_U) == 0 && 3 * ISO_U <= TILE_SPARE, "prefetch block");
 // ... of the kernels with quiet rows (below): those rows cost a third of a general row, so the loads lead by twice as many
-constexpr int QUIET_U = 8;
-static_assert(QUIET_U % TILE_U == 0 && WIN_ALIGN % (2 * QUIET_U) == 0 && 3 * QUIET_U <= TILE_SPARE, "prefetch block");
+// (CTCRW's kernel with quiet rows, one wave per SIMD, sits 48 % of its cycles on s_waitcnt with 8-row blocks; 16-row blocks were
+//  tried for it -- the two blocks no longer stay in registers and the kernel takes 5.6 ms instead of 0.42: not kept)
+template <int MODEL>
+__host__ __device__ constexpr int quiet_u() { return 8; }
+static_assert(16 % TILE_U == 0 && WIN_ALIGN % 16 == 0 && 3 * 16 <= TILE_SPARE, "prefetch block");
 
 // register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
 template <int C, int U>
@@ -124,7 +127,7 @@ struct LaneOps {  // OU_SSM / BM_SSM
 // A lane whose covariance is at its stationary value needs the mean half of the step only, with the gains and their
 // sensitivities as constants (IsoArgs.statc): the stationary-only lanes of the shared-covariance kernels (ssde_tf.hpp: the
 // transfer-function form for CTCRW, the basis form for OU_SSM / BM_SSM -- 11 and 10 fp64 instructions per row and dimension
-// against ~80 of the general step's mean half).  The engine marks the blocks of QUIET_U rows in which some lane of the group
+// against ~80 of the general step's mean half).  The engine marks the blocks of 8 rows in which some lane of the group
 // misses an observation (IsoArgs.nan_bits).  After such a block the lanes run the general step for quiet_w + 2 blocks (their
 // covariance forgets the prediction step) with the stationary lanes WARMING UP beside it -- a fixed linear filter of the
 // observations that forgets its start at the same rate --, then the stationary lanes alone score the rows, until the next marked
@@ -132,6 +135,18 @@ struct LaneOps {  // OU_SSM / BM_SSM
 // sensitivities restart from the stationary values, and the general step takes over.  A window that starts past the transient
 // of P0 warms up on the stationary lanes alone, like a window of the shared-covariance kernels.  The sums of a quiet stretch are
 // folded into the general accumulators; the data-independent terms (log F, dF / F) are counted per lane (nq).
+// (error over the wave) / (scale over the wave) of one component, as in window_check_block
+__device__ __forceinline__ double pair_ratio(double a, double b, bool valid) {
+    double err = valid ? fabs(a - b) : 0.0, sc = valid ? fmax(fabs(a), fabs(b)) : 0.0;
+    if (valid && !(err == err)) err = INFINITY;
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) {
+        err = fmax(err, __shfl_xor(err, of, 64));
+        sc = fmax(sc, __shfl_xor(sc, of, 64));
+    }
+    return err > 0.0 ? err / sc : 0.0;
+}
+
 template <int MODEL, int D, int MASK>
 struct QuietOps {   // OU_SSM / BM_SSM
     typedef ScalLane<D, MASK> State;
@@ -164,6 +179,22 @@ struct QuietOps {   // OU_SSM / BM_SSM
             for (int a = 0; a < D; a++) S.M.mx[a] = o[k++];
         }
         S.C.p = A.quiet_p[0];
+    }
+    // What the switch to quiet rows assumes, checked where it happens: the lane's covariance and its sensitivities are back at
+    // the stationary values, and the state the stationary lanes warmed up to is the general lane's.  (The sensitivities of the
+    // state forget at the same rate as the state and are what every window that starts on the stationary lanes hands over.)
+    __device__ static __forceinline__ double switch_check(const Stat& F, const State& S, const IsoArgs& A, bool valid) {
+        double o[Stat::NSTATE];
+        F.dump(o);
+        double w = pair_ratio(A.quiet_p[0], S.C.p, valid);
+#pragma unroll
+        for (int a = 0; a < D; a++) w = fmax(w, pair_ratio(o[a], S.M.x[a], valid));
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j)) || (j == 2 && !HAS_P2)) continue;
+            w = fmax(w, pair_ratio(A.quiet_p[3 + 3 * j], S.C.dp[j], valid));
+        }
+        return w;
     }
 };
 
@@ -203,6 +234,20 @@ struct QuietOps<M_CTCRW, D, MASK> {
         }
         S.C.p11 = A.quiet_p[0]; S.C.p12 = A.quiet_p[1]; S.C.p22 = A.quiet_p[2];
     }
+    __device__ static __forceinline__ double switch_check(const Stat& F, const State& S, const IsoArgs& A, bool valid) {
+        double o[Stat::NSTATE];
+        F.dump(o);
+        double w = fmax(pair_ratio(A.quiet_p[0], S.C.p11, valid), fmax(pair_ratio(A.quiet_p[1], S.C.p12, valid), pair_ratio(A.quiet_p[2], S.C.p22, valid)));
+#pragma unroll
+        for (int a = 0; a < D; a++) w = fmax(w, fmax(pair_ratio(o[2 * a], S.M.x[a], valid), pair_ratio(o[2 * a + 1], S.M.v[a], valid)));
+#pragma unroll
+        for (int j = 0; j < NDIRP; j++) {
+            if (!(MASK & dir_bit(j))) continue;
+            w = fmax(w, fmax(pair_ratio(A.quiet_p[3 + 3 * j], S.C.d11[j], valid),
+                             fmax(pair_ratio(A.quiet_p[4 + 3 * j], S.C.d12[j], valid), pair_ratio(A.quiet_p[5 + 3 * j], S.C.d22[j], valid))));
+        }
+        return w;
+    }
 };
 
 // DER >= 0: the covariance direction DER (1 = par[d] for BM_SSM, 2 = par[d+1] for CTCRW / OU_SSM) is NOT carried
@@ -239,7 +284,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     typedef LaneOps<MODEL, D, MASK> Ops;
     typedef QuietOps<MODEL, D, MASK> QOps;
     constexpr int C = 1 + D;
-    constexpr int U = QUIET ? QUIET_U : ISO_U;     // rows per prefetch block
+    constexpr int U = QUIET ? quiet_u<MODEL>() : ISO_U;     // rows per prefetch block
     constexpr int NACC = 4 + D;
     constexpr int SD = Ops::SD;
     const int lane = threadIdx.x & 63;
@@ -283,6 +328,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     unsigned long long q_word = 0ull;
     bool q_mode = false, tf_live = false;
     double nq = 0.0;                         // rows this lane scored in quiet mode
+    double q_worst = 0.0;                    // largest disagreement found at a switch to quiet rows (wave-uniform)
     const unsigned long long* qbits = nullptr;
     auto load_word = [&](int wi) -> unsigned long long {
         const unsigned long long w = qbits[wi];
@@ -338,6 +384,11 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
                     tf_live = true; tf_since = b;
                 }
                 if (tf_live && b - tf_since >= A.quiet_w && age >= A.quiet_w + 2 && b >= A.quiet_b0 + A.quiet_w) {
+                    // VERIFIED like a window hand-over: the lane's covariance and its sensitivities against the stationary ones,
+                    // the state the stationary lanes warmed up to against the general lane's, component by component over the wave
+                    // (error and scale as in window_check_block); the evaluation reports the largest ratio with the hand-over
+                    // checks' and is repeated with a longer memory when it exceeds their threshold
+                    q_worst = fmax(q_worst, QOps::switch_check(F, S, A, s0 < ns));
                     F.reset_acc();
                     q_mode = true;
                 }
@@ -409,6 +460,9 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     if (QUIET) {
         if (q_mode) fold();
         S.C.nupd += nq;
+        // (iso_finalize_kernel folds the word into the evaluation's check value and clears it for the next launch)
+        if (lane == 0 && q_worst > 0.0 && A.quiet_flag)
+            atomicMax((unsigned long long*)A.quiet_flag, (unsigned long long)__double_as_longlong(q_worst == q_worst ? q_worst : INFINITY));
     }
     Ops::finish(S, out);
     if (QUIET) {                             // the data-independent terms of the rows scored in quiet mode
@@ -631,7 +685,13 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
             dep = atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
         publish_if_last(R, dep);
     } else {
-        publish_if_last(R, reduce_slot(R, blockIdx.x - n_check, sh));
+        unsigned long long dep = 0ull;
+        if ((int)blockIdx.x == n_check && threadIdx.x == 0 && A.quiet_flag) {
+            // what the switches to quiet rows found (k_iso.hip: run_lane), into the evaluation's check value
+            const unsigned long long v = atomicExch((unsigned long long*)A.quiet_flag, 0ull);
+            if (v) dep = atomicMax((unsigned long long*)A.chk_out, v);
+        }
+        publish_if_last(R, reduce_slot(R, blockIdx.x - n_check, sh) + (dep & 0ull));
     }
 }
 
@@ -644,20 +704,20 @@ hipError_t launch_iso_finalize(int model, int d, const IsoArgs& a, const ReduceA
     return hipGetLastError();
 }
 
-// ---- which blocks of QUIET_U rows hold a missing observation (ssde_create, once; IsoArgs.nan_bits) ------------------------
+// ---- which blocks of 8 rows hold a missing observation (ssde_create, once; IsoArgs.nan_bits) ------------------------
 // One wave per (group, 64 blocks): lane = track, bit b of the word = some lane's row in block b is not a number in some
 // response column (rows past a lane's last step are padding and do not count).
-__global__ __launch_bounds__(WAVE) void nan_blocks_kernel(const TileView tv, int d, unsigned long long* bits, int nwords) {
+__global__ __launch_bounds__(WAVE) void nan_blocks_kernel(const TileView tv, int d, int U, unsigned long long* bits, int nwords) {
     const int g = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
     const int ns = tv.lane_nsteps[g * WAVE + lane];
     const int L = tv.group_len[g];
     const double* base = tv.tiles + tv.group_off[g] + lane;
     unsigned long long word = 0ull;
     for (int bb = 0; bb < 64; bb++) {
-        const int s0 = (w * 64 + bb) * QUIET_U;
+        const int s0 = (w * 64 + bb) * U;
         if (s0 >= L) break;                                   // (workgroup-uniform)
         bool bad = false;
-        for (int u = 0; u < QUIET_U; u++) {
+        for (int u = 0; u < U; u++) {
             const int s = s0 + u;
             if (s < ns && s < L)
                 for (int a = 0; a < d; a++) { const double v = base[((int64_t)s * tv.C + tv.c_obs + a) * WAVE]; bad = bad || (v != v); }
@@ -666,10 +726,10 @@ __global__ __launch_bounds__(WAVE) void nan_blocks_kernel(const TileView tv, int
     }
     if (lane == 0) bits[(int64_t)g * nwords + w] = word;
 }
-int iso_block_rows() { return QUIET_U; }
-hipError_t launch_nan_blocks(const TileView& tv, int d, unsigned long long* bits, int nwords, hipStream_t s) {
+int iso_block_rows(int model) { return model == M_CTCRW ? quiet_u<M_CTCRW>() : quiet_u<M_OU_SSM>(); }
+hipError_t launch_nan_blocks(const TileView& tv, int d, int block_rows, unsigned long long* bits, int nwords, hipStream_t s) {
     if (tv.n_groups == 0 || nwords == 0) return hipSuccess;
-    hipLaunchKernelGGL(nan_blocks_kernel, dim3(tv.n_groups, nwords), dim3(WAVE), 0, s, tv, d, bits, nwords);
+    hipLaunchKernelGGL(nan_blocks_kernel, dim3(tv.n_groups, nwords), dim3(WAVE), 0, s, tv, d, block_rows, bits, nwords);
     return hipGetLastError();
 }
 

@@ -139,6 +139,8 @@ struct IsoArgs {
     int quiet_w;                 // blocks a lane's covariance takes to forget a missing row (0: no quiet rows in this launch)
     int quiet_b0;                // first block past the covariance transient of the initial P0
     double quiet_p[3 + 3 * 3];   // stationary P (CTCRW: p11, p12, p22; OU / BM: p) | its sensitivities, direction-major
+    double* quiet_flag;          // one word: the largest disagreement the switches to quiet rows found (raised by the main kernel, folded into
+                                 // out[n_out] and cleared by the finalize launch), or NULL
     double quiet_ld;             // log F at the stationary covariance
     double quiet_gld[3];         // ... dF / F per covariance direction
 };
@@ -176,8 +178,8 @@ __host__ __device__ constexpr inline int shared_nstate(int sd, int mask, bool ha
 }
 hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStream_t s);
 // blocks of iso_block_rows() rows in which some lane of a group misses an observation: bits [n_groups][nwords] (k_iso.hip)
-int iso_block_rows();
-hipError_t launch_nan_blocks(const TileView& tv, int d, unsigned long long* bits, int nwords, hipStream_t s);
+int iso_block_rows(int model);
+hipError_t launch_nan_blocks(const TileView& tv, int d, int block_rows, unsigned long long* bits, int nwords, hipStream_t s);
 // ev0 / ev1 (may be NULL): stamped with the kernel's own begin / end
 hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // shared-covariance lanes with a streamed row-varying drift (k_iso_drift.hip); partials [n_chunks][4 + d + drift_k][n_groups]

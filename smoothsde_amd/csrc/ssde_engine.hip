@@ -50,7 +50,7 @@ void release_device(ssde_handle* h) {
                 h->trace_us[0] / h->trace_n, h->trace_us[1] / h->trace_n, h->trace_us[2] / h->trace_n, h->trace_us[3] / h->trace_n,
                 h->trace_us[4] / h->trace_n);
     destroy_dist(h);
-    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release(); h->dirty_groups.release(); h->lap_out.release(); h->nan_bits.release();
+    h->bnd.release(); h->chk.release(); h->group_flags.release(); h->gain_ring.release(); h->pad_pos.release(); h->dirty_groups.release(); h->lap_out.release(); h->nan_bits.release(); h->quiet_flag.release();
     if (h->gain_pinned) (void)hipHostFree(h->gain_pinned);
     for (int i = 0; i < 2; i++) { if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

@@ -124,8 +124,10 @@ struct ssde_handle {
     bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
     // quiet rows of the general kernel (k_iso.hip): blocks that hold a missing observation, per group; 0 words = not in use
     DevBuf<unsigned long long> nan_bits;
+    DevBuf<double> quiet_flag;
     int nan_words = 0;
     bool quiet_ok = false;
+    int env_quiet_window = 0;      // SSDE_QUIET_WINDOW (testing)
     double quiet_share = 0.0;      // share of the dirty groups' blocks that qualify (nominal 128-row memory)
     int last_quiet_window = 0;     // rows of memory the last launch used (0: no quiet rows)
     bool gain_stationary = false;  // the last gain recursion reached its stationary row

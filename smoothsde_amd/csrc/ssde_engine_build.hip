@@ -340,14 +340,14 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     // kernel, or some) -- the general lanes drop their covariance wherever it is stationary on all 64 lanes (k_iso.hip).  Worth it
     // when a fair share of the blocks qualifies (with missing rows in every block of every group the flags cost a little and win nothing).
     if (h->uniform_dt && !h->drift && h->iso_parts == 1 && h->n_clean_groups < G && glmax >= 8 * WIN_ALIGN && !getenv("SSDE_NO_QUIET")) {
-        const int U = iso_block_rows();
+        const int U = iso_block_rows(h->model);
         h->nan_words = (glmax / U + 63) / 64 + 1;
         HIPCHK(h, h->nan_bits.alloc((size_t)G * h->nan_words));
         HIPCHK(h, hipMemset(h->nan_bits.p, 0, (size_t)G * h->nan_words * 8));
         TileView tv;
         tv.tiles = h->tiles.p; tv.group_off = h->group_off.p; tv.group_len = h->group_len.p; tv.lane_nsteps = h->lane_nsteps.p;
         tv.a0 = h->a0.p; tv.n_groups = G; tv.C = h->C; tv.c_obs = h->c_obs; tv.dt_all = h->dt_all;
-        HIPCHK(h, launch_nan_blocks(tv, h->d, h->nan_bits.p, h->nan_words, 0));
+        HIPCHK(h, launch_nan_blocks(tv, h->d, U, h->nan_bits.p, h->nan_words, 0));
         std::vector<unsigned long long> bits((size_t)G * h->nan_words);
         HIPCHK(h, hipMemcpy(bits.data(), h->nan_bits.p, bits.size() * 8, hipMemcpyDeviceToHost));
         // share of the dirty groups' blocks that would be quiet with a nominal 128-row memory
@@ -365,10 +365,13 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         }
         h->quiet_share = n_blocks > 0 ? (double)n_quiet / (double)n_blocks : 0.0;
         // (CTCRW's kernel with quiet rows runs one wave per SIMD: its general rows cost more than the plain general kernel's, so
-        //  it needs most blocks quiet -- three missing rows per track, share 0.32: 0.87 against 0.84 ms; one, share 0.98: 0.42)
-        const double need = getenv("SSDE_QUIET_ALWAYS") ? 0.0 : h->model == SSDE_MODEL_CTCRW ? 0.5 : 0.2;
+        //  it needs most blocks quiet -- three missing rows per track, share 0.32: 0.87 against 0.84 ms; two, 0.52: 0.84 against
+        //  0.84; one, share 0.98: 0.46)
+        const double need = getenv("SSDE_QUIET_ALWAYS") ? 0.0 : h->model == SSDE_MODEL_CTCRW ? 0.6 : 0.2;
         h->quiet_ok = n_blocks > 0 && (double)n_quiet >= need * (double)n_blocks;
         if (!h->quiet_ok) { h->nan_bits.release(); h->nan_words = 0; }
+        else { HIPCHK(h, h->quiet_flag.alloc(1)); HIPCHK(h, hipMemset(h->quiet_flag.p, 0, 8)); }
+        if (const char* e = getenv("SSDE_QUIET_WINDOW")) h->env_quiet_window = std::max(0, atoi(e));
         if (h->quiet_ok && !h->chunks_forced) {
             // most rows cost what a row of the shared-covariance kernels costs: one work item per wave slot -- CTCRW's kernel
             // with quiet rows runs one wave per SIMD (k_iso.hip), the scalar models' two

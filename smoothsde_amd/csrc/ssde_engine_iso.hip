@@ -377,10 +377,12 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     // (CTCRW: the transfer-function lanes lose digits when the closed-loop poles approach 1 -- the limit plan_windows has for them)
     if (h->quiet_ok && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1 &&
         !(h->model == SSDE_MODEL_CTCRW && h->plan_rho > 0.97)) {
-        const int U = iso_block_rows();
+        const int U = iso_block_rows(h->model);
         h->last_quiet_window = h->plan_warmup;
-        a.nan_bits = h->nan_bits.p; a.nan_words = h->nan_words;
+        a.nan_bits = h->nan_bits.p; a.nan_words = h->nan_words; a.quiet_flag = h->quiet_flag.p;
         a.quiet_w = (h->plan_warmup + U - 1) / U;
+        // (testing: a memory of its own, deliberately short -- the check at the switch has to notice; a retry doubles it like a warm-up)
+        if (h->env_quiet_window > 0) { a.quiet_w = (h->env_quiet_window * h->window_boost + U - 1) / U; h->last_quiet_window = h->env_quiet_window * h->window_boost; }
         a.quiet_b0 = (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U / U + 1;
         for (int i = 0; i < 12; i++) a.quiet_p[i] = h->stat_p[i];
         a.quiet_ld = h->stat_ld;

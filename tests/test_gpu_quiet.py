@@ -143,7 +143,7 @@ def test_mixed_batch_keeps_its_complete_groups_on_the_shared_kernel():
 @pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
 def test_the_share_of_quiet_blocks_decides(model, monkeypatch):
     """one missing row per track of 2000 rows, four wavefronts: two thirds of the blocks qualify -- quiet rows for every model;
-    three per track: few do -- CTCRW's kernel with quiet rows (one wave per SIMD) wants half of them, the scalar models' (two
+    three per track: few do -- CTCRW's kernel with quiet rows (one wave per SIMD) wants three fifths of them, the scalar models' (two
     waves per SIMD either way) a fifth"""
     monkeypatch.delenv("SSDE_QUIET_ALWAYS")
     rng = np.random.default_rng(4)
@@ -155,7 +155,7 @@ def test_the_share_of_quiet_blocks_decides(model, monkeypatch):
         val, grad = eng.eval(par, order=1)
         inf = eng.info()
         eng.close()
-        want = inf["quiet_share"] >= (0.5 if model == "CTCRW" else 0.2)
+        want = inf["quiet_share"] >= (0.6 if model == "CTCRW" else 0.2)
         assert (inf["quiet_window"] > 0) == want and (want or n_na == 3), (n_na, inf["quiet_share"], inf["quiet_window"])
         oval, ograd = oracle_eval(pb, par, order=1, threads=8)
         _close(val, grad, oval, ograd)
@@ -251,3 +251,23 @@ def test_asynchronous_evaluations_and_a_one_rank_communicator():
         assert abs(o[0].item() + pen - v) <= 1e-12 * abs(v) and np.max(np.abs(o[1:-1].cpu().numpy() - g)) <= 1e-10 * max(1.0, np.max(np.abs(g)))
         assert o[-1].item() < 1e-11
     eng.close()
+
+
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_a_memory_too_short_is_detected_at_the_switch_and_repaired(model, monkeypatch):
+    """SSDE_QUIET_WINDOW=8: the lanes would return to quiet rows three blocks after a missing row, long before their covariance
+    has forgotten it (the windows keep their planned warm-up: their hand-over checks have nothing to report).  The switch compares the stationary lanes' state and the stationary covariance with the general lane's, the
+    evaluation reports the disagreement with the hand-over checks' and is repeated with a longer memory -- never returned
+    silently"""
+    M, T, d = 128, 1200, 2
+    ID, times, obs = _batch(model, M, T, d, seed=51)
+    pb = capi.Problem(model, ID, times, obs)
+    par = np.array([0.5, 0.0, 0.0, 0.5, 0.0]) + (np.array([0, 3.0, 3.0, 0, 0]) if model == "OU_SSM" else 0.0)   # sigma_obs = 1.6: slow forgetting
+    monkeypatch.setenv("SSDE_QUIET_WINDOW", "8")
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    eng.close()
+    assert inf["window_retries"] >= 1, inf
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
