@@ -44,10 +44,12 @@ constexpr int ISO_U = SSDE_ISO_U;
 #endif
 static_assert(ISO_U % TILE_U == 0 && WIN_ALIGN % (2 * ISO_U) == 0 && 3 * ISO_U <= TILE_SPARE, "prefetch block");
 // ... of the kernels with quiet rows (below): those rows cost a third of a general row, so the loads lead by twice as many
-// (CTCRW's kernel with quiet rows, one wave per SIMD, sits 48 % of its cycles on s_waitcnt with 8-row blocks; 16-row blocks were
-//  tried for it -- the two blocks no longer stay in registers and the kernel takes 5.6 ms instead of 0.42: not kept)
+// Kernels with quiet rows (below): block flags and general rows in blocks of quiet_u rows -- 4 for CTCRW, whose general lane fills
+// the registers of two waves per SIMD with 4-row blocks as it is --, quiet rows in blocks of QUIET_UQ (they cost a fifth of a
+// general row, so the loads lead by more rows)
 template <int MODEL>
-__host__ __device__ constexpr int quiet_u() { return 8; }
+__host__ __device__ constexpr int quiet_u() { return MODEL == M_CTCRW ? 4 : 8; }
+constexpr int QUIET_UQ = 8;
 static_assert(16 % TILE_U == 0 && WIN_ALIGN % 16 == 0 && 3 * 16 <= TILE_SPARE, "prefetch block");
 
 // register block [dt | y_1..y_D]; the tile may carry no dt channel (c_obs == 0): slot 0 is then left alone
@@ -152,11 +154,12 @@ struct QuietOps {   // OU_SSM / BM_SSM
     typedef ScalLane<D, MASK> State;
     typedef BasisScal<MODEL, D, MASK> Stat;
     static constexpr bool HAS_P2 = (MODEL == M_OU_SSM);
-    // start beside a running general lane: its state as it stands (the sensitivity bases warm up)
-    __device__ static __forceinline__ void start(Stat& F, const State& S, const double*, int64_t) { F.init(S.M.x); }
-    // start a window: the first observation (what the general lanes' warm_init takes)
-    __device__ static __forceinline__ void start_window(Stat& F, const double* y, const double*, int64_t) {
-        double a0[D];
+    // start at a row: its observation as the state (what the general lanes' warm_init takes); obs_row points at the row's first
+    // response channel for this lane, channels `stride` doubles apart
+    __device__ static __forceinline__ void start_at(Stat& F, const double* obs_row, const double*, int64_t stride) {
+        double y[D], a0[D];
+#pragma unroll
+        for (int a = 0; a < D; a++) y[a] = obs_row[a * stride];
         Stat::warm_a0(y, a0);
         F.init(a0);
     }
@@ -203,13 +206,7 @@ struct QuietOps<M_CTCRW, D, MASK> {
     typedef CtcrwLane<D, MASK> State;
     typedef TfCtcrw<D, MASK> Stat;
     // the transfer-function lanes start from the observation of the row before (a block without a missing row)
-    __device__ static __forceinline__ void start(Stat& F, const State&, const double* obs_prev, int64_t stride) {
-        double yp[D];
-#pragma unroll
-        for (int a = 0; a < D; a++) yp[a] = obs_prev[a * stride];
-        F.init(yp);
-    }
-    __device__ static __forceinline__ void start_window(Stat& F, const double*, const double* obs_prev, int64_t stride) {
+    __device__ static __forceinline__ void start_at(Stat& F, const double*, const double* obs_prev, int64_t stride) {
         double yp[D];
 #pragma unroll
         for (int a = 0; a < D; a++) yp[a] = obs_prev[a * stride];
@@ -279,12 +276,10 @@ struct DeriveOps {
     }
 };
 
-template <int MODEL, int D, int MASK, bool UNI, int DER = -1, bool QUIET = false>
+template <int MODEL, int D, int MASK, bool UNI, int DER = -1>
 __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int chunk) {
     typedef LaneOps<MODEL, D, MASK> Ops;
-    typedef QuietOps<MODEL, D, MASK> QOps;
     constexpr int C = 1 + D;
-    constexpr int U = QUIET ? quiet_u<MODEL>() : ISO_U;     // rows per prefetch block
     constexpr int NACC = 4 + D;
     constexpr int SD = Ops::SD;
     const int lane = threadIdx.x & 63;
@@ -310,8 +305,8 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
     ns_min = __builtin_amdgcn_readfirstlane(ns_min);
 
     // two register blocks in ping-pong: while one is consumed the other is in flight (no copies)
-    double bufA[U][C], bufB[U][C];
-    load_block<C, U>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
+    double bufA[ISO_U][C], bufB[ISO_U][C];
+    load_block<C, ISO_U>(bufA, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
@@ -321,36 +316,140 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         Ops::warm_init(S, &bufA[0][1], A);
     }
 
-    // quiet rows (QUIET): q_last = the latest block with a missing observation, q_word = the 64 block flags around the current
-    // block; tf_live: the stationary lanes F are running (since block tf_since), q_mode: they alone score the rows
+    auto run_block = [&](const double (&blk)[ISO_U][C], int s0) {
+        if (s0 + ISO_U <= ns_min) {          // every lane's track covers the block: no per-row predication
+#pragma unroll
+            for (int u = 0; u < ISO_U; u++) Ops::template step<UNI>(S, A, mu, blk[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < ISO_U; u++)
+                if (s0 + u < ns) Ops::template step<UNI>(S, A, mu, blk[u]);
+        }
+    };
+    auto handover = [&](int s0) {
+        if (s0 == s_acc && s_acc > s_begin) {
+            // end of warm-up: publish the state for the hand-over check, start scoring from zero
+            double st[Ops::State::NSTATE];
+            S.dump(st);
+            if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
+            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
+#pragma unroll
+            for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+            S.reset_acc();
+        }
+    };
+    for (int s0 = s_begin; s0 < s_end; s0 += 2 * ISO_U) {
+        // TILE_SPARE keeps the look-ahead loads inside the allocation
+        load_block<C, ISO_U>(bufB, base + (int64_t)(s0 + ISO_U) * Cr * WAVE, Cr, c_obs);
+        handover(s0);
+        run_block(bufA, s0);
+        load_block<C, ISO_U>(bufA, base + (int64_t)(s0 + 2 * ISO_U) * Cr * WAVE, Cr, c_obs);
+        if (s0 + ISO_U < s_end) {
+            handover(s0 + ISO_U);
+            run_block(bufB, s0 + ISO_U);
+        }
+    }
+    if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
+        // state on arrival at the next window's first scored row
+        double st[Ops::State::NSTATE];
+        S.dump(st);
+        if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+    }
+    double out[NACC];
+    Ops::finish(S, out);
+    if (DER >= 0) {   // gradient of the derived direction: slots [value, sig, mu.., par[d], par[d+1]]
+        constexpr double CB = DeriveOps<MODEL, DER>::CB;
+        out[1 + D + DER] = CB * ((double)D * S.C.nupd - S.M.accq - out[1]);
+    }
+    if (s_acc >= s_end) {
+#pragma unroll
+        for (int k = 0; k < NACC; k++) out[k] = 0.0;  // empty window
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; k++) {
+        const double t = wave_sum(out[k]);
+        if (lane == 0) A.partials[((int64_t)pc * NACC + k) * tv.n_groups + g] = t;
+    }
+}
+
+// The general lane with QUIET ROWS (see QuietOps above): stretches of general rows and stretches of quiet rows as loops of their
+// own, so that neither the general lane's state is live in the quiet loop nor the stationary lanes' in the general one (as one
+// loop with a mode flag the kernel needed both at once: 516 bytes of scratch at two waves per SIMD, or one wave per SIMD).  The
+// stationary lanes catch up at a switch by re-reading the quiet_w blocks before it (once per stretch, from L2 mostly).
+template <int MODEL, int D, int MASK, int DER = -1>
+__device__ __forceinline__ void run_lane_quiet(const IsoArgs& A, int g, int part, int chunk) {
+    typedef LaneOps<MODEL, D, MASK> Ops;
+    typedef QuietOps<MODEL, D, MASK> QOps;
+    constexpr int C = 1 + D;
+    constexpr int U = quiet_u<MODEL>();      // rows per prefetch block = rows per block flag
+    constexpr int NACC = 4 + D;
+    constexpr int SD = Ops::SD;
+    const int lane = threadIdx.x & 63;
+    const TileView& tv = A.tv;
+    const int Cr = tv.C, c_obs = tv.c_obs;
+    const double* base = tv.tiles + tv.group_off[g] + lane;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    const int pc = part * A.n_chunks + chunk;
+
+    int s_begin, s_acc, s_end;
+    window_bounds(L, A.n_chunks, A.window, A.t0, chunk, s_begin, s_acc, s_end, A.t0_delta);
+
+    typename Ops::State S;
+    double mu[D];
+#pragma unroll
+    for (int a = 0; a < D; a++) mu[a] = A.mu[a];
+
+    int ns_min = ns;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ns_min = min(ns_min, __shfl_xor(ns_min, o, 64));
+    ns_min = __builtin_amdgcn_readfirstlane(ns_min);
+
+    constexpr int UQ = QUIET_UQ, R = UQ / U;  // rows of a quiet block, block flags per quiet block
+    // the block being consumed and the one in flight behind it (general rows); the quiet loop has its own pair
+    double cur[U][C], nxt[U][C];
+    load_block<C, U>(cur, base + (int64_t)s_begin * Cr * WAVE, Cr, c_obs);
+    if (s_begin == 0) {
+        double a0[SD];
+#pragma unroll
+        for (int c = 0; c < SD; c++) a0[c] = tv.a0[((int64_t)g * SD + c) * WAVE + lane];
+        Ops::init(S, a0, A);
+    } else {
+        Ops::warm_init(S, &cur[0][1], A);
+    }
+
+    // q_last = the latest block with a missing observation (a window that does not start quiet counts its own start as one: the
+    // lane's covariance is a guess there), q_word = the 64 block flags around the current block
     typename QOps::Stat F;
-    int q_last = 0, q_wi = -1, tf_since = 0;
+    F.setup(A);
+    const unsigned long long* qbits = A.nan_bits + (int64_t)g * A.nan_words;
+    int q_last = -A.quiet_w - 2, q_wi = -1;
     unsigned long long q_word = 0ull;
-    bool q_mode = false, tf_live = false;
+    bool q_mode = false;
     double nq = 0.0;                         // rows this lane scored in quiet mode
     double q_worst = 0.0;                    // largest disagreement found at a switch to quiet rows (wave-uniform)
-    const unsigned long long* qbits = nullptr;
-    auto load_word = [&](int wi) -> unsigned long long {
-        const unsigned long long w = qbits[wi];
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0xffffffffull));
+    auto nanbit = [&](int b) -> bool {
+        if ((b >> 6) != q_wi) {
+            q_wi = b >> 6;
+            const unsigned long long w = qbits[q_wi];
+            q_word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w & 0xffffffffull));
+        }
+        return ((q_word >> (b & 63)) & 1ull) != 0ull;
     };
-    if (QUIET) {
-        F.setup(A);
-        qbits = A.nan_bits + (int64_t)g * A.nan_words;
+    {
         const int b0 = s_begin / U;
-        q_last = -A.quiet_w - 2;
         if (b0 > 0) {
             // the row before the window is in a block without a missing row, and the transient of P0 is over: the stationary
             // lanes alone from the first row on (the window's warm-up rows are theirs, as in k_iso_shared.inc)
-            const bool prev_nan = (load_word((b0 - 1) >> 6) >> ((b0 - 1) & 63)) & 1ull;
-            if (!prev_nan && b0 >= A.quiet_b0) {
-                QOps::start_window(F, &bufA[0][1], base + ((int64_t)(s_begin - 1) * Cr + c_obs) * WAVE, WAVE);
-                q_mode = tf_live = true;
-                tf_since = b0 - A.quiet_w;
-                q_last = b0 - A.quiet_w - 2;
+            if (!nanbit(b0 - 1) && b0 >= A.quiet_b0) {
+                QOps::start_at(F, base + ((int64_t)s_begin * Cr + c_obs) * WAVE, base + ((int64_t)(s_begin - 1) * Cr + c_obs) * WAVE, WAVE);
+                q_mode = true;
             } else {
-                q_last = b0 - 1;             // (the lane's covariance is a guess at the window's start: like a missing row)
+                q_last = b0 - 1;
             }
         }
     }
@@ -368,104 +467,121 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
         if (MASK & DIR_P2) S.M.gq[2] += fo[3 + D];
         F.reset_acc();
     };
-    auto run_block = [&](const double (&blk)[U][C], int s0) {
-        bool both = false;                    // general step with the stationary lanes warming up beside it
-        if (QUIET) {
-            const int b = s0 / U;
-            if ((b >> 6) != q_wi) { q_wi = b >> 6; q_word = load_word(q_wi); }
-            if ((q_word >> (b & 63)) & 1ull) {
-                q_last = b;
-                if (q_mode) { fold(); QOps::leave(F, S, A); }      // a missing row ahead: the lane's own covariance again
-                q_mode = tf_live = false;
-            } else if (!q_mode) {
-                const int age = b - q_last;
-                if (!tf_live && age >= 2 && s0 > 0) {
-                    QOps::start(F, S, base + ((int64_t)(s0 - 1) * Cr + c_obs) * WAVE, WAVE);
-                    tf_live = true; tf_since = b;
-                }
-                if (tf_live && b - tf_since >= A.quiet_w && age >= A.quiet_w + 2 && b >= A.quiet_b0 + A.quiet_w) {
-                    // VERIFIED like a window hand-over: the lane's covariance and its sensitivities against the stationary ones,
-                    // the state the stationary lanes warmed up to against the general lane's, component by component over the wave
-                    // (error and scale as in window_check_block); the evaluation reports the largest ratio with the hand-over
-                    // checks' and is repeated with a longer memory when it exceeds their threshold
-                    q_worst = fmax(q_worst, QOps::switch_check(F, S, A, s0 < ns));
+    auto dump_to = [&](int slot) {
+        double st[Ops::State::NSTATE];
+        S.dump(st);
+        if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
+        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + slot) * A.bnd_stride * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int c = 0; c < C; c++) cur[u][c] = nxt[u][c];
+    };
+    const bool has_warmup = s_acc > s_begin;
+    int s0 = s_begin;
+    while (s0 < s_end) {
+        if (q_mode) {
+            // ---- a quiet stretch: the stationary lanes alone, until a block with a missing observation comes up ----
+            double qcur[UQ][C], qnxt[UQ][C];
+            load_block<C, UQ>(qcur, base + (int64_t)s0 * Cr * WAVE, Cr, c_obs);              // (once per stretch: not prefetched)
+            while (s0 < s_end) {
+                if (nanbit(s0 / U) || (R > 1 && nanbit(s0 / U + 1))) break;
+                load_block<C, UQ>(qnxt, base + (int64_t)(s0 + UQ) * Cr * WAVE, Cr, c_obs);   // (TILE_SPARE keeps it inside the allocation)
+                if (has_warmup && s0 == s_acc) {             // end of warm-up: the state for the hand-over check, scoring from zero
+                    QOps::leave(F, S, A);
                     F.reset_acc();
-                    q_mode = true;
+                    dump_to(0);
+                    S.reset_acc();
+                    nq = 0.0;
                 }
-                both = tf_live && !q_mode;
+                if (s0 + UQ <= ns_min) {
+#pragma unroll
+                    for (int u = 0; u < UQ; u++) F.step_stat(&qcur[u][1]);
+                    nq += (double)UQ;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < UQ; u++)
+                        if (s0 + u < ns) { F.step_stat(&qcur[u][1]); nq += 1.0; }
+                }
+#pragma unroll
+                for (int u = 0; u < UQ; u++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) qcur[u][c] = qnxt[u][c];
+                s0 += UQ;
             }
-            if (q_mode) {
+            if (s0 < s_end) {                                // a missing row ahead: the lane's own covariance again
+                fold();
+                QOps::leave(F, S, A);
+                q_mode = false;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) cur[u][c] = qcur[u][c];
+            }
+        } else {
+            // ---- a general stretch: until every lane has forgotten its last missing row (and the transient of P0) ----
+            bool sw = false;
+            while (s0 < s_end) {
+                const int b = s0 / U;
+                if (nanbit(b)) q_last = b;
+                else if (b - q_last >= A.quiet_w + 2 && b >= A.quiet_b0 + A.quiet_w && s0 % UQ == 0 && !(R > 1 && nanbit(b + 1))) {
+                    sw = true;                // (the whole quiet block ahead is free of missing rows: the quiet loop will take it)
+                    break;
+                }
+                load_block<C, U>(nxt, base + (int64_t)(s0 + U) * Cr * WAVE, Cr, c_obs);
+                if (has_warmup && s0 == s_acc) {
+                    dump_to(0);
+                    S.reset_acc();
+                    nq = 0.0;
+                }
                 if (s0 + U <= ns_min) {
 #pragma unroll
-                    for (int u = 0; u < U; u++) F.step_stat(&blk[u][1]);
-                    nq += (double)U;
+                    for (int u = 0; u < U; u++) Ops::template step<true>(S, A, mu, cur[u]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < U; u++)
-                        if (s0 + u < ns) { F.step_stat(&blk[u][1]); nq += 1.0; }
+                        if (s0 + u < ns) Ops::template step<true>(S, A, mu, cur[u]);
                 }
-                return;
+                advance();
+                s0 += U;
             }
-        }
-        if (s0 + U <= ns_min) {          // every lane's track covers the block: no per-row predication
+            if (sw) {
+                // the stationary lanes catch up over the quiet_w blocks before this one (no missing row in them or in the block
+                // before them): a fixed stable filter of the observations, it forgets its start at the lanes' own rate
+                const int r0 = s0 - A.quiet_w * U;
+                QOps::start_at(F, base + ((int64_t)r0 * Cr + c_obs) * WAVE, base + ((int64_t)(r0 - 1) * Cr + c_obs) * WAVE, WAVE);
+                for (int r = r0; r < s0; r += U) {
+                    load_block<C, U>(nxt, base + (int64_t)r * Cr * WAVE, Cr, c_obs);
 #pragma unroll
-            for (int u = 0; u < U; u++) Ops::template step<UNI>(S, A, mu, blk[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (s0 + u < ns) Ops::template step<UNI>(S, A, mu, blk[u]);
-        }
-        if (QUIET && both) {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (s0 + u < ns) F.step_stat(&blk[u][1]);
-        }
-    };
-    auto handover = [&](int s0) {
-        if (s0 == s_acc && s_acc > s_begin) {
-            // end of warm-up: publish the state for the hand-over check, start scoring from zero
-            double st[Ops::State::NSTATE];
-            if (QUIET && q_mode) { QOps::leave(F, S, A); F.reset_acc(); }
-            S.dump(st);
-            if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
-            double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
-#pragma unroll
-            for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
-            S.reset_acc();
-            nq = 0.0;
-        }
-    };
-    for (int s0 = s_begin; s0 < s_end; s0 += 2 * U) {
-        // TILE_SPARE keeps the look-ahead loads inside the allocation
-        load_block<C, U>(bufB, base + (int64_t)(s0 + U) * Cr * WAVE, Cr, c_obs);
-        handover(s0);
-        run_block(bufA, s0);
-        load_block<C, U>(bufA, base + (int64_t)(s0 + 2 * U) * Cr * WAVE, Cr, c_obs);
-        if (s0 + U < s_end) {
-            handover(s0 + U);
-            run_block(bufB, s0 + U);
+                    for (int u = 0; u < U; u++)
+                        if (r + u < ns) F.step_stat(&nxt[u][1]);
+                }
+                // VERIFIED like a window hand-over: the lane's covariance and its sensitivities against the stationary ones, the
+                // state the stationary lanes arrived with against the general lane's (QuietOps::switch_check); the evaluation
+                // reports the largest ratio with the hand-over checks' and is repeated with a longer memory when it is too large
+                q_worst = fmax(q_worst, QOps::switch_check(F, S, A, s0 < ns));
+                F.reset_acc();
+                q_mode = true;
+            }
         }
     }
     if (A.n_chunks > 1 && chunk + 1 < A.n_chunks) {
         // state on arrival at the next window's first scored row
-        double st[Ops::State::NSTATE];
-        if (QUIET && q_mode) QOps::leave(F, S, A);
-        S.dump(st);
-        if (DER >= 0) DeriveOps<MODEL, DER>::template fill<D>(st);
-        double* o = A.bnd + (((int64_t)pc * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
-#pragma unroll
-        for (int k = 0; k < Ops::State::NSTATE; k++) o[k * WAVE] = st[k];
+        if (q_mode) QOps::leave(F, S, A);
+        dump_to(1);
     }
+    if (q_mode) fold();
+    S.C.nupd += nq;
+    // (iso_finalize_kernel folds the word into the evaluation's check value and clears it for the next launch)
+    if (lane == 0 && q_worst > 0.0 && A.quiet_flag)
+        atomicMax((unsigned long long*)A.quiet_flag, (unsigned long long)__double_as_longlong(q_worst == q_worst ? q_worst : INFINITY));
     double out[NACC];
-    if (QUIET) {
-        if (q_mode) fold();
-        S.C.nupd += nq;
-        // (iso_finalize_kernel folds the word into the evaluation's check value and clears it for the next launch)
-        if (lane == 0 && q_worst > 0.0 && A.quiet_flag)
-            atomicMax((unsigned long long*)A.quiet_flag, (unsigned long long)__double_as_longlong(q_worst == q_worst ? q_worst : INFINITY));
-    }
     Ops::finish(S, out);
-    if (QUIET) {                             // the data-independent terms of the rows scored in quiet mode
+    {                                        // the data-independent terms of the rows scored in quiet mode
         const double hn = 0.5 * (double)D * nq;
         out[0] = fma(hn, A.quiet_ld, out[0]);
         if (MASK & DIR_SIG) out[1] = fma(hn, A.quiet_gld[0], out[1]);
@@ -489,7 +605,7 @@ __device__ __forceinline__ void run_lane(const IsoArgs& A, int g, int part, int 
 
 // One kernel per (direction mask, regular / irregular grid) when the whole launch uses a single mask (n_parts == 1, the
 // default): a kernel's register allocation is the worst case over everything it contains.
-template <int MODEL, int D, int MASK, bool UNI, bool QUIET = false>
+template <int MODEL, int D, int MASK, bool UNI>
 __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;   // raised by the finalize launch
     int g, part, chunk;
@@ -497,8 +613,19 @@ __device__ __forceinline__ void iso_mask_body(const IsoArgs& A) {
     if (!group_selected(A, g)) return;
     constexpr int DERJ = (MODEL == M_BM_SSM) ? 1 : 2;
     constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
-    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), UNI, DERJ, QUIET>(A, g, part, chunk);
-    else run_lane<MODEL, D, MASK, UNI, -1, QUIET>(A, g, part, chunk);
+    if (CAN && chunk > 0 && A.derive) run_lane<MODEL, D, (MASK & ~dir_bit(DERJ)), UNI, DERJ>(A, g, part, chunk);
+    else run_lane<MODEL, D, MASK, UNI>(A, g, part, chunk);
+}
+template <int MODEL, int D, int MASK>
+__device__ __forceinline__ void iso_quiet_body(const IsoArgs& A) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
+    int g, part, chunk;
+    if (!decode_block(A, A.n_chunks, g, part, chunk)) return;
+    if (!group_selected(A, g)) return;
+    constexpr int DERJ = (MODEL == M_BM_SSM) ? 1 : 2;
+    constexpr bool CAN = (MASK & DIR_SIG) != 0 && (MASK & dir_bit(DERJ)) != 0;
+    if (CAN && chunk > 0 && A.derive) run_lane_quiet<MODEL, D, (MASK & ~dir_bit(DERJ)), DERJ>(A, g, part, chunk);
+    else run_lane_quiet<MODEL, D, MASK>(A, g, part, chunk);
 }
 
 // Two waves per SIMD (256 registers each): a lone wave leaves the fp64 pipe idle behind its dependent instructions
@@ -515,10 +642,8 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_I
 // ... the same lanes with quiet rows (regular grid, a.quiet_w > 0): a kernel of its own, so that batches without quiet rows run
 // the code (and the register allocation) they always ran
 template <int MODEL, int D, int MASK>
-// (CTCRW carries the general lane, the transfer-function lane and two 8-row blocks: one wave per SIMD with the whole register
-//  file, like the shared-covariance kernels whose rows most of its rows are; the engine plans half as many windows for it)
-__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? 1 : SSDE_ISO_WAVES_SCAL) void iso_quiet_kernel(const IsoArgs A) {
-    iso_mask_body<MODEL, D, MASK, true, true>(A);
+__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? SSDE_ISO_WAVES : SSDE_ISO_WAVES_SCAL) void iso_quiet_kernel(const IsoArgs A) {
+    iso_quiet_body<MODEL, D, MASK>(A);
 }
 
 // Direction-split launches (several parts with different masks; a testing path) keep the masks in one kernel.

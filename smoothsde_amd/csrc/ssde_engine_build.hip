@@ -364,18 +364,18 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             n_blocks += nb;
         }
         h->quiet_share = n_blocks > 0 ? (double)n_quiet / (double)n_blocks : 0.0;
-        // (CTCRW's kernel with quiet rows runs one wave per SIMD: its general rows cost more than the plain general kernel's, so
-        //  it needs most blocks quiet -- three missing rows per track, share 0.32: 0.87 against 0.84 ms; two, 0.52: 0.84 against
-        //  0.84; one, share 0.98: 0.46)
-        const double need = getenv("SSDE_QUIET_ALWAYS") ? 0.0 : h->model == SSDE_MODEL_CTCRW ? 0.6 : 0.2;
+        // (measured, 10^4 x 10^4 CTCRW with 1 / 2 / 3 / 5 missing rows per track = shares 0.98 / 0.53 / 0.33 / 0.18: 0.40 / 0.70 / 0.78 /
+        //  0.86 ms against 0.84-0.87 without quiet rows)
+        const double need = getenv("SSDE_QUIET_ALWAYS") ? 0.0 : h->model == SSDE_MODEL_CTCRW ? 0.25 : 0.2;
         h->quiet_ok = n_blocks > 0 && (double)n_quiet >= need * (double)n_blocks;
         if (!h->quiet_ok) { h->nan_bits.release(); h->nan_words = 0; }
         else { HIPCHK(h, h->quiet_flag.alloc(1)); HIPCHK(h, hipMemset(h->quiet_flag.p, 0, 8)); }
         if (const char* e = getenv("SSDE_QUIET_WINDOW")) h->env_quiet_window = std::max(0, atoi(e));
         if (h->quiet_ok && !h->chunks_forced) {
-            // most rows cost what a row of the shared-covariance kernels costs: one work item per wave slot -- CTCRW's kernel
-            // with quiet rows runs one wave per SIMD (k_iso.hip), the scalar models' two
-            const int slots = h->model == SSDE_MODEL_CTCRW ? 1024 : 2048;
+            // nearly every row a quiet row: the rows cost what the shared-covariance kernels' cost, and windows cost warm-up rows and
+            // hand-over checks -- one work item per SIMD (10^4 tracks: 6 windows 0.40 ms, 12 windows 0.435); otherwise one per wave
+            // slot (two waves per SIMD), which evens out the stretches of general rows (2 missing rows per track: 0.70 against 0.84)
+            const int slots = getenv("SSDE_QUIET_SLOTS") ? atoi(getenv("SSDE_QUIET_SLOTS")) : h->quiet_share >= 0.9 ? 1024 : 2048;
             if (h->use_shared && h->want_chunks_d > 0) {
                 const int gd8 = ((G - h->n_clean_groups) + 7) / 8 * 8;
                 h->want_chunks_d = std::max(1, std::min(h->want_chunks_d, slots / gd8));
