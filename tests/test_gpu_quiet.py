@@ -270,3 +270,40 @@ def test_a_memory_too_short_is_detected_at_the_switch_and_repaired(model, monkey
     assert inf["window_retries"] >= 1, inf
     oval, ograd = oracle_eval(pb, par, order=1, threads=8)
     _close(val, grad, oval, ograd)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sparse_patterns(seed, monkeypatch):
+    """random model, width, length, number and place of the missing rows (runs of them, rows next to block and window
+    boundaries, the second and the last row of a track), random share of complete tracks, a forced number of windows now and
+    then: value and gradient against the oracle, with and without the dealing by position"""
+    rng = np.random.default_rng(1000 + seed)
+    model = ["CTCRW", "OU_SSM", "BM_SSM"][seed % 3]
+    d = int(rng.integers(1, 3))
+    M = int(rng.choice([64, 130, 200]))
+    T = int(rng.integers(500, 1400))
+    ID, times, obs = simulate(model, M, T, d, seed=200 + seed)
+    for k in range(M):
+        if rng.random() < 0.25:
+            continue                                   # a complete track
+        n_na = int(rng.integers(1, 4))
+        for _ in range(n_na):
+            r = int(rng.choice([1, T - 1, rng.integers(1, T), 16 * rng.integers(1, T // 16), 8 * rng.integers(1, T // 8) - 1]))
+            run = int(rng.choice([1, 1, 2, 9]))
+            obs[k * T + r: k * T + min(T, r + run), :] = np.nan
+    if seed % 4 == 1:
+        monkeypatch.setenv("SSDE_CHUNKS", str(int(rng.integers(2, 9))))
+    if seed % 2 == 1:
+        monkeypatch.setenv("SSDE_NO_NA_SORT", "1")
+    pb = capi.Problem(model, ID, times, obs)
+    par = _par(model, d, rng)
+    if seed % 5 == 2:
+        par[0] += 1.2                                  # a larger sigma_obs: slower forgetting, longer memories and warm-ups
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    eng.close()
+    assert inf["window_check_max"] <= 1e-11 or inf["window_retries"] >= 1, inf
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
