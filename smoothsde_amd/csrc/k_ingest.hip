@@ -208,6 +208,37 @@ __global__ void na_follow_kernel(const double* id, const double* lead, double* c
         else col[i] = __longlong_as_double(0x7FF8000000000000ll);
     }
 }
+// ---- a response wider than two columns with a device-resident H_array (ssde_engine_dist.hip) ------------------------------------
+// H is [D x D x n], column-major per row.  couples != 0 afterwards: some row has an entry between different column pairs.
+__global__ void h_couples_kernel(const double* H, int64_t n, int D, int* couples) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double* Hr = H + (size_t)r * D * D;
+    bool bad = false;
+    for (int j = 0; j < D; j++)
+        for (int i = 0; i < D; i++)
+            if (i / 2 != j / 2) { const double v = Hr[i + (size_t)j * D]; bad = bad || !(v == 0.0); }   // (a NaN counts as coupling)
+    if (bad) atomicOr(couples, 1);
+}
+// the cnt x cnt block of every row that belongs to response columns [dlo, dlo + cnt)
+__global__ void h_block_kernel(const double* H, int64_t n, int D, int dlo, int cnt, double* out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    for (int jj = 0; jj < cnt; jj++)
+        for (int ii = 0; ii < cnt; ii++)
+            out[(size_t)r * cnt * cnt + ii + (size_t)jj * cnt] = H[(size_t)r * D * D + (dlo + ii) + (size_t)(dlo + jj) * D];
+}
+hipError_t launch_h_couples(const double* H, int64_t n, int D, int* couples, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(h_couples_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, H, n, D, couples);
+    return hipGetLastError();
+}
+hipError_t launch_h_block(const double* H, int64_t n, int D, int dlo, int cnt, double* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(h_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, H, n, D, dlo, cnt, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_na_follow(const double* id, const double* lead, double* col, int64_t n, int any_nan, int* poison, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(na_follow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, id, lead, col, n, any_nan, poison);

@@ -274,6 +274,8 @@ hipError_t launch_gather_i64(const int64_t* src, const int64_t* idx, int64_t m, 
 hipError_t launch_lattice_scatter(const int64_t* pos, const double* id, const double* times, const double* obs, int64_t n, int d,
                                   int64_t np, double delta, double* times_p, double* obs_p, hipStream_t s);
 hipError_t launch_lattice_gather(const int64_t* pos, const double* src, int64_t n, int64_t np, int ncol, double* dst, hipStream_t s);
+hipError_t launch_h_couples(const double* H, int64_t n, int D, int* couples, hipStream_t s);
+hipError_t launch_h_block(const double* H, int64_t n, int D, int dlo, int cnt, double* out, hipStream_t s);
 hipError_t launch_na_follow(const double* id, const double* lead, double* col, int64_t n, int any_nan, int* poison, hipStream_t s);
 
 // ---- general parameter description for the dense / direct kernels -------------------------------

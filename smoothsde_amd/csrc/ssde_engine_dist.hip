@@ -59,7 +59,7 @@ struct PartArrays {
     std::vector<const double*> fe_ptr, re_ptr;
     std::vector<const ssde_ppbasis*> pp_ptr;
     std::vector<double> p0, obs_host, t_decay_host, h_block;
-    DevBuf<double> obs_dev, t_decay_dev;
+    DevBuf<double> obs_dev, t_decay_dev, h_block_dev;
     DevBuf<int> poison_dev;
 };
 
@@ -99,10 +99,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
             // a per-row measurement covariance that is block-diagonal in the column pairs (independent axis errors, one error
             // ellipse per pair) keeps F block-diagonal: log det F and u' F^-1 u stay sums over the pairs, and every part gets
             // its own block of every row.  Anything else couples the parts.
-            if (on_dev)
-                return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with a device-resident H_array: the per-pair blocks are cut on the host "
-                                                    "(pass host arrays, or n_dim <= 2)");
-            for (int64_t r = 0; r < d->n; r++) {
+            for (int64_t r = 0; r < (on_dev ? 0 : d->n); r++) {          // (device-resident: checked where the blocks are cut, below)
                 const double* Hr = d->h_array + (size_t)r * D * D;
                 for (int i = 0; i < D; i++)
                     for (int j = 0; j < D; j++)
@@ -274,6 +271,24 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                         for (int j = 0; j < sc; j++) B.p0[i + (size_t)j * sc] = d->p0[(s0c + i) + (size_t)(s0c + j) * sdim];
                     cd.p0 = B.p0.data();
                 }
+                if (is_kalman(d->model) && sd.h_array && on_dev) {                 // the same on the device
+                    HIPCHK(parent, hipSetDevice(sd.device));
+                    if (p == 0) {
+                        DevBuf<int> couples;
+                        HIPCHK(parent, couples.alloc(1));
+                        HIPCHK(parent, hipMemset(couples.p, 0, sizeof(int)));
+                        HIPCHK(parent, launch_h_couples(sd.h_array, ns, D, couples.p, 0));
+                        int flag = 0;
+                        HIPCHK(parent, hipMemcpy(&flag, couples.p, sizeof(int), hipMemcpyDeviceToHost));
+                        couples.release();
+                        if (flag) return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: H_array[,, i] must not couple response columns of "
+                                                                      "different pairs (2k, 2k+1), which this engine evaluates side by side");
+                    }
+                    HIPCHK(parent, B.h_block_dev.alloc((size_t)cnt * cnt * ns));
+                    HIPCHK(parent, launch_h_block(sd.h_array, ns, D, dlo, cnt, B.h_block_dev.p, 0));
+                    HIPCHK(parent, hipDeviceSynchronize());
+                    cd.h_array = B.h_block_dev.p;
+                } else
                 if (is_kalman(d->model) && sd.h_array) {                           // the part's cnt x cnt block of every row
                     B.h_block.resize((size_t)cnt * cnt * ns);
                     for (int64_t r = 0; r < ns; r++)
@@ -327,7 +342,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                 }
                 const ParLayout CL = child_layout(PL, jmap);
                 st = build(&cd, sh, &CL);
-                B.obs_dev.release(); B.t_decay_dev.release(); B.poison_dev.release();
+                B.obs_dev.release(); B.t_decay_dev.release(); B.poison_dev.release(); B.h_block_dev.release();
             }
             if (st != SSDE_OK)
                 return fail(parent, st, (S > 1 ? "shard " + std::to_string(k) + " " : std::string()) + (P > 1 ? "dimension part " + std::to_string(p) + " " : std::string()) +

@@ -134,6 +134,20 @@ def test_wide_response_with_a_block_diagonal_H_array(model, d):
     _, _, oaest = oracle_eval(pb, spec["par"], order=1, report=True)
     assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
     eng.close()
+    if not spec.get("X_re") and not spec.get("X_fe"):
+        # the same batch from device-resident arrays: the blocks are cut by a kernel, a coupling entry found by one
+        import torch
+        dev = torch.device("cuda:0")
+        tz = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+        pbd = capi.Problem.from_torch(model, tz(spec["ID"]), tz(spec["times"]), tz(spec["obs"]), H=tz(H))
+        engd = capi.Engine(pbd)
+        vd, gd = engd.eval(spec["par"], order=1)
+        engd.close()
+        assert abs(vd - val) <= 1e-12 * abs(val) and np.max(np.abs(gd - grad)) <= 1e-10 * max(1.0, np.max(np.abs(grad)))
+        Hbad = H.copy()
+        Hbad[0, d - 1, 5] = Hbad[d - 1, 0, 5] = 0.01
+        with pytest.raises(capi.EngineError, match="must not couple"):
+            capi.Engine(capi.Problem.from_torch(model, tz(spec["ID"]), tz(spec["times"]), tz(spec["obs"]), H=tz(Hbad)))
 
 
 @pytest.mark.parametrize("model,d", [("CTCRW", 3), ("OU", 4), ("OU_SSM", 5)])
