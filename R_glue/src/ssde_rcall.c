@@ -231,12 +231,15 @@ SEXP ssdeR_info(SEXP ptr) {
     if (!h) Rf_error("engine handle was destroyed");
     ssde_info_t inf;
     ssde_info(h, &inf);
+    /* kernel_id: SSDE_KERNEL_* -- which kernel family ran the last evaluation's rows (ABI 10) */
     const char *nms[] = {"n_par_full", "n_free", "path", "uniform_dt", "n_tracks", "n_rows", "window", "window_check",
-                         "n_rows_tiled", "n_groups", "n_clean_groups", "n_devices"};
+                         "n_rows_tiled", "n_groups", "n_clean_groups", "n_devices", "kernel_id", "comm_ranks", "comm_ranks_reported"};
     double vals[] = {inf.n_par_full, inf.n_free, inf.path, inf.uniform_dt, (double)inf.n_tracks, (double)inf.n_rows,
-                     inf.window, inf.window_check, (double)inf.n_rows_tiled, inf.n_groups, inf.n_clean_groups, inf.n_devices};
-    SEXP out = PROTECT(Rf_allocVector(REALSXP, 12)), nm = PROTECT(Rf_allocVector(STRSXP, 12));
-    for (int i = 0; i < 12; i++) { REAL(out)[i] = vals[i]; SET_STRING_ELT(nm, i, Rf_mkChar(nms[i])); }
+                     inf.window, inf.window_check, (double)inf.n_rows_tiled, inf.n_groups, inf.n_clean_groups, inf.n_devices,
+                     inf.kernel_id, inf.comm_ranks, inf.comm_ranks_reported};
+    const int nv = (int)(sizeof(vals) / sizeof(vals[0]));
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, nv)), nm = PROTECT(Rf_allocVector(STRSXP, nv));
+    for (int i = 0; i < nv; i++) { REAL(out)[i] = vals[i]; SET_STRING_ELT(nm, i, Rf_mkChar(nms[i])); }
     Rf_setAttrib(out, R_NamesSymbol, nm);
     UNPROTECT(2);
     return out;

@@ -46,6 +46,38 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; peak engine clock.  An fp64 VALU instruction occupies a SIMD's issue port
+                                  # for 4 cycles (64 lanes at 16 lanes / cycle): the fp64-issue roof of a kernel that runs
+                                  # V VALU wave-instructions per launch is V x 4 / (1024 x 2.4 GHz) seconds
+
+
+def _valu_table():
+    """VALU wave-instructions per row of every kernel family, from the committed SQ_INSTS_VALU passes (profiles/valu_per_row.json,
+    written by tools/summarise_profiles.py from rocprofv3 --pmc runs of the same workloads) -- NOT measured in this run; the tag
+    says which profile session."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_per_row.json")))
+    except Exception:  # noqa: BLE001
+        return {"tag": None, "kernels": {}}
+
+
+def two_roofs(kernel_name, rows, bytes_required, kernel_ms, table=None):
+    """Both roofs of one launch: HBM (bytes the resident layout must read / 8 TB/s) and fp64 issue (VALU wave-instructions x 4
+    cycles / (1024 SIMDs x 2.4 GHz)); `bound` = the one that leaves less headroom."""
+    table = table or _valu_table()
+    fam = kernel_name.split("<")[0].split(" ")[0]
+    ent = table.get("kernels", {}).get(kernel_name) or table.get("kernels", {}).get(fam)
+    ks = kernel_ms * 1e-3
+    frac_hbm = bytes_required / ks / 1e9 / HBM_PEAK_GBS if ks > 0 else None
+    out = {"frac_hbm": frac_hbm, "frac_fp64_issue": None, "bound": "hbm", "valu_per_row": None, "valu_source": None}
+    if ent and ks > 0:
+        v = float(ent["valu_per_row"])
+        out["valu_per_row"] = v
+        out["valu_source"] = f"{ent.get('source')} (tag {table.get('tag')}; SQ_INSTS_VALU of a committed rocprofv3 --pmc pass, not measured in this run)"
+        out["frac_fp64_issue"] = rows * v * 4.0 / (N_SIMDS * CLOCK_HZ) / ks
+        if frac_hbm is None or out["frac_fp64_issue"] > frac_hbm:
+            out["bound"] = "fp64_issue"
+    return out
 
 CONFIGS = {
     "c2p": {"tracks": 10_000, "rows": 10_000, "label": "SURVEY 8(d) C2' (BASELINE metric)"},
@@ -265,14 +297,22 @@ def build_handles(args, dev, rank, world):
 
 
 def join_ranks(handles, rank, world, dist):
-    """ncclCommInitRank: the engines of all ranks, one communicator per handle.  If RCCL cannot be brought up on this
-    node (an exception on ANY rank -- agreed on over the gloo group), the run still produces a line, with the sum over
-    ranks done by the host over gloo after every evaluation and SAID SO in config.parallelism: a slower collective, the
-    same per-rank engine.  (The engine itself has no such fallback: ssde_comm_init_rank fails loudly.)"""
+    """ncclCommInitRank: the engines of all ranks into one communicator per handle that needs one (c5: ONE communicator, joined by
+    the first handle -- the three handles' result vectors are summed by a single collective per step, main()).  If RCCL cannot
+    be brought up on this node (an exception on ANY rank -- agreed on over the gloo group BEFORE anyone enters the next
+    collective call, so that no rank is left alone inside ncclCommInitRank), the run still produces a line, with the sum over
+    ranks done by the host over gloo after every evaluation and SAID SO in config.parallelism: a slower collective, the same
+    per-rank engine.  (The engine itself has no such fallback: ssde_comm_init_rank fails loudly.)"""
     import torch
     from smoothsde_amd import capi
+
+    def agreed(local_err):
+        flag = torch.tensor([1.0 if local_err else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag.item() > 0
+
     err = ""
-    for h in handles:
+    for h in handles[:1]:
         try:
             if os.environ.get("SSDE_BENCH_FAKE_RCCL_FAILURE"):        # rehearsal of the fallback on a one-GPU box
                 raise RuntimeError("faked for a rehearsal")
@@ -280,21 +320,35 @@ def join_ranks(handles, rank, world, dist):
         except Exception as e:                            # rank 0 could not even make an id
             box, err = [None], f"ssde_comm_unique_id: {e}"
         dist.broadcast_object_list(box, src=0)
-        if box[0] is not None and not err:
-            try:
-                h.eng.comm_init(world, rank, box[0])
-            except Exception as e:
-                err = f"ssde_comm_init_rank: {e}"
-        else:
+        if box[0] is None:
             err = err or "no communicator id from rank 0"
-    flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if flag.item() > 0:
-        for h in handles:                                 # some engine joined a communicator others did not: start over without
+        if agreed(err):                                   # nobody calls ncclCommInitRank unless everybody will
+            err = err or "RCCL initialisation failed on another rank"
+            break
+        try:
+            h.eng.comm_init(world, rank, box[0])
+        except Exception as e:
+            err = f"ssde_comm_init_rank: {e}"
+        if agreed(err):
+            err = err or "RCCL initialisation failed on another rank"
+            break
+    if err:
+        for h in handles:                                 # some engine may have joined a communicator others did not: start over without
             h.eng.close()
             h.eng = capi.Engine(h.pb)
-        return err or "RCCL initialisation failed on another rank"
+        return err
     return None
+
+
+def _roofs_of(inf, kern_ms):
+    """kernel family + both roofs of a secondary workload's dominant launch (`frac` stays the HBM fraction, as before)"""
+    from smoothsde_amd import capi
+    kname = capi.KERNEL_NAMES.get(inf["kernel_id"], "?")
+    if not kern_ms or kern_ms <= 0:
+        return {"kernel": kname, "frac": None, "frac_hbm": None, "frac_fp64_issue": None, "bound": None, "rows_in_launch": inf["main_kernel_rows"]}
+    tr = two_roofs(kname, inf["main_kernel_rows"], inf["required_bytes_per_row"] * inf["main_kernel_rows"], kern_ms)
+    return {"kernel": kname, "frac": tr["frac_hbm"], "frac_hbm": tr["frac_hbm"], "frac_fp64_issue": tr["frac_fp64_issue"],
+            "bound": tr["bound"], "valu_per_row": tr["valu_per_row"], "rows_in_launch": inf["main_kernel_rows"]}
 
 
 def secondary_workload(name, model, M, T, dev, steps, mutate):
@@ -330,7 +384,7 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
     return {"workload": name, "value": rows * steps / el, "unit": "track-timesteps/s", "steps": steps,
             "ms_per_step": 1e3 * el / steps, "kernel_ms": kern,
             "required_bytes_per_row": inf["required_bytes_per_row"],
-            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            **_roofs_of(inf, kern),
             "window_check_max": chk, "window_retries": inf["window_retries"],
             "rows_tiled": inf["n_rows_tiled"], "groups": inf["n_groups"], "clean_groups": inf["n_clean_groups"],
             "quiet_window": inf["quiet_window"], "quiet_share": inf["quiet_share"]}
@@ -377,7 +431,7 @@ def row_varying_workload(M, T, dev, steps, k_cols=9):
     return {"workload": f"{M} CTCRW x {T}, tau and nu smooth in a covariate ({2 * k_cols} design columns streamed), regular grid",
             "value": inf["n_rows"] * steps / el, "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
             "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]], "required_bytes_per_row": inf["required_bytes_per_row"],
-            "frac": inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            **_roofs_of(inf, kern),
             "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
 
 
@@ -420,7 +474,7 @@ def argos_workload(M, T, dev, steps):
     return {"workload": f"{M} CTCRW x {T} with a per-row 2 x 2 measurement covariance (H_array) and constant tau, nu", "value": inf["n_rows"] * steps / el,
             "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]],
             "required_bytes_per_row": inf["required_bytes_per_row"],
-            "frac": (inf["required_bytes_per_row"] * inf["main_kernel_rows"] / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern > 0 else None,
+            **_roofs_of(inf, kern),
             "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
 
 
@@ -489,6 +543,11 @@ def main():
         return float(buf[0]), buf[1:].numpy()
 
     last = {}
+    one_collective = concurrent and use_comm and not host_reduce
+    if one_collective:
+        # the three handles' result vectors are ONE contiguous buffer: the first handle's communicator sums it in a single
+        # ncclAllReduce per step (its own in-engine collective is deferred), instead of three collectives on three streams
+        handles[0].eng.set_option(capi.OPT_COMM_DEFER, 1)
 
     if not concurrent:
         h0 = handles[0]
@@ -507,14 +566,23 @@ def main():
         def step(k):                                      # the three handles side by side, each on its own stream
             for h in handles:
                 h.eng.eval_device(h.thetas[k], h.out.data_ptr(), order=1, stream=h.stream.cuda_stream)
+            if one_collective:
+                s0 = handles[0].stream
+                for h in handles[1:]:
+                    s0.wait_stream(h.stream)
+                handles[0].eng.comm_allreduce(outs.data_ptr(), outs.numel(), stream=s0.cuda_stream)
             for h in handles:
                 h.stream.synchronize()
             host = outs.cpu().numpy()
             for i, h in enumerate(handles):
-                if not host[i, 1 + h.npar] <= capi.WINDOW_TOL:     # (rare) a hand-over check failed: widen and repeat this handle
+                # (rare) a hand-over check failed: widen and repeat this handle -- the check value is the ranks' sum, so every
+                # rank takes this branch together
+                if not host[i, 1 + h.npar] <= capi.WINDOW_TOL:
                     for _ in range(4):
                         h.eng.widen_windows(4)
                         h.eng.eval_device(h.thetas[k], h.out.data_ptr(), order=1, stream=h.stream.cuda_stream)
+                        if one_collective:
+                            handles[0].eng.comm_allreduce(h.out.data_ptr(), h.out.numel(), stream=h.stream.cuda_stream)
                         h.stream.synchronize()
                         host[i] = h.out.cpu().numpy()
                         if host[i, 1 + h.npar] <= capi.WINDOW_TOL:
@@ -533,12 +601,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    t_step = [t0]
     for k in range(args.steps):
         step(k)
+        t_step.append(time.perf_counter())            # (the synchronous step has returned its result: one clock read per step)
     torch.cuda.synchronize(dev)
     if use_comm:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = 1e3 * np.diff(np.array(t_step))
     if use_comm:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -561,15 +632,23 @@ def main():
     torch.cuda.synchronize(dev)
     if use_comm:
         dist.barrier()
-    t1 = time.perf_counter()
+    stamped_s = 0.0
+    phases = []                                           # per step: where this rank's synchronous evaluation spent its time
     for k in range(args.steps):
+        t1 = time.perf_counter()
         step(k)                                           # the same parameter vectors
+        stamped_s += time.perf_counter() - t1
+        if not concurrent:
+            try:
+                phases.append(handles[0].eng.last_phase_ms())
+            except Exception:  # noqa: BLE001  (a measurement hook must never take the line down)
+                pass
         if (k + 1) % 64 == 0 or k + 1 == args.steps:
             cnt = (k % 64) + 1
             for h in handles:
                 h.ms.extend(h.eng.kernel_ms_history(cnt)[::-1])
     torch.cuda.synchronize(dev)
-    stamped_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    stamped_ms = 1e3 * stamped_s / args.steps
     if use_comm:
         dist.barrier()
     for h in handles:
@@ -610,16 +689,22 @@ def main():
         algo = info["algo_bytes_per_row"] * info["main_kernel_rows"]
         ach = req / (h.kernel_ms * 1e-3) / 1e9
         ach_a = algo / (h.kernel_ms * 1e-3) / 1e9
-        shared = info["path"] == 1 and info["uniform_dt"] and info["n_clean_groups"] * 4 >= info["n_groups"]
-        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        kname = capi.KERNEL_NAMES.get(info["kernel_id"], "?")
+        tr = two_roofs(kname, info["main_kernel_rows"], req, h.kernel_ms, valu_table)
+        return {"bound": tr["bound"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac_hbm": tr["frac_hbm"], "frac_fp64_issue": tr["frac_fp64_issue"], "valu_per_row": tr["valu_per_row"],
+                "valu_source": tr["valu_source"],
+                "roofs_note": "achieved / peak / frac are the HBM roof (bytes the resident layout must read over 8 TB/s); frac_fp64_issue = "
+                              "VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) / kernel time; bound = the larger of the two",
                 "frac_of_measured_copy_6290": ach / 6290.0,       # MI355X_MICROARCH.md: 6.29 TB/s measured copy
                 "required_bytes_per_row": info["required_bytes_per_row"], "algo_bytes_per_row": info["algo_bytes_per_row"],
                 "achieved_algorithmic": ach_a, "frac_algorithmic": ach_a / HBM_PEAK_GBS,
-                "kernel": ("iso_shared_kernel<stationary>" if shared else "iso_mask_kernel") + f" ({h.model})",
+                "kernel": f"{kname} ({h.model})", "kernel_id": info["kernel_id"],
                 "kernel_ms": h.kernel_ms, "required_bytes_per_launch": req, "algo_bytes_per_launch": algo,
                 "rows_in_launch": info["main_kernel_rows"], "clean_groups": info["n_clean_groups"], "groups": info["n_groups"],
                 "kernel_ms_source": "untimed second pass over the same parameter vectors, every launch stamped with HIP events on its stream"}
 
+    valu_table = _valu_table()
     roofs = [roof(h, i) for h, i in zip(handles, infos)]
     dom = int(np.argmax([h.kernel_ms for h in handles]))
     roofline = dict(roofs[dom])
@@ -649,6 +734,20 @@ def main():
         "host_enqueue_ms": host_enq_ms,
         "note": "all kernels of one evaluation incl. the hand-over check and the reduction; from an untimed ssde_eval_device "
                 "pass over the same evaluations between HIP events"}
+    # ---- per rank: rows, and where the stamped pass's synchronous evaluations spent their time (ssde_last_phase_ms) ----------
+    mine = {"rank": rank, "rows": int(rows_rank), "kernel_ms": float(np.mean([h.kernel_ms for h in handles])),
+            "ms_per_step": float(np.mean(step_ms)), "comm_ranks_reported": int(max(i["comm_ranks_reported"] for i in infos))}
+    if phases:
+        for key, out_key in (("kernel", "kernel_stamp_ms"), ("gpu_pre", "gpu_pre_ms"), ("finalize", "finalize_ms"),
+                             ("allreduce", "allreduce_wait_ms"), ("readback", "readback_ms"), ("host_enqueue", "host_enqueue_ms"),
+                             ("host_total", "host_total_ms")):
+            mine[out_key] = float(np.mean([ph[key] for ph in phases]))
+    if use_comm:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
+
     M, T = args.tracks, args.rows
     if args.config == "c5":
         wl = (f"{CONFIGS['c5']['label']}: BM_SSM + OU_SSM + CTCRW sub-batches of {M} tracks each, ragged lengths U[{T // 2}, {T}], d=2, "
@@ -664,24 +763,32 @@ def main():
         "value": value, "unit": "track-timesteps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_stamped": stamped_ms,
+        "extra": {"ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(np.min(step_ms)),
+                  "ms_per_step_p90": float(np.percentile(step_ms, 90)), "ms_per_step_max": float(np.max(step_ms)),
+                  "note": "spread of THIS rank's timed steps (one clock read after every synchronous step); `value` is all rows over "
+                          "the whole timed region, max over ranks"},
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl, "config": args.config, "tracks": M, "rows_per_track": T, "total_rows": total_rows,
                    "rows_this_rank": rows_rank, "seed": args.seed,
                    "nllk_at_last_step": val,                # the same number at every N under strong scaling (same batch, same theta)
                    "n_free_par": [i["n_free"] for i in infos] if concurrent else info0["n_free"],
-                   "engine_path": capi.PATH_NAMES[info0["path"]],
+                   "engine_path": capi.PATH_NAMES[info0["path"]], "engine_kernel": capi.KERNEL_NAMES.get(info0["kernel_id"], "?"),
+                   "comm_ranks_requested": max(i["comm_ranks"] for i in infos) if use_comm else 0,
+                   "comm_ranks_reported": max(i["comm_ranks_reported"] for i in infos),       # ncclCommCount of the joined communicator (0: none)
                    "uniform_dt": info0["uniform_dt"], "workgroups": info0["n_kernel_blocks"],
                    "rows_tiled": info0["n_rows_tiled"], "groups": info0["n_groups"], "clean_groups": info0["n_clean_groups"],
                    "lanes_per_track": info0["lanes_per_track"], "window_rows": info0["window"],
                    "window_check": check_max, "window_retries": sum(i["window_retries"] for i in infos),
                    "parallelism": f"tracks x{world}" + ("" if not use_comm else
-                                                         (", in-engine ncclAllReduce of 2+p doubles" + (" per handle" if concurrent else "")
+                                                         ((", ONE ncclAllReduce of the three handles' 2+p doubles per step (ssde_comm_allreduce)" if concurrent
+                                                           else ", in-engine ncclAllReduce of 2+p doubles")
                                                           if not host_reduce else
                                                           f", HOST all-reduce over gloo after every evaluation (RCCL could not be brought up: {host_reduce})")),
                    "api": "ssde_eval_device on one stream per handle + one read-back" if concurrent else "ssde_eval (synchronous C ABI call)",
                    "data_generator": "ssde_simulate (HIP, Philox4x32-10 keyed by seed / global track / row)"},
         "roofline": roofline,
+        "per_rank": per_rank,
     }
     for h in handles:
         h.eng.close()

@@ -38,6 +38,10 @@
  *   ssde_simulate      <- SDE$simulate          (R/sde.R:1393-1500; CTCRW_cov, R/utility.R:188-196): exact-transition
  *                         simulation of a batch of tracks, written straight into HBM in the reference's long format
  *   ssde_set_option    <- (new) per-handle switches of the measurement hooks
+ *   ssde_last_phase_ms <- (new) measurement hook: where the last stamped synchronous evaluation spent its time (kernel,
+ *                         finalising launch, all-reduce wait, host side) -- what a multi-GPU run's per-rank account is made of
+ *   ssde_comm_allreduce <- (new) sums a caller's HBM buffer over the handle's communicator: hosts that drive several
+ *                         handles at once issue ONE collective for all of them (SSDE_OPT_COMM_DEFER)
  *   ssde_destroy       <- external-pointer finalizer of the ADFun object
  *   ssde_last_error    <- Rf_error text         (src/smoothSDE.cpp:25)
  *
@@ -71,7 +75,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 9
+#define SSDE_ABI_VERSION 10
 
 /* model codes: DATA_STRING(type) of src/smoothSDE.cpp:12-27 */
 enum {
@@ -86,6 +90,28 @@ enum {
                               state (1, lipid mass), Z_i = (a1, a2 / R_i), H_i = tau^2 / h_i; needs a0, eseal_h, eseal_R */
     SSDE_MODEL_CIR    = 7  /* "CIR"     -> nllk_sde + tr_dens CIR branch (tr_dens.hpp:53-67): par = (log mu_a, log beta, log sigma),
                               positive observations; log I_q(x) is formed directly (no overflow at large x) */
+};
+
+/* Which kernel family ran the last evaluation's rows (ssde_info_t.kernel_id).  `path` says which engine path a handle is on;
+ * this says which of that path's kernels the dispatch picked for the batch at hand (kernel map). */
+enum {
+    SSDE_KERNEL_NONE          = 0,  /* nothing evaluated yet */
+    SSDE_KERNEL_DIRECT        = 1,  /* direct_kernel: BM / BM_t / OU / CIR transition densities, any slot layout (k_direct.hip) */
+    SSDE_KERNEL_DIRECT_FAST   = 2,  /* direct_fast_kernel: at most two parameters with streamed / table-evaluated columns */
+    SSDE_KERNEL_ISO_SHARED    = 3,  /* iso_shared_kernel: regular grid, complete tracks -- shared covariance, stationary lanes */
+    SSDE_KERNEL_ISO_MASK      = 4,  /* iso_mask_kernel: the lane's own covariance, irregular grid (k_iso.hip) */
+    SSDE_KERNEL_ISO_MASK_UNI  = 5,  /* ... regular grid with missing rows (transition hoisted) */
+    SSDE_KERNEL_ISO_QUIET     = 6,  /* iso_quiet_kernel: ... with quiet rows (stationary lanes between missing rows) */
+    SSDE_KERNEL_ISO_MIXED     = 7,  /* iso_shared_kernel and a general kernel side by side (complete and incomplete wavefronts) */
+    SSDE_KERNEL_ISO_SPLIT     = 8,  /* iso_kernel: gradient directions split over several waves per (group, window) */
+    SSDE_KERNEL_ISO_DRIFT     = 9,  /* iso_drift_kernel: shared covariance + streamed row-varying drift (k_iso_drift.hip) */
+    SSDE_KERNEL_ISO_DRIFT_GEN = 10, /* iso_drift_general_kernel: the same model with the lane's own covariance */
+    SSDE_KERNEL_ISO_COLVAR    = 11, /* iso_colvar_kernel: row-varying tau / nu, eight-wave pipeline (k_iso_colvar.hip) */
+    SSDE_KERNEL_ISO_FEW       = 12, /* iso_few_kernel: ... few design columns, one wave per (group, window) */
+    SSDE_KERNEL_ISO_FULL      = 13, /* iso_full_kernel: per-row H_array, constant tau / nu (4 x 4 covariance lanes) */
+    SSDE_KERNEL_DENSE         = 14, /* dense_kernel: general Kalman step, lane = track (k_dense.hip) */
+    SSDE_KERNEL_TV            = 15, /* tv_filter_kernel: row-varying coefficients, lane = gradient direction (k_tv.hip) */
+    SSDE_KERNEL_TV_DENSE      = 16  /* ... with full-covariance lanes (k_tv_dense.hip; ESEAL_SSM too) */
 };
 
 /* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with
@@ -238,9 +264,12 @@ typedef struct ssde_info_t {
     int32_t n_clean_groups; /* ... of which every track has every row: the shared-covariance kernel's share on a regular grid */
     int32_t quiet_window;   /* > 0: the general kernel of the last evaluation ran rows that lie this many rows past the last missing
                                observation of their wavefront with the stationary gains; 0: no such rows */
-    int32_t reserved_;
+    int32_t kernel_id;      /* SSDE_KERNEL_*: the kernel family that ran the rows of the last evaluation -- ABI 10 */
     double  quiet_share;    /* share of the blocks of wavefronts with missing rows that qualify, at a nominal 128-row memory
                                (found at ssde_create; 0 when the layout has no such wavefront or the grid is irregular) */
+    int32_t comm_ranks_reported; /* what ncclCommCount says about the joined communicator (0 = none joined); comm_ranks above
+                               echoes the caller's argument -- ABI 10 */
+    int32_t reserved2_;
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the
@@ -297,6 +326,20 @@ double ssde_last_kernel_ms(const ssde_handle *h);
  * AFTER the timed region (bench.py) instead of querying events between them. */
 int ssde_kernel_ms_history(const ssde_handle *h, double *ms, int32_t n);
 
+/* Where the last SYNCHRONOUS ssde_eval spent its time, in milliseconds (single-device handle; valid after an evaluation made with
+ * SSDE_OPT_KERNEL_STAMPS on, zeros otherwise).  GPU-side phases come from HIP events on the evaluation's stream:
+ *   ms[0] host_total   wall time of the call
+ *   ms[1] host_enqueue ... of which: planning, gain table, launches (the host side until everything was enqueued)
+ *   ms[2] gpu_pre      first operation of the evaluation on the stream -> the dominant kernel's begin (uploads, launch gap)
+ *   ms[3] kernel       the dominant kernel (== ssde_last_kernel_ms)
+ *   ms[4] finalize     its end -> the end of the finalising launch (hand-over checks + fixed-order sums)
+ *   ms[5] allreduce    ... -> the end of the ncclAllReduce behind it (0 without a communicator): wire time AND the wait for
+ *                      the slowest rank
+ *   ms[6] readback     host_total minus everything above (the blocking copy and what the runtime adds around it)
+ *   ms[7] reserved (0)
+ * Returns SSDE_ERR_ARG for a multi-device parent.  A measurement hook: bench.py gathers it per rank. */
+int ssde_last_phase_ms(ssde_handle *h, double ms[8]);
+
 /* Drop the memoised last result: the next ssde_eval runs on the device whatever its argument (determinism checks). */
 int ssde_forget(ssde_handle *h);
 
@@ -346,9 +389,17 @@ int ssde_comm_init_rank(ssde_handle *h, int32_t n_ranks, int32_t rank, const voi
 /* Per-handle options.
  *   SSDE_OPT_KERNEL_STAMPS (default 1): every evaluation stamps its dominant kernel with a HIP event pair
  *       (ssde_last_kernel_ms / ssde_kernel_ms_history).  0 = plain launches: a few microseconds less per evaluation,
- *       which is what a fitting host wants; measurement passes switch it back on. */
-enum { SSDE_OPT_KERNEL_STAMPS = 1 };
+ *       which is what a fitting host wants; measurement passes switch it back on.
+ *   SSDE_OPT_COMM_DEFER (default 0): 1 = ssde_eval_device leaves this rank's PARTIAL [nllk, grad..., check] in the caller's
+ *       buffer and the caller sums it over the ranks itself (ssde_comm_allreduce) -- a host that evaluates several handles
+ *       side by side packs their result vectors and issues one collective for all of them instead of one per handle on
+ *       as many streams.  ssde_eval ignores it. */
+enum { SSDE_OPT_KERNEL_STAMPS = 1, SSDE_OPT_COMM_DEFER = 2 };
 int ssde_set_option(ssde_handle *h, int32_t option, int64_t value);
+
+/* Sum buf_dev[0 .. count) (doubles, HBM) over the ranks of the communicator `h` joined, in place, on `stream` (enqueue only:
+ * one ncclAllReduce).  SSDE_ERR_ARG if the handle has joined none. */
+int ssde_comm_allreduce(ssde_handle *h, double *buf_dev, int64_t count, void *stream);
 
 /* Synthetic track batches in HBM: the exact-transition simulator of SDE$simulate (R/sde.R:1434-1478: BM increments,
  * OU transition density, CTCRW joint (velocity, position) transition with CTCRW_cov of R/utility.R:188-196), one

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 MODEL_CODES = {"BM": 0, "OU": 1, "BM_SSM": 2, "OU_SSM": 3, "CTCRW": 4, "BM_t": 5, "ESEAL_SSM": 6, "CIR": 7}
 KALMAN_MODELS = ("BM_SSM", "OU_SSM", "CTCRW")
@@ -72,7 +72,13 @@ class SsdeSimDesc(C.Structure):
                 ("reserved", C.c_int32)]
 
 
-OPT_KERNEL_STAMPS = 1
+OPT_KERNEL_STAMPS, OPT_COMM_DEFER = 1, 2
+# ssde_info_t.kernel_id (include/ssde.h: SSDE_KERNEL_*): the kernel family that ran the rows of the last evaluation
+KERNEL_NAMES = {0: "none", 1: "direct_kernel", 2: "direct_fast_kernel", 3: "iso_shared_kernel", 4: "iso_mask_kernel",
+                5: "iso_mask_kernel<uniform grid>", 6: "iso_quiet_kernel", 7: "iso_shared_kernel + general kernel (mixed batch)",
+                8: "iso_kernel (direction parts)", 9: "iso_drift_kernel", 10: "iso_drift_general_kernel", 11: "iso_colvar_kernel",
+                12: "iso_few_kernel", 13: "iso_full_kernel", 14: "dense_kernel", 15: "tv_filter_kernel", 16: "tv_filter_kernel<dense lanes>"}
+PHASE_NAMES = ("host_total", "host_enqueue", "gpu_pre", "kernel", "finalize", "allreduce", "readback", "reserved")
 
 
 class SsdeInfo(C.Structure):
@@ -86,7 +92,8 @@ class SsdeInfo(C.Structure):
         ("required_bytes_per_row", C.c_double), ("n_evals", C.c_int64), ("n_memo_hits", C.c_int64),
         ("n_devices", C.c_int32), ("comm_ranks", C.c_int32), ("window_check_max", C.c_double),
         ("n_rows_tiled", C.c_int64), ("n_groups", C.c_int32), ("n_clean_groups", C.c_int32),
-        ("quiet_window", C.c_int32), ("reserved_", C.c_int32), ("quiet_share", C.c_double),
+        ("quiet_window", C.c_int32), ("kernel_id", C.c_int32), ("quiet_share", C.c_double),
+        ("comm_ranks_reported", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
     def as_dict(self):
@@ -508,6 +515,10 @@ def load_library():
     lib.ssde_hess.restype = C.c_int
     lib.ssde_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     lib.ssde_set_option.restype = C.c_int
+    lib.ssde_last_phase_ms.argtypes = [C.c_void_p, _dp]
+    lib.ssde_last_phase_ms.restype = C.c_int
+    lib.ssde_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ssde_comm_allreduce.restype = C.c_int
     if lib.ssde_abi_version() != ABI_VERSION:
         raise RuntimeError("libssde_hip.so ABI version mismatch")
     _LIB = lib
@@ -515,14 +526,15 @@ def load_library():
 
 
 class EngineError(RuntimeError):
-    pass
+    """a non-zero status from the C ABI; `.status` holds it (include/ssde.h: SSDE_ERR_*)"""
+    status = None
 
 
 WINDOW_TOL = 1e-11  # largest tolerated relative hand-over disagreement between time windows
 
 EXPORTED_SYMBOLS = ("ssde_create", "ssde_eval", "ssde_eval_device", "ssde_penalty", "ssde_report", "ssde_widen_windows", "ssde_relax_windows",
                     "ssde_info", "ssde_destroy", "ssde_last_error", "ssde_abi_version", "ssde_comm_unique_id", "ssde_comm_init_rank", "ssde_forget", "ssde_laplace_eval", "ssde_last_kernel_ms", "ssde_kernel_ms_history",
-                    "ssde_simulate", "ssde_set_option", "ssde_hess")
+                    "ssde_simulate", "ssde_set_option", "ssde_hess", "ssde_last_phase_ms", "ssde_comm_allreduce")
 
 COMM_ID_BYTES = 128
 
@@ -608,7 +620,9 @@ class Engine:
     def _check(self, st):
         if st != 0:
             msg = self.lib.ssde_last_error(self._h)
-            raise EngineError(f"ssde call failed ({st}): {msg.decode() if msg else ''}")
+            err = EngineError(f"ssde call failed ({st}): {msg.decode() if msg else ''}")
+            err.status = int(st)
+            raise err
 
     def info(self) -> dict:
         inf = SsdeInfo()
@@ -674,6 +688,16 @@ class Engine:
         out = np.zeros(int(n))
         self._check(self.lib.ssde_kernel_ms_history(self._h, out.ctypes.data_as(_dp), int(n)))
         return out
+
+    def last_phase_ms(self) -> dict:
+        """Where the last stamped synchronous eval spent its time (ssde_last_phase_ms), in ms, by PHASE_NAMES."""
+        out = np.zeros(8)
+        self._check(self.lib.ssde_last_phase_ms(self._h, out.ctypes.data_as(_dp)))
+        return dict(zip(PHASE_NAMES[:7], out[:7].tolist()))
+
+    def comm_allreduce(self, buf_ptr: int, count: int, stream: int = 0):
+        """Sum `count` doubles at the HBM address buf_ptr over the ranks of this handle's communicator (enqueue only)."""
+        self._check(self.lib.ssde_comm_allreduce(self._h, C.c_void_p(buf_ptr), int(count), C.c_void_p(stream)))
 
     def hess(self, par, idx):
         """ssde_hess: exact second derivatives of the joint penalised nllk over the full-parameter indices `idx` (direct

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void iso_finalize_kernel(const IsoArgs A, cons
             const unsigned long long v = atomicExch((unsigned long long*)A.quiet_flag, 0ull);
             if (v) dep = atomicMax((unsigned long long*)A.chk_out, v);
         }
-        publish_if_last(R, reduce_slot(R, blockIdx.x - n_check, sh) + (dep & 0ull));
+        publish_if_last(R, reduce_slot(R, blockIdx.x - n_check, sh) ^ dep);      // (the count depends on BOTH atomics' return values)
     }
 }
 

@@ -140,6 +140,18 @@ int ssde_simulate(const ssde_sim_desc* d, double* id_dev, double* times_dev, dou
     case SSDE_MODEL_BM: case SSDE_MODEL_BM_SSM: a.kind = 2; break;
     default: g_sim_error = "Simulation not implemented yet for this model (R/sde.R:1496)"; return SSDE_ERR_MODEL;
     }
+    // the parameters the Cholesky factors below are formed from: a NaN / Inf factor would be written into HBM silently
+    {
+        const bool err_obs = d->model == SSDE_MODEL_CTCRW || d->model == SSDE_MODEL_OU_SSM || d->model == SSDE_MODEL_BM_SSM;
+        bool ok = !err_obs || (d->sigma_obs >= 0.0 && std::isfinite(d->sigma_obs));
+        if (a.kind == 0) ok = ok && d->tau > 0.0 && std::isfinite(d->tau) && d->nu > 0.0 && std::isfinite(d->nu);
+        else if (a.kind == 1) ok = ok && d->tau > 0.0 && std::isfinite(d->tau) && d->kappa >= 0.0 && std::isfinite(d->kappa);
+        else ok = ok && d->sigma >= 0.0 && std::isfinite(d->sigma);
+        if (!ok) {
+            g_sim_error = "ssde_simulate: tau > 0, nu > 0 (CTCRW), kappa >= 0 (OU), sigma >= 0 (BM) and sigma_obs >= 0, all finite, are required";
+            return SSDE_ERR_ARG;
+        }
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { g_sim_error = "no HIP device visible: there is no CPU fallback"; return SSDE_ERR_NODEVICE; }
     if (d->device >= 0 && hipSetDevice(d->device) != hipSuccess) { g_sim_error = "hipSetDevice failed"; return SSDE_ERR_HIP; }

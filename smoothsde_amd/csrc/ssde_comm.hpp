@@ -3,7 +3,7 @@
 // The library does not link librccl: a one-GPU host (the reference's usual case, one R process on one device) should
 // not pay for loading it.  The first multi-GPU use dlopen()s "librccl.so.1" -- the soname resolves to the copy the
 // process already holds (PyTorch ships one) or to the ROCm installation through this library's RUNPATH -- and binds
-// the seven calls the engine makes.  Types are taken from <rccl/rccl.h>; nothing else of RCCL is used.
+// the eight calls the engine makes.  Types are taken from <rccl/rccl.h>; nothing else of RCCL is used.
 #ifndef SSDE_COMM_HPP
 #define SSDE_COMM_HPP
 
@@ -20,6 +20,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -43,6 +44,7 @@ struct RcclApi {
         bind(CommInitRank, "ncclCommInitRank");
         bind(CommInitAll, "ncclCommInitAll");
         bind(CommDestroy, "ncclCommDestroy");
+        bind(CommCount, "ncclCommCount");
         bind(AllReduce, "ncclAllReduce");
         bind(GroupStart, "ncclGroupStart");
         bind(GroupEnd, "ncclGroupEnd");

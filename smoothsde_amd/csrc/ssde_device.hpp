@@ -111,6 +111,8 @@ struct IsoArgs {
     double* chk_out;             // &out[n_out]: zeroed by the main kernel, raised by the finalize kernel's checks
     double* wave_clock;          // debugging (SSDE_WAVE_CLOCK=file at create): [work item][4] = start, end (wall_clock64, 100 MHz), HW_ID, rows
     int deep_prefetch;           // shared-covariance kernel, d = 2: three-block rotation (two blocks in flight) instead of the ping-pong pair
+    int stream_nt;               // non-temporal loads of the tile stream (a batch far larger than the Infinity Cache); 0: ordinary loads -- the
+                                 // batch fits that cache and is still there at the next evaluation (k_iso_shared.inc: load_obs_block)
     int bnd_stride;              // components per hand-over dump in `bnd` (NSTATE_MAX, or more with drift columns)
     // Row-varying DRIFT on the shared-covariance path (k_iso_drift.hip): mu_a(i) = mu[a] + sum_k coef_k X_k(i) over the
     // streamed design columns that feed dimension a (nllk_ctcrw.hpp:143-149, 211-212; nllk_ou_ssm.hpp:113-124); tau,
@@ -457,6 +459,41 @@ hipError_t launch_tv_prepare(const TvArgs& a, hipStream_t s);
 hipError_t launch_tv_filter(const TvArgs& a, bool want_grad, hipStream_t s);
 hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s);
 
+// ---- exact second derivatives on the lane = direction path (k_tv_hess.hip, ssde_hdual.hpp) -----------------------------
+// one wavefront lane per coefficient PAIR, the primal recursion in hyper-dual arithmetic; isotropic lanes only
+constexpr int HESS_RS = 8;        // doubles per row record: dt | the row's linear predictors p_0 .. p_3 | y_0 y_1 | 0
+constexpr int HESS_NSTATE = 28;   // doubles per lane dumped at a window hand-over: (2 D + 3) hyper-dual numbers (CTCRW, d = 2)
+struct TvHessArgs {
+    const double* times;         // [n]
+    const double* obs;           // [n x d] column-major
+    const double* colbuf;        // streamed design columns
+    int64_t col_stride;
+    int64_t n;
+    int d, model, any_nan;
+    const SlotTable* slots;      // device
+    int n_slots;
+    const double* par;           // device, full parameter vector
+    double* rec;                 // [n][HESS_RS]
+    const double* wdir;          // [n][ndp]: d par_row / d coefficient of every direction (TvArgs.wdir)
+    int ndp;
+    const TvDir* dirs;           // [ndp]
+    const int64_t* trk_row0;     // [n_tracks]
+    const int32_t* trk_ns;
+    const double* a0;            // [n_tracks][sdim]
+    const TvItem* items;         // (track, window c of nc, block of 64 pairs), ordered track / pair block / window
+    int n_items;
+    int window;                  // warm-up rows
+    const int16_t* pair_a;       // [n_pairs] direction of the pair's first coefficient (index into dirs / wdir)
+    const int16_t* pair_b;
+    int n_pairs, n_pb;           // pairs, blocks of 64 pairs
+    double p0[3];
+    double last_dt;
+    double* bnd;                 // [n_items][2][HESS_NSTATE][64]
+    double* part;                // [n_items][4][64]: ab | a | b | value part of every lane's likelihood
+    double* out;                 // [4][n_pb][64] sums over (track, window) + [1] largest hand-over disagreement
+};
+hipError_t launch_tv_hess(const TvHessArgs& a, hipStream_t s);
+
 // ---- device helpers -------------------------------------------------------------------------------
 // Window geometry shared by the kernels, the hand-over check and the engine.
 //   t0 == 0 : n_chunks equal windows over [0, L)
@@ -468,30 +505,43 @@ hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s);
 __host__ __device__ inline void window_bounds(int L, int n_chunks, int window, int t0, int c, int& s_begin, int& s_acc,
                                               int& s_end, int delta_rows = -1) {
     if (n_chunks <= 1) { s_begin = 0; s_acc = 0; s_end = L; return; }
+    // Equal windows are equal up to ONE alignment unit: `units` units of WIN_ALIGN rows are dealt to `nw` windows, the first
+    // units % nw of them get one more.  (Round 3 rounded every window's length up instead: one rank's share of a strong-scaled
+    // batch -- 42 windows over 10^4 rows -- ran 256-row windows where 241 were needed, its last two windows were empty and every
+    // other wave walked 5 % more rows than its share; profiles/r04_a_wave_clock_share8.txt.)
     if (t0 > 0) {
         if (c == 0) { s_begin = 0; s_acc = 0; s_end = L < t0 ? L : t0; return; }
-        // the wave that owns window 1 also runs window 0 first (and window 0's rows cost ~1.5x): window 1
+        // the wave that owns window 1 also runs window 0 first (and window 0's rows cost more): window 1
         // is shortened by delta so that all waves finish together
         const int delta = delta_rows >= 0 ? delta_rows : (3 * t0 / 2 + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
         const int rest = L > t0 ? L - t0 : 0;
-        int cl = ((rest + delta + n_chunks - 2) / (n_chunks - 1) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
+        const int nw = n_chunks - 1;
+        const int units = (rest + delta + WIN_ALIGN - 1) / WIN_ALIGN, per = units / nw, extra = units % nw;
+        const int cl = (per + (extra ? 1 : 0)) * WIN_ALIGN;         // the longest window
         if (cl <= delta + WIN_ALIGN) {
             // Short tracks (C2: 10^3 rows): the transient is worth more than a whole window.  Its wave gets a token
             // window 1 and windows 2.. share the rest EQUALLY (the geometry above would leave the last ones empty).
             const int w1 = rest < 2 * WIN_ALIGN ? rest : 2 * WIN_ALIGN;
-            const int cl2 = n_chunks > 2 ? ((rest - w1 + n_chunks - 3) / (n_chunks - 2) + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN : 0;
             if (c == 1) { s_acc = t0; s_end = n_chunks > 2 ? t0 + w1 : L; }
-            else { s_acc = t0 + w1 + (c - 2) * cl2; s_end = s_acc + cl2; }
+            else {
+                const int nw2 = n_chunks - 2;
+                const int u2 = (rest - w1 + WIN_ALIGN - 1) / WIN_ALIGN, per2 = u2 / nw2, ex2 = u2 % nw2;
+                const int k = c - 2;
+                s_acc = t0 + w1 + (k * per2 + (k < ex2 ? k : ex2)) * WIN_ALIGN;
+                s_end = t0 + w1 + ((k + 1) * per2 + (k + 1 < ex2 ? k + 1 : ex2)) * WIN_ALIGN;
+            }
             if (s_acc > L) s_acc = L;
             if (s_end > L) s_end = L;
         } else {
-            s_acc = (c == 1) ? t0 : t0 + (c - 1) * cl - delta; if (s_acc > L) s_acc = L;
-            s_end = t0 + c * cl - delta; if (s_end > L) s_end = L; if (s_end < s_acc) s_end = s_acc;
+            const int e0 = t0 - delta + ((c - 1) * per + (c - 1 < extra ? c - 1 : extra)) * WIN_ALIGN;   // end of window c - 1
+            const int e1 = t0 - delta + (c * per + (c < extra ? c : extra)) * WIN_ALIGN;
+            s_acc = (c == 1) ? t0 : e0; if (s_acc > L) s_acc = L;
+            s_end = e1; if (s_end > L) s_end = L; if (s_end < s_acc) s_end = s_acc;
         }
     } else {
-        const int cl = ((L + n_chunks - 1) / n_chunks + WIN_ALIGN - 1) / WIN_ALIGN * WIN_ALIGN;
-        s_acc = c * cl; if (s_acc > L) s_acc = L;
-        s_end = s_acc + cl; if (s_end > L) s_end = L;
+        const int units = (L + WIN_ALIGN - 1) / WIN_ALIGN, per = units / n_chunks, extra = units % n_chunks;
+        s_acc = (c * per + (c < extra ? c : extra)) * WIN_ALIGN; if (s_acc > L) s_acc = L;
+        s_end = ((c + 1) * per + (c + 1 < extra ? c + 1 : extra)) * WIN_ALIGN; if (s_end > L) s_end = L;
     }
     s_begin = s_acc - window; if (s_begin < 0) s_begin = 0;
 }
@@ -507,7 +557,12 @@ __device__ __forceinline__ void publish_if_last(const ReduceArgs& R, unsigned lo
     if (threadIdx.x >= WAVE) return;               // wave 0 (thread 0 carried the block's result)
     unsigned old = 0;
     if (threadIdx.x == 0) {
-        const unsigned one = 1u + (unsigned)(dep & 0ull);     // (a data dependency on the atomic's return value)
+        // A data dependency on the atomic's RETURN value, one the compiler cannot fold away (`1 + (dep & 0)` was folded: the
+        // exchange became a non-returning atomic and the add followed it with no s_waitcnt in between -- ADVICE r03): the
+        // operand of the add is produced by instructions that read the returned register, after an explicit wait for it.
+        const unsigned lo = (unsigned)dep;
+        unsigned one;
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_and_b32 %0, 0, %1\n\tv_add_u32 %0, 1, %0" : "=v"(one) : "v"(lo) : "memory");
         old = __hip_atomic_fetch_add(R.pub_count, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     old = __shfl(old, 0, WAVE);

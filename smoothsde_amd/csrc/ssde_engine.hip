@@ -32,15 +32,16 @@ void release_device(ssde_handle* h) {
         if (hipSetDevice(h->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
             hipMemcpy(w.data(), h->wave_clock.p, w.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             if (FILE* f = fopen(h->wave_clock_file.c_str(), "w")) {
-                fprintf(f, "# work item, start, end (100 MHz ticks), HW_ID; windows %d, warm-up %d, t0 %d\n", h->last_chunks, h->last_window, h->last_t0);
+                fprintf(f, "# work item, start, end (100 MHz ticks), HW_ID, rows; windows %d, warm-up %d, t0 %d, t0_delta %d, groups %d, longest group %d\n", h->last_chunks, h->last_window, h->last_t0, h->last_t0_delta, h->n_groups, h->glen_max);
                 for (int i = 0; i < h->wave_clock_items; i++)
                     if (h->drift == 3) fprintf(f, "%d %.1f %.1f %.1f %.1f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2], w[4 * (size_t)i + 3]);
-                    else if (w[4 * (size_t)i + 3] != 0.0) fprintf(f, "%d %.0f %.0f %.0f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2]);
+                    else if (w[4 * (size_t)i + 3] != 0.0) fprintf(f, "%d %.0f %.0f %.0f %.0f\n", i, w[4 * (size_t)i], w[4 * (size_t)i + 1], w[4 * (size_t)i + 2], w[4 * (size_t)i + 3] - 1.0);
                 fclose(f);
             }
         }
     }
     h->wave_clock.release();
+    for (hipEvent_t& e : h->ev_ph) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     h->cv_ranges.release(); h->cv_parts.release();
     if (h->cv_ranges_pinned) { (void)hipHostFree(h->cv_ranges_pinned); h->cv_ranges_pinned = nullptr; }
     h->hs_partials.release(); h->hs_hess.release(); h->hs_i16.release();
@@ -155,6 +156,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_dense(a, order >= 1, s));
+        h->last_kernel_id = SSDE_KERNEL_DENSE;
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
         h->ev_k_valid = h->stamps; h->last_s_stat = -1;
         if (order >= 1) {
@@ -188,6 +190,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
             if (h->df_jb >= 0 && h->pp_fast[h->df_jb]) f.ppB = h->pp[h->df_jb];
             if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
             HIPCHK(h, launch_direct_fast(f, s));
+            h->last_kernel_id = SSDE_KERNEL_DIRECT_FAST;
             if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
             h->ev_k_valid = h->stamps; h->last_s_stat = -1;
             ra.n_parts = 1; ra.nacc = 1 + MAX_Q + f.ncA + f.ncB; ra.n_blocks = h->direct_blocks;
@@ -216,6 +219,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         if (a.n_slots > 64) { h->err = "direct families: more than 64 coefficients"; return SSDE_ERR_ARG; }
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
         HIPCHK(h, launch_direct(a, s));
+        h->last_kernel_id = SSDE_KERNEL_DIRECT;
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
         h->ev_k_valid = h->stamps; h->last_s_stat = -1;
         ra.n_parts = 1; ra.nacc = 1 + a.n_slots + L.n_decay; ra.n_blocks = h->direct_blocks;
@@ -283,7 +287,7 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
             HIPCHK(h, hipMemcpyAsync(out_dev, nan_vec.data(), (count - 1) * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
         }
         int stw = SSDE_OK;
-        if (!h->comms.empty()) stw = reduce_ranks(h, out_dev, (hipStream_t)stream);
+        if (!h->comms.empty() && !h->comm_defer) stw = reduce_ranks(h, out_dev, (hipStream_t)stream);
         if (stw) return stw;
         // a later synchronous ssde_eval runs the parts on their own stream and shares their work buffers with this evaluation
         for (ssde_handle* sh : h->shards) {
@@ -293,7 +297,7 @@ int ssde_eval_device(ssde_handle* h, const double* par, int32_t n_par_full, int3
         return SSDE_OK;
     }
     int st = eval_device(h, par, order, out_dev, (hipStream_t)stream);
-    if (st == SSDE_OK && !h->comms.empty()) st = reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
+    if (st == SSDE_OK && !h->comms.empty() && !h->comm_defer) st = reduce_ranks(h, out_dev, (hipStream_t)stream);     // one ncclAllReduce of 2 + p doubles on the same stream
     if (st) return st;
     // a later synchronous ssde_eval runs on the handle's own stream and shares this evaluation's work buffers
     HIPCHK(h, hipEventRecord(h->ev_async, (hipStream_t)stream));
@@ -375,15 +379,31 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         if (h->tv_stream) HIPCHK(h, hipStreamWaitEvent(h->tv_stream, h->ev_async, 0));
         h->async_pending = false;
     }
+    // (measurement passes -- SSDE_OPT_KERNEL_STAMPS on -- also mark the evaluation's first operation, the end of its finalising
+    //  launch and the end of the all-reduce on the stream: ssde_last_phase_ms)
+    const bool ph = h->stamps && h->path != PATH_TV;
+    const auto ph_t0 = std::chrono::steady_clock::now();
+    auto ph_mark = [&](int k) -> hipError_t {
+        if (!ph) return hipSuccess;
+        if (!h->ev_ph[k]) { hipError_t e = hipEventCreate(&h->ev_ph[k]); if (e != hipSuccess) return e; }
+        return hipEventRecord(h->ev_ph[k], 0);
+    };
+    auto ph_ms = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    h->ph_valid = false;
     if (!h->comms.empty()) {
         // the collective sits between the finalize launch and the read-back, on the same stream
+        HIPCHK(h, ph_mark(0));
         h->sync_call = true;
         int st = eval_device(h, par, order, h->out.p, 0);
         h->sync_call = false;
         if (st) return st;
+        HIPCHK(h, ph_mark(1));
         st = reduce_ranks(h, h->out.p, 0);
         if (st) return st;
+        HIPCHK(h, ph_mark(2));
+        h->ph_host_enq_ms = ph_ms(ph_t0);
         HIPCHK(h, hipMemcpy(o, h->out.p, nout * 8, hipMemcpyDeviceToHost));
+        h->ph_host_total_ms = ph_ms(ph_t0); h->ph_valid = ph; h->ph_has_comm = true;
         return SSDE_OK;
     }
     if (h->path == PATH_TV && !h->env_no_graph && h->tv_stats_valid) {
@@ -403,11 +423,18 @@ int run_once(ssde_handle* h, const double* par, int order, double* o) {
         memcpy(o, h->out_pinned, nout * 8);
         return SSDE_OK;
     }
+    HIPCHK(h, ph_mark(0));
     h->sync_call = true;
     h->pub_request = true;
     int st = eval_device(h, par, order, h->out.p, 0);
     h->sync_call = false;
     if (st) return st;
+    HIPCHK(h, ph_mark(1));
+    h->ph_host_enq_ms = ph_ms(ph_t0);
+    struct PhDone {                   // (the read-back below has several exits)
+        ssde_handle* h; bool ph; std::chrono::steady_clock::time_point t0;
+        ~PhDone() { h->ph_host_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); h->ph_valid = ph; h->ph_has_comm = false; }
+    } ph_done{h, ph, ph_t0};
     const auto t0 = std::chrono::steady_clock::now();
     // The reducing launch's last workgroup has been told to copy the result into pinned memory and to store this
     // evaluation's sequence number after it: spin on that word.  (tools/microbench_latency.hip, 40-us kernel: 12.7 us of
@@ -454,7 +481,9 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
         // hand-over check of the time windows (k_iso.hip): widen the warm-up and re-evaluate
         // until the windows agree with each other; 64x the estimate ends in one sequential window
         if (h->last_check <= SSDE_WINDOW_TOL) break;
-        if (!dist && h->last_chunks <= 1) break;
+        // (one window has no hand-over to disagree -- unless quiet rows ran: their switch check is folded into the same
+        //  value, and a longer memory, finally none at all, is the repair)
+        if (!dist && h->last_chunks <= 1 && h->last_quiet_window == 0) break;
         // a non-finite nllk is rejected by the caller whatever the windows did: no retry, and no lasting
         // widening of the plan because an optimiser probed an absurd parameter once
         if (!std::isfinite(o[0])) break;
@@ -684,8 +713,33 @@ int ssde_set_option(ssde_handle* h, int32_t option, int64_t value) {
         for (ssde_handle* s : h->shards) s->stamps = h->stamps;
         return SSDE_OK;
     }
+    if (option == SSDE_OPT_COMM_DEFER) { h->comm_defer = value != 0; return SSDE_OK; }
     h->err = "ssde_set_option: unknown option";
     return SSDE_ERR_ARG;
+}
+
+int ssde_last_phase_ms(ssde_handle* h, double ms[8]) {
+    if (!h || !ms) return SSDE_ERR_ARG;
+    for (int k = 0; k < 8; k++) ms[k] = 0.0;
+    if (!h->shards.empty()) { h->err = "ssde_last_phase_ms: single-device handles only"; return SSDE_ERR_ARG; }
+    if (!h->ph_valid || !h->ev_ph[0] || !h->ev_ph[1]) return SSDE_OK;      // no stamped synchronous evaluation yet: zeros
+    HIPCHK(h, hipSetDevice(h->device));
+    hipEvent_t last = (h->ph_has_comm && h->ev_ph[2]) ? h->ev_ph[2] : h->ev_ph[1];
+    HIPCHK(h, hipEventSynchronize(last));
+    auto el = [](hipEvent_t a, hipEvent_t b) { float t = 0.f; return hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : -1.0; };
+    ms[0] = h->ph_host_total_ms; ms[1] = h->ph_host_enq_ms;
+    const bool kv = h->ev_k_valid && h->ev_k0 && h->ev_k1;
+    double pre = kv ? el(h->ev_ph[0], h->ev_k0) : -1.0, ker = kv ? el(h->ev_k0, h->ev_k1) : -1.0, fin = kv ? el(h->ev_k1, h->ev_ph[1]) : -1.0;
+    if (pre < 0.0 || ker < 0.0 || fin < 0.0) {
+        // no stamp pair on this path (or the runtime will not difference a kernel stamp and a stream marker): the whole span as one
+        pre = 0.0; ker = 0.0; fin = el(h->ev_ph[0], h->ev_ph[1]);
+        if (fin < 0.0) fin = 0.0;
+    }
+    ms[2] = pre; ms[3] = ker; ms[4] = fin;
+    if (h->ph_has_comm && h->ev_ph[2]) { const double ar = el(h->ev_ph[1], h->ev_ph[2]); ms[5] = ar > 0.0 ? ar : 0.0; }
+    const double rb = ms[0] - (ms[1] > (ms[2] + ms[3] + ms[4] + ms[5]) ? ms[1] : (ms[2] + ms[3] + ms[4] + ms[5]));
+    ms[6] = rb > 0.0 ? rb : 0.0;
+    return SSDE_OK;
 }
 
 int ssde_forget(ssde_handle* h) {
@@ -738,7 +792,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         }
         info->window_check = h->last_check; info->window_retries = h->n_retries; info->window_check_max = h->check_max;
         info->n_memo_hits = h->n_memo_hits;
-        info->n_devices = h->n_track_shards; info->comm_ranks = h->comm_ranks;
+        info->n_devices = h->n_track_shards; info->comm_ranks = h->comm_ranks; info->comm_ranks_reported = h->comm_ranks_reported;
         return SSDE_OK;
     }
     info->n_par_full = h->L.n_full;
@@ -774,6 +828,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     }
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
+    info->comm_ranks_reported = h->comm_ranks_reported; info->kernel_id = h->last_kernel_id;
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
         info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * ((h->use_shared && h->last_t0 > 0) ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;

@@ -122,6 +122,7 @@ struct ssde_handle {
     double dt_min = 0.0;           // smallest interval used inside a track
     double dt_max = 0.0;           // ... and the largest
     bool chunks_forced = false;    // SSDE_CHUNKS given: the window count is the tester's (1 = plain sequential filter)
+    bool stream_nt = true;         // the tile stream is read with non-temporal loads (a batch far larger than the Infinity Cache)
     // quiet rows of the general kernel (k_iso.hip): blocks that hold a missing observation, per group; 0 words = not in use
     DevBuf<unsigned long long> nan_bits;
     DevBuf<double> quiet_flag;
@@ -248,7 +249,7 @@ struct ssde_handle {
     unsigned long long* pub_flag = nullptr;
     unsigned long long pub_seq = 0;
     DevBuf<unsigned int> pub_count;
-    bool pub_ok = false;                      // buffers exist and SSDE_NO_PUBLISH is not set
+    bool pub_ok = false;                      // buffers exist and SSDE_PUBLISH is set (opt-in)
     DevBuf<double> wave_clock;                // SSDE_WAVE_CLOCK=file: per-wave stamps of the last shared-covariance launch, written at destroy
     std::string wave_clock_file;
     int wave_clock_items = 0;
@@ -281,7 +282,14 @@ struct ssde_handle {
     bool poison = false;                      // SSDE_NA_ANY_NAN, n_dim > 2: an observed row with a NaN outside column 0
     std::vector<void*> comms;                 // ncclComm_t: one per shard (parent), or one (ssde_comm_init_rank)
     bool shards_share_device = false;         // rehearsal on a one-GPU machine: shards summed by a kernel, not RCCL
-    int comm_ranks = 1;                       // ranks of a multi-process communicator
+    int comm_ranks = 1;                       // ranks of a multi-process communicator (the caller's argument)
+    int comm_ranks_reported = 0;              // ... what ncclCommCount says about it (0: no communicator)
+    bool comm_defer = false;                  // SSDE_OPT_COMM_DEFER: ssde_eval_device leaves the rank's partial result to the caller's own collective
+    int last_kernel_id = 0;                   // SSDE_KERNEL_*: the family that ran the last evaluation's rows
+    // where a stamped synchronous evaluation spent its time (ssde_last_phase_ms): events on the evaluation's stream
+    hipEvent_t ev_ph[3] = {nullptr, nullptr, nullptr};   // first operation | end of the finalising launch | end of the all-reduce
+    bool ph_valid = false, ph_has_comm = false;
+    double ph_host_total_ms = 0.0, ph_host_enq_ms = 0.0;
     // Decisions that shape the SEQUENCE of collectives must be the same on every rank, whatever each rank's own data look
     // like (one rank's shard on a regular grid, another's with missing rows): agreed on once, at ssde_comm_init_rank
     // (min over ranks), and used instead of the local facts while a communicator is joined.  -1 = no communicator.

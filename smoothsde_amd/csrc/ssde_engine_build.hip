@@ -316,6 +316,11 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
     // row-varying tau / nu: a WORKGROUP per (group, window), one per CU -- up to eight rounds' worth; plan_windows picks the count
     if (h->drift == 3 && !h->cv_one_wave()) want = std::max(1, (8 * 256 + G - 1) / G);
+    // The resident tiles against the 256 MB Infinity Cache: a batch that fits is still there at the next evaluation if the loads
+    // are ordinary ones; a batch far beyond it is streamed past the caches (measured, profiles/r04_a_nt_vs_plain.txt: 205 MB
+    // 0.053 -> 0.044 ms with ordinary loads, 260 / 330 / 410 MB no difference, 1.6 GB 0.259 -> 0.274 ms)
+    h->stream_nt = (double)h->tile_doubles * 8.0 > 300e6;
+    if (const char* e = getenv("SSDE_NT")) h->stream_nt = atoi(e) != 0;
     if (const char* e = getenv("SSDE_CHUNKS")) { want = atoi(e); h->chunks_forced = true; }   // testing
     h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (4 * WIN_ALIGN))));
     // (row-varying tau / nu with few groups: windows down to two alignment units, shorter than their warm-up -- with CUs idle

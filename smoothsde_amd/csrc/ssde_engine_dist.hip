@@ -450,6 +450,14 @@ int ssde_comm_unique_id(void* id128) {
     return SSDE_OK;
 }
 
+int ssde_comm_allreduce(ssde_handle* h, double* buf_dev, int64_t count, void* stream) {
+    if (!h || !buf_dev || count < 1) return SSDE_ERR_ARG;
+    if (h->comms.empty()) { h->err = "ssde_comm_allreduce: the handle has joined no communicator"; return SSDE_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    NCCLCHK(h, rccl().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)h->comms[0], (hipStream_t)stream));
+    return SSDE_OK;
+}
+
 int ssde_comm_init_rank(ssde_handle* h, int32_t n_ranks, int32_t rank, const void* id128) {
     if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SSDE_ERR_ARG;
     if ((!h->shards.empty() && h->n_track_shards > 1) || !h->comms.empty()) { h->err = "ssde_comm_init_rank: the handle already evaluates over several devices"; return SSDE_ERR_ARG; }
@@ -461,6 +469,12 @@ int ssde_comm_init_rank(ssde_handle* h, int32_t n_ranks, int32_t rank, const voi
     NCCLCHK(h, rccl().CommInitRank(&c, n_ranks, id, rank));
     h->comms.push_back((void*)c);
     h->comm_ranks = n_ranks;
+    {
+        // what the communicator itself says (ssde_info.comm_ranks_reported): a bench line that claims N ranks shows RCCL's count
+        int cnt = 0;
+        NCCLCHK(h, rccl().CommCount(c, &cnt));
+        h->comm_ranks_reported = cnt;
+    }
     if (h->shards.empty() && !h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->memo_order = -1;
     // ---- what the ranks have to agree on (collective: every rank is here) ------------------------------------------

@@ -309,6 +309,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     a.bnd_stride = h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX;
     a.chk_out = out_dev + (1 + L.n_full);
     a.derive = (h->env_no_derive || h->drift) ? 0 : 1;
+    a.stream_nt = h->stream_nt ? 1 : 0;
     a.all_clean = ((h->use_shared && h->n_clean_groups == h->n_groups) || h->drift) ? 1 : 0;      // (drift: one dump layout for every group)
     a.nstate_clean = h->drift ? h->drift_nstate
                    : h->use_shared ? shared_nstate(h->sdim, order >= 1 ? a.part_mask[0] : 0, h->model != SSDE_MODEL_BM_SSM) : 0;
@@ -435,6 +436,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         }
         if (h->drift) HIPCHK(h, launch_iso_drift(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
         else HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+        h->last_kernel_id = h->drift ? SSDE_KERNEL_ISO_DRIFT : any_dirty ? SSDE_KERNEL_ISO_MIXED : SSDE_KERNEL_ISO_SHARED;
         h->ev_k_valid = h->stamps;
         h->last_s_stat = h->drift ? -1 : (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
         if (any_dirty) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[1], 0));
@@ -448,6 +450,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
+            h->last_kernel_id = h->cv_single ? SSDE_KERNEL_ISO_FULL : h->cv_few ? SSDE_KERNEL_ISO_FEW : SSDE_KERNEL_ISO_COLVAR;
             if (h->cv_single) HIPCHK(h, launch_iso_full(h->model, a, h->cv_parts.p, s));
             else if (h->cv_few) HIPCHK(h, launch_iso_few(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
             else {
@@ -458,8 +461,12 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             HIPCHK(h, launch_colvar_range_reduce(h->cv_ranges.p, n_wg, h->cv_ranges_pinned, s));
             }
         }
-        else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); }
-        else HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+        else if (h->drift) { a.t0 = 0; a.t0_delta = 0; HIPCHK(h, launch_iso_drift_general(h->model, h->d, a, s)); h->last_kernel_id = SSDE_KERNEL_ISO_DRIFT_GEN; }
+        else {
+            HIPCHK(h, launch_iso(h->model, h->d, a, false, s));
+            h->last_kernel_id = a.n_parts > 1 ? SSDE_KERNEL_ISO_SPLIT : a.quiet_w > 0 ? SSDE_KERNEL_ISO_QUIET
+                              : a.uniform_dt ? SSDE_KERNEL_ISO_MASK_UNI : SSDE_KERNEL_ISO_MASK;
+        }
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
         h->ev_k_valid = h->stamps;
         h->last_s_stat = -1;

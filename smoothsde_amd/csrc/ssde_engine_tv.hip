@@ -301,6 +301,7 @@ int eval_tv(ssde_handle* h, const double* par, int order, double* out_dev, hipSt
     a.out = out_dev;
     if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
     HIPCHK(h, launch_tv_filter(a, grad, s));
+    h->last_kernel_id = (h->tv_dense || is_eseal(h->model)) ? SSDE_KERNEL_TV_DENSE : SSDE_KERNEL_TV;
     if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k1, s));
     h->ev_k_valid = h->stamps; h->last_s_stat = -1;
     HIPCHK(h, launch_tv_finalize(a, s));
@@ -331,6 +332,7 @@ int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) 
         if (e == hipSuccess) e = launch_tv_prepare(a, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = launch_tv_filter(a, ord == 1, s);
+        h->last_kernel_id = (h->tv_dense || is_eseal(h->model)) ? SSDE_KERNEL_TV_DENSE : SSDE_KERNEL_TV;
         if (e == hipSuccess) e = launch_tv_finalize(a, s);
         if (e == hipSuccess) e = hipMemcpyAsync(h->tv_out_pinned, h->out.p, (size_t)(2 + n_full) * 8, hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipStreamEndCapture(s, &g);

@@ -21,6 +21,12 @@ namespace ssde_engine {
 int hess_exact_scope(const ssde_handle* h) {
     const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
     if (h->n_dim_parts > 1 || e->env_no_exact_hess) return 0;
+    if (e->path == PATH_TV) {
+        // row-varying coefficients on the isotropic lane = direction path: second-order forward mode over coefficient pairs
+        // (k_tv_hess.hip).  Not the full-covariance lanes (per-row H_array, general P0), not ESEAL_SSM; single engine.
+        if (!h->shards.empty() || !h->comms.empty() || e->tv_dense || is_eseal(e->model)) return 0;
+        return 3;
+    }
     if (e->path == PATH_ISO) {
         // a smooth drift on the shared-covariance lanes: the data term is QUADRATIC in the drift coefficients (k_iso_drift.hip)
         if (e->drift != 1) return 0;
@@ -62,7 +68,9 @@ static int hess_drift_device(ssde_handle* h, const double* par, const std::vecto
     for (int k = 0; k < n; k++) {
         const Slot* sl = nullptr;
         for (auto& t : h->slots) if (t.pidx == idx[k]) sl = &t;
-        if (!sl || sl->par_j >= h->d) { h->err = "ssde_hess: on a state-space model only the drift coefficients (and log_lambda) have exact second derivatives"; return SSDE_ERR_ARG; }
+        // (SSDE_ERR_MODEL = "not exact here": R's he() and the Laplace layer fall back to differencing the gradient -- an argument
+        //  error would stop a fit whose he(x) runs over ALL free parameters, tau / nu intercepts included)
+        if (!sl || sl->par_j >= h->d) { h->err = "ssde_hess: on a state-space model only the drift coefficients (and log_lambda) have exact second derivatives"; return SSDE_ERR_MODEL; }
         chan[k] = sl->col >= 0 ? (int16_t)(h->c_obs + h->d + sl->col) : (int16_t)-1;
         dim_of[k] = sl->par_j;
     }
@@ -128,23 +136,137 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     return SSDE_OK;
 }
 
+// lane = direction handle (row-varying coefficients): data-term Hessian over the DIRECTIONS dk[] (indices into the handle's gradient
+// directions: log_sigma_obs and every free coefficient), host matrix Hd (n x n, column-major).  One lane per pair, hyper-dual
+// arithmetic (k_tv_hess.hip); the time windows are the evaluation's, with a warm-up of their own and a hand-over check on every
+// component -- widened until it passes, finally one sequential window.
+static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<int>& dk, std::vector<double>& Hd) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int n = (int)dk.size();
+    // the plan (and the parameter ranges it is made from) is the evaluation's: evaluate once at these parameters (memoised after an ssde_eval)
+    {
+        double v;
+        std::vector<double> g((size_t)h->L.n_full);
+        int st = ssde_eval(h, par, h->L.n_full, 1, &v, g.data());
+        if (st) return st;
+    }
+    std::vector<int16_t> pa, pb;
+    for (int a = 0; a < n; a++) for (int b = a; b < n; b++) { pa.push_back((int16_t)dk[a]); pb.push_back((int16_t)dk[b]); }
+    const int n_pairs = (int)pa.size(), n_pb = (n_pairs + WAVE - 1) / WAVE;
+    hipStream_t s = h->tv_stream ? h->tv_stream : 0;
+    const double* pdev = nullptr;
+    int st = push_par(h, par, s, &pdev);
+    if (st) return st;
+    struct Scratch {                 // (freed on every exit)
+        DevBuf<int16_t> pairs; DevBuf<double> rec, bnd, part, out; DevBuf<TvItem> items;
+        ~Scratch() { pairs.release(); rec.release(); bnd.release(); part.release(); out.release(); items.release(); }
+    } sc;
+    DevBuf<int16_t>& d_pairs = sc.pairs;
+    DevBuf<double>&d_rec = sc.rec, &d_bnd = sc.bnd, &d_part = sc.part, &d_out = sc.out;
+    DevBuf<TvItem>& d_items = sc.items;
+    {
+        std::vector<int16_t> both(pa);
+        both.insert(both.end(), pb.begin(), pb.end());
+        HIPCHK(h, d_pairs.upload(both));
+    }
+    HIPCHK(h, d_rec.alloc((size_t)h->n * HESS_RS));
+    HIPCHK(h, d_out.alloc((size_t)4 * n_pb * WAVE + 1));
+    const int64_t M = h->n_seg;
+    int W = h->tv_window > 0 ? 2 * h->tv_window + WIN_ALIGN : 0;      // second-order tangents forget like t^2 rho^t
+    Hd.assign((size_t)n * n, 0.0);
+    for (int attempt = 0;; attempt++) {
+        // windows per track: as many as keep ~2048 waves busy, each at least two alignment units of scored rows
+        std::vector<TvItem> items;
+        const int target = h->env_tv_waves > 0 ? h->env_tv_waves : 2048;
+        const int nc_cap = (int)std::max<int64_t>(1, (target + M * n_pb - 1) / (M * n_pb));
+        for (int64_t t = 0; t < M; t++) {
+            const int L = h->tv_ns_host[(size_t)t];
+            int nc = 1;
+            if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + 2 * WIN_ALIGN - 1) / (2 * WIN_ALIGN)));
+            for (int b = 0; b < n_pb; b++)
+                for (int c = 0; c < nc; c++) items.push_back({(int32_t)t, c, nc, b});
+        }
+        d_items.release(); d_bnd.release(); d_part.release();
+        HIPCHK(h, d_items.upload(items));
+        HIPCHK(h, d_bnd.alloc(items.size() * 2 * HESS_NSTATE * WAVE));
+        HIPCHK(h, d_part.alloc(items.size() * 4 * WAVE));
+        TvHessArgs a;
+        memset(&a, 0, sizeof(a));
+        a.times = h->times.p; a.obs = h->obs.p; a.colbuf = h->colbuf.p; a.col_stride = h->col_stride; a.n = h->n;
+        a.d = h->d; a.model = h->model; a.any_nan = h->na_any; a.slots = h->slot_table.p; a.n_slots = (int)h->slots.size();
+        a.par = pdev; a.rec = d_rec.p; a.wdir = h->tv_wdir.p; a.ndp = h->tv_ndp; a.dirs = h->tv_dirs.p;
+        a.trk_row0 = h->tv_row0.p; a.trk_ns = h->tv_ns.p; a.a0 = h->tv_a0.p;
+        a.items = d_items.p; a.n_items = (int)items.size(); a.window = W;
+        a.pair_a = d_pairs.p; a.pair_b = d_pairs.p + n_pairs; a.n_pairs = n_pairs; a.n_pb = n_pb;
+        for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+        a.last_dt = h->last_dt;
+        a.bnd = d_bnd.p; a.part = d_part.p; a.out = d_out.p;
+        HIPCHK(h, launch_tv_hess(a, s));
+        std::vector<double> out((size_t)4 * n_pb * WAVE + 1);
+        HIPCHK(h, hipMemcpyAsync(out.data(), d_out.p, out.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        const double check = out.back();
+        if (check <= 1e-10 || W == 0) {
+            int p = 0;
+            for (int a2 = 0; a2 < n; a2++)
+                for (int b2 = a2; b2 < n; b2++, p++) {
+                    const double v = out[p];                                    // [0][pb][lane]: the mixed second derivative
+                    Hd[a2 + (size_t)b2 * n] = v; Hd[b2 + (size_t)a2 * n] = v;
+                }
+            break;
+        }
+        // the hand-over of some component disagrees: a longer warm-up, finally one sequential window
+        W = attempt >= 3 ? 0 : 4 * W;
+        if ((int64_t)2 * W > h->glen_max) W = 0;
+    }
+    return SSDE_OK;
+}
+
 // H (n_idx x n_idx, column-major, host) of the joint penalised nllk over the full-parameter indices idx[]
 int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H) {
     const int scope = hess_exact_scope(h);
-    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms) and for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows"; return SSDE_ERR_MODEL; }
+    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms), for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows, and for every free parameter of a state-space model with row-varying coefficients on the isotropic lane = direction path"; return SSDE_ERR_MODEL; }
     const ParLayout& L = h->L;
     const int np = L.n_full;
     for (int k = 0; k < n_idx; k++)
         if (idx[k] < 0 || idx[k] >= np) { h->err = "ssde_hess: index out of range"; return SSDE_ERR_ARG; }
+    {
+        // a duplicated entry would get the penalty in one copy and the data term in both
+        std::vector<char> seen((size_t)np, 0);
+        for (int k = 0; k < n_idx; k++) {
+            if (seen[idx[k]]) { h->err = "ssde_hess: duplicate index"; return SSDE_ERR_ARG; }
+            seen[idx[k]] = 1;
+        }
+    }
     for (size_t k = 0; k < (size_t)n_idx * n_idx; k++) H[k] = 0.0;
     // ---- data term: the entries that are coefficients of the linear predictor -------------------------------------
     std::vector<int> cidx, cpos;
     for (int k = 0; k < n_idx; k++) {
         const bool is_coef = (idx[k] >= L.off_fe && idx[k] < L.off_fe + L.n_fe) || (idx[k] >= L.off_re && idx[k] < L.off_re + L.n_re);
+        const bool is_lambda = idx[k] >= L.off_lambda && idx[k] < L.off_lambda + L.n_lambda;
         if (is_coef) { cidx.push_back(idx[k]); cpos.push_back(k); }
+        else if (scope == 3 && idx[k] == L.off_sig && L.off_sig >= 0) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_sigma_obs is a direction like any other there
+        else if (!is_lambda) {
+            // log_sigma_obs, log_decay: no closed form here -- say so instead of returning zero rows and columns
+            h->err = "ssde_hess: exact second derivatives cover coefficients of the linear predictor and log_lambda only (not log_sigma_obs / log_decay)";
+            return SSDE_ERR_MODEL;
+        }
     }
     const int nu = (int)cidx.size();
     if (nu > MAX_COLS) { h->err = "ssde_hess: more than 96 coefficients"; return SSDE_ERR_ARG; }
+    if (nu > 0 && scope == 3) {
+        // every requested entry must be one of the handle's gradient directions (a free parameter that reaches the data term)
+        std::vector<int> dk(nu);
+        for (int k = 0; k < nu; k++) {
+            dk[k] = h->tv_dir_of_par[cidx[k]];
+            if (dk[k] < 0) { h->err = "ssde_hess: an entry held fixed (par_fixed) has no second derivatives on the row-varying path"; return SSDE_ERR_MODEL; }
+        }
+        std::vector<double> Hd;
+        int st = hess_tv_device(h, par, dk, Hd);
+        if (st) return st;
+        for (int a = 0; a < nu; a++)
+            for (int b = 0; b < nu; b++) H[cpos[a] + (size_t)cpos[b] * n_idx] = Hd[a + (size_t)b * nu];
+    } else
     if (nu > 0) {
         std::vector<double> Hd((size_t)nu * nu, 0.0), tmp((size_t)nu * nu);
         auto one = [&](ssde_handle* e, bool all_reduce) -> int {

@@ -69,7 +69,7 @@ struct Laplace {
     std::vector<int> ir;               // coeff_re entries that are not fixed
     double hess_step, fd_step, newton_tol;
     int max_newton;
-    bool exact = false;                // exact second derivatives over EVERY parameter (ssde_engine::hess_exact_scope == 2)
+    bool exact = false;                // exact second derivatives over EVERY free parameter (ssde_engine::hess_exact_scope == 2 or 3)
     bool exact_uu = false;             // ... over the random-effect coefficients at least (scope >= 1)
     std::vector<double> work, grad;
 
@@ -221,7 +221,7 @@ extern "C" int ssde_laplace_eval(ssde_handle* h, double* par, int32_t n_par_full
     if (n_par_full != h->L.n_full) { h->err = "parameter vector has the wrong length"; return SSDE_ERR_ARG; }
     Laplace lp;
     lp.h = h; lp.np = n_par_full;
-    lp.exact = ssde_engine::hess_exact_scope(h) == 2;
+    lp.exact = ssde_engine::hess_exact_scope(h) == 2 || ssde_engine::hess_exact_scope(h) == 3;   // (3: row-varying coefficients, k_tv_hess.hip -- every free entry)
     lp.exact_uu = ssde_engine::hess_exact_scope(h) >= 1;
     lp.hess_step = (opts && opts->hess_step > 0) ? opts->hess_step : 1e-4;
     // the log-determinant term differences H_uu: with exact Hessians a shorter step is affordable (truncation e^2, rounding 1e-16 / e)

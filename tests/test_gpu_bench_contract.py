@@ -35,8 +35,20 @@ def test_bench_line_has_what_the_driver_reads():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert r["bound"] in ("hbm", "fp64_issue") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # two roofs: the HBM fraction and the fp64-issue fraction side by side, neither above 1; `bound` names the larger
+    assert r["frac_hbm"] == r["frac"] and r["kernel"].startswith("iso_shared_kernel") and r["kernel_id"] == 3
+    assert r["frac_fp64_issue"] is None or 0 < r["frac_fp64_issue"] <= 1.0
+    if r["frac_fp64_issue"] is not None:
+        assert r["bound"] == ("fp64_issue" if r["frac_fp64_issue"] > r["frac_hbm"] else "hbm") and "SQ_INSTS_VALU" in r["valu_source"]
+    # the line carries its own spread, and the per-rank account exists at N = 1 too
+    ex = d["extra"]
+    assert 0 < ex["ms_per_step_min"] <= ex["ms_per_step_median"] <= ex["ms_per_step_p90"] <= ex["ms_per_step_max"]
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["rows"] == 640 * 800 and pr[0]["kernel_ms"] > 0
+    assert pr[0]["finalize_ms"] > 0 and pr[0]["allreduce_wait_ms"] == 0.0 and pr[0]["host_total_ms"] >= pr[0]["kernel_stamp_ms"] > 0
+    assert d["config"]["comm_ranks_reported"] == 0 and d["config"]["engine_kernel"] == "iso_shared_kernel"
     assert r["required_bytes_per_row"] == 16.0 and r["algo_bytes_per_row"] == 24.0 and r["kernel_ms"] > 0
     assert d["ms_per_step_stamped"] > 0 and "strong scaling" in d["config"]["workload"] and d["config"]["total_rows"] == 640 * 800
     c = d["cpu_baseline"]
@@ -44,6 +56,11 @@ def test_bench_line_has_what_the_driver_reads():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     assert len(d["secondary"]) == 6 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
+    for s in d["secondary"]:                                       # every entry names its kernel and carries both roofs, each <= 1
+        assert s["kernel"] != "?" and s["bound"] in ("hbm", "fp64_issue") and 0 < s["frac_hbm"] <= 1.0, s
+        assert s["frac_fp64_issue"] is None or 0 < s["frac_fp64_issue"] <= 1.0, s
+    kern = [s["kernel"] for s in d["secondary"]]
+    assert kern[0] == "iso_mask_kernel" and kern[2] == "iso_quiet_kernel" and kern[4] in ("iso_colvar_kernel", "iso_few_kernel") and kern[5] == "iso_full_kernel", kern
     assert "H_array" in d["secondary"][5]["workload"] and d["secondary"][5]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
     assert "tau and nu smooth" in d["secondary"][4]["workload"] and d["secondary"][4]["path"] == "isotropic-register"   # the lane = track kernel
     assert "one missing row" in d["secondary"][2]["workload"] and d["secondary"][2]["quiet_window"] > 0             # quiet rows of the general kernel
@@ -58,6 +75,29 @@ def test_one_rank_communicator_rehearsal_prints_one_line_too():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "ncclAllReduce" in d["config"]["parallelism"]
+    # what makes the first real N > 1 run diagnosable (VERDICT r03 #1b): RCCL's own count of the communicator, and per rank
+    # the kernel, the finalising launch, the wait inside the all-reduce and the read-back
+    assert d["config"]["comm_ranks_requested"] == 1 and d["config"]["comm_ranks_reported"] == 1
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["comm_ranks_reported"] == 1
+    for k in ("rows", "kernel_ms", "finalize_ms", "allreduce_wait_ms", "readback_ms", "host_total_ms"):
+        assert k in pr[0], k
+    assert pr[0]["allreduce_wait_ms"] > 0 and pr[0]["kernel_ms"] > 0 and pr[0]["finalize_ms"] > 0
+
+
+def test_c5_with_a_communicator_sums_the_three_handles_in_one_collective():
+    env = dict(os.environ, SSDE_BENCH_SELF_LAUNCH="1", SSDE_BENCH_FORCE_COMM="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tracks", "640", "--rows", "800", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline", "--config", "c5"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert "ONE ncclAllReduce" in d["config"]["parallelism"] and d["config"]["comm_ranks_reported"] == 1
+    # the same batch without a communicator: same numbers (a one-rank sum changes nothing)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tracks", "640", "--rows", "800", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline", "--config", "c5"], capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    e = json.loads([l for l in q.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["nllk_at_last_step"] == e["config"]["nllk_at_last_step"] and d["config"]["total_rows"] == e["config"]["total_rows"]
 
 
 def test_strong_and_weak_modes_with_one_rank_time_the_same_batch():

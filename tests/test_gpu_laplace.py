@@ -150,8 +150,62 @@ def test_exact_hessian_matches_autograd(name):
     eng.close(); em.close()
 
 
+# ---- exact second derivatives with ROW-VARYING coefficients: second-order forward mode, one lane per coefficient pair (k_tv_hess.hip) ----
+@pytest.mark.parametrize("name", ["CTCRW_d1_tv", "CTCRW_d2_tv", "OU_SSM_d1_tv", "OU_SSM_d2_tv", "BM_SSM_d1_tv", "BM_SSM_d2_tv",
+                                  "CTCRW_d2_tv2_RNA"])
+def test_exact_hessian_with_row_varying_coefficients_matches_autograd(name):
+    """tmb_obj_joint$he(x) (R/sde.R:1363) for the models the reference exists for (tau ~ s(x), nu ~ s(x), mu ~ s(x):
+    smoothSDE.rmd:476-497): every FREE entry -- log_sigma_obs, fixed-effect and random-effect coefficients, log_lambda --,
+    missing rows included, against the autograd Hessian of the dense joint-Gaussian restatement."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k]]
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == 3, eng.info()
+    H = eng.hess(par, idx)
+    g = eng.eval(par, order=1)[1]
+    eng.close()
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
+    assert np.max(np.abs(H - H.T)) == 0.0
+    assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
+    assert np.all(np.isfinite(g))
+
+
+def test_row_varying_hessian_on_a_long_track_with_time_windows(monkeypatch):
+    """one animal, 3000 fixes, tau and nu smooth in a covariate (the vignette's model): the Hessian pass cuts the track into
+    windows with a warm-up of their own and a hand-over check on every hyper-dual component; against central differences of the
+    device gradient (an autograd Hessian of the dense restatement is out of reach at this length)"""
+    from smoothsde_amd.synth import simulate, bspline_basis, second_difference_penalty
+    T, K = 3000, 5
+    ID, times, obs = simulate("CTCRW", 1, T, 2, tau=1.0, nu=1.0, sigma_obs=0.05, seed=3)
+    B = bspline_basis((np.sin(np.arange(T) * 0.013) + 1) / 2, K)
+    S = second_difference_penalty(K)
+    pb = capi.Problem("CTCRW", ID, times, obs, X_re=[None, None, B, B], S_list=[S, S], par_fixed=[0, 1, 1, 0, 0, 0, 0] + [0] * (2 * K))
+    par = np.concatenate([[np.log(0.05), 0.0, 0.0, 0.1, -0.1], [0.2, 0.1], 0.1 * np.sin(np.arange(2 * K))])
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k]]
+    eng = capi.Engine(pb)
+    H = eng.hess(par, idx)
+    assert eng.info()["lanes_per_track"] > 1                      # the evaluation behind it ran time windows
+    Hfd = np.zeros_like(H)
+    for j, k in enumerate(idx):
+        e = 1e-5 * max(1.0, abs(par[k]))
+        pp, pm = par.copy(), par.copy()
+        pp[k] += e
+        pm[k] -= e
+        Hfd[:, j] = (eng.eval(pp, order=1)[1][idx] - eng.eval(pm, order=1)[1][idx]) / (2 * e)
+    eng.close()
+    assert np.max(np.abs(H - Hfd)) <= 2e-6 * np.max(np.abs(H)), np.max(np.abs(H - Hfd)) / np.max(np.abs(H))
+    # the same entries from one sequential window (SSDE_WINDOW forces nothing here: a one-window plan has no warm-up at all)
+    monkeypatch.setenv("SSDE_TV_WAVES", "1")
+    e1 = capi.Engine(pb)
+    H1 = e1.hess(par, idx)
+    e1.close()
+    assert np.max(np.abs(H - H1)) <= 1e-9 * np.max(np.abs(H)), np.max(np.abs(H - H1)) / np.max(np.abs(H))
+
+
 def test_exact_hessian_is_refused_where_it_does_not_exist():
-    for name in ("CTCRW_d1_tv", "BM_t_d1_tv", "OU_d1_decay"):
+    for name in ("CTCRW_d2_tv_H_P0", "BM_t_d1_tv", "OU_d1_decay"):
         rec = GOLD[name]
         pb = problem_from_spec(rec)
         eng = capi.Engine(pb)
@@ -244,8 +298,18 @@ def test_exact_hessian_of_the_drift_coefficients_matches_autograd(rec, monkeypat
     H = eng.hess(par, idx)
     H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
     assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
-    with pytest.raises(capi.EngineError, match="only the drift coefficients"):
-        eng.hess(par, [pb.off_fe + pb.fe_off[pb.n_dim]])            # tau / sigma: no exact second derivative here
+    # entries without an exact second derivative here are REFUSED with "not exact" (status 2 = SSDE_ERR_MODEL: R's he() and the
+    # Laplace layer fall back to differences on it), never answered with zero rows -- ADVICE r03
+    ERR_ARG, ERR_MODEL = 1, 2
+    with pytest.raises(capi.EngineError, match="only the drift coefficients") as ei:
+        eng.hess(par, [pb.off_fe + pb.fe_off[pb.n_dim]])            # tau / sigma
+    assert ei.value.status == ERR_MODEL
+    with pytest.raises(capi.EngineError, match="log_sigma_obs") as ei:
+        eng.hess(par, [0] + idx)                                    # log_sigma_obs next to the drift coefficients
+    assert ei.value.status == ERR_MODEL
+    with pytest.raises(capi.EngineError, match="duplicate index") as ei:
+        eng.hess(par, idx + [idx[0]])
+    assert ei.value.status == ERR_ARG
     eng.close()
 
 

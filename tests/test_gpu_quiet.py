@@ -272,6 +272,27 @@ def test_a_memory_too_short_is_detected_at_the_switch_and_repaired(model, monkey
     _close(val, grad, oval, ograd)
 
 
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM"])
+def test_a_memory_too_short_is_repaired_on_a_one_window_plan_too(model, monkeypatch):
+    """SSDE_CHUNKS=1: one window, so no hand-over exists -- but quiet rows still run (the plan keeps a usable warm-up length) and
+    their switch check is the only thing that can notice a memory that is too short.  ssde_eval used to accept any check value
+    on a one-window plan; it must retry with a longer memory like everywhere else."""
+    M, T, d = 128, 1200, 2
+    ID, times, obs = _batch(model, M, T, d, seed=52)
+    pb = capi.Problem(model, ID, times, obs)
+    par = np.array([0.5, 0.0, 0.0, 0.5, 0.0]) + (np.array([0, 3.0, 3.0, 0, 0]) if model == "OU_SSM" else 0.0)
+    monkeypatch.setenv("SSDE_QUIET_WINDOW", "8")
+    monkeypatch.setenv("SSDE_CHUNKS", "1")
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    inf = eng.info()
+    eng.close()
+    assert inf["lanes_per_track"] == 1, inf
+    assert inf["window_retries"] >= 1, inf
+    oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    _close(val, grad, oval, ograd)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("seed", range(24))
 def test_random_sparse_patterns(seed, monkeypatch):

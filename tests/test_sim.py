@@ -101,3 +101,8 @@ def test_simulate_refuses_what_the_reference_refuses():
         capi.simulate_device("CIR", 4, 8, 1)
     with pytest.raises(ValueError):
         capi.simulate_device("nope", 4, 8, 1)
+    # parameters that would put a NaN / Inf Cholesky factor into HBM are refused, not simulated
+    for model, kw in (("CTCRW", {"tau": 0.0}), ("CTCRW", {"nu": -1.0}), ("CTCRW", {"nu": 0.0}), ("OU", {"kappa": -0.5}),
+                      ("OU_SSM", {"tau": -2.0}), ("BM", {"sigma": float("nan")}), ("BM_SSM", {"sigma_obs": -0.1})):
+        with pytest.raises(capi.EngineError, match="are required"):
+            capi.simulate_device(model, 4, 8, 1, **kw)
