@@ -814,9 +814,16 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             bool mu_only = true;
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;
+            // Which side wins is a matter of the batch's ROWS, not of its tracks (tools/sweep_dispatch.py, profiles/r04_d_dispatch_sweep*.txt:
+            // the lane = direction path costs ~0.07 ms + 0.2 us per 1000 rows, the register lanes ~0.09 ms (0.18 for CTCRW: its transient
+            // window) + 0.012 us per 1000 rows -- round 3's rule, >= 32 tracks, was wrong by 17-117 % at 32-64 tracks x 10^3 rows).
+            // SSDE_DRIFT_MIN_TRACKS keeps its meaning for the tests: a track count decides.
             int min_tracks = 32;
-            if (const char* e = getenv("SSDE_DRIFT_MIN_TRACKS")) min_tracks = atoi(e);
-            if (iso_cfg && mu_only && h->n_seg >= min_tracks && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
+            const bool by_tracks = getenv("SSDE_DRIFT_MIN_TRACKS") != nullptr;
+            if (by_tracks) min_tracks = atoi(getenv("SSDE_DRIFT_MIN_TRACKS"));
+            const double n_rows = (double)n;
+            const bool drift_pays = by_tracks ? h->n_seg >= min_tracks : n_rows >= (h->model == SSDE_MODEL_CTCRW ? 5e5 : 1.5e5);
+            if (iso_cfg && mu_only && drift_pays && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.
@@ -841,8 +848,18 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
                                    !getenv("SSDE_CV_NO_FEW");                   // (columns may still be shared below: checked again at the plan)
             //  (With H_array the lane = direction lanes carry a full covariance and cost three times as much: 64 / 640 / 1280 tracks x 10^3 rows,
             //   constant tau / nu: 0.245 / 0.30 / 0.53 ms there against 0.23-0.24 on iso_full_kernel; row-varying, 160 tracks: 0.60 against 0.36.)
-            const int min_tracks_cv = getenv("SSDE_DRIFT_MIN_TRACKS") ? min_tracks : h->has_h ? 64 : few_shape ? 1200 : std::max(160, 3400 / std::max(n_dirs, 1));
-            if (par_only && h->n_seg >= min_tracks_cv && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
+            // (round 4, the same sweep: rows decide here too.  The lane = direction path costs ~0.1 ms + 0.35 us per 1000 rows and 32 lanes per
+            //  track, the eight-wave pipeline ~0.175 ms + 0.11 us per 1000 rows whatever the directions: it pays from rows x lanes-per-track
+            //  ~ 4.5 10^6 on (160 tracks x 10^3 rows and 32 lanes: 0.19 against 0.22 ms; 64 tracks x 10^4 rows: 0.24 against 0.37 ms, which round 3's track rule sent the other way); iso_few_kernel from
+            //  1.5 10^6 rows on (CTCRW, d = 2; 5 10^5 for the scalar-covariance models: 1000 tracks x 10^4 rows 0.41 against 1.32 ms);
+            //  with H_array the lane = direction lanes cost 55 ms per 10^6 rows: iso_full_kernel / the full-covariance pipeline from 8 tracks on.)
+            int lpt_dirs = 1;
+            while (lpt_dirs < n_dirs && lpt_dirs < 64) lpt_dirs *= 2;
+            const bool cv_pays = by_tracks ? h->n_seg >= min_tracks
+                               : h->has_h ? h->n_seg >= 8
+                               : few_shape ? n_rows >= ((h->model == SSDE_MODEL_CTCRW && h->d == 2) ? 1.5e6 : 5e5)
+                               : n_rows * lpt_dirs >= 4.5e6;
+            if (par_only && cv_pays && h->d <= 2 && h->n_stream_cols <= 2 * DRIFT_KMAX) {
                 int nd = h->n_stream_cols;
                 if (!getenv("SSDE_CV_NO_SHARE")) { int st = share_equal_columns(d, h, on_dev, n, &nd); if (st) return st; }
                 if (nd <= DRIFT_KMAX) { h->n_stream_cols = nd; h->drift = 3; h->path = PATH_ISO; h->cv_full = full_cfg; h->cv_single = h->cv_full && nd == 0 && !getenv("SSDE_CV_NO_SINGLE"); }

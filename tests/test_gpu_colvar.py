@@ -19,8 +19,9 @@ PATH_ISO, PATH_TV = 1, 3
 
 @pytest.fixture(autouse=True)
 def _take_the_lane_track_path_from_32_tracks(monkeypatch):
-    """The engine sends row-varying tau / nu batches to this kernel from 160 tracks on (the measured crossover against the
-    lane = direction path); the cases below are smaller so that the oracle stays quick."""
+    """The engine sends row-varying tau / nu batches to this kernel by their rows (rows x lanes per track >= 4.5 10^6: the measured
+    crossover against the lane = direction path, tools/sweep_dispatch.py); the cases below are smaller so that the oracle stays
+    quick, and ask for the kernel by track count."""
     monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
 
 
@@ -711,9 +712,9 @@ def test_few_tracks_and_mixed_designs_stay_on_the_lane_direction_path(monkeypatc
     eng = capi.Engine(pb1)
     assert eng.info()["path"] == PATH_TV
     eng.close()
-    monkeypatch.delenv("SSDE_DRIFT_MIN_TRACKS")                 # the engine's own threshold: 3400 / directions, at least 160 tracks
-    for M, want in ((100, PATH_TV), (400, PATH_ISO)):
-        pbm, _ = _batch("CTCRW", 1, M, 100, 9, 0, seed=9)
+    monkeypatch.delenv("SSDE_DRIFT_MIN_TRACKS")                 # the engine's own rule: rows x lanes per track >= 4.5 10^6 (round 4: rows decide, not tracks)
+    for M, T, want in ((100, 100, PATH_TV), (400, 100, PATH_TV), (400, 2000, PATH_ISO), (64, 12000, PATH_ISO)):
+        pbm, _ = _batch("CTCRW", 1, M, T, 9, 0, seed=9)
         eng = capi.Engine(pbm)
         assert eng.info()["path"] == want
         eng.close()

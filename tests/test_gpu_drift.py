@@ -17,6 +17,14 @@ GOLD = load_golden()
 PATH_ISO, PATH_TV = 1, 3
 
 
+@pytest.fixture(autouse=True)
+def _take_the_register_lanes_from_32_tracks(monkeypatch):
+    """The engine sends smooth-drift batches to these kernels by their ROWS (from 1.5 10^5 on, 5 10^5 for CTCRW: the measured
+    crossover against the lane = direction path, tools/sweep_dispatch.py); the cases below are smaller so that the oracle stays
+    quick, and ask for the kernels by track count, as round 3's rule did."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
+
+
 def _oracle(pb, par, **kw):
     from oracle_lib import oracle_eval
     return oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=8, **kw)
