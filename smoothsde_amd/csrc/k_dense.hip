@@ -116,6 +116,9 @@ hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s) {
         return hipGetLastError();                                                                 \
     }
     SSDE_L(M_CTCRW, 1) SSDE_L(M_CTCRW, 2) SSDE_L(M_OU_SSM, 1) SSDE_L(M_OU_SSM, 2) SSDE_L(M_BM_SSM, 1) SSDE_L(M_BM_SSM, 2)
+    // responses of three or four columns whose measurement covariance or P0 couples the columns (ssde_engine_dist.hip sends every
+    // other wide response to this engine pair by pair): one filter over all columns, F by LU as the reference does it
+    SSDE_L(M_CTCRW, 3) SSDE_L(M_CTCRW, 4) SSDE_L(M_OU_SSM, 3) SSDE_L(M_OU_SSM, 4) SSDE_L(M_BM_SSM, 3) SSDE_L(M_BM_SSM, 4)
 #undef SSDE_L
     return hipErrorInvalidValue;
 }

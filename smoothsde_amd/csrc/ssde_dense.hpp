@@ -53,6 +53,67 @@ template <int N> SSDE_HD DualN<N> dsqrt(const DualN<N>& a) {
     DualN<N> r; r.v = sqrt(a.v); const double h = 0.5 / r.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * h; return r; }
 template <int N> SSDE_HD DualN<N> dfabs(const DualN<N>& a) { return a.v < 0.0 ? -a : a; }
 
+// ---- d x d helpers for responses wider than two columns (n_dim = 3, 4 with a measurement covariance or a P0 that couples the
+// columns): what Eigen's F.inverse() and TMB's atomic::logdet do in the reference (nllk_ctcrw.hpp:12-24, 231, 236) -- Gaussian
+// elimination with partial pivoting on the VALUES, carried out in dual arithmetic so the tangents follow
+template <int D, int N>
+SSDE_HD void dense_lu(const DualN<N> (&F)[D][D], DualN<N> (&LU)[D][D], int (&piv)[D], int& sign) {
+    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) LU[i][j] = F[i][j];
+    sign = 1;
+    for (int k = 0; k < D; k++) {
+        int p = k;
+        double best = fabs(LU[k][k].v);
+        for (int i = k + 1; i < D; i++) if (fabs(LU[i][k].v) > best) { best = fabs(LU[i][k].v); p = i; }
+        piv[k] = p;
+        if (p != k) {
+            sign = -sign;
+            for (int j = 0; j < D; j++) {
+                // (static indices only: a select per candidate row keeps the matrix in registers on the device)
+                DualN<N> a = LU[k][j], b = LU[k][j];
+                for (int i = k + 1; i < D; i++) if (i == p) b = LU[i][j];
+                LU[k][j] = b;
+                for (int i = k + 1; i < D; i++) if (i == p) LU[i][j] = a;
+            }
+        }
+        const DualN<N> ip = 1.0 / LU[k][k];
+        for (int i = k + 1; i < D; i++) {
+            LU[i][k] = LU[i][k] * ip;
+            for (int j = k + 1; j < D; j++) LU[i][j] = LU[i][j] - LU[i][k] * LU[k][j];
+        }
+    }
+}
+template <int D, int N>
+SSDE_HD DualN<N> dense_det_lu(const DualN<N> (&F)[D][D]) {
+    DualN<N> LU[D][D];
+    int piv[D], sign;
+    dense_lu<D, N>(F, LU, piv, sign);
+    DualN<N> det((double)sign);
+    for (int k = 0; k < D; k++) det = det * LU[k][k];
+    return det;
+}
+template <int D, int N>
+SSDE_HD void dense_inverse_lu(const DualN<N> (&F)[D][D], DualN<N> (&Fi)[D][D]) {
+    DualN<N> LU[D][D];
+    int piv[D], sign;
+    dense_lu<D, N>(F, LU, piv, sign);
+    for (int c = 0; c < D; c++) {
+        DualN<N> x[D];
+        for (int i = 0; i < D; i++) x[i] = DualN<N>(i == c ? 1.0 : 0.0);
+        for (int k = 0; k < D; k++) {                                // the row interchanges, in order
+            DualN<N> a = x[k], b = x[k];
+            for (int i = k + 1; i < D; i++) if (i == piv[k]) b = x[i];
+            x[k] = b;
+            for (int i = k + 1; i < D; i++) if (i == piv[k]) x[i] = a;
+        }
+        for (int i = 1; i < D; i++) for (int j = 0; j < i; j++) x[i] = x[i] - LU[i][j] * x[j];            // L y = P e_c
+        for (int i = D - 1; i >= 0; i--) {
+            for (int j = i + 1; j < D; j++) x[i] = x[i] - LU[i][j] * x[j];
+            x[i] = x[i] / LU[i][i];
+        }
+        for (int i = 0; i < D; i++) Fi[i][c] = x[i];
+    }
+}
+
 template <int MODEL, int D>
 struct DenseDims {
     static constexpr int SD = (MODEL == M_CTCRW) ? 2 * D : D;
@@ -168,7 +229,8 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
         for (int i = 0; i < D; i++)
             for (int j = 0; j < D; j++) F[i][j] = L.P[DM::z(i)][DM::z(j)] + H[i][j];   // F = Z P Z' + H
         if (D == 1) det = F[0][0];
-        else det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                                // det(): nllk_ctcrw.hpp:16-19
+        else if (D == 2) det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                    // det(): nllk_ctcrw.hpp:16-19
+        else det = dfabs(dense_det_lu<D, N>(F));                                         // det = exp(atomic::logdet(F)) = |det F|: nllk_ctcrw.hpp:20-22
         // CTCRW tests det <= 0; OU/BM take exp(logdet) = |det|, which fails the test only at 0
         upd = (MODEL == M_CTCRW) ? !(det.v <= 0.0) : !(fabs(det.v) <= 0.0);   // (a NaN takes the update branch)
     }
@@ -183,6 +245,8 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
     T_ Fi[D][D];
     if (D == 1) {
         Fi[0][0] = 1.0 / F[0][0];
+    } else if (D > 2) {
+        dense_inverse_lu<D, N>(F, Fi);                                                   // F.inverse(): partial-pivot LU (nllk_ctcrw.hpp:231, 236)
     } else {
         const T_ id = 1.0 / det;
         Fi[0][0] = F[1][1] * id; Fi[0][1] = -(F[0][1] * id);

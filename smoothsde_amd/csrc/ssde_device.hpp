@@ -389,7 +389,7 @@ struct DenseArgs {
     const SlotTable* slots;      // device
     const double* par;           // device
     int n_slots;
-    double p0[16];               // sdim x sdim column-major
+    double p0[64];               // sdim x sdim column-major (sdim <= 8: CTCRW with four response columns)
     int n_dirblocks;
     const DenseDir* dirs;        // device [n_dirblocks * DENSE_NT]
     double* partials;            // [n_dirblocks][1 + DENSE_NT][n_groups]

@@ -438,7 +438,9 @@ static int check_descriptor(const ssde_desc* d, ssde_handle* h, const ParLayout*
         h->tdf = d->other_data[0];
         h->tconst = std::lgamma(0.5 * (h->tdf + 1.0)) - std::lgamma(0.5 * h->tdf) - 0.5 * std::log(h->tdf * M_PI);
     }
-    if (d->n_dim < 1 || d->n_dim > 2)
+    // (three or four response columns as ONE filter: only the lane = track general kernel, and only where ssde_create found that the
+    //  measurement covariance or P0 couples the column pairs -- every other wide response is evaluated pair by pair)
+    if (d->n_dim < 1 || (d->n_dim > 2 && !(h->wide_ok && d->n_dim <= 4 && is_kalman(d->model))))
         return fail(h, SSDE_ERR_MODEL, "n_dim must be 1 or 2 (wider responses are outside this engine's kernels)");
     if (d->n_par != n_sde_par(d->model, d->n_dim)) return fail(h, SSDE_ERR_ARG, "n_par does not match model / n_dim");
     if (d->n < 2) return fail(h, SSDE_ERR_ARG, "need at least two rows");
@@ -516,6 +518,11 @@ static int stage_basis_tables(const ssde_desc* d, ssde_handle* h, bool on_dev, i
     // Fast route: a direct family whose fast kernel applies (<= 2 parameters with columns, no decay), the whole
     // random-effect block of the parameter is the table and its fixed-effect part is the intercept: the kernel
     // evaluates the block from x (8 B/row).  Everything else gets the dense block materialised once in HBM.
+    if (d->basis_re && d->n_par > MAX_Q) {
+        // (a response of three or four columns run as one filter: q = d + 2 > MAX_Q parameters, and the table slots are MAX_Q wide)
+        for (int j = 0; j < d->n_par; j++)
+            if (d->basis_re[j]) return fail(h, SSDE_ERR_MODEL, "basis_re is not available for responses wider than two columns that run as one filter (coupling H_array / P0): pass the dense block");
+    } else
     if (d->basis_re) {
         std::vector<int> with_cols;
         for (auto& sl : h->slots)
@@ -795,7 +802,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // ---- Kalman families: pick the path, then tile ------------------------------------------------
         for (int i = 0; i < h->sdim; i++)
             for (int j = 0; j < h->sdim; j++) h->p0_full[i + j * h->sdim] = p0_entry(d, i, j);
-        const bool iso_ok = !h->has_h && h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
+        const bool iso_ok = h->d <= 2 && !h->has_h && h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
                             !(d->flags & SSDE_FLAG_FORCE_DENSE);
         h->path = iso_ok ? PATH_ISO : PATH_DENSE;
         // Row-varying DRIFT only (design columns in the rows of mu_1 .. mu_d, everything else constant), many tracks: the
@@ -809,7 +816,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // (one response column: H_array[,,i] is the row's measurement variance -- the isotropic lanes of k_iso_colvar.hip with h = H_i)
         const bool h1_cfg = h->has_h && h->d == 1 && p0_is_isotropic(d, h->p0_iso) && !getenv("SSDE_NO_COLVAR_FULL");
         // (... also with CONSTANT coefficients: tracks with error ellipses and one tau, one nu -- the intercepts are columns of ones)
-        if (!iso_ok && allow_drift && (iso_cfg || full_cfg || h1_cfg) && (!h->const_coeff || full_cfg || h1_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
+        if (!iso_ok && h->d <= 2 && allow_drift && (iso_cfg || full_cfg || h1_cfg) && (!h->const_coeff || full_cfg || h1_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
             !getenv("SSDE_NO_DRIFT")) {
             bool mu_only = true;
             for (auto& sl : h->slots)
@@ -869,7 +876,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // row-varying coefficients with H = sigma_obs^2 I and a block-identical P0: the tv path
         // everything the constant-coefficient register path does not take: row-varying coefficients (isotropic
         // lanes), per-row H_array or a P0 that is not block-identical (full-covariance lanes)
-        const bool tv_ok = !iso_ok && !h->drift && !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
+        const bool tv_ok = !iso_ok && h->d <= 2 && !h->drift && !(d->flags & SSDE_FLAG_FORCE_DENSE) && !getenv("SSDE_NO_TV") &&
                            (double)n * (TV_RS + 64) * 8.0 < 150e9;
         if (tv_ok) {
             h->tv_dense = h->has_h || !p0_is_isotropic(d, h->p0_iso);

@@ -92,6 +92,15 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     const int D = d->n_dim, q = d->n_par, n_shared = q - D, sdim = state_dim(d->model, D);
     const int P = D > 2 ? (D + 1) / 2 : 1;                  // dimension parts
     const int per_dim = d->model == SSDE_MODEL_CTCRW ? 2 : 1;   // state components per dimension
+    // A measurement covariance or a P0 that couples response columns of different pairs makes F a full matrix: the reference
+    // evaluates it through atomic::logdet and F.inverse() (nllk_ctcrw.hpp:12-24, 203-205, 231-241).  For three or four columns
+    // (host arrays, one device) the whole response then runs as ONE filter on the lane = track general kernel (k_dense.hip:
+    // F by LU with partial pivoting, ssde_dense.hpp) instead of pair by pair.
+    const bool can_run_whole = is_kalman(d->model) && D <= 4 && !multi && !on_dev;
+    auto run_whole = [&]() -> int {
+        parent->wide_ok = true;
+        return build(d, parent);
+    };
     if (P > 1) {
         if (is_eseal(d->model)) return fail(parent, SSDE_ERR_MODEL, "ESEAL_SSM takes one response variable");
         if (d->model == SSDE_MODEL_BM_T) return fail(parent, SSDE_ERR_MODEL, "BM_t takes one response variable");
@@ -103,16 +112,22 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                 const double* Hr = d->h_array + (size_t)r * D * D;
                 for (int i = 0; i < D; i++)
                     for (int j = 0; j < D; j++)
-                        if (i / 2 != j / 2 && Hr[i + (size_t)j * D] != 0.0)       // (a NaN entry counts as coupling)
+                        if (i / 2 != j / 2 && Hr[i + (size_t)j * D] != 0.0) {     // (a NaN entry counts as coupling)
+                            if (can_run_whole) return run_whole();
                             return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: H_array[,, i] must not couple response columns of "
-                                                                "different pairs (2k, 2k+1), which this engine evaluates side by side");
+                                                                "different pairs (2k, 2k+1), which this engine evaluates side by side "
+                                                                "(three or four columns from host arrays on one device run as one filter)");
+                        }
             }
         }
         if (is_kalman(d->model) && d->p0)
             for (int i = 0; i < sdim; i++)
                 for (int j = 0; j < sdim; j++)
-                    if (i / (2 * per_dim) != j / (2 * per_dim) && d->p0[i + (size_t)j * sdim] != 0.0)
-                        return fail(parent, SSDE_ERR_MODEL, "n_dim > 2: P0 must not couple response columns of different pairs (2k, 2k+1)");
+                    if (i / (2 * per_dim) != j / (2 * per_dim) && d->p0[i + (size_t)j * sdim] != 0.0) {
+                        if (can_run_whole) return run_whole();
+                        return fail(parent, SSDE_ERR_MODEL, "n_dim > 2: P0 must not couple response columns of different pairs (2k, 2k+1) "
+                                                            "(three or four columns from host arrays on one device run as one filter)");
+                    }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)

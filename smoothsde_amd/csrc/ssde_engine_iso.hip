@@ -244,10 +244,14 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         // p_j(i) = intercept_j + sum_k coef_k X_k(i) for the rows of par[d] and par[d + 1] (nllk_ctcrw.hpp:143-156); and the range
         // each can reach on this design (column ranges found at create), for the window plan
         for (int j = 0; j < 2; j++) h->cv_eta_lo[j] = h->cv_eta_hi[j] = 0.0;
+        // (a drift with a fixed-effect design of its own -- mu ~ 1 + x -- has NO intercept slot: its column of ones is a streamed
+        // column like the others, and the constant part of mu_a is zero)
+        for (int i = 0; i < h->d; i++) a.mu[i] = 0.0;
         for (auto& sl : h->slots) {
             const int j = sl.par_j - h->d;
             if (j < 0) {                                        // a design column of the drift: mu_a(i) = intercept + sum_k coef_k X_k(i)
                 if (sl.col >= 0) { (sl.par_j == 0 ? a.coefC : a.coefD)[sl.col] = par[sl.pidx]; a.cv_mu_cols = 1; }
+                else a.mu[sl.par_j] = par[sl.pidx];
                 continue;
             }
             const double b = par[sl.pidx];

@@ -57,12 +57,19 @@ def test_bench_line_has_what_the_driver_reads():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     assert len(d["secondary"]) == 6 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
     for s in d["secondary"]:                                       # every entry names its kernel and carries both roofs, each <= 1
-        assert s["kernel"] != "?" and s["bound"] in ("hbm", "fp64_issue") and 0 < s["frac_hbm"] <= 1.0, s
+        assert s["kernel"] != "?", s
+        if s["kernel"] == "tv_filter_kernel":                      # replayed from a hipGraph: no event pair around the launch, no roofs
+            assert s["bound"] is None and s["frac_hbm"] is None, s
+            continue
+        assert s["bound"] in ("hbm", "fp64_issue") and 0 < s["frac_hbm"] <= 1.0, s
         assert s["frac_fp64_issue"] is None or 0 < s["frac_fp64_issue"] <= 1.0, s
     kern = [s["kernel"] for s in d["secondary"]]
-    assert kern[0] == "iso_mask_kernel" and kern[2] == "iso_quiet_kernel" and kern[4] in ("iso_colvar_kernel", "iso_few_kernel") and kern[5] == "iso_full_kernel", kern
+    assert kern[0] == "iso_mask_kernel" and kern[2] == "iso_quiet_kernel" and kern[5] == "iso_full_kernel", kern
     assert "H_array" in d["secondary"][5]["workload"] and d["secondary"][5]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
-    assert "tau and nu smooth" in d["secondary"][4]["workload"] and d["secondary"][4]["path"] == "isotropic-register"   # the lane = track kernel
+    # tau and nu smooth: 640 x 80 rows x 32 lanes per track is below the rows rule of ssde_create (4.5e6 lane-rows): the lane = direction
+    # path here, the eight-wave pipeline at the default size (tests/test_gpu_colvar.py pins the rule on both sides)
+    assert "tau and nu smooth" in d["secondary"][4]["workload"] and kern[4] in ("tv_filter_kernel", "iso_colvar_kernel", "iso_few_kernel"), kern
+    assert d["secondary"][4]["path"] == ("isotropic-row-varying" if kern[4] == "tv_filter_kernel" else "isotropic-register")
     assert "one missing row" in d["secondary"][2]["workload"] and d["secondary"][2]["quiet_window"] > 0             # quiet rows of the general kernel
 
 

@@ -548,6 +548,32 @@ def test_mixed_designs_drift_columns_next_to_tau_nu_columns(model, d, kmu, k1, k
     eng.close(); e2.close()
 
 
+@pytest.mark.parametrize("model,d,which", [("CTCRW", 1, 0), ("CTCRW", 2, 1), ("OU_SSM", 2, 0), ("BM_SSM", 1, 0)])
+def test_drift_with_a_fixed_effect_design_of_its_own_next_to_smooth_tau_nu(model, d, which):
+    """mu_a ~ 1 + x as a FIXED-effect design (X_fe[a] = [1, x]): that drift has no intercept slot -- its column of ones is a
+    streamed column -- and the constant part of mu_a handed to the filter wave is zero (round 4: it was the coefficient of the
+    ones column a second time; found by the fuzz once small batches reached these kernels)."""
+    pb, par0 = _batch(model, d, 96, 700, 5, 0, seed=77)
+    n = pb.n
+    q = capi.n_sde_par(model, d)
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 41), 0, 1)
+    X_fe = [None] * q
+    X_fe[which] = np.column_stack([np.ones(n), x])
+    pb2 = capi.Problem(model, pb.id, pb.times, pb.obs, X_fe=X_fe, X_re=pb.X_re, S_list=pb.S_list)
+    rng = np.random.default_rng(5)
+    par = 0.1 * rng.standard_normal(pb2.n_par_full)
+    par[0] = np.log(0.12)
+    for a in range(d):
+        par[pb2.off_fe + pb2.fe_off[a]] = (2.0 if model == "OU_SSM" else 0.4) + 0.1 * a
+    par[pb2.off_fe + pb2.fe_off[which] + 1] = 0.3
+    par[pb2.off_fe + pb2.fe_off[d]] = np.log(2.0 if model != "BM_SSM" else 0.7)
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    _close(val, grad, *_oracle(pb2, par))
+    eng.close()
+
+
 def test_bench_size_properties(monkeypatch):
     """At the size tools/bench_colvar.py and bench.py time (10^4 tracks x 10^3 rows, 18 design columns), where the oracle is out of
     reach: the windowed evaluation agrees with the sequential one (one window per track) and with the lane = direction path, the

@@ -191,7 +191,8 @@ def test_few_tracks_stay_on_the_lane_direction_path(monkeypatch):
     eng.close()
 
 
-def test_smooths_on_other_parameters_do_not_take_the_drift_path():
+def test_smooths_on_other_parameters_do_not_take_the_drift_path(monkeypatch):
+    monkeypatch.delenv("SSDE_DRIFT_MIN_TRACKS")                 # the engine's own rule (a batch this small: the lane = direction path)
     pb, par = _batch("CTCRW", 1, 64, 200, (5,), seed=3)
     n = pb.n
     B = bspline_basis(np.clip(np.linspace(0, 1, n), 0, 1), 4)

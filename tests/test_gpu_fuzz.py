@@ -192,6 +192,35 @@ def test_random_problem_matches_oracle(seed):
     eng.close()
 
 
+def _kalman_seeds(lo, hi, models):
+    return [s for s in range(lo, hi) if models[s % len(models)] in ("CTCRW", "OU_SSM", "BM_SSM")]
+
+
+@pytest.mark.parametrize("seed,wide", [(s, False) for s in _kalman_seeds(_LO, _HI, MODELS)] + [(s, True) for s in _kalman_seeds(_WLO, _WHI, WIDE_MODELS)])
+def test_random_problem_on_the_register_lanes_whatever_its_size(seed, wide, monkeypatch):
+    """The size rules of ssde_create keep small batches off the register-lane kernels with streamed columns (k_iso_drift.hip,
+    k_iso_colvar.hip, k_iso_onewave.hip), so the seeds above hardly reach them; SSDE_DRIFT_MIN_TRACKS=1 sends every design
+    that QUALIFIES there, whatever its size (round 4 found mu ~ 1 + x next to smooth tau / nu wrong this way: the drift's
+    column of ones was counted as an intercept too)."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb, par = random_problem(seed, wide=wide)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par, order=1)
+    oval, ograd = _oracle(pb, par)
+    info = eng.info()
+    ctx = (pb.model, pb.n_dim, pb.n, pb.n_seg, info["path"], capi.KERNEL_NAMES.get(info["kernel_id"]))
+    if not np.isfinite(oval):
+        assert not np.isfinite(val), ctx
+    else:
+        assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (val, oval, ctx)
+        assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (grad, ograd, ctx)
+        from oracle_lib import oracle_eval
+        _, _, oaest = oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4, report=True)
+        sc = max(1.0, np.nanmax(np.abs(oaest)))
+        assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9 * sc, equal_nan=True), ctx
+    eng.close()
+
+
 _BLO, _BHI = (int(v) for v in os.environ.get("SSDE_FUZZ_BIG_SEEDS", "0:16").split(":"))
 
 

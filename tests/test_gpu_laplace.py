@@ -341,8 +341,9 @@ def test_exact_hessian_of_the_drift_coefficients_matches_autograd(rec, monkeypat
     eng.close()
 
 
-def test_drift_hessian_on_long_tracks_with_time_windows_matches_the_differenced_gradient():
+def test_drift_hessian_on_long_tracks_with_time_windows_matches_the_differenced_gradient(monkeypatch):
     from test_gpu_drift import _batch
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")      # (144 000 rows: below the rows rule of ssde_create; this test is about the drift lanes)
     pb, par = _batch("CTCRW", 2, 96, 1500, (9, 5), seed=11)
     eng = capi.Engine(pb)
     idx = [k for k in range(pb.off_re, pb.off_re + pb.n_re)] + [pb.off_fe, pb.off_fe + 1]

@@ -103,13 +103,46 @@ def test_block_diagonal_P0_and_supplied_a0():
     eng.close()
 
 
-def test_what_couples_the_pairs_is_refused_with_a_reason():
-    spec = make_spec("wide_bad", "CTCRW", 3, seed=5, lengths=[20, 20])
-    P0 = np.eye(6); P0[0, 4] = P0[4, 0] = 0.1
+@pytest.mark.parametrize("model,d,variant", [("CTCRW", 3, "const"), ("CTCRW", 4, "const"), ("OU_SSM", 3, "tv"), ("OU_SSM", 4, "const"),
+                                             ("BM_SSM", 3, "const"), ("BM_SSM", 4, "tv"), ("CTCRW", 3, "tv")])
+@pytest.mark.parametrize("what", ["H", "P0", "both"])
+def test_three_and_four_columns_that_couple_run_as_one_filter(model, d, variant, what):
+    """A per-row measurement covariance with entries between ALL columns (H_array[,, i] a full d x d matrix), a P0 that couples the
+    column pairs, or both: F is a full matrix and the reference evaluates it through atomic::logdet and F.inverse()
+    (nllk_ctcrw.hpp:12-24, 203-205, 231-241).  Round 3 refused these; the response now runs as ONE filter over all columns on the
+    lane = track general kernel (k_dense.hip: F by LU with partial pivoting).  Value, gradient and filtered states against the
+    oracle's full-matrix recursion, missing rows included."""
+    spec = make_spec("wide_coupled", model, d, seed=31 + d, lengths=[40, 7, 23, 2, 61, 1, 30], variant=variant, na_rows=(5, 17, 50, 90),
+                     with_H=what in ("H", "both"))
+    sd = capi.state_dim(model, d)
+    if what in ("P0", "both"):
+        rng = np.random.default_rng(7 + d)
+        A = rng.standard_normal((sd, sd))
+        spec["P0"] = A @ A.T / sd + np.eye(sd)                                  # every state component coupled with every other
+    pb = problem_from_spec(spec)
+    eng = capi.Engine(pb)
+    inf = eng.info()
+    assert inf["path"] == 2 and inf["n_devices"] == 1 and inf["sdim"] == sd, inf     # one dense engine, not a parent of column pairs
+    val, grad = eng.eval(spec["par"], order=1)
+    assert eng.info()["kernel_id"] == 14                                              # SSDE_KERNEL_DENSE
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    assert np.isfinite(oval)
+    _close(val, grad, oval, ograd)
+    assert eng.eval(spec["par"], order=0) == val
+    aest = eng.report(spec["par"])
+    _, _, oaest = oracle_eval(pb, spec["par"], order=1, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
+    eng.close()
+
+
+def test_what_still_couples_the_pairs_is_refused_with_a_reason():
+    """beyond four columns, and from device-resident arrays, a coupling entry is still refused (and says what does run)"""
+    spec = make_spec("wide_bad", "CTCRW", 5, seed=5, lengths=[20, 20])
+    P0 = np.eye(10); P0[0, 4] = P0[4, 0] = 0.1
     with pytest.raises(capi.EngineError, match="P0 must not couple"):
         capi.Engine(problem_from_spec(dict(spec, P0=P0)))
-    spec = make_spec("wide_bad", "OU_SSM", 3, seed=5, lengths=[20, 20], with_H=True)        # full 3 x 3 matrices: column 2 coupled with 0, 1
-    with pytest.raises(capi.EngineError, match="H_array.*must not couple"):
+    spec = make_spec("wide_bad", "OU_SSM", 5, seed=5, lengths=[20, 20], with_H=True)        # full 5 x 5 matrices
+    with pytest.raises(capi.EngineError, match="H_array.*must not couple.*run as one filter"):
         capi.Engine(problem_from_spec(spec))
 
 
