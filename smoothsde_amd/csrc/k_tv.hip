@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     constexpr int NS = TV_STATS / 2;
     __shared__ double sh[TV_STATS][4];
     const SlotTable* __restrict__ T = A.slots;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && A.out) A.out[A.n_out] = 0.0;   // raised by the finalize launch's checks
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (A.out && !A.chk_items) A.out[A.n_out] = 0.0;             // raised by the finalize launch's checks
+        if (A.par0_w) A.par0_w[0] = A.par[0];
+    }
     double smin[NS], smax[NS];
 #pragma unroll
     for (int k = 0; k < NS; k++) { smin[k] = INFINITY; smax[k] = -INFINITY; }
@@ -75,24 +78,32 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
     __shared__ int s_ns;
     __shared__ double t_coef[MAX_COLS];
     __shared__ int t_col[MAX_COLS], t_pj[MAX_COLS];
-    if ((int)threadIdx.x < A.n_slots) {                               // all slots' loads in flight together
+    // (the compaction is done by all threads at once: one thread walking 26 slots through LDS was 1.5 us of the C1 pre-pass's 10)
+    {
         const int k = threadIdx.x;
-        t_col[k] = T->col[k]; t_pj[k] = T->par_j[k]; t_coef[k] = A.par[T->pidx[k]];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int m = 0;
-        double base[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
-        for (int k = 0; k < A.n_slots; k++) {
-            if (t_col[k] < 0) {
-#pragma unroll
-                for (int j = 0; j < MAX_Q; j++) base[j] += (t_pj[k] == j) ? t_coef[k] : 0.0;
-                continue;
-            }
-            s_col[m] = t_col[k]; s_pj[m] = t_pj[k]; s_coef[m] = t_coef[k]; m++;
+        const bool in = k < A.n_slots;
+        int col = -1, pj = 0;
+        double coef = 0.0;
+        if (in) { col = T->col[k]; pj = T->par_j[k]; coef = A.par[T->pidx[k]]; }       // all slots' loads in flight together
+        const bool streamed = in && col >= 0;
+        const unsigned long long bal = __ballot(streamed);
+        const int wv_ = k >> 6, ln_ = k & 63;
+        __shared__ int s_cnt[4];
+        if (ln_ == 0) s_cnt[wv_] = __popcll(bal);
+        if (in) { t_col[k] = col; t_pj[k] = pj; t_coef[k] = coef; }
+        __syncthreads();
+        int m0 = 0;
+        for (int w = 0; w < wv_; w++) m0 += s_cnt[w];
+        if (streamed) {
+            const int m = m0 + __popcll(bal & ((1ull << ln_) - 1ull));
+            s_col[m] = col; s_pj[m] = pj; s_coef[m] = coef;
         }
-        s_ns = m;
-        for (int j = 0; j < MAX_Q; j++) s_base[j] = base[j];
+        if (k < MAX_Q) {                                              // the intercepts of parameter k, in slot order
+            double base = 0.0;
+            for (int q = 0; q < A.n_slots; q++) base += (t_col[q] < 0 && t_pj[q] == k) ? t_coef[q] : 0.0;
+            s_base[k] = base;
+        }
+        if (k == 0) s_ns = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
     __syncthreads();
     const int nsl = s_ns;
@@ -162,7 +173,10 @@ __global__ __launch_bounds__(256) void tv_prepare_kernel(const TvArgs A) {
 // ---- ESEAL_SSM pre-pass (nllk_e_seal_ssm.hpp:136-137, 170-173): z_i, H_i, drift, q per row ---------------------------
 __global__ __launch_bounds__(256) void tv_prepare_eseal_kernel(const TvArgs A) {
     const SlotTable* __restrict__ T = A.slots;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && A.out) A.out[A.n_out] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (A.out && !A.chk_items) A.out[A.n_out] = 0.0;
+        if (A.par0_w) A.par0_w[0] = A.par[0];
+    }
     const double tau = exp(A.par[0]), a1 = A.par[1], a2 = exp(A.par[2]);          // :114-118
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
         double par[2] = {0.0, 0.0};
@@ -204,16 +218,29 @@ __device__ __forceinline__ double tv_check_item(const TvArgs& A, int item, int l
         const bool valid = (ns > s_next) && (s_next < L);
         const double* arrived = A.bnd + ((int64_t)item * 2 + 1) * TV_NSTATE * WAVE + lane;
         const double* warmed = A.bnd + ((int64_t)(item + 1) * 2 + 0) * TV_NSTATE * WAVE + lane;
-        for (int q = 0; q < nstate; q++) {
-            const double a = valid ? arrived[q * WAVE] : 0.0, b = valid ? warmed[q * WAVE] : 0.0;
-            double err = fabs(a - b), sc = fmax(fabs(a), fabs(b));
-            if (valid && !(err == err)) err = INFINITY;
+        // (eight state entries at a time: their loads are in flight together and their reductions interleave -- the launch is a chain
+        //  of latencies, C1 waits for it)
+        for (int q0 = 0; q0 < nstate; q0 += 8) {
+            double err[8], sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool on = valid && q0 + u < nstate;
+                const int q = q0 + u < nstate ? q0 + u : 0;
+                const double a = on ? arrived[q * WAVE] : 0.0, b = on ? warmed[q * WAVE] : 0.0;
+                err[u] = fabs(a - b); sc[u] = fmax(fabs(a), fabs(b));
+                if (on && !(err[u] == err[u])) err[u] = INFINITY;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                err = fmax(err, __shfl_xor(err, o, 64));
-                sc = fmax(sc, __shfl_xor(sc, o, 64));
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    err[u] = fmax(err[u], __shfl_xor(err[u], o, 64));
+                    sc[u] = fmax(sc[u], __shfl_xor(sc[u], o, 64));
+                }
             }
-            if (err > 0.0) worst = fmax(worst, err / sc);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (err[u] > 0.0) worst = fmax(worst, err[u] / sc[u]);
         }
     }
     return worst;
@@ -222,12 +249,13 @@ __device__ __forceinline__ double tv_check_item(const TvArgs& A, int item, int l
 // workgroups [0, n_check): four items' checks each (one per wave), raising out[n_out] (zeroed by the pre-pass; a
 // non-negative double orders like its bit pattern); the others: one output slot each (0 = nllk, 1.. = gradient)
 __global__ __launch_bounds__(256) void tv_finalize_kernel(const TvArgs A, int nstate, int n_check) {
-    __shared__ double sh[256];
+    __shared__ double sh[4];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < n_check) {
         const int item = blockIdx.x * 4 + (tid >> 6);
         if (item >= A.n_items) return;
         const double w = tv_check_item(A, item, tid & 63, nstate);
+        if (A.chk_items) { if ((tid & 63) == 0) A.chk_items[item] = w == w ? w : INFINITY; return; }
         if ((tid & 63) == 0 && w > 0.0)
             atomicMax((unsigned long long*)(A.out + A.n_out), (unsigned long long)__double_as_longlong(w == w ? w : INFINITY));
         return;
@@ -251,13 +279,11 @@ __global__ __launch_bounds__(256) void tv_finalize_kernel(const TvArgs A, int ns
             for (int t = 0; t < tpw; t++) acc += p[t * lpt];
         }
     }
-    sh[tid] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);     // (a fixed order: the same sums on every launch)
+    if ((tid & 63) == 0) sh[tid >> 6] = acc;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] += sh[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) A.out[slot] = sh[0];
+    if (tid == 0) A.out[slot] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 }  // namespace

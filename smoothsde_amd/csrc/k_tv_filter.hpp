@@ -51,7 +51,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void tv_filter_kernel(const TvA
     const double* wp = A.wdir + k;
     const int64_t imax = A.n - 1;
     // sigma_obs^2: by value, or from the parameter vector when the launch is replayed from a hipGraph
-    const double h = A.h_from_par ? exp(2.0 * A.par[0]) : A.h;
+    const double h = A.h_from_par ? exp(2.0 * (A.par0_w ? A.par0_w : A.par)[0]) : A.h;
     double p0[Ops::DENSE ? 16 : 3];
 #pragma unroll
     for (int q = 0; q < (Ops::DENSE ? SD * SD : 3); q++) p0[q] = Ops::DENSE ? A.p0f[q] : A.p0[q];

@@ -406,6 +406,7 @@ hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 // lane = (track of the pack, gradient direction).
 constexpr int TV_U = 4;           // rows per prefetch block (divides WIN_ALIGN)
 constexpr int TV_NSTATE = 40;     // doubles per lane dumped at a window hand-over (dense CTCRW, d = 2: 2 (4 + 16))
+constexpr int TV_LEAN_BLOCKS = 64, TV_LEAN_ITEMS = 2048;   // the lean replay (TvArgs.par0_w): pre-pass blocks / work items at most
 constexpr int TV_STATS = 8;       // per block: min/max of dt, par[d], par[d+1], largest diag(H) over the rows the filter propagates
 struct TvItem { int32_t pack, c, nc, b; };        // work item of one wave: track pack, window c of nc, direction block
 struct TvDir { int16_t kind, dim, pidx, slot; };  // TVK_* kind, dimension (TVK_MU), full-par index, coefficient slot
@@ -451,6 +452,11 @@ struct TvArgs {
     double last_dt;              // dtimes(n-1), see IngestArgs
     int16_t dir_of_par[MAX_PAR]; // full-par index -> direction, -1 = no gradient (fixed, or not in the data term)
     double* out;                 // n_out + 1 doubles
+    // The lean form of a replayed evaluation (few rows: C1, one animal -- every graph node costs ~4 us there): `par`, `stats` and `out`
+    // are PINNED HOST memory the kernels read / write directly (no copy nodes); sigma_obs reaches the filter through a device word the
+    // pre-pass fills, and the hand-over checks land per item in pinned memory, the host takes their maximum.
+    double* par0_w;              // device, 1 double: the pre-pass writes par[0] here (NULL: the filter reads par[0] itself)
+    double* chk_items;           // pinned, [n_items]: each item's hand-over check (NULL: atomicMax into out[n_out])
 };
 hipError_t launch_tv_weights(const TvArgs& a, hipStream_t s);
 hipError_t launch_tv_a0(const TvArgs& a, const double* a0_src, const int64_t* trk_seg, int64_t n_seg, int sdim,

@@ -65,6 +65,7 @@ void release_device(ssde_handle* h) {
     h->tv_par_dev.release();
     if (h->tv_par_pinned) (void)hipHostFree(h->tv_par_pinned);
     if (h->tv_out_pinned) (void)hipHostFree(h->tv_out_pinned);
+    if (h->tv_chk_pinned) (void)hipHostFree(h->tv_chk_pinned);
     if (h->tv_stats_pinned) (void)hipHostFree(h->tv_stats_pinned);
     if (h->tv_stats_ev) (void)hipEventDestroy(h->tv_stats_ev);
     h->tiles.release(); h->a0.release(); h->group_off.release(); h->lane_row0.release();

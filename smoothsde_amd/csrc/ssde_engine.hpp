@@ -242,6 +242,9 @@ struct ssde_handle {
     DevBuf<double> tv_par_dev;
     double* tv_par_pinned = nullptr;
     double* tv_out_pinned = nullptr;
+    double* tv_chk_pinned = nullptr;          // [TV_LEAN_ITEMS] the items' hand-over checks of a lean replay (eval_tv_graph)
+    bool tv_graph_lean[2] = {false, false};
+    bool env_tv_no_lean = false;
     DevBuf<double> lap_out;                   // ssde_laplace_eval: result vectors of a batch of asynchronous evaluations
     double* out_pinned = nullptr;             // read-back target of the synchronous ssde_eval (2 + n_full doubles)
     // publication of a synchronous evaluation's result by its reducing launch (ReduceArgs.pub, ssde_device.hpp): the host spins

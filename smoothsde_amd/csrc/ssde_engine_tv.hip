@@ -123,6 +123,9 @@ int build_tv(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& sta
     HIPCHK(h, h->tv_par_dev.alloc(MAX_PAR));
     HIPCHK(h, hipHostMalloc((void**)&h->tv_par_pinned, MAX_PAR * 8, hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void**)&h->tv_out_pinned, (MAX_PAR + 2) * 8, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&h->tv_chk_pinned, (size_t)TV_LEAN_ITEMS * 8, hipHostMallocDefault));
+    memset(h->tv_chk_pinned, 0, (size_t)TV_LEAN_ITEMS * 8);
+    h->env_tv_no_lean = getenv("SSDE_TV_NO_LEAN") != nullptr;
     TvArgs a;
     tv_base_args(h, a);
     HIPCHK(h, launch_tv_weights(a, 0));
@@ -231,7 +234,7 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
         // As many windows as the chip has room for (nc_cap): with idle SIMDs around, a window may be much
         // shorter than its warm-up -- the redundant warm-up rows run in parallel, the serial chain of a wave
         // is what the evaluation waits for.  SSDE_TV_MINLEN: shortest scored stretch of a window (rows).
-        int minlen = 2 * WIN_ALIGN;
+        int minlen = WIN_ALIGN;                          // (round 4: 16 rows, not 32 -- C1's filter launch 41.5 -> 33 us)
         if (h->env_tv_minlen > 0) minlen = h->env_tv_minlen;
         if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + minlen - 1) / minlen));
         max_nc = std::max(max_nc, nc);
@@ -318,23 +321,32 @@ int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) 
     const double sig = exp(par[0]);
     int st = tv_plan(h, sig * sig, h->tv_stream);        // from the statistics of the previous evaluation
     if (st) return st;
-    if (!h->tv_gexec[ord] || h->tv_graph_plan[ord] != h->tv_plan_gen) {
+    // few rows (C1: one animal): every node of the graph costs ~4 us, the three copies as much as the kernels between them -- the
+    // kernels read the parameters from, and write the statistics / sums / checks to, pinned host memory themselves (TvArgs.par0_w)
+    const int n_items_now = ord ? h->tv_n_items_g : h->tv_n_items_v;
+    const bool lean = !h->env_tv_no_lean && h->tv_chk_pinned && h->tv_stats_blocks <= TV_LEAN_BLOCKS && n_items_now <= TV_LEAN_ITEMS;
+    if (!h->tv_gexec[ord] || h->tv_graph_plan[ord] != h->tv_plan_gen || h->tv_graph_lean[ord] != lean) {
         if (h->tv_gexec[ord]) { (void)hipGraphExecDestroy(h->tv_gexec[ord]); h->tv_gexec[ord] = nullptr; }
         TvArgs a;
         tv_base_args(h, a);
         a.par = h->tv_par_dev.p; a.h_from_par = 1; a.h = 0.0; a.out = h->out.p; a.window = h->tv_window;
         a.items = ord ? h->tv_items_g.p : h->tv_items_v.p;
-        a.n_items = ord ? h->tv_n_items_g : h->tv_n_items_v;
+        a.n_items = n_items_now;
+        if (lean) {
+            a.par = h->tv_par_pinned; a.par0_w = h->tv_par_dev.p; a.stats = h->tv_stats_pinned;
+            a.out = h->tv_out_pinned; a.chk_items = h->tv_chk_pinned;
+        }
         hipStream_t s = h->tv_stream;
         hipGraph_t g = nullptr;
         HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(h->tv_par_dev.p, h->tv_par_pinned, (size_t)n_full * 8, hipMemcpyHostToDevice, s);
+        hipError_t e = hipSuccess;
+        if (!lean) e = hipMemcpyAsync(h->tv_par_dev.p, h->tv_par_pinned, (size_t)n_full * 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = launch_tv_prepare(a, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !lean) e = hipMemcpyAsync(h->tv_stats_pinned, h->tv_stats.p, (size_t)h->tv_stats_blocks * TV_STATS * 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = launch_tv_filter(a, ord == 1, s);
         h->last_kernel_id = (h->tv_dense || is_eseal(h->model)) ? SSDE_KERNEL_TV_DENSE : SSDE_KERNEL_TV;
         if (e == hipSuccess) e = launch_tv_finalize(a, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->tv_out_pinned, h->out.p, (size_t)(2 + n_full) * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !lean) e = hipMemcpyAsync(h->tv_out_pinned, h->out.p, (size_t)(2 + n_full) * 8, hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipStreamEndCapture(s, &g);
         if (e != hipSuccess || e2 != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
@@ -345,11 +357,17 @@ int eval_tv_graph(ssde_handle* h, const double* par, int order, double* o_host) 
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) { h->tv_gexec[ord] = nullptr; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return SSDE_ERR_HIP; }
         h->tv_graph_plan[ord] = h->tv_plan_gen;
+        h->tv_graph_lean[ord] = lean;
     }
     memcpy(h->tv_par_pinned, par, (size_t)n_full * 8);
     HIPCHK(h, hipGraphLaunch(h->tv_gexec[ord], h->tv_stream));
     HIPCHK(h, hipStreamSynchronize(h->tv_stream));
     memcpy(o_host, h->tv_out_pinned, (size_t)(2 + n_full) * 8);
+    if (lean) {                                          // the largest of the items' hand-over checks (NaN was stored as +inf)
+        double w = 0.0;
+        for (int i = 0; i < n_items_now; i++) w = std::max(w, h->tv_chk_pinned[i]);
+        o_host[1 + n_full] = w;
+    }
     h->ev_k_valid = false;                               // no per-kernel timing inside a replayed graph
     h->last_chunks = h->tv_max_nc; h->last_window = h->tv_window;
     return SSDE_OK;
