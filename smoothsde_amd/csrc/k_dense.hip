@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WAVE) void dense_kernel(const DenseArgs A) {
         for (int j = 0; j < Q; j++) par[j] = DualN<N>(0.0);
         for (int k = 0; k < nslots; k++) {
             const int col = T->col[k];
-            const double w = (col >= 0) ? o[(c0 + col) * WAVE] : 1.0;
+            const double w = (col >= 0) ? (A.pp.nb ? ppd_value_hbm(A.pp, col, o + c0 * WAVE) : o[(c0 + col) * WAVE]) : 1.0;
             const double t = w * A.par[T->pidx[k]];
             const int j = T->par_j[k];
 #pragma unroll

@@ -59,6 +59,68 @@ struct TileView {
 };
 
 // ---- constant-coefficient isotropic Kalman kernels (k_iso.hip) -----------------------------
+// ---- a smooth drift whose design blocks are FUNCTIONS of a covariate (ssde_ppbasis, include/ssde.h): the tiles carry the covariate
+// (one channel per block: 8 B/row) and the lanes evaluate the block's K columns from the piecewise-cubic table in LDS, instead of
+// streaming K columns (8 K B/row).  At most two blocks (mu_1, mu_2); block b's columns are slots k0[b] .. k0[b] + kcols[b] - 1.
+constexpr int PPD_LDS = 1024;              // doubles per block in LDS: (nk - 1) * (K * 4 + 2) table entries (padded, ppd_stage) + nk knots
+struct PpDrift {
+    int nb;                                // 0: the columns are streamed
+    int kcols[2], k0[2], nk[2], uniform[2];
+    double x0[2], inv_h[2];                // equally spaced knots: interval by multiplication
+    const double* tab[2];                  // HBM [(nk - 1) * kcols * 4]
+    const double* knots[2];                // HBM [nk]
+};
+#ifdef __HIPCC__
+// tables and knots into LDS, once per workgroup (every thread of the block calls this, before any wave leaves).  An interval's
+// K x 4 coefficients are followed by two doubles of padding: the lanes of a wave sit in DIFFERENT intervals and read 16 bytes each --
+// with a stride that is an odd number of 16-byte slots, eight consecutive intervals land in eight different bank groups (the unpadded
+// stride, 32 K bytes, lands intervals iv and iv + 4 in the same banks).
+__device__ __forceinline__ int ppd_stride(int K) { return K * 4 + 2; }
+__device__ __forceinline__ void ppd_stage(const PpDrift& P, double* lds /* [2 * PPD_LDS] */) {
+    for (int b = 0; b < P.nb; b++) {
+        const int K4 = P.kcols[b] * 4, KS = ppd_stride(P.kcols[b]), ni = P.nk[b] - 1;
+        for (int k = threadIdx.x; k < ni * K4; k += blockDim.x) lds[b * PPD_LDS + (k / K4) * KS + (k % K4)] = P.tab[b][k];
+        for (int k = threadIdx.x; k < P.nk[b]; k += blockDim.x) lds[b * PPD_LDS + ni * KS + k] = P.knots[b][k];
+    }
+    __syncthreads();
+}
+// this lane's interval and offset in block b for covariate value x: returns the LDS index of the interval's first entry MINUS the
+// block's first slot (so that slot k's four coefficients sit at [ret + 4 k]), t = x - knots[iv]
+__device__ __forceinline__ int ppd_locate(const PpDrift& P, const double* lds, int b, double x, double& t) {
+    const int nk = P.nk[b], K = P.kcols[b], KS = ppd_stride(K);
+    const double* knots = lds + b * PPD_LDS + (nk - 1) * KS;
+    int iv;
+    if (P.uniform[b]) {
+        iv = (int)floor((x - P.x0[b]) * P.inv_h[b]);
+        iv = iv < 0 ? 0 : (iv > nk - 2 ? nk - 2 : iv);
+        if (iv > 0 && x < knots[iv]) iv--;                   // (the multiplication may land one interval off at a breakpoint)
+        else if (iv < nk - 2 && x >= knots[iv + 1]) iv++;
+    } else {
+        iv = 0;
+        for (int k = 1; k < nk - 1; k++) iv += (x >= knots[k]) ? 1 : 0;
+    }
+    t = x - knots[iv];
+    return b * PPD_LDS + iv * KS - P.k0[b] * 4;
+}
+// the same without LDS, straight from the tables in HBM (ssde_report of such a handle: once per fit)
+__device__ __forceinline__ double ppd_value_hbm(const PpDrift& P, int k, const double* xs /* the row's covariates, stride WAVE */) {
+    const int b = (P.nb > 1 && k >= P.k0[1]) ? 1 : 0;
+    const double x = xs[b * WAVE];
+    const int nk = P.nk[b], K = P.kcols[b];
+    int iv = 0;
+    for (int q = 1; q < nk - 1; q++) iv += (x >= P.knots[b][q]) ? 1 : 0;
+    const double t = x - P.knots[b][iv];
+    const double* q = P.tab[b] + ((int64_t)iv * K + (k - P.k0[b])) * 4;
+    return fma(fma(fma(q[3], t, q[2]), t, q[1]), t, q[0]);
+}
+// slot k's value: the cubic of its block's interval (uniform k)
+__device__ __forceinline__ double ppd_value(const double* lds, int at, int k, double t) {
+    const double2* q = (const double2*)(lds + at + 4 * k);
+    const double2 lo = q[0], hi = q[1];
+    return fma(fma(fma(hi.y, t, hi.x), t, lo.y), t, lo.x);
+}
+#endif
+
 struct IsoArgs {
     TileView tv;
     double* partials;            // [n_parts * n_chunks][NACC][n_groups]
@@ -122,6 +184,7 @@ struct IsoArgs {
     double coefA[DRIFT_KMAX];    // coefficient of column k if it feeds dimension 0, else 0
     double coefB[DRIFT_KMAX];    // ... dimension 1
     unsigned drift_dim1;         // bit k: column k feeds dimension 1
+    PpDrift pp;                  // pp.nb > 0: tile channels c_col .. c_col + pp.nb - 1 hold the blocks' covariates instead of the columns
     // Row-varying tau / nu (kappa, sigma) on lane = track lanes (k_iso_colvar.hip): the linear predictors are
     // p1(i) = cv_eta0[0] + sum_k coefA[k] X_k(i) and p2(i) = cv_eta0[1] + sum_k coefB[k] X_k(i) over the drift_k streamed columns
     double cv_eta0[2];
@@ -397,6 +460,7 @@ struct DenseArgs {
     const int64_t* lane_row0;
     int64_t n;
     double last_dt;              // dtimes(n-1), see IngestArgs
+    PpDrift pp;                  // pp.nb > 0: the tiles hold covariates, the slots' columns come out of the blocks' tables (REPORT of such a handle)
 };
 hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s);
 

@@ -645,6 +645,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
     for (int i = 0; i < 64; i++) a.p0[i] = h->p0_full[i];
     a.n_dirblocks = 1; a.dirs = nullptr; a.partials = nullptr;
+    a.pp = h->pp_drift;
     a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = nt; a.last_dt = h->last_dt;
     HIPCHK(h, launch_dense(a, false, 0));
     if (h->n_pad > 0) {                                          // the caller's rows out of the lattice's
@@ -821,6 +822,8 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     }
     // row-varying tau / nu: a design column both parameters use is resident (and read) once
     if (h->drift == 3) info->required_bytes_per_row -= 8.0 * (double)(h->n_stream_cols_algo - h->n_stream_cols);
+    // a smooth drift evaluated from its blocks' tables: one covariate per block is resident, not the columns
+    if (h->pp_drift.nb > 0) info->required_bytes_per_row -= 8.0 * (double)(h->n_stream_cols - h->pp_drift.nb);
     if (h->n_pad > 0) info->required_bytes_per_row *= (double)h->n_pad / (double)h->n;
     if (h->path == PATH_ISO || h->path == PATH_DENSE) {
         info->n_rows_tiled = h->n_pad > 0 ? h->n_pad : h->n;

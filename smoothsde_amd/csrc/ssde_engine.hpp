@@ -88,6 +88,9 @@ struct ssde_handle {
     PPRef pp[MAX_Q] = {};
     bool pp_fast[MAX_Q] = {false, false, false, false};
     DevBuf<double> pp_x[MAX_Q], pp_knots[MAX_Q], pp_tab[MAX_Q], pp_mat[MAX_Q];
+    PpDrift pp_drift = {};                     // nb > 0: a smooth drift whose blocks the lanes evaluate from the tables (k_iso_drift_pp.hip); the tiles hold the covariates
+    int pp_drift_j[2] = {-1, -1};              // ... the SDE parameter of each block
+    bool no_drift_pp = false;                  // (a second build after SSDE_RETRY_WITHOUT_PP)
     int n_stream_cols_algo = 0;                    // streamed columns of the reference's data contract (algorithmic bytes)
 
     // fast direct kernel (<= 2 parameters with streamed columns)

@@ -129,6 +129,7 @@ int lattice_pad(const ssde_desc* d, ssde_handle* h, const std::vector<int64_t>& 
 
 namespace ssde_engine {
 constexpr int SSDE_RETRY_WITHOUT_DRIFT = -77;     // internal: the drift layout was tried and the data do not qualify
+constexpr int SSDE_RETRY_WITHOUT_PP = -78;        // internal: the drift's blocks were tiled as covariates and the lanes that would read them are the general ones
 // ---- step 5 (register path): which lanes run it (shared covariance / own covariance, with or without drift columns), how many
 // time windows, and the buffers of the hand-over check.  gflags[g] != 0: group g has no missing row; glen: padded steps per group ----
 static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>& gflags, const std::vector<int32_t>& lane_ns,
@@ -262,6 +263,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         // (SSDE_NO_DRIFT_GENERAL: back to the lane = direction path instead, for A/B)
         bool all_clean = h->uniform_dt;
         for (int g = 0; g < G; g++) all_clean = all_clean && gflags[g] != 0;
+        // (the lanes that carry their own covariance are issue-bound already: the table form costs them a third more -- tile the columns)
+        if (!all_clean && h->pp_drift.nb > 0 && !getenv("SSDE_DRIFT_PP_ALL")) return SSDE_RETRY_WITHOUT_PP;
         if (!all_clean && getenv("SSDE_NO_DRIFT_GENERAL")) return SSDE_RETRY_WITHOUT_DRIFT;
         if (getenv("SSDE_NO_SHARED")) all_clean = false;                  // (testing: the general lanes on a batch the shared ones would take)
         h->drift = all_clean ? 1 : 2;
@@ -316,6 +319,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         want = std::max(1, (h->model == SSDE_MODEL_CTCRW ? 2048 : 3072) / (((G + 7) / 8 * 8) * h->iso_parts));
     // row-varying tau / nu: a WORKGROUP per (group, window), one per CU -- up to eight rounds' worth; plan_windows picks the count
     if (h->drift == 3 && !h->cv_one_wave()) want = std::max(1, (8 * 256 + G - 1) / G);
+    // a smooth drift evaluated from tables: the lanes wait for LDS, two waves per SIMD hide each other's round trips (1.88 -> 1.24 ms)
+    if (h->drift && h->pp_drift.nb > 0) want = std::max(1, 2048 / (((G + 7) / 8 * 8) * h->iso_parts));
     // The resident tiles against the 256 MB Infinity Cache: a batch that fits is still there at the next evaluation if the loads
     // are ordinary ones; a batch far beyond it is streamed past the caches (measured, profiles/r04_a_nt_vs_plain.txt: 205 MB
     // 0.053 -> 0.044 ms with ordinary loads, 260 / 330 / 410 MB no difference, 1.6 GB 0.259 -> 0.274 ms)
@@ -406,6 +411,12 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
 static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout, bool allow_drift);
 int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
     int st = build_impl(d, h, part_layout, true);
+    if (st == SSDE_RETRY_WITHOUT_PP) {
+        release_device(h);
+        *h = ssde_handle();
+        h->no_drift_pp = true;
+        st = build_impl(d, h, part_layout, true);
+    }
     if (st == SSDE_RETRY_WITHOUT_DRIFT) {
         // the row-varying-drift layout needs a regular grid and no missing row, which only the tiling pass finds out:
         // start over on the path such a batch takes otherwise
@@ -830,7 +841,43 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (by_tracks) min_tracks = atoi(getenv("SSDE_DRIFT_MIN_TRACKS"));
             const double n_rows = (double)n;
             const bool drift_pays = by_tracks ? h->n_seg >= min_tracks : n_rows >= (h->model == SSDE_MODEL_CTCRW ? 5e5 : 1.5e5);
-            if (iso_cfg && mu_only && drift_pays && h->n_stream_cols <= DRIFT_KMAX) { h->drift = 1; h->path = PATH_ISO; }
+            if (iso_cfg && mu_only && drift_pays && h->n_stream_cols <= DRIFT_KMAX) {
+                h->drift = 1; h->path = PATH_ISO;
+                // Every streamed column belongs to a block given as a FUNCTION of a covariate (basis_re): the tiles carry the covariate, the lanes
+                // evaluate the block from its table in LDS (k_iso_drift_pp.hip): 8 B/row per block where the columns cost 8 K.
+                // Measured (tools/bench_drift.py ... table, 10^4 x 10^4, K = 9, two waves per SIMD): the lanes' per-row table reads -- 2 K
+                // 16-byte LDS reads at per-lane addresses -- bind, not HBM: BM_SSM 1.13 against 1.27 ms streamed, OU_SSM d = 1 1.24 / 1.29,
+                // d = 2 1.54 / 1.49; CTCRW (AGPR spills on top) 2.3 / 1.44 and the general lanes 1.99 / 1.48 are slower and keep the
+                // streamed form (SSDE_DRIFT_PP_ALL=1: everything that qualifies, for the tests).  What the table form always wins is
+                // HBM: tiles of 8 (d + blocks) bytes per row instead of 8 (d + K).
+                const bool pp_all = getenv("SSDE_DRIFT_PP_ALL") != nullptr;
+                bool pp = !getenv("SSDE_NO_DRIFT_PP") && !h->no_drift_pp && (h->model != SSDE_MODEL_CTCRW || pp_all);
+                int nb = 0, blk_j[2] = {-1, -1};
+                for (auto& sl : h->slots) {
+                    if (sl.col < 0) continue;
+                    if (sl.basis_c < 0) { pp = false; break; }
+                    if (nb == 0 || blk_j[nb - 1] != sl.par_j) { if (nb == 2) { pp = false; break; } blk_j[nb++] = sl.par_j; }
+                }
+                const int ng = (h->n_stream_cols + 3) / 4;
+                // (the instantiations the compiler spills to scratch: the streamed form keeps those shapes)
+                if (h->model == SSDE_MODEL_CTCRW && ((h->d == 2 && ng >= 4) || ng >= 6)) pp = false;
+                PpDrift P;
+                memset(&P, 0, sizeof(P));
+                if (pp && nb > 0) {
+                    int k0 = 0;
+                    for (int b = 0; b < nb; b++) {
+                        const int j = blk_j[b];
+                        const PPRef& R = h->pp[j];
+                        const int K = h->L.ncol_re[j];
+                        if (!R.x || (R.nk - 1) * (K * 4 + 2) + R.nk > PPD_LDS) { pp = false; break; }
+                        P.kcols[b] = K; P.k0[b] = k0; P.nk[b] = R.nk; P.uniform[b] = R.uniform; P.x0[b] = R.k0; P.inv_h[b] = R.inv_h;
+                        P.tab[b] = R.tab; P.knots[b] = R.knots;
+                        k0 += K;
+                    }
+                    if (pp && k0 != h->n_stream_cols) pp = false;
+                    if (pp) { P.nb = nb; h->pp_drift = P; h->pp_drift_j[0] = blk_j[0]; h->pp_drift_j[1] = blk_j[1]; }
+                }
+            }
             // Row-varying tau / nu (kappa, sigma) with a constant drift, many tracks: lane = track lanes that carry one filter
             // tangent per design column (k_iso_colvar.hip) -- the lane = direction path below costs a wave-row per track-row
             // whatever the batch.
@@ -963,7 +1010,9 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
             if (const char* e = getenv("SSDE_GRID_RTOL")) rtol = std::max(0.0, atof(e));
             if (std::isfinite(lo) && lo > 0.0 && hi <= lo * (1.0 + rtol)) { h->c_obs = 0; h->dt_all = 0.5 * (lo + hi); }
         }
-        h->C = h->c_obs + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + h->n_stream_cols;
+        // (a smooth drift evaluated from tables: one channel per block -- its covariate -- instead of one per column)
+        const int n_tile_cols = h->pp_drift.nb > 0 ? h->pp_drift.nb : h->n_stream_cols;
+        h->C = h->c_obs + d->n_dim + (h->has_h ? d->n_dim * d->n_dim : 0) + n_tile_cols;
         std::vector<int64_t> lane_row0((size_t)G * WAVE, -1), lane_seg((size_t)G * WAVE, 0), goff(G);
         std::vector<int32_t> lane_ns((size_t)G * WAVE, 0), glen(G);
         int64_t off = 0;
@@ -1002,7 +1051,11 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         if (!t_on_dev) {
             if (h->has_h) { HIPCHK(h, stage(d->h_array, (size_t)tn * d->n_dim * d->n_dim, false, s_h)); p_h = s_h.p; }
         }
-        std::vector<const double*> cp(h->n_stream_cols, nullptr);
+        std::vector<const double*> cp(n_tile_cols, nullptr);
+        if (h->pp_drift.nb > 0) {
+            for (int b = 0; b < h->pp_drift.nb; b++) cp[b] = h->pp[h->pp_drift_j[b]].x;      // (engine-owned copies in HBM: stage_basis_tables)
+            HIPCHK(h, s_colptr.upload(cp));
+        } else
         if (h->n_stream_cols > 0) {
             if (!t_on_dev) HIPCHK(h, s_cols.alloc((size_t)tn * h->n_stream_cols));
             for (auto& s : h->slots)
@@ -1028,7 +1081,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         HIPCHK(h, mm.alloc((size_t)G * ych * 3));
         IngestArgs ia;
         ia.times = p_times; ia.obs = p_obs; ia.h_array = h->has_h ? p_h : nullptr;
-        ia.cols = s_colptr.p; ia.ncols = h->n_stream_cols; ia.d = d->n_dim; ia.n = tn;
+        ia.cols = s_colptr.p; ia.ncols = n_tile_cols; ia.d = d->n_dim; ia.n = tn;
         ia.lane_row0 = h->lane_row0.p; ia.lane_nsteps = h->lane_nsteps.p;
         ia.group_off = h->group_off.p; ia.group_len = h->group_len.p;
         ia.n_groups = G; ia.C = h->C; ia.c_obs = h->c_obs; ia.tiles = h->tiles.p; ia.a0 = h->a0.p;
@@ -1062,6 +1115,8 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         if (h->path == PATH_ISO) {
             const int st = plan_register_path(h, G, gflags, lane_ns, glen);
             if (st) return st;
+            if (h->pp_drift.nb > 0)                                 // the tiles hold the covariates: neither the materialised blocks nor the copies are read again
+                for (int b = 0; b < h->pp_drift.nb; b++) { h->pp_mat[h->pp_drift_j[b]].release(); h->pp_x[h->pp_drift_j[b]].release(); h->pp[h->pp_drift_j[b]].x = nullptr; }
         } else {
             // gradient directions of the dense kernel: free parameters that reach the data term
             std::vector<DenseDir> dirs;

@@ -288,6 +288,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             else { a.coefB[sl.col] = par[sl.pidx]; a.drift_dim1 |= 1u << sl.col; }
         }
         a.drift_k = h->n_stream_cols; a.c_col = h->c_obs + h->d;
+        a.pp = h->pp_drift;
     }
     const double p1 = par[L.off_fe + L.fe_off[h->d]];
     const double p2 = (h->q > h->d + 1) ? par[L.off_fe + L.fe_off[h->d + 1]] : 0.0;

@@ -161,9 +161,9 @@ def bspline_ppbasis(x, n_basis: int = 9, degree: int = 3, centre=None):
             idx = np.where((pp.x[:-1] == inner[iv]) & (pp.x[1:] == inner[iv + 1]))[0][0]
             tab[iv, j, :] = pp.c[::-1, idx]
     tab = tab[:, 1:, :].copy()
-    xs = np.clip(np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, dtype=np.float64), 0.0, 1.0)
     basis = PPBasis(x, inner, tab)
     if centre is None:
+        xs = np.clip(np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, dtype=np.float64), 0.0, 1.0)
         centre = PPBasis(xs, inner, tab).dense().mean(axis=0)
     basis.coef[:, :, 0] -= np.asarray(centre)[None, :]
     return basis

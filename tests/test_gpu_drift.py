@@ -241,3 +241,92 @@ def test_a_response_wider_than_two_columns_runs_the_drift_kernels_as_column_pair
     val, grad = eng.eval(par)
     _close(val, grad, *_oracle(pb, par))
     eng.close()
+
+
+# ---- drift blocks given as functions of a covariate (ssde_ppbasis): evaluated by the lanes from the table (k_iso_drift_pp.hip) ----
+def _table_batch(model, d, M, T, ks, seed, what="clean"):
+    from smoothsde_amd.synth import bspline_ppbasis
+    pb0, par = _batch(model, d, M, T, ks, seed)
+    n = pb0.n
+    x = np.clip(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 37) + 0.05 * np.random.default_rng(seed + 1).standard_normal(n), 0, 1)
+    q = capi.n_sde_par(model, d)
+    basis = [None] * q
+    for a in range(d):
+        if ks[a]:
+            basis[a] = bspline_ppbasis(np.clip(x ** (1 + a), 0, 1), ks[a])
+    o, t = pb0.obs.copy(), pb0.times.copy()
+    rng = np.random.default_rng(4)
+    if what in ("missing", "both"):
+        na = rng.random(n) < 0.05
+        na[pb0.seg_start] = False
+        o[na, 0] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, n))
+    pb = capi.Problem(model, pb0.id, t, o, S_list=pb0.S_list, basis_re=basis)
+    return pb, par
+
+
+@pytest.mark.parametrize("model,d,ks", [("OU_SSM", 1, (9,)), ("CTCRW", 2, (6, 6)), ("BM_SSM", 2, (0, 6)), ("CTCRW", 1, (5,)), ("OU_SSM", 2, (12, 10))])
+@pytest.mark.parametrize("what", ["clean", "missing", "irregular"])
+def test_drift_blocks_given_as_tables_are_evaluated_by_the_lanes(model, d, ks, what, monkeypatch):
+    """basis_re on the drift of a state-space model: the tiles carry the block's COVARIATE (8 B/row per block instead of 8 K),
+    the lanes evaluate the row's K columns from the piecewise-cubic table in LDS -- value, gradient, REPORT(aest_all) and the
+    exact drift Hessian against the oracle (which reads the dense block the table stands for) and against the streamed form."""
+    pb, par = _table_batch(model, d, 96, 700, ks, seed=31, what=what)
+    nb = sum(1 for k in ks if k)
+    if model == "CTCRW" or what != "clean":
+        # where the table form is slower than the streamed one (CTCRW; the lanes that carry their own covariance) ssde_create keeps
+        # the columns: the kernels exist all the same, SSDE_DRIFT_PP_ALL=1 runs them
+        e0 = capi.Engine(pb)
+        assert _is_drift(e0) and e0.info()["required_bytes_per_row"] == 8.0 * (d + sum(ks) + (1 if what == "irregular" else 0))
+        e0.close()
+        monkeypatch.setenv("SSDE_DRIFT_PP_ALL", "1")
+    eng = capi.Engine(pb)
+    assert _is_drift(eng)
+    inf = eng.info()
+    assert inf["required_bytes_per_row"] == 8.0 * (d + nb + (1 if what == "irregular" else 0)), inf["required_bytes_per_row"]
+    val, grad = eng.eval(par)
+    assert eng.info()["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb, par))
+    aest = eng.report(par)
+    _, _, oaest = _oracle(pb, par, report=True)
+    assert np.allclose(aest, oaest, rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("SSDE_NO_DRIFT_PP", "1")
+    e2 = capi.Engine(pb)
+    assert _is_drift(e2) and e2.info()["required_bytes_per_row"] == 8.0 * (d + sum(ks) + (1 if what == "irregular" else 0))
+    v2, g2 = e2.eval(par)
+    assert abs(val - v2) <= 1e-12 * max(1.0, abs(val)) and np.max(np.abs(grad - g2)) <= 1e-10 * np.max(np.abs(grad))
+    if what == "clean":                                    # the exact Hessian over the drift coefficients (shared-covariance lanes)
+        idx = list(range(pb.off_re, pb.off_re + pb.n_re)) + [pb.off_fe + pb.fe_off[a] for a in range(d)]
+        H1, H2 = eng.hess(par, idx), e2.hess(par, idx)
+        assert np.max(np.abs(H1 - H2)) <= 1e-10 * np.max(np.abs(H2))
+    assert eng.info()["hbm_bytes"] < e2.info()["hbm_bytes"]
+    eng.close(); e2.close()
+
+
+def test_table_drift_on_long_tracks_with_time_windows_and_device_resident_covariates():
+    import torch
+    from smoothsde_amd.synth import bspline_ppbasis
+    pb, par = _table_batch("OU_SSM", 1, 128, 4000, (9,), seed=5)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert _is_drift(eng) and inf["lanes_per_track"] > 1 and inf["window"] > 0 and inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb, par))
+    # the same batch handed over as HBM tensors (SSDE_FLAG_DEVICE_DATA): the covariate never exists as a block of columns
+    dev = "cuda:0"
+    bd = bspline_ppbasis(torch.tensor(np.asarray(pb.basis_re[0].x), device=dev), 9, centre=_centre_of(pb.basis_re[0]))
+    pbd = capi.Problem.from_torch("OU_SSM", torch.tensor(pb.id, device=dev), torch.tensor(pb.times, device=dev), torch.tensor(pb.obs, device=dev),
+                                  basis_re=[bd, None, None], S_list=pb.S_list)
+    ed = capi.Engine(pbd)
+    vd, gd = ed.eval(par)
+    assert ed.info()["required_bytes_per_row"] == 16.0
+    assert vd == val and np.array_equal(gd, grad)
+    eng.close(); ed.close()
+
+
+def _centre_of(basis):
+    """the column means a bspline_ppbasis subtracted (its table's constant terms against the uncentred table's)"""
+    from smoothsde_amd.synth import bspline_ppbasis
+    raw = bspline_ppbasis(np.asarray(basis.x), basis.n_cols, centre=np.zeros(basis.n_cols))
+    return raw.coef[0, :, 0] - basis.coef[0, :, 0]

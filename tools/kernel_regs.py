@@ -25,5 +25,5 @@ for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
     rows.append((name, acc if acc else total, total - acc if acc else 0, f("next_free_sgpr"), f("private_segment_fixed_size"), f("group_segment_fixed_size")))
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
 for nm, r in zip(names, rows):
-    nm = re.sub(r"^void ssde::", "", nm).split("(")[0]
+    nm = re.sub(r"^void ssde::", "", nm.replace("(anonymous namespace)::", "")).split("(")[0]
     print(f"{nm:60s} vgpr {r[1]:4d} agpr {r[2]:4d} sgpr {r[3]:4d} scratch {r[4]:6d} lds {r[5]:6d}")
