@@ -135,6 +135,12 @@ enum {
 #define SSDE_FLAG_DEVICE_DATA   0x1u /* id/times/obs/x_fe/x_re/h_array pointers are HBM pointers on `device` */
 #define SSDE_FLAG_FORCE_DENSE   0x2u /* disable the isotropic register path (testing the dense path)         */
 #define SSDE_FLAG_NO_UNIFORM_DT 0x4u /* disable hoisting of the transition matrices on a regular time grid    */
+#define SSDE_FLAG_EXACT_HESS    0x8u /* the caller will ask for exact second derivatives (ssde_hess, ssde_laplace_eval): a state-space
+                                        batch with row-varying coefficients that ssde_create puts on the lane = track register kernels
+                                        (k_iso_colvar.hip, the general lanes of k_iso_drift.hip -- first-order kernels) gets a second,
+                                        lane = direction copy of its rows for the second-order pass (k_tv_hess.hip): ~0.5 KB of HBM per
+                                        row on top of the tiles.  Without the flag such a handle answers SSDE_ERR_MODEL and the
+                                        Laplace layer differences the gradient.  Single device. */
 
 /* A random-effect design block given as a FUNCTION of one covariate instead of as n x K numbers: a piecewise-cubic
  * table (regression-spline bases -- mgcv "cr", "cs", "bs", "ps" -- are exactly that; thin-plate bases are not and

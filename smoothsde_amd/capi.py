@@ -26,7 +26,7 @@ UNSUPPORTED_MODELS = ()
 
 NA_R_ONLY, NA_ANY_NAN = 0, 1
 PATH_NAMES = {0: "direct", 1: "isotropic-register", 2: "dense", 3: "isotropic-row-varying"}
-FLAG_DEVICE_DATA, FLAG_FORCE_DENSE, FLAG_NO_UNIFORM_DT = 0x1, 0x2, 0x4
+FLAG_DEVICE_DATA, FLAG_FORCE_DENSE, FLAG_NO_UNIFORM_DT, FLAG_EXACT_HESS = 0x1, 0x2, 0x4, 0x8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

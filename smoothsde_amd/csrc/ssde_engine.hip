@@ -84,6 +84,7 @@ void release_device(ssde_handle* h) {
 
 void destroy(ssde_handle* h) {
     if (!h) return;
+    if (h->hess_companion) { destroy(h->hess_companion); h->hess_companion = nullptr; }
     release_device(h);
     delete h;
 }
@@ -254,6 +255,16 @@ int ssde_create(const ssde_desc* desc, ssde_handle** out) {
         g_create_error = h->err;
         destroy(h);
         return st;
+    }
+    if (!sharded && (desc->flags & SSDE_FLAG_EXACT_HESS) && h->path == PATH_ISO && (h->drift == 2 || h->drift == 3) && !h->has_h) {
+        // the rows a second time, in the layout the second-order kernels read (ssde_hess.hip: hess_tv_device)
+        ssde_handle* c = new (std::nothrow) ssde_handle();
+        if (c) {
+            c->force_tv = true;
+            const int stc = build(desc, c);
+            if (stc == SSDE_OK && c->path == PATH_TV && !c->tv_dense) h->hess_companion = c;
+            else destroy(c);                                 // (not exact there either: ssde_hess says so when asked)
+        }
     }
     *out = h;
     return SSDE_OK;

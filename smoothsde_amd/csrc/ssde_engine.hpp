@@ -91,6 +91,8 @@ struct ssde_handle {
     PpDrift pp_drift = {};                     // nb > 0: a smooth drift whose blocks the lanes evaluate from the tables (k_iso_drift_pp.hip); the tiles hold the covariates
     int pp_drift_j[2] = {-1, -1};              // ... the SDE parameter of each block
     bool no_drift_pp = false;                  // (a second build after SSDE_RETRY_WITHOUT_PP)
+    bool force_tv = false;                     // the lane = direction path whatever the batch's size (the companion of SSDE_FLAG_EXACT_HESS)
+    ssde_handle* hess_companion = nullptr;     // SSDE_FLAG_EXACT_HESS: the same problem on the lane = direction path, for k_tv_hess.hip
     int n_stream_cols_algo = 0;                    // streamed columns of the reference's data contract (algorithmic bytes)
 
     // fast direct kernel (<= 2 parameters with streamed columns)

@@ -828,7 +828,7 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         const bool h1_cfg = h->has_h && h->d == 1 && p0_is_isotropic(d, h->p0_iso) && !getenv("SSDE_NO_COLVAR_FULL");
         // (... also with CONSTANT coefficients: tracks with error ellipses and one tau, one nu -- the intercepts are columns of ones)
         if (!iso_ok && h->d <= 2 && allow_drift && (iso_cfg || full_cfg || h1_cfg) && (!h->const_coeff || full_cfg || h1_cfg) && !(d->flags & SSDE_FLAG_FORCE_DENSE) &&
-            !getenv("SSDE_NO_DRIFT")) {
+            !getenv("SSDE_NO_DRIFT") && !h->force_tv) {
             bool mu_only = true;
             for (auto& sl : h->slots)
                 if (sl.col >= 0 && sl.par_j >= h->d) mu_only = false;

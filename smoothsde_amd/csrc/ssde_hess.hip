@@ -21,6 +21,8 @@ namespace ssde_engine {
 int hess_exact_scope(const ssde_handle* h) {
     const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
     if (h->n_dim_parts > 1 || e->env_no_exact_hess) return 0;
+    // SSDE_FLAG_EXACT_HESS: the same rows on the lane = direction path next to a handle whose own kernels are first-order only
+    if (h->hess_companion && h->shards.empty() && h->comms.empty()) return hess_exact_scope(h->hess_companion);
     if (e->path == PATH_TV) {
         // row-varying coefficients on the isotropic lane = direction path: second-order forward mode over coefficient pairs
         // (k_tv_hess.hip).  Not the full-covariance lanes (per-row H_array, general P0), not ESEAL_SSM; single engine.
@@ -256,14 +258,15 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
     if (nu > MAX_COLS) { h->err = "ssde_hess: more than 96 coefficients"; return SSDE_ERR_ARG; }
     if (nu > 0 && scope == 3) {
         // every requested entry must be one of the handle's gradient directions (a free parameter that reaches the data term)
+        ssde_handle* t = h->hess_companion ? h->hess_companion : h;
         std::vector<int> dk(nu);
         for (int k = 0; k < nu; k++) {
-            dk[k] = h->tv_dir_of_par[cidx[k]];
+            dk[k] = t->tv_dir_of_par[cidx[k]];
             if (dk[k] < 0) { h->err = "ssde_hess: an entry held fixed (par_fixed) has no second derivatives on the row-varying path"; return SSDE_ERR_MODEL; }
         }
         std::vector<double> Hd;
-        int st = hess_tv_device(h, par, dk, Hd);
-        if (st) return st;
+        int st = hess_tv_device(t, par, dk, Hd);
+        if (st) { if (t != h) h->err = t->err; return st; }
         for (int a = 0; a < nu; a++)
             for (int b = 0; b < nu; b++) H[cpos[a] + (size_t)cpos[b] * n_idx] = Hd[a + (size_t)b * nu];
     } else

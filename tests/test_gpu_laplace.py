@@ -384,3 +384,63 @@ def test_laplace_on_a_smooth_drift_uses_the_exact_hessian(rec, monkeypatch):
     H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(pe), ir), torch.tensor(u_exact)).numpy()
     assert np.max(np.abs(H - H_exact)) <= 1e-8 * np.max(np.abs(H_exact))
     eng.close()
+
+
+# ---- SSDE_FLAG_EXACT_HESS: exact second derivatives for handles whose own kernels are first-order only ---------------------------
+@pytest.mark.parametrize("kind", ["colvar", "drift_general"])
+def test_exact_hessians_for_batches_on_the_lane_track_kernels(kind, monkeypatch):
+    """A batch with row-varying tau / nu large enough for the eight-wave pipeline (k_iso_colvar.hip), or a smooth drift with missing
+    rows (the general lanes of k_iso_drift.hip): first-order kernels.  With SSDE_FLAG_EXACT_HESS ssde_create keeps the rows a second
+    time on the lane = direction path and ssde_hess / ssde_laplace_eval run the hyper-dual lanes there (k_tv_hess.hip); without
+    the flag the handle says SSDE_ERR_MODEL and the Laplace layer differences the gradient."""
+    monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
+    if kind == "colvar":
+        from test_gpu_colvar import _batch
+        pb, par = _batch("CTCRW", 2, 96, 300, 5, 4, seed=9)
+    else:
+        from test_gpu_drift import _batch
+        pb0, par = _batch("OU_SSM", 1, 96, 300, (6,), seed=9)
+        o = pb0.obs.copy()
+        na = np.random.default_rng(2).random(pb0.n) < 0.05
+        na[pb0.seg_start] = False
+        o[na, 0] = np.nan
+        pb = capi.Problem("OU_SSM", pb0.id, pb0.times, o, X_re=pb0.X_re, S_list=pb0.S_list)
+    e0 = capi.Engine(pb)
+    assert e0.info()["path"] == 1 and e0.info()["const_coeff"] == 0
+    idx = list(range(pb.off_re, pb.off_re + pb.n_re)) + [pb.off_fe + pb.fe_off[pb.n_dim]]
+    with pytest.raises(capi.EngineError) as ei:
+        e0.hess(par, idx)
+    assert ei.value.status == 2
+    pb.flags |= capi.FLAG_EXACT_HESS
+    e1 = capi.Engine(pb)
+    assert e1.info()["path"] == 1                       # the evaluation stays where it was
+    v0, g0 = e0.eval(par)
+    v1, g1 = e1.eval(par)
+    assert v0 == v1 and np.array_equal(g0, g1)
+    H = e1.hess(par, idx)
+    Hfd = np.zeros_like(H)
+    for j, k in enumerate(idx):
+        e = 1e-4
+        pp, pm = par.copy(), par.copy()
+        pp[k] += e; pm[k] -= e
+        Hfd[:, j] = (e1.eval(pp)[1][idx] - e1.eval(pm)[1][idx]) / (2 * e)
+    assert np.max(np.abs(H - H.T)) <= 1e-10 * np.max(np.abs(H))
+    assert np.max(np.abs(H - Hfd)) <= 2e-6 * np.max(np.abs(H)), np.max(np.abs(H - Hfd)) / np.max(np.abs(H))
+    # ... and the same numbers as a handle that runs the lane = direction path outright
+    monkeypatch.setenv("SSDE_NO_DRIFT", "1")
+    pb.flags &= ~capi.FLAG_EXACT_HESS
+    e2 = capi.Engine(pb)
+    assert e2.info()["path"] == 3
+    H2 = e2.hess(par, idx)
+    assert np.max(np.abs(H - H2)) <= 1e-12 * np.max(np.abs(H2))
+    # the Laplace layer takes the exact route with the flag (few joint evaluations), the differenced one without
+    n1 = e1.info()["n_evals"]
+    f1, gm1, _, _ = e1.laplace_eval(par, order=1, want_hessian=True)
+    n1 = e1.info()["n_evals"] - n1
+    n0 = e0.info()["n_evals"]
+    f0, gm0, _, _ = e0.laplace_eval(par, order=1, want_hessian=True)
+    n0 = e0.info()["n_evals"] - n0
+    io = [k for k in range(pb.n_par_full) if not (pb.off_re <= k < pb.off_re + pb.n_re) and not pb.par_fixed[k]]
+    assert abs(f1 - f0) <= 1e-7 * max(1.0, abs(f0)) and np.max(np.abs(gm1[io] - gm0[io])) <= 1e-3 * max(1.0, np.max(np.abs(gm0[io])))
+    assert n1 < n0, (n1, n0)
+    e0.close(); e1.close(); e2.close()
