@@ -117,4 +117,9 @@ try:
                      f"plus the warm-up rows of the time windows)\n")
 except Exception as e:  # noqa: BLE001
     print("no quiet-rows PMC:", e)
+# round 4: the table drift, C1's latency, the vignette fit
+for name in ("drift_table.txt", f"pmc_{tag}_drift_table.txt", "c1_probe.txt", "fit_vignette.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
 print("wrote", pre + "*", "and profiles/pmc_latest.json; main kernel", main, f"{main_bytes / 1e9:.3f} GB per launch")
