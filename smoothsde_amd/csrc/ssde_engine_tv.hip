@@ -199,7 +199,10 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
         bool ok = std::isfinite(lo[0]) && std::isfinite(hi[0]) && std::isfinite(lo[1]) && std::isfinite(hi[1]) &&
                   std::isfinite(lo[2]) && std::isfinite(hi[2]);
         // per-row H_array: the largest observation variance forgets slowest
-        if (h->has_h) { ok = ok && std::isfinite(hi[3]) && hi[3] > 0.0; hobs = hi[3]; }
+        // (the slowest mode sees the LARGEST EIGENVALUE of H_array[,,i], which the largest diagonal entry underestimates when the ellipse is
+        //  tilted: lambda_max <= trace <= d x the largest diagonal entry.  Round 4: with the diagonal alone C1 with error ellipses sat at
+        //  1e-12 of a 1e-11 tolerance, a tenth of its evaluations were retried, and 16-row windows tipped it over)
+        if (h->has_h) { ok = ok && std::isfinite(hi[3]) && hi[3] > 0.0; hobs = hi[3] * h->d; }
         const double p0d[3] = {h->p0_full[0], h->model == SSDE_MODEL_CTCRW ? h->p0_full[1] : 0.0,
                                h->model == SSDE_MODEL_CTCRW ? h->p0_full[1 + h->sdim] : 0.0};
         if (ok)
@@ -210,6 +213,9 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
             }
         if (ok && rho < 0.9995) {
             int64_t w = (int64_t)std::ceil(std::log(1e-18) / std::log(std::max(rho, 1e-300))) + 16;
+            // (full-covariance lanes: the isotropic estimate of rho is optimistic for them -- measured on C1 with error ellipses: checks of
+            //  1e-12 .. 7e-12 against the 1e-11 tolerance, two failures in 400 evaluations and 32 evaluations on a four-fold plan after each)
+            if (h->tv_dense) w += WIN_ALIGN;
             w = std::max<int64_t>(w, 16);
             if (h->env_window > 0) w = h->env_window;
             w *= h->window_boost;
@@ -234,7 +240,8 @@ int tv_plan(ssde_handle* h, double hobs, hipStream_t s) {   // hobs: sigma_obs^2
         // As many windows as the chip has room for (nc_cap): with idle SIMDs around, a window may be much
         // shorter than its warm-up -- the redundant warm-up rows run in parallel, the serial chain of a wave
         // is what the evaluation waits for.  SSDE_TV_MINLEN: shortest scored stretch of a window (rows).
-        int minlen = WIN_ALIGN;                          // (round 4: 16 rows, not 32 -- C1's filter launch 41.5 -> 33 us)
+        int minlen = h->tv_dense ? 2 * WIN_ALIGN : WIN_ALIGN;   // (round 4: 16 rows, not 32, on the isotropic lanes -- C1's filter launch 41.5 -> 33 us; the
+                                                                  //  full-covariance lanes cost three times as much per warm-up row: 32)
         if (h->env_tv_minlen > 0) minlen = h->env_tv_minlen;
         if (W > 0 && L >= 2 * W) nc = std::max(1, std::min(nc_cap, (L + minlen - 1) / minlen));
         max_nc = std::max(max_nc, nc);

@@ -39,7 +39,8 @@ ts = 1e3 * np.sort(np.array(ts))
 inf = eng.info()
 out = dict(tool="probe_c1", rows=a.tracks * a.rows, reps=a.reps, ms_median=float(np.median(ts)), ms_min=float(ts[0]), ms_p90=float(ts[int(0.9 * len(ts))]),
            window=inf["window"], chunks=inf["n_chunks"] if "n_chunks" in inf else None, workgroups=inf["n_kernel_blocks"], lanes_per_track=inf["lanes_per_track"],
-           check=inf["window_check"], kernel=capi.KERNEL_NAMES.get(inf["kernel_id"]))
+           check=inf["window_check"], check_max=inf["window_check_max"], retries=inf["window_retries"], n_evals=inf["n_evals"],
+           slow_calls=int(np.sum(ts > 1.5 * np.median(ts))), kernel=capi.KERNEL_NAMES.get(inf["kernel_id"]))
 os.environ["SSDE_NO_GRAPH"] = "1"
 eng.eval(par); eng.eval(par)
 out["plain_kernel_ms"] = eng.info()["main_kernel_ms"]
