@@ -78,6 +78,7 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
                  a0 = tmb_dat$a0, P0 = tmb_dat$P0,
                  H = if(length(tmb_dat$H_array) > 1) tmb_dat$H_array else NULL,
                  par_fixed = fixed, include_penalty = tmb_dat$include_penalty, device = device,
+                 exact_hess = isTRUE(laplace) && is.null(devices),   # SSDE_FLAG_EXACT_HESS: second derivatives wherever the batch is evaluated
                  devices = if(is.null(devices)) NULL else as.integer(devices),
                  other_data = if(sde$type() == "BM_t") as.numeric(tmb_dat$other_data) else NULL,
                  eseal_h = if(eseal) as.numeric(tmb_dat$h) else NULL, eseal_R = if(eseal) as.numeric(tmb_dat$R) else NULL,

@@ -143,6 +143,10 @@ SEXP ssdeR_create(SEXP spec) {
         d.basis_re = pb;
     }
     d.na_mode = SSDE_NA_R_ONLY;                                     /* R_IsNA semantics (nllk_ctcrw.hpp:214) */
+    /* exact_hess = TRUE (what make_hip_obj sets with random = "coeff_re"): a batch that ssde_create puts on the lane = track
+     * kernels keeps its rows a second time for the second-order pass (include/ssde.h: SSDE_FLAG_EXACT_HESS) */
+    SEXP eh2 = get_elt(spec, "exact_hess");
+    if (eh2 != R_NilValue && Rf_asInteger(eh2) == 1) d.flags |= SSDE_FLAG_EXACT_HESS;
     SEXP dev = get_elt(spec, "device");
     d.device = (dev == R_NilValue) ? -1 : Rf_asInteger(dev);
     /* devices = c(0, 1, ..., 7): one R process, several GPUs -- whole tracks are sharded over them inside the engine
