@@ -295,6 +295,8 @@ class SDE:
         self.laplace_ = has_re if laplace is None else (bool(laplace) and has_re)
         pb = self._problem(include_penalty=1, fix_lambda=not self.laplace_)
         self.problem_ = pb
+        if self.laplace_:                                  # exact H_uu / H_u,theta wherever the batch is evaluated (include/ssde.h)
+            pb.flags |= capi.FLAG_EXACT_HESS
         self.engine_ = capi.Engine(pb)
         self.joint_obj_ = TmbObj(self.engine_, self._par_full(pb), pb.free_index())   # all free parameters, fixed + random
         self.tmb_obj_ = self.joint_obj_
