@@ -176,6 +176,22 @@ def test_random_problem_matches_oracle(seed):
             _, _, oaest = oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4, report=True)
             sc = max(1.0, np.nanmax(np.abs(oaest)))
             assert aest.shape == oaest.shape and np.allclose(aest, oaest, rtol=1e-9, atol=1e-9 * sc, equal_nan=True), ctx
+        if info["path"] == 3 and pb.model in ("CTCRW", "OU_SSM", "BM_SSM"):
+            # row-varying coefficients on the lane = direction path: the exact second derivatives (hyper-dual lanes, k_tv_hess.hip)
+            # over up to eight free entries against central differences of the engine's own gradient
+            free = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and not (pb.off_lambda <= k < pb.off_lambda + pb.n_smooth)][:8]
+            try:
+                H = eng.hess(par, free)
+            except capi.EngineError as e:
+                assert e.status == 2, (e, ctx)                     # "not exact here" (full-covariance lanes): nothing to compare
+                H = None
+            if H is not None:
+                Hfd = np.zeros_like(H)
+                for j, k in enumerate(free):
+                    pp, pm = np.array(par, dtype=float), np.array(par, dtype=float)
+                    pp[k] += 1e-5; pm[k] -= 1e-5
+                    Hfd[:, j] = (eng.eval(pp, order=1)[1][free] - eng.eval(pm, order=1)[1][free]) / 2e-5
+                assert np.max(np.abs(H - Hfd)) <= 2e-5 * max(1.0, np.max(np.abs(Hfd))), (np.max(np.abs(H - Hfd)), np.max(np.abs(Hfd)), ctx)
         d = pb.desc()
         if (pb.model in ("BM", "OU", "BM_SSM", "OU_SSM", "CTCRW") and not (d.h_array or d.p0 or d.a0) and
                 all(x is None for x in pb.X_fe) and not getattr(pb, "n_decay", 0)):
