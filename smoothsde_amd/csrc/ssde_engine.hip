@@ -817,7 +817,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_tracks = h->n_seg;
     info->n_rows = h->n;
     info->n_steps = h->n_steps;
-    info->hbm_bytes = h->hbm_bytes;
+    info->hbm_bytes = h->hbm_bytes + (h->hess_companion ? h->hess_companion->hbm_bytes : 0);     // (SSDE_FLAG_EXACT_HESS: the rows a second time)
     info->algo_bytes_per_row = 8.0 * (h->d + 1 + (h->has_h ? h->d * h->d : 0) + h->n_stream_cols_algo);
     // what the resident layout has to read per row: the `times` stream is not even stored when the grid is globally
     // regular (Kalman tiles without a dt channel); the direct families do not read it on a regular grid either

@@ -414,6 +414,7 @@ def test_exact_hessians_for_batches_on_the_lane_track_kernels(kind, monkeypatch)
     pb.flags |= capi.FLAG_EXACT_HESS
     e1 = capi.Engine(pb)
     assert e1.info()["path"] == 1                       # the evaluation stays where it was
+    assert e1.info()["hbm_bytes"] > e0.info()["hbm_bytes"]       # ... and the second copy of the rows is accounted for
     v0, g0 = e0.eval(par)
     v1, g1 = e1.eval(par)
     assert v0 == v1 and np.array_equal(g0, g1)
