@@ -111,7 +111,8 @@ enum {
     SSDE_KERNEL_ISO_FULL      = 13, /* iso_full_kernel: per-row H_array, constant tau / nu (4 x 4 covariance lanes) */
     SSDE_KERNEL_DENSE         = 14, /* dense_kernel: general Kalman step, lane = track (k_dense.hip) */
     SSDE_KERNEL_TV            = 15, /* tv_filter_kernel: row-varying coefficients, lane = gradient direction (k_tv.hip) */
-    SSDE_KERNEL_TV_DENSE      = 16  /* ... with full-covariance lanes (k_tv_dense.hip; ESEAL_SSM too) */
+    SSDE_KERNEL_TV_DENSE      = 16, /* ... with full-covariance lanes (k_tv_dense.hip; ESEAL_SSM too) */
+    SSDE_KERNEL_ISO_ADJ       = 17  /* iso_adj_kernel: row-varying tau / nu / drift, gradient by a reverse sweep (k_iso_adj.hip) */
 };
 
 /* status codes (0 = ok).  HIP runtime failures are reported as SSDE_ERR_HIP with

@@ -77,7 +77,8 @@ OPT_KERNEL_STAMPS, OPT_COMM_DEFER = 1, 2
 KERNEL_NAMES = {0: "none", 1: "direct_kernel", 2: "direct_fast_kernel", 3: "iso_shared_kernel", 4: "iso_mask_kernel",
                 5: "iso_mask_kernel<uniform grid>", 6: "iso_quiet_kernel", 7: "iso_shared_kernel + general kernel (mixed batch)",
                 8: "iso_kernel (direction parts)", 9: "iso_drift_kernel", 10: "iso_drift_general_kernel", 11: "iso_colvar_kernel",
-                12: "iso_few_kernel", 13: "iso_full_kernel", 14: "dense_kernel", 15: "tv_filter_kernel", 16: "tv_filter_kernel<dense lanes>"}
+                12: "iso_few_kernel", 13: "iso_full_kernel", 14: "dense_kernel", 15: "tv_filter_kernel", 16: "tv_filter_kernel<dense lanes>",
+                17: "iso_adj_kernel"}
 PHASE_NAMES = ("host_total", "host_enqueue", "gpu_pre", "kernel", "finalize", "allreduce", "readback", "reserved")
 
 

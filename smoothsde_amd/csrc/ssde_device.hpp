@@ -195,6 +195,12 @@ struct IsoArgs {
     int cv_full;                 // 4 x 4 covariance lanes (CTCRW, d = 2): per-row H_array and / or a P0 that is not block-identical
     int cv_has_h;                // ... the tiles hold H_array[,,i] in the d^2 channels after the observations
     double cv_p0[16];            // ... P0, column-major
+    // ... the same models with the gradient by a reverse sweep (k_iso_adj.hip): the state entering every CB-th row of a window
+    double* adj_ckpt;            // [work item][adj_ckpt_stride]
+    int64_t adj_ckpt_stride;     // doubles per work item: checkpoints of its window x state doubles x 64
+    int adj_diag;                // testing (SSDE_ADJ_DIAG): bit 0 = every row load from the window's first rows (what the kernel takes without HBM)
+    int adj_tail;                // rows a window that is not the last walks past its end before its backward recursion starts (= window;
+                                 // testing: SSDE_ADJ_TAIL, deliberately short)
     // Quiet rows of the general kernel (regular grid; k_iso.hip): a block of ISO_U rows with no missing observation in it or in
     // the quiet_w blocks before it (any lane), past the covariance transient, has the STATIONARY covariance on every lane --
     // the lanes run the mean half with the stationary gains (statc) there and take up their own covariance again, from the
@@ -233,6 +239,14 @@ constexpr int CV_FEW_K = 4;
 hipError_t launch_iso_few(int model, int d, const IsoArgs& a, const CvPart* parts, int kc, hipStream_t s);
 // constant tau / nu with per-row H_array (CTCRW, d = 2): one wave per (group, window), the tangents of parts[0] (columns of ones)
 hipError_t launch_iso_full(int model, const IsoArgs& a, const CvPart* parts, hipStream_t s);
+// row-varying tau / nu (and drift), gradient by a reverse sweep: one wave per (group, window), two passes (k_iso_adj.hip)
+hipError_t launch_iso_adj(int model, int d, const IsoArgs& a, hipStream_t s);
+int adj_ks(int k);                                   // streamed-column capacity of the instantiation that takes k columns, -1: none
+int adj_nk(int model, int d, bool mu);               // accumulators per streamed column
+int adj_nacc(int model, int d, int k, bool mu);      // [value | log sigma_obs | mu_a | par[d] | par[d + 1] | column 0's kinds | ...]
+int adj_nstate(int model, int d);                    // doubles of a hand-over record: the state and its adjoint
+int adj_ckpt_rows(int model, int d);                 // rows between checkpoints
+int adj_items(int n_groups, int n_chunks);           // work items (waves) of a launch
 hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, int d, double* out /* [n_groups][2]: max diag(H), max |H01 - H10| */, hipStream_t s);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);
 // components of a compact hand-over dump (shared-covariance kernels): state, one block per wanted covariance

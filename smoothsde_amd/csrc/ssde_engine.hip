@@ -42,7 +42,7 @@ void release_device(ssde_handle* h) {
     }
     h->wave_clock.release();
     for (hipEvent_t& e : h->ev_ph) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    h->cv_ranges.release(); h->cv_parts.release();
+    h->cv_ranges.release(); h->cv_parts.release(); h->adj_ckpt.release();
     if (h->cv_ranges_pinned) { (void)hipHostFree(h->cv_ranges_pinned); h->cv_ranges_pinned = nullptr; }
     h->hs_partials.release(); h->hs_hess.release(); h->hs_i16.release();
     if (h->trace && h->trace_n > 0)
@@ -499,6 +499,9 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
         // a non-finite nllk is rejected by the caller whatever the windows did: no retry, and no lasting
         // widening of the plan because an optimiser probed an absurd parameter once
         if (!std::isfinite(o[0])) break;
+        // (a plan that has given up runs one window WITHOUT quiet rows -- eval_iso -- so nothing is left to disagree; the cap is
+        //  for whatever that reasoning missed: the failure is then reported through window_check_max instead of spinning -- ADVICE r04)
+        if (attempt > 6) break;
         h->n_retries++;
         h->calm = 0;
         if (h->probing && attempt == 0) {
@@ -726,7 +729,13 @@ int ssde_set_option(ssde_handle* h, int32_t option, int64_t value) {
         for (ssde_handle* s : h->shards) s->stamps = h->stamps;
         return SSDE_OK;
     }
-    if (option == SSDE_OPT_COMM_DEFER) { h->comm_defer = value != 0; return SSDE_OK; }
+    if (option == SSDE_OPT_COMM_DEFER) {
+        // (a multi-device parent holds one communicator per shard: deferring ITS collective would leave a partial sum with no
+        //  call that could finish it -- ssde_comm_allreduce speaks for one rank)
+        if (!h->shards.empty() && value != 0) { h->err = "SSDE_OPT_COMM_DEFER: only for a handle that joined through ssde_comm_init_rank"; return SSDE_ERR_ARG; }
+        h->comm_defer = value != 0;
+        return SSDE_OK;
+    }
     h->err = "ssde_set_option: unknown option";
     return SSDE_ERR_ARG;
 }

@@ -172,7 +172,10 @@ struct ssde_handle {
     bool cv_full = false;          // 4 x 4 covariance lanes (CTCRW, d = 2, per-row H_array)
     bool cv_single = false;        // ... with constant tau / nu: one wave per (group, window) runs filter and tangents (iso_full_kernel)
     bool cv_few = false;           // few design columns, H = sigma_obs^2 I: one wave per (group, window) too (iso_few_kernel)
-    bool cv_one_wave() const { return cv_single || cv_few; }
+    int env_adj_tail = 0;          // testing (SSDE_ADJ_TAIL): rows past a window's end before its backward recursion starts
+    bool cv_adj = false;           // gradient by a reverse sweep: one wave per (group, window), two passes (iso_adj_kernel)
+    DevBuf<double> adj_ckpt;       // ... the state entering every adj_ckpt_rows-th row of every window (grown on demand)
+    bool cv_one_wave() const { return cv_single || cv_few || cv_adj; }
     double cv_hmax = 0.0;          // ... the largest diagonal entry of H_array over the batch (the window planner's observation variance)
     std::vector<double> cv_col_lo, cv_col_hi;   // range of every streamed column over the batch (found at create)
     DevBuf<double> cv_ranges;      // [workgroup][4] ranges of the linear predictors seen by the last launch

@@ -159,7 +159,20 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             const bool wide = h->n_stream_cols > CV_FEW_K || (int)cols.size() > CV_KC;
             if (wide && h->model == SSDE_MODEL_CTCRW && h->d == 2 && !getenv("SSDE_CV_FEW_WIDE")) h->cv_few = false;
         }
-        if ((int)cols.size() > (h->cv_full ? CV_WAVES - 2 : CV_WAVES) * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;     // (full-covariance lanes: the two stage waves carry no columns)
+        {
+            // the gradient by a reverse sweep (k_iso_adj.hip): its cost does not depend on the number of columns, so it takes every batch
+            // the eight-wave pipeline would; iso_few_kernel keeps the handful-of-columns shapes it was built for unless told otherwise
+            // (SSDE_CV_ADJ=2: those too; SSDE_CV_ADJ=0: forward tangents everywhere, the A/B)
+            bool mu_streamed = false;
+            for (auto& c : cols) mu_streamed = mu_streamed || (c.type >= 3 && c.chan >= 0);
+            const char* e = getenv("SSDE_CV_ADJ");
+            const int mode = e ? atoi(e) : 1;
+            h->cv_adj = mode > 0 && !h->cv_full && !h->cv_single && (!h->has_h || h->d == 1) && h->n_stream_cols >= 1 &&
+                        adj_ks(h->n_stream_cols) >= 0 && (!mu_streamed || adj_ks(h->n_stream_cols) <= 9) && (!h->cv_few || mode > 1);
+            if (h->cv_adj) h->cv_few = false;
+        }
+        if (!h->cv_adj && (int)cols.size() > (h->cv_full ? CV_WAVES - 2 : CV_WAVES) * CV_KC) return SSDE_RETRY_WITHOUT_DRIFT;     // (full-covariance lanes: the two stage waves carry no columns)
+        if (h->cv_adj) cols.clear();                               // (no tangents to deal: every direction comes out of the one sweep)
         std::vector<CvPart> parts(CV_WAVES);
         memset(parts.data(), 0, sizeof(CvPart) * CV_WAVES);
         h->cv_pidx.assign((size_t)CV_WAVES * CV_KC, -1);
@@ -241,7 +254,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = h->cv_single ? (h->model == SSDE_MODEL_CTCRW ? 14 + 2 * 14 + 2 * 4 : 5 + 2 * 5 + 2 * 2) : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
+        h->drift_nstate = h->cv_adj ? adj_nstate(h->model, h->d)
+                        : h->cv_single ? (h->model == SSDE_MODEL_CTCRW ? 14 + 2 * 14 + 2 * 4 : 5 + 2 * 5 + 2 * 2) : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
         if (h->has_h) {
             DevBuf<double> hs;
             HIPCHK(h, hs.alloc((size_t)G * 2));
@@ -331,6 +345,8 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     // (row-varying tau / nu with few groups: windows down to two alignment units, shorter than their warm-up -- with CUs idle
     //  the redundant warm-up rows run in parallel, only a workgroup's own chain of rows matters; ssde_engine_iso.hip picks)
     if (h->drift == 3 && !h->cv_one_wave() && !h->chunks_forced) h->max_chunks = std::max(1, std::min(want + 1, std::max(1, glmax / (2 * WIN_ALIGN))));
+    // (the reverse sweep: plan_windows picks the count by cost, up to two alignment units per window)
+    if (h->cv_adj && !h->chunks_forced) h->max_chunks = std::max(1, std::min((1024 + G - 1) / G * 2, std::max(1, glmax / (2 * WIN_ALIGN))));
     h->want_chunks = std::max(1, std::min(want, h->max_chunks));
     // Mixed batch: most wavefronts on the shared-covariance kernel, the few that hold the tracks with missing rows on
     // the general kernel.  With ONE plan -- the shared kernel's few long windows -- the general launch is a handful of
@@ -400,28 +416,35 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
         HIPCHK(h, hipHostMalloc((void**)&h->gain_pinned, (size_t)PAR_RING * h->gain_rows_cap * GAIN_ROW * 8,
                                 hipHostMallocDefault));
     }
-    HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * buf_chunks * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
+    HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * (buf_chunks + (h->cv_adj ? 1 : 0)) * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
     if (h->drift == 3) HIPCHK(h, hipMemset(h->bnd.p, 0, h->bnd.n * 8));      // (a part dumps its own block of a hand-over record; the check reads all of it)
     h->partial_doubles = (size_t)std::max(MAX_PARTS, CV_WAVES) * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
+    if (h->cv_adj) h->partial_doubles = std::max(h->partial_doubles, (size_t)buf_chunks * adj_nacc(h->model, h->d, h->n_stream_cols, true) * G);
     h->hbm_bytes += (int64_t)(h->bnd.n + h->chk.n) * 8;
     return SSDE_OK;
 }
 
 static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout, bool allow_drift);
 int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout) {
-    int st = build_impl(d, h, part_layout, true);
-    if (st == SSDE_RETRY_WITHOUT_PP) {
+    // (what the caller set on the handle before build() survives a retry: the reset below wipes everything else -- ADVICE r04)
+    const bool force_tv = h->force_tv, wide_ok = h->wide_ok;
+    bool no_drift_pp = h->no_drift_pp;
+    auto reset = [&]() {
         release_device(h);
         *h = ssde_handle();
-        h->no_drift_pp = true;
+        h->force_tv = force_tv; h->wide_ok = wide_ok; h->no_drift_pp = no_drift_pp;
+    };
+    int st = build_impl(d, h, part_layout, true);
+    if (st == SSDE_RETRY_WITHOUT_PP) {
+        no_drift_pp = true;
+        reset();
         st = build_impl(d, h, part_layout, true);
     }
     if (st == SSDE_RETRY_WITHOUT_DRIFT) {
         // the row-varying-drift layout needs a regular grid and no missing row, which only the tiling pass finds out:
         // start over on the path such a batch takes otherwise
-        release_device(h);
-        *h = ssde_handle();
+        reset();
         st = build_impl(d, h, part_layout, false);
     }
     return st;
@@ -458,6 +481,7 @@ static int check_descriptor(const ssde_desc* d, ssde_handle* h, const ParLayout*
     if (!d->id || !d->times || !d->obs || !d->ncol_fe) return fail(h, SSDE_ERR_ARG, "id/times/obs/ncol_fe must be non-NULL");
     h->model = d->model; h->d = d->n_dim; h->q = d->n_par; h->n = d->n;
     if (const char* e = getenv("SSDE_WINDOW")) h->env_window = std::max(1, atoi(e));     // testing: deliberately short overlaps
+    if (const char* e = getenv("SSDE_ADJ_TAIL")) h->env_adj_tail = std::max(1, atoi(e));  // testing: ... of the backward recursion only (k_iso_adj.hip)
     if (const char* e = getenv("SSDE_TV_WAVES")) h->env_tv_waves = std::max(1, atoi(e));
     if (const char* e = getenv("SSDE_TV_MINLEN")) h->env_tv_minlen = std::max(WIN_ALIGN, atoi(e) / WIN_ALIGN * WIN_ALIGN);
     if (const char* e = getenv("SSDE_T0_COST")) h->env_t0_cost = atof(e);

@@ -468,6 +468,7 @@ int ssde_comm_unique_id(void* id128) {
 int ssde_comm_allreduce(ssde_handle* h, double* buf_dev, int64_t count, void* stream) {
     if (!h || !buf_dev || count < 1) return SSDE_ERR_ARG;
     if (h->comms.empty()) { h->err = "ssde_comm_allreduce: the handle has joined no communicator"; return SSDE_ERR_ARG; }
+    if (!h->shards.empty()) { h->err = "ssde_comm_allreduce: a multi-device parent reduces inside ssde_eval (one communicator per shard)"; return SSDE_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     NCCLCHK(h, rccl().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)h->comms[0], (hipStream_t)stream));
     return SSDE_OK;

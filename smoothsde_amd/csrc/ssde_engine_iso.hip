@@ -89,6 +89,21 @@ void plan_windows(ssde_handle* h, const IsoArgs& a, int* n_chunks, int* window) 
     }
     int nc = h->want_chunks;
     if (h->drift == 3 && !h->cv_one_wave() && !h->chunks_forced) { while (nc > 1 && (glmax / nc) < 2 * WIN_ALIGN) nc--; }     // (the cost below decides, not a rule)
+    else if (h->cv_adj && !h->chunks_forced) {
+        // one wave per (group, window) and per SIMD; a window walks its warm-up, its rows and -- for the backward recursion -- W rows
+        // past its end forwards (~0.8 us a row), then its rows and that tail backwards (~1.2 us a row): rounds x that is what the
+        // launch takes.  With SIMDs idle (few groups) windows shorter than their warm-up pay: the redundant rows run in parallel.
+        nc = std::max(1, std::min(h->max_chunks, glmax / (2 * WIN_ALIGN)));
+        const int ng = h->n_groups;                           // (the grid pads the groups to eight: those waves leave at once)
+        int best = 1;
+        double best_cost = (double)((ng + 1023) / 1024) * 2.0 * glmax;
+        for (int c = 2; c <= nc; c++) {
+            const double len = (double)glmax / c;
+            const double cost = (double)(((int64_t)ng * c + 1023) / 1024) * (0.8 * (len + 2.0 * W) + 1.2 * (len + W));
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+        nc = best;
+    }
     else
     while (nc > 1 && (glmax / nc) < 2 * W) nc--;
     if (h->drift == 3 && !h->cv_one_wave() && !h->chunks_forced) {
@@ -233,7 +248,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     } else {
         a.n_parts = 1;
     }
-    if (h->drift == 3) { a.n_parts = h->cv_few ? h->cv_kc / CV_KC : h->cv_single ? 1 : CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
+    if (h->drift == 3) { a.n_parts = h->cv_adj ? 1 : h->cv_few ? h->cv_kc / CV_KC : h->cv_single ? 1 : CV_WAVES; a.part_mask[0] = order >= 1 ? 1 : 0; }    // k_iso_colvar.hip: the parts are the waves of a workgroup
     a.any_nan = h->na_any;
     a.uniform_dt = h->uniform_dt ? 1 : 0;
     const double sig = exp(par[0]);                     // nllk_ctcrw.hpp:136
@@ -381,7 +396,8 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
     h->last_t0 = a.t0; h->last_t0_delta = a.t0_delta;
     h->last_quiet_window = 0;
     // (CTCRW: the transfer-function lanes lose digits when the closed-loop poles approach 1 -- the limit plan_windows has for them)
-    if (h->quiet_ok && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1 &&
+    // (a plan that has given up on windows gives up on quiet rows too: with them the retry would run the identical plan again)
+    if (h->quiet_ok && !h->gave_up && h->gain_stationary && h->plan_warmup > 0 && a.gain_stat[0] != 0.0 && a.n_parts == 1 &&
         !(h->model == SSDE_MODEL_CTCRW && h->plan_rho > 0.97)) {
         const int U = iso_block_rows(h->model);
         h->last_quiet_window = h->plan_warmup;
@@ -455,7 +471,24 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 HIPCHK(h, hipMemsetAsync(h->wave_clock.p, 0, (size_t)4 * items * 8, s));
                 a.wave_clock = h->wave_clock.p; h->wave_clock_items = items;
             }
-            h->last_kernel_id = h->cv_single ? SSDE_KERNEL_ISO_FULL : h->cv_few ? SSDE_KERNEL_ISO_FEW : SSDE_KERNEL_ISO_COLVAR;
+            h->last_kernel_id = h->cv_adj ? SSDE_KERNEL_ISO_ADJ : h->cv_single ? SSDE_KERNEL_ISO_FULL : h->cv_few ? SSDE_KERNEL_ISO_FEW : SSDE_KERNEL_ISO_COLVAR;
+            if (h->cv_adj) {
+                // checkpoints: the state entering every CB-th row from a window's first scored row to where its backward recursion starts
+                const int items = adj_items(h->n_groups, a.n_chunks), cb = adj_ckpt_rows(h->model, h->d), nst = adj_nstate(h->model, h->d) / 2;
+                const int units = (h->glen_max + WIN_ALIGN - 1) / WIN_ALIGN;
+                a.adj_tail = a.window;
+                if (const char* e = getenv("SSDE_ADJ_DIAG")) a.adj_diag = atoi(e);
+                if (h->env_adj_tail > 0) a.adj_tail = (int)std::min<int64_t>((int64_t)h->env_adj_tail * h->window_boost, h->glen_max);      // (testing)
+                const int len = (units / a.n_chunks + 1) * WIN_ALIGN + (a.n_chunks > 1 ? a.adj_tail : 0);
+                a.adj_ckpt_stride = (int64_t)((len + cb - 1) / cb + 1) * nst * WAVE;
+                const size_t need = order >= 1 ? (size_t)items * (size_t)a.adj_ckpt_stride : (size_t)WAVE;
+                if (h->adj_ckpt.n < need) { h->adj_ckpt.release(); HIPCHK(h, h->adj_ckpt.alloc(need)); }
+                a.adj_ckpt = h->adj_ckpt.p;
+                if ((int)h->cv_ranges.n < 4 * items) { h->cv_ranges.release(); HIPCHK(h, h->cv_ranges.alloc((size_t)4 * items)); }
+                a.cv_ranges = h->cv_ranges.p;
+                HIPCHK(h, launch_iso_adj(h->model, h->d, a, s));
+                HIPCHK(h, launch_colvar_range_reduce(h->cv_ranges.p, items, h->cv_ranges_pinned, s));
+            } else
             if (h->cv_single) HIPCHK(h, launch_iso_full(h->model, a, h->cv_parts.p, s));
             else if (h->cv_few) HIPCHK(h, launch_iso_few(h->model, h->d, a, h->cv_parts.p, h->cv_kc, s));
             else {
@@ -486,11 +519,23 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
                 if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
         }
     }
-    const int nacc = h->drift == 3 ? 2 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
+    const int nacc = h->cv_adj ? adj_nacc(h->model, h->d, h->n_stream_cols, a.cv_mu_cols != 0)
+                   : h->drift == 3 ? 2 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
     const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
     ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
     ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
     ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
+    if (order >= 1 && h->cv_adj) {
+        // accumulators of k_iso_adj.hip: [value | log sigma_obs | mu_a | par[d] | par[d + 1] | per streamed column: par[d], par[d + 1] (, mu_a)]
+        const int nkp = h->model == SSDE_MODEL_BM_SSM ? 1 : 2, nk = adj_nk(h->model, h->d, a.cv_mu_cols != 0);
+        if (!h->fixed[0] && !h->has_h) ra.map[0] = 1;
+        for (auto& sl : h->slots) {
+            if (h->fixed[sl.pidx]) continue;
+            const int kind = sl.par_j < h->d ? nkp + sl.par_j : sl.par_j - h->d;
+            const int k = sl.col >= 0 ? 4 + h->d + sl.col * nk + kind : (sl.par_j < h->d ? 2 + sl.par_j : 2 + h->d + (sl.par_j - h->d));
+            ra.map[k - 1] = (int16_t)(1 + sl.pidx);
+        }
+    } else
     if (order >= 1 && h->drift == 3) {
         // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d | log sigma_obs]
         for (int p = 0; p < CV_WAVES; p++) {

@@ -11,6 +11,8 @@
 
 #include "../../smoothsde_amd/csrc/ssde_math.hpp"
 #include "../../smoothsde_amd/csrc/ssde_tv.hpp"
+#include "../../smoothsde_amd/csrc/ssde_adj.hpp"
+#include <vector>
 
 using namespace ssde;
 
@@ -127,6 +129,55 @@ void run_tv(int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const
     }
 }
 
+// reverse sweep (ssde_adj.hpp): forward pass with a record per row, backward pass; G[i + j n] = d nllk / d parmat(i, j)
+template <int MODEL, int D>
+void run_adj(int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows, const double* times,
+             const double* obs, const double* parmat, int q, double log_sigma_obs, const double* p0, const double* a0,
+             double* out, double* G) {
+    typedef typename AdjModel<MODEL, D>::Lane Lane;
+    constexpr int SD = Lane::SD, NF = Lane::NF;
+    const double h = exp(log_sigma_obs) * exp(log_sigma_obs);
+    out[0] = out[1] = 0.0;
+    for (int64_t k = 0; k < n * q; k++) G[k] = 0.0;
+    for (int64_t m = 0; m < n_tracks; m++) {
+        Lane L;
+        double a[SD];
+        for (int c = 0; c < SD; c++) a[c] = 0.0;
+        if (a0) for (int c = 0; c < SD; c++) a[c] = a0[m * SD + c];
+        else for (int c = 0; c < D; c++) a[MODEL == M_CTCRW ? 2 * c : c] = obs[row0[m] + c * n];
+        L.init(a, p0);
+        LogAcc ld; ld.init();
+        double accq = 0.0;
+        std::vector<double> recs((size_t)nrows[m] * NF);
+        auto dt_of = [&](int64_t s) { const int64_t i = row0[m] + s; return (s < nrows[m] - 1) ? times[i + 1] - times[i] : 1.0; };
+        for (int64_t s = 1; s < nrows[m]; s++) {
+            const int64_t i = row0[m] + s;
+            double mu[D], y[D];
+            for (int c = 0; c < D; c++) { mu[c] = parmat[i + (int64_t)c * n]; y[c] = obs[i + c * n]; }
+            typename Lane::Trans tr;
+            Lane::trans(dt_of(s), parmat[i + (int64_t)D * n], q > D + 1 ? parmat[i + (int64_t)(D + 1) * n] : 0.0, tr);
+            Lane::template put_trans<1>(&recs[(size_t)s * NF], tr);
+            typename Lane::Trans tb;                                // (the forward step reads its transition back from the record, as the kernel does)
+            Lane::template get_trans<1>(&recs[(size_t)s * NF], dt_of(s), tb);
+            L.template fwd<true, 1>(tb, h, mu, y, is_na(y[0], any_nan), ld, accq, &recs[(size_t)s * NF]);
+        }
+        out[0] += 0.5 * ((double)D * ld.value() + accq);
+        typename Lane::Adj A;
+        A.zero();
+        for (int64_t s = nrows[m] - 1; s >= 1; s--) {
+            const int64_t i = row0[m] + s;
+            double mu[D];
+            for (int c = 0; c < D; c++) mu[c] = parmat[i + (int64_t)c * n];
+            AdjRowGrad<D> g;
+            Lane::template bwd<1>(A, &recs[(size_t)s * NF], h, mu, dt_of(s), g);
+            for (int c = 0; c < D; c++) G[i + (int64_t)c * n] = g.gmu[c];
+            G[i + (int64_t)D * n] = g.g1;
+            if (q > D + 1) G[i + (int64_t)(D + 1) * n] = g.g2;
+            out[1] += 2.0 * h * g.gh;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +190,16 @@ int hostsim_kalman_tv(int model, int d, int any_nan, int64_t n, int64_t n_tracks
 #define TV(MODEL, D) if (model == MODEL && d == D) { run_tv<MODEL, D>(any_nan, n, n_tracks, row0, nrows, times, obs, parmat, q, nd, kinds, dims, wmat, log_sigma_obs, p0, a0, out); return 0; }
     TV(M_CTCRW, 1) TV(M_CTCRW, 2) TV(M_OU_SSM, 1) TV(M_OU_SSM, 2) TV(M_BM_SSM, 1) TV(M_BM_SSM, 2)
 #undef TV
+    return 1;
+}
+
+// out = [nllk (data term), d / d log_sigma_obs]; G (n x q, column-major) = d nllk / d parmat
+int hostsim_kalman_adj(int model, int d, int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows,
+                       const double* times, const double* obs, const double* parmat, int q, double log_sigma_obs, const double* p0,
+                       const double* a0, double* out, double* G) {
+#define ADJ(MODEL, D) if (model == MODEL && d == D) { run_adj<MODEL, D>(any_nan, n, n_tracks, row0, nrows, times, obs, parmat, q, log_sigma_obs, p0, a0, out, G); return 0; }
+    ADJ(M_CTCRW, 1) ADJ(M_CTCRW, 2) ADJ(M_OU_SSM, 1) ADJ(M_OU_SSM, 2) ADJ(M_BM_SSM, 1) ADJ(M_BM_SSM, 2)
+#undef ADJ
     return 1;
 }
 

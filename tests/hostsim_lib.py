@@ -27,8 +27,48 @@ def load():
         lib.hostsim_kalman_tv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp,
                                           C.c_int, C.c_int, _ipt, _ipt, _dp, C.c_double, _dp, _dp, _dp]
         lib.hostsim_kalman_tv.restype = C.c_int
+        lib.hostsim_kalman_adj.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp,
+                                           C.c_int, C.c_double, _dp, _dp, _dp, _dp]
+        lib.hostsim_kalman_adj.restype = C.c_int
         _LIB = lib
     return _LIB
+
+
+def kalman_adj(pb, par):
+    """The same nllk (data term) + gradient by the REVERSE sweep of csrc/ssde_adj.hpp: one forward pass leaving a record
+    per row, one backward pass giving d nllk / d par_mat(i, j); the coefficient gradient is X' G, formed here."""
+    from smoothsde_amd.capi import MODEL_CODES
+    lib = load()
+    d, q, n = pb.n_dim, pb.q, pb.n
+    par = np.asarray(par, dtype=np.float64)
+    parmat = np.zeros((n, q), order="F")
+    blocks = []
+    for j in range(q):
+        for src, off, nc in ((pb.X_fe[j], pb.off_fe + pb.fe_off[j], pb.ncol_fe[j]),
+                             (pb.X_re[j], pb.off_re + pb.re_off[j], pb.ncol_re[j])):
+            for c in range(nc):
+                col = np.ones(n) if src is None else src[:, c]
+                parmat[:, j] += col * par[off + c]
+                blocks.append((j, off + c, col))
+    row0 = np.ascontiguousarray(pb.seg_start, dtype=np.int64)
+    nrows = np.diff(np.append(pb.seg_start, n)).astype(np.int64)
+    if pb.model == "CTCRW":
+        p0 = np.array([1.0, 0.0, 10.0]) if pb.P0 is None else np.array([pb.P0[0, 0], pb.P0[0, 1], pb.P0[1, 1]])
+    else:
+        p0 = np.array([10.0, 0, 0]) if pb.P0 is None else np.array([pb.P0[0, 0], 0, 0])
+    a0 = None if pb.a0 is None else np.ascontiguousarray(pb.a0)
+    out = np.zeros(2)
+    G = np.zeros((n, q), order="F")
+    st = lib.hostsim_kalman_adj(MODEL_CODES[pb.model], d, int(pb.na_mode == 1), n, pb.n_seg, row0.ctypes.data_as(_lp),
+                                nrows.ctypes.data_as(_lp), pb.times.ctypes.data_as(_dp), pb.obs.ctypes.data_as(_dp),
+                                parmat.ctypes.data_as(_dp), q, float(par[0]), p0.ctypes.data_as(_dp),
+                                None if a0 is None else a0.ctypes.data_as(_dp), out.ctypes.data_as(_dp), G.ctypes.data_as(_dp))
+    assert st == 0
+    grad = np.zeros(pb.n_par_full)
+    grad[0] = out[1]
+    for j, pidx, col in blocks:
+        grad[pidx] += float(col @ G[:, j])
+    return out[0], grad
 
 
 def kalman_tv(pb, par):

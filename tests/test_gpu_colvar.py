@@ -17,12 +17,20 @@ GOLD = load_golden()
 PATH_ISO, PATH_TV = 1, 3
 
 
-@pytest.fixture(autouse=True)
-def _take_the_lane_track_path_from_32_tracks(monkeypatch):
+@pytest.fixture(autouse=True, params=["tangents", "adjoint"])
+def _take_the_lane_track_path_from_32_tracks(request, monkeypatch):
     """The engine sends row-varying tau / nu batches to this kernel by their rows (rows x lanes per track >= 4.5 10^6: the measured
     crossover against the lane = direction path, tools/sweep_dispatch.py); the cases below are smaller so that the oracle stays
-    quick, and ask for the kernel by track count."""
+    quick, and ask for the kernel by track count.
+    Every case runs twice: on the forward-tangent kernels this file was written for (SSDE_CV_ADJ=0: the eight-wave pipeline,
+    iso_few_kernel, iso_full_kernel) and as the engine dispatches it (the reverse sweep of k_iso_adj.hip wherever it applies)."""
     monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "32")
+    monkeypatch.setenv("SSDE_CV_ADJ", "0" if request.param == "tangents" else "1")
+
+
+def _wpw(eng):
+    """waves per (group, window) of the kernel that ran: eight in the pipeline, one in the one-wave kernels"""
+    return 8 if eng.info()["kernel_id"] == 11 else 1
 
 
 def _oracle(pb, par, **kw):
@@ -218,7 +226,7 @@ def test_window_plan_follows_the_range_the_predictors_actually_reach():
     w_first = eng.info()["window"]
     v2, g2 = eng.eval(big + 1e-6)
     inf = eng.info()
-    assert inf["window"] > 0 and inf["lanes_per_track"] > 8 and inf["window_check"] <= 1e-11
+    assert inf["window"] > 0 and inf["lanes_per_track"] > _wpw(eng) and inf["window_check"] <= 1e-11
     assert w_first == 0 or inf["window"] <= w_first                # the measured range never asks for a longer warm-up than the bound
     _close(v1, g1, *_oracle(pb, big))
     _close(v2, g2, *_oracle(pb, big + 1e-6))
@@ -596,7 +604,7 @@ def test_bench_size_properties(monkeypatch):
     assert _is_colvar(eng)
     val, grad = eng.eval(par)
     inf = eng.info()
-    assert inf["lanes_per_track"] > 8 and inf["window_check"] <= 1e-11
+    assert inf["lanes_per_track"] > _wpw(eng) and inf["window_check"] <= 1e-11
     v2, g2 = eng.eval(par + 0.0)
     assert v2 == val and np.array_equal(g2, grad)
     assert abs(eng.eval(par, order=0) - val) <= 1e-12 * abs(val)
@@ -607,7 +615,7 @@ def test_bench_size_properties(monkeypatch):
     monkeypatch.setenv("SSDE_CHUNKS", "1")
     e1 = capi.Engine(pb)
     v1, g1 = e1.eval(par)
-    assert e1.info()["lanes_per_track"] == 8                                # one window per track (x eight waves)
+    assert e1.info()["lanes_per_track"] == _wpw(e1)                         # one window per track (x eight waves in the pipeline)
     assert abs(v1 - val) <= 1e-11 * abs(val) and np.max(np.abs(g1 - grad)) <= 1e-9 * np.max(np.abs(grad))
     monkeypatch.delenv("SSDE_CHUNKS")
     monkeypatch.setenv("SSDE_NO_COLVAR", "1")
@@ -711,7 +719,10 @@ def test_linear_covariate_effects_run_on_one_wave_per_window(model, d, which, wh
     monkeypatch.setenv("SSDE_CV_NO_FEW", "1")
     e2 = capi.Engine(pb)
     v2, g2 = e2.eval(par)
-    assert e2.info()["lanes_per_track"] % 8 == 0 and e2.info()["lanes_per_track"] != n_win      # the pipeline: eight waves per window
+    if e2.info()["kernel_id"] == 11:
+        assert e2.info()["lanes_per_track"] % 8 == 0 and e2.info()["lanes_per_track"] != n_win      # the pipeline: eight waves per window
+    else:
+        assert e2.info()["kernel_id"] == 17                         # ... or the reverse sweep, which takes what the pipeline would
     assert abs(val - v2) <= 1e-11 * max(1.0, abs(val)) and np.max(np.abs(grad - g2)) <= 1e-9 * np.max(np.abs(grad))
     eng.close(); e2.close()
 

@@ -6,7 +6,7 @@ import pytest
 
 from cases import problem_from_spec
 from golden_io import load_golden
-from hostsim_lib import kalman_iso, kalman_tv, load
+from hostsim_lib import kalman_adj, kalman_iso, kalman_tv, load
 from oracle_lib import oracle_eval
 
 GOLD = {r["name"]: r for r in load_golden()}
@@ -43,6 +43,25 @@ def test_tv_lane_math_matches_oracle(name):
     grad[pb.par_fixed != 0] = 0.0
     assert abs(val - oval) <= 1e-11 * max(1.0, abs(oval))
     assert np.max(np.abs(grad - ograd)) <= 1e-9 * np.max(np.abs(ograd)) + 1e-11
+
+
+@pytest.mark.parametrize("name", TV)
+def test_adjoint_lane_math_matches_oracle(name):
+    """csrc/ssde_adj.hpp (the reverse sweep k_iso_adj.hip runs lane = track: a record per row forwards, the transposed step
+    backwards, the coefficient gradient as X' g) against the oracle's data term and against the forward tangents, on every
+    golden Kalman case without H_array / custom P0."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = np.asarray(rec["par"], dtype=np.float64)
+    val, grad = kalman_adj(pb, par)
+    oval, ograd = oracle_eval(pb, par, order=1, data_only=True)
+    grad[pb.par_fixed != 0] = 0.0
+    assert abs(val - oval) <= 1e-11 * max(1.0, abs(oval))
+    assert np.max(np.abs(grad - ograd)) <= 1e-9 * np.max(np.abs(ograd)) + 1e-11
+    tval, tgrad = kalman_tv(pb, par)
+    tgrad[pb.par_fixed != 0] = 0.0
+    assert abs(val - tval) <= 1e-12 * max(1.0, abs(tval))
+    assert np.max(np.abs(grad - tgrad)) <= 1e-10 * np.max(np.abs(tgrad)) + 1e-12
 
 
 @pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 5, 10])

@@ -61,18 +61,20 @@ par = np.r_[np.log(0.05), 0, 0, 0, 0, np.zeros(len(S)), 0.05 * np.sin(np.arange(
 if args.linear:
     par = np.array([np.log(0.05), 0, 0, 0.0, 0.3, 0.0])
 bytes_row = 8.0 * (2 + nre + (4 if args.with_h else 0))
-for label, env in (("lane=track", None), ("lane=direction", "1")):
-    if args.only and args.only != label:
+ref = None
+for label, env in (("lane=track adjoint", {"SSDE_CV_ADJ": "2"}), ("lane=track tangents", {"SSDE_CV_ADJ": "0"}), ("lane=direction", {"SSDE_NO_COLVAR": "1"})):
+    if args.only and args.only not in label:
         continue
-    if env:
-        os.environ["SSDE_NO_COLVAR"] = env
-    else:
-        os.environ.pop("SSDE_NO_COLVAR", None)
+    for k in ("SSDE_NO_COLVAR", "SSDE_CV_ADJ"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
     t0 = time.perf_counter()
     eng = capi.Engine(pb)
     t_create = time.perf_counter() - t0
-    reps = args.evals if not env else max(3, args.evals // 4)
+    reps = args.evals if "direction" not in label else max(3, args.evals // 4)
     v0, g0 = eng.eval(par)
+    if ref is None:
+        ref = (v0, g0)
     eng.eval(par + 1e-3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -80,9 +82,13 @@ for label, env in (("lane=track", None), ("lane=direction", "1")):
         eng.eval(par + 1e-3 * np.sin(k + np.arange(len(par))))
     wall = (time.perf_counter() - t0) / reps
     inf = eng.info()
-    print(json.dumps(dict(kernel=label, path=capi.PATH_NAMES[inf["path"]], tracks=M, rows=T, columns=nre, ms_per_eval=1e3 * wall,
+    print(json.dumps(dict(kernel=label, engine_kernel=capi.KERNEL_NAMES.get(inf["kernel_id"], "?"), path=capi.PATH_NAMES[inf["path"]], tracks=M, rows=T,
+                          columns=nre, ms_per_eval=1e3 * wall,
                           rows_per_s=n / wall, main_kernel_ms=inf["main_kernel_ms"], windows=inf["lanes_per_track"], warm_up=inf["window"],
                           window_check=inf["window_check"], retries=inf["window_retries"], create_s=t_create,
-                          frac_of_8TBps_required=bytes_row * n / wall / 8e12, value=v0, grad_norm=float(np.linalg.norm(g0)))), flush=True)
+                          frac_of_8TBps_required=bytes_row * n / wall / 8e12, value=v0, grad_norm=float(np.linalg.norm(g0)),
+                          value_rel_vs_first=abs(v0 - ref[0]) / max(1.0, abs(ref[0])),
+                          grad_rel_vs_first=float(np.max(np.abs(g0 - ref[1])) / max(1e-300, np.max(np.abs(ref[1])))))), flush=True)
     eng.close()
-os.environ.pop("SSDE_NO_COLVAR", None)
+for k in ("SSDE_NO_COLVAR", "SSDE_CV_ADJ"):
+    os.environ.pop(k, None)
