@@ -390,10 +390,85 @@ def secondary_workload(name, model, M, T, dev, steps, mutate):
             "quiet_window": inf["quiet_window"], "quiet_share": inf["quiet_share"]}
 
 
+def _timed_engine(name, eng, theta, steps, dev, extra=None):
+    """`steps` evaluations of an engine at distinct parameter vectors (theta(k)); the entry every secondary workload reports"""
+    import torch
+    from smoothsde_amd import capi
+    for k in range(2):
+        eng.eval(theta(-1 - k))
+    ssde_eval = eng.bound_eval(order=1)
+    ths = [np.ascontiguousarray(theta(k)) for k in range(steps)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kms = []
+    for k in range(steps):
+        ssde_eval(ths[k])
+        kms.append(eng.last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    inf = eng.info()
+    eng.close()
+    kern = float(np.mean(kms))
+    out = {"workload": name, "value": inf["n_rows"] * steps / el, "unit": "track-timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+           "kernel_ms": kern, "path": capi.PATH_NAMES[inf["path"]], "required_bytes_per_row": inf["required_bytes_per_row"],
+           "algo_bytes_per_row": inf["algo_bytes_per_row"], **_roofs_of(inf, kern),
+           "window_check_max": inf["window_check_max"], "window_retries": inf["window_retries"], "groups": inf["n_groups"]}
+    out.update(extra or {})
+    return out
+
+
+def baseline_config_workloads(dev, steps, tracks=10_000, rows=10_000):
+    """BASELINE.json's configurations 1, 2 and 3 at their named sizes (the metric's line is configuration 2 with 10^4 rows per track):
+    C1 one elephant-like CTCRW track with tau and nu splines of a covariate (smoothSDE.rmd:476-490; the reference's own CPU-runnable
+    case -- a latency measurement here: 3672 rows); C2 10^4 CTCRW tracks x 10^3 rows, constant coefficients; C3 10^4 OU tracks x 10^4
+    rows with a 9-column spline-varying drift, the design block streamed (88 B/row) and -- the same model -- evaluated by the lanes
+    from its B-spline table (ssde_ppbasis: 24 B/row resident)."""
+    import torch
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import bspline_basis, bspline_ppbasis, second_difference_penalty, simulate
+    out = []
+    # C1
+    ID1, t1, o1 = simulate("CTCRW", 1, 3672, 2, tau=1.0, nu=1.0, sigma_obs=0.05, z0=[572.34, 1675.42], seed=342)
+    temp = 30 + 10 * np.sin(np.arange(3672) * 2 * np.pi / 24) + np.random.default_rng(342).normal(0, 2, 3672)
+    B = bspline_basis((temp - temp.min()) / (temp.max() - temp.min()), 9)
+    S9 = second_difference_penalty(9)
+    eng = capi.Engine(capi.Problem("CTCRW", ID1, t1, o1, X_re=[None, None, B, B], S_list=[S9, S9],
+                                   par_fixed=np.r_[0, 1, 1, 0, 0, 1, 1, np.zeros(18)].astype(np.uint8)))
+    p1 = np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(18))]
+    out.append(_timed_engine("BASELINE config 1: one elephant-like CTCRW track x 3672 rows, tau and nu splines of a covariate (18 columns)",
+                             eng, lambda k: p1 + 1e-3 * np.sin(k + np.arange(len(p1))), max(steps, 10), dev, {"baseline_config": 1}))
+    # C2
+    T2 = max(16, rows // 10)
+    ID, times, obs = capi.simulate_device("CTCRW", tracks, T2, 2, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=1, device=dev)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=[0, 1, 1, 0, 0]))
+    del ID, times, obs
+    out.append(_timed_engine(f"BASELINE config 2: {tracks} CTCRW x {T2}, constant coefficients, regular grid", eng,
+                             lambda k: theta_for(5, 2, 4, k), max(steps, 10), dev, {"baseline_config": 2}))
+    # C3, streamed and table form
+    ID, times, obs = simulate("OU", tracks, rows, 1, mu=1.0, tau=2.0, kappa=1.0, seed=2, backend="torch", device=dev)
+    n = len(ID)
+    x = torch.cumsum(torch.randn(n, device=dev, dtype=torch.float64) * 0.01, 0)
+    x = (x - x.min()) / (x.max() - x.min())
+    p3 = np.concatenate([[1.0, np.log(2.0), 0.0], [0.0], 0.05 * np.sin(np.arange(9))])
+    th3 = lambda k: p3 + 1e-3 * np.sin(k + np.arange(len(p3)))
+    basis = bspline_ppbasis(x, 9, centre=np.zeros(9))
+    Bd = torch.stack([torch.cos((k + 1) * np.pi * x) for k in range(9)], dim=1)         # (a 9-column block built in HBM; tools/bench_configs.py)
+    eng = capi.Engine(capi.Problem.from_torch("OU", ID, times, obs, X_re=[Bd, None, None], S_list=[second_difference_penalty(9)]))
+    del Bd
+    out.append(_timed_engine(f"BASELINE config 3: {tracks} OU x {rows}, spline-varying drift, 9 design columns streamed (88 B/row)", eng, th3,
+                             steps, dev, {"baseline_config": 3}))
+    eng = capi.Engine(capi.Problem.from_torch("OU", ID, times, obs, basis_re=[basis, None, None], S_list=[second_difference_penalty(9)]))
+    del ID, times, obs, x
+    out.append(_timed_engine("BASELINE config 3 with the design block evaluated by the lanes from its B-spline table (ssde_ppbasis)", eng, th3,
+                             steps, dev, {"baseline_config": 3, "form": "table"}))
+    return out
+
+
 def row_varying_workload(M, T, dev, steps, k_cols=9):
     """1e4 CTCRW tracks with tau AND nu smooth in a covariate (2 x 9 design columns streamed next to the observations): the
-    batch-scale form of BASELINE's config 1 (nllk_ctcrw.hpp:143-156), on the lane = track kernel with one filter tangent per
-    design column (k_iso_colvar.hip).  Hat-function basis of a per-row covariate, built on the device."""
+    batch-scale form of BASELINE's config 1 (nllk_ctcrw.hpp:143-156), on the lane = track kernel with the gradient by a reverse
+    sweep (k_iso_adj.hip; SSDE_CV_ADJ=0: one filter tangent per design column, k_iso_colvar.hip).  Hat-function basis of a per-row
+    covariate, built on the device."""
     import torch
     from smoothsde_amd import capi
     from smoothsde_amd.synth import second_difference_penalty
@@ -726,6 +801,16 @@ def main():
         except Exception:
             profiled = None
     roofline["traffic_profiled"] = profiled
+    # `traffic`: HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, as
+    # MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process: the figure is the one of the committed
+    # rocprofv3 --pmc run of this very command (profiles/pmc_latest.json), given only when that run profiled the kernel family that
+    # dominated here.
+    pjm = json.load(open(pmc)) if profiled else {}
+    if (profiled and profiled.get("main_kernel_bytes") and str(pjm.get("main_kernel", "")).find(roofline["kernel"].split(" ")[0]) >= 0
+            and abs(float(pjm.get("algorithmic_bytes_per_launch", 0.0)) - float(roofline.get("algo_bytes_per_launch") or -1.0)) < 0.5):      # the same launch
+        roofline["traffic"] = float(profiled["main_kernel_bytes"])
+        roofline["traffic_over_required"] = roofline["traffic"] / roofline["required_bytes_per_launch"] if roofline.get("required_bytes_per_launch") else None
+        roofline["traffic_source"] = f"profiles/pmc_latest.json (tag {profiled.get('tag')}): rocprofv3 --pmc of this command, an earlier run"
     info0 = infos[dom]
     roofline["whole_evaluation"] = None if eval_ms is None else {
         "gpu_ms": eval_ms,
@@ -835,6 +920,7 @@ def main():
                                           max(3, args.steps // 2), absent))
             sec.append(row_varying_workload(M, max(16, T // 10), dev, max(3, args.steps // 2)))
             sec.append(argos_workload(M, T, dev, max(3, args.steps // 2)))
+            sec.extend(baseline_config_workloads(dev, max(3, args.steps // 2), M, T))
         except Exception as e:  # the secondary numbers must never take the bench line down
             sec.append({"workload": "failed", "error": str(e)})
         line["secondary"] = sec

@@ -223,7 +223,11 @@ def eseal_spec(name, seed, lengths, variant="const", na_rows=()):
     return spec
 
 
+SPEC_CALLS = [0]     # problems built from golden records so far (the kernel-coverage ledger of tests/conftest.py reads it)
+
+
 def problem_from_spec(spec, **over) -> Problem:
+    SPEC_CALLS[0] += 1
     kw = dict(a0=spec.get("a0"), P0=spec.get("P0"), H=spec.get("H"), par_fixed=spec.get("par_fixed"),
               include_penalty=spec.get("include_penalty", 1), na_mode=spec.get("na_mode", 1),
               other_data=spec.get("other_data"), t_decay=spec.get("t_decay"), col_decay=spec.get("col_decay"),

@@ -20,6 +20,9 @@ _LIB = None
 _dp = C.POINTER(C.c_double)
 
 
+CALLS = [0]          # evaluations of the oracle so far (tests/conftest.py: the kernel-coverage ledger reads it around every GPU test)
+
+
 def build_oracle():
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
 
@@ -117,6 +120,7 @@ def oracle_eval(problem: Problem, par, order: int = 1, threads: int = 1, report:
                 data_only: bool = False):
     """nllk (+ penalty unless data_only), gradient over the full parameter vector, and
     optionally aest_all (n x sdim)."""
+    CALLS[0] += 1
     lib = load_oracle()
     d = problem.desc()
     par = np.ascontiguousarray(par, dtype=np.float64)

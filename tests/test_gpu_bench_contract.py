@@ -35,6 +35,7 @@ def test_bench_line_has_what_the_driver_reads():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
+    # (`traffic` is the PMC figure of the committed profile of THIS command at ITS size -- null for any other launch, such as this small one)
     assert r["bound"] in ("hbm", "fp64_issue") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # two roofs: the HBM fraction and the fp64-issue fraction side by side, neither above 1; `bound` names the larger
@@ -55,7 +56,7 @@ def test_bench_line_has_what_the_driver_reads():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
-    assert len(d["secondary"]) == 6 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
+    assert len(d["secondary"]) == 10 and all(s["value"] > 0 and s["window_check_max"] <= 1e-11 for s in d["secondary"])
     for s in d["secondary"]:                                       # every entry names its kernel and carries both roofs, each <= 1
         assert s["kernel"] != "?", s
         if s["kernel"] == "tv_filter_kernel":                      # replayed from a hipGraph: no event pair around the launch, no roofs
@@ -68,7 +69,13 @@ def test_bench_line_has_what_the_driver_reads():
     assert "H_array" in d["secondary"][5]["workload"] and d["secondary"][5]["path"] == "isotropic-register"     # the one-wave full-covariance kernel
     # tau and nu smooth: 640 x 80 rows x 32 lanes per track is below the rows rule of ssde_create (4.5e6 lane-rows): the lane = direction
     # path here, the eight-wave pipeline at the default size (tests/test_gpu_colvar.py pins the rule on both sides)
-    assert "tau and nu smooth" in d["secondary"][4]["workload"] and kern[4] in ("tv_filter_kernel", "iso_colvar_kernel", "iso_few_kernel"), kern
+    assert "tau and nu smooth" in d["secondary"][4]["workload"] and kern[4] in ("tv_filter_kernel", "iso_colvar_kernel", "iso_few_kernel", "iso_adj_kernel"), kern
+    # BASELINE configurations 1, 2, 3 (+ 3 with the block evaluated from its table): driver-timed entries with their kernels
+    assert [s.get("baseline_config") for s in d["secondary"][6:]] == [1, 2, 3, 3] and d["secondary"][9]["form"] == "table"
+    assert kern[6] == "tv_filter_kernel" and kern[7] == "iso_shared_kernel" and kern[8] == "direct_fast_kernel" and kern[9] == "direct_fast_kernel", kern
+    # (regular grid: no time stamps resident -- 8 B of observation + 72 B of columns; from the table: the observation and the covariate)
+    assert d["secondary"][8]["required_bytes_per_row"] == 80.0 and d["secondary"][8]["algo_bytes_per_row"] == 88.0
+    assert d["secondary"][9]["required_bytes_per_row"] <= 24.0
     assert d["secondary"][4]["path"] == ("isotropic-row-varying" if kern[4] == "tv_filter_kernel" else "isotropic-register")
     assert "one missing row" in d["secondary"][2]["workload"] and d["secondary"][2]["quiet_window"] > 0             # quiet rows of the general kernel
 

@@ -6,9 +6,10 @@
          T ~ U[0.5 T, T], 5 % missing rows (half of them NA in column 0 only, half in every column: the reference tests
          column 0, nllk_ctcrw.hpp:214), one GPU's share (3 750 tracks per model), the three handles evaluated
          CONCURRENTLY on one GPU (three streams).
-The oracle takes minutes at these sizes, so parity is asserted through size-independent properties (additivity over
-track shards, gradient = derivative of the value, determinism) plus a random sample of whole tracks against the oracle
-at the usual tolerance (value 1e-10, gradient 1e-8)."""
+Parity is asserted here through size-independent properties (additivity over track shards, gradient = derivative of the
+value, determinism) plus a random sample of whole tracks against the oracle at the usual tolerance (value 1e-10, gradient
+1e-8); the WHOLE batches of C2 (10^7 rows) and of the headline configuration (10^8 rows) against the oracle -- seconds to a
+minute of the literal oracle on the box's 16 threads -- are tests/test_gpu_whole_batch.py."""
 import numpy as np
 import pytest
 

@@ -58,6 +58,7 @@ def test_golden_drift_cases_take_the_shared_covariance_path(rec, monkeypatch):
     engt = capi.Engine(problem_from_spec(rec))
     assert engt.info()["path"] == PATH_TV
     vt, gt = engt.eval(rec["par"], order=1)
+    assert engt.info()["kernel_id"] == 15 and eng.info()["kernel_id"] in (9, 10)        # tv_filter_kernel against the drift lanes
     _close(val, grad, vt, gt)
     eng.close(); engt.close()
 
@@ -170,6 +171,7 @@ def test_general_and_shared_lanes_agree_on_a_complete_regular_batch(monkeypatch)
     e2 = capi.Engine(pb)
     assert _is_drift(e2)
     v2, g2 = e2.eval(par)
+    assert e1.info()["kernel_id"] == 9 and e2.info()["kernel_id"] == 10                 # iso_drift_kernel / iso_drift_general_kernel
     assert abs(v1 - v2) <= 1e-11 * abs(v1) and np.max(np.abs(g1 - g2)) <= 1e-9 * np.max(np.abs(g1))
     e1.close(); e2.close()
 

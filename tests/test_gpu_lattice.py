@@ -70,6 +70,7 @@ def test_lattice_with_absent_fixes_matches_the_oracle_on_the_callers_rows(model,
     assert info["path"] == 1 and info["uniform_dt"] == 1, info            # laid out on the lattice: the hoisted transition
     assert info["n_rows"] == pb.n and pb.n < info["n_rows_tiled"] <= 1.35 * pb.n + 64
     val, grad = eng.eval(par, order=1)
+    assert eng.info()["kernel_id"] in (3, 5, 6, 7)                          # a regular-grid kernel (shared / hoisted transition / quiet rows / mixed)
     _close(val, grad, oval, ograd)
     assert np.allclose(eng.report(par), oaest, rtol=1e-9, atol=1e-9, equal_nan=True)
     eng.close()
@@ -77,6 +78,7 @@ def test_lattice_with_absent_fixes_matches_the_oracle_on_the_callers_rows(model,
     eng = capi.Engine(pb)
     assert eng.info()["uniform_dt"] == 0
     v2, g2 = eng.eval(par, order=1)
+    assert eng.info()["kernel_id"] == 4                                     # iso_mask_kernel, per-row transition
     _close(v2, g2, oval, ograd)
     eng.close()
 

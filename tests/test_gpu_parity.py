@@ -61,6 +61,32 @@ def test_direction_split_variants(split, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("split", ["split", "1,2,4,8", "3,12"])
+@pytest.mark.parametrize("model,par", [
+    ("CTCRW", [-1.0, 0.1, -0.1, 0.5, 0.2]), ("OU_SSM", [-1.0, 0.3, -0.2, 0.6, 0.1]), ("BM_SSM", [-1.0, 0.05, 0.0, 0.2])])
+@pytest.mark.parametrize("grid", ["missing", "irregular"])
+def test_direction_parts_on_windowed_batches_vs_oracle(split, model, par, grid, monkeypatch):
+    """iso_kernel (SSDE_KERNEL_ISO_SPLIT): the gradient directions of one (group, window) split over several waves, each recomputing
+    the primal -- a testing path of the general lanes (SSDE_ISO_SPLIT), here on batches long enough for several verified windows,
+    with missing rows or on an irregular grid, against the oracle."""
+    monkeypatch.setenv("SSDE_ISO_SPLIT", split)
+    rng = np.random.default_rng(23)
+    ID, times, obs = simulate(model, 70, 2500, 2, seed=31)
+    if grid == "missing":
+        na = rng.random(len(ID)) < 0.03
+        na[::2500] = False
+        obs[na] = np.nan
+    else:
+        times = np.cumsum(rng.uniform(0.5, 1.5, size=len(ID)))
+    pb = capi.Problem(model, ID, times, obs)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(np.array(par))
+    inf = eng.info()
+    assert inf["kernel_id"] == 8 and inf["window"] > 0 and inf["window_check"] <= capi.WINDOW_TOL
+    _close(val, grad, *_oracle(pb, np.array(par)))
+    eng.close()
+
+
 KALMAN = [r for r in GOLD if r["model"] in ("CTCRW", "OU_SSM", "BM_SSM")]
 
 
@@ -245,7 +271,8 @@ def _full_size_check(model, par, fixed, na_frac, sim_kw, M=10_000, T=10_000):
 
 def test_full_bench_size_properties():
     """BASELINE.json's configuration itself (10^4 CTCRW tracks x 10^4 rows, d = 2, mu fixed; 10^8 rows, built in HBM
-    like bench.py does), where the oracle would take minutes -- size-independent properties instead:
+    like bench.py does) under size-independent properties (the whole batch against the oracle: tests/test_gpu_whole_batch.py,
+    ~50 s of the literal oracle on 16 threads):
       * additivity: the batch equals the sum of its two halves (disjoint track shards) in value and gradient;
       * the gradient is the derivative of the value (central difference along a random direction, 1e-7 relative);
       * repeated evaluations are bitwise identical; the window hand-over check passes;
@@ -488,6 +515,7 @@ def test_shared_covariance_path_mixed_groups(model, par, d, monkeypatch):
     monkeypatch.setenv("SSDE_NO_SHARED", "1")
     gen = capi.Engine(pb)
     v2, g2 = gen.eval(par)
+    assert eng.info()["kernel_id"] == 3 and gen.info()["kernel_id"] in (5, 6)           # iso_shared_kernel / the general lanes on a regular grid
     assert abs(v - v2) <= 1e-12 * abs(v2)
     assert np.max(np.abs(g - g2)) <= 1e-10 * np.max(np.abs(g2))
     eng.close(); gen.close()
@@ -503,6 +531,7 @@ def test_generic_direct_kernel(rec, monkeypatch):
     monkeypatch.setenv("SSDE_NO_DIRECT_FAST", "1")
     eng = capi.Engine(problem_from_spec(rec))
     val, grad = eng.eval(rec["par"], order=1)
+    assert eng.info()["kernel_id"] == 1                            # direct_kernel
     _close(val, grad, rec["expected"]["value"], rec["expected"]["grad"])
     eng.close()
 

@@ -75,7 +75,7 @@ def test_one_missing_row_per_track_against_the_oracle(model, d, monkeypatch):
     monkeypatch.setenv("SSDE_NO_QUIET", "1")
     e2 = capi.Engine(pb)
     v2, g2 = e2.eval(par, order=1)
-    assert e2.info()["quiet_window"] == 0
+    assert e2.info()["quiet_window"] == 0 and e2.info()["kernel_id"] in (4, 5, 7)       # the general lanes without quiet rows (7: next to the shared kernel)
     e2.close()
     assert abs(v2 - val) <= 1e-11 * abs(val) and np.max(np.abs(g2 - grad)) <= 1e-9 * max(1.0, np.max(np.abs(grad)))
 
