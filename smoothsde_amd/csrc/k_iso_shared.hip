@@ -6,9 +6,9 @@
 
 namespace ssde {
 
-hipError_t launch_iso_shared_ctcrw(int d, const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
-hipError_t launch_iso_shared_ou(int d, const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
-hipError_t launch_iso_shared_bm(int d, const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
+hipError_t launch_iso_shared_ctcrw(int d, const IsoArgs& a, const ReduceArgs& r, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
+hipError_t launch_iso_shared_ou(int d, const IsoArgs& a, const ReduceArgs& r, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
+hipError_t launch_iso_shared_bm(int d, const IsoArgs& a, const ReduceArgs& r, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep);
 
 // host side: the stationary constants (layout in ssde_device.hpp)
 void fill_stat_consts(int model, int d, IsoArgs& a) {
@@ -49,17 +49,20 @@ void fill_stat_consts(int model, int d, IsoArgs& a) {
     }
 }
 
-// the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0])
-hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (a.n_parts != 1) return hipErrorInvalidValue;
+// the shared path runs all directions in one part (n_parts == 1, mask = part_mask[0]).  r: the reduction's arguments, read by the kernel
+// only when a.fused (the finalising work inside this launch); a.fuse_items is set here
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a0, const ReduceArgs& r, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (a0.n_parts != 1) return hipErrorInvalidValue;
+    IsoArgs a = a0;
     const int g8 = (a.tv.n_groups + 7) / 8;
     const int n_grid_chunks = a.t0 > 0 ? a.n_chunks - 1 : a.n_chunks;
     dim3 grid((g8 * 8 * n_grid_chunks + WG_WAVES - 1) / WG_WAVES);
     if (grid.x == 0) return hipSuccess;
+    a.fuse_items = a.tv.n_groups * n_grid_chunks;              // (fused launches run every group: the engine sees to it)
     const bool deep = a.deep_prefetch != 0;
-    if (model == M_CTCRW) return launch_iso_shared_ctcrw(d, a, grid, s, ev0, ev1, deep);
-    if (model == M_OU_SSM) return launch_iso_shared_ou(d, a, grid, s, ev0, ev1, deep);
-    if (model == M_BM_SSM) return launch_iso_shared_bm(d, a, grid, s, ev0, ev1, deep);
+    if (model == M_CTCRW) return launch_iso_shared_ctcrw(d, a, r, grid, s, ev0, ev1, deep);
+    if (model == M_OU_SSM) return launch_iso_shared_ou(d, a, r, grid, s, ev0, ev1, deep);
+    if (model == M_BM_SSM) return launch_iso_shared_bm(d, a, r, grid, s, ev0, ev1, deep);
     return hipErrorInvalidValue;
 }
 

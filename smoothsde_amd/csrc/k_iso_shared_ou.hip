@@ -3,7 +3,7 @@
 #include "k_iso_shared.inc"
 
 namespace ssde {
-hipError_t launch_iso_shared_ou(int d, const IsoArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep) {
-    return launch_shared_model<M_OU_SSM>(d, a, grid, s, ev0, ev1, deep);
+hipError_t launch_iso_shared_ou(int d, const IsoArgs& a, const ReduceArgs& r, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, bool deep) {
+    return launch_shared_model<M_OU_SSM>(d, a, r, grid, s, ev0, ev1, deep);
 }
 }  // namespace ssde

@@ -195,6 +195,12 @@ struct IsoArgs {
     int cv_full;                 // 4 x 4 covariance lanes (CTCRW, d = 2): per-row H_array and / or a P0 that is not block-identical
     int cv_has_h;                // ... the tiles hold H_array[,,i] in the d^2 channels after the observations
     double cv_p0[16];            // ... P0, column-major
+    // The finalising work INSIDE the main launch (iso_shared_kernel; fused_finalize_wave below): the second wave to arrive at a window
+    // boundary checks that hand-over, the last wave of the launch forms the sums and publishes -- no dependent second launch.
+    int fused;                   // 0: launch_iso_finalize follows
+    int fuse_items;              // work items (waves that run a window) of this launch
+    unsigned* fuse_arrive;       // [n_chunks - 1][n_groups] arrivals at a boundary (zero between launches)
+    unsigned* fuse_done;         // one word: work items that have finished (zero between launches)
     // ... the same models with the gradient by a reverse sweep (k_iso_adj.hip): the state entering every CB-th row of a window
     double* adj_ckpt;            // [work item][adj_ckpt_stride]
     int64_t adj_ckpt_stride;     // doubles per work item: checkpoints of its window x state doubles x 64
@@ -260,7 +266,8 @@ hipError_t launch_iso(int model, int d, const IsoArgs& a, bool any_dirty, hipStr
 int iso_block_rows(int model);
 hipError_t launch_nan_blocks(const TileView& tv, int d, int block_rows, unsigned long long* bits, int nwords, hipStream_t s);
 // ev0 / ev1 (may be NULL): stamped with the kernel's own begin / end
-hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+struct ReduceArgs;
+hipError_t launch_iso_shared(int model, int d, const IsoArgs& a, const ReduceArgs& r, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // shared-covariance lanes with a streamed row-varying drift (k_iso_drift.hip); partials [n_chunks][4 + d + drift_k][n_groups]
 hipError_t launch_iso_drift(int model, int d, const IsoArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 int drift_nstate(int model, int d, int k);
@@ -296,6 +303,8 @@ struct ReduceArgs {
     int n_parts, nacc, n_blocks;
     int n_value_parts, chunks_per_part;
     int n_out;                    // 1 + n_par_full
+    int kfast;                    // partials laid out [part][block][acc] instead of [part][acc][block] (the kernel whose last wave forms the sums
+                                  // itself reads all accumulators of an entry with one wide load: fused_finalize_wave)
     const double* chk;
     int n_chk;
     double add[4];                // data-independent terms of the shared-covariance path, added to
@@ -714,7 +723,9 @@ __device__ __forceinline__ unsigned long long reduce_slot(const ReduceArgs& A, i
     // a run = `chunks` parts that feed the same slot, n_blocks entries each, `stride` doubles apart; walked as one
     // flat index range with four independent loads in flight per thread (fixed order: bitwise reproducible)
     const int64_t stride = (int64_t)A.nacc * A.n_blocks;
-    auto sum_run = [&](const double* base, int chunks) {
+    // accumulator k of the parts [p0, p0 + chunks): entry i = c n_blocks + b in the order the sums have always been formed
+    auto sum_run = [&](int p0, int k, int chunks) {
+        const double* base = A.kfast ? A.partials + (int64_t)p0 * stride + k : A.partials + ((int64_t)p0 * A.nacc + k) * A.n_blocks;
         const int total = chunks * A.n_blocks;
         for (int i0 = tid; i0 < total; i0 += 4 * 256) {
             double v[4];
@@ -722,19 +733,19 @@ __device__ __forceinline__ unsigned long long reduce_slot(const ReduceArgs& A, i
             for (int u = 0; u < 4; u++) {
                 const int i = i0 + u * 256;
                 const int c = i / A.n_blocks, b = i - c * A.n_blocks;
-                v[u] = i < total ? base[c * stride + b] : 0.0;
+                v[u] = i < total ? (A.kfast ? base[(int64_t)i * A.nacc] : base[c * stride + b]) : 0.0;
             }
             acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
     };
     if (slot == 0) {
-        sum_run(A.partials, A.n_value_parts);                                        // accumulator 0
+        sum_run(0, 0, A.n_value_parts);                                              // accumulator 0
     } else {
         const int nk = A.nacc - 1, cpp = A.chunks_per_part;
         for (int pg = 0; pg * cpp < A.n_parts; pg++)
             for (int k = 1; k < A.nacc; k++)
                 if (A.map[pg * nk + (k - 1)] == slot)
-                    sum_run(A.partials + ((int64_t)pg * cpp * A.nacc + k) * A.n_blocks, cpp);
+                    sum_run(pg * cpp, k, cpp);
     }
     sh[tid] = acc;
     __syncthreads();
@@ -749,6 +760,144 @@ __device__ __forceinline__ unsigned long long reduce_slot(const ReduceArgs& A, i
         return publish_store(&A.out[slot], r);
     }
     return 0ull;
+}
+// ---- the finalising work fused into the main launch -----------------------------------------------------------------------------------
+// iso_finalize_kernel is a dependent launch of ~10 us (+ the gap before it) that re-reads what the main kernel's waves have just
+// written.  Fused: a wave that has run its window(s) announces itself at the boundaries it shares with its neighbours; the SECOND
+// wave to arrive at a boundary compares the two hand-over records (the arithmetic of window_check_block, one wave instead of four:
+// maxima, order-free); the LAST wave of the launch forms the fixed-order sums -- reduce_slot's order exactly, its 256 threads as four
+// virtual threads per lane, so the result is bitwise the two-launch one -- and publishes them.
+// The records and partial sums cross XCDs (each has its own L2): they are written and read with DEVICE-scope accesses (dev_store /
+// dev_load: past the local L2), a wave waits for its stores (s_waitcnt vmcnt(0)) before it announces them with a relaxed device-scope
+// atomic -- and no fence anywhere: a release / acquire fence here is a write-back / invalidate of the XCD's whole L2, a thousand of
+// them per launch cost 0.1-0.15 ms (measured: 0.477 against 0.328 ms on the headline batch).
+__device__ __forceinline__ void dev_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double dev_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dev_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ double window_check_wave(const IsoArgs& A, int nstate, int g, int c) {
+    const int lane = threadIdx.x & 63;
+    const TileView& tv = A.tv;
+    const int L = tv.group_len[g];
+    const int ns = tv.lane_nsteps[g * WAVE + lane];
+    int sb_, s_next, se_;
+    window_bounds(L, A.n_chunks, A.window, A.t0, c + 1, sb_, s_next, se_, A.t0_delta);
+    const bool valid = (ns > s_next) && (s_next < L);
+    const double* out_c = A.bnd + (((int64_t)c * tv.n_groups + g) * 2 + 1) * A.bnd_stride * WAVE + lane;
+    const double* in_n = A.bnd + (((int64_t)(c + 1) * tv.n_groups + g) * 2 + 0) * A.bnd_stride * WAVE + lane;
+    double worst = 0.0;
+    for (int k0 = 0; k0 < nstate; k0 += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool on = k0 + i < nstate;
+            av[i] = on ? dev_load(out_c + (k0 + i) * WAVE) : 0.0;
+            bv[i] = on ? dev_load(in_n + (k0 + i) * WAVE) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (k0 + i >= nstate) break;
+            const double a = valid ? av[i] : 0.0, b = valid ? bv[i] : 0.0;
+            double err = fabs(a - b), sc = fmax(fabs(a), fabs(b));
+            if (valid && !(err == err)) err = INFINITY;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                err = fmax(err, __shfl_xor(err, o, 64));
+                sc = fmax(sc, __shfl_xor(sc, o, 64));
+            }
+            if (err > 0.0) worst = fmax(worst, err / sc);
+        }
+    }
+    return worst;
+}
+// reduce_slot for ALL NACC accumulators of a one-part launch by ONE wave, bitwise: lane l carries the virtual threads l, l + 64,
+// l + 128, l + 192 of the 256-thread form; the partial sums are laid out [window][group][accumulator] (ReduceArgs.kfast), so an
+// entry's accumulators arrive with one wide load and every load of the pass is in flight before the first sum
+template <int NACC>
+__device__ __forceinline__ void reduce_all_wave(const ReduceArgs& A, double (&r)[NACC]) {
+    const int lane = threadIdx.x & 63;
+    double acc[NACC][4];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+    const int total = A.n_value_parts * A.n_blocks;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int tid = lane + 64 * j;
+        for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+            double v[4][NACC];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 256;
+                const double* e = A.partials + (int64_t)(i < total ? i : 0) * NACC;
+#pragma unroll
+                for (int k = 0; k < NACC; k++) v[u][k] = i < total ? e[k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NACC; k++) acc[k][j] += (v[0][k] + v[1][k]) + (v[2][k] + v[3][k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; k++) {
+        acc[k][0] += acc[k][2]; acc[k][1] += acc[k][3];             // the tree: o = 128,
+        double x = acc[k][0] + acc[k][1];                            // 64,
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);   // 32 .. 1 (lane l < o reads lane l + o: sh[tid] += sh[tid + o])
+        r[k] = x;                                                    // (lane 0's is the sum)
+    }
+}
+// every lane of a wave that ran windows c_lo .. c_hi of group g calls this once, after its last store (dev_store: records, partial sums)
+template <int NACC>
+__device__ __forceinline__ void fused_finalize_wave(const IsoArgs& A, const ReduceArgs& R, int nstate, int g, int c_lo, int c_hi) {
+    const int lane = threadIdx.x & 63;
+    const int G = A.tv.n_groups;
+    dev_stores_done();                                               // this wave's records and partial sums have left it
+    double worst = 0.0;
+    for (int b = c_lo; b < c_hi; b++) worst = fmax(worst, window_check_wave(A, nstate, g, b));      // boundaries between this wave's own windows
+    for (int side = 0; side < 2; side++) {
+        const int b = side == 0 ? c_lo - 1 : c_hi;                   // the boundary before the first window, after the last one
+        if (b < 0 || b >= A.n_chunks - 1) continue;
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&A.fuse_arrive[(int64_t)b * G + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != 1u) continue;                                     // the first to arrive: the neighbour will check
+        worst = fmax(worst, window_check_wave(A, nstate, g, b));
+        if (lane == 0) __hip_atomic_store(&A.fuse_arrive[(int64_t)b * G + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    unsigned done = 0;
+    if (lane == 0) {
+        if (worst > 0.0 || worst != worst)
+            atomicMax((unsigned long long*)A.chk_out, (unsigned long long)__double_as_longlong(worst == worst ? worst : INFINITY));
+        dev_stores_done();                                           // (the atomicMax has returned: it precedes the count)
+        done = __hip_atomic_fetch_add(A.fuse_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != (unsigned)A.fuse_items - 1u) return;
+    // the last wave of the launch.  One acquire (an invalidate of this XCD's L2 -- once per launch): the partial sums, written through
+    // by the other waves, are then read with ordinary wide loads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double r[NACC];
+    reduce_all_wave<NACC>(R, r);
+    if (lane == 0) {
+        for (int slot = 0; slot < R.n_out; slot++) {                 // (a slot nothing feeds -- a fixed parameter -- is zero, as reduce_slot leaves it)
+            double v = slot == 0 ? r[0] : 0.0;
+#pragma unroll
+            for (int k = 1; k < NACC; k++)
+                if (R.map[k - 1] == slot) v = r[k];
+            for (int i = 0; i < 4; i++)
+                if (R.add_slot[i] == slot) v += R.add[i];
+            dev_store(&R.out[slot], v);
+        }
+        // the check word has a slot of its own (nobody zeroes out[] between launches): moved, and cleared for the next launch
+        const unsigned long long w = __hip_atomic_exchange((unsigned long long*)A.chk_out, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dev_store(&R.out[R.n_out], __longlong_as_double((long long)w));
+        __hip_atomic_store(A.fuse_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (R.pub) {
+        dev_stores_done();
+        for (int k = lane; k <= R.n_out; k += WAVE) R.pub[k] = dev_load(&R.out[k]);
+        __threadfence_system();                                      // the wave's stores have reached the host before the flag does
+        if (lane == 0) __hip_atomic_store(R.pub_flag, R.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 #endif
 

@@ -42,7 +42,7 @@ void release_device(ssde_handle* h) {
     }
     h->wave_clock.release();
     for (hipEvent_t& e : h->ev_ph) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    h->cv_ranges.release(); h->cv_parts.release(); h->adj_ckpt.release();
+    h->cv_ranges.release(); h->cv_parts.release(); h->adj_ckpt.release(); h->fuse_words.release();
     if (h->cv_ranges_pinned) { (void)hipHostFree(h->cv_ranges_pinned); h->cv_ranges_pinned = nullptr; }
     h->hs_partials.release(); h->hs_hess.release(); h->hs_i16.release();
     if (h->trace && h->trace_n > 0)

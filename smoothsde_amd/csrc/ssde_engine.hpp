@@ -172,6 +172,8 @@ struct ssde_handle {
     bool cv_full = false;          // 4 x 4 covariance lanes (CTCRW, d = 2, per-row H_array)
     bool cv_single = false;        // ... with constant tau / nu: one wave per (group, window) runs filter and tangents (iso_full_kernel)
     bool cv_few = false;           // few design columns, H = sigma_obs^2 I: one wave per (group, window) too (iso_few_kernel)
+    DevBuf<unsigned> fuse_words;   // the fused finalising work of iso_shared_kernel: [0] finished work items, [2..3] the check word, [4..] arrivals per (boundary, group)
+    bool env_no_fused = false, last_fused = false;
     int env_adj_tail = 0;          // testing (SSDE_ADJ_TAIL): rows past a window's end before its backward recursion starts
     bool cv_adj = false;           // gradient by a reverse sweep: one wave per (group, window), two passes (iso_adj_kernel)
     DevBuf<double> adj_ckpt;       // ... the state entering every adj_ckpt_rows-th row of every window (grown on demand)

@@ -418,6 +418,15 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     }
     HIPCHK(h, h->bnd.alloc((size_t)h->iso_parts * (buf_chunks + (h->cv_adj ? 1 : 0)) * G * 2 * (h->drift ? std::max(NSTATE_MAX, h->drift_nstate) : NSTATE_MAX) * WAVE));
     HIPCHK(h, h->chk.alloc((size_t)h->iso_parts * buf_chunks * G));
+    if (h->use_shared && !h->drift) {
+        HIPCHK(h, h->fuse_words.alloc(4 + (size_t)(buf_chunks + 1) * G));
+        HIPCHK(h, hipMemset(h->fuse_words.p, 0, h->fuse_words.n * sizeof(unsigned)));
+        // (measured, profiles/r05_fused_finalize_ab.txt: SLOWER than the dependent launch it replaces -- a wave's way from "my rows are
+        //  done" to "the result is out" is six device-scope round trips of ~2 us across the XCDs -- so the two-launch form stays the
+        //  default and SSDE_FUSED_FINALIZE=1 selects this one, bitwise the same numbers)
+        h->env_no_fused = true;
+        if (const char* e = getenv("SSDE_FUSED_FINALIZE")) h->env_no_fused = atoi(e) == 0;
+    }
     if (h->drift == 3) HIPCHK(h, hipMemset(h->bnd.p, 0, h->bnd.n * 8));      // (a part dumps its own block of a hand-over record; the check reads all of it)
     h->partial_doubles = (size_t)std::max(MAX_PARTS, CV_WAVES) * buf_chunks * std::max(NACC_MAX, 2 + CV_KC + 2) * G;
     if (h->cv_adj) h->partial_doubles = std::max(h->partial_doubles, (size_t)buf_chunks * adj_nacc(h->model, h->d, h->n_stream_cols, true) * G);

@@ -410,6 +410,71 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         a.quiet_ld = h->stat_ld;
         for (int j = 0; j < NDIRP; j++) a.quiet_gld[j] = h->stat_gld[j];
     }
+    // The finalising work inside the main launch (fused_finalize_wave, ssde_device.hpp): the shared-covariance kernel alone on the
+    // batch (no group on the general kernel, no drift columns); SSDE_FUSED_FINALIZE=0: the two-launch form (A/B -- bitwise the same)
+    const bool fused = h->use_shared && !h->drift && h->n_clean_groups == h->n_groups && !h->hess_req && h->fuse_words.p && !h->env_no_fused;
+    // the reduction's arguments: which accumulator of which part feeds which output slot (needed BEFORE the main launch when the
+    // finalising work is fused into it)
+    auto fill_ra = [&]() {
+        for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
+        if (h->use_shared) {
+            ra.add_slot[0] = 0;
+            if (order >= 1) {
+                const int pj[NDIRP] = {0, L.off_fe + L.fe_off[h->d], h->q > h->d + 1 ? L.off_fe + L.fe_off[h->d + 1] : 0};
+                for (int j = 0; j < NDIRP; j++)
+                    if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
+            }
+        }
+        const int nacc = h->cv_adj ? adj_nacc(h->model, h->d, h->n_stream_cols, a.cv_mu_cols != 0)
+                       : h->drift == 3 ? 2 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
+        const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
+        ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
+        ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
+        ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
+        if (order >= 1 && h->cv_adj) {
+            // accumulators of k_iso_adj.hip: [value | log sigma_obs | mu_a | par[d] | par[d + 1] | per streamed column: par[d], par[d + 1] (, mu_a)]
+            const int nkp = h->model == SSDE_MODEL_BM_SSM ? 1 : 2, nk = adj_nk(h->model, h->d, a.cv_mu_cols != 0);
+            if (!h->fixed[0] && !h->has_h) ra.map[0] = 1;
+            for (auto& sl : h->slots) {
+                if (h->fixed[sl.pidx]) continue;
+                const int kind = sl.par_j < h->d ? nkp + sl.par_j : sl.par_j - h->d;
+                const int k = sl.col >= 0 ? 4 + h->d + sl.col * nk + kind : (sl.par_j < h->d ? 2 + sl.par_j : 2 + h->d + (sl.par_j - h->d));
+                ra.map[k - 1] = (int16_t)(1 + sl.pidx);
+            }
+        } else
+        if (order >= 1 && h->drift == 3) {
+            // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d | log sigma_obs]
+            for (int p = 0; p < CV_WAVES; p++) {
+                for (int k = 0; k < CV_KC; k++) {
+                    const int pidx = h->cv_pidx[(size_t)p * CV_KC + k];
+                    if (pidx >= 0) ra.map[p * (nacc - 1) + k] = (int16_t)(1 + pidx);
+                }
+                if (p == h->cv_mu_part)
+                    for (auto& sl : h->slots)
+                        if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) ra.map[p * (nacc - 1) + CV_KC + sl.par_j] = (int16_t)(1 + sl.pidx);
+                if (p == h->cv_sig_part) ra.map[p * (nacc - 1) + CV_KC + h->d] = 1;
+            }
+        } else
+        if (order >= 1 && h->drift) {
+            // accumulators of k_iso_drift.hip: [value | sigma_obs | mu intercepts | par d | par d+1 | streamed columns]
+            if (!h->fixed[0]) ra.map[0] = 1;
+            for (auto& sl : h->slots) {
+                if (h->fixed[sl.pidx]) continue;
+                const int k = sl.col >= 0 ? 4 + h->d + sl.col : (sl.par_j < h->d ? 2 + sl.par_j : sl.par_j == h->d ? 2 + h->d : 3 + h->d);
+                ra.map[k - 1] = (int16_t)(1 + sl.pidx);
+            }
+        } else
+        if (order >= 1) {
+            for (int p = 0; p < a.n_parts; p++)
+                for (int k = 1; k < nacc; k++) {
+                    // accumulators are ordered like the constant-coefficient parameter vector: sigma_obs, one per SDE parameter
+                    const int j = k - 2;     // SDE parameter of accumulator k (k == 1: log_sigma_obs)
+                    if (j >= h->q) continue;
+                    const int pidx = j < 0 ? 0 : L.off_fe + L.fe_off[j];
+                    if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
+                }
+        }
+    };
     if (h->use_shared) {
         // two independent launches (NaN-free groups on the shared-covariance kernel, NaN-carrying groups on
         // the general kernel): fork onto a side stream so they share the chip, join before the hand-over check
@@ -456,7 +521,16 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             return SSDE_OK;
         }
         if (h->drift) HIPCHK(h, launch_iso_drift(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
-        else HIPCHK(h, launch_iso_shared(h->model, h->d, b, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+        else {
+            if (fused) {
+                fill_ra();
+                ra.kfast = 1;
+                b.fused = 1;
+                b.fuse_arrive = h->fuse_words.p + 4; b.fuse_done = h->fuse_words.p;
+                b.chk_out = (double*)(h->fuse_words.p + 2);         // (its own word, zero between launches: the last wave moves it to out[n_out])
+            }
+            HIPCHK(h, launch_iso_shared(h->model, h->d, b, ra, s, h->stamps ? h->ev_k0 : nullptr, h->stamps ? h->ev_k1 : nullptr));
+        }
         h->last_kernel_id = h->drift ? SSDE_KERNEL_ISO_DRIFT : any_dirty ? SSDE_KERNEL_ISO_MIXED : SSDE_KERNEL_ISO_SHARED;
         h->ev_k_valid = h->stamps;
         h->last_s_stat = h->drift ? -1 : (a.gain_last + SHARED_U - 1) / SHARED_U * SHARED_U;
@@ -510,66 +584,10 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
         h->last_s_stat = -1;
     }
     if (h->trace) { const double t = tick(); h->trace_us[2] += t - tk0; tk0 = t; }
-    for (int i = 0; i < 4; i++) { ra.add[i] = add[i]; ra.add_slot[i] = -1; }
-    if (h->use_shared) {
-        ra.add_slot[0] = 0;
-        if (order >= 1) {
-            const int pj[NDIRP] = {0, L.off_fe + L.fe_off[h->d], h->q > h->d + 1 ? L.off_fe + L.fe_off[h->d + 1] : 0};
-            for (int j = 0; j < NDIRP; j++)
-                if (pj[j] < L.n_full && !h->fixed[pj[j]] && (j < 2 || h->q > h->d + 1)) ra.add_slot[1 + j] = (int16_t)(1 + pj[j]);
-        }
-    }
-    const int nacc = h->cv_adj ? adj_nacc(h->model, h->d, h->n_stream_cols, a.cv_mu_cols != 0)
-                   : h->drift == 3 ? 2 + CV_KC + h->d : 4 + h->d + (h->drift ? h->n_stream_cols : 0);
-    const int ncr = (a.dual && a.n_chunks_d > a.n_chunks) ? a.n_chunks_d : a.n_chunks;     // windows the final sums run over
-    ra.n_parts = a.n_parts * ncr; ra.nacc = nacc; ra.n_blocks = h->n_groups;
-    ra.n_value_parts = ncr; ra.chunks_per_part = ncr;
-    ra.chk = h->chk.p; ra.n_chk = a.n_chunks > 1 ? a.n_parts * (a.n_chunks - 1) * h->n_groups : 0;
-    if (order >= 1 && h->cv_adj) {
-        // accumulators of k_iso_adj.hip: [value | log sigma_obs | mu_a | par[d] | par[d + 1] | per streamed column: par[d], par[d + 1] (, mu_a)]
-        const int nkp = h->model == SSDE_MODEL_BM_SSM ? 1 : 2, nk = adj_nk(h->model, h->d, a.cv_mu_cols != 0);
-        if (!h->fixed[0] && !h->has_h) ra.map[0] = 1;
-        for (auto& sl : h->slots) {
-            if (h->fixed[sl.pidx]) continue;
-            const int kind = sl.par_j < h->d ? nkp + sl.par_j : sl.par_j - h->d;
-            const int k = sl.col >= 0 ? 4 + h->d + sl.col * nk + kind : (sl.par_j < h->d ? 2 + sl.par_j : 2 + h->d + (sl.par_j - h->d));
-            ra.map[k - 1] = (int16_t)(1 + sl.pidx);
-        }
-    } else
-    if (order >= 1 && h->drift == 3) {
-        // accumulators of k_iso_colvar.hip, per part: [value | the part's columns | mu_1 .. mu_d | log sigma_obs]
-        for (int p = 0; p < CV_WAVES; p++) {
-            for (int k = 0; k < CV_KC; k++) {
-                const int pidx = h->cv_pidx[(size_t)p * CV_KC + k];
-                if (pidx >= 0) ra.map[p * (nacc - 1) + k] = (int16_t)(1 + pidx);
-            }
-            if (p == h->cv_mu_part)
-                for (auto& sl : h->slots)
-                    if (sl.par_j < h->d && sl.col < 0 && !h->fixed[sl.pidx]) ra.map[p * (nacc - 1) + CV_KC + sl.par_j] = (int16_t)(1 + sl.pidx);
-            if (p == h->cv_sig_part) ra.map[p * (nacc - 1) + CV_KC + h->d] = 1;
-        }
-    } else
-    if (order >= 1 && h->drift) {
-        // accumulators of k_iso_drift.hip: [value | sigma_obs | mu intercepts | par d | par d+1 | streamed columns]
-        if (!h->fixed[0]) ra.map[0] = 1;
-        for (auto& sl : h->slots) {
-            if (h->fixed[sl.pidx]) continue;
-            const int k = sl.col >= 0 ? 4 + h->d + sl.col : (sl.par_j < h->d ? 2 + sl.par_j : sl.par_j == h->d ? 2 + h->d : 3 + h->d);
-            ra.map[k - 1] = (int16_t)(1 + sl.pidx);
-        }
-    } else
-    if (order >= 1) {
-        for (int p = 0; p < a.n_parts; p++)
-            for (int k = 1; k < nacc; k++) {
-                // accumulators are ordered like the constant-coefficient parameter vector: sigma_obs, one per SDE parameter
-                const int j = k - 2;     // SDE parameter of accumulator k (k == 1: log_sigma_obs)
-                if (j >= h->q) continue;
-                const int pidx = j < 0 ? 0 : L.off_fe + L.fe_off[j];
-                if (pidx < L.n_full && !h->fixed[pidx]) ra.map[p * (nacc - 1) + (k - 1)] = (int16_t)(1 + pidx);
-            }
-    }
-    // the hand-over checks and the final sums in one launch
-    HIPCHK(h, launch_iso_finalize(h->model, h->d, a, ra, s));
+    if (!fused) fill_ra();
+    // the hand-over checks and the final sums in one launch (unless the main launch has done them)
+    if (!fused) HIPCHK(h, launch_iso_finalize(h->model, h->d, a, ra, s));
+    h->last_fused = fused;
     if (h->trace) {
         const double t = tick(); h->trace_us[3] += t - tk0; h->trace_n++;
         if (h->trace_skip < 8) {                        // the first calls load code objects: not what is being measured

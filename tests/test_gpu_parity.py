@@ -400,6 +400,29 @@ def test_time_windows_match_sequential_and_oracle(model, par, monkeypatch):
     eng.close(); seq.close()
 
 
+@pytest.mark.parametrize("model", ["CTCRW", "OU_SSM", "BM_SSM"])
+def test_fused_finalising_work_is_bitwise_the_two_launch_form(model, monkeypatch):
+    """SSDE_FUSED_FINALIZE=1: the hand-over checks by the second wave to arrive at a boundary and the fixed-order sums by the last wave
+    of iso_shared_kernel itself, instead of the dependent iso_finalize_kernel launch (the default: the fused form measured slower,
+    profiles/r05_fused_finalize_ab.txt) -- value, gradient and check value must be the same bits, evaluation after evaluation."""
+    ID, times, obs = simulate(model, 700, 3000, 2, seed=17)
+    pb = capi.Problem(model, ID, times, obs, par_fixed=[0, 1, 1, 0, 0][:1 + capi.n_sde_par(model, 2)])
+    q = capi.n_sde_par(model, 2)
+    pars = [np.r_[-1.0, 0.0, 0.0, 0.4, 0.1][:1 + q] + 0.01 * np.sin(k + np.arange(1 + q)) for k in range(4)]
+    two = capi.Engine(pb)
+    monkeypatch.setenv("SSDE_FUSED_FINALIZE", "1")
+    fused = capi.Engine(pb)
+    for p in pars + pars[:1]:
+        v2, g2 = two.eval(p)
+        vf, gf = fused.eval(p)
+        assert two.info()["kernel_id"] == 3 and fused.info()["kernel_id"] == 3 and two.info()["lanes_per_track"] > 1
+        assert vf == v2 and np.array_equal(gf, g2)
+        assert fused.info()["window_check"] == two.info()["window_check"] <= capi.WINDOW_TOL
+        two.forget(); fused.forget()
+    _close(vf, gf, *_oracle(pb, pars[0]))
+    two.close(); fused.close()
+
+
 def test_short_overlap_is_detected_and_repaired(monkeypatch):
     """A deliberately useless warm-up (4 rows) must fail the hand-over check and be repaired by
     ssde_eval (longer overlap, finally one sequential window) -- never returned silently."""
