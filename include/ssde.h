@@ -137,11 +137,13 @@ enum {
 #define SSDE_FLAG_FORCE_DENSE   0x2u /* disable the isotropic register path (testing the dense path)         */
 #define SSDE_FLAG_NO_UNIFORM_DT 0x4u /* disable hoisting of the transition matrices on a regular time grid    */
 #define SSDE_FLAG_EXACT_HESS    0x8u /* the caller will ask for exact second derivatives (ssde_hess, ssde_laplace_eval): a state-space
-                                        batch with row-varying coefficients that ssde_create puts on the lane = track register kernels
-                                        (k_iso_colvar.hip, the general lanes of k_iso_drift.hip -- first-order kernels) gets a second,
-                                        lane = direction copy of its rows for the second-order pass (k_tv_hess.hip): ~0.5 KB of HBM per
-                                        row on top of the tiles.  Without the flag such a handle answers SSDE_ERR_MODEL and the
-                                        Laplace layer differences the gradient.  Single device. */
+                                        batch (H = sigma_obs^2 I) that ssde_create puts on the lane = track register kernels -- constant
+                                        coefficients, a smooth drift, row-varying tau / nu: first-order kernels -- gets a second,
+                                        lane = direction copy of its rows for the second-order pass (k_tv_hess.hip): ~0.64 KB of HBM
+                                        per row on top of the tiles, kept only when that is at most a third of the device memory still
+                                        free (ssde_info.exact_hess_scope tells).  Without the flag (or the copy) such a handle answers
+                                        SSDE_ERR_MODEL and the Laplace layer differences the gradient.  Every track shard of a
+                                        multi-device handle keeps its own copy; the ranks of a communicator sum theirs. */
 
 /* A random-effect design block given as a FUNCTION of one covariate instead of as n x K numbers: a piecewise-cubic
  * table (regression-spline bases -- mgcv "cr", "cs", "bs", "ps" -- are exactly that; thin-plate bases are not and
@@ -276,7 +278,8 @@ typedef struct ssde_info_t {
                                (found at ssde_create; 0 when the layout has no such wavefront or the grid is irregular) */
     int32_t comm_ranks_reported; /* what ncclCommCount says about the joined communicator (0 = none joined); comm_ranks above
                                echoes the caller's argument -- ABI 10 */
-    int32_t reserved2_;
+    int32_t exact_hess_scope; /* what ssde_hess is exact over on this handle: 0 nothing (difference the gradient), 1 the drift coefficients
+                                 (+ log_lambda), 2 every coefficient of a direct family (+ log_lambda), 3 every free entry (was reserved: 0) */
 } ssde_info_t;
 
 /* Create an engine: validates the descriptor, finds the ID segments, uploads the

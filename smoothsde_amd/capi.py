@@ -94,7 +94,7 @@ class SsdeInfo(C.Structure):
         ("n_devices", C.c_int32), ("comm_ranks", C.c_int32), ("window_check_max", C.c_double),
         ("n_rows_tiled", C.c_int64), ("n_groups", C.c_int32), ("n_clean_groups", C.c_int32),
         ("quiet_window", C.c_int32), ("kernel_id", C.c_int32), ("quiet_share", C.c_double),
-        ("comm_ranks_reported", C.c_int32), ("reserved2_", C.c_int32),
+        ("comm_ranks_reported", C.c_int32), ("exact_hess_scope", C.c_int32),
     ]
 
     def as_dict(self):
@@ -701,8 +701,11 @@ class Engine:
         self._check(self.lib.ssde_comm_allreduce(self._h, C.c_void_p(buf_ptr), int(count), C.c_void_p(stream)))
 
     def hess(self, par, idx):
-        """ssde_hess: exact second derivatives of the joint penalised nllk over the full-parameter indices `idx` (direct
-        families BM / OU; EngineError with status 2 elsewhere).  Returns an (len(idx), len(idx)) array."""
+        """ssde_hess: exact second derivatives of the joint penalised nllk over the full-parameter indices `idx` -- what
+        info()["exact_hess_scope"] says: 3 every free entry (state-space models with H = sigma_obs^2 I on the lane = direction path,
+        or created with FLAG_EXACT_HESS: constant or row-varying coefficients, track shards and communicator ranks summed),
+        2 the coefficients of the direct families BM / OU (+ log_lambda), 1 the drift coefficients of a smooth-drift state-space
+        batch (+ log_lambda), 0 nothing: EngineError with status 2, difference the gradient.  Returns an (len(idx), len(idx)) array."""
         par = np.ascontiguousarray(par, dtype=np.float64)
         ix = np.ascontiguousarray(idx, dtype=np.int32)
         H = np.zeros((len(ix), len(ix)), order="F")

@@ -256,16 +256,7 @@ int ssde_create(const ssde_desc* desc, ssde_handle** out) {
         destroy(h);
         return st;
     }
-    if (!sharded && (desc->flags & SSDE_FLAG_EXACT_HESS) && h->path == PATH_ISO && (h->drift == 2 || h->drift == 3) && !h->has_h) {
-        // the rows a second time, in the layout the second-order kernels read (ssde_hess.hip: hess_tv_device)
-        ssde_handle* c = new (std::nothrow) ssde_handle();
-        if (c) {
-            c->force_tv = true;
-            const int stc = build(desc, c);
-            if (stc == SSDE_OK && c->path == PATH_TV && !c->tv_dense) h->hess_companion = c;
-            else destroy(c);                                 // (not exact there either: ssde_hess says so when asked)
-        }
-    }
+    if (!sharded) attach_hess_companion(desc, h);
     *out = h;
     return SSDE_OK;
 }
@@ -557,6 +548,27 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
 
 }  // namespace
 
+namespace ssde_engine {
+// SSDE_FLAG_EXACT_HESS: a state-space handle whose own kernels are first-order only -- every register-path (lane = track) handle with
+// H = sigma_obs^2 I: constant coefficients, a smooth drift, row-varying tau / nu -- keeps its rows a second time in the layout the
+// second-order lanes read (the lane = direction path, k_tv_hess.hip), and ssde_hess / ssde_laplace_eval take exact second derivatives
+// from there.  ~(TV_RS + 64) x 8 bytes per row: built only when that is at most a third of the device memory still free (a fit of
+// 10^8 rows keeps differencing its gradient instead and ssde_info.exact_hess_scope says so).
+void attach_hess_companion(const ssde_desc* desc, ssde_handle* h) {
+    if (!(desc->flags & SSDE_FLAG_EXACT_HESS) || h->path != PATH_ISO || h->has_h) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(h->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const double need = (double)h->n * (TV_RS + 64) * 8.0;
+    if (need > (double)free_b / 3.0) return;
+    ssde_handle* c = new (std::nothrow) ssde_handle();
+    if (!c) return;
+    c->force_tv = true;
+    const int stc = build(desc, c);
+    if (stc == SSDE_OK && c->path == PATH_TV && !c->tv_dense) h->hess_companion = c;
+    else destroy(c);                                     // (not exact there either: ssde_hess says so when asked)
+}
+}  // namespace ssde_engine
+
 extern "C" {
 
 int ssde_eval(ssde_handle* h, const double* par, int32_t n_par_full, int32_t order, double* value, double* grad) {
@@ -815,6 +827,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
         info->window_check = h->last_check; info->window_retries = h->n_retries; info->window_check_max = h->check_max;
         info->n_memo_hits = h->n_memo_hits;
         info->n_devices = h->n_track_shards; info->comm_ranks = h->comm_ranks; info->comm_ranks_reported = h->comm_ranks_reported;
+        info->exact_hess_scope = hess_exact_scope(h);
         return SSDE_OK;
     }
     info->n_par_full = h->L.n_full;
@@ -853,6 +866,7 @@ int ssde_info(const ssde_handle* h, ssde_info_t* info) {
     info->n_evals = h->n_evals; info->n_memo_hits = h->n_memo_hits;
     info->n_devices = 1; info->comm_ranks = h->comm_ranks; info->window_check_max = h->check_max;
     info->comm_ranks_reported = h->comm_ranks_reported; info->kernel_id = h->last_kernel_id;
+    info->exact_hess_scope = hess_exact_scope(h);
     if (h->path == PATH_ISO)   // 4-wave workgroups; with a transient window the grid enumerates windows 1.. only
         info->n_kernel_blocks = ((h->n_groups + 7) / 8 * 8 * h->iso_parts * ((h->use_shared && h->last_t0 > 0) ? h->last_chunks - 1 : h->last_chunks) + WG_WAVES - 1) / WG_WAVES;
     else if (h->path == PATH_DENSE) info->n_kernel_blocks = h->n_groups * h->n_dirblocks;

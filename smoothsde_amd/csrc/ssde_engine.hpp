@@ -342,6 +342,7 @@ int fail(ssde_handle* h, int code, const std::string& msg);
 // ssde_engine_build.hip
 int build(const ssde_desc* d, ssde_handle* h, const ParLayout* part_layout = nullptr);
 void destroy(ssde_handle* h);
+void attach_hess_companion(const ssde_desc* desc, ssde_handle* h);     // SSDE_FLAG_EXACT_HESS (ssde_engine.hip)
 void release_device(ssde_handle* h);          // everything the handle holds on the device / in pinned memory (the handle stays)
 int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipStream_t s, ReduceArgs& ra);   // ssde_engine_iso.hip
 // spectral radius of the stationary closed-loop matrix T - K Z at constant parameters p1, p2 (ssde_engine_tv.hip); p0 = {p11, p12, p22} or {p}

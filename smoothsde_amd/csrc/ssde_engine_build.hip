@@ -846,8 +846,10 @@ static int build_impl(const ssde_desc* d, ssde_handle* h, const ParLayout* part_
         // ---- Kalman families: pick the path, then tile ------------------------------------------------
         for (int i = 0; i < h->sdim; i++)
             for (int j = 0; j < h->sdim; j++) h->p0_full[i + j * h->sdim] = p0_entry(d, i, j);
+        // (force_tv: the companion of SSDE_FLAG_EXACT_HESS -- the lane = direction path whatever the design, constant coefficients
+        //  included: their intercepts are directions like any other there)
         const bool iso_ok = h->d <= 2 && !h->has_h && h->const_coeff && p0_is_isotropic(d, h->p0_iso) &&
-                            !(d->flags & SSDE_FLAG_FORCE_DENSE);
+                            !(d->flags & SSDE_FLAG_FORCE_DENSE) && !h->force_tv;
         h->path = iso_ok ? PATH_ISO : PATH_DENSE;
         // Row-varying DRIFT only (design columns in the rows of mu_1 .. mu_d, everything else constant), many tracks: the
         // register path with the design columns streamed next to the observations (k_iso_drift.hip) -- on a regular grid with

@@ -257,6 +257,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
             if (P == 1) {
                 parent->shard_col0.push_back(0);
                 st = build(&sd, sh);
+                if (st == SSDE_OK) attach_hess_companion(&sd, sh);      // (SSDE_FLAG_EXACT_HESS: every track shard keeps its own second copy)
             } else {
                 // ---- dimension part p: response columns [dlo, dlo + cnt), SDE parameters mu_dlo.., then the shared ones ------
                 const int dlo = 2 * p, cnt = std::min(2, D - dlo), qc = cnt + n_shared;

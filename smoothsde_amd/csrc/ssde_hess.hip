@@ -18,32 +18,31 @@
 
 namespace ssde_engine {
 
-int hess_exact_scope(const ssde_handle* h) {
-    const ssde_handle* e = h->shards.empty() ? h : h->shards[0];
-    if (h->n_dim_parts > 1 || e->env_no_exact_hess) return 0;
+// one engine by itself: 3 = every free entry (hyper-dual lanes, k_tv_hess.hip -- its own rows or those of its companion),
+// 2 = the coefficients of a direct family (k_direct_hess.hip), 1 = the drift coefficients of a shared-covariance batch, 0 = none
+static int scope_one(const ssde_handle* e) {
+    if (e->env_no_exact_hess) return 0;
     // SSDE_FLAG_EXACT_HESS: the same rows on the lane = direction path next to a handle whose own kernels are first-order only
-    if (h->hess_companion && h->shards.empty() && h->comms.empty()) return hess_exact_scope(h->hess_companion);
+    if (e->hess_companion) return scope_one(e->hess_companion);
     if (e->path == PATH_TV) {
-        // row-varying coefficients on the isotropic lane = direction path: second-order forward mode over coefficient pairs
-        // (k_tv_hess.hip).  Not the full-covariance lanes (per-row H_array, general P0), not ESEAL_SSM; single engine.
-        if (!h->shards.empty() || !h->comms.empty() || e->tv_dense || is_eseal(e->model)) return 0;
-        return 3;
+        // row-varying (or, as the companion of a constant-coefficient handle, intercept-only) coefficients on the isotropic lane =
+        // direction path: second-order forward mode over coefficient pairs.  Not the full-covariance lanes, not ESEAL_SSM.
+        return (e->tv_dense || is_eseal(e->model)) ? 0 : 3;
     }
-    if (e->path == PATH_ISO) {
-        // a smooth drift on the shared-covariance lanes: the data term is QUADRATIC in the drift coefficients (k_iso_drift.hip)
-        if (e->drift != 1) return 0;
-        for (const ssde_handle* s : h->shards) if (s->path != PATH_ISO || s->drift != 1) return 0;
-        return 1;
-    }
+    if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
     if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
-    for (const ssde_handle* s : h->shards) if (s->path != PATH_DIRECT) return 0;
-    auto resident = [](const ssde_handle* g) {
-        for (auto& sl : g->slots) if (sl.col == -2) return false;          // a block evaluated from its basis table has no columns to read
-        return true;
-    };
-    if (h->shards.empty()) return resident(h) ? 2 : 0;
-    for (const ssde_handle* s : h->shards) if (!resident(s)) return 0;
+    for (auto& sl : e->slots) if (sl.col == -2) return 0;           // a block evaluated from its basis table has no columns to read
     return 2;
+}
+
+int hess_exact_scope(const ssde_handle* h) {
+    if (h->n_dim_parts > 1) return 0;
+    if (h->shards.empty()) return scope_one(h);
+    // whole-track shards over several devices: the batch's Hessian is the sum of the shards' (tracks are independent,
+    // nllk_ctcrw.hpp:196-200, 234) -- if every shard has one of the same kind
+    const int s0 = scope_one(h->shards[0]);
+    for (const ssde_handle* s : h->shards) if (scope_one(s) != s0) return 0;
+    return s0;
 }
 
 // scratch of a Hessian pass, kept in the handle between calls: three small index arrays (one upload), partials, the result
@@ -227,7 +226,7 @@ static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<i
 // H (n_idx x n_idx, column-major, host) of the joint penalised nllk over the full-parameter indices idx[]
 int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H) {
     const int scope = hess_exact_scope(h);
-    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms), for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows, and for every free parameter of a state-space model with row-varying coefficients on the isotropic lane = direction path"; return SSDE_ERR_MODEL; }
+    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms), for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows, and for every free parameter of a state-space model (constant or row-varying coefficients, H = sigma_obs^2 I, block-identical P0) evaluated on the isotropic lane = direction path or created with SSDE_FLAG_EXACT_HESS"; return SSDE_ERR_MODEL; }
     const ParLayout& L = h->L;
     const int np = L.n_full;
     for (int k = 0; k < n_idx; k++)
@@ -257,18 +256,44 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
     const int nu = (int)cidx.size();
     if (nu > MAX_COLS) { h->err = "ssde_hess: more than 96 coefficients"; return SSDE_ERR_ARG; }
     if (nu > 0 && scope == 3) {
-        // every requested entry must be one of the handle's gradient directions (a free parameter that reaches the data term)
-        ssde_handle* t = h->hess_companion ? h->hess_companion : h;
-        std::vector<int> dk(nu);
-        for (int k = 0; k < nu; k++) {
-            dk[k] = t->tv_dir_of_par[cidx[k]];
-            if (dk[k] < 0) { h->err = "ssde_hess: an entry held fixed (par_fixed) has no second derivatives on the row-varying path"; return SSDE_ERR_MODEL; }
+        // every requested entry must be one of the handle's gradient directions (a free parameter that reaches the data term);
+        // shards / ranks: the sum of theirs
+        std::vector<double> Hsum((size_t)nu * nu, 0.0), Hd;
+        auto one = [&](ssde_handle* e) -> int {
+            ssde_handle* t = e->hess_companion ? e->hess_companion : e;
+            std::vector<int> dk(nu);
+            for (int k = 0; k < nu; k++) {
+                dk[k] = t->tv_dir_of_par[cidx[k]];
+                if (dk[k] < 0) { h->err = "ssde_hess: an entry held fixed (par_fixed) has no second derivatives on the row-varying path"; return SSDE_ERR_MODEL; }
+            }
+            int st = hess_tv_device(t, par, dk, Hd);
+            if (st) { h->err = t->err; return st; }
+            for (size_t k = 0; k < Hsum.size(); k++) Hsum[k] += Hd[k];
+            return SSDE_OK;
+        };
+        if (h->shards.empty()) {
+            int st = one(h);
+            if (st) return st;
+            if (!h->comms.empty()) {
+                // ranks of a communicator: every rank calls ssde_hess (a collective, like ssde_eval)
+                HIPCHK(h, hipSetDevice(h->device));
+                if (h->hs_hess.n < Hsum.size()) { h->hs_hess.release(); HIPCHK(h, h->hs_hess.alloc(std::max<size_t>(Hsum.size(), 1024))); }
+                HIPCHK(h, hipMemcpy(h->hs_hess.p, Hsum.data(), Hsum.size() * 8, hipMemcpyHostToDevice));
+                ncclResult_t r = rccl().AllReduce(h->hs_hess.p, h->hs_hess.p, Hsum.size(), ncclDouble, ncclSum, (ncclComm_t)h->comms[0], 0);
+                if (r != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + rccl().GetErrorString(r); return SSDE_ERR_HIP; }
+                HIPCHK(h, hipMemcpy(Hsum.data(), h->hs_hess.p, Hsum.size() * 8, hipMemcpyDeviceToHost));
+            }
+        } else {
+            int dev_before = 0;
+            (void)hipGetDevice(&dev_before);
+            for (ssde_handle* sh : h->shards) {
+                int st = one(sh);
+                if (st) { (void)hipSetDevice(dev_before); return st; }
+            }
+            (void)hipSetDevice(dev_before);
         }
-        std::vector<double> Hd;
-        int st = hess_tv_device(t, par, dk, Hd);
-        if (st) { if (t != h) h->err = t->err; return st; }
         for (int a = 0; a < nu; a++)
-            for (int b = 0; b < nu; b++) H[cpos[a] + (size_t)cpos[b] * n_idx] = Hd[a + (size_t)b * nu];
+            for (int b = 0; b < nu; b++) H[cpos[a] + (size_t)cpos[b] * n_idx] = Hsum[a + (size_t)b * nu];
     } else
     if (nu > 0) {
         std::vector<double> Hd((size_t)nu * nu, 0.0), tmp((size_t)nu * nu);

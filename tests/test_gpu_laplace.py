@@ -445,3 +445,58 @@ def test_exact_hessians_for_batches_on_the_lane_track_kernels(kind, monkeypatch)
     assert abs(f1 - f0) <= 1e-7 * max(1.0, abs(f0)) and np.max(np.abs(gm1[io] - gm0[io])) <= 1e-3 * max(1.0, np.max(np.abs(gm0[io])))
     assert n1 < n0, (n1, n0)
     e0.close(); e1.close(); e2.close()
+
+
+# ---- ... for CONSTANT-coefficient state-space handles, track shards and the ranks of a communicator -------------
+CONST_KALMAN = ["CTCRW_d2_const", "CTCRW_d1_const_regular_fixmu", "OU_SSM_d2_const", "OU_SSM_d1_const", "BM_SSM_d1_const", "BM_SSM_d2_const"]
+
+
+@pytest.mark.parametrize("name", [n for n in CONST_KALMAN if n in GOLD])
+def test_exact_hessian_of_constant_coefficient_state_space_models_matches_autograd(name):
+    """tmb_obj_joint$he(x) is AD-exact for every model (R/sde.R:1363); the constant-coefficient register kernels carry first-order
+    sensitivities only.  With SSDE_FLAG_EXACT_HESS the handle keeps its rows on the lane = direction path too -- the intercepts are
+    directions like any other there -- and ssde_hess is exact over every free entry; without the flag it says so (status 2)."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k]]
+    e0 = capi.Engine(pb)
+    assert e0.info()["path"] == 1 and e0.info()["exact_hess_scope"] == 0
+    with pytest.raises(capi.EngineError) as ei:
+        e0.hess(par, idx)
+    assert ei.value.status == 2
+    pb.flags |= capi.FLAG_EXACT_HESS
+    eng = capi.Engine(pb)
+    assert eng.info()["path"] == 1 and eng.info()["exact_hess_scope"] == 3
+    v0, g0 = e0.eval(par)
+    v1, g1 = eng.eval(par)
+    assert v0 == v1 and np.array_equal(g0, g1)                  # the evaluation is the register kernels', unchanged
+    H = eng.hess(par, idx)
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
+    assert np.max(np.abs(H - H.T)) == 0.0
+    assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
+    e0.close(); eng.close()
+
+
+@pytest.mark.parametrize("name", ["CTCRW_d2_tv", "OU_SSM_d1_tv", "CTCRW_d2_const"])
+def test_exact_hessian_over_track_shards_and_a_one_rank_communicator(name):
+    """Whole-track shards of a multi-device handle (here: two shards on one device, the rehearsal mode) and the ranks of a
+    communicator sum their Hessians -- tracks are independent (nllk_ctcrw.hpp:196-200, 234)."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    if pb.n_seg < 2:
+        pytest.skip("one track: nothing to shard")
+    pb.flags |= capi.FLAG_EXACT_HESS
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k]]
+    one = capi.Engine(pb)
+    H = one.hess(par, idx)
+    two = capi.Engine(pb, devices=[0, 0])
+    assert two.info()["exact_hess_scope"] == 3
+    H2 = two.hess(par, idx)
+    assert np.max(np.abs(H2 - H)) <= 1e-11 * np.max(np.abs(H)), np.max(np.abs(H2 - H)) / np.max(np.abs(H))
+    comm = capi.Engine(pb)
+    comm.comm_init(1, 0, capi.comm_unique_id())
+    Hc = comm.hess(par, idx)
+    assert np.max(np.abs(Hc - H)) <= 1e-13 * np.max(np.abs(H))
+    one.close(); two.close(); comm.close()
