@@ -18,6 +18,7 @@
 #include "ssde_device.hpp"
 #include "ssde_hdual.hpp"
 #include "ssde_tv.hpp"
+#include "ssde_dense.hpp"
 
 namespace ssde {
 
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(256) void hess_prepare_kernel(const TvHessArgs A) {
 #pragma unroll
         for (int a = 0; a < 2; a++) r[5 + a] = a < D ? A.obs[i + (int64_t)a * A.n] : 0.0;
         r[7] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[8 + k] = (A.has_h && k < D * D) ? A.h_array[i * (D * D) + k] : 0.0;   // H_array[,,i]
     }
 }
 
@@ -132,15 +135,66 @@ struct HessLane {                                  // OU_SSM / BM_SSM
     }
 };
 
+// Full-covariance lanes (per-row H_array, nllk_ctcrw.hpp:203-205, and / or a P0 that is not block-identical, R/sde.R:552-557,
+// 582-587): the general step of ssde_dense.hpp -- the text the first-order lanes run in DualN -- in hyper-dual arithmetic.  sd + sd^2
+// hyper-dual numbers of state (80 doubles for CTCRW with two response columns): the kernel spills; a Hessian is asked for once
+// per outer iteration of a fit.
+template <int MODEL, int D>
+struct HessLaneDense {
+    static constexpr int SD = DenseDims<MODEL, D>::SD;
+    static constexpr int NSTATE = 4 * (SD + SD * SD);
+    static constexpr int Q = DenseDims<MODEL, D>::Q;
+    struct State { HD a[SD]; HD P[SD][SD]; HD nll; } S;
+    bool has_h;
+    __device__ __forceinline__ void init(const double* a0, const double* p0f) {
+        for (int i = 0; i < SD; i++) {
+            S.a[i] = HD(a0[i]);
+            for (int j = 0; j < SD; j++) S.P[i][j] = HD(p0f[i + j * SD]);
+        }
+        S.nll = HD(0.0);
+    }
+    __device__ __forceinline__ void warm_init(const double* y, const double* p0f) {
+        double a0[SD];
+        for (int c = 0; c < SD; c++) a0[c] = 0.0;
+        for (int a = 0; a < D; a++) a0[DenseDims<MODEL, D>::z(a)] = (y[a] == y[a]) ? y[a] : 0.0;
+        init(a0, p0f);
+    }
+    __device__ __forceinline__ void step(const double* r, const HD& h, const PairSeed& sd, double wa, double wb, int any_nan) {
+        HD p[Q];
+        for (int j = 0; j < Q; j++) {
+            const bool ma = (j < D) ? (sd.kind_a == TVK_MU && sd.dim_a == j) : (j == D ? sd.kind_a == TVK_P1 : sd.kind_a == TVK_P2);
+            const bool mb = (j < D) ? (sd.kind_b == TVK_MU && sd.dim_b == j) : (j == D ? sd.kind_b == TVK_P1 : sd.kind_b == TVK_P2);
+            p[j] = HD(r[1 + j], ma ? wa : 0.0, mb ? wb : 0.0, 0.0);
+        }
+        HD H[D][D];
+        for (int i = 0; i < D; i++)
+            for (int j = 0; j < D; j++) H[i][j] = has_h ? HD(r[8 + i + j * D]) : (i == j ? h : HD(0.0));       // H_array[,,i] holds no parameter
+        double y[D];
+        for (int a = 0; a < D; a++) y[a] = r[5 + a];
+        dense_step_g<MODEL, D, HD>(S, p, H, r[0], y, is_na(y[0], any_nan));
+    }
+    __device__ __forceinline__ void dump(double* o) const {
+        int k = 0;
+        auto put = [&](const HD& z) { o[k++] = z.v; o[k++] = z.a; o[k++] = z.b; o[k++] = z.ab; };
+        for (int i = 0; i < SD; i++) put(S.a[i]);
+        for (int i = 0; i < SD; i++)
+            for (int j = 0; j < SD; j++) put(S.P[i][j]);
+    }
+};
+template <int MODEL, int D, bool DENSE>
+struct HessLaneSel { typedef HessLane<MODEL, D> type; };
+template <int MODEL, int D>
+struct HessLaneSel<MODEL, D, true> { typedef HessLaneDense<MODEL, D> type; };
+
 constexpr int HESS_U = 2;          // rows per prefetch block of the lane's two weights
 
 // One wave = one (track, window, block of 64 pairs).  The row record is the same for every lane (one track per wave): it is
 // read through a wave-uniform pointer -- scalar loads, scalar registers -- and only the two design-matrix entries of the
 // lane's pair are vector loads, prefetched one block of rows ahead.  The row loop is NOT unrolled beyond that block: a row is
 // ~10^3 instructions of hyper-dual arithmetic, and the registers are better spent on the state than on a second copy of it.
-template <int MODEL, int D>
+template <int MODEL, int D, bool DENSE>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void hess_filter_kernel(const TvHessArgs A) {
-    typedef HessLane<MODEL, D> Lane;
+    typedef typename HessLaneSel<MODEL, D, DENSE>::type Lane;
     constexpr int SD = (MODEL == M_CTCRW) ? 2 * D : D;
     const int item = blockIdx.x * WG_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // one work item per WAVE, no barriers
     if (item >= A.n_items) return;
@@ -162,14 +216,15 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void hess_filter_kernel(const T
     const double sa = (da.kind == TVK_SIG) ? 2.0 : 0.0, sb = (db.kind == TVK_SIG) ? 2.0 : 0.0;
     const HD h(h0, sa * h0, sb * h0, sa * sb * h0);
     const int64_t imax = A.n - 1;
-    double p0[3];
+    double p0[DENSE ? 16 : 3];                                  // (the full-covariance lanes: P0 as given, sd x sd)
 #pragma unroll
-    for (int q = 0; q < 3; q++) p0[q] = A.p0[q];
+    for (int q = 0; q < (DENSE ? 16 : 3); q++) p0[q] = DENSE ? A.p0_full[q] : A.p0[q < 3 ? q : 0];
     const double* wpa = A.wdir + ka;
     const double* wpb = A.wdir + kb;
     auto row_of = [&](int s) { const int64_t i = row0 + 1 + s; return i < imax ? i : imax; };     // (look-ahead rows stay inside the buffers)
 
     Lane S;
+    if constexpr (DENSE) S.has_h = A.has_h != 0;
     if (s_begin == 0) {
         double a0[SD];
 #pragma unroll
@@ -271,8 +326,13 @@ hipError_t launch_tv_hess(const TvHessArgs& a, hipStream_t s) {
 #define SSDE_HESS_ONE(MODEL, D)                                                                              \
     if (a.model == MODEL && a.d == D) {                                                                      \
         hipLaunchKernelGGL((hess_prepare_kernel<MODEL, D>), dim3(pblocks), dim3(256), 0, s, a);              \
-        hipLaunchKernelGGL((hess_filter_kernel<MODEL, D>), grid, block, 0, s, a);                            \
-        nstate = HessLane<MODEL, D>::NSTATE;                                                                 \
+        if (a.dense) {                                                                                       \
+            hipLaunchKernelGGL((hess_filter_kernel<MODEL, D, true>), grid, block, 0, s, a);                  \
+            nstate = HessLaneDense<MODEL, D>::NSTATE;                                                        \
+        } else {                                                                                             \
+            hipLaunchKernelGGL((hess_filter_kernel<MODEL, D, false>), grid, block, 0, s, a);                 \
+            nstate = HessLane<MODEL, D>::NSTATE;                                                             \
+        }                                                                                                    \
     }
     SSDE_HESS_ONE(M_CTCRW, 1) SSDE_HESS_ONE(M_CTCRW, 2) SSDE_HESS_ONE(M_OU_SSM, 1) SSDE_HESS_ONE(M_OU_SSM, 2)
     SSDE_HESS_ONE(M_BM_SSM, 1) SSDE_HESS_ONE(M_BM_SSM, 2)

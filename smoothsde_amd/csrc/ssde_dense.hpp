@@ -56,8 +56,8 @@ template <int N> SSDE_HD DualN<N> dfabs(const DualN<N>& a) { return a.v < 0.0 ? 
 // ---- d x d helpers for responses wider than two columns (n_dim = 3, 4 with a measurement covariance or a P0 that couples the
 // columns): what Eigen's F.inverse() and TMB's atomic::logdet do in the reference (nllk_ctcrw.hpp:12-24, 231, 236) -- Gaussian
 // elimination with partial pivoting on the VALUES, carried out in dual arithmetic so the tangents follow
-template <int D, int N>
-SSDE_HD void dense_lu(const DualN<N> (&F)[D][D], DualN<N> (&LU)[D][D], int (&piv)[D], int& sign) {
+template <int D, class T_>
+SSDE_HD void dense_lu(const T_ (&F)[D][D], T_ (&LU)[D][D], int (&piv)[D], int& sign) {
     for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) LU[i][j] = F[i][j];
     sign = 1;
     for (int k = 0; k < D; k++) {
@@ -69,38 +69,38 @@ SSDE_HD void dense_lu(const DualN<N> (&F)[D][D], DualN<N> (&LU)[D][D], int (&piv
             sign = -sign;
             for (int j = 0; j < D; j++) {
                 // (static indices only: a select per candidate row keeps the matrix in registers on the device)
-                DualN<N> a = LU[k][j], b = LU[k][j];
+                T_ a = LU[k][j], b = LU[k][j];
                 for (int i = k + 1; i < D; i++) if (i == p) b = LU[i][j];
                 LU[k][j] = b;
                 for (int i = k + 1; i < D; i++) if (i == p) LU[i][j] = a;
             }
         }
-        const DualN<N> ip = 1.0 / LU[k][k];
+        const T_ ip = 1.0 / LU[k][k];
         for (int i = k + 1; i < D; i++) {
             LU[i][k] = LU[i][k] * ip;
             for (int j = k + 1; j < D; j++) LU[i][j] = LU[i][j] - LU[i][k] * LU[k][j];
         }
     }
 }
-template <int D, int N>
-SSDE_HD DualN<N> dense_det_lu(const DualN<N> (&F)[D][D]) {
-    DualN<N> LU[D][D];
+template <int D, class T_>
+SSDE_HD T_ dense_det_lu(const T_ (&F)[D][D]) {
+    T_ LU[D][D];
     int piv[D], sign;
-    dense_lu<D, N>(F, LU, piv, sign);
-    DualN<N> det((double)sign);
+    dense_lu<D, T_>(F, LU, piv, sign);
+    T_ det((double)sign);
     for (int k = 0; k < D; k++) det = det * LU[k][k];
     return det;
 }
-template <int D, int N>
-SSDE_HD void dense_inverse_lu(const DualN<N> (&F)[D][D], DualN<N> (&Fi)[D][D]) {
-    DualN<N> LU[D][D];
+template <int D, class T_>
+SSDE_HD void dense_inverse_lu(const T_ (&F)[D][D], T_ (&Fi)[D][D]) {
+    T_ LU[D][D];
     int piv[D], sign;
-    dense_lu<D, N>(F, LU, piv, sign);
+    dense_lu<D, T_>(F, LU, piv, sign);
     for (int c = 0; c < D; c++) {
-        DualN<N> x[D];
-        for (int i = 0; i < D; i++) x[i] = DualN<N>(i == c ? 1.0 : 0.0);
+        T_ x[D];
+        for (int i = 0; i < D; i++) x[i] = T_(i == c ? 1.0 : 0.0);
         for (int k = 0; k < D; k++) {                                // the row interchanges, in order
-            DualN<N> a = x[k], b = x[k];
+            T_ a = x[k], b = x[k];
             for (int i = k + 1; i < D; i++) if (i == piv[k]) b = x[i];
             x[k] = b;
             for (int i = k + 1; i < D; i++) if (i == piv[k]) x[i] = a;
@@ -138,10 +138,11 @@ struct DenseLane {
 
 // One row: par[] = the row's linear predictors (working scale) as duals, H = observation
 // covariance (d x d, row-major here), dt = interval after the row, y = observation, na = obs(i,0) NA.
-template <int MODEL, int D, int N>
-SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const DualN<N> (&H)[D][D], double dt,
-                        const double* y, bool na) {
-    typedef DualN<N> T_;
+// Generic in the number type T_ (DualN<N>: first-order tangents; HD, ssde_hdual.hpp: the hyper-dual numbers of the exact Hessian):
+// T_ needs + - * / with itself and with double, dexp / dlog / dsqrt / dfabs, a constructor from double and a member v (the value).
+// L: the lane's state -- members a[SD], P[SD][SD], nll of type T_.
+template <int MODEL, int D, class T_, class ST>
+SSDE_HD void dense_step_g(ST& L, const T_* par, const T_ (&H)[D][D], double dt, const double* y, bool na) {
     typedef DenseDims<MODEL, D> DM;
     constexpr int SD = DM::SD;
 
@@ -230,7 +231,7 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
             for (int j = 0; j < D; j++) F[i][j] = L.P[DM::z(i)][DM::z(j)] + H[i][j];   // F = Z P Z' + H
         if (D == 1) det = F[0][0];
         else if (D == 2) det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                    // det(): nllk_ctcrw.hpp:16-19
-        else det = dfabs(dense_det_lu<D, N>(F));                                         // det = exp(atomic::logdet(F)) = |det F|: nllk_ctcrw.hpp:20-22
+        else det = dfabs(dense_det_lu<D, T_>(F));                                         // det = exp(atomic::logdet(F)) = |det F|: nllk_ctcrw.hpp:20-22
         // CTCRW tests det <= 0; OU/BM take exp(logdet) = |det|, which fails the test only at 0
         upd = (MODEL == M_CTCRW) ? !(det.v <= 0.0) : !(fabs(det.v) <= 0.0);   // (a NaN takes the update branch)
     }
@@ -246,7 +247,7 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
     if (D == 1) {
         Fi[0][0] = 1.0 / F[0][0];
     } else if (D > 2) {
-        dense_inverse_lu<D, N>(F, Fi);                                                   // F.inverse(): partial-pivot LU (nllk_ctcrw.hpp:231, 236)
+        dense_inverse_lu<D, T_>(F, Fi);                                                   // F.inverse(): partial-pivot LU (nllk_ctcrw.hpp:231, 236)
     } else {
         const T_ id = 1.0 / det;
         Fi[0][0] = F[1][1] * id; Fi[0][1] = -(F[0][1] * id);
@@ -282,6 +283,12 @@ SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const Du
             for (int j = 0; j < D; j++) s = s - TP[r][DM::z(j)] * K[c][j];
             L.P[r][c] = s;
         }
+}
+
+template <int MODEL, int D, int N>
+SSDE_HD void dense_step(DenseLane<MODEL, D, N>& L, const DualN<N>* par, const DualN<N> (&H)[D][D], double dt,
+                        const double* y, bool na) {
+    dense_step_g<MODEL, D, DualN<N>>(L, par, H, dt, y, na);
 }
 
 }  // namespace ssde

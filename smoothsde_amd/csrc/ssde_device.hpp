@@ -554,8 +554,9 @@ hipError_t launch_tv_finalize(const TvArgs& a, hipStream_t s);
 
 // ---- exact second derivatives on the lane = direction path (k_tv_hess.hip, ssde_hdual.hpp) -----------------------------
 // one wavefront lane per coefficient PAIR, the primal recursion in hyper-dual arithmetic; isotropic lanes only
-constexpr int HESS_RS = 8;        // doubles per row record: dt | the row's linear predictors p_0 .. p_3 | y_0 y_1 | 0
-constexpr int HESS_NSTATE = 28;   // doubles per lane dumped at a window hand-over: (2 D + 3) hyper-dual numbers (CTCRW, d = 2)
+constexpr int HESS_RS = 12;       // doubles per row record: dt | the row's linear predictors p_0 .. p_3 | y_0 y_1 | 0 | H_array[,,i] (d x d, column-major; full-covariance lanes)
+constexpr int HESS_NSTATE = 80;   // doubles per lane dumped at a window hand-over: (2 D + 3) hyper-dual numbers on the isotropic lanes, sd + sd^2 = 20 on the
+                                  // full-covariance ones (CTCRW, d = 2)
 struct TvHessArgs {
     const double* times;         // [n]
     const double* obs;           // [n x d] column-major
@@ -580,6 +581,9 @@ struct TvHessArgs {
     const int16_t* pair_b;
     int n_pairs, n_pb;           // pairs, blocks of 64 pairs
     double p0[3];
+    int dense, has_h;            // full-covariance lanes (per-row H_array and / or a P0 that is not block-identical: ssde_dense.hpp in hyper-dual arithmetic)
+    const double* h_array;       // [n][d x d] (has_h)
+    double p0_full[16];          // sd x sd, column-major
     double last_dt;
     double* bnd;                 // [n_items][2][HESS_NSTATE][64]
     double* part;                // [n_items][4][64]: ab | a | b | value part of every lane's likelihood

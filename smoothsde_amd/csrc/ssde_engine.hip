@@ -549,13 +549,13 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
 }  // namespace
 
 namespace ssde_engine {
-// SSDE_FLAG_EXACT_HESS: a state-space handle whose own kernels are first-order only -- every register-path (lane = track) handle with
-// H = sigma_obs^2 I: constant coefficients, a smooth drift, row-varying tau / nu -- keeps its rows a second time in the layout the
+// SSDE_FLAG_EXACT_HESS: a state-space handle whose own kernels are first-order only -- every register-path (lane = track) handle:
+// constant coefficients, a smooth drift, row-varying tau / nu, with H = sigma_obs^2 I or per-row H_array -- keeps its rows a second time in the layout the
 // second-order lanes read (the lane = direction path, k_tv_hess.hip), and ssde_hess / ssde_laplace_eval take exact second derivatives
 // from there.  ~(TV_RS + 64) x 8 bytes per row: built only when that is at most a third of the device memory still free (a fit of
 // 10^8 rows keeps differencing its gradient instead and ssde_info.exact_hess_scope says so).
 void attach_hess_companion(const ssde_desc* desc, ssde_handle* h) {
-    if (!(desc->flags & SSDE_FLAG_EXACT_HESS) || h->path != PATH_ISO || h->has_h) return;
+    if (!(desc->flags & SSDE_FLAG_EXACT_HESS) || h->path != PATH_ISO) return;
     size_t free_b = 0, total_b = 0;
     if (hipSetDevice(h->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     const double need = (double)h->n * (TV_RS + 64) * 8.0;
@@ -564,7 +564,7 @@ void attach_hess_companion(const ssde_desc* desc, ssde_handle* h) {
     if (!c) return;
     c->force_tv = true;
     const int stc = build(desc, c);
-    if (stc == SSDE_OK && c->path == PATH_TV && !c->tv_dense) h->hess_companion = c;
+    if (stc == SSDE_OK && c->path == PATH_TV && !is_eseal(c->model)) h->hess_companion = c;
     else destroy(c);                                     // (not exact there either: ssde_hess says so when asked)
 }
 }  // namespace ssde_engine

@@ -58,6 +58,14 @@ SSDE_HD HD hd_log(const HD& x) {
     return hd_chain(x, log(x.v), r, -r * r);
 }
 
+// the names the general (full-covariance) step of ssde_dense.hpp is written in, so that dense_step_g runs in HD as it runs in DualN
+SSDE_HD HD operator/(double c, const HD& x) { return hd_rcp(x) * c; }
+SSDE_HD HD operator/(const HD& x, double c) { return x * (1.0 / c); }
+SSDE_HD HD dexp(const HD& x) { return hd_exp(x); }
+SSDE_HD HD dlog(const HD& x) { return hd_log(x); }
+SSDE_HD HD dsqrt(const HD& x) { return hd_sqrt(x); }
+SSDE_HD HD dfabs(const HD& x) { return x.v < 0.0 ? -x : x; }
+
 // ---- scalar-type generic helpers: the same template text runs in double (host checks) and in HD ------------------------
 SSDE_HD double g_exp(double x) { return exp(x); }
 SSDE_HD HD g_exp(const HD& x) { return hd_exp(x); }

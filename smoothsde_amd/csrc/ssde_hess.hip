@@ -25,9 +25,10 @@ static int scope_one(const ssde_handle* e) {
     // SSDE_FLAG_EXACT_HESS: the same rows on the lane = direction path next to a handle whose own kernels are first-order only
     if (e->hess_companion) return scope_one(e->hess_companion);
     if (e->path == PATH_TV) {
-        // row-varying (or, as the companion of a constant-coefficient handle, intercept-only) coefficients on the isotropic lane =
-        // direction path: second-order forward mode over coefficient pairs.  Not the full-covariance lanes, not ESEAL_SSM.
-        return (e->tv_dense || is_eseal(e->model)) ? 0 : 3;
+        // row-varying (or, as the companion of a constant-coefficient handle, intercept-only) coefficients on the lane = direction
+        // path: second-order forward mode over coefficient pairs -- the isotropic lanes, or (per-row H_array, a general P0) the
+        // full-covariance step in the same hyper-dual arithmetic.  Not ESEAL_SSM.
+        return is_eseal(e->model) ? 0 : 3;
     }
     if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
     if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
@@ -200,6 +201,8 @@ static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<i
         a.items = d_items.p; a.n_items = (int)items.size(); a.window = W;
         a.pair_a = d_pairs.p; a.pair_b = d_pairs.p + n_pairs; a.n_pairs = n_pairs; a.n_pb = n_pb;
         for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
+        a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
+        for (int i = 0; i < 16; i++) a.p0_full[i] = h->p0_full[i];
         a.last_dt = h->last_dt;
         a.bnd = d_bnd.p; a.part = d_part.p; a.out = d_out.p;
         HIPCHK(h, launch_tv_hess(a, s));

@@ -205,7 +205,7 @@ def test_row_varying_hessian_on_a_long_track_with_time_windows(monkeypatch):
 
 
 def test_exact_hessian_is_refused_where_it_does_not_exist():
-    for name in ("CTCRW_d2_tv_H_P0", "BM_t_d1_tv", "OU_d1_decay"):
+    for name in ("BM_t_d1_tv", "OU_d1_decay", "ESEAL_const"):
         rec = GOLD[name]
         pb = problem_from_spec(rec)
         eng = capi.Engine(pb)
@@ -500,3 +500,27 @@ def test_exact_hessian_over_track_shards_and_a_one_rank_communicator(name):
     Hc = comm.hess(par, idx)
     assert np.max(np.abs(Hc - H)) <= 1e-13 * np.max(np.abs(H))
     one.close(); two.close(); comm.close()
+
+
+# ---- ... and on the FULL-COVARIANCE lanes: per-row H_array, a P0 that is not block-identical -- ssde_dense.hpp in hyper-dual arithmetic ----
+DENSE_TV = [n for n in GOLD if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and GOLD[n]["n_dim"] <= 2
+            and (GOLD[n].get("H") is not None or GOLD[n].get("P0") is not None)]
+
+
+@pytest.mark.parametrize("name", DENSE_TV)
+def test_exact_hessian_on_the_full_covariance_lanes_matches_autograd(name):
+    """tmb_obj_joint$he(x) with error ellipses on the fixes (H_array, nllk_ctcrw.hpp:203-205) or a general P0: the general step
+    (ssde_dense.hpp) run in hyper-dual numbers, one lane per coefficient pair, against the autograd Hessian of the dense
+    joint-Gaussian restatement -- on the lane = direction path outright and as the companion of a register-path handle."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and not (pb.H is not None and k == 0)]      # (H_array: log_sigma_obs is not in the model)
+    pb.flags |= capi.FLAG_EXACT_HESS
+    eng = capi.Engine(pb)
+    assert eng.info()["exact_hess_scope"] == 3, eng.info()
+    H = eng.hess(par, idx)
+    eng.close()
+    H_exact = torch.autograd.functional.hessian(_joint_fn(pb, torch.tensor(par), idx), torch.tensor(par[idx])).numpy()
+    assert np.max(np.abs(H - H.T)) == 0.0
+    assert np.max(np.abs(H - H_exact)) <= 1e-8 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
