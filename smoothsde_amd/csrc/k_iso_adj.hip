@@ -32,27 +32,37 @@
 namespace ssde {
 
 // rows of a backward block: its records fill the wave's LDS slab (at most 36 KB: four waves per CU)
-constexpr int adj_block_rows(int nf) { return 72 / nf < 2 ? 2 : (72 / nf > 4 ? 4 : 72 / nf); }
+constexpr int adj_block_rows(int nf) { return 76 / nf < 2 ? 2 : (76 / nf > 4 ? 4 : 76 / nf); }
 // streamed columns the instantiations are built for
 int adj_ks(int k) { return k <= 6 ? 6 : k <= 9 ? 9 : k <= 12 ? 12 : k <= 18 ? 18 : -1; }
 int adj_nk(int model, int d, bool mu) { return (model != M_BM_SSM ? 2 : 1) + (mu ? d : 0); }
 // accumulators: [value | log sigma_obs | mu_1 .. mu_d | par[d] | par[d + 1] | per streamed column: its kinds]
 int adj_nacc(int model, int d, int k, bool mu) { return 4 + d + adj_ks(k) * adj_nk(model, d, mu); }
-int adj_nstate(int model, int d) { return 2 * (model == M_CTCRW ? 2 * d + 3 : d + 1); }
-int adj_ckpt_rows(int model, int d) {
+int adj_nstate(int model, int d, bool full) { return full ? 2 * (model == M_CTCRW ? 14 : 5) : 2 * (model == M_CTCRW ? 2 * d + 3 : d + 1); }
+int adj_ckpt_rows(int model, int d, bool full) {
+    if (full) return model == M_CTCRW ? adj_block_rows(AdjFull<M_CTCRW>::NF) : adj_block_rows(AdjFull<M_OU_SSM>::NF);
     if (model == M_CTCRW) return d == 1 ? adj_block_rows(AdjCtcrw<1>::NF) : adj_block_rows(AdjCtcrw<2>::NF);
     return d == 1 ? adj_block_rows(AdjScal<1, true>::NF) : adj_block_rows(AdjScal<2, true>::NF);
 }
 
-template <int MODEL, int D, int KS, bool MU>
+// FULL: two response columns with a full covariance (per-row H_array: ssde_adj.hpp, AdjFull) instead of the isotropic lanes
+template <int MODEL, int D, bool FULL>
+struct AdjLaneSel { typedef typename AdjModel<MODEL, D>::Lane type; };
+template <int MODEL>
+struct AdjLaneSel<MODEL, 2, true> { typedef AdjFull<MODEL> type; };
+
+template <int MODEL, int D, int KS, bool MU, bool FULL>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoArgs A) {
-    typedef typename AdjModel<MODEL, D>::Lane Lane;
+    static_assert(!FULL || D == 2, "full-covariance lanes: two response columns");
+    typedef typename AdjLaneSel<MODEL, D, FULL>::type Lane;
     typedef typename Lane::Trans Trans;
     typedef typename Lane::Adj Adj;
     constexpr int NST = Lane::NST, NF = Lane::NF, SD = Lane::SD, CB = adj_block_rows(NF);
     constexpr bool P2 = MODEL != M_BM_SSM;
     constexpr int NKP = P2 ? 2 : 1, NK = NKP + (MU ? D : 0);
-    constexpr int W = 2 + D + KS;                              // register row: [dt | y | H (d = 1 with H_array) | the streamed columns]
+    constexpr int NHS = FULL ? 3 : 1, CO = 1 + D + NHS;        // register row: [dt | y | h (d = 1 with H_array: H_i; FULL: H00 H01 H11) | the streamed columns]
+    constexpr int W = CO + KS;
+    constexpr double LDS_ = FULL ? 1.0 : (double)D;            // the value: (LDS_ sum log F + sum u' F^-1 u) / 2 (FULL: the lanes accumulate log det F)
     constexpr int nacc = 4 + D + KS * NK;
     __shared__ double recs[WG_WAVES][CB * NF * WAVE];
     if (blockIdx.x == 0 && threadIdx.x == 0 && A.chk_out) *A.chk_out = 0.0;
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
     const TileView& tv = A.tv;
     const int C = tv.C, c_obs = tv.c_obs, G = tv.n_groups, K = A.drift_k, c_col = A.c_col;
     const bool grad = A.part_mask[0] != 0;
-    const bool has_h = D == 1 && A.cv_has_h != 0;
+    const bool has_h = (D == 1 || FULL) && A.cv_has_h != 0;
     const double* const gbase = tv.tiles + tv.group_off[g];      // (uniform: a row's address is scalar arithmetic + the lane's 32-bit offset)
     const int L = tv.group_len[g];
     const int ns = tv.lane_nsteps[g * WAVE + lane];
@@ -100,9 +110,10 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
     voff[0] = (unsigned)lane * 8u;
 #pragma unroll
     for (int a = 0; a < D; a++) voff[1 + a] = (unsigned)((c_obs + a) * WAVE + lane) * 8u;
-    voff[1 + D] = (unsigned)((c_obs + D) * WAVE + lane) * 8u;
 #pragma unroll
-    for (int k = 0; k < KS; k++) voff[2 + D + k] = (unsigned)((c_col + (k < K ? k : 0)) * WAVE + lane) * 8u;      // (past the last column: column 0 again, coefficient 0)
+    for (int i = 0; i < NHS; i++) voff[1 + D + i] = (unsigned)((c_obs + D + (i == 0 ? 0 : i + 1)) * WAVE + lane) * 8u;      // H_array[,,i] column-major: 00 | (10) 01 11
+#pragma unroll
+    for (int k = 0; k < KS; k++) voff[CO + k] = (unsigned)((c_col + (k < K ? k : 0)) * WAVE + lane) * 8u;      // (past the last column: column 0 again, coefficient 0)
     auto load_row = [&](double (&dst)[W], int s) {
         if (A.adj_diag & 1) s = s_begin + (s & 3);                 // (timing experiment: every row from the cache -- the numbers mean nothing)
         const int so = (s - s_begin) * C * (WAVE * 8);
@@ -114,10 +125,14 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
         if (c_obs) dst[0] = at(0);
 #pragma unroll
         for (int a = 0; a < D; a++) dst[1 + a] = at(1 + a);
-        dst[1 + D] = h;
-        if (has_h) dst[1 + D] = at(1 + D);
 #pragma unroll
-        for (int k = 0; k < KS; k++) dst[2 + D + k] = at(2 + D + k);
+        for (int i = 0; i < NHS; i++) dst[1 + D + i] = i == 1 ? 0.0 : h;      // (sigma_obs^2 I without H_array)
+        if (has_h) {
+#pragma unroll
+            for (int i = 0; i < NHS; i++) dst[1 + D + i] = at(1 + D + i);
+        }
+#pragma unroll
+        for (int k = 0; k < KS; k++) dst[CO + k] = at(CO + k);
     };
 #else
     auto load_row = [&](double (&dst)[W], int s) {
@@ -128,10 +143,14 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
         if (c_obs) dst[0] = p[ul];
 #pragma unroll
         for (int a = 0; a < D; a++) dst[1 + a] = p[(unsigned)((c_obs + a) * WAVE) + ul];
-        dst[1 + D] = h;
-        if (has_h) dst[1 + D] = p[(unsigned)((c_obs + D) * WAVE) + ul];
 #pragma unroll
-        for (int k = 0; k < KS; k++) dst[2 + D + k] = p[(unsigned)((c_col + (k < K ? k : 0)) * WAVE) + ul];
+        for (int i = 0; i < NHS; i++) dst[1 + D + i] = i == 1 ? 0.0 : h;
+        if (has_h) {
+#pragma unroll
+            for (int i = 0; i < NHS; i++) dst[1 + D + i] = p[(unsigned)((c_obs + D + (i == 0 ? 0 : i + 1)) * WAVE) + ul];
+        }
+#pragma unroll
+        for (int k = 0; k < KS; k++) dst[CO + k] = p[(unsigned)((c_col + (k < K ? k : 0)) * WAVE) + ul];
     };
 #endif
     // the row's linear predictors (nllk_ctcrw.hpp:143-149) and drift
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
         for (int a = 0; a < D; a++) mu[a] = A.mu[a];
 #pragma unroll
         for (int k = 0; k < KS; k++) {
-            const double x = r[2 + D + k];
+            const double x = r[CO + k];
             p1 = fma(A.coefA[k], x, p1);
             if (P2) p2 = fma(A.coefB[k], x, p2);
             if (MU) { mu[0] = fma(A.coefC[k], x, mu[0]); if (D > 1) mu[D - 1] = fma(A.coefD[k], x, mu[D - 1]); }
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
                 else a0[a] = (y0 == y0) ? y0 : 0.0;
             }
         }
-        F.init(a0, A.p0);
+        if constexpr (FULL) F.init(a0, A.cv_p0); else F.init(a0, A.p0);
     }
     LogAcc ld;
     ld.init();
@@ -201,9 +220,12 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
                 const int s = s0 + u;
                 if (s >= s_hi) break;                              // (uniform)
                 if (s == s_acc) { if (s_acc > s_begin) F.template put<WAVE>(dump0); ld.init(); accq = 0.0; }
-                if (s == s_end) { value = 0.5 * ((double)D * ld.value() + accq); if (!last_chunk) F.template put<WAVE>(dump1); }
+                if (s == s_end) { value = 0.5 * (LDS_ * ld.value() + accq); if (!last_chunk) F.template put<WAVE>(dump1); }
                 if (grad && s >= s_acc && (s - s_acc) % CB == 0) F.template put<WAVE>(ck + (int64_t)((s - s_acc) / CB * ck_mul) * NST * WAVE);
-                if (s < lim) F.template fwd<false, WAVE>(tr[u], blk[u][1 + D], mu[u], &blk[u][1], is_na(blk[u][1], A.any_nan), ld, accq, nullptr);
+                if (s < lim) {
+                    if constexpr (FULL) F.template fwd<false, WAVE>(tr[u], &blk[u][1 + D], mu[u], &blk[u][1], is_na(blk[u][1], A.any_nan), ld, accq, nullptr);
+                    else F.template fwd<false, WAVE>(tr[u], blk[u][1 + D], mu[u], &blk[u][1], is_na(blk[u][1], A.any_nan), ld, accq, nullptr);
+                }
             }
         };
 #pragma unroll
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
         }
         if (s_end >= s_hi) {                                       // (no rows past the window's end: the events of row s_end)
             if (s_acc >= s_hi) { ld.init(); accq = 0.0; }
-            value = 0.5 * ((double)D * ld.value() + accq);
+            value = 0.5 * (LDS_ * ld.value() + accq);
             if (!last_chunk) F.template put<WAVE>(dump1);
         }
     }
@@ -278,7 +300,8 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
                 if (s < lim) {
                     Trans tr;
                     Lane::template get_trans<WAVE>(rec + r * NF * WAVE, row_dt(row, s), tr);
-                    Fb.template fwd<true, WAVE>(tr, row[1 + D], mub[r], &row[1], is_na(row[1], A.any_nan), ld2, aq2, rec + r * NF * WAVE);
+                    if constexpr (FULL) Fb.template fwd<true, WAVE>(tr, &row[1 + D], mub[r], &row[1], is_na(row[1], A.any_nan), ld2, aq2, rec + r * NF * WAVE);
+                    else Fb.template fwd<true, WAVE>(tr, row[1 + D], mub[r], &row[1], is_na(row[1], A.any_nan), ld2, aq2, rec + r * NF * WAVE);
                 }
             }
             if (j > 0) {
@@ -291,14 +314,15 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
                 double (&row)[W] = rows[REV ? CB - 1 - r : r];
                 if (s < lim) {
                     AdjRowGrad<D> gr;
-                    Lane::template bwd<WAVE>(Lm, rec + r * NF * WAVE, row[1 + D], mub[r], row_dt(row, s), gr);
+                    if constexpr (FULL) Lane::template bwd<WAVE>(Lm, rec + r * NF * WAVE, &row[1 + D], mub[r], &row[1], row_dt(row, s), gr);
+                    else Lane::template bwd<WAVE>(Lm, rec + r * NF * WAVE, row[1 + D], mub[r], row_dt(row, s), gr);
                     if (s < s_end) {                               // (uniform: the rows past the window's end belong to the next window)
                         gs1 += gr.g1; gs2 += gr.g2; gsh += gr.gh;
 #pragma unroll
                         for (int a = 0; a < D; a++) gsm[a] += gr.gmu[a];
 #pragma unroll
                         for (int k = 0; k < KS; k++) {
-                            const double x = row[2 + D + k];
+                            const double x = row[CO + k];
                             acc[k][0] = fma(x, gr.g1, acc[k][0]);
                             if (P2) acc[k][NKP - 1] = fma(x, gr.g2, acc[k][NKP - 1]);
                             if (MU) {
@@ -343,26 +367,31 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void iso_adj_kernel(const IsoAr
 // one wave per (group, window); a.drift_k <= 18 streamed columns (adj_ks), <= 9 when the drift has design columns too; a.adj_ckpt: [work item][a.adj_ckpt_stride] doubles
 hipError_t launch_iso_adj(int model, int d, const IsoArgs& a0, hipStream_t s) {
     const int ks = adj_ks(a0.drift_k);
-    if (a0.cv_full || (a0.cv_has_h && d != 1) || ks < 0 || !a0.adj_ckpt) return hipErrorInvalidValue;
+    if ((a0.cv_full && d != 2) || (a0.cv_has_h && d != 1 && !a0.cv_full) || ks < 0 || !a0.adj_ckpt) return hipErrorInvalidValue;
     IsoArgs a = a0;
     a.n_parts = 1;
     const int g8 = (a.tv.n_groups + 7) / 8;
     dim3 grid((g8 * 8 * a.n_chunks + WG_WAVES - 1) / WG_WAVES), block(WG_WAVES * WAVE);
     if (grid.x == 0) return hipSuccess;
     const bool mu = a.cv_mu_cols != 0;
-#define SSDE_CASE(M_, D_) if (model == M_ && d == D_) { \
+#define SSDE_KS(M_, D_, F_) { \
         if (mu) { \
-            if (ks == 6) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 6, true>), grid, block, 0, s, a); \
-            else if (ks == 9) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 9, true>), grid, block, 0, s, a); \
+            if (ks == 6) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 6, true, F_>), grid, block, 0, s, a); \
+            else if (ks == 9) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 9, true, F_>), grid, block, 0, s, a); \
             else return hipErrorInvalidValue; \
         } \
-        else if (ks == 6) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 6, false>), grid, block, 0, s, a); \
-        else if (ks == 9) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 9, false>), grid, block, 0, s, a); \
-        else if (ks == 12) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 12, false>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 18, false>), grid, block, 0, s, a); \
+        else if (ks == 6) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 6, false, F_>), grid, block, 0, s, a); \
+        else if (ks == 9) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 9, false, F_>), grid, block, 0, s, a); \
+        else if (ks == 12) hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 12, false, F_>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((iso_adj_kernel<M_, D_, 18, false, F_>), grid, block, 0, s, a); \
         return hipGetLastError(); }
+#define SSDE_CASE(M_, D_) if (model == M_ && d == D_ && !a.cv_full) SSDE_KS(M_, D_, false)
     SSDE_CASE(M_CTCRW, 1) SSDE_CASE(M_CTCRW, 2) SSDE_CASE(M_OU_SSM, 1) SSDE_CASE(M_OU_SSM, 2) SSDE_CASE(M_BM_SSM, 1) SSDE_CASE(M_BM_SSM, 2)
 #undef SSDE_CASE
+#define SSDE_CASE(M_) if (model == M_ && a.cv_full) SSDE_KS(M_, 2, true)
+    SSDE_CASE(M_CTCRW) SSDE_CASE(M_OU_SSM) SSDE_CASE(M_BM_SSM)
+#undef SSDE_CASE
+#undef SSDE_KS
     return hipErrorInvalidValue;
 }
 // work items of a launch (the grid's waves) and checkpoints a window of `rows` scored + trailing rows needs

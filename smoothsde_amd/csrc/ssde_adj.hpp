@@ -16,6 +16,8 @@
 // Written as __host__ __device__ inline code: k_iso_adj.hip runs it lane = track; tests/hostsim compiles it with g++.
 #ifndef SSDE_ADJ_HPP
 #define SSDE_ADJ_HPP
+#include <type_traits>
+
 #include "ssde_math.hpp"
 
 namespace ssde {
@@ -338,6 +340,261 @@ struct AdjScal {
         g.gh = fma(c, iF, Fb);
         L.bp = fma(pfb, a_, fma(bb, iF, Fb));
         for (int a = 0; a < D; a++) L.bx[a] = fma(a_, bxf[a], -iF * u[a]);
+    }
+};
+
+// ---- two response columns with a FULL covariance: a per-row measurement covariance H_i (H_array, nllk_ctcrw.hpp:203-205) couples the
+// dimensions, and / or P0 is not block-identical.  State a (sd), P symmetric (sd (sd + 1) / 2 numbers, row-major upper triangle);
+// Z picks the positions (components 0 and 2 of CTCRW's (x0, v0, x1, v1); the identity for OU_SSM / BM_SSM).  The step in its filtered form
+//     w = F^-1 u,  af = a + P Z' w,  Pf = P - P Z' F^-1 Z P,  a' = T af + B mu,  P' = T Pf T' + Q        (nllk_ctcrw.hpp:219-242)
+// and its transpose; the adjoint of P is kept as the symmetric matrix G with d l = sum_rc G_rc dP_rc over symmetric dP.
+template <int MODEL>
+struct AdjFull {
+    static constexpr int D = 2;
+    static constexpr bool CT = MODEL == M_CTCRW, HAS_P2 = MODEL != M_BM_SSM;
+    static constexpr int SD = CT ? 4 : 2, NP = SD * (SD + 1) / 2, NST = SD + NP;
+    static constexpr int NTR = CT ? 10 : 5, NF = NST + 1 + NTR;
+    typedef typename std::conditional<CT, CtcrwTrans, ScalTrans>::type Trans;
+    double a[SD], p[NP];
+    static SSDE_HD constexpr int z(int i) { return CT ? 2 * i : i; }
+    static SSDE_HD constexpr int sidx(int i, int j) { return i <= j ? i * SD - i * (i - 1) / 2 + (j - i) : j * SD - j * (j - 1) / 2 + (i - j); }
+
+    SSDE_HD void init(const double* a0, const double* p0f /* sd x sd, column-major */) {
+        for (int i = 0; i < SD; i++) a[i] = a0[i];
+        for (int i = 0; i < SD; i++)
+            for (int j = i; j < SD; j++) p[sidx(i, j)] = p0f[i + SD * j];
+    }
+    template <int RS>
+    SSDE_HD void put(double* o) const {
+        for (int i = 0; i < SD; i++) o[i * RS] = a[i];
+        for (int i = 0; i < NP; i++) o[(SD + i) * RS] = p[i];
+    }
+    template <int RS>
+    SSDE_HD void get(const double* o) {
+        for (int i = 0; i < SD; i++) a[i] = o[i * RS];
+        for (int i = 0; i < NP; i++) p[i] = o[(SD + i) * RS];
+    }
+    static SSDE_HD void trans(double dt, double p1, double p2, Trans& tr) {
+        if constexpr (CT) adj_ctcrw_trans(dt, p1, p2, tr);
+        else AdjScal<2, HAS_P2>::trans(dt, p1, p2, tr);
+    }
+    template <int RS>
+    static SSDE_HD void put_trans(double* rec, const Trans& tr) {
+        int n = NST + 1;
+        if constexpr (CT) {
+            rec[(n++) * RS] = tr.e; rec[(n++) * RS] = tr.t12; rec[(n++) * RS] = tr.de; rec[(n++) * RS] = tr.dt12;
+            rec[(n++) * RS] = tr.dq11; rec[(n++) * RS] = tr.dq12; rec[(n++) * RS] = tr.dq22;
+            rec[(n++) * RS] = tr.q11; rec[(n++) * RS] = tr.q12; rec[(n++) * RS] = tr.q22;
+        } else {
+            rec[(n++) * RS] = HAS_P2 ? tr.t : 1.0; rec[(n++) * RS] = tr.b; rec[(n++) * RS] = tr.q; rec[(n++) * RS] = tr.dt_; rec[(n++) * RS] = tr.dq;
+        }
+    }
+    template <int RS>
+    static SSDE_HD void get_trans(const double* rec, double dt, Trans& tr) {
+        const int n = NST + 1;
+        if constexpr (CT) {
+            tr.e = rec[n * RS]; tr.t12 = rec[(n + 1) * RS]; tr.q11 = rec[(n + 7) * RS]; tr.q12 = rec[(n + 8) * RS]; tr.q22 = rec[(n + 9) * RS];
+            tr.b1 = dt - tr.t12; tr.b2 = 1.0 - tr.e; tr.e2 = tr.e * tr.e;
+        } else {
+            tr.t = rec[n * RS]; tr.b = rec[(n + 1) * RS]; tr.q = rec[(n + 2) * RS];
+        }
+    }
+    // v <- T v, v <- T' v for one vector of the state's layout
+    static SSDE_HD void mulT(const Trans& tr, const double* v, double* o) {
+        if constexpr (CT) { for (int d = 0; d < D; d++) { o[2 * d] = fma(tr.t12, v[2 * d + 1], v[2 * d]); o[2 * d + 1] = tr.e * v[2 * d + 1]; } }
+        else { const double t = HAS_P2 ? tr.t : 1.0; for (int i = 0; i < SD; i++) o[i] = t * v[i]; }
+    }
+    static SSDE_HD void mulTt(const Trans& tr, const double* v, double* o) {
+        if constexpr (CT) { for (int d = 0; d < D; d++) { o[2 * d] = v[2 * d]; o[2 * d + 1] = fma(tr.t12, v[2 * d], tr.e * v[2 * d + 1]); } }
+        else { const double t = HAS_P2 ? tr.t : 1.0; for (int i = 0; i < SD; i++) o[i] = t * v[i]; }
+    }
+    // what both directions form from (a, P, H, y): the update's pieces.  idet: 1 / det F, 0 on a row that is not scored
+    struct Upd {
+        double P[SD][SD], u[D], w[D], Fi[3], M[SD][D], MFi[SD][D], af[SD], Pf[SD][SD];
+    };
+    SSDE_HD void update_pieces(const double* H, const double* y, double idet, Upd& U) const {
+        for (int i = 0; i < SD; i++)
+            for (int j = 0; j < SD; j++) U.P[i][j] = p[sidx(i, j)];
+        const double F00 = U.P[z(0)][z(0)] + H[0], F01 = U.P[z(0)][z(1)] + H[1], F11 = U.P[z(1)][z(1)] + H[2];
+        U.Fi[0] = F11 * idet; U.Fi[1] = -F01 * idet; U.Fi[2] = F00 * idet;
+        const bool upd = idet != 0.0;
+        for (int i = 0; i < D; i++) U.u[i] = upd ? y[i] - a[z(i)] : 0.0;
+        U.w[0] = fma(U.Fi[0], U.u[0], U.Fi[1] * U.u[1]); U.w[1] = fma(U.Fi[1], U.u[0], U.Fi[2] * U.u[1]);
+        for (int r = 0; r < SD; r++) {
+            U.M[r][0] = U.P[r][z(0)]; U.M[r][1] = U.P[r][z(1)];
+            U.MFi[r][0] = fma(U.M[r][0], U.Fi[0], U.M[r][1] * U.Fi[1]); U.MFi[r][1] = fma(U.M[r][0], U.Fi[1], U.M[r][1] * U.Fi[2]);
+            U.af[r] = fma(U.M[r][0], U.w[0], fma(U.M[r][1], U.w[1], a[r]));
+        }
+        for (int r = 0; r < SD; r++)
+            for (int c = r; c < SD; c++) U.Pf[r][c] = U.Pf[c][r] = U.P[r][c] - fma(U.MFi[r][0], U.M[c][0], U.MFi[r][1] * U.M[c][1]);
+    }
+    // H = (H00, H01, H11) of the row (sigma_obs^2 I without H_array)
+    template <bool REC, int RS>
+    SSDE_HD void fwd(const Trans& tr, const double* H, const double* mu, const double* y, bool na, LogAcc& ld, double& accq, double* rec) {
+        const double F00 = p[sidx(z(0), z(0))] + H[0], F01 = p[sidx(z(0), z(1))] + H[1], F11 = p[sidx(z(1), z(1))] + H[2];
+        const double detF = fma(F00, F11, -F01 * F01);             // det(): nllk_ctcrw.hpp:16-19
+        const bool upd = !na && (CT ? !(detF <= 0.0) : !(fabs(detF) <= 0.0));     // :214, 226; nllk_ou_ssm.hpp:190-195
+        const double dete = upd ? (CT ? detF : fabs(detF)) : 1.0;
+        const double idet = upd ? rcp(detF) : 0.0;
+        ld.mul(dete);
+        const bool bm = na || upd || !CT;                          // Q3: CTCRW's detF <= 0 branch predicts without B mu
+        if (REC) {
+            put<RS>(rec);
+            rec[NST * RS] = bm ? idet : -0.0;
+        }
+        Upd U;
+        update_pieces(H, y, idet, U);
+        accq = fma(U.u[0], U.w[0], fma(U.u[1], U.w[1], accq));
+        double Taf[SD];
+        mulT(tr, U.af, Taf);
+        for (int d = 0; d < D; d++) {
+            const double mue = bm ? mu[d] : 0.0;
+            if constexpr (CT) { a[2 * d] = fma(tr.b1, mue, Taf[2 * d]); a[2 * d + 1] = fma(tr.b2, mue, Taf[2 * d + 1]); }
+            else a[d] = fma(tr.b, mue, Taf[d]);
+        }
+        // P' = T Pf T' + Q
+        double G1[SD][SD];
+        for (int c = 0; c < SD; c++) {
+            double col[SD], o[SD];
+            for (int r = 0; r < SD; r++) col[r] = U.Pf[r][c];
+            mulT(tr, col, o);
+            for (int r = 0; r < SD; r++) G1[r][c] = o[r];
+        }
+        for (int r = 0; r < SD; r++) {
+            double o[SD];
+            mulT(tr, G1[r], o);                                    // (row r of G1 T' = T (row r)')
+            for (int c = r; c < SD; c++) p[sidx(r, c)] = o[c];
+        }
+        if constexpr (CT) {
+            for (int d = 0; d < D; d++) { p[sidx(2 * d, 2 * d)] += tr.q11; p[sidx(2 * d, 2 * d + 1)] += tr.q12; p[sidx(2 * d + 1, 2 * d + 1)] += tr.q22; }
+        } else {
+            for (int r = 0; r < SD; r++) p[sidx(r, r)] += tr.q;
+        }
+    }
+    struct Adj {
+        double ba[SD], G[NP];                                      // G: the symmetric adjoint of P, stored like P
+        SSDE_HD void zero() { for (int i = 0; i < SD; i++) ba[i] = 0.0; for (int i = 0; i < NP; i++) G[i] = 0.0; }
+        template <int RS>
+        SSDE_HD void put(double* o) const {
+            for (int i = 0; i < SD; i++) o[i * RS] = ba[i];
+            for (int i = 0; i < NP; i++) o[(SD + i) * RS] = G[i];
+        }
+    };
+    template <int RS>
+    static SSDE_HD void bwd(Adj& L, const double* rec, const double* H, const double* mu, const double* y, double dt, AdjRowGrad<2>& g) {
+        AdjFull S;
+        S.template get<RS>(rec);
+        const double idr = rec[NST * RS];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool nodrift = (unsigned long long)__double_as_longlong(idr) == 0x8000000000000000ull;
+#else
+        uint64_t bits; memcpy(&bits, &idr, 8);
+        const bool nodrift = bits == 0x8000000000000000ull;
+#endif
+        const double idet = nodrift ? 0.0 : idr;
+        Trans tr;
+        get_trans<RS>(rec, dt, tr);
+        Upd U;
+        S.update_pieces(H, y, idet, U);
+        double Gp[SD][SD];                                         // P-bar' as a full matrix
+        for (int i = 0; i < SD; i++)
+            for (int j = 0; j < SD; j++) Gp[i][j] = L.G[sidx(i, j)];
+        // ---- the prediction: a' = T af + B mu, P' = T Pf T' + Q ----
+        double baf[SD];
+        mulTt(tr, L.ba, baf);
+        const int n = NST + 1;
+        if constexpr (CT) {
+            const double de = rec[(n + 2) * RS], dt12 = rec[(n + 3) * RS], dq11 = rec[(n + 4) * RS], dq12 = rec[(n + 5) * RS], dq22 = rec[(n + 6) * RS];
+            // T-bar = 2 P-bar' (T Pf): only its (x_d, v_d) and (v_d, v_d) entries move t12 and e
+            double t12b = 0.0, eb = 0.0, q11b = 0.0, q12b = 0.0, q22b = 0.0, b1b = 0.0, b2b = 0.0;
+            for (int d = 0; d < D; d++) {
+                double colv[SD], R[SD];                            // column v_d of T Pf = T (column v_d of Pf)
+                for (int r = 0; r < SD; r++) colv[r] = U.Pf[r][2 * d + 1];
+                mulT(tr, colv, R);
+                double tx = 0.0, tv = 0.0;
+                for (int r = 0; r < SD; r++) { tx = fma(Gp[2 * d][r], R[r], tx); tv = fma(Gp[2 * d + 1][r], R[r], tv); }
+                t12b += fma(2.0, tx, L.ba[2 * d] * U.af[2 * d + 1]);
+                eb += fma(2.0, tv, L.ba[2 * d + 1] * U.af[2 * d + 1]);
+                q11b += Gp[2 * d][2 * d]; q12b += 2.0 * Gp[2 * d][2 * d + 1]; q22b += Gp[2 * d + 1][2 * d + 1];
+                const double mue = nodrift ? 0.0 : mu[d];
+                b1b = fma(L.ba[2 * d], mue, b1b); b2b = fma(L.ba[2 * d + 1], mue, b2b);
+                g.gmu[d] = nodrift ? 0.0 : fma(tr.b1, L.ba[2 * d], tr.b2 * L.ba[2 * d + 1]);
+            }
+            g.g1 = fma(de, eb - b2b, fma(dt12, t12b - b1b, fma(q11b, dq11, fma(q12b, dq12, q22b * dq22))));
+            g.g2 = 2.0 * fma(q11b, tr.q11, fma(q12b, tr.q12, q22b * tr.q22));
+        } else {
+            const double t = HAS_P2 ? tr.t : 1.0, dt_ = rec[(n + 3) * RS], dq = rec[(n + 4) * RS];
+            double tb = 0.0, qb = 0.0, bb = 0.0, gp = 0.0;
+            for (int r = 0; r < SD; r++) {
+                tb = fma(L.ba[r], U.af[r], tb); qb += Gp[r][r]; bb = fma(L.ba[r], mu[r], bb);
+                for (int c = 0; c < SD; c++) gp = fma(Gp[r][c], U.Pf[r][c], gp);
+                g.gmu[r] = tr.b * L.ba[r];
+            }
+            tb = fma(2.0 * t, gp, tb);
+            g.g1 = HAS_P2 ? fma(dt_, tb - bb, qb * dq) : qb * dq;
+            g.g2 = HAS_P2 ? qb * tr.q : 0.0;
+        }
+        // G-bar = T' P-bar' T
+        double Gb[SD][SD];
+        {
+            double X[SD][SD];
+            for (int c = 0; c < SD; c++) {                         // X = T' Gp (column by column)
+                double col[SD], o[SD];
+                for (int r = 0; r < SD; r++) col[r] = Gp[r][c];
+                mulTt(tr, col, o);
+                for (int r = 0; r < SD; r++) X[r][c] = o[r];
+            }
+            for (int r = 0; r < SD; r++) {                         // Gb = X T: row r of X T = (T' (row r)')'
+                double o[SD];
+                mulTt(tr, X[r], o);
+                for (int c = 0; c < SD; c++) Gb[r][c] = o[c];
+            }
+        }
+        // ---- the update: af = a + M w, Pf = P - M F^-1 M', l = (log det F + u' w) / 2, w = F^-1 u, M = P Z', F = Z P Z' + H ----
+        double Mb[SD][D], wb[D] = {0.0, 0.0};
+        for (int r = 0; r < SD; r++) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int c = 0; c < SD; c++) { s0 = fma(Gb[r][c], U.MFi[c][0], s0); s1 = fma(Gb[r][c], U.MFi[c][1], s1); }
+            Mb[r][0] = fma(baf[r], U.w[0], -2.0 * s0); Mb[r][1] = fma(baf[r], U.w[1], -2.0 * s1);
+            wb[0] = fma(U.M[r][0], baf[r], wb[0]); wb[1] = fma(U.M[r][1], baf[r], wb[1]);
+        }
+        // F^-1-bar (symmetric) = - M' Gb M + u u' / 2 + sym(wb u')
+        double GM[SD][D];
+        for (int r = 0; r < SD; r++) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int c = 0; c < SD; c++) { s0 = fma(Gb[r][c], U.M[c][0], s0); s1 = fma(Gb[r][c], U.M[c][1], s1); }
+            GM[r][0] = s0; GM[r][1] = s1;
+        }
+        double Fib[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < SD; r++) { Fib[0] = fma(-U.M[r][0], GM[r][0], Fib[0]); Fib[1] = fma(-U.M[r][0], GM[r][1], Fib[1]); Fib[2] = fma(-U.M[r][1], GM[r][1], Fib[2]); }
+        Fib[0] += fma(0.5 * U.u[0], U.u[0], wb[0] * U.u[0]);
+        Fib[1] += fma(0.5 * U.u[0], U.u[1], 0.5 * fma(wb[0], U.u[1], wb[1] * U.u[0]));
+        Fib[2] += fma(0.5 * U.u[1], U.u[1], wb[1] * U.u[1]);
+        const double ub[D] = {U.w[0] + fma(U.Fi[0], wb[0], U.Fi[1] * wb[1]), U.w[1] + fma(U.Fi[1], wb[0], U.Fi[2] * wb[1])};
+        // F-bar = F^-1 / 2 - F^-1 F^-1-bar F^-1   (on a row that is not scored F^-1 = 0: nothing)
+        const double A00 = fma(U.Fi[0], Fib[0], U.Fi[1] * Fib[1]), A01 = fma(U.Fi[0], Fib[1], U.Fi[1] * Fib[2]);
+        const double A10 = fma(U.Fi[1], Fib[0], U.Fi[2] * Fib[1]), A11 = fma(U.Fi[1], Fib[1], U.Fi[2] * Fib[2]);
+        const double Fb00 = 0.5 * U.Fi[0] - fma(A00, U.Fi[0], A01 * U.Fi[1]);
+        const double Fb01 = 0.5 * U.Fi[1] - fma(A00, U.Fi[1], A01 * U.Fi[2]);
+        const double Fb11 = 0.5 * U.Fi[2] - fma(A10, U.Fi[1], A11 * U.Fi[2]);
+        g.gh = Fb00 + Fb11;
+        const bool upd = idet != 0.0;
+        for (int r = 0; r < SD; r++) L.ba[r] = baf[r];
+        if (upd) for (int i = 0; i < D; i++) L.ba[z(i)] -= ub[i];
+        for (int r = 0; r < SD; r++)
+            for (int c = r; c < SD; c++) {
+                double v = Gb[r][c];
+                if (upd) {
+                    for (int j = 0; j < D; j++) {
+                        if (c == z(j)) v = fma(0.5, Mb[r][j], v);
+                        if (r == z(j)) v = fma(0.5, Mb[c][j], v);
+                    }
+                    if (r == z(0) && c == z(0)) v += Fb00;
+                    if (r == z(0) && c == z(1)) v += Fb01;
+                    if (r == z(1) && c == z(1)) v += Fb11;
+                }
+                L.G[sidx(r, c)] = v;
+            }
     }
 };
 

@@ -250,8 +250,8 @@ hipError_t launch_iso_adj(int model, int d, const IsoArgs& a, hipStream_t s);
 int adj_ks(int k);                                   // streamed-column capacity of the instantiation that takes k columns, -1: none
 int adj_nk(int model, int d, bool mu);               // accumulators per streamed column
 int adj_nacc(int model, int d, int k, bool mu);      // [value | log sigma_obs | mu_a | par[d] | par[d + 1] | column 0's kinds | ...]
-int adj_nstate(int model, int d);                    // doubles of a hand-over record: the state and its adjoint
-int adj_ckpt_rows(int model, int d);                 // rows between checkpoints
+int adj_nstate(int model, int d, bool full);         // doubles of a hand-over record: the state and its adjoint
+int adj_ckpt_rows(int model, int d, bool full);      // rows between checkpoints
 int adj_items(int n_groups, int n_chunks);           // work items (waves) of a launch
 hipError_t launch_colvar_h_stats(const TileView& tv, int c_h, int d, double* out /* [n_groups][2]: max diag(H), max |H01 - H10| */, hipStream_t s);
 hipError_t launch_colvar_ranges(const TileView& tv, int c_col, int K, double* out /* [n_groups][K][2] */, hipStream_t s);

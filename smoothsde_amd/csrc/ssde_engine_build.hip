@@ -167,7 +167,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             for (auto& c : cols) mu_streamed = mu_streamed || (c.type >= 3 && c.chan >= 0);
             const char* e = getenv("SSDE_CV_ADJ");
             const int mode = e ? atoi(e) : 1;
-            h->cv_adj = mode > 0 && !h->cv_full && !h->cv_single && (!h->has_h || h->d == 1) && h->n_stream_cols >= 1 &&
+            h->cv_adj = mode > 0 && !h->cv_single && (!h->has_h || h->d == 1 || h->cv_full) && (!h->cv_full || h->d == 2) && h->n_stream_cols >= 1 &&
                         adj_ks(h->n_stream_cols) >= 0 && (!mu_streamed || adj_ks(h->n_stream_cols) <= 9) && (!h->cv_few || mode > 1);
             if (h->cv_adj) h->cv_few = false;
         }
@@ -254,7 +254,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
                     h->cv_col_hi[k] = std::max(h->cv_col_hi[k], rh[((size_t)g * K + k) * 2 + 1]);
                 }
         }
-        h->drift_nstate = h->cv_adj ? adj_nstate(h->model, h->d)
+        h->drift_nstate = h->cv_adj ? adj_nstate(h->model, h->d, h->cv_full)
                         : h->cv_single ? (h->model == SSDE_MODEL_CTCRW ? 14 + 2 * 14 + 2 * 4 : 5 + 2 * 5 + 2 * 2) : colvar_nstate(h->model, h->d, h->cv_kc, h->cv_full);
         if (h->has_h) {
             DevBuf<double> hs;

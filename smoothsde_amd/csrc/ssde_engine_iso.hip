@@ -551,7 +551,7 @@ int eval_iso(ssde_handle* h, const double* par, int order, double* out_dev, hipS
             h->last_kernel_id = h->cv_adj ? SSDE_KERNEL_ISO_ADJ : h->cv_single ? SSDE_KERNEL_ISO_FULL : h->cv_few ? SSDE_KERNEL_ISO_FEW : SSDE_KERNEL_ISO_COLVAR;
             if (h->cv_adj) {
                 // checkpoints: the state entering every CB-th row from a window's first scored row to where its backward recursion starts
-                const int items = adj_items(h->n_groups, a.n_chunks), cb = adj_ckpt_rows(h->model, h->d), nst = adj_nstate(h->model, h->d) / 2;
+                const int items = adj_items(h->n_groups, a.n_chunks), cb = adj_ckpt_rows(h->model, h->d, h->cv_full), nst = adj_nstate(h->model, h->d, h->cv_full) / 2;
                 const int units = (h->glen_max + WIN_ALIGN - 1) / WIN_ALIGN;
                 a.adj_tail = a.window;
                 if (const char* e = getenv("SSDE_ADJ_DIAG")) a.adj_diag = atoi(e);

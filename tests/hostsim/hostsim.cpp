@@ -178,6 +178,57 @@ void run_adj(int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, cons
     }
 }
 
+// ... on the full-covariance lanes (AdjFull: two response columns, per-row H_array or sigma_obs^2 I, any P0)
+template <int MODEL>
+void run_adj_full(int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows, const double* times,
+                  const double* obs, const double* parmat, int q, double log_sigma_obs, const double* p0f, const double* a0,
+                  const double* harr /* d x d x n or NULL */, double* out, double* G) {
+    typedef AdjFull<MODEL> Lane;
+    constexpr int SD = Lane::SD, NF = Lane::NF, D = 2;
+    const double h = exp(log_sigma_obs) * exp(log_sigma_obs);
+    out[0] = out[1] = 0.0;
+    for (int64_t k = 0; k < n * q; k++) G[k] = 0.0;
+    for (int64_t m = 0; m < n_tracks; m++) {
+        Lane L;
+        double a[SD];
+        for (int c = 0; c < SD; c++) a[c] = 0.0;
+        if (a0) for (int c = 0; c < SD; c++) a[c] = a0[m * SD + c];
+        else for (int c = 0; c < D; c++) a[Lane::z(c)] = obs[row0[m] + c * n];
+        L.init(a, p0f);
+        LogAcc ld; ld.init();
+        double accq = 0.0;
+        std::vector<double> recs((size_t)nrows[m] * NF);
+        auto dt_of = [&](int64_t s) { const int64_t i = row0[m] + s; return (s < nrows[m] - 1) ? times[i + 1] - times[i] : 1.0; };
+        auto H_of = [&](int64_t i, double* H) { if (harr) { H[0] = harr[i * 4]; H[1] = harr[i * 4 + 2]; H[2] = harr[i * 4 + 3]; } else { H[0] = h; H[1] = 0.0; H[2] = h; } };
+        for (int64_t s = 1; s < nrows[m]; s++) {
+            const int64_t i = row0[m] + s;
+            double mu[D], y[D], H[3];
+            for (int c = 0; c < D; c++) { mu[c] = parmat[i + (int64_t)c * n]; y[c] = obs[i + c * n]; }
+            H_of(i, H);
+            typename Lane::Trans tr, tb;
+            Lane::trans(dt_of(s), parmat[i + (int64_t)D * n], q > D + 1 ? parmat[i + (int64_t)(D + 1) * n] : 0.0, tr);
+            Lane::template put_trans<1>(&recs[(size_t)s * NF], tr);
+            Lane::template get_trans<1>(&recs[(size_t)s * NF], dt_of(s), tb);
+            L.template fwd<true, 1>(tb, H, mu, y, is_na(y[0], any_nan), ld, accq, &recs[(size_t)s * NF]);
+        }
+        out[0] += 0.5 * (ld.value() + accq);
+        typename Lane::Adj A;
+        A.zero();
+        for (int64_t s = nrows[m] - 1; s >= 1; s--) {
+            const int64_t i = row0[m] + s;
+            double mu[D], y[D], H[3];
+            for (int c = 0; c < D; c++) { mu[c] = parmat[i + (int64_t)c * n]; y[c] = obs[i + c * n]; }
+            H_of(i, H);
+            AdjRowGrad<2> g;
+            Lane::template bwd<1>(A, &recs[(size_t)s * NF], H, mu, y, dt_of(s), g);
+            for (int c = 0; c < D; c++) G[i + (int64_t)c * n] = g.gmu[c];
+            G[i + (int64_t)D * n] = g.g1;
+            if (q > D + 1) G[i + (int64_t)(D + 1) * n] = g.g2;
+            if (!harr) out[1] += 2.0 * h * g.gh;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -200,6 +251,15 @@ int hostsim_kalman_adj(int model, int d, int any_nan, int64_t n, int64_t n_track
 #define ADJ(MODEL, D) if (model == MODEL && d == D) { run_adj<MODEL, D>(any_nan, n, n_tracks, row0, nrows, times, obs, parmat, q, log_sigma_obs, p0, a0, out, G); return 0; }
     ADJ(M_CTCRW, 1) ADJ(M_CTCRW, 2) ADJ(M_OU_SSM, 1) ADJ(M_OU_SSM, 2) ADJ(M_BM_SSM, 1) ADJ(M_BM_SSM, 2)
 #undef ADJ
+    return 1;
+}
+
+int hostsim_kalman_adj_full(int model, int any_nan, int64_t n, int64_t n_tracks, const int64_t* row0, const int64_t* nrows,
+                            const double* times, const double* obs, const double* parmat, int q, double log_sigma_obs, const double* p0f,
+                            const double* a0, const double* harr, double* out, double* G) {
+#define ADJF(MODEL) if (model == MODEL) { run_adj_full<MODEL>(any_nan, n, n_tracks, row0, nrows, times, obs, parmat, q, log_sigma_obs, p0f, a0, harr, out, G); return 0; }
+    ADJF(M_CTCRW) ADJF(M_OU_SSM) ADJF(M_BM_SSM)
+#undef ADJF
     return 1;
 }
 

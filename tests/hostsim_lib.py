@@ -30,8 +30,53 @@ def load():
         lib.hostsim_kalman_adj.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp,
                                            C.c_int, C.c_double, _dp, _dp, _dp, _dp]
         lib.hostsim_kalman_adj.restype = C.c_int
+        lib.hostsim_kalman_adj_full.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, _lp, _lp, _dp, _dp, _dp,
+                                                C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]
+        lib.hostsim_kalman_adj_full.restype = C.c_int
         _LIB = lib
     return _LIB
+
+
+def kalman_adj_full(pb, par):
+    """The reverse sweep on the FULL-covariance lanes (csrc/ssde_adj.hpp: AdjFull -- two response columns, per-row H_array or
+    sigma_obs^2 I, any P0): nllk (data term) and gradient, the coefficient gradient formed here as X' G."""
+    from smoothsde_amd.capi import MODEL_CODES
+    lib = load()
+    d, q, n = pb.n_dim, pb.q, pb.n
+    assert d == 2
+    par = np.asarray(par, dtype=np.float64)
+    parmat = np.zeros((n, q), order="F")
+    blocks = []
+    for j in range(q):
+        for src, off, nc in ((pb.X_fe[j], pb.off_fe + pb.fe_off[j], pb.ncol_fe[j]),
+                             (pb.X_re[j], pb.off_re + pb.re_off[j], pb.ncol_re[j])):
+            for c in range(nc):
+                col = np.ones(n) if src is None else src[:, c]
+                parmat[:, j] += col * par[off + c]
+                blocks.append((j, off + c, col))
+    row0 = np.ascontiguousarray(pb.seg_start, dtype=np.int64)
+    nrows = np.diff(np.append(pb.seg_start, n)).astype(np.int64)
+    sd = 4 if pb.model == "CTCRW" else 2
+    if pb.P0 is None:
+        P0 = np.diag([1.0, 10.0, 1.0, 10.0]) if pb.model == "CTCRW" else np.diag([10.0, 10.0])
+    else:
+        P0 = np.asarray(pb.P0, dtype=float)
+    p0f = np.asfortranarray(P0).ravel(order="F")
+    a0 = None if pb.a0 is None else np.ascontiguousarray(pb.a0)
+    harr = None if pb.H is None else np.ascontiguousarray(np.transpose(np.asarray(pb.H, dtype=float), (2, 1, 0)).reshape(n, 4))   # [i][col][row]: column-major d x d per row
+    out = np.zeros(2)
+    G = np.zeros((n, q), order="F")
+    st = lib.hostsim_kalman_adj_full(MODEL_CODES[pb.model], int(pb.na_mode == 1), n, pb.n_seg, row0.ctypes.data_as(_lp),
+                                     nrows.ctypes.data_as(_lp), pb.times.ctypes.data_as(_dp), pb.obs.ctypes.data_as(_dp),
+                                     parmat.ctypes.data_as(_dp), q, float(par[0]), p0f.ctypes.data_as(_dp),
+                                     None if a0 is None else a0.ctypes.data_as(_dp), None if harr is None else harr.ctypes.data_as(_dp),
+                                     out.ctypes.data_as(_dp), G.ctypes.data_as(_dp))
+    assert st == 0
+    grad = np.zeros(pb.n_par_full)
+    grad[0] = out[1]
+    for j, pidx, col in blocks:
+        grad[pidx] += float(col @ G[:, j])
+    return out[0], grad
 
 
 def kalman_adj(pb, par):

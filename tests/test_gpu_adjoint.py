@@ -154,6 +154,39 @@ def test_one_response_column_with_h_array():
     eng.close()
 
 
+@pytest.mark.parametrize("model,k1,k2,what", [("CTCRW", 9, 9, "plain"), ("CTCRW", 5, 0, "missing"), ("CTCRW", 0, 7, "irregular"), ("CTCRW", 6, 6, "both"),
+                                              ("OU_SSM", 6, 5, "plain"), ("BM_SSM", 7, 0, "missing"), ("OU_SSM", 4, 4, "both")])
+def test_error_ellipses_on_every_fix_full_covariance_lanes(model, k1, k2, what):
+    """Two response columns with a per-row measurement covariance (H_array, nllk_ctcrw.hpp:203-205): the dimensions couple, the
+    covariance is a full 4 x 4 (CTCRW) / 2 x 2 (OU_SSM, BM_SSM) and the reverse sweep runs AdjFull (ssde_adj.hpp) -- 14 / 5 doubles of
+    state and of adjoint; missing rows, irregular grids, a general P0; the drift intercepts free."""
+    from test_gpu_colvar import _with_h
+    pb, par = _batch(model, 2, 96, 900, k1, k2, seed=61, same_basis=(what == "plain"))
+    o, t = pb.obs.copy(), pb.times.copy()
+    rng = np.random.default_rng(6)
+    if what in ("missing", "both"):
+        na = rng.random(len(t)) < 0.05
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan
+    if what in ("irregular", "both"):
+        t = np.cumsum(rng.uniform(0.4, 1.6, len(t)))
+    P0 = None
+    if what == "both":
+        sd = 4 if model == "CTCRW" else 2
+        A = rng.standard_normal((sd, sd))
+        P0 = A @ A.T + np.eye(sd)
+    pb2 = capi.Problem(model, pb.id, t, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, H=_with_h(pb, 7), P0=P0)
+    eng = capi.Engine(pb2)
+    assert _is_colvar(eng)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["kernel_id"] == K_ADJ and inf["lanes_per_track"] > 1 and inf["window_check"] <= 1e-11
+    _close(val, grad, *_oracle(pb2, par))
+    assert grad[0] == 0.0                                        # log_sigma_obs is not in the model
+    assert abs(eng.eval(par, order=0) - val) <= 1e-12 * max(1.0, abs(val))
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_against_the_oracle(seed):
     rng = np.random.default_rng(7000 + seed)

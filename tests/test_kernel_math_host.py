@@ -6,7 +6,7 @@ import pytest
 
 from cases import problem_from_spec
 from golden_io import load_golden
-from hostsim_lib import kalman_adj, kalman_iso, kalman_tv, load
+from hostsim_lib import kalman_adj, kalman_adj_full, kalman_iso, kalman_tv, load
 from oracle_lib import oracle_eval
 
 GOLD = {r["name"]: r for r in load_golden()}
@@ -62,6 +62,25 @@ def test_adjoint_lane_math_matches_oracle(name):
     tgrad[pb.par_fixed != 0] = 0.0
     assert abs(val - tval) <= 1e-12 * max(1.0, abs(tval))
     assert np.max(np.abs(grad - tgrad)) <= 1e-10 * np.max(np.abs(tgrad)) + 1e-12
+
+
+FULL = [n for n in GOLD if GOLD[n]["model"] in ("CTCRW", "OU_SSM", "BM_SSM") and GOLD[n]["n_dim"] == 2]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_adjoint_full_covariance_lane_math_matches_oracle(name):
+    """csrc/ssde_adj.hpp, AdjFull: the reverse sweep with a full covariance -- per-row H_array (nllk_ctcrw.hpp:203-205), a P0 that is
+    not block-identical, and (the special case) sigma_obs^2 I with the default P0 -- on every golden Kalman case with two response columns."""
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = np.asarray(rec["par"], dtype=np.float64)
+    val, grad = kalman_adj_full(pb, par)
+    oval, ograd = oracle_eval(pb, par, order=1, data_only=True)
+    grad[pb.par_fixed != 0] = 0.0
+    if pb.H is not None:
+        grad[0] = 0.0
+    assert abs(val - oval) <= 1e-11 * max(1.0, abs(oval)), (val, oval)
+    assert np.max(np.abs(grad - ograd)) <= 1e-9 * np.max(np.abs(ograd)) + 1e-11, (grad, ograd)
 
 
 @pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 5, 10])
