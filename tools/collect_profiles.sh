@@ -50,8 +50,10 @@ bash tools/pmc_kernel.sh "iso_full" ${TAG}_isofull -- python3 $ROOT/tools/bench_
 cp gpurun_out/pmc_${TAG}_isofull.txt "$OUT/" 2>/dev/null || true
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/colvar_stats" -o stats --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track > "$OUT/colvar_under_rocprof.log" 2>&1 ) || true
 find "$OUT/colvar_stats" -name "*kernel_trace*" -delete 2>/dev/null || true
-bash tools/pmc_kernel.sh "iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > /dev/null 2>&1 || true
-( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_colvar" -d "$OUT/pmc_colvar_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > "$OUT/pmc_colvar_fetch.log" 2>&1 ) || true
+bash tools/pmc_kernel.sh "iso_adj|iso_colvar" ${TAG}_colvar -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > /dev/null 2>&1 || true
+bash tools/pmc_kernel.sh "iso_adj|iso_colvar" ${TAG}_colvar_h -- python3 $ROOT/tools/bench_colvar.py --with-h --only lane=track --evals 5 > /dev/null 2>&1 || true
+cp gpurun_out/pmc_${TAG}_colvar_h.txt "$OUT/" 2>/dev/null || true
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "iso_adj|iso_colvar" -d "$OUT/pmc_colvar_fetch" -o fetch --output-format csv -- python3 $ROOT/tools/bench_colvar.py --only lane=track --evals 5 > "$OUT/pmc_colvar_fetch.log" 2>&1 ) || true
 cp gpurun_out/pmc_${TAG}_colvar.txt "$OUT/" 2>/dev/null || true
 echo "[collect] colvar kernel done"
 # round 3, last part: one missing row in every track -- quiet rows of the general kernel, against SSDE_NO_QUIET=1

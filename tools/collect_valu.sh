@@ -19,8 +19,9 @@ for w in headline share8 headline_ou c2 irregular missing missing_one row_varyin
   one $w "iso_|tv_|direct_|dense_" python3 $ROOT/tools/valu_workload.py $w 3
 done
 one drift "iso_drift" python3 $ROOT/tools/bench_drift.py 10000 10000 9
-one few "iso_few|iso_colvar" python3 $ROOT/tools/bench_colvar.py --linear --only lane=track --evals 4
+one few "iso_few|iso_colvar|iso_adj" python3 $ROOT/tools/bench_colvar.py --linear --only lane=track --evals 4
 one direct_c3 "direct_fast_kernel" python3 $ROOT/tools/bench_c3.py
+one row_varying_h "iso_adj|iso_colvar" python3 $ROOT/tools/bench_colvar.py --with-h --only adjoint --evals 4
 find "$OUT" -type f -size +8M -print -delete
 du -sh "$OUT"
 ls "$OUT"

@@ -19,7 +19,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for f in glob.glob(out + "/raw/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVE_CYCLES":
             cnt[k] += 1

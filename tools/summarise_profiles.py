@@ -87,7 +87,7 @@ try:   # FETCH_SIZE of the drift kernel (same x2 calibration)
 except Exception as e:  # noqa: BLE001
     print("no drift PMC:", e)
 # round 3, second half: the row-varying tau / nu kernel (k_iso_colvar.hip)
-for name in ("colvar.txt", f"pmc_{tag}_colvar.txt", f"pmc_{tag}_isofull.txt", "quiet.txt", f"pmc_{tag}_quiet.txt"):
+for name in ("colvar.txt", f"pmc_{tag}_colvar.txt", f"pmc_{tag}_colvar_h.txt", f"pmc_{tag}_isofull.txt", "quiet.txt", f"pmc_{tag}_quiet.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, pre + name.replace(f"pmc_{tag}_", "pmc_"))
@@ -98,13 +98,14 @@ try:
         with open(pre + "colvar_kernel_stats.csv", "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
             w.writeheader(); w.writerows(rows)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_colvar_fetch", "fetch_counter_collection.csv")))
-            if "iso_colvar" in r["Kernel_Name"]]
-    if vals:
-        with open(pre + "pmc_colvar_fetch.txt", "w") as fh:
-            fh.write(f"iso_colvar_kernel: {len(vals)} dispatches, FETCH_SIZE avg {sum(vals) / len(vals):.1f} KiB -> {2 * 1024 * sum(vals) / len(vals) / 1e9:.3f} GB per launch "
-                     f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_colvar.py (1e4 CTCRW x 1e3, 18 streamed columns: 160 B/row required = 1.6 GB, "
-                     f"plus the warm-up rows of the time windows)\n")
+    with open(pre + "pmc_colvar_fetch.txt", "w") as fh:
+        for fam in ("iso_adj", "iso_colvar"):
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, "pmc_colvar_fetch", "fetch_counter_collection.csv")))
+                    if fam in r["Kernel_Name"]]
+            if vals:
+                fh.write(f"{fam}_kernel: {len(vals)} dispatches, FETCH_SIZE avg {sum(vals) / len(vals):.1f} KiB -> {2 * 1024 * sum(vals) / len(vals) / 1e9:.3f} GB per launch "
+                         f"(x2 calibration of tools/microbench_fetch.hip); tools/bench_colvar.py (1e4 CTCRW x 1e3, 18 design columns of which 9 distinct: 88 B/row "
+                         f"required = 0.88 GB; the reverse sweep reads every row twice, plus the warm-up and trailing rows of the time windows and its checkpoints)\n")
 except Exception as e:  # noqa: BLE001
     print("no colvar profile:", e)
 try:

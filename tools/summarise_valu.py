@@ -15,14 +15,14 @@ src = os.path.join(ROOT, "gpurun_out", f"valu_{tag}")
 # rows the dominant launch scores, for the workloads whose script does not print them
 KNOWN_ROWS = {"drift": 10_000 * 9_999, "direct_c3": 10_000 * 9_999, "few": 10_000 * 999}
 FAMILIES = ("iso_shared_kernel", "iso_mask_kernel", "iso_quiet_kernel", "iso_kernel", "iso_drift_kernel", "iso_drift_general_kernel",
-            "iso_colvar_kernel", "iso_few_kernel", "iso_full_kernel", "dense_kernel", "tv_filter_kernel", "direct_fast_kernel", "direct_kernel")
+            "iso_colvar_kernel", "iso_adj_kernel", "iso_few_kernel", "iso_full_kernel", "dense_kernel", "tv_filter_kernel", "direct_fast_kernel", "direct_kernel")
 table, lines = {}, []
 for f in sorted(glob.glob(os.path.join(src, "*.csv"))):
     name = os.path.basename(f)[:-4]
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ssde::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ssde::", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_INSTS_VALU":
             cnt[k] += 1
