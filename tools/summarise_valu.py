@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"valu_{tag}")
 # rows the dominant launch scores, for the workloads whose script does not print them
-KNOWN_ROWS = {"drift": 10_000 * 9_999, "direct_c3": 10_000 * 9_999, "few": 10_000 * 999}
+KNOWN_ROWS = {"drift": 10_000 * 9_999, "direct_c3": 10_000 * 9_999, "few": 10_000 * 999, "row_varying_h": 10_000 * 999}
 FAMILIES = ("iso_shared_kernel", "iso_mask_kernel", "iso_quiet_kernel", "iso_kernel", "iso_drift_kernel", "iso_drift_general_kernel",
             "iso_colvar_kernel", "iso_adj_kernel", "iso_few_kernel", "iso_full_kernel", "dense_kernel", "tv_filter_kernel", "direct_fast_kernel", "direct_kernel")
 table, lines = {}, []
