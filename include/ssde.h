@@ -364,7 +364,7 @@ int ssde_forget(ssde_handle *h);
  *           coeff_re entries hold u^ (TMB's par.random / env$last.par)
  *   order   0: *value;  1: also grad[n_par_full] = df/dtheta (zeros at coeff_re and at fixed entries)
  *   hess_uu NULL or [n_u x n_u] column-major: H_uu at u^ (the random-effect block of sdreport's jointPrecision)
- * Direct families BM / OU: H_uu and H_u,theta are EXACT (ssde_hess), only 1/2 d log det H_uu / dtheta is a central
+ * Direct families BM / OU / BM_t: H_uu and H_u,theta are EXACT (ssde_hess), only 1/2 d log det H_uu / dtheta is a central
  * difference -- of exact Hessians, along the implicit-function tangent of u^.  Elsewhere H_uu comes from central
  * differences of the device gradient.  The inner problem is solved by Newton iterations; the gradient is the exact
  * dg/dtheta at u^ plus that log-determinant term (ssde_laplace.hip).  A joint nllk that has no minimum in u gives

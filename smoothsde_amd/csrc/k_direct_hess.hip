@@ -1,4 +1,4 @@
-// k_direct_hess.hip -- EXACT second derivatives of the data term of the direct families "BM" and "OU" with respect to
+// k_direct_hess.hip -- EXACT second derivatives of the data term of the direct families "BM", "OU" and "BM_t" with respect to
 // coefficients of the linear predictor (nllk_sde.hpp:61-84 with tr_dens.hpp:32-37, 45-52), for gfx950.
 //
 // What the reference gets from TMB's second-order AD (tmb_obj_joint$he, R/sde.R:1363; the Laplace approximation's
@@ -22,6 +22,20 @@ __device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, 
     for (int p = 0; p < MAX_Q; p++)
 #pragma unroll
         for (int q = 0; q < MAX_Q; q++) Dm[p][q] = 0.0;
+    if (MODEL == M_BM_T) {
+        // BM_t (tr_dens.hpp:38-44; one response column): l = phi(x) + log scale + const, phi(x) = (df + 1) / 2 log(1 + x^2 / df),
+        // x = (z1 - z0 - mu dt) / scale, scale = e^{ls} sqrt(dt) / sqrt(df / (df - 2)):  d x / d mu = -dt / scale,  d x / d ls = -x
+        const double df = A.tdf;
+        const double scale = exp(par[1]) * sqrt(dt) / sqrt(df / (df - 2.0)), isc = 1.0 / scale;
+        const double z0 = A.obs[i - 1], z1 = A.obs[i];
+        if (!(is_na(z0, A.any_nan) || is_na(z1, A.any_nan))) {
+            const double x = (z1 - z0 - par[0] * dt) * isc, den = 1.0 / (df + x * x);
+            const double p1 = (df + 1.0) * x * den, p2 = (df + 1.0) * (df - x * x) * den * den;      // phi', phi''
+            Dm[0][0] = p2 * dt * dt * isc * isc;
+            Dm[0][1] = Dm[1][0] = (p2 * x + p1) * dt * isc;
+            Dm[1][1] = (p2 * x + p1) * x;
+        }
+    } else
     if (MODEL == M_BM) {
         const double sd = exp(par[D]) * sqrt(dt), isd = 1.0 / sd;
 #pragma unroll
@@ -162,6 +176,7 @@ hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks
     else if (a.model == M_BM && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 2>), grid, block, 0, s, a);
     else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 1>), grid, block, 0, s, a);
     else if (a.model == M_OU && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 2>), grid, block, 0, s, a);
+    else if (a.model == M_BM_T && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_BM_T, 1>), grid, block, 0, s, a);
     else return hipErrorInvalidValue;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -447,6 +447,7 @@ struct DirectHessArgs {
     const uint32_t* scored;
     int64_t n;
     int d, model, any_nan;
+    double tdf;                  // BM_t: degrees of freedom (other_data(0), tr_dens.hpp:40)
     const SlotTable* slots;      // device
     const double* par;           // device, full parameter vector
     int n_slots;

@@ -31,7 +31,7 @@ static int scope_one(const ssde_handle* e) {
         return is_eseal(e->model) ? 0 : 3;
     }
     if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
-    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
+    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU || e->model == SSDE_MODEL_BM_T) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
     for (auto& sl : e->slots) if (sl.col == -2) return 0;           // a block evaluated from its basis table has no columns to read
     return 2;
 }
@@ -132,6 +132,7 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     memset(&a, 0, sizeof(a));
     a.times = h->times.p; a.obs = h->obs.p; a.cols = h->colptr.p; a.scored = h->scored.p; a.n = h->n;
     a.d = h->d; a.model = h->model; a.any_nan = h->na_any; a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
+    a.tdf = h->tdf;
     a.nu = nu; a.uslot = p_us; a.tile_i = p_ti; a.tile_j = p_tj; a.partials = h->hs_partials.p; a.hess = h->hs_hess.p;
     HIPCHK(h, launch_direct_hess(a, n_tiles, n_blocks, s));
     HIPCHK(h, hipStreamSynchronize(s));

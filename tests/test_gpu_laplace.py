@@ -117,7 +117,7 @@ def test_sdreport_quantities_on_the_device_gradient_match_autograd_hessians(name
     eng.close()
 
 
-# ---- exact second derivatives (ssde_hess: direct families BM / OU) -----------------------------------------------------
+# ---- exact second derivatives (ssde_hess: direct families BM / OU / BM_t) -----------------------------------------------------
 def _joint_fn(pb, p0, idx):
     def f(x):
         p = p0.clone()
@@ -126,7 +126,8 @@ def _joint_fn(pb, p0, idx):
     return f
 
 
-@pytest.mark.parametrize("name", ["OU_d1_tv", "OU_d2_tv", "BM_d1_tv", "BM_d2_tv", "OU_d1_tv2", "OU_d1_const", "BM_d2_const"])
+@pytest.mark.parametrize("name", ["OU_d1_tv", "OU_d2_tv", "BM_d1_tv", "BM_d2_tv", "OU_d1_tv2", "OU_d1_const", "BM_d2_const",
+                                  "BM_t_d1_tv", "BM_t_d1_const"])
 def test_exact_hessian_matches_autograd(name):
     """tmb_obj_joint$he(x) (R/sde.R:1363): every coefficient and log_lambda entry, missing rows included."""
     rec = GOLD[name]
@@ -205,7 +206,7 @@ def test_row_varying_hessian_on_a_long_track_with_time_windows(monkeypatch):
 
 
 def test_exact_hessian_is_refused_where_it_does_not_exist():
-    for name in ("BM_t_d1_tv", "OU_d1_decay", "ESEAL_const"):
+    for name in ("CIR_d1_const", "OU_d1_decay", "ESEAL_const"):
         rec = GOLD[name]
         pb = problem_from_spec(rec)
         eng = capi.Engine(pb)

@@ -538,7 +538,7 @@ def test_shared_covariance_path_mixed_groups(model, par, d, monkeypatch):
     monkeypatch.setenv("SSDE_NO_SHARED", "1")
     gen = capi.Engine(pb)
     v2, g2 = gen.eval(par)
-    assert eng.info()["kernel_id"] == 3 and gen.info()["kernel_id"] in (5, 6)           # iso_shared_kernel / the general lanes on a regular grid
+    assert eng.info()["kernel_id"] in (3, 7) and gen.info()["kernel_id"] in (5, 6)           # iso_shared_kernel (alone or beside a general kernel) / the general lanes
     assert abs(v - v2) <= 1e-12 * abs(v2)
     assert np.max(np.abs(g - g2)) <= 1e-10 * np.max(np.abs(g2))
     eng.close(); gen.close()
