@@ -40,17 +40,21 @@ inline bool is_na(double x, int na_mode) {
 // Small dense matrices (the reference uses heap-allocated Eigen dynamic matrices,
 // tmbutils matrix<Type>; state dimension is at most 2*n_dim).
 // ---------------------------------------------------------------------------------------
-constexpr int MAXD = 8;
+constexpr int MAXD = 16;         // widest state: CTCRW with eight response columns run as one filter
+constexpr int MAT_INLINE = 64;   // entries kept in the object (sdim <= 8: every configuration but the widest coupled responses)
 
 template <class Type>
 struct Mat {
     int r, c;
-    Type a[MAXD * MAXD];
+    Type small_[MAT_INLINE];
+    std::vector<Type> big_;       // used beyond MAT_INLINE entries only
     Mat() : r(0), c(0) {}
-    Mat(int r_, int c_) : r(r_), c(c_) { setZero(); }
-    void setZero() { for (int i = 0; i < r * c; i++) a[i] = Type(0.0); }
-    Type& operator()(int i, int j) { return a[i + j * r]; }
-    const Type& operator()(int i, int j) const { return a[i + j * r]; }
+    Mat(int r_, int c_) : r(r_), c(c_) { if (r * c > MAT_INLINE) big_.resize((size_t)r * c); setZero(); }
+    Type* data() { return big_.empty() ? small_ : big_.data(); }
+    const Type* data() const { return big_.empty() ? small_ : big_.data(); }
+    void setZero() { Type* a = data(); for (int i = 0; i < r * c; i++) a[i] = Type(0.0); }
+    Type& operator()(int i, int j) { return data()[i + j * r]; }
+    const Type& operator()(int i, int j) const { return data()[i + j * r]; }
 };
 
 template <class Type>
@@ -71,13 +75,13 @@ Mat<Type> transpose(const Mat<Type>& A) {
 template <class Type>
 Mat<Type> add(const Mat<Type>& A, const Mat<Type>& B) {
     Mat<Type> C(A.r, A.c);
-    for (int i = 0; i < A.r * A.c; i++) C.a[i] = A.a[i] + B.a[i];
+    for (int i = 0; i < A.r * A.c; i++) C.data()[i] = A.data()[i] + B.data()[i];
     return C;
 }
 template <class Type>
 Mat<Type> sub(const Mat<Type>& A, const Mat<Type>& B) {
     Mat<Type> C(A.r, A.c);
-    for (int i = 0; i < A.r * A.c; i++) C.a[i] = A.a[i] - B.a[i];
+    for (int i = 0; i < A.r * A.c; i++) C.data()[i] = A.data()[i] - B.data()[i];
     return C;
 }
 

@@ -102,9 +102,8 @@ __global__ __launch_bounds__(WAVE) void dense_kernel(const DenseArgs A) {
     }
 }
 
-hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s) {
-    if (a.tv.n_groups == 0) return hipSuccess;
-    dim3 block(WAVE);
+hipError_t launch_dense_wide(const DenseArgs& a, bool want_grad, hipStream_t s);     // k_dense_wide.hip: five to eight columns
+
 #define SSDE_L(MODEL, D)                                                                          \
     if (a.model == MODEL && a.d == D) {                                                           \
         if (a.report)                                                                             \
@@ -115,12 +114,27 @@ hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s) {
             hipLaunchKernelGGL((dense_kernel<MODEL, D, DENSE_NT, false>), dim3(a.tv.n_groups, a.n_dirblocks), block, 0, s, a); \
         return hipGetLastError();                                                                 \
     }
+#ifndef SSDE_DENSE_WIDE_TU
+hipError_t launch_dense(const DenseArgs& a, bool want_grad, hipStream_t s) {
+    if (a.tv.n_groups == 0) return hipSuccess;
+    dim3 block(WAVE);
     SSDE_L(M_CTCRW, 1) SSDE_L(M_CTCRW, 2) SSDE_L(M_OU_SSM, 1) SSDE_L(M_OU_SSM, 2) SSDE_L(M_BM_SSM, 1) SSDE_L(M_BM_SSM, 2)
     // responses of three or four columns whose measurement covariance or P0 couples the columns (ssde_engine_dist.hip sends every
     // other wide response to this engine pair by pair): one filter over all columns, F by LU as the reference does it
     SSDE_L(M_CTCRW, 3) SSDE_L(M_CTCRW, 4) SSDE_L(M_OU_SSM, 3) SSDE_L(M_OU_SSM, 4) SSDE_L(M_BM_SSM, 3) SSDE_L(M_BM_SSM, 4)
-#undef SSDE_L
+    return launch_dense_wide(a, want_grad, s);
+}
+#else
+// five to eight columns: the same step; the lane's covariance (up to 16 x 16 duals) lives in scratch memory there -- the coverage
+// path of a rare configuration (the reference's atomic::logdet branch, nllk_ctcrw.hpp:20-22), not a throughput path
+hipError_t launch_dense_wide(const DenseArgs& a, bool want_grad, hipStream_t s) {
+    dim3 block(WAVE);
+    SSDE_L(M_CTCRW, 5) SSDE_L(M_CTCRW, 6) SSDE_L(M_CTCRW, 7) SSDE_L(M_CTCRW, 8)
+    SSDE_L(M_OU_SSM, 5) SSDE_L(M_OU_SSM, 6) SSDE_L(M_OU_SSM, 7) SSDE_L(M_OU_SSM, 8)
+    SSDE_L(M_BM_SSM, 5) SSDE_L(M_BM_SSM, 6) SSDE_L(M_BM_SSM, 7) SSDE_L(M_BM_SSM, 8)
     return hipErrorInvalidValue;
 }
+#endif
+#undef SSDE_L
 
 }  // namespace ssde

@@ -17,6 +17,14 @@
 
 namespace ssde {
 
+// k_dense_wide.hip (five to eight response columns) compiles the step with its loops kept as loops: fully unrolled, the 16 x 16
+// covariance of dual numbers needs ~800 spilled scalar registers and the generated code gave wrong tangents at sdim = 16
+#ifdef SSDE_DENSE_NOUNROLL
+#define SSDE_DLOOP _Pragma("nounroll")
+#else
+#define SSDE_DLOOP
+#endif
+
 template <int N>
 struct DualN {
     double v;
@@ -53,32 +61,32 @@ template <int N> SSDE_HD DualN<N> dsqrt(const DualN<N>& a) {
     DualN<N> r; r.v = sqrt(a.v); const double h = 0.5 / r.v; for (int k = 0; k < N; k++) r.d[k] = a.d[k] * h; return r; }
 template <int N> SSDE_HD DualN<N> dfabs(const DualN<N>& a) { return a.v < 0.0 ? -a : a; }
 
-// ---- d x d helpers for responses wider than two columns (n_dim = 3, 4 with a measurement covariance or a P0 that couples the
+// ---- d x d helpers for responses wider than two columns (n_dim = 3 ... 8 with a measurement covariance or a P0 that couples the
 // columns): what Eigen's F.inverse() and TMB's atomic::logdet do in the reference (nllk_ctcrw.hpp:12-24, 231, 236) -- Gaussian
 // elimination with partial pivoting on the VALUES, carried out in dual arithmetic so the tangents follow
 template <int D, class T_>
 SSDE_HD void dense_lu(const T_ (&F)[D][D], T_ (&LU)[D][D], int (&piv)[D], int& sign) {
-    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) LU[i][j] = F[i][j];
+    SSDE_DLOOP for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) LU[i][j] = F[i][j];
     sign = 1;
-    for (int k = 0; k < D; k++) {
+    SSDE_DLOOP for (int k = 0; k < D; k++) {
         int p = k;
         double best = fabs(LU[k][k].v);
-        for (int i = k + 1; i < D; i++) if (fabs(LU[i][k].v) > best) { best = fabs(LU[i][k].v); p = i; }
+        SSDE_DLOOP for (int i = k + 1; i < D; i++) if (fabs(LU[i][k].v) > best) { best = fabs(LU[i][k].v); p = i; }
         piv[k] = p;
         if (p != k) {
             sign = -sign;
-            for (int j = 0; j < D; j++) {
+            SSDE_DLOOP for (int j = 0; j < D; j++) {
                 // (static indices only: a select per candidate row keeps the matrix in registers on the device)
                 T_ a = LU[k][j], b = LU[k][j];
-                for (int i = k + 1; i < D; i++) if (i == p) b = LU[i][j];
+                SSDE_DLOOP for (int i = k + 1; i < D; i++) if (i == p) b = LU[i][j];
                 LU[k][j] = b;
-                for (int i = k + 1; i < D; i++) if (i == p) LU[i][j] = a;
+                SSDE_DLOOP for (int i = k + 1; i < D; i++) if (i == p) LU[i][j] = a;
             }
         }
         const T_ ip = 1.0 / LU[k][k];
-        for (int i = k + 1; i < D; i++) {
+        SSDE_DLOOP for (int i = k + 1; i < D; i++) {
             LU[i][k] = LU[i][k] * ip;
-            for (int j = k + 1; j < D; j++) LU[i][j] = LU[i][j] - LU[i][k] * LU[k][j];
+            SSDE_DLOOP for (int j = k + 1; j < D; j++) LU[i][j] = LU[i][j] - LU[i][k] * LU[k][j];
         }
     }
 }
@@ -88,7 +96,7 @@ SSDE_HD T_ dense_det_lu(const T_ (&F)[D][D]) {
     int piv[D], sign;
     dense_lu<D, T_>(F, LU, piv, sign);
     T_ det((double)sign);
-    for (int k = 0; k < D; k++) det = det * LU[k][k];
+    SSDE_DLOOP for (int k = 0; k < D; k++) det = det * LU[k][k];
     return det;
 }
 template <int D, class T_>
@@ -96,21 +104,21 @@ SSDE_HD void dense_inverse_lu(const T_ (&F)[D][D], T_ (&Fi)[D][D]) {
     T_ LU[D][D];
     int piv[D], sign;
     dense_lu<D, T_>(F, LU, piv, sign);
-    for (int c = 0; c < D; c++) {
+    SSDE_DLOOP for (int c = 0; c < D; c++) {
         T_ x[D];
-        for (int i = 0; i < D; i++) x[i] = T_(i == c ? 1.0 : 0.0);
-        for (int k = 0; k < D; k++) {                                // the row interchanges, in order
+        SSDE_DLOOP for (int i = 0; i < D; i++) x[i] = T_(i == c ? 1.0 : 0.0);
+        SSDE_DLOOP for (int k = 0; k < D; k++) {                                // the row interchanges, in order
             T_ a = x[k], b = x[k];
-            for (int i = k + 1; i < D; i++) if (i == piv[k]) b = x[i];
+            SSDE_DLOOP for (int i = k + 1; i < D; i++) if (i == piv[k]) b = x[i];
             x[k] = b;
-            for (int i = k + 1; i < D; i++) if (i == piv[k]) x[i] = a;
+            SSDE_DLOOP for (int i = k + 1; i < D; i++) if (i == piv[k]) x[i] = a;
         }
-        for (int i = 1; i < D; i++) for (int j = 0; j < i; j++) x[i] = x[i] - LU[i][j] * x[j];            // L y = P e_c
-        for (int i = D - 1; i >= 0; i--) {
-            for (int j = i + 1; j < D; j++) x[i] = x[i] - LU[i][j] * x[j];
+        SSDE_DLOOP for (int i = 1; i < D; i++) for (int j = 0; j < i; j++) x[i] = x[i] - LU[i][j] * x[j];            // L y = P e_c
+        SSDE_DLOOP for (int i = D - 1; i >= 0; i--) {
+            SSDE_DLOOP for (int j = i + 1; j < D; j++) x[i] = x[i] - LU[i][j] * x[j];
             x[i] = x[i] / LU[i][i];
         }
-        for (int i = 0; i < D; i++) Fi[i][c] = x[i];
+        SSDE_DLOOP for (int i = 0; i < D; i++) Fi[i][c] = x[i];
     }
 }
 
@@ -128,9 +136,9 @@ struct DenseLane {
     DualN<N> P[SD][SD];
     DualN<N> nll;
     SSDE_HD void init(const double* a0, const double* p0 /* SD x SD column-major */) {
-        for (int i = 0; i < SD; i++) {
+        SSDE_DLOOP for (int i = 0; i < SD; i++) {
             a[i] = DualN<N>(a0[i]);
-            for (int j = 0; j < SD; j++) P[i][j] = DualN<N>(p0[i + j * SD]);
+            SSDE_DLOOP for (int j = 0; j < SD; j++) P[i][j] = DualN<N>(p0[i + j * SD]);
         }
         nll = DualN<N>(0.0);
     }
@@ -160,7 +168,7 @@ SSDE_HD void dense_step_g(ST& L, const T_* par, const T_ (&H)[D][D], double dt, 
         q11 = sb * sb * (dt - 2.0 / beta * (1.0 - e) + 1.0 / (2.0 * beta) * (1.0 - e2));  // makeQ :68-69
         q12 = sigma * sigma / (2.0 * beta * beta) * (1.0 - 2.0 * e + e2);                  // :70
         q22 = sigma * sigma / (2.0 * beta) * (1.0 - e2);                                   // :72
-        for (int a = 0; a < D; a++) {
+        SSDE_DLOOP for (int a = 0; a < D; a++) {
             drift[2 * a] = (dt - t12) * par[a];                    // makeB :87
             drift[2 * a + 1] = (1.0 - e) * par[a];                 // makeB :88
         }
@@ -168,67 +176,67 @@ SSDE_HD void dense_step_g(ST& L, const T_* par, const T_ (&H)[D][D], double dt, 
         const T_ tau = dexp(par[D]), kappa = dexp(par[D + 1]);     // nllk_ou_ssm.hpp:123-124
         e = dexp(-dt / tau);                                       // makeT :35   (-dt/tau)
         q11 = kappa * (1.0 - dexp(-2.0 * dt / tau));               // makeQ :66
-        for (int a = 0; a < D; a++) drift[a] = (1.0 - e) * par[a]; // makeB :50
+        SSDE_DLOOP for (int a = 0; a < D; a++) drift[a] = (1.0 - e) * par[a]; // makeB :50
     } else {
         const T_ sigma = dexp(par[D]);                             // nllk_bm_ssm.hpp:90
         q11 = sigma * sigma * dt;                                  // makeQ :33
-        for (int a = 0; a < D; a++) drift[a] = par[a] * dt;        // :139
+        SSDE_DLOOP for (int a = 0; a < D; a++) drift[a] = par[a] * dt;        // :139
     }
 
     // TP = T P using the sparsity of T
     T_ TP[SD][SD];
-    for (int c = 0; c < SD; c++) {
+    SSDE_DLOOP for (int c = 0; c < SD; c++) {
         if (MODEL == M_CTCRW) {
-            for (int a = 0; a < D; a++) {
+            SSDE_DLOOP for (int a = 0; a < D; a++) {
                 TP[2 * a][c] = L.P[2 * a][c] + t12 * L.P[2 * a + 1][c];
                 TP[2 * a + 1][c] = e * L.P[2 * a + 1][c];
             }
         } else if (MODEL == M_OU_SSM) {
-            for (int r = 0; r < SD; r++) TP[r][c] = e * L.P[r][c];
+            SSDE_DLOOP for (int r = 0; r < SD; r++) TP[r][c] = e * L.P[r][c];
         } else {
-            for (int r = 0; r < SD; r++) TP[r][c] = L.P[r][c];
+            SSDE_DLOOP for (int r = 0; r < SD; r++) TP[r][c] = L.P[r][c];
         }
     }
     // Ta = T a
     T_ Ta[SD];
     if (MODEL == M_CTCRW) {
-        for (int a = 0; a < D; a++) { Ta[2 * a] = L.a[2 * a] + t12 * L.a[2 * a + 1]; Ta[2 * a + 1] = e * L.a[2 * a + 1]; }
+        SSDE_DLOOP for (int a = 0; a < D; a++) { Ta[2 * a] = L.a[2 * a] + t12 * L.a[2 * a + 1]; Ta[2 * a + 1] = e * L.a[2 * a + 1]; }
     } else if (MODEL == M_OU_SSM) {
-        for (int r = 0; r < SD; r++) Ta[r] = e * L.a[r];
+        SSDE_DLOOP for (int r = 0; r < SD; r++) Ta[r] = e * L.a[r];
     } else {
-        for (int r = 0; r < SD; r++) Ta[r] = L.a[r];
+        SSDE_DLOOP for (int r = 0; r < SD; r++) Ta[r] = L.a[r];
     }
     // TPT = TP T' + Q
     T_ TPT[SD][SD];
-    for (int r = 0; r < SD; r++) {
+    SSDE_DLOOP for (int r = 0; r < SD; r++) {
         if (MODEL == M_CTCRW) {
-            for (int a = 0; a < D; a++) {
+            SSDE_DLOOP for (int a = 0; a < D; a++) {
                 TPT[r][2 * a] = TP[r][2 * a] + t12 * TP[r][2 * a + 1];
                 TPT[r][2 * a + 1] = e * TP[r][2 * a + 1];
             }
         } else if (MODEL == M_OU_SSM) {
-            for (int c = 0; c < SD; c++) TPT[r][c] = e * TP[r][c];
+            SSDE_DLOOP for (int c = 0; c < SD; c++) TPT[r][c] = e * TP[r][c];
         } else {
-            for (int c = 0; c < SD; c++) TPT[r][c] = TP[r][c];
+            SSDE_DLOOP for (int c = 0; c < SD; c++) TPT[r][c] = TP[r][c];
         }
     }
     if (MODEL == M_CTCRW) {
-        for (int a = 0; a < D; a++) {
+        SSDE_DLOOP for (int a = 0; a < D; a++) {
             TPT[2 * a][2 * a] = TPT[2 * a][2 * a] + q11;
             TPT[2 * a][2 * a + 1] = TPT[2 * a][2 * a + 1] + q12;
             TPT[2 * a + 1][2 * a] = TPT[2 * a + 1][2 * a] + q12;
             TPT[2 * a + 1][2 * a + 1] = TPT[2 * a + 1][2 * a + 1] + q22;
         }
     } else {
-        for (int r = 0; r < SD; r++) TPT[r][r] = TPT[r][r] + q11;
+        SSDE_DLOOP for (int r = 0; r < SD; r++) TPT[r][r] = TPT[r][r] + q11;
     }
 
     // ---- measurement --------------------------------------------------------------------
     bool upd = !na;
     T_ F[D][D], det(1.0);
     if (upd) {
-        for (int i = 0; i < D; i++)
-            for (int j = 0; j < D; j++) F[i][j] = L.P[DM::z(i)][DM::z(j)] + H[i][j];   // F = Z P Z' + H
+        SSDE_DLOOP for (int i = 0; i < D; i++)
+            SSDE_DLOOP for (int j = 0; j < D; j++) F[i][j] = L.P[DM::z(i)][DM::z(j)] + H[i][j];   // F = Z P Z' + H
         if (D == 1) det = F[0][0];
         else if (D == 2) det = F[0][0] * F[1][1] - F[1][0] * F[0][1];                    // det(): nllk_ctcrw.hpp:16-19
         else det = dfabs(dense_det_lu<D, T_>(F));                                         // det = exp(atomic::logdet(F)) = |det F|: nllk_ctcrw.hpp:20-22
@@ -238,9 +246,9 @@ SSDE_HD void dense_step_g(ST& L, const T_* par, const T_ (&H)[D][D], double dt, 
     if (!upd) {
         // missing observation, or detF <= 0; Q3: CTCRW drops the drift in the latter case only
         const bool keep_drift = na || (MODEL != M_CTCRW);
-        for (int r = 0; r < SD; r++) L.a[r] = keep_drift ? Ta[r] + drift[r] : Ta[r];
-        for (int r = 0; r < SD; r++)
-            for (int c = 0; c < SD; c++) L.P[r][c] = TPT[r][c];
+        SSDE_DLOOP for (int r = 0; r < SD; r++) L.a[r] = keep_drift ? Ta[r] + drift[r] : Ta[r];
+        SSDE_DLOOP for (int r = 0; r < SD; r++)
+            SSDE_DLOOP for (int c = 0; c < SD; c++) L.P[r][c] = TPT[r][c];
         return;
     }
     T_ Fi[D][D];
@@ -254,33 +262,33 @@ SSDE_HD void dense_step_g(ST& L, const T_* par, const T_ (&H)[D][D], double dt, 
         Fi[1][0] = -(F[1][0] * id); Fi[1][1] = F[0][0] * id;
     }
     T_ u[D];
-    for (int i = 0; i < D; i++) u[i] = y[i] - L.a[DM::z(i)];                             // line 221
+    SSDE_DLOOP for (int i = 0; i < D; i++) u[i] = y[i] - L.a[DM::z(i)];                             // line 221
     T_ uFu(0.0);
-    for (int i = 0; i < D; i++) {
+    SSDE_DLOOP for (int i = 0; i < D; i++) {
         T_ s(0.0);
-        for (int j = 0; j < D; j++) s = s + Fi[j][i] * u[j];                             // F^-T u (lines 231-232)
+        SSDE_DLOOP for (int j = 0; j < D; j++) s = s + Fi[j][i] * u[j];                             // F^-T u (lines 231-232)
         uFu = uFu + u[i] * s;
     }
     L.nll = L.nll + (dlog(MODEL == M_CTCRW ? det : dfabs(det)) + uFu) * 0.5;             // line 234
     // K = (T P Z') F^-1   (line 236)
     T_ K[SD][D];
-    for (int r = 0; r < SD; r++)
-        for (int j = 0; j < D; j++) {
+    SSDE_DLOOP for (int r = 0; r < SD; r++)
+        SSDE_DLOOP for (int j = 0; j < D; j++) {
             T_ s(0.0);
-            for (int i = 0; i < D; i++) s = s + TP[r][DM::z(i)] * Fi[i][j];
+            SSDE_DLOOP for (int i = 0; i < D; i++) s = s + TP[r][DM::z(i)] * Fi[i][j];
             K[r][j] = s;
         }
     // a = T a + K u + drift   (line 238)
-    for (int r = 0; r < SD; r++) {
+    SSDE_DLOOP for (int r = 0; r < SD; r++) {
         T_ s = Ta[r] + drift[r];
-        for (int j = 0; j < D; j++) s = s + K[r][j] * u[j];
+        SSDE_DLOOP for (int j = 0; j < D; j++) s = s + K[r][j] * u[j];
         L.a[r] = s;
     }
     // P = T P (T - K Z)' + Q = (T P T' + Q) - (T P Z') K'   (lines 240-241)
-    for (int r = 0; r < SD; r++)
-        for (int c = 0; c < SD; c++) {
+    SSDE_DLOOP for (int r = 0; r < SD; r++)
+        SSDE_DLOOP for (int c = 0; c < SD; c++) {
             T_ s = TPT[r][c];
-            for (int j = 0; j < D; j++) s = s - TP[r][DM::z(j)] * K[c][j];
+            SSDE_DLOOP for (int j = 0; j < D; j++) s = s - TP[r][DM::z(j)] * K[c][j];
             L.P[r][c] = s;
         }
 }

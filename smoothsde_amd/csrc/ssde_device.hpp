@@ -464,6 +464,7 @@ hipError_t launch_dt_minmax(const double* times, const uint32_t* scored, int64_t
 
 // ---- dense / time-varying Kalman (k_dense.hip) ----------------------------------------------------
 constexpr int DENSE_NT = 2;      // tangent directions per lane
+constexpr int DENSE_MAXD = 8;    // widest response run as ONE filter (coupling H_array / P0); wider ones only pair by pair
 struct DenseDir {                // one gradient direction
     int16_t kind;                // 0 none, 1 log_sigma_obs, 2 coefficient slot
     int16_t slot;                // slot index (kind 2)
@@ -476,7 +477,7 @@ struct DenseArgs {
     const SlotTable* slots;      // device
     const double* par;           // device
     int n_slots;
-    double p0[64];               // sdim x sdim column-major (sdim <= 8: CTCRW with four response columns)
+    double p0[256];              // sdim x sdim column-major (sdim <= 16: CTCRW with eight response columns)
     int n_dirblocks;
     const DenseDir* dirs;        // device [n_dirblocks * DENSE_NT]
     double* partials;            // [n_dirblocks][1 + DENSE_NT][n_groups]

@@ -153,7 +153,7 @@ int eval_device(ssde_handle* h, const double* par, int order, double* out_dev, h
         a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
         a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
         a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
-        for (int i = 0; i < 64; i++) a.p0[i] = h->p0_full[i];
+        for (int i = 0; i < 256; i++) a.p0[i] = h->p0_full[i];
         a.n_dirblocks = h->n_dirblocks; a.dirs = h->dirs.p; a.partials = h->partials.p;
         a.report = nullptr; a.lane_row0 = h->lane_row0.p; a.n = h->n; a.last_dt = h->last_dt;
         if (h->stamps) HIPCHK(h, hipEventRecord(h->ev_k0, s));
@@ -669,7 +669,7 @@ int ssde_report(ssde_handle* h, const double* par, int32_t n_par_full, double* a
     a.tv.lane_nsteps = h->lane_nsteps.p; a.tv.a0 = h->a0.p; a.tv.n_groups = h->n_groups; a.tv.C = h->C; a.tv.c_obs = h->c_obs; a.tv.dt_all = h->dt_all;
     a.model = h->model; a.d = h->d; a.any_nan = h->na_any; a.has_h = h->has_h ? 1 : 0;
     a.slots = stb.p; a.par = pbuf.p; a.n_slots = st.n_slots;
-    for (int i = 0; i < 64; i++) a.p0[i] = h->p0_full[i];
+    for (int i = 0; i < 256; i++) a.p0[i] = h->p0_full[i];
     a.n_dirblocks = 1; a.dirs = nullptr; a.partials = nullptr;
     a.pp = h->pp_drift;
     a.report = rep.p; a.lane_row0 = h->lane_row0.p; a.n = nt; a.last_dt = h->last_dt;

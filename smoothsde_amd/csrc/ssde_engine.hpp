@@ -59,8 +59,8 @@ struct ssde_handle {
     double dt_uniform = 0.0;
     double tdf = 0.0, tconst = 0.0;     // BM_t: degrees of freedom, normalising constant of dt(., df)
     double p0_iso[3] = {0, 0, 0};
-    double p0_full[64] = {0};      // sdim x sdim column-major (sdim <= 8)
-    bool wide_ok = false;          // set by ssde_create for a response of 3 or 4 columns that has to run as ONE filter (coupling H_array / P0)
+    double p0_full[256] = {0};     // sdim x sdim column-major (sdim <= 16)
+    bool wide_ok = false;          // set by ssde_create for a response of 3 to 8 columns that has to run as ONE filter (coupling H_array / P0)
     ParLayout L;
     Penalty pen;
     std::vector<Slot> slots;

@@ -481,9 +481,9 @@ static int check_descriptor(const ssde_desc* d, ssde_handle* h, const ParLayout*
         h->tdf = d->other_data[0];
         h->tconst = std::lgamma(0.5 * (h->tdf + 1.0)) - std::lgamma(0.5 * h->tdf) - 0.5 * std::log(h->tdf * M_PI);
     }
-    // (three or four response columns as ONE filter: only the lane = track general kernel, and only where ssde_create found that the
+    // (three to eight response columns as ONE filter: only the lane = track general kernel, and only where ssde_create found that the
     //  measurement covariance or P0 couples the column pairs -- every other wide response is evaluated pair by pair)
-    if (d->n_dim < 1 || (d->n_dim > 2 && !(h->wide_ok && d->n_dim <= 4 && is_kalman(d->model))))
+    if (d->n_dim < 1 || (d->n_dim > 2 && !(h->wide_ok && d->n_dim <= DENSE_MAXD && is_kalman(d->model))))
         return fail(h, SSDE_ERR_MODEL, "n_dim must be 1 or 2 (wider responses are outside this engine's kernels)");
     if (d->n_par != n_sde_par(d->model, d->n_dim)) return fail(h, SSDE_ERR_ARG, "n_par does not match model / n_dim");
     if (d->n < 2) return fail(h, SSDE_ERR_ARG, "need at least two rows");
@@ -563,7 +563,7 @@ static int stage_basis_tables(const ssde_desc* d, ssde_handle* h, bool on_dev, i
     // random-effect block of the parameter is the table and its fixed-effect part is the intercept: the kernel
     // evaluates the block from x (8 B/row).  Everything else gets the dense block materialised once in HBM.
     if (d->basis_re && d->n_par > MAX_Q) {
-        // (a response of three or four columns run as one filter: q = d + 2 > MAX_Q parameters, and the table slots are MAX_Q wide)
+        // (a response of three to eight columns run as one filter: q = d + 2 > MAX_Q parameters, and the table slots are MAX_Q wide)
         for (int j = 0; j < d->n_par; j++)
             if (d->basis_re[j]) return fail(h, SSDE_ERR_MODEL, "basis_re is not available for responses wider than two columns that run as one filter (coupling H_array / P0): pass the dense block");
     } else

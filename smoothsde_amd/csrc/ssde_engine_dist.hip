@@ -93,10 +93,10 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     const int P = D > 2 ? (D + 1) / 2 : 1;                  // dimension parts
     const int per_dim = d->model == SSDE_MODEL_CTCRW ? 2 : 1;   // state components per dimension
     // A measurement covariance or a P0 that couples response columns of different pairs makes F a full matrix: the reference
-    // evaluates it through atomic::logdet and F.inverse() (nllk_ctcrw.hpp:12-24, 203-205, 231-241).  For three or four columns
+    // evaluates it through atomic::logdet and F.inverse() (nllk_ctcrw.hpp:12-24, 203-205, 231-241).  For three to eight columns
     // (host arrays, one device) the whole response then runs as ONE filter on the lane = track general kernel (k_dense.hip:
     // F by LU with partial pivoting, ssde_dense.hpp) instead of pair by pair.
-    const bool can_run_whole = is_kalman(d->model) && D <= 4 && !multi && !on_dev;
+    const bool can_run_whole = is_kalman(d->model) && D <= DENSE_MAXD && !multi && !on_dev;
     auto run_whole = [&]() -> int {
         parent->wide_ok = true;
         return build(d, parent);
@@ -116,7 +116,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                             if (can_run_whole) return run_whole();
                             return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: H_array[,, i] must not couple response columns of "
                                                                 "different pairs (2k, 2k+1), which this engine evaluates side by side "
-                                                                "(three or four columns from host arrays on one device run as one filter)");
+                                                                "(three to eight columns from host arrays on one device run as one filter)");
                         }
             }
         }
@@ -126,7 +126,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                     if (i / (2 * per_dim) != j / (2 * per_dim) && d->p0[i + (size_t)j * sdim] != 0.0) {
                         if (can_run_whole) return run_whole();
                         return fail(parent, SSDE_ERR_MODEL, "n_dim > 2: P0 must not couple response columns of different pairs (2k, 2k+1) "
-                                                            "(three or four columns from host arrays on one device run as one filter)");
+                                                            "(three to eight columns from host arrays on one device run as one filter)");
                     }
     }
     int ndev = 0;

@@ -104,7 +104,10 @@ def test_block_diagonal_P0_and_supplied_a0():
 
 
 @pytest.mark.parametrize("model,d,variant", [("CTCRW", 3, "const"), ("CTCRW", 4, "const"), ("OU_SSM", 3, "tv"), ("OU_SSM", 4, "const"),
-                                             ("BM_SSM", 3, "const"), ("BM_SSM", 4, "tv"), ("CTCRW", 3, "tv")])
+                                             ("BM_SSM", 3, "const"), ("BM_SSM", 4, "tv"), ("CTCRW", 3, "tv"),
+                                             # round 5: five to eight columns (k_dense_wide.hip; the covariance of a lane in scratch memory)
+                                             ("CTCRW", 5, "const"), ("OU_SSM", 6, "const"), ("BM_SSM", 7, "const"), ("CTCRW", 8, "const"),
+                                             ("OU_SSM", 5, "tv"), ("BM_SSM", 8, "tv"), ("CTCRW", 6, "tv")])
 @pytest.mark.parametrize("what", ["H", "P0", "both"])
 def test_three_and_four_columns_that_couple_run_as_one_filter(model, d, variant, what):
     """A per-row measurement covariance with entries between ALL columns (H_array[,, i] a full d x d matrix), a P0 that couples the
@@ -136,12 +139,12 @@ def test_three_and_four_columns_that_couple_run_as_one_filter(model, d, variant,
 
 
 def test_what_still_couples_the_pairs_is_refused_with_a_reason():
-    """beyond four columns, and from device-resident arrays, a coupling entry is still refused (and says what does run)"""
-    spec = make_spec("wide_bad", "CTCRW", 5, seed=5, lengths=[20, 20])
-    P0 = np.eye(10); P0[0, 4] = P0[4, 0] = 0.1
+    """beyond eight columns, and from device-resident arrays, a coupling entry is still refused (and says what does run)"""
+    spec = make_spec("wide_bad", "CTCRW", 9, seed=5, lengths=[20, 20])
+    P0 = np.eye(18); P0[0, 4] = P0[4, 0] = 0.1
     with pytest.raises(capi.EngineError, match="P0 must not couple"):
         capi.Engine(problem_from_spec(dict(spec, P0=P0)))
-    spec = make_spec("wide_bad", "OU_SSM", 5, seed=5, lengths=[20, 20], with_H=True)        # full 5 x 5 matrices
+    spec = make_spec("wide_bad", "OU_SSM", 9, seed=5, lengths=[20, 20], with_H=True)        # full 9 x 9 matrices
     with pytest.raises(capi.EngineError, match="H_array.*must not couple.*run as one filter"):
         capi.Engine(problem_from_spec(spec))
 

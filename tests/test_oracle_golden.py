@@ -46,6 +46,27 @@ def test_independent_restatement_live(name):
     assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
 
 
+@pytest.mark.parametrize("model,d,variant", [("CTCRW", 3, "const"), ("OU_SSM", 4, "tv"), ("CTCRW", 5, "const"), ("BM_SSM", 6, "tv"),
+                                             ("OU_SSM", 7, "const"), ("CTCRW", 8, "const")])
+def test_wide_coupled_responses_against_the_independent_restatement(model, d, variant):
+    """three to eight response columns with a full per-row measurement covariance AND a full P0 (F a full d x d matrix: the
+    reference's atomic::logdet / F.inverse() branch, nllk_ctcrw.hpp:12-24, 231-241): the oracle's LU recursion against the
+    joint Gaussian of every scored observation of a track (tests/refimpl.py), values and autograd gradients"""
+    from cases import make_spec
+    from refimpl import ref_eval
+    from smoothsde_amd import capi
+    spec = make_spec("wide_pin", model, d, seed=70 + d, lengths=[9, 6, 2, 12], variant=variant, na_rows=(3, 11), with_H=True)
+    sd = capi.state_dim(model, d)
+    A = np.random.default_rng(d).standard_normal((sd, sd))
+    spec["P0"] = A @ A.T / sd + np.eye(sd)
+    pb = problem_from_spec(spec)
+    val, grad = oracle_eval(pb, spec["par"], order=1)
+    rval, rgrad = ref_eval(pb, spec["par"])
+    assert np.isfinite(val)
+    assert abs(val - rval) <= 1e-10 * max(1.0, abs(rval))
+    assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
+
+
 def test_cir_weak_diffusion_against_mpmath_restatement():
     """CIR with sigma = 0.05: Bessel arguments of 10^3-10^4 and orders ~10^3, where the reference's unscaled
     besselI has long overflowed.  The oracle's series (summed outwards from its largest term) against the
