@@ -57,6 +57,24 @@ __global__ __launch_bounds__(256) void hess_prepare_kernel(const TvHessArgs A) {
     }
 }
 
+// ESEAL_SSM (nllk_e_seal_ssm.hpp:104-118, 136-137): record [dt | mu | log sigma | a1 | log a2 | y | . | . | R_i | h_i]
+__global__ __launch_bounds__(256) void hess_prepare_eseal_kernel(const TvHessArgs A) {
+    const SlotTable* __restrict__ T = A.slots;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
+        double par[2] = {0.0, 0.0};
+        for (int k = 0; k < A.n_slots; k++) {
+            const int col = T->col[k], j = T->par_j[k];
+            const double t = ((col >= 0) ? A.colbuf[(int64_t)col * A.col_stride + i] : 1.0) * A.par[T->pidx[k]];
+            par[0] += (j == 0) ? t : 0.0; par[1] += (j == 1) ? t : 0.0;
+        }
+        double* r = A.rec + i * HESS_RS;
+        r[0] = (i + 1 < A.n) ? A.times[i + 1] - A.times[i] : A.last_dt;
+        r[1] = par[0]; r[2] = par[1]; r[3] = A.par[1]; r[4] = A.par[2];
+        r[5] = A.obs[i]; r[6] = r[7] = 0.0;
+        r[8] = A.eseal_R[i]; r[9] = A.eseal_h[i]; r[10] = r[11] = 0.0;
+    }
+}
+
 // the lane's two directions as seeds of the row's predictors
 struct PairSeed {
     int kind_a, dim_a, kind_b, dim_b;
@@ -181,8 +199,49 @@ struct HessLaneDense {
             for (int j = 0; j < SD; j++) put(S.P[i][j]);
     }
 };
+// ESEAL_SSM: the scalar lipid-mass filter of ssde_tv.hpp (TvEsealOps: the first state component is the constant 1) in hyper-dual
+// arithmetic.  y_i = a1 + z_i L + N(0, H_i), z_i = a2 / R_i, H_i = tau^2 / h_i; L' = L + mu_i dt_i + N(0, sigma_i^2 dt_i)
+// (nllk_e_seal_ssm.hpp:139-207).  Directions: log tau (the kernel's h = tau^2 carries its seeds), a1, log a2, coefficients of mu / log sigma.
+struct HessLaneEseal {
+    static constexpr int NSTATE = 8;
+    struct State { HD x, p, nll; } S;
+    bool has_h;
+    __device__ __forceinline__ void init(const double* a0 /* (1, L0) */, const double* p0f /* 2 x 2 */) {
+        S.x = HD(a0[1]); S.p = HD(p0f[3]); S.nll = HD(0.0);
+    }
+    __device__ __forceinline__ void warm_init(const double*, const double* p0f) { S.x = HD(0.0); S.p = HD(p0f[3]); S.nll = HD(0.0); }
+    __device__ __forceinline__ void step(const double* r, const HD& h, const PairSeed& sd, double wa, double wb, int any_nan) {
+        const HD mu(r[1], sd.kind_a == TVK_MU ? wa : 0.0, sd.kind_b == TVK_MU ? wb : 0.0, 0.0);
+        const HD ls(r[2], sd.kind_a == TVK_P1 ? wa : 0.0, sd.kind_b == TVK_P1 ? wb : 0.0, 0.0);
+        const HD a1(r[3], sd.kind_a == TVK_A1 ? 1.0 : 0.0, sd.kind_b == TVK_A1 ? 1.0 : 0.0, 0.0);
+        const HD la2(r[4], sd.kind_a == TVK_A2 ? 1.0 : 0.0, sd.kind_b == TVK_A2 ? 1.0 : 0.0, 0.0);
+        const double dt = r[0];
+        const HD z = dexp(la2) * (1.0 / r[8]);                         // makeZ :43-48
+        const HD H = h * (1.0 / r[9]);                                 // makeH :55-59
+        const HD drift = mu * dt;                                      // makeT :16-23
+        const HD q = dexp(2.0 * ls) * dt;                              // makeQ :30-35
+        const bool na = is_na(r[5], any_nan);                          // :175
+        const HD F = z * z * S.p + H;                                  // :184
+        if (!na && !(F.v <= 0.0)) {                                    // :188 (a NaN takes the update branch)
+            const HD u = r[5] - a1 - z * S.x;                          // :182
+            S.nll = S.nll + (dlog(F) + u * u / F) * 0.5;
+            const HD k = S.p * z / F;                                  // :197
+            S.x = S.x + drift + k * u;                                 // :199
+            S.p = S.p * (H / F) + q;                                   // :201-202: p - k z p = p H / F
+        } else {
+            S.x = S.x + drift;                                         // :176
+            S.p = S.p + q;                                             // :177
+        }
+    }
+    __device__ __forceinline__ void dump(double* o) const {
+        o[0] = S.x.v; o[1] = S.x.a; o[2] = S.x.b; o[3] = S.x.ab; o[4] = S.p.v; o[5] = S.p.a; o[6] = S.p.b; o[7] = S.p.ab;
+    }
+};
+
 template <int MODEL, int D, bool DENSE>
 struct HessLaneSel { typedef HessLane<MODEL, D> type; };
+template <>
+struct HessLaneSel<M_ESEAL, 1, true> { typedef HessLaneEseal type; };
 template <int MODEL, int D>
 struct HessLaneSel<MODEL, D, true> { typedef HessLaneDense<MODEL, D> type; };
 
@@ -195,7 +254,7 @@ constexpr int HESS_U = 2;          // rows per prefetch block of the lane's two 
 template <int MODEL, int D, bool DENSE>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 1) void hess_filter_kernel(const TvHessArgs A) {
     typedef typename HessLaneSel<MODEL, D, DENSE>::type Lane;
-    constexpr int SD = (MODEL == M_CTCRW) ? 2 * D : D;
+    constexpr int SD = (MODEL == M_CTCRW || MODEL == M_ESEAL) ? 2 * D : D;
     const int item = blockIdx.x * WG_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // one work item per WAVE, no barriers
     if (item >= A.n_items) return;
     const int lane = threadIdx.x & 63;
@@ -337,6 +396,11 @@ hipError_t launch_tv_hess(const TvHessArgs& a, hipStream_t s) {
     SSDE_HESS_ONE(M_CTCRW, 1) SSDE_HESS_ONE(M_CTCRW, 2) SSDE_HESS_ONE(M_OU_SSM, 1) SSDE_HESS_ONE(M_OU_SSM, 2)
     SSDE_HESS_ONE(M_BM_SSM, 1) SSDE_HESS_ONE(M_BM_SSM, 2)
 #undef SSDE_HESS_ONE
+    if (a.model == M_ESEAL && a.d == 1) {
+        hipLaunchKernelGGL(hess_prepare_eseal_kernel, dim3(pblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((hess_filter_kernel<M_ESEAL, 1, true>), grid, block, 0, s, a);
+        nstate = HessLaneEseal::NSTATE;
+    }
     if (nstate == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(hess_finish_kernel, dim3(a.n_items + a.n_pb), dim3(WAVE), 0, s, a, nstate);
     return hipGetLastError();

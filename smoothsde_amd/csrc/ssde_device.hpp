@@ -585,6 +585,8 @@ struct TvHessArgs {
     double p0[3];
     int dense, has_h;            // full-covariance lanes (per-row H_array and / or a P0 that is not block-identical: ssde_dense.hpp in hyper-dual arithmetic)
     const double* h_array;       // [n][d x d] (has_h)
+    const double* eseal_h;       // ESEAL_SSM: [n] h_i and R_i (nllk_e_seal_ssm.hpp:43-59)
+    const double* eseal_R;
     double p0_full[16];          // sd x sd, column-major
     double last_dt;
     double* bnd;                 // [n_items][2][HESS_NSTATE][64]

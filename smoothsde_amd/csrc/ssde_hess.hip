@@ -27,8 +27,8 @@ static int scope_one(const ssde_handle* e) {
     if (e->path == PATH_TV) {
         // row-varying (or, as the companion of a constant-coefficient handle, intercept-only) coefficients on the lane = direction
         // path: second-order forward mode over coefficient pairs -- the isotropic lanes, or (per-row H_array, a general P0) the
-        // full-covariance step in the same hyper-dual arithmetic.  Not ESEAL_SSM.
-        return is_eseal(e->model) ? 0 : 3;
+        // full-covariance step in the same hyper-dual arithmetic; ESEAL_SSM: its scalar lipid-mass filter (HessLaneEseal).
+        return 3;
     }
     if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
     if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU || e->model == SSDE_MODEL_BM_T) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
@@ -176,6 +176,7 @@ static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<i
     HIPCHK(h, d_out.alloc((size_t)4 * n_pb * WAVE + 1));
     const int64_t M = h->n_seg;
     int W = h->tv_window > 0 ? 2 * h->tv_window + WIN_ALIGN : 0;      // second-order tangents forget like t^2 rho^t
+    if (is_eseal(h->model)) W = 0;                                    // (one sequential window per track, as its evaluation)
     Hd.assign((size_t)n * n, 0.0);
     for (int attempt = 0;; attempt++) {
         // windows per track: as many as keep ~2048 waves busy, each at least two alignment units of scored rows
@@ -203,6 +204,7 @@ static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<i
         a.pair_a = d_pairs.p; a.pair_b = d_pairs.p + n_pairs; a.n_pairs = n_pairs; a.n_pb = n_pb;
         for (int i = 0; i < 3; i++) a.p0[i] = h->p0_iso[i];
         a.dense = h->tv_dense ? 1 : 0; a.has_h = h->has_h ? 1 : 0; a.h_array = h->tv_harr.p;
+        a.eseal_h = h->tv_eh.p; a.eseal_R = h->tv_eR.p;
         for (int i = 0; i < 16; i++) a.p0_full[i] = h->p0_full[i];
         a.last_dt = h->last_dt;
         a.bnd = d_bnd.p; a.part = d_part.p; a.out = d_out.p;
@@ -230,7 +232,7 @@ static int hess_tv_device(ssde_handle* h, const double* par, const std::vector<i
 // H (n_idx x n_idx, column-major, host) of the joint penalised nllk over the full-parameter indices idx[]
 int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx, double* H) {
     const int scope = hess_exact_scope(h);
-    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM and OU (resident design columns, no decaying terms), for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows, and for every free parameter of a state-space model (constant or row-varying coefficients, H = sigma_obs^2 I, block-identical P0) evaluated on the isotropic lane = direction path or created with SSDE_FLAG_EXACT_HESS"; return SSDE_ERR_MODEL; }
+    if (scope == 0) { h->err = "ssde_hess: exact second derivatives exist for the direct families BM, OU and BM_t (resident design columns, no decaying terms), for the drift coefficients of a smooth-drift state-space batch on a regular grid without missing rows, and for every free parameter of a state-space model evaluated on the lane = direction path (row-varying coefficients, ESEAL_SSM) or created with SSDE_FLAG_EXACT_HESS"; return SSDE_ERR_MODEL; }
     const ParLayout& L = h->L;
     const int np = L.n_full;
     for (int k = 0; k < n_idx; k++)
@@ -251,6 +253,7 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
         const bool is_lambda = idx[k] >= L.off_lambda && idx[k] < L.off_lambda + L.n_lambda;
         if (is_coef) { cidx.push_back(idx[k]); cpos.push_back(k); }
         else if (scope == 3 && idx[k] == L.off_sig && L.off_sig >= 0) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_sigma_obs is a direction like any other there
+        else if (scope == 3 && is_eseal(h->model) && idx[k] >= 0 && idx[k] <= 2) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
         else if (!is_lambda) {
             // log_sigma_obs, log_decay: no closed form here -- say so instead of returning zero rows and columns
             h->err = "ssde_hess: exact second derivatives cover coefficients of the linear predictor and log_lambda only (not log_sigma_obs / log_decay)";
@@ -338,7 +341,21 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
     }
     // ---- smoothing penalty (nllk_sde.hpp:91-124): sum_s [ -Sn/2 log_lambda_s + exp(log_lambda_s)/2 b_s' S_s b_s ] -----
     const Penalty& P = h->pen;
-    if (!P.ncol.empty() && (P.include_penalty || is_kalman(h->model))) {       // (the Kalman templates ignore include_penalty: Q7)
+    if (is_eseal(h->model)) {
+        // the inverse-gamma priors on sigma(0)^2 and tau^2 (nllk_e_seal_ssm.hpp:212-216, Penalty::eseal_priors):
+        // -log prior = ... + 2 (shape + 1) l + scale exp(-2 l) in l = log sigma(0) = sum_k w_k coef_k, resp. l = log tau
+        std::vector<int> where(np, -1);
+        for (int k = 0; k < n_idx; k++) where[idx[k]] = k;
+        const double n = (double)P.eseal_n, nh = (double)(P.eseal_n / 2);
+        double ls0 = 0.0;
+        for (auto& e : P.eseal_sig0) ls0 += e.second * par[e.first];
+        const double c1 = 4.0 * (4.0 * (10.0 * n - 1.0)) * std::exp(-2.0 * ls0), c2 = 4.0 * (nh - 1.0) * std::exp(-2.0 * par[0]);
+        for (auto& ea : P.eseal_sig0)
+            for (auto& eb : P.eseal_sig0)
+                if (where[ea.first] >= 0 && where[eb.first] >= 0) H[where[ea.first] + (size_t)where[eb.first] * n_idx] += c1 * (ea.second * eb.second);
+        if (where[0] >= 0) H[where[0] + (size_t)where[0] * n_idx] += c2;
+    }
+    if (!P.ncol.empty() && (P.include_penalty || is_kalman(h->model) || is_eseal(h->model))) {       // (the Kalman templates ignore include_penalty: Q7)
         std::vector<int> where(np, -1);
         for (int k = 0; k < n_idx; k++) where[idx[k]] = k;
         int start = 0;

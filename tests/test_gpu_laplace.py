@@ -206,7 +206,7 @@ def test_row_varying_hessian_on_a_long_track_with_time_windows(monkeypatch):
 
 
 def test_exact_hessian_is_refused_where_it_does_not_exist():
-    for name in ("CIR_d1_const", "OU_d1_decay", "ESEAL_const"):
+    for name in ("CIR_d1_const", "OU_d1_decay"):
         rec = GOLD[name]
         pb = problem_from_spec(rec)
         eng = capi.Engine(pb)
@@ -446,6 +446,36 @@ def test_exact_hessians_for_batches_on_the_lane_track_kernels(kind, monkeypatch)
     assert abs(f1 - f0) <= 1e-7 * max(1.0, abs(f0)) and np.max(np.abs(gm1[io] - gm0[io])) <= 1e-3 * max(1.0, np.max(np.abs(gm0[io])))
     assert n1 < n0, (n1, n0)
     e0.close(); e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("name", ["ESEAL_const", "ESEAL_tv"])
+def test_exact_hessian_of_the_elephant_seal_model_matches_autograd(name):
+    """ESEAL_SSM (nllk_e_seal_ssm.hpp:104-216): every free entry -- log_tau, a1, log_a2, the coefficients of mu and log sigma,
+    log_lambda -- through the scalar lipid-mass filter in hyper-dual arithmetic (HessLaneEseal, k_tv_hess.hip) plus the closed-form
+    second derivatives of the two inverse-gamma priors; against autograd through the dense joint-Gaussian restatement."""
+    from refimpl import eseal_dense_nllk, eseal_priors
+    rec = GOLD[name]
+    pb = problem_from_spec(rec)
+    par = rec["par"].copy()
+    idx = [k for k in range(pb.n_par_full) if not pb.par_fixed[k]]
+    eng = capi.Engine(pb)
+    assert eng.info()["exact_hess_scope"] == 3
+    p0 = torch.tensor(par)
+
+    def joint(x):
+        p = p0.clone()
+        p[idx] = x
+        return eseal_dense_nllk(pb, p) + penalty(pb, p) + eseal_priors(pb, p)
+
+    H = eng.hess(par, idx)
+    H_exact = torch.autograd.functional.hessian(joint, torch.tensor(par[idx])).numpy()
+    assert np.max(np.abs(H - H.T)) == 0.0
+    assert np.max(np.abs(H - H_exact)) <= 1e-9 * np.max(np.abs(H_exact)), np.max(np.abs(H - H_exact)) / np.max(np.abs(H_exact))
+    sub = idx[::-2]
+    Hs = eng.hess(par, sub)
+    pos = [idx.index(k) for k in sub]
+    assert np.allclose(Hs, H[np.ix_(pos, pos)], rtol=1e-12, atol=1e-12 * np.max(np.abs(H)))
+    eng.close()
 
 
 # ---- ... for CONSTANT-coefficient state-space handles, track shards and the ranks of a communicator (VERDICT r04 #6) -------------
