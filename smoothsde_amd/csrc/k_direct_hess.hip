@@ -17,11 +17,15 @@
 namespace ssde {
 
 template <int MODEL, int D>
-__device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, double dt, const double* par, double (&Dm)[MAX_Q][MAX_Q]) {
+__device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, double dt, const double* par, double (&Dm)[MAX_Q][MAX_Q],
+                                            double (&gm)[MAX_Q]) {
+    // Dm = d2 (-log dens_i) / d par d par', gm = d (-log dens_i) / d par (used by the decaying-column variant only)
 #pragma unroll
-    for (int p = 0; p < MAX_Q; p++)
+    for (int p = 0; p < MAX_Q; p++) {
+        gm[p] = 0.0;
 #pragma unroll
         for (int q = 0; q < MAX_Q; q++) Dm[p][q] = 0.0;
+    }
     if (MODEL == M_BM_T) {
         // BM_t (tr_dens.hpp:38-44; one response column): l = phi(x) + log scale + const, phi(x) = (df + 1) / 2 log(1 + x^2 / df),
         // x = (z1 - z0 - mu dt) / scale, scale = e^{ls} sqrt(dt) / sqrt(df / (df - 2)):  d x / d mu = -dt / scale,  d x / d ls = -x
@@ -34,6 +38,7 @@ __device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, 
             Dm[0][0] = p2 * dt * dt * isc * isc;
             Dm[0][1] = Dm[1][0] = (p2 * x + p1) * dt * isc;
             Dm[1][1] = (p2 * x + p1) * x;
+            gm[0] = -p1 * dt * isc; gm[1] = 1.0 - p1 * x;
         }
     } else
     if (MODEL == M_BM) {
@@ -46,6 +51,7 @@ __device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, 
             Dm[a][a] = dt * dt * isd * isd;
             Dm[a][D] = Dm[D][a] = 2.0 * r * dt * isd;
             Dm[D][D] += 2.0 * r * r;
+            gm[a] = -r * dt * isd; gm[D] += 1.0 - r * r;
         }
     } else {
         const double tau = exp(par[D]), kap = exp(par[D + 1]);
@@ -71,6 +77,7 @@ __device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, 
             const double h_tk = L_dv * d_t * v + L_vv * v_t * v + L_v * v_t;
             Dm[D][D + 1] += h_tk;
             Dm[D + 1][D + 1] += L_vv * v * v + L_v * v;
+            gm[a] = L_d * d_m; gm[D] += L_d * d_t + L_v * v_t; gm[D + 1] += L_v * v;
         }
         Dm[D + 1][D] = Dm[D][D + 1];
     }
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A
             const double t = (cp ? cp[i - 1] : 1.0) * s_coef[k];
             par[0] += j == 0 ? t : 0.0; par[1] += j == 1 ? t : 0.0; par[2] += j == 2 ? t : 0.0; par[3] += j == 3 ? t : 0.0;
         }
-        double Dm[MAX_Q][MAX_Q];
-        row_hessian<MODEL, D>(A, i, dt, par, Dm);
+        double Dm[MAX_Q][MAX_Q], gm[MAX_Q];
+        row_hessian<MODEL, D>(A, i, dt, par, Dm, gm);
         double xb[HESS_T];
 #pragma unroll
         for (int b = 0; b < HESS_T; b++) xb[b] = !ob[b] ? 0.0 : (cb[b] ? cb[b][i - 1] : 1.0);
@@ -158,6 +165,149 @@ __global__ __launch_bounds__(256) void direct_hess_kernel(const DirectHessArgs A
             (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
+// ---- decaying random-effect columns (nllk_sde.hpp:30-32, 47-58): X_k(i) is scaled by exp(-rho_m t_j(i)), rho_m = exp(log_decay_m) --------
+// The predictors stay linear in the coefficients but not in log_decay.  With w_k = X_k exp(-rho t) and the tangent of every unknown
+//     coefficient k:  v = w_k e_{j(k)}            log_decay_m:  v_j = e1[j][m] = sum_{k in m, j(k) = j} coef_k w_k (-rho_m t_j)
+// the Hessian entry is  sum_i [ v_a' D_i v_b  +  g_i . d2 par / d a d b ],  and the second part is non-zero for
+//     (coefficient k in m, log_decay_m):  g[j(k)] w_k (-rho_m t)      (log_decay_m, log_decay_m):  sum_j g[j] e2[j][m],
+//     e2[j][m] = sum_k coef_k w_k ((rho t)^2 - rho t).
+// An unknown is a slot (uslot >= 0) or a decay rate (uslot = -1 - m).  Same tiles, same fixed-order sums as the kernel above.
+template <int MODEL, int D>
+__global__ __launch_bounds__(256) void direct_hess_decay_kernel(const DirectHessArgs A) {
+    const SlotTable* __restrict__ T = A.slots;
+    const int ns = A.n_slots;
+    const int tile = blockIdx.y, ti = A.tile_i[tile], tj = A.tile_j[tile];
+    double acc[HESS_T][HESS_T];
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) acc[a][b] = 0.0;
+    double rho[MAX_DECAY];
+#pragma unroll
+    for (int m = 0; m < MAX_DECAY; m++) rho[m] = m < A.n_decay ? exp(A.par[A.off_decay + m]) : 0.0;      // nllk_sde.hpp:47
+    // the tile's unknowns (side 0: rows of the tile, side 1: columns)
+    int uj[2][HESS_T], um[2][HESS_T];              // SDE parameter of a coefficient; decay rate (of the coefficient's column, or the unknown itself)
+    bool on[2][HESS_T], isd[2][HESS_T];            // inside the wanted set; the unknown IS a decay rate
+    const double* uc[2][HESS_T];
+#pragma unroll
+    for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+        for (int a = 0; a < HESS_T; a++) {
+            const int k = (sd == 0 ? ti : tj) * HESS_T + a;
+            on[sd][a] = k < A.nu;
+            const int us = on[sd][a] ? A.uslot[k] : 0;
+            isd[sd][a] = us < 0;
+            const int s = us < 0 ? 0 : us;
+            uj[sd][a] = T->par_j[s];
+            um[sd][a] = us < 0 ? -1 - us : T->decay[s];
+            uc[sd][a] = (us >= 0 && T->col[s] >= 0) ? A.cols[T->col[s]] : nullptr;
+        }
+    __shared__ const double* s_col[MAX_COLS];
+    __shared__ double s_coef[MAX_COLS];
+    __shared__ int s_pj[MAX_COLS], s_dk[MAX_COLS];
+    for (int k = threadIdx.x; k < ns; k += 256) {
+        const int c = T->col[k];
+        s_col[k] = c >= 0 ? A.cols[c] : nullptr;
+        s_coef[k] = A.par[T->pidx[k]];
+        s_pj[k] = T->par_j[k];
+        s_dk[k] = T->decay[k];
+    }
+    __syncthreads();
+    auto rho_of = [&](int m) { return m == 0 ? rho[0] : m == 1 ? rho[1] : m == 2 ? rho[2] : rho[3]; };
+    const int64_t per_block = ((A.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t row_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t row_hi = row_lo + per_block < A.n ? row_lo + per_block : A.n;
+    for (int64_t i = row_lo + threadIdx.x; i < row_hi; i += 256) {
+        if (!((A.scored[i >> 5] >> (i & 31)) & 1u)) continue;
+        const double dt = A.times[i] - A.times[i - 1];
+        double par[MAX_Q] = {0.0, 0.0, 0.0, 0.0};
+        double e1[MAX_Q][MAX_DECAY], e2[MAX_Q][MAX_DECAY];
+#pragma unroll
+        for (int j = 0; j < MAX_Q; j++)
+#pragma unroll
+            for (int m = 0; m < MAX_DECAY; m++) e1[j][m] = e2[j][m] = 0.0;
+        for (int k = 0; k < ns; k++) {                                             // the linear predictor of row i-1 (Q6) and its log_decay tangents
+            const double* cp = s_col[k];
+            const int j = s_pj[k], m = s_dk[k];
+            double w = cp ? cp[i - 1] : 1.0, rt = 0.0;
+            if (cp && m >= 0) { rt = rho_of(m) * A.t_decay[(int64_t)j * A.n + (i - 1)]; w *= exp(-rt); }      // nllk_sde.hpp:47-57
+            const double t = w * s_coef[k];
+#pragma unroll
+            for (int jj = 0; jj < MAX_Q; jj++) {
+                par[jj] += j == jj ? t : 0.0;
+#pragma unroll
+                for (int mm = 0; mm < MAX_DECAY; mm++) {
+                    const bool hit = j == jj && m == mm;
+                    e1[jj][mm] += hit ? -t * rt : 0.0;
+                    e2[jj][mm] += hit ? t * (rt * rt - rt) : 0.0;
+                }
+            }
+        }
+        double Dm[MAX_Q][MAX_Q], gm[MAX_Q];
+        row_hessian<MODEL, D>(A, i, dt, par, Dm, gm);
+        // tangents of the tile's unknowns, and for coefficients their own d w / d log_decay
+        double v[2][HESS_T][MAX_Q], dw[2][HESS_T];
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+            for (int a = 0; a < HESS_T; a++) {
+                const int j = uj[sd][a], m = um[sd][a];
+                double w = 0.0, rt = 0.0;
+                if (on[sd][a] && !isd[sd][a]) {
+                    w = uc[sd][a] ? uc[sd][a][i - 1] : 1.0;
+                    if (uc[sd][a] && m >= 0) { rt = rho_of(m) * A.t_decay[(int64_t)j * A.n + (i - 1)]; w *= exp(-rt); }
+                }
+                dw[sd][a] = -w * rt;
+#pragma unroll
+                for (int q = 0; q < MAX_Q; q++) {
+                    double e = 0.0;
+#pragma unroll
+                    for (int mm = 0; mm < MAX_DECAY; mm++) e += m == mm ? e1[q][mm] : 0.0;
+                    v[sd][a][q] = !on[sd][a] ? 0.0 : isd[sd][a] ? e : (j == q ? w : 0.0);
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < HESS_T; a++) {
+            if (!on[0][a]) continue;                                               // (uniform)
+            double row[MAX_Q];                                                     // v_a' D
+#pragma unroll
+            for (int q = 0; q < MAX_Q; q++) row[q] = v[0][a][0] * Dm[0][q] + v[0][a][1] * Dm[1][q] + v[0][a][2] * Dm[2][q] + v[0][a][3] * Dm[3][q];
+#pragma unroll
+            for (int b = 0; b < HESS_T; b++) {
+                if (!on[1][b]) continue;
+                double t = row[0] * v[1][b][0] + row[1] * v[1][b][1] + row[2] * v[1][b][2] + row[3] * v[1][b][3];
+                // the part through d2 par / d a d b
+                const bool same = um[0][a] >= 0 && um[0][a] == um[1][b];
+                if (same && isd[0][a] != isd[1][b]) {                              // (coefficient of a decaying column, its decay rate)
+                    const int j = isd[0][a] ? uj[1][b] : uj[0][a];
+                    t += pick4(gm, j) * (isd[0][a] ? dw[1][b] : dw[0][a]);
+                } else if (same && isd[0][a] && isd[1][b]) {                       // (log_decay_m, log_decay_m)
+#pragma unroll
+                    for (int q = 0; q < MAX_Q; q++) {
+                        double e = 0.0;
+#pragma unroll
+                        for (int mm = 0; mm < MAX_DECAY; mm++) e += um[0][a] == mm ? e2[q][mm] : 0.0;
+                        t += gm[q] * e;
+                    }
+                }
+                acc[a][b] += t;
+            }
+        }
+    }
+    __shared__ double sh[HESS_T * HESS_T][4];
+#pragma unroll
+    for (int a = 0; a < HESS_T; a++)
+#pragma unroll
+        for (int b = 0; b < HESS_T; b++) {
+            const double t = wave_sum(acc[a][b]);
+            if ((threadIdx.x & 63) == 0) sh[a * HESS_T + b][threadIdx.x >> 6] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < HESS_T * HESS_T)
+        A.partials[((int64_t)tile * HESS_T * HESS_T + threadIdx.x) * gridDim.x + blockIdx.x] =
+            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
 // H[k + l nu] (and its mirror) = sum over blocks of the tile's partials, in block order
 __global__ __launch_bounds__(64) void direct_hess_reduce_kernel(const DirectHessArgs A, int n_blocks) {
     const int tile = blockIdx.x, e = blockIdx.y, a = e / HESS_T, b = e % HESS_T;
@@ -172,6 +322,14 @@ __global__ __launch_bounds__(64) void direct_hess_reduce_kernel(const DirectHess
 
 hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks, hipStream_t s) {
     dim3 grid(n_blocks, n_tiles), block(256);
+    if (a.n_decay > 0) {
+        if (a.model == M_BM && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_BM, 1>), grid, block, 0, s, a);
+        else if (a.model == M_BM && a.d == 2) hipLaunchKernelGGL((direct_hess_decay_kernel<M_BM, 2>), grid, block, 0, s, a);
+        else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_OU, 1>), grid, block, 0, s, a);
+        else if (a.model == M_OU && a.d == 2) hipLaunchKernelGGL((direct_hess_decay_kernel<M_OU, 2>), grid, block, 0, s, a);
+        else if (a.model == M_BM_T && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_BM_T, 1>), grid, block, 0, s, a);
+        else return hipErrorInvalidValue;
+    } else
     if (a.model == M_BM && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 1>), grid, block, 0, s, a);
     else if (a.model == M_BM && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 2>), grid, block, 0, s, a);
     else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 1>), grid, block, 0, s, a);

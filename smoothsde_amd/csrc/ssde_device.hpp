@@ -451,8 +451,10 @@ struct DirectHessArgs {
     const SlotTable* slots;      // device
     const double* par;           // device, full parameter vector
     int n_slots;
-    int nu;                      // wanted coefficients
-    const int16_t* uslot;        // device [nu]: slot of every wanted coefficient
+    const double* t_decay;       // [q * n] or NULL: decaying columns (nllk_sde.hpp:47-57), as DirectArgs
+    int n_decay, off_decay;
+    int nu;                      // wanted unknowns
+    const int16_t* uslot;        // device [nu]: slot of every wanted coefficient; -1 - m: log_decay_m (n_decay > 0 only)
     const int16_t* tile_i;       // device [n_tiles]: tile (ti, tj), ti <= tj
     const int16_t* tile_j;
     double* partials;            // [n_tiles][HESS_T * HESS_T][n_blocks]

@@ -31,7 +31,7 @@ static int scope_one(const ssde_handle* e) {
         return 3;
     }
     if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
-    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU || e->model == SSDE_MODEL_BM_T) || e->path != PATH_DIRECT || e->L.n_decay > 0) return 0;
+    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU || e->model == SSDE_MODEL_BM_T) || e->path != PATH_DIRECT) return 0;
     for (auto& sl : e->slots) if (sl.col == -2) return 0;           // a block evaluated from its basis table has no columns to read
     return 2;
 }
@@ -113,6 +113,7 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     for (int k = 0; k < nu; k++) {
         int found = -1;
         for (size_t t = 0; t < h->slots.size(); t++) if (h->slots[t].pidx == idx[k]) found = (int)t;
+        if (found < 0 && idx[k] >= h->L.off_decay && idx[k] < h->L.off_decay + h->L.n_decay) { uslot[k] = (int16_t)(-1 - (idx[k] - h->L.off_decay)); continue; }
         if (found < 0) { h->err = "ssde_hess: internal: index without a coefficient slot"; return SSDE_ERR_ARG; }
         uslot[k] = (int16_t)found;
     }
@@ -133,6 +134,7 @@ static int hess_data_device(ssde_handle* h, const double* par, const std::vector
     a.times = h->times.p; a.obs = h->obs.p; a.cols = h->colptr.p; a.scored = h->scored.p; a.n = h->n;
     a.d = h->d; a.model = h->model; a.any_nan = h->na_any; a.slots = h->slot_table.p; a.par = pdev; a.n_slots = (int)h->slots.size();
     a.tdf = h->tdf;
+    a.t_decay = h->tdecay.p; a.n_decay = h->L.n_decay; a.off_decay = h->L.off_decay;
     a.nu = nu; a.uslot = p_us; a.tile_i = p_ti; a.tile_j = p_tj; a.partials = h->hs_partials.p; a.hess = h->hs_hess.p;
     HIPCHK(h, launch_direct_hess(a, n_tiles, n_blocks, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -254,6 +256,7 @@ int hess_exact(ssde_handle* h, const double* par, const int32_t* idx, int n_idx,
         if (is_coef) { cidx.push_back(idx[k]); cpos.push_back(k); }
         else if (scope == 3 && idx[k] == L.off_sig && L.off_sig >= 0) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_sigma_obs is a direction like any other there
         else if (scope == 3 && is_eseal(h->model) && idx[k] >= 0 && idx[k] <= 2) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_tau, a1, log_a2 (nllk_e_seal_ssm.hpp:114-116)
+        else if (scope == 2 && idx[k] >= L.off_decay && idx[k] < L.off_decay + L.n_decay) { cidx.push_back(idx[k]); cpos.push_back(k); }   // log_decay: an unknown of the direct-family kernel
         else if (!is_lambda) {
             // log_sigma_obs, log_decay: no closed form here -- say so instead of returning zero rows and columns
             h->err = "ssde_hess: exact second derivatives cover coefficients of the linear predictor and log_lambda only (not log_sigma_obs / log_decay)";
