@@ -365,7 +365,7 @@ int ssde_forget(ssde_handle *h);
  *           coeff_re entries hold u^ (TMB's par.random / env$last.par)
  *   order   0: *value;  1: also grad[n_par_full] = df/dtheta (zeros at coeff_re and at fixed entries)
  *   hess_uu NULL or [n_u x n_u] column-major: H_uu at u^ (the random-effect block of sdreport's jointPrecision)
- * Direct families BM / OU / BM_t: H_uu and H_u,theta are EXACT (ssde_hess), only 1/2 d log det H_uu / dtheta is a central
+ * Direct families BM / OU / BM_t / CIR: H_uu and H_u,theta are EXACT (ssde_hess), only 1/2 d log det H_uu / dtheta is a central
  * difference -- of exact Hessians, along the implicit-function tangent of u^.  Elsewhere H_uu comes from central
  * differences of the device gradient.  The inner problem is solved by Newton iterations; the gradient is the exact
  * dg/dtheta at u^ plus that log-determinant term (ssde_laplace.hip).  A joint nllk that has no minimum in u gives
@@ -381,13 +381,13 @@ int ssde_laplace_eval(ssde_handle *h, double *par, int32_t n_par_full, int32_t o
                       double *hess_uu, const ssde_laplace_opts *opts);
 
 /* Second derivatives of the joint penalised nllk (ssde_eval's value) over the parameter entries idx[0 .. n_idx):
- * hess [n_idx x n_idx] column-major.  EXACT -- no differencing -- for the direct families "BM", "OU" and "BM_t"
- * (tr_dens.hpp:32-52) with resident design columns (decaying ones and log_decay included): the SDE parameters are linear in coeff_fe /
+ * hess [n_idx x n_idx] column-major.  EXACT -- no differencing -- for the direct families "BM", "OU", "BM_t" and "CIR"
+ * (tr_dens.hpp:32-67) with resident design columns (decaying ones and log_decay included): the SDE parameters are linear in coeff_fe /
  * coeff_re, so the data term's Hessian is X' D X with a closed-form per-row D, and the penalty is exp(log_lambda) times a
  * quadratic form (nllk_sde.hpp:91-124); and for the state-space families CTCRW / OU_SSM / BM_SSM on handles whose rows the
  * lane = direction filter holds (row-varying coefficients, ESEAL_SSM, or any handle created with SSDE_FLAG_EXACT_HESS):
  * second-order forward mode through the filter.  ssde_info.exact_hess_scope says which entries a handle covers.  idx may name coeff_fe,
- * coeff_re and log_lambda entries, fixed or free.  Where the scope does not cover idx (CIR) the
+ * coeff_re and log_lambda entries, fixed or free.  Where the scope does not cover idx (exact_hess_scope 0 or 1) the
  * call returns SSDE_ERR_MODEL: difference ssde_eval's gradient there, as ssde_laplace_eval does.  Works on single-device,
  * multi-device and communicator handles (the shards' / ranks' Hessians are summed). */
 int ssde_hess(ssde_handle *h, const double *par, int32_t n_par_full, const int32_t *idx, int32_t n_idx, double *hess);

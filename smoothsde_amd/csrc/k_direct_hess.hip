@@ -13,6 +13,7 @@
 // one tile per blockIdx.y, accumulated in registers and reduced in a fixed order (bitwise reproducible).  Not a hot
 // kernel: it runs a handful of times per marginal-likelihood evaluation.
 #include "ssde_device.hpp"
+#include "ssde_hdual.hpp"
 
 namespace ssde {
 
@@ -26,6 +27,48 @@ __device__ __forceinline__ void row_hessian(const DirectHessArgs& A, int64_t i, 
 #pragma unroll
         for (int q = 0; q < MAX_Q; q++) Dm[p][q] = 0.0;
     }
+    if (MODEL == M_CIR) {
+        // CIR (tr_dens.hpp:53-67): -log dens = -(log c - u - v + q/2 (log v - log u) + log I_q(2 sqrt(u v))) in (log mu_a, log beta,
+        // log sigma).  log I_q and its five derivatives once per (row, dimension) from the series (log_bessel_i2); the rest of the
+        // density is run in hyper-dual arithmetic, one pass per parameter pair -- nothing derived by hand, nothing differenced.
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            const double z0 = A.obs[(i - 1) + (int64_t)a * A.n], z1 = A.obs[i + (int64_t)a * A.n];
+            if (is_na(z0, A.any_nan) || is_na(z1, A.any_nan)) continue;              // tr_dens.hpp:31
+            double lb5[5], lI = 0.0;
+            {
+                const double mu = exp(par[a]), beta = exp(par[D]), s2 = exp(2.0 * par[D + 1]);
+                const double em = exp(-beta * dt), c = 2.0 * beta / ((1.0 - em) * s2);
+                lI = log_bessel_i2(2.0 * sqrt(c * z0 * em * c * z1), 2.0 * beta * mu / s2 - 1.0, lb5);
+            }
+            const int pos[3] = {a, D, D + 1};
+#pragma unroll
+            for (int pa = 0; pa < 3; pa++)
+#pragma unroll
+                for (int pb = pa; pb < 3; pb++) {
+                    const HD lm(par[a], pa == 0 ? 1.0 : 0.0, pb == 0 ? 1.0 : 0.0, 0.0);
+                    const HD lbt(par[D], pa == 1 ? 1.0 : 0.0, pb == 1 ? 1.0 : 0.0, 0.0);
+                    const HD ls(par[D + 1], pa == 2 ? 1.0 : 0.0, pb == 2 ? 1.0 : 0.0, 0.0);
+                    const HD mu = hd_exp(lm), beta = hd_exp(lbt), s2 = hd_exp(2.0 * ls);
+                    const HD em = hd_exp(-(beta * dt));
+                    const HD c = 2.0 * beta / ((1.0 - em) * s2);                          // :60
+                    const HD q = 2.0 * beta * mu / s2 - 1.0;                              // :61
+                    const HD u = c * (z0 * em), v = c * z1;                                // :62-63
+                    const HD x = 2.0 * hd_sqrt(u * v);                                     // :64
+                    const HD lbes = hd_chain2(x, q, lI, lb5[0], lb5[1], lb5[2], lb5[3], lb5[4]);
+                    const HD ld = hd_log(c) - u - v + 0.5 * (q * (hd_log(v) - hd_log(u))) + lbes;   // :66
+                    if (pa == pb) {
+                        if (pa == 0) { Dm[a][a] = -ld.ab; gm[a] = -ld.a; }
+                        else { Dm[pos[pa]][pos[pa]] -= ld.ab; gm[pos[pa]] -= ld.a; }
+                    } else if (pa == 0) {
+                        Dm[a][pos[pb]] = Dm[pos[pb]][a] = -ld.ab;
+                    } else {
+                        Dm[D][D + 1] -= ld.ab;
+                    }
+                }
+        }
+        Dm[D + 1][D] = Dm[D][D + 1];
+    } else
     if (MODEL == M_BM_T) {
         // BM_t (tr_dens.hpp:38-44; one response column): l = phi(x) + log scale + const, phi(x) = (df + 1) / 2 log(1 + x^2 / df),
         // x = (z1 - z0 - mu dt) / scale, scale = e^{ls} sqrt(dt) / sqrt(df / (df - 2)):  d x / d mu = -dt / scale,  d x / d ls = -x
@@ -328,6 +371,8 @@ hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks
         else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_OU, 1>), grid, block, 0, s, a);
         else if (a.model == M_OU && a.d == 2) hipLaunchKernelGGL((direct_hess_decay_kernel<M_OU, 2>), grid, block, 0, s, a);
         else if (a.model == M_BM_T && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_BM_T, 1>), grid, block, 0, s, a);
+        else if (a.model == M_CIR && a.d == 1) hipLaunchKernelGGL((direct_hess_decay_kernel<M_CIR, 1>), grid, block, 0, s, a);
+        else if (a.model == M_CIR && a.d == 2) hipLaunchKernelGGL((direct_hess_decay_kernel<M_CIR, 2>), grid, block, 0, s, a);
         else return hipErrorInvalidValue;
     } else
     if (a.model == M_BM && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_BM, 1>), grid, block, 0, s, a);
@@ -335,6 +380,8 @@ hipError_t launch_direct_hess(const DirectHessArgs& a, int n_tiles, int n_blocks
     else if (a.model == M_OU && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 1>), grid, block, 0, s, a);
     else if (a.model == M_OU && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_OU, 2>), grid, block, 0, s, a);
     else if (a.model == M_BM_T && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_BM_T, 1>), grid, block, 0, s, a);
+    else if (a.model == M_CIR && a.d == 1) hipLaunchKernelGGL((direct_hess_kernel<M_CIR, 1>), grid, block, 0, s, a);
+    else if (a.model == M_CIR && a.d == 2) hipLaunchKernelGGL((direct_hess_kernel<M_CIR, 2>), grid, block, 0, s, a);
     else return hipErrorInvalidValue;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

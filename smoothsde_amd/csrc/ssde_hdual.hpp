@@ -58,6 +58,12 @@ SSDE_HD HD hd_log(const HD& x) {
     return hd_chain(x, log(x.v), r, -r * r);
 }
 
+// f(x, q) with its first and second partial derivatives known at (x.v, q.v)
+SSDE_HD HD hd_chain2(const HD& x, const HD& q, double f, double fx, double fq, double fxx, double fxq, double fqq) {
+    return HD(f, fx * x.a + fq * q.a, fx * x.b + fq * q.b,
+              fx * x.ab + fq * q.ab + fxx * x.a * x.b + fxq * (x.a * q.b + x.b * q.a) + fqq * q.a * q.b);
+}
+
 // the names the general (full-covariance) step of ssde_dense.hpp is written in, so that dense_step_g runs in HD as it runs in DualN
 SSDE_HD HD operator/(double c, const HD& x) { return hd_rcp(x) * c; }
 SSDE_HD HD operator/(const HD& x, double c) { return x * (1.0 / c); }

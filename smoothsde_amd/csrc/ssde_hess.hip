@@ -31,7 +31,7 @@ static int scope_one(const ssde_handle* e) {
         return 3;
     }
     if (e->path == PATH_ISO) return e->drift == 1 ? 1 : 0;          // a smooth drift on the shared-covariance lanes: QUADRATIC in its coefficients
-    if (!(e->model == SSDE_MODEL_BM || e->model == SSDE_MODEL_OU || e->model == SSDE_MODEL_BM_T) || e->path != PATH_DIRECT) return 0;
+    if (e->path != PATH_DIRECT) return 0;                           // BM, BM_t, OU, CIR: closed-form (CIR: series + hyper-dual) per-row D
     for (auto& sl : e->slots) if (sl.col == -2) return 0;           // a block evaluated from its basis table has no columns to read
     return 2;
 }

@@ -699,6 +699,62 @@ SSDE_HD double log_bessel_i(double x, double q, double& dlog_dx, double& dlog_dq
     return q * lx2 + lt + log(S);
 }
 
+// psi'(x), x > 0
+SSDE_HD double trigamma_pos(double x) {
+    double r = 0.0;
+    while (x < 8.0) { r += 1.0 / (x * x); x += 1.0; }
+    const double ix = 1.0 / x, i2 = ix * ix;
+    // 1/x + 1/(2x^2) + sum B_2n / x^(2n+1): 1/6, -1/30, 1/42, -1/30, 5/66, -691/2730, 7/6
+    return r + ix + 0.5 * i2 + ix * i2 * (1.0 / 6.0 - i2 * (1.0 / 30.0 - i2 * (1.0 / 42.0 - i2 * (1.0 / 30.0 - i2 * (5.0 / 66.0 -
+               i2 * (691.0 / 2730.0 - i2 * (7.0 / 6.0)))))));
+}
+
+// log I_q(x) with its first AND second derivatives (the exact Hessian of the CIR density, k_direct_hess.hip).  The same outward walk;
+// with the weights w_k = t_k / S of the series the derivatives are moments of k and psi_k = psi(k + q + 1) under w:
+//     l_x = (q + 2 E k) / x,   l_q = log(x/2) - E psi,
+//     l_xx = (4 Var k - q - 2 E k) / x^2,   l_xq = (1 - 2 Cov(k, psi)) / x,   l_qq = Var psi - E psi'
+// (moments taken about the largest term's k* and psi_k*: no cancellation in the variances).  out = {l_x, l_q, l_xx, l_xq, l_qq}.
+SSDE_HD double log_bessel_i2(double x, double q, double (&out)[5]) {
+    const double y = 0.25 * x * x;
+    double ks = floor(0.5 * (sqrt(q * q + x * x) - q));
+    if (!(ks >= 1.0)) ks = 0.0;
+    const double sd = sqrt(ks * (ks + q) / (2.0 * ks + q + 1e-300));
+    if (!(sd < 3.0e3)) { for (int i = 0; i < 5; i++) out[i] = NAN; return NAN; }
+    const int cap = 100 + (int)(12.0 * sd);
+    const double psi0 = digamma_pos(ks + q + 1.0), tri0 = trigamma_pos(ks + q + 1.0);
+    double S = 1.0, Sk = 0.0, Skk = 0.0, Sp = 0.0, Spp = 0.0, Skp = 0.0, St = tri0;
+    double t = 1.0, dp = 0.0, tri = tri0, k = ks;
+    for (int it = 0; it < cap; it++) {                           // upwards
+        k += 1.0;
+        const double ik = 1.0 / (k + q);
+        t *= y * ik / k;
+        dp += ik; tri -= ik * ik;
+        const double dk = k - ks;
+        S += t; Sk += t * dk; Skk += t * dk * dk; Sp += t * dp; Spp += t * dp * dp; Skp += t * dk * dp; St += t * tri;
+        if (!(t >= 1e-17 * S)) break;
+    }
+    t = 1.0; dp = 0.0; tri = tri0; k = ks;
+    for (int it = 0; it < cap && k >= 1.0; it++) {               // downwards: t_{k-1} = t_k k (k + q) / y
+        const double ik = 1.0 / (k + q);
+        t *= k * (k + q) / y;
+        dp -= ik; tri += ik * ik;
+        k -= 1.0;
+        const double dk = k - ks;
+        S += t; Sk += t * dk; Skk += t * dk * dk; Sp += t * dp; Spp += t * dp * dp; Skp += t * dk * dp; St += t * tri;
+        if (!(t >= 1e-17 * S)) break;
+    }
+    const double iS = 1.0 / S, Ek = Sk * iS, Ep = Sp * iS;
+    const double Vk = Skk * iS - Ek * Ek, Vp = Spp * iS - Ep * Ep, Ckp = Skp * iS - Ek * Ep;
+    const double lx2 = log(0.5 * x), ix = 1.0 / x, km = ks + Ek;
+    const double lt = (ks > 0.0 ? ks * log(y) - lgamma(ks + 1.0) : 0.0) - lgamma(ks + q + 1.0);
+    out[0] = (q + 2.0 * km) * ix;
+    out[1] = lx2 - (psi0 + Ep);
+    out[2] = (4.0 * Vk - q - 2.0 * km) * ix * ix;
+    out[3] = (1.0 - 2.0 * Ckp) * ix;
+    out[4] = Vp - St * iS;
+    return q * lx2 + lt + log(S);
+}
+
 // CIR: par = (log mu_a, log beta, log sigma).  Returns -log density, adds d/d(log mu_a, log beta, log sigma).
 SSDE_HD double cir_direct(double z0, double z1, double dt, double lmu, double lbeta, double lsig, double& g_lm,
                           double& g_lb, double& g_ls) {

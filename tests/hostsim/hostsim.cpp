@@ -282,6 +282,12 @@ int hostsim_kalman_iso(int model, int d, int mask, int any_nan, int64_t n, int64
 
 // log I_q(x) and its derivatives w.r.t. x and q (CIR); out = [value, d/dx, d/dq]
 void hostsim_log_bessel_i(double x, double q, double* out) { out[0] = log_bessel_i(x, q, out[1], out[2]); }
+// ... with the second derivatives (the CIR Hessian, k_direct_hess.hip); out = [value, l_x, l_q, l_xx, l_xq, l_qq]
+void hostsim_log_bessel_i2(double x, double q, double* out) {
+    double d5[5];
+    out[0] = log_bessel_i2(x, q, d5);
+    for (int i = 0; i < 5; i++) out[1 + i] = d5[i];
+}
 // CIR transition: returns nll and adds gradient wrt (log mu, log beta, log sigma)
 double hostsim_cir(double z0, double z1, double dt, double lmu, double lb, double ls, double* g) {
     return cir_direct(z0, z1, dt, lmu, lb, ls, g[0], g[1], g[2]);

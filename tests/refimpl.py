@@ -232,22 +232,45 @@ def eseal_priors(pb: Problem, par: torch.Tensor) -> torch.Tensor:
     return out
 
 
-class _LogBesselI(torch.autograd.Function):
-    """log I_nu(x) with both derivatives from mpmath at 30 digits (independent of the series in oracle/)."""
+def _mp_log_bessel(x, nu, nx, nn):
+    """d^(nx + nn) log I_nu(x) / dx^nx dnu^nn from mpmath at 30 digits (independent of the series in oracle/ and csrc/)"""
+    import mpmath as mp
+    mp.mp.dps = 30
+    f = lambda a, b: mp.log(mp.besseli(b, a))
+    xf, nf = mp.mpf(float(x)), mp.mpf(float(nu))
+    if nx == 0 and nn == 0:
+        return float(f(xf, nf))
+    return float(mp.diff(f, (xf, nf), (nx, nn)))
+
+
+class _LogBesselIDeriv(torch.autograd.Function):
+    """a first derivative of log I_nu(x) as a differentiable function of (x, nu): its own derivatives are the second ones"""
 
     @staticmethod
-    def forward(ctx, x, nu):
-        import mpmath as mp
-        mp.mp.dps = 30
-        xf, nf = mp.mpf(float(x)), mp.mpf(float(nu))
-        f = lambda a, b: mp.log(mp.besseli(b, a))
-        ctx.dx = float(mp.diff(lambda a: f(a, nf), xf))
-        ctx.dnu = float(mp.diff(lambda b: f(xf, b), nf))
-        return torch.tensor(float(f(xf, nf)), dtype=torch.float64)
+    def forward(ctx, x, nu, wrt_nu):
+        ctx.save_for_backward(x, nu)
+        ctx.wrt_nu = wrt_nu
+        return torch.tensor(_mp_log_bessel(x, nu, 0 if wrt_nu else 1, 1 if wrt_nu else 0), dtype=torch.float64)
 
     @staticmethod
     def backward(ctx, g):
-        return g * ctx.dx, g * ctx.dnu
+        x, nu = ctx.saved_tensors
+        k = 1 if ctx.wrt_nu else 0
+        return g * _mp_log_bessel(x, nu, 2 - k, k), g * _mp_log_bessel(x, nu, 1 - k, 1 + k), None
+
+
+class _LogBesselI(torch.autograd.Function):
+    """log I_nu(x); first derivatives by mpmath, and (through _LogBesselIDeriv) second ones for autograd Hessians"""
+
+    @staticmethod
+    def forward(ctx, x, nu):
+        ctx.save_for_backward(x, nu)
+        return torch.tensor(_mp_log_bessel(x, nu, 0, 0), dtype=torch.float64)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, nu = ctx.saved_tensors
+        return g * _LogBesselIDeriv.apply(x, nu, False), g * _LogBesselIDeriv.apply(x, nu, True)
 
 
 def direct_nllk(pb: Problem, par: torch.Tensor) -> torch.Tensor:

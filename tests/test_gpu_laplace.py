@@ -127,7 +127,7 @@ def _joint_fn(pb, p0, idx):
 
 
 @pytest.mark.parametrize("name", ["OU_d1_tv", "OU_d2_tv", "BM_d1_tv", "BM_d2_tv", "OU_d1_tv2", "OU_d1_const", "BM_d2_const",
-                                  "BM_t_d1_tv", "BM_t_d1_const", "OU_d1_decay", "BM_d2_decay2"])
+                                  "BM_t_d1_tv", "BM_t_d1_const", "OU_d1_decay", "BM_d2_decay2", "CIR_d1_const", "CIR_d2_tv"])
 def test_exact_hessian_matches_autograd(name):
     """tmb_obj_joint$he(x) (R/sde.R:1363): every coefficient and log_lambda entry, missing rows included."""
     rec = GOLD[name]
@@ -206,13 +206,15 @@ def test_row_varying_hessian_on_a_long_track_with_time_windows(monkeypatch):
 
 
 def test_exact_hessian_is_refused_where_it_does_not_exist():
-    for name in ("CIR_d1_const", "CIR_d2_tv"):
-        rec = GOLD[name]
-        pb = problem_from_spec(rec)
-        eng = capi.Engine(pb)
-        with pytest.raises(capi.EngineError, match="exact second derivatives"):
-            eng.hess(rec["par"], [pb.off_fe])
-        eng.close()
+    """what is left without exact second derivatives: a constant-coefficient state-space handle created WITHOUT SSDE_FLAG_EXACT_HESS
+    (its register kernels carry first-order sensitivities only); the call says so with SSDE_ERR_MODEL and the callers difference"""
+    rec = GOLD["CTCRW_d2_const"]
+    pb = problem_from_spec(rec)
+    eng = capi.Engine(pb)
+    assert eng.info()["exact_hess_scope"] == 0
+    with pytest.raises(capi.EngineError, match="exact second derivatives"):
+        eng.hess(rec["par"], [pb.off_fe])
+    eng.close()
 
 
 def _exact_marginal_gradient(pb, p_hat, io, ir):

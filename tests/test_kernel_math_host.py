@@ -147,3 +147,31 @@ def test_log_bessel_i_matches_mpmath():
         assert abs(out[0] - float(val)) <= 2e-14 * max(1.0, abs(float(val))), (x, q, out[0], float(val))
         assert abs(out[1] - float(dx)) <= 1e-11 * max(1.0, abs(float(dx))), (x, q, out[1], float(dx))
         assert abs(out[2] - float(dq)) <= 1e-11 * max(1.0, abs(float(dq))), (x, q, out[2], float(dq))
+
+
+def test_log_bessel_i_second_derivatives_match_mpmath():
+    """log_bessel_i2 (ssde_math.hpp): the five derivatives the exact CIR Hessian needs -- moments of k and psi(k + q + 1) under the
+    series' weights -- against mpmath at 40 digits.  l_xx is a difference of two O(1/x) terms that leaves O(1/x^2): its relative
+    tolerance grows with x (1e-10 * max(1, x / 100))."""
+    import ctypes as C
+    mp = pytest.importorskip("mpmath")
+    lib = load()
+    dp = C.POINTER(C.c_double)
+    lib.hostsim_log_bessel_i2.argtypes = [C.c_double, C.c_double, dp]
+    lib.hostsim_log_bessel_i2.restype = None
+    lib.hostsim_log_bessel_i.argtypes = [C.c_double, C.c_double, dp]
+    lib.hostsim_log_bessel_i.restype = None
+    mp.mp.dps = 40
+    f = lambda a, b: mp.log(mp.besseli(b, a, maxterms=10 ** 7))
+    for x, q in [(0.01, -0.5), (0.3, 0.0), (2.5, 0.7), (9.0, 3.2), (35.0, -0.7), (80.0, 12.0), (700.0, 1.5), (3830.0, 2000.0),
+                 (3830.0, 0.25), (2.0e4, 150.0), (50.0, 5000.0)]:
+        out, o1 = np.zeros(6), np.zeros(3)
+        lib.hostsim_log_bessel_i2(x, q, out.ctypes.data_as(dp))
+        lib.hostsim_log_bessel_i(x, q, o1.ctypes.data_as(dp))
+        assert abs(out[0] - o1[0]) <= 4e-15 * max(1.0, abs(o1[0])) and np.allclose(out[1:3], o1[1:3], rtol=1e-12, atol=1e-13)
+        xf, qf = mp.mpf(x), mp.mpf(q)
+        for k, (nx, nq) in enumerate([(2, 0), (1, 1), (0, 2)]):
+            ref = float(mp.diff(f, (xf, qf), (nx, nq)))
+            tol = 1e-10 * max(1.0, x / 100.0) if k == 0 else 1e-10
+            assert abs(out[3 + k] - ref) <= tol * max(abs(ref), 1e-12 if k else 0.0) + 1e-300, (x, q, k, out[3 + k], ref)
+
