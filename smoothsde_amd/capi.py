@@ -702,9 +702,10 @@ class Engine:
 
     def hess(self, par, idx):
         """ssde_hess: exact second derivatives of the joint penalised nllk over the full-parameter indices `idx` -- what
-        info()["exact_hess_scope"] says: 3 every free entry (state-space models with H = sigma_obs^2 I on the lane = direction path,
-        or created with FLAG_EXACT_HESS: constant or row-varying coefficients, track shards and communicator ranks summed),
-        2 the coefficients of the direct families BM / OU (+ log_lambda), 1 the drift coefficients of a smooth-drift state-space
+        info()["exact_hess_scope"] says: 3 every free entry (state-space models on the lane = direction path -- row-varying
+        coefficients, per-row H_array, ESEAL_SSM -- or created with FLAG_EXACT_HESS; track shards and communicator ranks summed),
+        2 the coefficients of the direct families BM / OU / BM_t / CIR, decaying columns and log_decay included (+ log_lambda),
+        1 the drift coefficients of a smooth-drift state-space
         batch (+ log_lambda), 0 nothing: EngineError with status 2, difference the gradient.  Returns an (len(idx), len(idx)) array."""
         par = np.ascontiguousarray(par, dtype=np.float64)
         ix = np.ascontiguousarray(idx, dtype=np.int32)

@@ -33,6 +33,8 @@ def random_problem(seed, big=False, wide=False):
     d = 1 if model in ("BM_t", "ESEAL_SSM") else int(rng.integers(1, 3))
     if wide:                              # responses wider than two columns: column pairs behind one handle
         d = 3 + (seed // len(WIDE_MODELS)) % 2
+        if seed >= 96:                    # round 5: five to eight columns (coupled ones: one filter on k_dense_wide.hip)
+            d = 5 + (seed // len(WIDE_MODELS)) % 4
     kalman = model in ("CTCRW", "OU_SSM", "BM_SSM")
     n_tracks = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(60, 140))
     long_tracks = rng.random() < 0.35
@@ -127,12 +129,13 @@ def random_problem(seed, big=False, wide=False):
     return pb, par
 
 
-_WLO, _WHI = (int(v) for v in os.environ.get("SSDE_FUZZ_WIDE_SEEDS", "0:96").split(":"))
+_WLO, _WHI = (int(v) for v in os.environ.get("SSDE_FUZZ_WIDE_SEEDS", "0:144").split(":"))
 
 
 @pytest.mark.parametrize("seed", range(_WLO, _WHI))
 def test_random_wide_problem_matches_oracle(seed):
-    """n_dim in {3, 4}: the engine's column pairs against the oracle's full n_dim-dimensional matrix recursion"""
+    """n_dim in {3, 4} (seeds from 96 on: 5 ... 8): the engine's column pairs -- or, where H / P0 couple them, its one wide filter -- against
+    the oracle's full n_dim-dimensional matrix recursion"""
     pb, par = random_problem(seed, wide=True)
     eng = capi.Engine(pb)
     val, grad = eng.eval(par, order=1)
