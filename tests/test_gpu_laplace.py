@@ -240,7 +240,7 @@ def _exact_marginal_gradient(pb, p_hat, io, ir):
     return (g_theta + hl_theta + du.T @ hl_u).numpy()
 
 
-@pytest.mark.parametrize("name", ["OU_d1_tv", "BM_d2_tv", "OU_d1_tv2"])
+@pytest.mark.parametrize("name", ["OU_d1_tv", "BM_d2_tv", "OU_d1_tv2", "BM_t_d1_tv", "OU_d1_decay"])
 def test_laplace_gradient_with_exact_hessians_reaches_1e_7(name):
     rec = GOLD[name]
     pb = problem_from_spec(rec)
