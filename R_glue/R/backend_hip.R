@@ -126,7 +126,7 @@ make_hip_obj <- function(sde, tmb_dat, tmb_par, map, device = NULL, random = NUL
     list(par = setNames(par_full[free], nm_full[free]),
          fn = function(x = par_full[free]) eval_at(x)$value,
          gr = function(x = par_full[free]) matrix(eval_at(x)$gradient[free], nrow = 1),
-         he = function(x = par_full[free]) {     # exact where the engine has second derivatives (ssde_hess: BM / OU), else
+         he = function(x = par_full[free]) {     # exact where the engine has second derivatives (ssde_hess; info()["exact_hess_scope"]), else
              if(!laplace) {                      # finite differences of the GPU gradient
                  full <- par_full; full[free] <- x
                  He <- .Call("ssdeR_hess", ptr, full, as.integer(free - 1L), PACKAGE = "smoothSDE")

@@ -237,10 +237,11 @@ SEXP ssdeR_info(SEXP ptr) {
     ssde_info(h, &inf);
     /* kernel_id: SSDE_KERNEL_* -- which kernel family ran the last evaluation's rows (ABI 10) */
     const char *nms[] = {"n_par_full", "n_free", "path", "uniform_dt", "n_tracks", "n_rows", "window", "window_check",
-                         "n_rows_tiled", "n_groups", "n_clean_groups", "n_devices", "kernel_id", "comm_ranks", "comm_ranks_reported"};
+                         "n_rows_tiled", "n_groups", "n_clean_groups", "n_devices", "kernel_id", "comm_ranks", "comm_ranks_reported",
+                         "exact_hess_scope"};
     double vals[] = {inf.n_par_full, inf.n_free, inf.path, inf.uniform_dt, (double)inf.n_tracks, (double)inf.n_rows,
                      inf.window, inf.window_check, (double)inf.n_rows_tiled, inf.n_groups, inf.n_clean_groups, inf.n_devices,
-                     inf.kernel_id, inf.comm_ranks, inf.comm_ranks_reported};
+                     inf.kernel_id, inf.comm_ranks, inf.comm_ranks_reported, inf.exact_hess_scope};
     const int nv = (int)(sizeof(vals) / sizeof(vals[0]));
     SEXP out = PROTECT(Rf_allocVector(REALSXP, nv)), nm = PROTECT(Rf_allocVector(STRSXP, nv));
     for (int i = 0; i < nv; i++) { REAL(out)[i] = vals[i]; SET_STRING_ELT(nm, i, Rf_mkChar(nms[i])); }
