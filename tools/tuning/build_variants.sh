@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/scratch/build_variants.sh NAME "FLAGS" ... : kernel-tuning builds of k_iso_adj.hip linked against the current objects
+# tools/tuning/build_variants.sh NAME "FLAGS" ... : kernel-tuning builds of k_iso_adj.hip linked against the current objects
 set -e
 cd /root/repo/smoothsde_amd/csrc
 mkdir -p ../../build/variants
