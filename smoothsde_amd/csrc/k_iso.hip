@@ -39,6 +39,9 @@ constexpr int ISO_U = SSDE_ISO_U;
 #ifndef SSDE_ISO_WAVES
 #define SSDE_ISO_WAVES 2        // waves per SIMD the general kernels are built for
 #endif
+#ifndef SSDE_ISO_WAVES_IRR
+#define SSDE_ISO_WAVES_IRR 1    // ... CTCRW on an irregular grid (a per-row transition: 16 more doubles per lane)
+#endif
 #ifndef SSDE_ISO_WAVES_SCAL
 #define SSDE_ISO_WAVES_SCAL 2   // ... the scalar-covariance models (OU_SSM, BM_SSM)
 #endif
@@ -636,7 +639,7 @@ __device__ __forceinline__ void iso_quiet_body(const IsoArgs& A) {
 // (CTCRW on an irregular grid carries a per-row transition -- 16 more doubles per lane and an exp -- and spills under
 // that cap: one wave per SIMD with the whole register file, as before.)
 template <int MODEL, int D, int MASK, bool UNI>
-__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_ISO_WAVES : 1) : SSDE_ISO_WAVES_SCAL) void iso_mask_kernel(const IsoArgs A) {
+__global__ __launch_bounds__(WG_WAVES * WAVE, (MODEL == M_CTCRW) ? (UNI ? SSDE_ISO_WAVES : SSDE_ISO_WAVES_IRR) : SSDE_ISO_WAVES_SCAL) void iso_mask_kernel(const IsoArgs A) {
     iso_mask_body<MODEL, D, MASK, UNI>(A);
 }
 // ... the same lanes with quiet rows (regular grid, a.quiet_w > 0): a kernel of its own, so that batches without quiet rows run

@@ -82,7 +82,13 @@ for label, env in (("lane=track adjoint", {"SSDE_CV_ADJ": "2"}), ("lane=track ta
         eng.eval(par + 1e-3 * np.sin(k + np.arange(len(par))))
     wall = (time.perf_counter() - t0) / reps
     inf = eng.info()
-    print(json.dumps(dict(kernel=label, engine_kernel=capi.KERNEL_NAMES.get(inf["kernel_id"], "?"), path=capi.PATH_NAMES[inf["path"]], tracks=M, rows=T,
+    phases = {}
+    for k in range(8):                                     # where an evaluation's time goes (median of 8 stamped evaluations)
+        eng.eval(par + 1e-3 * np.cos(k + np.arange(len(par))))
+        for name, ms in eng.last_phase_ms().items():
+            phases.setdefault(name, []).append(ms)
+    phases = {name: round(float(np.median(v)), 5) for name, v in phases.items()}
+    print(json.dumps(dict(kernel=label, phases_ms=phases, engine_kernel=capi.KERNEL_NAMES.get(inf["kernel_id"], "?"), path=capi.PATH_NAMES[inf["path"]], tracks=M, rows=T,
                           columns=nre, ms_per_eval=1e3 * wall,
                           rows_per_s=n / wall, main_kernel_ms=inf["main_kernel_ms"], windows=inf["lanes_per_track"], warm_up=inf["window"],
                           window_check=inf["window_check"], retries=inf["window_retries"], create_s=t_create,
