@@ -556,8 +556,8 @@ def argos_workload(M, T, dev, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2p")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the configuration's batch split over the ranks; weak: that many tracks PER rank")
