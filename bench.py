@@ -17,7 +17,9 @@ last one).  Workloads (`--config`):
 `--scaling strong` (the default: the metric names ONE batch "on 1/2/4/8 GPUs") cuts the batch into whole-track shards,
 rank r of N owning tracks [r M / N, (r + 1) M / N) -- the same batch at every N, because the simulator's numbers are a
 function of (seed, global track index, row) and of nothing else (ssde_simulate, csrc/k_sim.hip); `--scaling weak` gives
-every rank the whole configuration's track count (N times the work at N ranks).
+every rank the whole configuration's track count (N times the work at N ranks).  At N > 1 the strong-scaling line also
+carries, as `secondary[0]`, the weak-scaling reading of the same launch timed in the same run (weak_scaling_probe: every
+rank a whole configuration's batch through the same engines and collective; BASELINE config 4's shape to within 25 %).
 
     python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -338,6 +340,71 @@ def join_ranks(handles, rank, world, dist):
             h.eng = capi.Engine(h.pb)
         return err
     return None
+
+
+def weak_scaling_probe(args, dev, rank, world, dist, steps):
+    """N > 1, strong scaling (the default): the SAME launch once more as a weak-scaling batch -- every rank a whole configuration's
+    worth of tracks (N x 10^4 x 10^4 rows in all: BASELINE config 4's shape, 10^5 tracks on 8 GPUs, to within 25 %) -- so that the
+    driver's run shows both readings of "1/2/4/8 GPUs".  Every phase ends with an agreement over the gloo group: a rank that failed
+    makes ALL ranks leave together (no rank is left alone in a collective), and the main line is printed either way."""
+    import copy
+    import torch
+    from smoothsde_amd import capi
+
+    def agreed(local_err):
+        flag = torch.tensor([1.0 if local_err else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag.item() > 0
+
+    a2 = copy.copy(args)
+    a2.scaling, a2.steps, a2.warmup = "weak", steps, min(args.warmup, 3)
+    hs, err = [], ""
+    try:
+        hs = build_handles(a2, dev, rank, world)
+    except Exception as e:  # noqa: BLE001
+        err = f"build: {e}"
+    if agreed(err):
+        for h in hs:
+            h.eng.close()
+        return {"workload": "weak-scaling probe", "error": err or "another rank could not build its batch"}
+    host_reduce = join_ranks(hs, rank, world, dist)          # (agrees by itself; falls back to the host sum like the main run)
+    h0 = hs[0]
+    val_c, grad = C.c_double(), np.zeros(h0.npar)
+    gp, vp = grad.ctypes.data_as(C.POINTER(C.c_double)), C.byref(val_c)
+    err = ""
+    try:
+        for k in range(a2.warmup):
+            h0.eng._check(h0.eng.lib.ssde_eval(h0.eng._h, h0.ptrs[-1 - k], h0.npar, 1, vp, gp))
+    except Exception as e:  # noqa: BLE001
+        err = f"warm-up: {e}"
+    if agreed(err):
+        h0.eng.close()
+        return {"workload": "weak-scaling probe", "error": err or "another rank failed in its warm-up"}
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    try:
+        for k in range(steps):
+            h0.eng._check(h0.eng.lib.ssde_eval(h0.eng._h, h0.ptrs[k], h0.npar, 1, vp, gp))
+            if host_reduce:
+                buf = torch.from_numpy(np.concatenate([[val_c.value], grad]))
+                dist.all_reduce(buf)
+    except Exception as e:  # noqa: BLE001  (an engine error is the same on every rank -- same parameters -- so nobody waits alone)
+        err = f"step: {e}"
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    inf = h0.eng.info()
+    h0.eng.close()
+    if agreed(err):
+        return {"workload": "weak-scaling probe", "error": err or "another rank failed in a timed step"}
+    rows = h0.rows_total
+    return {"workload": f"weak scaling: {world} ranks x {args.tracks} {args.model} tracks x {args.rows} rows (every rank a whole configuration's batch), "
+                        f"{'in-engine ncclAllReduce' if not host_reduce else 'HOST all-reduce over gloo'} of 2+p doubles per step",
+            "scaling": "weak", "n_gpus": world, "value": rows * steps / float(el.item()), "unit": "track-timesteps/s", "steps": steps,
+            "ms_per_step": 1e3 * float(el.item()) / steps, "rows_total": rows, "kernel": capi.KERNEL_NAMES.get(inf["kernel_id"], "?"),
+            "comm_ranks_reported": inf["comm_ranks_reported"], "nllk_at_last_step": val_c.value}
 
 
 def _roofs_of(inf, kern_ms):
@@ -878,6 +945,15 @@ def main():
     for h in handles:
         h.eng.close()
     del handles
+    # N > 1 under strong scaling: the weak-scaling reading of the same launch beside it (SSDE_BENCH_WEAK_PROBE=1: also with one rank,
+    # to rehearse it on a one-GPU box)
+    if use_comm and args.scaling == "strong" and args.config in ("c2p", "c4") and not args.no_secondary and \
+            (world > 1 or os.environ.get("SSDE_BENCH_WEAK_PROBE")):
+        try:
+            probe = weak_scaling_probe(args, dev, rank, world, dist, max(3, min(args.steps, 50)))
+        except Exception as e:  # noqa: BLE001  (never the line)
+            probe = {"workload": "weak-scaling probe", "error": str(e)}
+        line["secondary"] = [probe]
     if rank == 0 and world == 1 and not args.no_secondary and args.config == "c2p" and args.model == "CTCRW":
         # outside the timed region of `value`: the same batch shape on an irregular grid and with 5 % missing rows
         sec = []
@@ -923,7 +999,7 @@ def main():
             sec.extend(baseline_config_workloads(dev, max(3, args.steps // 2), M, T))
         except Exception as e:  # the secondary numbers must never take the bench line down
             sec.append({"workload": "failed", "error": str(e)})
-        line["secondary"] = sec
+        line["secondary"] = line.get("secondary", []) + sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline()

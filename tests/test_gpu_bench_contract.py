@@ -3,6 +3,8 @@
 One JSON object on stdout and nothing else: the keys the driver reads, a roofline object whose fraction is formed on the
 bytes the resident layout has to read and never exceeds 1, the secondary workloads, the CPU baseline."""
 import json
+
+import numpy as np
 import os
 import subprocess
 import sys
@@ -97,6 +99,25 @@ def test_one_rank_communicator_rehearsal_prints_one_line_too():
     for k in ("rows", "kernel_ms", "finalize_ms", "allreduce_wait_ms", "readback_ms", "host_total_ms"):
         assert k in pr[0], k
     assert pr[0]["allreduce_wait_ms"] > 0 and pr[0]["kernel_ms"] > 0 and pr[0]["finalize_ms"] > 0
+
+
+def test_strong_scaling_line_carries_the_weak_scaling_reading_of_the_same_launch():
+    """at N > 1 (rehearsed here with ONE rank and a real one-rank communicator) the line of the default, strong-scaling run carries
+    a `secondary` entry that times the weak-scaling batch -- every rank a whole configuration's worth of tracks -- through the same
+    engines and collective; its failure modes end in an entry with `error`, never in a missing line"""
+    env = dict(os.environ, SSDE_BENCH_SELF_LAUNCH="1", SSDE_BENCH_FORCE_COMM="1", SSDE_BENCH_WEAK_PROBE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tracks", "640", "--rows", "800", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong"
+    w = d["secondary"][0]
+    assert "error" not in w, w
+    assert w["scaling"] == "weak" and w["n_gpus"] == 1 and w["rows_total"] == 640 * 800 and w["value"] > 0 and w["comm_ranks_reported"] == 1
+    assert "ncclAllReduce" in w["workload"]
+    assert abs(w["nllk_at_last_step"]) > 0 and np.isfinite(w["nllk_at_last_step"])
 
 
 def test_c5_with_a_communicator_sums_the_three_handles_in_one_collective():
