@@ -153,6 +153,9 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             // few columns and few tangents besides the directions the filter carries: one wave per (group, window) does it all
             bool mu_streamed = false;
             for (auto& c : cols) mu_streamed = mu_streamed || c.type >= 3;
+            // (a drift column whose coefficient is held FIXED is no tangent, but the drift still varies from row to row: iso_few_kernel
+            //  has no such lanes -- found by fuzz seed 552, round 5: launch_iso_few refused the launch)
+            for (auto& sl : h->slots) mu_streamed = mu_streamed || (sl.par_j < h->d && sl.col >= 0);
             h->cv_few = !h->cv_full && !h->has_h && !mu_streamed && h->n_stream_cols >= 1 && h->n_stream_cols <= 2 * CV_FEW_K &&
                         (int)cols.size() <= 2 * CV_KC && !getenv("SSDE_CV_NO_FEW");
             // (the wide instantiation -- more than four columns or tangents -- of CTCRW with two response columns spills: the pipeline)
@@ -165,6 +168,7 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
             // (SSDE_CV_ADJ=2: those too; SSDE_CV_ADJ=0: forward tangents everywhere, the A/B)
             bool mu_streamed = false;
             for (auto& c : cols) mu_streamed = mu_streamed || (c.type >= 3 && c.chan >= 0);
+            for (auto& sl : h->slots) mu_streamed = mu_streamed || (sl.par_j < h->d && sl.col >= 0);       // (free or fixed: the lanes are the MU ones either way)
             const char* e = getenv("SSDE_CV_ADJ");
             const int mode = e ? atoi(e) : 1;
             h->cv_adj = mode > 0 && !h->cv_single && (!h->has_h || h->d == 1 || h->cv_full) && (!h->cv_full || h->d == 2) && h->n_stream_cols >= 1 &&

@@ -218,7 +218,13 @@ def _kalman_seeds(lo, hi, models):
     return [s for s in range(lo, hi) if models[s % len(models)] in ("CTCRW", "OU_SSM", "BM_SSM")]
 
 
-@pytest.mark.parametrize("seed,wide", [(s, False) for s in _kalman_seeds(_LO, _HI, MODELS)] + [(s, True) for s in _kalman_seeds(_WLO, _WHI, WIDE_MODELS)])
+# seeds a one-off hunt found something with (kept in the suite whatever the range): 552 = a drift column with a FIXED coefficient next to
+# a smooth tau -- the few-column kernel has no row-varying-drift lanes and refused the launch (round 5)
+_HUNTED = [552]
+
+
+@pytest.mark.parametrize("seed,wide", [(s, False) for s in _kalman_seeds(_LO, _HI, MODELS)] + [(s, True) for s in _kalman_seeds(_WLO, _WHI, WIDE_MODELS)] +
+                         [(s, False) for s in _HUNTED if not _LO <= s < _HI])
 def test_random_problem_on_the_register_lanes_whatever_its_size(seed, wide, monkeypatch):
     """The size rules of ssde_create keep small batches off the register-lane kernels with streamed columns (k_iso_drift.hip,
     k_iso_colvar.hip, k_iso_onewave.hip), so the seeds above hardly reach them; SSDE_DRIFT_MIN_TRACKS=1 sends every design
