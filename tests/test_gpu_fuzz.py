@@ -179,10 +179,12 @@ def test_random_problem_matches_oracle(seed):
             _, _, oaest = oracle_eval(pb, np.asarray(par, dtype=float), order=1, threads=4, report=True)
             sc = max(1.0, np.nanmax(np.abs(oaest)))
             assert aest.shape == oaest.shape and np.allclose(aest, oaest, rtol=1e-9, atol=1e-9 * sc, equal_nan=True), ctx
-        if info["path"] == 3 and pb.model in ("CTCRW", "OU_SSM", "BM_SSM"):
-            # row-varying coefficients on the lane = direction path: the exact second derivatives (hyper-dual lanes, k_tv_hess.hip)
-            # over up to eight free entries against central differences of the engine's own gradient
-            free = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and not (pb.off_lambda <= k < pb.off_lambda + pb.n_smooth)][:8]
+        if info["exact_hess_scope"] >= 2:
+            # the exact second derivatives -- hyper-dual lanes on the lane = direction path (row-varying coefficients, ESEAL_SSM:
+            # k_tv_hess.hip), the closed-form / series + hyper-dual per-row D of the direct families incl. decaying columns and
+            # log_decay (k_direct_hess.hip) -- over up to eight free entries against central differences of the engine's own gradient
+            free = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and not (pb.off_lambda <= k < pb.off_lambda + pb.n_smooth)]
+            free = free[:4] + free[-4:] if len(free) > 8 else free           # (the first coefficients and the last: log_decay / coeff_re)
             try:
                 H = eng.hess(par, free)
             except capi.EngineError as e:
@@ -195,6 +197,25 @@ def test_random_problem_matches_oracle(seed):
                     pp[k] += 1e-5; pm[k] -= 1e-5
                     Hfd[:, j] = (eng.eval(pp, order=1)[1][free] - eng.eval(pm, order=1)[1][free]) / 2e-5
                 assert np.max(np.abs(H - Hfd)) <= 2e-5 * max(1.0, np.max(np.abs(Hfd))), (np.max(np.abs(H - Hfd)), np.max(np.abs(Hfd)), ctx)
+        if info["exact_hess_scope"] == 0 and info["path"] == 1 and seed % 3 == 0 and pb.n <= 4000:
+            # a handle on the register kernels (first-order sensitivities only): with SSDE_FLAG_EXACT_HESS it keeps its rows on the
+            # lane = direction path as well and answers ssde_hess from there -- same evaluation, exact second derivatives
+            flags0 = pb.flags
+            pb.flags |= capi.FLAG_EXACT_HESS
+            e2 = capi.Engine(pb)
+            pb.flags = flags0
+            v2, g2 = e2.eval(par, order=1)
+            assert v2 == val and np.array_equal(g2, grad), ctx
+            if e2.info()["exact_hess_scope"] == 3:
+                free = [k for k in range(pb.n_par_full) if not pb.par_fixed[k] and not (pb.off_lambda <= k < pb.off_lambda + pb.n_smooth)][:6]
+                H = e2.hess(par, free)
+                Hfd = np.zeros_like(H)
+                for j, k in enumerate(free):
+                    pp, pm = np.array(par, dtype=float), np.array(par, dtype=float)
+                    pp[k] += 1e-5; pm[k] -= 1e-5
+                    Hfd[:, j] = (eng.eval(pp, order=1)[1][free] - eng.eval(pm, order=1)[1][free]) / 2e-5
+                assert np.max(np.abs(H - Hfd)) <= 2e-5 * max(1.0, np.max(np.abs(Hfd))), (np.max(np.abs(H - Hfd)), np.max(np.abs(Hfd)), ctx)
+            e2.close()
         d = pb.desc()
         if (pb.model in ("BM", "OU", "BM_SSM", "OU_SSM", "CTCRW") and not (d.h_array or d.p0 or d.a0) and
                 all(x is None for x in pb.X_fe) and not getattr(pb, "n_decay", 0)):
