@@ -531,11 +531,9 @@ def baseline_config_workloads(dev, steps, tracks=10_000, rows=10_000):
     return out
 
 
-def row_varying_workload(M, T, dev, steps, k_cols=9):
-    """1e4 CTCRW tracks with tau AND nu smooth in a covariate (2 x 9 design columns streamed next to the observations): the
-    batch-scale form of BASELINE's config 1 (nllk_ctcrw.hpp:143-156), on the lane = track kernel with the gradient by a reverse
-    sweep (k_iso_adj.hip; SSDE_CV_ADJ=0: one filter tangent per design column, k_iso_colvar.hip).  Hat-function basis of a per-row
-    covariate, built on the device."""
+def row_varying_batch(M, T, dev, k_cols=9):
+    """the batch of row_varying_workload, in HBM: (ID, times, obs, B, S, par_fixed) -- tests/test_gpu_whole_batch.py compares the very
+    launch that is timed with the oracle"""
     import torch
     from smoothsde_amd import capi
     from smoothsde_amd.synth import second_difference_penalty
@@ -550,11 +548,26 @@ def row_varying_workload(M, T, dev, steps, k_cols=9):
     del i, u
     S = second_difference_penalty(k_cols)
     fixed = np.r_[0, 1, 1, 0, 0, 1, 1, np.zeros(2 * k_cols)].astype(np.uint8)            # mu and the smoothing parameters held
-    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), X_re=[None, None, B, B], S_list=[S, S], par_fixed=fixed))
-    del ID, times, obs, B
+    return ID, times, obs.contiguous(), B, S, fixed
+
+
+def row_varying_theta(k, k_cols=9):
     npar = 7 + 2 * k_cols
+    return np.ascontiguousarray(np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(2 * k_cols))] + 1e-3 * np.sin(k + np.arange(npar)))
+
+
+def row_varying_workload(M, T, dev, steps, k_cols=9):
+    """1e4 CTCRW tracks with tau AND nu smooth in a covariate (2 x 9 design columns streamed next to the observations): the
+    batch-scale form of BASELINE's config 1 (nllk_ctcrw.hpp:143-156), on the lane = track kernel with the gradient by a reverse
+    sweep (k_iso_adj.hip; SSDE_CV_ADJ=0: one filter tangent per design column, k_iso_colvar.hip).  Hat-function basis of a per-row
+    covariate, built on the device."""
+    import torch
+    from smoothsde_amd import capi
+    ID, times, obs, B, S, fixed = row_varying_batch(M, T, dev, k_cols)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, X_re=[None, None, B, B], S_list=[S, S], par_fixed=fixed))
+    del ID, times, obs, B
     def theta(k):
-        return np.ascontiguousarray(np.r_[np.log(0.05), 0, 0, 0, 0, 0, 0, 0.05 * np.sin(np.arange(2 * k_cols))] + 1e-3 * np.sin(k + np.arange(npar)))
+        return row_varying_theta(k, k_cols)
     for k in range(2):
         eng.eval(theta(-1 - k))
     ssde_eval = eng.bound_eval(order=1)

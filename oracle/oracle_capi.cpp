@@ -117,3 +117,7 @@ int oracle_eval_data(const ssde_desc* d, const double* par, int order, double* v
 }
 
 }  // extern "C"
+
+// arbiter mode of the restatement (ssde_oracle.hpp: keep_P_symmetric): 0 = the literal recursion (default), 1 = P <- (P + P') / 2
+extern "C" void ssde_oracle_keep_P_symmetric(int on) { ssde_oracle::keep_P_symmetric() = on != 0; }
+

@@ -40,6 +40,14 @@ inline bool is_na(double x, int na_mode) {
 // Small dense matrices (the reference uses heap-allocated Eigen dynamic matrices,
 // tmbutils matrix<Type>; state dimension is at most 2*n_dim).
 // ---------------------------------------------------------------------------------------
+// ARBITER MODE (off by default; ssde_oracle_keep_P_symmetric(1) in either library).  The reference propagates P as a full matrix
+// (nllk_ctcrw.hpp:241, Q8); with a measurement covariance that couples the response columns that recursion AMPLIFIES the antisymmetric
+// part rounding leaves in P (~1.2 per row), and the literal evaluation in double loses the likelihood after ~150 rows -- the literal
+// evaluation in binary128 after ~400.  With this switch the update ends with P <- (P + P') / 2, which is the identity in exact
+// arithmetic: NOT the reference's arithmetic, the value the reference's MODEL defines; used only to arbitrate between the engine and
+// the literal restatement where the latter is roundoff (tests/test_oracle_golden.py::test_reference_form_loses_...).
+inline bool& keep_P_symmetric() { static bool on = false; return on; }
+
 constexpr int MAXD = 16;         // widest state: CTCRW with eight response columns run as one filter
 constexpr int MAT_INLINE = 64;   // entries kept in the object (sdim <= 8: every configuration but the widest coupled responses)
 
@@ -501,6 +509,9 @@ Type nllk_kalman(const Problem& p, const Type* par, double* aest_all) {
                     aest = add(add(mul(T, aest), mul(K, u)), drift);    // line 238
                     Mat<Type> L = sub(T, mul(K, Z));                     // line 240
                     Pest = add(mul(mul(T, Pest), transpose(L)), Q);     // line 241
+                    if (keep_P_symmetric())                             // (arbiter mode only: see the top of this file)
+                        for (int a = 0; a < sdim; a++)
+                            for (int b = a + 1; b < sdim; b++) { const Type m = (Pest(a, b) + Pest(b, a)) / Type(2.0); Pest(a, b) = m; Pest(b, a) = m; }
                 }
             }
         }

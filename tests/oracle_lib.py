@@ -47,10 +47,15 @@ def load_oracle():
 _QLIB = None
 
 
-def oracle_eval_quad(problem: Problem, par, order: int = 1, fd_step: float = 1e-10):
-    """The same restated templates evaluated in IEEE binary128 (oracle/oracle_quad.cpp): value rounded to double once,
-    gradient by central differences of the binary128 function.  Slow (single thread, software quad arithmetic):
-    the arbiter for cases where the double-precision oracle and the engine disagree."""
+def keep_P_symmetric(on: bool):
+    """ARBITER mode of both oracle libraries (oracle/ssde_oracle.hpp: keep_P_symmetric): the update ends with P <- (P + P') / 2.  Not the
+    reference's arithmetic -- the value its model defines where the literal recursion is roundoff (a coupling H_array on long tracks)."""
+    global _QLIB
+    load_oracle().ssde_oracle_keep_P_symmetric(int(bool(on)))
+    _load_quad().ssde_oracle_keep_P_symmetric(int(bool(on)))
+
+
+def _load_quad():
     global _QLIB
     if _QLIB is None:
         path = os.path.join(_ORACLE_DIR, "liboracle_quad.so")
@@ -59,6 +64,14 @@ def oracle_eval_quad(problem: Problem, par, order: int = 1, fd_step: float = 1e-
         _QLIB = C.CDLL(path)
         _QLIB.oracle_eval_quad.argtypes = [C.POINTER(SsdeDesc), _dp, C.c_int, _dp, _dp, C.c_double]
         _QLIB.oracle_eval_quad.restype = C.c_int
+    return _QLIB
+
+
+def oracle_eval_quad(problem: Problem, par, order: int = 1, fd_step: float = 1e-10):
+    """The same restated templates evaluated in IEEE binary128 (oracle/oracle_quad.cpp): value rounded to double once,
+    gradient by central differences of the binary128 function.  Slow (single thread, software quad arithmetic):
+    the arbiter for cases where the double-precision oracle and the engine disagree."""
+    _load_quad()
     d = problem.desc()
     par = np.ascontiguousarray(par, dtype=np.float64)
     val = C.c_double()

@@ -793,3 +793,54 @@ def test_sharded_handle_and_one_rank_communicator():
         vb, gb = eb.eval(parh)
         assert abs(va - vb) <= 1e-11 * abs(va) and np.max(np.abs(ga - gb)) <= 1e-9 * np.max(np.abs(ga))
         ea.close(); eb.close()
+
+
+# ---- a measurement covariance that COUPLES the response columns, on long tracks: every engine path against the arbiter ----------------------
+@pytest.mark.parametrize("path", ["iso_full", "lane=direction dense lanes", "dense_kernel", "reverse sweep, full lanes", "tangent pipeline, full lanes"])
+def test_coupling_H_on_long_tracks_every_path_against_the_stabilised_oracle(path, monkeypatch):
+    """Argos error ellipses (H_array with off-diagonal entries) on tracks of 1500 rows.  The reference's recursion keeps P as a full
+    matrix and amplifies the antisymmetric rounding residue there (tests/test_oracle_golden.py::test_reference_form_loses_...): the
+    LITERAL oracle is 1e-3 or worse from the likelihood after a few hundred rows, so the comparison is made with the oracle in
+    arbiter mode (P kept symmetric: equal to the binary128 evaluation and to the joint Gaussian where those can be computed).  Every
+    engine path that takes such an H -- the 4 x 4 covariance lanes (iso_full_kernel), the lane = direction dense lanes and the
+    lane = track dense kernel (ssde_dense.hpp, P symmetrised since round 5), the full-covariance lanes of the reverse sweep and of
+    the tangent pipeline (row-varying tau / nu) -- must give THAT value: 1e-10 / 1e-8."""
+    from oracle_lib import keep_P_symmetric, oracle_eval
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty, simulate
+    M, T = 96, 1500
+    ID, times, obs = simulate("CTCRW", M, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13)
+    n = len(ID)
+    rng = np.random.default_rng(17)
+    A = 0.05 * rng.standard_normal((n, 2, 2))
+    H = np.ascontiguousarray(np.transpose(np.einsum("nij,nkj->nik", A, A) + 0.0025 * np.eye(2), (1, 2, 0)))
+    kw, par = dict(par_fixed=np.array([1, 1, 1, 0, 0], dtype=np.uint8)), np.array([0.0, 0.0, 0.0, np.log(2.0), 0.1])
+    flags = 0
+    if path == "lane=direction dense lanes":
+        monkeypatch.setenv("SSDE_NO_COLVAR", "1")
+    elif path == "dense_kernel":
+        flags = capi.FLAG_FORCE_DENSE
+    elif path in ("reverse sweep, full lanes", "tangent pipeline, full lanes"):
+        u = 0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 24)
+        B = bspline_basis(u, 5)
+        S = second_difference_penalty(5)
+        kw = dict(X_re=[None, None, B, B], S_list=[S, S], par_fixed=np.r_[1, 1, 1, 0, 0, 1, 1, np.zeros(10)].astype(np.uint8))
+        par = np.r_[0.0, 0.0, 0.0, np.log(2.0), 0.1, 0.0, 0.0, 0.05 * np.sin(np.arange(10))]
+        monkeypatch.setenv("SSDE_CV_ADJ", "2" if path.startswith("reverse") else "0")
+        monkeypatch.setenv("SSDE_DRIFT_MIN_TRACKS", "1")
+    pb = capi.Problem("CTCRW", ID, times, obs, H=H, flags=flags, **kw)
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    want = {"iso_full": 13, "lane=direction dense lanes": 16, "dense_kernel": 14, "reverse sweep, full lanes": 17, "tangent pipeline, full lanes": 11}[path]
+    assert inf["kernel_id"] == want, (path, capi.KERNEL_NAMES.get(inf["kernel_id"]))
+    assert inf["window_check"] <= capi.WINDOW_TOL
+    eng.close()
+    lit, _ = oracle_eval(pb, par, order=1, threads=8)
+    keep_P_symmetric(True)
+    try:
+        oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    finally:
+        keep_P_symmetric(False)
+    assert abs(val - oval) <= 1e-10 * abs(oval), (path, val, oval, lit)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (path, grad, ograd)
+    assert abs(lit - oval) >= 1e-8 * abs(oval), (lit, oval)          # (the literal recursion has long left: that is why the arbiter is used)

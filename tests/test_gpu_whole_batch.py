@@ -95,3 +95,29 @@ def test_config_c3_whole_batch_vs_oracle():
     assert abs(val - oval) <= 1e-10 * abs(oval), (val, oval)
     assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (grad, ograd)
     eng.close()
+
+
+def test_row_varying_whole_batch_vs_oracle():
+    """the row-varying launch bench.py times as `secondary` (10^4 CTCRW tracks x 10^3 rows, tau and nu smooth in a covariate, 2 x 9
+    design columns streamed; nllk_ctcrw.hpp:143-156 feeding :195-247): all 10^7 rows, value and all 21 free gradient entries of the
+    reverse sweep (k_iso_adj.hip) against the oracle's forward duals, at the parameter vector of the first timed step"""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    M, T, K = 10_000, 1_000, 9
+    ID, times, obs, B, S, fixed = bench.row_varying_batch(M, T, dev, K)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, X_re=[None, None, B, B], S_list=[S, S], par_fixed=fixed))
+    Bh = B.cpu().numpy()
+    host = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), X_re=[None, None, Bh, Bh], S_list=[S, S], par_fixed=fixed)
+    del ID, times, obs, B
+    theta = bench.row_varying_theta(0, K)
+    val, grad = eng.eval(theta)
+    inf = eng.info()
+    assert inf["n_rows"] == M * T and inf["kernel_id"] == 17 and inf["lanes_per_track"] > 1 and inf["window_check"] <= capi.WINDOW_TOL, inf
+    (oval, ograd), secs = _oracle(host, theta)
+    print("\noracle: %d rows x 21 directions in %.1f s on %d threads" % (M * T, secs, THREADS))
+    assert abs(val - oval) <= 1e-10 * abs(oval), (val, oval)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (grad, ograd)
+    assert np.all(grad[fixed != 0] == 0.0)
+    eng.close()
+

@@ -67,6 +67,45 @@ def test_wide_coupled_responses_against_the_independent_restatement(model, d, va
     assert np.max(np.abs(grad - rgrad)) <= 1e-8 * np.max(np.abs(rgrad)) + 1e-10
 
 
+def test_reference_form_loses_the_likelihood_when_H_couples_the_columns():
+    """A finding of round 5, kept as a test.  The reference propagates P as a FULL matrix, P <- T P (T - K Z)' + Q (nllk_ctcrw.hpp:240-241,
+    Q8).  With a measurement covariance that couples the response columns (H_array with off-diagonal entries: Argos error ellipses) the
+    antisymmetric part that rounding leaves in P is AMPLIFIED by that recursion (~1.2 per row here): the literal restatement in double
+    drifts away from its own evaluation in binary128 -- 1e-10 after 100 rows, 1e-3 after 200 -- while the joint Gaussian of the track
+    (tests/refimpl.py, no recursion) agrees with binary128 to 1e-11, and so does the restatement once P is kept symmetric (the identity
+    in exact arithmetic; oracle/ssde_oracle.hpp: keep_P_symmetric, the ARBITER mode the GPU tests use on long tracks with such an H).
+    With a diagonal H nothing of the kind happens."""
+    from oracle_lib import keep_P_symmetric, oracle_eval_quad
+    from refimpl import ref_eval
+    from smoothsde_amd import capi
+    from smoothsde_amd.synth import simulate
+    fixed = np.array([1, 1, 1, 0, 0], dtype=np.uint8)
+    theta = np.array([0.0, 0.0, 0.0, np.log(2.0), 0.0])
+    drift = {}
+    for T in (100, 200):
+        ID, times, obs = simulate("CTCRW", 2, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13)
+        n = len(ID)
+        for label, H2 in (("coupling", [[0.005, 0.002], [0.002, 0.004]]), ("diagonal", [[0.005, 0.0], [0.0, 0.004]])):
+            H = np.ascontiguousarray(np.transpose(np.tile(np.array(H2), (n, 1, 1)), (1, 2, 0)))
+            pb = capi.Problem("CTCRW", ID, times, obs, par_fixed=fixed, H=H)
+            lit = oracle_eval(pb, theta, order=0)
+            q = oracle_eval_quad(pb, theta, order=0)
+            keep_P_symmetric(True)
+            try:
+                sym, sym_grad = oracle_eval(pb, theta, order=1)
+            finally:
+                keep_P_symmetric(False)
+            rel = lambda a: abs(a - q) / abs(q)     # noqa: E731
+            drift[(T, label)] = rel(lit)
+            assert rel(sym) <= 1e-11, (T, label, rel(sym))                      # the stabilised recursion = binary128
+            if T == 100:
+                rv, rg = ref_eval(pb, theta)                                    # ... = the joint Gaussian, value and gradient
+                assert rel(rv) <= 1e-11, (label, rel(rv))
+                assert np.max(np.abs(sym_grad - rg)) <= 1e-8 * np.max(np.abs(rg)), (label, sym_grad, rg)
+    assert drift[(100, "diagonal")] <= 1e-13 and drift[(200, "diagonal")] <= 1e-13, drift
+    assert drift[(100, "coupling")] >= 1e-12 and drift[(200, "coupling")] >= 1e-5, drift      # (measured 4e-11 and 3e-3)
+
+
 def test_cir_weak_diffusion_against_mpmath_restatement():
     """CIR with sigma = 0.05: Bessel arguments of 10^3-10^4 and orders ~10^3, where the reference's unscaled
     besselI has long overflowed.  The oracle's series (summed outwards from its largest term) against the

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""tools/whole_batch_secondary.py [names...] -- run ON THE GPU BOX: the `secondary` workloads bench.py times, compared WHOLE with the
+literal oracle at their timed sizes (10^4 tracks x 10^4 rows unless said), value and gradient at the parameter vector of the first
+timed step.  tests/test_gpu_whole_batch.py does this for the metric's batch, configs 2 and 3 and the row-varying batch inside the suite;
+these five would add ~6 minutes of oracle time to it, so they are a tool whose output is kept under profiles/.  Uses oracle/ as the
+CHECKER (tests/oracle_lib.py), like the tests.  One JSON line per workload.
+    names: irregular missing missing_one absent argos  (default: all)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from smoothsde_amd import capi  # noqa: E402
+from oracle_lib import keep_P_symmetric, oracle_eval  # noqa: E402
+
+M, T = int(os.environ.get("WB_TRACKS", 10_000)), int(os.environ.get("WB_ROWS", 10_000))
+THREADS = min(16, os.cpu_count() or 8)
+dev = torch.device("cuda:0")
+
+
+def irregular(ID, times, obs):
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    return ID, torch.cumsum(0.5 + torch.rand(len(ID), device=dev, dtype=torch.float64, generator=gen), 0), obs
+
+
+def missing(ID, times, obs):
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    na = torch.rand(len(ID), device=dev, generator=gen) < 0.05
+    na[::T] = False
+    obs[na] = float("nan")
+    return ID, times, obs
+
+
+def missing_one(ID, times, obs):
+    gen = torch.Generator(device=dev); gen.manual_seed(8)
+    rows = torch.randint(1, T, (M,), device=dev, generator=gen) + T * torch.arange(M, device=dev)
+    obs[rows] = float("nan")
+    return ID, times, obs
+
+
+def absent(ID, times, obs):
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    keep = torch.rand(len(ID), device=dev, generator=gen) >= 0.05
+    keep[::T] = True
+    return ID[keep].contiguous(), times[keep].contiguous(), obs[keep].contiguous()
+
+
+def general(mutate):
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=11, device=dev)
+    ID, times, obs = mutate(ID, times, obs.contiguous())
+    fixed = np.zeros(5, dtype=np.uint8); fixed[1:3] = 1
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=fixed))
+    host = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), par_fixed=fixed)
+    return eng, host, bench.theta_for(5, 2, 4, 0)
+
+
+def argos():
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(17)
+    A = 0.05 * torch.randn(M * T, 2, 2, device=dev, dtype=torch.float64, generator=gen)
+    Hn = A @ A.transpose(1, 2)
+    Hn[:, 0, 0] += 0.0025
+    Hn[:, 1, 1] += 0.0025
+    H = Hn.permute(1, 2, 0)
+    fixed = np.array([1, 1, 1, 0, 0], dtype=np.uint8)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs.contiguous(), par_fixed=fixed, H=H))
+    host = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), par_fixed=fixed, H=np.ascontiguousarray(H.cpu().numpy()))
+    return eng, host, np.ascontiguousarray(np.array([0.0, 0.0, 0.0, np.log(2.0), 0.0]) + 1e-3 * np.sin(np.arange(5)))
+
+
+WORK = {"irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
+        "absent": lambda: general(absent), "argos": argos}
+for name in (sys.argv[1:] or list(WORK)):
+    eng, host, theta = WORK[name]()
+    val, grad = eng.eval(theta)
+    inf = eng.info()
+    eng.close()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    extra = {}
+    if name == "argos":
+        # a coupling H_array on 10^4-row tracks: the literal recursion (P a full matrix, nllk_ctcrw.hpp:241) amplifies rounding there and
+        # is percent-level noise; the comparison is with the restatement in ARBITER mode (P kept symmetric = binary128 = joint Gaussian
+        # where those can be computed: tests/test_oracle_golden.py::test_reference_form_loses_...), the literal value printed beside it
+        lit = oracle_eval(host, np.asarray(theta, dtype=float), order=0, threads=THREADS)
+        keep_P_symmetric(True)
+        extra = {"oracle_mode": "arbiter (P kept symmetric)", "literal_oracle_value": lit}
+    oval, ograd = oracle_eval(host, np.asarray(theta, dtype=float), order=1, threads=THREADS)
+    keep_P_symmetric(False)
+    if extra:
+        extra["literal_vs_arbiter_rel"] = abs(extra["literal_oracle_value"] - oval) / abs(oval)
+    secs = time.perf_counter() - t0
+    rel_v = abs(val - oval) / abs(oval)
+    rel_g = float(np.max(np.abs(grad - ograd)) / np.max(np.abs(ograd)))
+    print(json.dumps({"workload": name, "rows": inf["n_rows"], "kernel": capi.KERNEL_NAMES.get(inf["kernel_id"], "?"), "windows": inf["lanes_per_track"],
+                      "window_check": inf["window_check"], "value": val, "oracle_value": oval, "value_rel": rel_v, "grad_rel_of_max": rel_g,
+                      "ok": bool(rel_v <= 1e-10 and rel_g <= 1e-8 and inf["window_check"] <= capi.WINDOW_TOL),
+                      "oracle_seconds": round(secs, 1), "oracle_threads": THREADS, **extra}), flush=True)
+    del host
