@@ -4,7 +4,7 @@ literal oracle at their timed sizes (10^4 tracks x 10^4 rows unless said), value
 timed step.  tests/test_gpu_whole_batch.py does this for the metric's batch, configs 2 and 3 and the row-varying batch inside the suite;
 these five would add ~6 minutes of oracle time to it, so they are a tool whose output is kept under profiles/.  Uses oracle/ as the
 CHECKER (tests/oracle_lib.py), like the tests.  One JSON line per workload.
-    names: irregular missing missing_one absent argos  (default: all)"""
+    names: irregular missing missing_one absent argos  (default: these five);  c5_bm c5_ou c5_ctcrw: the three sub-batches of BASELINE config 5"""
 import json
 import os
 import sys
@@ -75,9 +75,26 @@ def argos():
     return eng, host, np.ascontiguousarray(np.array([0.0, 0.0, 0.0, np.log(2.0), 0.0]) + 1e-3 * np.sin(np.arange(5)))
 
 
-WORK = {"irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
+def c5(i):
+    """BASELINE config 5 as bench.py --config c5 builds it on one GPU: sub-batch i of (BM_SSM, OU_SSM, CTCRW), 30000 ragged tracks of
+    5000-10000 rows, 5 % of the rows missing (column 0 only / every column), every parameter free"""
+    import argparse
+    a = argparse.Namespace(config="c5", tracks=int(os.environ.get("WB_C5_TRACKS", bench.CONFIGS["c5"]["tracks"])), rows=T, scaling="strong", seed=1,
+                           warmup=1, steps=1, model="CTCRW")
+    hs = bench.build_handles(a, dev, 0, 1)
+    for j, h in enumerate(hs):
+        if j != i:
+            h.eng.close()
+    h = hs[i]
+    pb = h.pb
+    host = capi.Problem(h.model, pb._t_id.cpu().numpy(), pb._t_times.cpu().numpy(), pb._t_obs.t().contiguous().cpu().numpy())
+    return h.eng, host, h.thetas[0]
+
+
+WORK = {"c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
+        "irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
         "absent": lambda: general(absent), "argos": argos}
-for name in (sys.argv[1:] or list(WORK)):
+for name in (sys.argv[1:] or [k for k in WORK if not k.startswith('c5')]):
     eng, host, theta = WORK[name]()
     val, grad = eng.eval(theta)
     inf = eng.info()
