@@ -278,3 +278,35 @@ def test_full_size_wide_batch_is_the_sum_of_its_column_pairs():
     want[[0, 3, 4, 5]] += g2
     assert abs(val - (v01 + v2)) <= 1e-12 * abs(val)
     assert np.max(np.abs(grad - want)) <= 1e-11 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("model,d", [("CTCRW", 3), ("OU_SSM", 4), ("CTCRW", 5)])
+def test_wide_coupled_response_on_long_tracks_against_the_stabilised_oracle(model, d):
+    """a CONSTANT measurement covariance with entries between all neighbouring columns, tracks of 400 rows: the reference's full-matrix
+    update amplifies rounding there (the literal oracle is percents away after 400 rows), the engine's dense step keeps P
+    symmetric -- value and gradient against the oracle in arbiter mode, and the literal value is checked to HAVE left"""
+    from oracle_lib import keep_P_symmetric
+    from smoothsde_amd.synth import simulate
+    M, T = 12, 400
+    ID, times, obs = simulate(model, M, T, d, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=13)
+    n = len(ID)
+    H1 = np.diag(np.where(np.arange(d) % 2 == 0, 0.005, 0.004)) + 0.002 * (np.eye(d, k=1) + np.eye(d, k=-1))
+    H = np.ascontiguousarray(np.transpose(np.tile(H1, (n, 1, 1)), (1, 2, 0)))
+    pb = capi.Problem(model, ID, times, obs, H=H)
+    par = np.zeros(pb.n_par_full)
+    par[1 + d] = np.log(2.0) if model != "BM_SSM" else 0.0
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    assert eng.info()["kernel_id"] == 14 and eng.info()["sdim"] == capi.state_dim(model, d)
+    eng.close()
+    lit, _ = oracle_eval(pb, par, order=1, threads=8)
+    keep_P_symmetric(True)
+    try:
+        oval, ograd = oracle_eval(pb, par, order=1, threads=8)
+    finally:
+        keep_P_symmetric(False)
+    assert abs(val - oval) <= 1e-10 * abs(oval), (val, oval, lit)
+    free = pb.par_fixed == 0
+    assert np.max(np.abs(grad - ograd)[free]) <= 1e-8 * np.max(np.abs(ograd[free])), (grad, ograd)
+    if model == "CTCRW":
+        assert abs(lit - oval) >= 1e-6 * abs(oval), (lit, oval)
