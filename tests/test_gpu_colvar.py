@@ -844,3 +844,32 @@ def test_coupling_H_on_long_tracks_every_path_against_the_stabilised_oracle(path
     assert abs(val - oval) <= 1e-10 * abs(oval), (path, val, oval, lit)
     assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (path, grad, ograd)
     assert abs(lit - oval) >= 1e-8 * abs(oval), (lit, oval)          # (the literal recursion has long left: that is why the arbiter is used)
+
+
+@pytest.mark.parametrize("no_tv", [False, True])
+def test_general_P0_on_long_ctcrw_tracks_against_the_stabilised_oracle(no_tv, monkeypatch):
+    """the other trigger of DESIGN 5c: a P0 with entries BETWEEN the response dimensions (H = sigma_obs^2 I).  As long as the cross-dimension
+    entries of P are exact zeros nothing seeds the unstable antisymmetric mode of the reference's full-matrix update; a general P0 makes
+    them non-zero and the literal recursion leaves the likelihood by percents within 600 rows (CTCRW only: T is a multiple of the identity
+    for OU_SSM / BM_SSM).  The engine's dense lanes keep P symmetric: value and gradient against the oracle in arbiter mode."""
+    from oracle_lib import keep_P_symmetric, oracle_eval
+    from smoothsde_amd.synth import simulate
+    if no_tv:
+        monkeypatch.setenv("SSDE_NO_TV", "1")
+    ID, times, obs = simulate("CTCRW", 6, 600, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13)
+    A = np.random.default_rng(3).standard_normal((4, 4))
+    pb = capi.Problem("CTCRW", ID, times, obs, P0=A @ A.T + np.eye(4))
+    par = np.array([np.log(0.07), 0.02, -0.01, np.log(2.0), 0.1])
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    assert eng.info()["kernel_id"] in ((14,) if no_tv else (14, 16)), capi.KERNEL_NAMES.get(eng.info()["kernel_id"])
+    eng.close()
+    lit, _ = oracle_eval(pb, par, order=1, threads=4)
+    keep_P_symmetric(True)
+    try:
+        oval, ograd = oracle_eval(pb, par, order=1, threads=4)
+    finally:
+        keep_P_symmetric(False)
+    assert abs(val - oval) <= 1e-10 * abs(oval), (val, oval, lit)
+    assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (grad, ograd)
+    assert abs(lit - oval) >= 1e-6 * abs(oval), (lit, oval)

@@ -104,6 +104,22 @@ def test_reference_form_loses_the_likelihood_when_H_couples_the_columns():
                 assert np.max(np.abs(sym_grad - rg)) <= 1e-8 * np.max(np.abs(rg)), (label, sym_grad, rg)
     assert drift[(100, "diagonal")] <= 1e-13 and drift[(200, "diagonal")] <= 1e-13, drift
     assert drift[(100, "coupling")] >= 1e-12 and drift[(200, "coupling")] >= 1e-5, drift      # (measured 4e-11 and 3e-3)
+    # The unstable mode is the CROSS-DIMENSION antisymmetric part of P: while those entries are exact zeros (H = sigma^2 I or diagonal,
+    # block-diagonal P0) nothing seeds it.  A P0 with entries between the dimensions seeds it as well as a coupling H does -- and only
+    # CTCRW has it: T is a multiple of the identity for OU_SSM / BM_SSM.
+    A = np.random.default_rng(3).standard_normal((4, 4))
+    for model, sd, unstable in (("CTCRW", 4, True), ("OU_SSM", 2, False)):
+        ID, times, obs = simulate(model, 2, 600, 2, tau=2.0, nu=1.0, kappa=1.0, sigma_obs=0.1, seed=13)
+        pb = capi.Problem(model, ID, times, obs, P0=(A @ A.T + np.eye(4))[:sd, :sd])
+        par = np.zeros(pb.n_par_full)
+        par[0], par[3] = np.log(0.07), np.log(2.0)
+        lit = oracle_eval(pb, par, order=0)
+        keep_P_symmetric(True)
+        try:
+            sym = oracle_eval(pb, par, order=0)
+        finally:
+            keep_P_symmetric(False)
+        assert (abs(lit - sym) >= 1e-6 * abs(sym)) if unstable else (abs(lit - sym) <= 1e-13 * abs(sym)), (model, lit, sym)
 
 
 def test_cir_weak_diffusion_against_mpmath_restatement():
