@@ -4,7 +4,8 @@ literal oracle at their timed sizes (10^4 tracks x 10^4 rows unless said), value
 timed step.  tests/test_gpu_whole_batch.py does this for the metric's batch, configs 2 and 3 and the row-varying batch inside the suite;
 these five would add ~6 minutes of oracle time to it, so they are a tool whose output is kept under profiles/.  Uses oracle/ as the
 CHECKER (tests/oracle_lib.py), like the tests.  One JSON line per workload.
-    names: irregular missing missing_one absent argos  (default: these five);  c5_bm c5_ou c5_ctcrw: the three sub-batches of BASELINE config 5"""
+    names: irregular missing missing_one absent argos  (default: these five);  c5_bm c5_ou c5_ctcrw: the three sub-batches of BASELINE config 5;
+    report_headline report_irregular report_missing: ssde_report (aest_all) of a whole batch against the oracle's filtered states"""
 import json
 import os
 import sys
@@ -94,7 +95,32 @@ def c5(i):
 WORK = {"c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
         "irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
         "absent": lambda: general(absent), "argos": argos}
-for name in (sys.argv[1:] or [k for k in WORK if not k.startswith('c5')]):
+def headline():
+    ID, times, obs = capi.simulate_device("CTCRW", M, T, 2, mu=0.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, seed=1, device=dev)
+    fixed = np.zeros(5, dtype=np.uint8); fixed[1:3] = 1
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, par_fixed=fixed))
+    host = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), par_fixed=fixed)
+    return eng, host, bench.theta_for(5, 2, 4, 0)
+
+
+REPORT = {"report_headline": headline, "report_irregular": lambda: general(irregular), "report_missing": lambda: general(missing)}
+for name in [a for a in sys.argv[1:] if a in REPORT]:
+    # REPORT(aest_all) (nllk_ctcrw.hpp:192-194, 246, 249) of a whole timed batch: ssde_report against the oracle's filtered states
+    eng, host, theta = REPORT[name]()
+    aest = eng.report(theta)
+    inf = eng.info()
+    eng.close()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    _, _, oaest = oracle_eval(host, np.asarray(theta, dtype=float), order=1, threads=THREADS, report=True)
+    secs = time.perf_counter() - t0
+    sc = float(np.nanmax(np.abs(oaest)))
+    err = float(np.nanmax(np.abs(aest - oaest)))
+    same_nan = bool(np.array_equal(np.isnan(aest), np.isnan(oaest)))
+    print(json.dumps({"workload": name, "rows": inf["n_rows"], "states": list(aest.shape), "max_abs_err": err, "scale": sc, "rel": err / sc, "same_nan_pattern": same_nan,
+                      "ok": bool(err <= 1e-9 * sc and same_nan), "oracle_seconds": round(secs, 1)}), flush=True)
+    del host, aest, oaest
+for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not k.startswith('c5')])):
     eng, host, theta = WORK[name]()
     val, grad = eng.eval(theta)
     inf = eng.info()
