@@ -92,7 +92,21 @@ def c5(i):
     return h.eng, host, h.thetas[0]
 
 
-WORK = {"c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
+def c3_table():
+    """BASELINE config 3 with the design block evaluated by the lanes from its B-spline table (ssde_ppbasis); the oracle gets the
+    n x 9 matrix the table stands for (PPBasis.dense: ~4 temporaries of n x 9 doubles on the host -- run it with WB_ROWS=1000)"""
+    from smoothsde_amd.synth import bspline_ppbasis, second_difference_penalty, simulate
+    ID, times, obs = simulate("OU", M, T, 1, mu=1.0, tau=2.0, kappa=1.0, seed=2, backend="torch", device=dev)
+    x = torch.cumsum(torch.randn(len(ID), device=dev, dtype=torch.float64) * 0.01, 0)
+    x = (x - x.min()) / (x.max() - x.min())
+    basis = bspline_ppbasis(x, 9, centre=np.zeros(9))
+    S = [second_difference_penalty(9)]
+    eng = capi.Engine(capi.Problem.from_torch("OU", ID, times, obs, basis_re=[basis, None, None], S_list=S))
+    host = capi.Problem("OU", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), X_re=[basis.dense(), None, None], S_list=S)
+    return eng, host, np.concatenate([[1.0, np.log(2.0), 0.0], [0.0], 0.05 * np.sin(np.arange(9))])
+
+
+WORK = {"c3_table": c3_table, "c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
         "irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
         "absent": lambda: general(absent), "argos": argos}
 def headline():
@@ -120,7 +134,7 @@ for name in [a for a in sys.argv[1:] if a in REPORT]:
     print(json.dumps({"workload": name, "rows": inf["n_rows"], "states": list(aest.shape), "max_abs_err": err, "scale": sc, "rel": err / sc, "same_nan_pattern": same_nan,
                       "ok": bool(err <= 1e-9 * sc and same_nan), "oracle_seconds": round(secs, 1)}), flush=True)
     del host, aest, oaest
-for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not k.startswith('c5')])):
+for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not k.startswith('c')])):
     eng, host, theta = WORK[name]()
     val, grad = eng.eval(theta)
     inf = eng.info()
