@@ -106,7 +106,47 @@ def c3_table():
     return eng, host, np.concatenate([[1.0, np.log(2.0), 0.0], [0.0], 0.05 * np.sin(np.arange(9))])
 
 
-WORK = {"c3_table": c3_table, "c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
+def drift(model, d, K, na_frac=0.0, table=False):
+    """tools/bench_drift.py's batches: mu a K-column smooth of a covariate, everything else constant -- iso_drift_kernel (regular grid,
+    complete tracks), iso_drift_general_kernel (missing rows), the block as a table (k_iso_drift_pp.hip)"""
+    from smoothsde_amd.synth import bspline_ppbasis, second_difference_penalty
+    ID, times, obs = capi.simulate_device(model, M, T, d, mu=2.0, tau=2.0, nu=1.0, kappa=1.0, sigma=1.0, sigma_obs=0.1, z0=2.0, seed=2, device=dev)
+    n = M * T
+    obs = obs.contiguous()
+    if na_frac > 0:
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        na = torch.rand(n, device=dev, generator=gen) < na_frac
+        na[::T] = False
+        obs[na] = float("nan")
+    x = 0.5 + 0.45 * torch.sin(torch.arange(n, device=dev, dtype=torch.float64) * (2 * np.pi / 977.0))
+    q = capi.n_sde_par(model, d)
+    S = [second_difference_penalty(K)]
+    if table:
+        basis = [None] * q
+        basis[0] = bspline_ppbasis(x, K, centre=np.zeros(K))
+        pb = capi.Problem.from_torch(model, ID, times, obs, basis_re=basis, S_list=S)
+        Xh = basis[0].dense()
+    else:
+        X = torch.stack([torch.cos(np.pi * k * x) for k in range(1, K + 1)], dim=1)
+        X_re = [None] * q
+        X_re[0] = X
+        pb = capi.Problem.from_torch(model, ID, times, obs, X_re=X_re, S_list=S)
+        Xh = X.cpu().numpy()
+    Xr = [None] * q
+    Xr[0] = Xh
+    host = capi.Problem(model, ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), X_re=Xr, S_list=S)
+    par0 = np.zeros(pb.n_par_full)
+    par0[0] = np.log(0.1)
+    par0[pb.off_fe] = 2.0
+    par0[pb.off_fe + d] = np.log(2.0)
+    par0[pb.off_re:] = 0.05 * np.random.default_rng(1).standard_normal(pb.n_re)
+    return capi.Engine(pb), host, par0
+
+
+WORK = {"drift_ou": lambda: drift("OU_SSM", 1, 9), "drift_ou_na": lambda: drift("OU_SSM", 1, 9, na_frac=0.02),
+        "drift_ou_table": lambda: drift("OU_SSM", 1, 9, table=True), "drift_ctcrw": lambda: drift("CTCRW", 2, 9),
+        "drift_bm_na": lambda: drift("BM_SSM", 2, 6, na_frac=0.02),
+        "c3_table": c3_table, "c5_bm": lambda: c5(0), "c5_ou": lambda: c5(1), "c5_ctcrw": lambda: c5(2),
         "irregular": lambda: general(irregular), "missing": lambda: general(missing), "missing_one": lambda: general(missing_one),
         "absent": lambda: general(absent), "argos": argos}
 def headline():
@@ -134,7 +174,7 @@ for name in [a for a in sys.argv[1:] if a in REPORT]:
     print(json.dumps({"workload": name, "rows": inf["n_rows"], "states": list(aest.shape), "max_abs_err": err, "scale": sc, "rel": err / sc, "same_nan_pattern": same_nan,
                       "ok": bool(err <= 1e-9 * sc and same_nan), "oracle_seconds": round(secs, 1)}), flush=True)
     del host, aest, oaest
-for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not k.startswith('c')])):
+for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not (k.startswith('c') or k.startswith('drift'))])):
     eng, host, theta = WORK[name]()
     val, grad = eng.eval(theta)
     inf = eng.info()
