@@ -221,3 +221,52 @@ def test_fuzz_against_the_oracle(seed):
     _close(val, grad, *_oracle(pb2, par))
     assert np.all(grad[fixed.astype(bool)] == 0.0)
     eng.close()
+
+
+_HLO, _HHI = (int(v) for v in __import__("os").environ.get("SSDE_FUZZ_ADJ_H_SEEDS", "0:8").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_HLO, _HHI))
+def test_fuzz_with_error_ellipses_against_the_oracle_in_arbiter_mode(seed, monkeypatch):
+    """row-varying tau / nu with a per-row measurement covariance (one response column: a variance; two: an ellipse, with or without
+    entries between the columns), both gradient forms.  The oracle runs in ARBITER mode (P kept symmetric): where H couples the columns
+    of a CTCRW the literal recursion drifts away within a few hundred rows; everywhere else the two modes are the same number."""
+    from oracle_lib import keep_P_symmetric, oracle_eval
+    rng = np.random.default_rng(9000 + seed)
+    model = ["CTCRW", "OU_SSM", "BM_SSM"][rng.integers(3)]
+    d = int(rng.integers(1, 3))
+    k1 = int(rng.choice([3, 4, 6, 9]))
+    k2 = int(rng.choice([0, 3, 5])) if model != "BM_SSM" else 0
+    pb, par = _batch(model, d, int(rng.integers(33, 100)), int(rng.integers(100, 700)), k1, k2, seed=9500 + seed, ragged=bool(rng.integers(2)),
+                     same_basis=bool(rng.integers(2)))
+    n = len(pb.times)
+    A = 0.1 * rng.standard_normal((n, d, d))
+    Hn = np.einsum("nij,nkj->nik", A, A) + 0.01 * np.eye(d)
+    if d == 2 and rng.integers(2):
+        Hn = Hn * np.eye(2)                                        # independent axis errors
+    H = np.ascontiguousarray(np.transpose(Hn, (1, 2, 0)))
+    o = pb.obs.copy()
+    if rng.integers(2):
+        na = rng.random(n) < 0.03
+        na[pb.seg_start] = False
+        o[na, 0] = np.nan
+    fixed = np.zeros(pb.n_par_full, dtype=np.uint8)
+    fixed[0] = 1
+    fixed[pb.off_fe:pb.off_fe + d] = np.uint8(rng.integers(2))
+    pb2 = capi.Problem(model, pb.id, pb.times, o, X_fe=pb.X_fe, X_re=pb.X_re, S_list=pb.S_list, par_fixed=fixed, H=H)
+    par = par + 0.05 * rng.standard_normal(len(par))
+    keep_P_symmetric(True)
+    try:
+        oval, ograd = oracle_eval(pb2, par, order=1, threads=8)
+    finally:
+        keep_P_symmetric(False)
+    for mode in ("2", "0"):
+        monkeypatch.setenv("SSDE_CV_ADJ", mode)
+        eng = capi.Engine(pb2)
+        val, grad = eng.eval(par)
+        inf = eng.info()
+        ctx = (model, d, k1, k2, n, capi.KERNEL_NAMES.get(inf["kernel_id"]), inf["lanes_per_track"])
+        assert inf["window_check"] <= 1e-11, ctx
+        assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (ctx, val, oval)
+        assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (ctx, grad, ograd)
+        eng.close()
