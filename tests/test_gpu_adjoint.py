@@ -270,3 +270,28 @@ def test_fuzz_with_error_ellipses_against_the_oracle_in_arbiter_mode(seed, monke
         assert abs(val - oval) <= 1e-10 * max(1.0, abs(oval)), (ctx, val, oval)
         assert np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)) + 1e-10, (ctx, grad, ograd)
         eng.close()
+
+
+def test_queued_asynchronous_evaluations_of_the_reverse_sweep():
+    """ssde_eval_device (what a sharded host uses): eight evaluations at different parameter vectors queued on one stream without a
+    synchronisation between them, each into its own HBM buffer -- every one must be the number the synchronous call returns (the
+    checkpoints, range words and partial sums of the launches are reused from one evaluation to the next; the parameter slots are a ring)"""
+    import torch
+    pb, par = _batch("CTCRW", 2, 128, 800, 6, 5, seed=21)
+    eng = capi.Engine(pb)
+    eng.eval(par)                                                  # (plans the windows from the measured ranges once)
+    pars = [par + 0.02 * np.sin(k + np.arange(len(par))) for k in range(8)]
+    outs = torch.zeros(8, 2 + pb.n_par_full, dtype=torch.float64, device="cuda:0")
+    st = torch.cuda.Stream()
+    for k in range(8):
+        eng.eval_device(pars[k], outs[k].data_ptr(), order=1, stream=st.cuda_stream)
+    st.synchronize()
+    host = outs.cpu().numpy()
+    assert eng.info()["kernel_id"] == K_ADJ
+    for k in range(8):
+        assert host[k, -1] <= capi.WINDOW_TOL
+        v, g = eng.eval(pars[k])
+        pen, pg = eng.penalty(pars[k])
+        assert abs(host[k, 0] + pen - v) <= 1e-12 * max(1.0, abs(v)), (k, host[k, 0] + pen, v)
+        assert np.max(np.abs(host[k, 1:-1] + pg - g)) <= 1e-11 * np.max(np.abs(g)), k
+    eng.close()
