@@ -157,6 +157,16 @@ def headline():
     return eng, host, bench.theta_for(5, 2, 4, 0)
 
 
+def row_varying():
+    ID, times, obs, B, S, fixed = bench.row_varying_batch(M, T, dev, 9)
+    eng = capi.Engine(capi.Problem.from_torch("CTCRW", ID, times, obs, X_re=[None, None, B, B], S_list=[S, S], par_fixed=fixed))
+    Bh = B.cpu().numpy()
+    host = capi.Problem("CTCRW", ID.cpu().numpy(), times.cpu().numpy(), obs.cpu().numpy(), X_re=[None, None, Bh, Bh], S_list=[S, S], par_fixed=fixed)
+    return eng, host, bench.row_varying_theta(0, 9)
+
+
+WORK["headline"] = headline
+WORK["row_varying"] = row_varying
 REPORT = {"report_headline": headline, "report_irregular": lambda: general(irregular), "report_missing": lambda: general(missing)}
 for name in [a for a in sys.argv[1:] if a in REPORT]:
     # REPORT(aest_all) (nllk_ctcrw.hpp:192-194, 246, 249) of a whole timed batch: ssde_report against the oracle's filtered states
@@ -174,7 +184,7 @@ for name in [a for a in sys.argv[1:] if a in REPORT]:
     print(json.dumps({"workload": name, "rows": inf["n_rows"], "states": list(aest.shape), "max_abs_err": err, "scale": sc, "rel": err / sc, "same_nan_pattern": same_nan,
                       "ok": bool(err <= 1e-9 * sc and same_nan), "oracle_seconds": round(secs, 1)}), flush=True)
     del host, aest, oaest
-for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in WORK if not (k.startswith('c') or k.startswith('drift'))])):
+for name in ([a for a in sys.argv[1:] if a not in REPORT] or ([] if sys.argv[1:] else [k for k in ('irregular', 'missing', 'missing_one', 'absent', 'argos')])):
     eng, host, theta = WORK[name]()
     val, grad = eng.eval(theta)
     inf = eng.info()
