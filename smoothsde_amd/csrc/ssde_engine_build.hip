@@ -322,7 +322,9 @@ static int plan_register_path(ssde_handle* h, int G, const std::vector<int32_t>&
     for (int g = 0; g < G; g++) glmax = std::max(glmax, glen[g]);
     h->glen_max = glmax;
     // one wave per SIMD (1024 work items INCLUDING the padding of the group count to a multiple of 8):
-    // a lone wave already issues fp64 at the SIMD's rate, and fewer windows mean fewer warm-up rows
+    // the shared-covariance lanes are bound by memory -- a lone wave per SIMD reaches the read ceiling (profiles/r04_a_issue_microbench.txt;
+    // pure fp64 issue is another matter: 6.5 cycles per instruction for a lone wave against 4.7 with four, profiles/r05_fp64_issue_microbench.txt) --
+    // and fewer windows mean fewer warm-up rows
     int want = std::max(1, 1024 / (((G + 7) / 8 * 8) * h->iso_parts));
     // ... except for the scalar-covariance models on the general kernel (irregular grid or missing rows in
     // most groups): too few independent chains per row for one wave, so two waves per SIMD (k_iso.hip)
