@@ -305,3 +305,41 @@ def test_eseal_fixed_ssm_parameters_and_errors():
     pb_bad = capi.Problem("ESEAL_SSM", pb.id, pb.times, pb.obs, a0=bad, eseal_h=pb.eseal_h, eseal_R=pb.eseal_R)
     with pytest.raises(capi.EngineError):
         capi.Engine(pb_bad)
+
+
+def test_one_animal_with_error_ellipses_on_a_long_track_against_the_stabilised_oracle():
+    """BASELINE config 1's model with an error ellipse on every fix, ONE track of 6000 rows: the lane = direction dense lanes
+    (ssde_dense.hpp, P kept symmetric) against the oracle in arbiter mode -- the literal recursion is percents away at this length
+     -- and the exact second derivatives of the same lanes against differences of the gradient."""
+    from oracle_lib import keep_P_symmetric, oracle_eval
+    from smoothsde_amd.synth import bspline_basis, second_difference_penalty, simulate
+    ID, times, obs = simulate("CTCRW", 1, 6000, 2, tau=2.0, nu=1.0, sigma_obs=0.1, seed=13)
+    n = len(ID)
+    A = 0.05 * np.random.default_rng(17).standard_normal((n, 2, 2))
+    H = np.ascontiguousarray(np.transpose(np.einsum("nij,nkj->nik", A, A) + 0.0025 * np.eye(2) + np.array([[0, .001], [.001, 0]]), (1, 2, 0)))
+    B = bspline_basis(0.5 + 0.4 * np.sin(np.arange(n) * 2 * np.pi / 24), 4)
+    S = second_difference_penalty(4)
+    pb = capi.Problem("CTCRW", ID, times, obs, H=H, X_re=[None, None, B, B], S_list=[S, S], par_fixed=np.r_[1, 1, 1, 0, 0, 1, 1, np.zeros(8)].astype(np.uint8))
+    par = np.r_[0.0, 0.0, 0.0, np.log(2.0), 0.1, 0.0, 0.0, 0.05 * np.sin(np.arange(8))]
+    eng = capi.Engine(pb)
+    val, grad = eng.eval(par)
+    inf = eng.info()
+    assert inf["kernel_id"] == 16 and inf["lanes_per_track"] > 64 and inf["window_check"] <= capi.WINDOW_TOL, inf
+    idx = [3, 4, 7, 10, 11, 14]
+    Hs = eng.hess(par, idx)
+    Hfd = np.zeros_like(Hs)
+    for j, k in enumerate(idx):
+        pp, pm = par.copy(), par.copy()
+        pp[k] += 1e-5
+        pm[k] -= 1e-5
+        Hfd[:, j] = (eng.eval(pp)[1][idx] - eng.eval(pm)[1][idx]) / 2e-5
+    eng.close()
+    lit = oracle_eval(pb, par, order=0)
+    keep_P_symmetric(True)
+    try:
+        oval, ograd = oracle_eval(pb, par, order=1)
+    finally:
+        keep_P_symmetric(False)
+    assert abs(val - oval) <= 1e-10 * abs(oval) and np.max(np.abs(grad - ograd)) <= 1e-8 * np.max(np.abs(ograd)), (val, oval)
+    assert abs(lit - oval) >= 1e-4 * abs(oval), (lit, oval)
+    assert np.max(np.abs(Hs - Hfd)) <= 1e-6 * np.max(np.abs(Hfd))
