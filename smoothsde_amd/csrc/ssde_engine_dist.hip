@@ -90,14 +90,17 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     if (d->n_dim < 1 || d->n_dim > 64) return fail(parent, SSDE_ERR_MODEL, "n_dim must be between 1 and 64");
     if (d->n_par != n_sde_par(d->model, d->n_dim)) return fail(parent, SSDE_ERR_ARG, "n_par does not match model / n_dim");
     const int D = d->n_dim, q = d->n_par, n_shared = q - D, sdim = state_dim(d->model, D);
-    const int P = D > 2 ? (D + 1) / 2 : 1;                  // dimension parts
+    int P = D > 2 ? (D + 1) / 2 : 1;                        // dimension parts (1 again below when the columns couple and every shard runs them as one filter)
     const int per_dim = d->model == SSDE_MODEL_CTCRW ? 2 : 1;   // state components per dimension
     // A measurement covariance or a P0 that couples response columns of different pairs makes F a full matrix: the reference
     // evaluates it through atomic::logdet and F.inverse() (nllk_ctcrw.hpp:12-24, 203-205, 231-241).  For three to eight columns
     // (host arrays, one device) the whole response then runs as ONE filter on the lane = track general kernel (k_dense.hip:
     // F by LU with partial pivoting, ssde_dense.hpp) instead of pair by pair.
-    const bool can_run_whole = is_kalman(d->model) && D <= DENSE_MAXD && !multi && !on_dev;
+    // (several devices: whole-track shards as ever, every shard one filter over all columns -- round 5)
+    const bool can_run_whole = is_kalman(d->model) && D <= DENSE_MAXD && !on_dev;
+    bool whole_shards = false;
     auto run_whole = [&]() -> int {
+        if (multi) { whole_shards = true; return SSDE_OK; }
         parent->wide_ok = true;
         return build(d, parent);
     };
@@ -113,10 +116,10 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                 for (int i = 0; i < D; i++)
                     for (int j = 0; j < D; j++)
                         if (i / 2 != j / 2 && Hr[i + (size_t)j * D] != 0.0) {     // (a NaN entry counts as coupling)
-                            if (can_run_whole) return run_whole();
+                            if (can_run_whole) { int st = run_whole(); if (!whole_shards) return st; goto coupled_done; }
                             return fail(parent, SSDE_ERR_MODEL, "n_dim > 2 with H_array: H_array[,, i] must not couple response columns of "
                                                                 "different pairs (2k, 2k+1), which this engine evaluates side by side "
-                                                                "(three to eight columns from host arrays on one device run as one filter)");
+                                                                "(three to eight columns from host arrays run as one filter)");
                         }
             }
         }
@@ -124,11 +127,13 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
             for (int i = 0; i < sdim; i++)
                 for (int j = 0; j < sdim; j++)
                     if (i / (2 * per_dim) != j / (2 * per_dim) && d->p0[i + (size_t)j * sdim] != 0.0) {
-                        if (can_run_whole) return run_whole();
+                        if (can_run_whole) { int st = run_whole(); if (!whole_shards) return st; goto coupled_done; }
                         return fail(parent, SSDE_ERR_MODEL, "n_dim > 2: P0 must not couple response columns of different pairs (2k, 2k+1) "
-                                                            "(three to eight columns from host arrays on one device run as one filter)");
+                                                            "(three to eight columns from host arrays run as one filter)");
                     }
     }
+coupled_done:
+    if (whole_shards) P = 1;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(parent, SSDE_ERR_NODEVICE, "no HIP device visible: this engine has no CPU fallback");
@@ -256,6 +261,7 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
             int st;
             if (P == 1) {
                 parent->shard_col0.push_back(0);
+                sh->wide_ok = whole_shards;
                 st = build(&sd, sh);
                 if (st == SSDE_OK) attach_hess_companion(&sd, sh);      // (SSDE_FLAG_EXACT_HESS: every track shard keeps its own second copy)
             } else {

@@ -310,3 +310,31 @@ def test_wide_coupled_response_on_long_tracks_against_the_stabilised_oracle(mode
     assert np.max(np.abs(grad - ograd)[free]) <= 1e-8 * np.max(np.abs(ograd[free])), (grad, ograd)
     if model == "CTCRW":
         assert abs(lit - oval) >= 1e-6 * abs(oval), (lit, oval)
+
+
+@pytest.mark.parametrize("model,d,what", [("CTCRW", 3, "H"), ("OU_SSM", 5, "both"), ("BM_SSM", 4, "P0")])
+def test_coupled_wide_response_over_track_shards(model, d, what):
+    """several devices (rehearsed as two / three shards on the one GPU): whole-track shards as ever, every shard runs all columns as ONE
+    filter -- the sum is the single engine's value, gradient and filtered states"""
+    spec = make_spec("wide_shards", model, d, seed=41 + d, lengths=[40, 7, 23, 2, 61, 1, 30, 12], variant="const", na_rows=(5, 17, 50, 90),
+                     with_H=what in ("H", "both"))
+    sd = capi.state_dim(model, d)
+    if what in ("P0", "both"):
+        A = np.random.default_rng(7 + d).standard_normal((sd, sd))
+        spec["P0"] = A @ A.T / sd + np.eye(sd)
+    pb = problem_from_spec(spec)
+    one = capi.Engine(pb)
+    v1, g1 = one.eval(spec["par"])
+    a1 = one.report(spec["par"])
+    one.close()
+    for devs in ([0, 0], [0, 0, 0]):
+        eng = capi.Engine(pb, devices=devs)
+        inf = eng.info()
+        assert inf["n_devices"] == len(devs) and inf["kernel_id"] in (0, 14), inf
+        v, g = eng.eval(spec["par"])
+        assert eng.info()["kernel_id"] == 14
+        assert abs(v - v1) <= 1e-12 * max(1.0, abs(v1)) and np.max(np.abs(g - g1)) <= 1e-11 * np.max(np.abs(g1)), (devs, v, v1)
+        assert np.allclose(eng.report(spec["par"]), a1, rtol=1e-12, atol=1e-12, equal_nan=True)
+        eng.close()
+    oval, ograd = oracle_eval(pb, spec["par"], order=1)
+    _close(v1, g1, oval, ograd)
