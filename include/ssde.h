@@ -166,9 +166,9 @@ typedef struct ssde_desc {
                                  columns (0,1), (2,3), ... behind the one handle (the likelihood is a sum over dimensions:
                                  nllk_ctcrw.hpp:49-89 are block-diagonal in the dimension, nllk_sde.hpp:77-84 loops over it),
                                  which needs a P0 and an H_array without entries between different pairs.  BOUND: a measurement
-                                 covariance or P0 that couples the pairs is accepted for d <= 8 (host arrays; the whole response as one
-                                 filter, F by LU -- k_dense.hip, k_dense_wide.hip -- on one device or on every whole-track shard of
-                                 several); d >= 9 with coupling, or device-resident arrays, is SSDE_ERR_MODEL */
+                                 covariance or P0 that couples the pairs is accepted for d <= 8 (the whole response as one filter, F by
+                                 LU -- k_dense.hip, k_dense_wide.hip -- on one device, host or device-resident arrays, or on every
+                                 whole-track shard of several); d >= 9 with coupling is SSDE_ERR_MODEL */
     int32_t  n_par;           /* q = SDE parameters per row: d+1 (BM, BM_t, BM_SSM), d+2 (OU, OU_SSM, CTCRW) */
     int64_t  n;               /* rows of the long-format data (all tracks concatenated) */
     const double *id;         /* [n] track codes (TMB passes the factor as doubles); only

@@ -97,7 +97,8 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
     // (host arrays, one device) the whole response then runs as ONE filter on the lane = track general kernel (k_dense.hip:
     // F by LU with partial pivoting, ssde_dense.hpp) instead of pair by pair.
     // (several devices: whole-track shards as ever, every shard one filter over all columns -- round 5)
-    const bool can_run_whole = is_kalman(d->model) && D <= DENSE_MAXD && !on_dev;
+    // (device-resident arrays: one device by construction -- checked above -- and the same route; H is scanned by a kernel)
+    const bool can_run_whole = is_kalman(d->model) && D <= DENSE_MAXD;
     bool whole_shards = false;
     auto run_whole = [&]() -> int {
         if (multi) { whole_shards = true; return SSDE_OK; }
@@ -122,6 +123,21 @@ int create_sharded(const ssde_desc* d, ssde_handle* parent) {
                                                                 "(three to eight columns from host arrays run as one filter)");
                         }
             }
+        }
+        if (is_kalman(d->model) && d->h_array && on_dev && can_run_whole) {
+            // device-resident H_array: the same test by a kernel (k_ingest.hip), before anything is cut into column pairs
+            int dev_was = 0;
+            (void)hipGetDevice(&dev_was);
+            if (d->device >= 0) HIPCHK(parent, hipSetDevice(d->device));
+            DevBuf<int> couples;
+            HIPCHK(parent, couples.alloc(1));
+            HIPCHK(parent, hipMemset(couples.p, 0, sizeof(int)));
+            HIPCHK(parent, launch_h_couples(d->h_array, d->n, D, couples.p, 0));
+            int flag = 0;
+            HIPCHK(parent, hipMemcpy(&flag, couples.p, sizeof(int), hipMemcpyDeviceToHost));
+            couples.release();
+            (void)hipSetDevice(dev_was);
+            if (flag) return run_whole();
         }
         if (is_kalman(d->model) && d->p0)
             for (int i = 0; i < sdim; i++)
