@@ -122,6 +122,30 @@ def test_reference_form_loses_the_likelihood_when_H_couples_the_columns():
         assert (abs(lit - sym) >= 1e-6 * abs(sym)) if unstable else (abs(lit - sym) <= 1e-13 * abs(sym)), (model, lit, sym)
 
 
+def test_unstable_fixtures_for_a_machine_with_tmb_are_what_the_generator_writes():
+    """tests/golden/unstable_cases.json (the hand-off of DESIGN 5c to a machine with R + TMB: tools/tmb_oracle.R reads it like
+    cases.json) holds what tests/golden/gen_unstable.py computes: literal double, binary128 and arbiter values of four small cases"""
+    import json
+    import os
+    from golden_io import dec
+    from oracle_lib import keep_P_symmetric
+    from smoothsde_amd import capi
+    recs = [dec(r) for r in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "unstable_cases.json")))]
+    assert [r["name"] for r in recs] == ["unstable_H_coupling", "stable_H_diagonal", "unstable_P0_coupling", "stable_P0_default"]
+    for r in recs:
+        pb = capi.Problem("CTCRW", r["ID"], r["times"], r["obs"], par_fixed=r["par_fixed"], H=r["H"], P0=r["P0"])
+        e = r["expected"]
+        lit = oracle_eval(pb, r["par"], order=0)
+        keep_P_symmetric(True)
+        try:
+            arb = oracle_eval(pb, r["par"], order=0)
+        finally:
+            keep_P_symmetric(False)
+        assert abs(arb - e["arbiter_value"]) <= 1e-12 * abs(arb) and abs(arb - e["binary128_value"]) <= 1e-11 * abs(arb), r["name"]
+        gap = abs(lit - e["binary128_value"]) / abs(e["binary128_value"])
+        assert (gap >= 1e-5) if r["name"].startswith("unstable") else (gap <= 1e-13), (r["name"], gap)
+
+
 def test_cir_weak_diffusion_against_mpmath_restatement():
     """CIR with sigma = 0.05: Bessel arguments of 10^3-10^4 and orders ~10^3, where the reference's unscaled
     besselI has long overflowed.  The oracle's series (summed outwards from its largest term) against the

@@ -6,6 +6,8 @@
 # Written blind: this image has no R / TMB / smoothSDE.  On a machine that has them
 # (install.packages(c("TMB","Matrix","jsonlite")); devtools::install_github("TheoMichelot/smoothSDE")):
 #     Rscript tools/tmb_oracle.R tests/golden/cases.json tmb_dump.json
+# (the same with tests/golden/unstable_cases.json: four fixtures where the covariance recursion of nllk_ctcrw.hpp:241 amplifies rounding --
+#  DESIGN.md 5c; compare with: python tools/compare_tmb_dump.py dump.json tests/golden/unstable_cases.json)
 # then compare tmb_dump.json with the "expected" blocks of cases.json (value rel <= 1e-8, gradient
 # |d| <= 1e-8 * max|g| + 1e-10): python tools/compare_tmb_dump.py tmb_dump.json
 #
