@@ -316,6 +316,7 @@ struct ssde_handle {
     int memo_order = -1;                      // -1 = nothing memoised
     int64_t n_evals = 0, n_memo_hits = 0;
     double check_max = 0.0;                   // largest accepted hand-over disagreement since create
+    double check_floor = 0.0;                 // > 0: a disagreement that a 4x longer warm-up did NOT reduce -- rounding in the states, not a short warm-up; accepted up to here
     // host-side phase clock of the isotropic path (SSDE_TRACE=1 at create; printed at destroy): plan, gain table,
     // main launch(es), finalize launch, read-back
     bool trace = false;
