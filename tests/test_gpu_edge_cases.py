@@ -151,7 +151,7 @@ def test_extreme_and_nan_parameters_follow_the_oracle(model):
 def test_very_precise_fixes_keep_their_time_windows(what):
     """sigma_obs = 3e-4 against a movement of ~0.5 per step (P11 ~ 1e-7 next to P22 ~ 1): the hand-over states of two windows disagree
     at ~1e-10 whatever the warm-up -- rounding in the states, not a short warm-up.  The policy used to quadruple the warm-up three times
-    and end in ONE sequential window per track; now a small disagreement that a 4x longer warm-up did not reduce is recognised as the
+    and end in ONE sequential window per track; now a small disagreement that stays flat while the warm-up is quadrupled twice is recognised as the
     rounding floor (ssde_engine.hip: run_checked), accepted from then on, and the windows stay.  Same digits as the oracle either way."""
     from oracle_lib import oracle_eval
     from smoothsde_amd.synth import simulate
@@ -169,7 +169,7 @@ def test_very_precise_fixes_keep_their_time_windows(what):
     th = np.array([np.log(so), 0.0, 0.0, np.log(2.0), 0.0])
     v, g = eng.eval(th)
     inf = eng.info()
-    assert inf["lanes_per_track"] > 1 and inf["window_retries"] <= 1, inf                    # (one quadrupled warm-up at most, no sequential fallback)
+    assert inf["lanes_per_track"] > 1 and inf["window_retries"] <= 2, inf                    # (two quadrupled warm-ups at most, no sequential fallback)
     assert capi.WINDOW_TOL < inf["window_check"] <= 1e-8, inf["window_check"]              # (the floor, reported as it is)
     th2 = th + 0.01 * np.sin(np.arange(5))
     v2, g2 = eng.eval(th2)
