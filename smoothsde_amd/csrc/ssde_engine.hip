@@ -540,6 +540,9 @@ int run_checked(ssde_handle* h, const double* par, int order, std::vector<double
         }
     }
     if (std::isfinite(o[0]) && !(h->last_check <= h->check_max)) h->check_max = h->last_check;
+    // (the floor belongs to the regime that showed it: an evaluation whose windows agree outright ends it, so that a later, genuinely
+    //  short warm-up is not waved through under an old allowance)
+    if (h->last_check <= SSDE_WINDOW_TOL) h->check_floor = 0.0;
     // A widened plan is not for life: one slow-forgetting parameter vector in a line search would otherwise tax every
     // later evaluation.  Every evaluation is checked, so narrowing on probation is safe -- a failure costs one retry.
     const bool forced = h->shards.empty() ? h->chunks_forced : h->shards[0]->chunks_forced;
