@@ -258,7 +258,9 @@ typedef struct ssde_info_t {
                                direction lanes x time windows (row-varying path) */
     int32_t window;         /* warm-up rows of a time window in the last evaluation (0 = sequential) */
     int32_t window_retries; /* evaluations repeated because the window hand-over check failed */
-    double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval */
+    double  window_check;   /* largest relative hand-over disagreement of the last ssde_eval (<= 1e-11 when the windows agree; a value up
+                               to 1e-8 is accepted only as a ROUNDING FLOOR: one that stayed flat while the warm-up was quadrupled twice --
+                               very precise fixes -- and is reported here as it is) */
     double  main_kernel_ms; /* HIP-event duration of the dominant kernel launch of the last evaluation */
     int64_t main_kernel_rows;/* rows scored by that launch (the rest belong to the small concurrent launches) */
     double  required_bytes_per_row; /* bytes per row the engine's resident layout really has to read: algo_bytes_per_row
